@@ -1,0 +1,480 @@
+/*
+ * matpbr_oracle.c -- CPU restatement of the reference's PBR shading path.          TEST INFRASTRUCTURE
+ *
+ * This file is the ORACLE: a plain-C restatement of the arithmetic of lez-s/Materialist's hot path
+ * (citations are file:line into the reference tree).  It exists to check the HIP kernels.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product path
+ * (materialist_amd/) never does and fails loudly when its HIP library is missing.
+ *
+ * Parity pin: every function below that restates a reference function is checked against golden
+ * vectors produced by importing the reference's own Python arithmetic under stub modules
+ * (tests/golden/gen_golden.py writes the .npz fixtures; tests/test_oracle_golden.py).  The image-level
+ * render (oracle_shade_fwd/bwd) has no reference counterpart that can run here or anywhere
+ * deterministic (Mitsuba's stochastic path tracer): "parity unpinned" at the
+ * mi.render boundary; it is the build's own deterministic definition composed
+ * only of pinned functions, and its backward pass is pinned by finite differences.
+ *
+ * Precision: compiled twice from this one source, -DORACLE_REAL=double (the checker) and
+ * -DORACLE_REAL=float with OpenMP (the timed "cpu_baseline" port).
+ */
+#include <tgmath.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#ifndef ORACLE_REAL
+#define ORACLE_REAL double
+#endif
+typedef ORACLE_REAL real;
+
+#define R(x) ((real)(x))
+#define O_PI R(3.14159265358979323846264338327950288)
+
+#define MATPBR_NSH 25
+#define MATPBR_MAX_SPP 256
+
+static inline real rmax(real a, real b) { return a > b ? a : b; }
+static inline real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline real pow5(real x) { real x2 = x * x; return x2 * x2 * x; }
+
+/* ------------------------------------------------------------------------------------------------
+ * a2: G1_GGX_Schlick / G_Smith            myutils/mi_plugin.py:60-76
+ * ---------------------------------------------------------------------------------------------- */
+real oracle_G1_GGX_Schlick(real NoV, real eta) {
+    real k = eta + R(1);
+    k = k * k / R(8);
+    real denom = NoV * (R(1) - k) + k + R(1e-6);
+    return R(1) / denom;
+}
+real oracle_G_Smith(real NoV, real NoL, real eta) {
+    return oracle_G1_GGX_Schlick(NoL, eta) * oracle_G1_GGX_Schlick(NoV, eta);
+}
+/* a3: fresnelSchlick                       myutils/mi_plugin.py:78-81 */
+real oracle_fresnelSchlick(real VoH, real F0) {
+    real x = pow5(R(1) - VoH);
+    return F0 + (R(1) - F0) * x;
+}
+/* a1: D_GGX                                myutils/mi_plugin.py:89-97 */
+real oracle_D_GGX(real cos_h, real eta) {
+    real alpha = eta * eta;
+    real alpha2 = alpha * alpha;
+    real denom = (cos_h * cos_h * (alpha2 - R(1)) + R(1)) + R(1e-6);
+    denom = O_PI * denom * denom;
+    return alpha2 / denom;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a4: MatDiffBSDF.eval_brdf (disney_brdf=True branch)     myutils/mi_plugin.py:1372-1427
+ *     wi = light direction, wo = view direction (F9), value already includes the cosine NoL.
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_eval_brdf(const real wi[3], const real wo[3], const real n[3], const real a[3], real r, real m,
+                      real f[3], real* pdf) {
+    real h[3] = {wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2]};
+    real hl = sqrt(dot3(h, h));
+    h[0] /= hl; h[1] /= hl; h[2] /= hl;                                   /* :1392 */
+    real NoL = rmax(dot3(n, wi), R(0));                                   /* :1393 */
+    real NoV = rmax(dot3(n, wo), R(0));
+    real VoH = rmax(dot3(wo, h), R(0));
+    real NoH = rmax(dot3(n, h), R(0));
+    real D = oracle_D_GGX(NoH, r);                                        /* :1398 */
+    real pdf_spec = D / (R(4) * rmax(VoH, R(1e-6))) * NoH;                /* :1399 */
+    real pdf_diff = NoL / O_PI;                                           /* :1400 */
+    *pdf = R(0.5) * pdf_spec + R(0.5) * pdf_diff;                         /* :1401 */
+    real F_D90 = R(0.5) + R(2) * VoH * VoH * r;                           /* :1406 */
+    real F_D_w_out = R(1) + (F_D90 - R(1)) * pow5(R(1) - NoV);            /* :1407 */
+    real F_D_w_in = R(1) + (F_D90 - R(1)) * pow5(R(1) - NoL);             /* :1408 */
+    real G = oracle_G_Smith(NoV, NoL, r);                                 /* :1411 */
+    real x5 = pow5(R(1) - VoH);
+    for (int c = 0; c < 3; ++c) {
+        real baseColor_d = a[c] * (R(1) - m);                             /* :1405 */
+        real brdf_diff = baseColor_d / O_PI * F_D_w_out * F_D_w_in * NoL; /* :1409 */
+        real C_0 = (R(1) - m) * R(0.04) + m * a[c];                       /* :1412 */
+        real F_m = C_0 + (R(1) - C_0) * x5;                               /* :1413 */
+        real brdf_metal = D * G * F_m / R(4) * NoL;                       /* :1414 */
+        f[c] = brdf_diff + brdf_metal;                                    /* :1415 */
+    }
+}
+
+/* Analytic gradient of eval_brdf's value (not of pdf) w.r.t. a, r, m, n for an upstream RGB weight g:
+ *   d_a[c] = g[c] * df[c]/da[c];  d_r = sum_c g[c] df[c]/dr;  d_m likewise;  d_n[3] = sum_c g[c] df[c]/dn.
+ * Pinned against torch autograd of the reference function (tests/golden/eval_brdf.npz). */
+void oracle_eval_brdf_grad(const real wi[3], const real wo[3], const real n[3], const real a[3], real r, real m,
+                           const real g[3], real d_a[3], real* d_r, real* d_m, real d_n[3]) {
+    real h[3] = {wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2]};
+    real hl = sqrt(dot3(h, h));
+    h[0] /= hl; h[1] /= hl; h[2] /= hl;
+    real nl = dot3(n, wi), nv = dot3(n, wo), nh = dot3(n, h);
+    real NoL = rmax(nl, R(0)), NoV = rmax(nv, R(0)), NoH = rmax(nh, R(0));
+    real VoH = rmax(dot3(wo, h), R(0));
+    real alpha2 = r * r * r * r;
+    real den = NoH * NoH * (alpha2 - R(1)) + R(1) + R(1e-6);
+    real D = alpha2 / (O_PI * den * den);
+    real dD_dalpha2 = R(1) / (O_PI * den * den) - R(2) * alpha2 * NoH * NoH / (O_PI * den * den * den);
+    real dD_dr = dD_dalpha2 * R(4) * r * r * r;
+    real dD_dNoH = -R(2) * alpha2 / (O_PI * den * den * den) * R(2) * NoH * (alpha2 - R(1));
+    real k = (r + R(1)) * (r + R(1)) / R(8);
+    real dk_dr = (r + R(1)) / R(4);
+    real g1l = R(1) / (NoL * (R(1) - k) + k + R(1e-6));
+    real g1v = R(1) / (NoV * (R(1) - k) + k + R(1e-6));
+    real G = g1l * g1v;
+    real dg1l_dk = -g1l * g1l * (R(1) - NoL), dg1v_dk = -g1v * g1v * (R(1) - NoV);
+    real dG_dr = (dg1l_dk * g1v + g1l * dg1v_dk) * dk_dr;
+    real dG_dNoL = -g1l * g1l * (R(1) - k) * g1v;
+    real dG_dNoV = -g1v * g1v * (R(1) - k) * g1l;
+    real FD90 = R(0.5) + R(2) * VoH * VoH * r;
+    real po = pow5(R(1) - NoV), pi_ = pow5(R(1) - NoL);
+    real Fo = R(1) + (FD90 - R(1)) * po, Fi = R(1) + (FD90 - R(1)) * pi_;
+    real dFoFi_dr = (po * Fi + Fo * pi_) * R(2) * VoH * VoH;
+    real q4o = (R(1) - NoV); q4o = q4o * q4o; q4o = q4o * q4o;
+    real q4i = (R(1) - NoL); q4i = q4i * q4i; q4i = q4i * q4i;
+    real dFo_dNoV = -(FD90 - R(1)) * R(5) * q4o;
+    real dFi_dNoL = -(FD90 - R(1)) * R(5) * q4i;
+    real x5 = pow5(R(1) - VoH);
+    real dr_acc = R(0), dm_acc = R(0), dNoL = R(0), dNoV = R(0), dNoH = R(0);
+    for (int c = 0; c < 3; ++c) {
+        real kd = a[c] * (R(1) - m) / O_PI;
+        real C0 = (R(1) - m) * R(0.04) + m * a[c];
+        real Fm = C0 + (R(1) - C0) * x5;
+        /* f = kd*Fo*Fi*NoL + D*G*Fm/4*NoL */
+        real df_da = (R(1) - m) / O_PI * Fo * Fi * NoL + D * G / R(4) * NoL * (R(1) - x5) * m;
+        real df_dm = -a[c] / O_PI * Fo * Fi * NoL + D * G / R(4) * NoL * (R(1) - x5) * (a[c] - R(0.04));
+        real df_dr = kd * dFoFi_dr * NoL + (dD_dr * G + D * dG_dr) * Fm / R(4) * NoL;
+        real df_dNoL = kd * Fo * (dFi_dNoL * NoL + Fi) + D * Fm / R(4) * (dG_dNoL * NoL + G);
+        real df_dNoV = kd * dFo_dNoV * Fi * NoL + D * dG_dNoV * Fm / R(4) * NoL;
+        real df_dNoH = dD_dNoH * G * Fm / R(4) * NoL;
+        d_a[c] = g[c] * df_da;
+        dr_acc += g[c] * df_dr;
+        dm_acc += g[c] * df_dm;
+        dNoL += g[c] * df_dNoL;
+        dNoV += g[c] * df_dNoV;
+        dNoH += g[c] * df_dNoH;
+    }
+    *d_r = dr_acc;
+    *d_m = dm_acc;
+    /* dr.maximum(x, 0): gradient passes where x > 0 */
+    if (!(nl > R(0))) dNoL = R(0);
+    if (!(nv > R(0))) dNoV = R(0);
+    if (!(nh > R(0))) dNoH = R(0);
+    for (int i = 0; i < 3; ++i) d_n[i] = dNoL * wi[i] + dNoV * wo[i] + dNoH * h[i];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * [ext] mi.Frame3f(n): Mitsuba 3 coordinate_system() = Duff et al. 2017 branchless orthonormal basis.
+ * Not in the reference tree (mitsuba==3.5.2 wheel); restated from the published algorithm.
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_frame(const real n[3], real s[3], real t[3]) {
+    real sign = n[2] >= R(0) ? R(1) : -R(1);
+    real a = -R(1) / (sign + n[2]);
+    real b = n[0] * n[1] * a;
+    s[0] = R(1) + sign * n[0] * n[0] * a; s[1] = sign * b; s[2] = -sign * n[0];
+    t[0] = b; t[1] = sign + n[1] * n[1] * a; t[2] = -n[1];
+}
+static inline void to_world(const real s[3], const real t[3], const real n[3], const real v[3], real out[3]) {
+    for (int i = 0; i < 3; ++i) out[i] = s[i] * v[0] + t[i] * v[1] + n[i] * v[2];
+}
+
+/* a5: mi_diffuse_sampler                   myutils/mi_plugin.py:255-281 */
+void oracle_diffuse_sampler(real u0, real u1, const real n[3], real wi[3]) {
+    real theta = asin(sqrt(rmax(u0, R(0))));
+    real phi = R(2) * O_PI * u1;
+    real l[3] = {sin(theta) * cos(phi), sin(theta) * sin(phi), cos(theta)};
+    real s[3], t[3];
+    oracle_frame(n, s, t);
+    to_world(s, t, n, l, wi);
+}
+/* a5: mi_specular_sampler                  myutils/mi_plugin.py:217-253 */
+void oracle_specular_sampler(real u0, real u1, real roughness, const real wo[3], const real n[3], real wi[3]) {
+    real alpha = roughness * roughness;
+    real cos_theta = sqrt(rmax((R(1) - u0) / (u0 * (alpha * alpha - R(1)) + R(1)), R(0)));
+    real sin_theta = sqrt(rmax(R(0), R(1) - cos_theta * cos_theta));
+    real phi = R(2) * O_PI * u1;
+    real l[3] = {sin_theta * cos(phi), sin_theta * sin(phi), cos_theta};
+    real s[3], t[3], wh[3];
+    oracle_frame(n, s, t);
+    to_world(s, t, n, l, wh);
+    real d = R(2) * dot3(wo, wh);
+    for (int i = 0; i < 3; ++i) wi[i] = d * wh[i] - wo[i];
+    real len = sqrt(dot3(wi, wi));
+    for (int i = 0; i < 3; ++i) wi[i] /= len;
+}
+/* a5: MatDiffBSDF.sample_brdf              myutils/mi_plugin.py:1296-1341
+ *     sample1 > 0.5 -> diffuse lobe, else specular; weight = f*cos/(pdf+1e-6) where pdf > 1e-6. */
+void oracle_sample_brdf(real sample1, real u0, real u1, const real wo[3], const real n[3], const real a[3], real r,
+                        real m, real wi[3], real* pdf_out, real weight[3]) {
+    if (sample1 > R(0.5)) oracle_diffuse_sampler(u0, u1, n, wi);
+    else oracle_specular_sampler(u0, u1, r, wo, n, wi);
+    real f[3], pdf;
+    oracle_eval_brdf(wi, wo, n, a, r, m, f, &pdf);
+    for (int c = 0; c < 3; ++c) weight[c] = pdf > R(1e-6) ? f[c] / (pdf + R(1e-6)) : R(0);
+    *pdf_out = pdf > R(0) ? pdf : R(0);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a6: perspective_projection_matrix + mi_world_to_screen      myutils/mi_plugin.py:585-595,645-671
+ *     view = inverse(to_world) with to_world = diag(-1,1,-1,1) (myutils/default_cam.json).
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_world_to_screen(const real p[3], real fov_x_rad, real aspect, real near_, real far_, int width,
+                            int height, real screen[2]) {
+    real f = R(1) / tan(fov_x_rad / R(2));
+    real cam[4] = {-p[0], p[1], -p[2], R(1)};          /* view_matrix @ (p,1) */
+    real clip[4];
+    clip[0] = f / aspect * cam[0];
+    clip[1] = f * cam[1];
+    clip[2] = (far_ + near_) / (near_ - far_) * cam[2] + (R(2) * far_ * near_) / (near_ - far_) * cam[3];
+    clip[3] = -cam[2];
+    real ndc0 = clip[0] / clip[3], ndc1 = clip[1] / clip[3];
+    screen[0] = (ndc0 + R(1)) * R(0.5) * (real)width;  /* x_screen */
+    screen[1] = (ndc1 + R(1)) * R(0.5) * (real)height; /* y_screen */
+}
+
+/* App. E / myutils/mesh_recon.py:17-25: f = (W/2)/tan(fov/2), c = (W-1)/2, (H-1)/2; pixel (i,j) centre
+ * <-> world ((j-cx)/f*d, -(i-cy)/f*d, -d); view direction wo = -p/|p| (independent of d). */
+void oracle_pixel_to_world(int i, int j, real depth, int H, int W, real fov_x_deg, real p[3]) {
+    real f = (R(0.5) * (real)W) / tan(R(0.5) * fov_x_deg * O_PI / R(180));
+    real cx = R(0.5) * (real)(W - 1), cy = R(0.5) * (real)(H - 1);
+    p[0] = ((real)j - cx) / f * depth;
+    p[1] = -((real)i - cy) / f * depth;
+    p[2] = -depth;
+}
+void oracle_view_dir(int i, int j, int H, int W, real fov_x_deg, real wo[3]) {
+    real p[3];
+    oracle_pixel_to_world(i, j, R(1), H, W, fov_x_deg, p);
+    real l = sqrt(dot3(p, p));
+    for (int k = 0; k < 3; ++k) wo[k] = -p[k] / l;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a10: order-4 real spherical harmonics, 25 coefficients, index l(l+1)+m.
+ *      Convention of myutils/computeSH.py:13-68 (associated Legendre with Condon-Shortley sign,
+ *      K = sqrt((2l+1)(l-|m|)!/(4pi (l+|m|)!)), sqrt2 sin(|m|phi) / 1 / sqrt2 cos(m phi)).
+ *      Angles <-> world direction follow myutils/envmap_utils.py:29-36 and computeSH.py:233-235:
+ *      theta = acos(y) (pole = +y), phi = atan2(x, -z) (phi = 0 <-> camera-forward -z).
+ * ---------------------------------------------------------------------------------------------- */
+static real fact(int n) { real f = R(1); for (int i = 2; i <= n; ++i) f *= (real)i; return f; }
+real oracle_sh_K(int l, int m) {
+    if (m < 0) m = -m;
+    return sqrt((real)(2 * l + 1) * fact(l - m) / fact(l + m) / R(4) / O_PI);
+}
+void oracle_sh_basis_angles(real theta, real phi, real Y[MATPBR_NSH]) {
+    real ct = cos(theta), st = sin(theta);
+    real P[5][5];
+    P[0][0] = R(1);
+    P[1][0] = ct; P[1][1] = -st;
+    P[2][0] = R(0.5) * (R(3) * ct * ct - R(1)); P[2][1] = -R(3) * ct * st; P[2][2] = R(3) * st * st;
+    P[3][0] = R(0.5) * (R(5) * ct * ct * ct - R(3) * ct);
+    P[3][1] = -R(1.5) * (R(5) * ct * ct - R(1)) * st;
+    P[3][2] = R(15) * ct * st * st;
+    P[3][3] = -R(15) * st * st * st;
+    P[4][0] = R(0.125) * (R(35) * ct * ct * ct * ct - R(30) * ct * ct + R(3));
+    P[4][1] = -R(2.5) * (R(7) * ct * ct * ct - R(3) * ct) * st;
+    P[4][2] = R(7.5) * (R(7) * ct * ct - R(1)) * st * st;
+    P[4][3] = -R(105) * ct * st * st * st;
+    P[4][4] = R(105) * st * st * st * st;
+    const real s2 = sqrt(R(2));
+    for (int l = 0; l <= 4; ++l)
+        for (int m = -l; m <= l; ++m) {
+            int am = m < 0 ? -m : m;
+            real K = oracle_sh_K(l, am);
+            real v = K * P[l][am];
+            if (m < 0) v *= s2 * sin((real)am * phi);
+            else if (m > 0) v *= s2 * cos((real)am * phi);
+            Y[l * (l + 1) + m] = v;
+        }
+}
+void oracle_dir_to_angles(const real w[3], real* theta, real* phi) {
+    real y = w[1];
+    if (y > R(1)) y = R(1);
+    if (y < -R(1)) y = -R(1);
+    *theta = acos(y);
+    *phi = atan2(w[0], -w[2]);
+}
+void oracle_sh_basis_dir(const real w[3], real Y[MATPBR_NSH]) {
+    real th, ph;
+    oracle_dir_to_angles(w, &th, &ph);
+    oracle_sh_basis_angles(th, ph, Y);
+}
+/* radiance L(w)[c] = sum_k coef[k][c] * Y_k(w)      (computeSH.py:165-224 `projection`) */
+void oracle_sh_eval(const real w[3], const real* coef /*[25][3]*/, real L[3]) {
+    real Y[MATPBR_NSH];
+    oracle_sh_basis_dir(w, Y);
+    L[0] = L[1] = L[2] = R(0);
+    for (int k = 0; k < MATPBR_NSH; ++k)
+        for (int c = 0; c < 3; ++c) L[c] += coef[k * 3 + c] * Y[k];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Deterministic sample set (the build's replacement for Mitsuba's `independent` sampler):
+ *   n = spp/2 points per lobe, u0_i = (i+0.5)/n, u1_i = vdC_2(i) + 0.5/m, m = 2^ceil(log2 n).
+ *   Samples [0, n) use the diffuse sampler (reference: sample1 > 0.5), [n, 2n) the specular one.
+ * ---------------------------------------------------------------------------------------------- */
+static real vdc2(uint32_t i) {
+    i = (i << 16) | (i >> 16);
+    i = ((i & 0x55555555u) << 1) | ((i & 0xAAAAAAAAu) >> 1);
+    i = ((i & 0x33333333u) << 2) | ((i & 0xCCCCCCCCu) >> 2);
+    i = ((i & 0x0F0F0F0Fu) << 4) | ((i & 0xF0F0F0F0u) >> 4);
+    i = ((i & 0x00FF00FFu) << 8) | ((i & 0xFF00FF00u) >> 8);
+    return (real)((double)i * 2.3283064365386963e-10);
+}
+void oracle_sample_point(int spp, int i, real* u0, real* u1) {
+    int n = spp / 2;
+    int m = 1;
+    while (m < n) m <<= 1;
+    *u0 = ((real)i + R(0.5)) / (real)n;
+    *u1 = vdc2((uint32_t)i) + R(0.5) / (real)m;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a8/a2(Mitsuba): the deterministic render  R(a, r, m, n; light)  for one pixel
+ *   L_o = (1/spp) sum_s  w_s * L_SH(wi_s),   (wi_s, w_s) = sample_brdf(lobe_s, u_s; wo, n, a, r, m)
+ * i.e. the BSDF-sampling arm of a depth-1 path (direct light from the environment, unshadowed) with
+ * the one-sample-model mixture pdf of eval_brdf (:1398-1401) and the MC weight of sample_brdf (:1335-1341).
+ * ---------------------------------------------------------------------------------------------- */
+static void shade_pixel(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef,
+                        int spp, real out[3]) {
+    int half = spp / 2;
+    out[0] = out[1] = out[2] = R(0);
+    for (int s = 0; s < spp; ++s) {
+        real u0, u1, wi[3], pdf, w[3], L[3];
+        oracle_sample_point(spp, s < half ? s : s - half, &u0, &u1);
+        oracle_sample_brdf(s < half ? R(1) : R(0), u0, u1, wo, n, a, r, m, wi, &pdf, w);
+        oracle_sh_eval(wi, coef, L);
+        for (int c = 0; c < 3; ++c) out[c] += w[c] * L[c];
+    }
+    for (int c = 0; c < 3; ++c) out[c] /= (real)spp;
+}
+
+/* Backward of shade_pixel with sample directions and pdf treated as constants (stop-gradient), the
+ * convention of the reference's torch variants (`D.data`, `alpha.data`: myutils/mi_plugin.py:366,179). */
+static void shade_pixel_bwd(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef,
+                            int spp, const real g_out[3], real d_a[3], real* d_r, real* d_m, real d_n[3],
+                            real* d_coef /*[25][3] accumulated, may be NULL*/) {
+    int half = spp / 2;
+    d_a[0] = d_a[1] = d_a[2] = R(0);
+    *d_r = R(0); *d_m = R(0);
+    d_n[0] = d_n[1] = d_n[2] = R(0);
+    for (int s = 0; s < spp; ++s) {
+        real u0, u1, wi[3], f[3], pdf, Y[MATPBR_NSH], L[3] = {0, 0, 0};
+        oracle_sample_point(spp, s < half ? s : s - half, &u0, &u1);
+        if (s < half) oracle_diffuse_sampler(u0, u1, n, wi);
+        else oracle_specular_sampler(u0, u1, r, wo, n, wi);
+        oracle_eval_brdf(wi, wo, n, a, r, m, f, &pdf);
+        if (!(pdf > R(1e-6))) continue;
+        real inv = R(1) / ((pdf + R(1e-6)) * (real)spp);
+        oracle_sh_basis_dir(wi, Y);
+        for (int k = 0; k < MATPBR_NSH; ++k)
+            for (int c = 0; c < 3; ++c) L[c] += coef[k * 3 + c] * Y[k];
+        real g[3], ga[3], gr, gm, gn[3];
+        for (int c = 0; c < 3; ++c) g[c] = g_out[c] * L[c] * inv;
+        oracle_eval_brdf_grad(wi, wo, n, a, r, m, g, ga, &gr, &gm, gn);
+        for (int c = 0; c < 3; ++c) { d_a[c] += ga[c]; d_n[c] += gn[c]; }
+        *d_r += gr; *d_m += gm;
+        if (d_coef)
+            for (int k = 0; k < MATPBR_NSH; ++k)
+                for (int c = 0; c < 3; ++c) d_coef[k * 3 + c] += g_out[c] * f[c] * inv * Y[k];
+    }
+}
+
+/* Image-level entry points.  Layout = the reference's: row-major HWC float maps
+ * a[H,W,3] r[H,W,1] m[H,W,1] n[H,W,3] (myutils/mi_plugin.py:1238-1241), light = SH coef [batch,25,3]. */
+void oracle_shade_fwd(const real* a, const real* r, const real* m, const real* n, const real* light, real* out,
+                      int H, int W, int batch, int spp, real fov_x_deg) {
+    const long P = (long)H * W;
+#pragma omp parallel for schedule(static)
+    for (long idx = 0; idx < P * batch; ++idx) {
+        long b = idx / P, p = idx % P;
+        int i = (int)(p / W), j = (int)(p % W);
+        real wo[3];
+        oracle_view_dir(i, j, H, W, fov_x_deg, wo);
+        shade_pixel(wo, n + idx * 3, a + idx * 3, r[idx], m[idx], light + b * MATPBR_NSH * 3, spp, out + idx * 3);
+    }
+}
+void oracle_shade_bwd(const real* a, const real* r, const real* m, const real* n, const real* light,
+                      const real* d_out, real* d_a, real* d_r, real* d_m, real* d_n /*nullable*/,
+                      real* d_light /*nullable, [batch,25,3], overwritten*/, int H, int W, int batch, int spp,
+                      real fov_x_deg) {
+    const long P = (long)H * W;
+    if (d_light) memset(d_light, 0, sizeof(real) * (size_t)batch * MATPBR_NSH * 3);
+    for (long b = 0; b < batch; ++b) {
+#pragma omp parallel
+        {
+            real acc[MATPBR_NSH * 3];
+            memset(acc, 0, sizeof(acc));
+#pragma omp for schedule(static)
+            for (long p = 0; p < P; ++p) {
+                long idx = b * P + p;
+                int i = (int)(p / W), j = (int)(p % W);
+                real wo[3], ga[3], gr, gm, gn[3];
+                oracle_view_dir(i, j, H, W, fov_x_deg, wo);
+                shade_pixel_bwd(wo, n + idx * 3, a + idx * 3, r[idx], m[idx], light + b * MATPBR_NSH * 3, spp,
+                                d_out + idx * 3, ga, &gr, &gm, gn, d_light ? acc : NULL);
+                if (d_a) for (int c = 0; c < 3; ++c) d_a[idx * 3 + c] = ga[c];
+                if (d_r) d_r[idx] = gr;
+                if (d_m) d_m[idx] = gm;
+                if (d_n) for (int c = 0; c < 3; ++c) d_n[idx * 3 + c] = gn[c];
+            }
+            if (d_light) {
+#pragma omp critical
+                for (int k = 0; k < MATPBR_NSH * 3; ++k) d_light[b * MATPBR_NSH * 3 + k] += acc[k];
+            }
+        }
+    }
+}
+
+/* a9 (scene prep): per-pixel geometric normal of the depth heightfield.  The reference shades with the
+ * face normal of the triangulated depth mesh (inverse_img_w_mi.py:751-758, myutils/mesh_recon.py:41-74);
+ * the per-pixel restatement is the normalised cross product of central differences of the back-projected
+ * positions (one-sided at the border), oriented towards the camera. */
+void oracle_normals_from_depth(const real* depth, real* out_n, int H, int W, int batch, real fov_x_deg) {
+    const long P = (long)H * W;
+#pragma omp parallel for schedule(static)
+    for (long idx = 0; idx < P * batch; ++idx) {
+        long b = idx / P, p = idx % P;
+        int i = (int)(p / W), j = (int)(p % W);
+        const real* d = depth + b * P;
+        int j0 = j > 0 ? j - 1 : j, j1 = j < W - 1 ? j + 1 : j;
+        int i0 = i > 0 ? i - 1 : i, i1 = i < H - 1 ? i + 1 : i;
+        real pl[3], pr[3], pu[3], pd[3], c[3];
+        oracle_pixel_to_world(i, j0, d[(long)i * W + j0], H, W, fov_x_deg, pl);
+        oracle_pixel_to_world(i, j1, d[(long)i * W + j1], H, W, fov_x_deg, pr);
+        oracle_pixel_to_world(i0, j, d[(long)i0 * W + j], H, W, fov_x_deg, pu);
+        oracle_pixel_to_world(i1, j, d[(long)i1 * W + j], H, W, fov_x_deg, pd);
+        real dx[3] = {pr[0] - pl[0], pr[1] - pl[1], pr[2] - pl[2]};
+        real dy[3] = {pd[0] - pu[0], pd[1] - pu[1], pd[2] - pu[2]};
+        /* +x is image-right, image-down is -y: dx cross (-dy) ... orient afterwards */
+        real nn[3] = {dx[1] * dy[2] - dx[2] * dy[1], dx[2] * dy[0] - dx[0] * dy[2], dx[0] * dy[1] - dx[1] * dy[0]};
+        real l = sqrt(dot3(nn, nn));
+        oracle_pixel_to_world(i, j, d[(long)i * W + j], H, W, fov_x_deg, c);
+        real s = (dot3(nn, c) > R(0)) ? -R(1) : R(1); /* face the camera at the origin */
+        if (l > R(0)) for (int k = 0; k < 3; ++k) out_n[idx * 3 + k] = s * nn[k] / l;
+        else { out_n[idx * 3] = R(0); out_n[idx * 3 + 1] = R(0); out_n[idx * 3 + 2] = R(1); }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch wrappers for the tests (N lanes, AoS [N,3] vectors).
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_eval_brdf_batch(long N, const real* wi, const real* wo, const real* n, const real* a, const real* r,
+                            const real* m, real* f, real* pdf) {
+    for (long k = 0; k < N; ++k) oracle_eval_brdf(wi + 3 * k, wo + 3 * k, n + 3 * k, a + 3 * k, r[k], m[k], f + 3 * k, pdf + k);
+}
+void oracle_eval_brdf_grad_batch(long N, const real* wi, const real* wo, const real* n, const real* a, const real* r,
+                                 const real* m, const real* g, real* d_a, real* d_r, real* d_m, real* d_n) {
+    for (long k = 0; k < N; ++k)
+        oracle_eval_brdf_grad(wi + 3 * k, wo + 3 * k, n + 3 * k, a + 3 * k, r[k], m[k], g + 3 * k, d_a + 3 * k, d_r + k, d_m + k, d_n + 3 * k);
+}
+void oracle_sample_brdf_batch(long N, const real* sample1, const real* sample2 /*[N,2]*/, const real* wo, const real* n,
+                              const real* a, const real* r, const real* m, real* wi, real* pdf, real* weight) {
+    for (long k = 0; k < N; ++k)
+        oracle_sample_brdf(sample1[k], sample2[2 * k], sample2[2 * k + 1], wo + 3 * k, n + 3 * k, a + 3 * k, r[k], m[k],
+                           wi + 3 * k, pdf + k, weight + 3 * k);
+}
+void oracle_sh_basis_batch(long N, const real* theta, const real* phi, real* Y /*[N,25]*/) {
+    for (long k = 0; k < N; ++k) oracle_sh_basis_angles(theta[k], phi[k], Y + MATPBR_NSH * k);
+}
+void oracle_sh_basis_dir_batch(long N, const real* w, real* Y) {
+    for (long k = 0; k < N; ++k) oracle_sh_basis_dir(w + 3 * k, Y + MATPBR_NSH * k);
+}
+void oracle_sample_table(int spp, real* u /*[spp/2,2]*/) {
+    for (int i = 0; i < spp / 2; ++i) oracle_sample_point(spp, i, u + 2 * i, u + 2 * i + 1);
+}
+int oracle_sizeof_real(void) { return (int)sizeof(real); }

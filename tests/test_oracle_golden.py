@@ -1,0 +1,128 @@
+"""Pin the CPU oracle (oracle/matpbr_oracle.c) to the golden vectors that tests/golden/gen_golden.py
+produced by running the reference's own arithmetic.  fp64 against fp64."""
+import os
+
+import numpy as np
+import pytest
+
+TOL = 1e-12
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_scalar_grids(oracle64, golden_dir):
+    g = _load(golden_dir, "brdf_scalar_grids.npz")
+    R, C = np.meshgrid(g["r"], g["c"], indexing="ij")
+    np.testing.assert_allclose(oracle64.D_GGX(C, R), g["D"], rtol=TOL)
+    np.testing.assert_allclose(oracle64.G1(C, R), g["G1"], rtol=TOL)
+    nol = g["Gs_nol"][:, None, None] * np.ones((1,) + R.shape)
+    np.testing.assert_allclose(oracle64.G_Smith(C[None] * np.ones_like(nol), nol, R[None] * np.ones_like(nol)), g["Gs"], rtol=TOL)
+    np.testing.assert_allclose(oracle64.fresnel(g["c"][None, :], g["F0"][:, None]), g["Fr"], rtol=TOL)
+
+
+def test_appendix_c_known_answers(oracle64):
+    # SURVEY.md App. C
+    assert oracle64.lib.oracle_D_GGX(0.9, 0.5) == pytest.approx(0.343593581, rel=1e-8)
+    assert oracle64.lib.oracle_G_Smith(0.7, 0.6, 0.5) == pytest.approx(1.7893291, rel=1e-7)
+    assert oracle64.lib.oracle_fresnelSchlick(0.8, 0.04) == pytest.approx(0.0403072, rel=1e-7)
+
+
+@pytest.mark.parametrize("name", ["eval_brdf.npz", "eval_brdf_kat.npz"])
+def test_eval_brdf_forward_and_grads(oracle64, golden_dir, name):
+    g = _load(golden_dir, name)
+    wi, wo, n, a = (g[k].T for k in ("wi", "wo", "n", "a"))
+    f, pdf = oracle64.eval_brdf(wi, wo, n, a, g["r"], g["m"])
+    np.testing.assert_allclose(f, g["f"].T, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(pdf, g["pdf"], rtol=1e-11, atol=1e-14)
+    ones = np.ones_like(f)
+    d_a, d_r, d_m, d_n = oracle64.eval_brdf_grad(wi, wo, n, a, g["r"], g["m"], ones)
+    scale = lambda x: 1e-10 * max(1.0, np.abs(x).max())
+    np.testing.assert_allclose(d_a, g["d_a"].T, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(d_r, g["d_r"], rtol=1e-9, atol=scale(g["d_r"]))
+    np.testing.assert_allclose(d_m, g["d_m"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(d_n, g["d_n"].T, rtol=1e-9, atol=scale(g["d_n"]))
+    # per-channel upstream weights
+    for ch in range(3):
+        e = np.zeros_like(f)
+        e[:, ch] = 1.0
+        d_a, d_r, d_m, d_n = oracle64.eval_brdf_grad(wi, wo, n, a, g["r"], g["m"], e)
+        np.testing.assert_allclose(d_a, g[f"d_a_ch{ch}"].T, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(d_r, g[f"d_r_ch{ch}"], rtol=1e-9, atol=scale(g["d_r"]))
+        np.testing.assert_allclose(d_m, g[f"d_m_ch{ch}"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(d_n, g[f"d_n_ch{ch}"].T, rtol=1e-9, atol=scale(g["d_n"]))
+
+
+def test_samplers(oracle64, golden_dir):
+    g = _load(golden_dir, "samplers.npz")
+    u = g["u"]
+    for k in range(g["normals"].shape[1]):
+        nk, vk = g["normals"][:, k], g["views"][:, k]
+        for s in range(u.shape[1]):
+            np.testing.assert_allclose(oracle64.diffuse_sampler(u[0, s], u[1, s], nk), g["diffuse"][k][:, s], rtol=1e-11, atol=1e-13)
+            for ri, rv in enumerate(g["rough"]):
+                np.testing.assert_allclose(oracle64.specular_sampler(u[0, s], u[1, s], rv, vk, nk), g["specular"][k][ri][:, s],
+                                           rtol=1e-10, atol=1e-12)
+
+
+def test_sample_brdf(oracle64, golden_dir):
+    g = _load(golden_dir, "sample_brdf.npz")
+    wi, pdf, w = oracle64.sample_brdf(g["sample1"], g["sample2"].T, g["wo"].T, g["n"].T, g["a"].T, g["r"], g["m"])
+    np.testing.assert_allclose(wi, g["wi"].T, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(pdf, g["pdf"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(w, g["weight"].T, rtol=1e-9, atol=1e-12)
+
+
+def test_world_to_screen_is_texel_identity(oracle64, golden_dir):
+    g = _load(golden_dir, "world_to_screen.npz")
+    W, H = int(g["width"]), int(g["height"])
+    for k in range(g["row"].shape[0]):
+        i, j = int(g["row"][k]), int(g["col"][k])
+        p = oracle64.pixel_to_world(i, j, g["depth"][k], H, W, float(g["fov_deg"]))
+        np.testing.assert_allclose(p, g["points"][:, k], rtol=1e-12)
+        s = oracle64.world_to_screen(p, np.deg2rad(35.0), W / H, 0.009999999776482582, 10000.0, W, H)
+        # the reference builds its projection matrix in float32 (mi_plugin.py:585-595): 1e-5 px agreement
+        np.testing.assert_allclose(s, g["screen"][:, k], atol=2e-5)
+        # a6: primary hits read the texel of the pixel they are seen through
+        assert (int(np.floor(g["screen"][0, k])), int(np.floor(g["screen"][1, k]))) == (j, i)
+        assert (int(np.floor(s[0] + 1e-9)), int(np.floor(s[1] + 1e-9))) == (j, i)
+
+
+def test_sh_convention(oracle64, golden_dir):
+    g = _load(golden_dir, "sh.npz")
+    # computeK works in float32 (computeSH.py:64-66)
+    np.testing.assert_allclose(oracle64.sh_K(), g["K"], rtol=2e-7)
+    Y = oracle64.sh_basis_angles(g["theta"], g["phi"])
+    np.testing.assert_allclose(Y, g["basis"], rtol=1e-6, atol=2e-7)
+    # reconstImageFromSH grid: theta = pi*row/nrows, phi = -pi + 2pi*col/ncols (computeSH.py:233-235)
+    for coef, img in ((g["coef_c"], g["img_c"]), (g["coef_r"], g["img_r"])):
+        rows, cols = np.meshgrid(np.arange(16), np.arange(32), indexing="ij")
+        th = np.pi * rows.reshape(-1) / 16
+        ph = -np.pi + 2 * np.pi * cols.reshape(-1) / 32
+        rec = (oracle64.sh_basis_angles(th, ph) @ coef).reshape(16, 32, 3)
+        np.testing.assert_allclose(rec, img, rtol=1e-5, atol=1e-6)
+    # App. C spot values
+    np.testing.assert_allclose(g["img_c"][0, 0], (0.52639605, 0.3798153, 0.33095504), rtol=1e-6)
+    np.testing.assert_allclose(g["img_c"][15, 31], (0.05183672, 0.18625196, 0.21547537), rtol=1e-6)
+
+
+def test_sh_direction_mapping(oracle64):
+    # theta = acos(y), phi = atan2(x, -z): envmap_utils.py:29-36
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(32, 3))
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    th = np.arccos(w[:, 1])
+    ph = np.arctan2(w[:, 0], -w[:, 2])
+    np.testing.assert_allclose(oracle64.sh_basis_dir(w), oracle64.sh_basis_angles(th, ph), rtol=1e-12, atol=1e-14)
+
+
+def test_sh_orthonormal(oracle64):
+    # Gauss-Legendre x uniform-phi quadrature integrates degree-8 products exactly
+    x, wq = np.polynomial.legendre.leggauss(16)
+    phi = -np.pi + 2 * np.pi * (np.arange(32) + 0.5) / 32
+    T, Pp = np.meshgrid(np.arccos(x), phi, indexing="ij")
+    Wt = (wq[:, None] * np.ones_like(Pp) * (2 * np.pi / 32)).reshape(-1)
+    Y = oracle64.sh_basis_angles(T.reshape(-1), Pp.reshape(-1))
+    gram = (Y * Wt[:, None]).T @ Y
+    np.testing.assert_allclose(gram, np.eye(25), atol=1e-12)
