@@ -1,0 +1,101 @@
+/*
+ * matpbr.h -- C ABI of libmatpbr.so: MI355X (gfx950) differentiable PBR shading kernels.
+ *
+ * This is the drop-in boundary for the hot path of lez-s/Materialist.  Every
+ * entry point names the reference interface it replaces (file:line into the reference tree).
+ *
+ * Conventions
+ *   - All tensor pointers are DEVICE pointers owned by the caller (PyTorch), fp32, contiguous,
+ *     in the reference's row-major HWC layout: a[B,H,W,3] r[B,H,W,1] m[B,H,W,1] n[B,H,W,3]
+ *     (myutils/mi_plugin.py:1238-1241 holds the same maps as TensorXf [512,512,C]); B = `batch`
+ *     independent images (the reference processes one image per process; B>1 is the build's batching).
+ *   - `light` is [B, n_light, 3]: MATPBR_LIGHT_SH25 = 25 real SH coefficients per colour channel in
+ *     the convention of myutils/computeSH.py:13-68 (index l(l+1)+m), directions mapped by
+ *     theta = acos(y), phi = atan2(x,-z) (myutils/envmap_utils.py:29-36).
+ *   - `stream` is the caller's hipStream_t (NULL = default stream).  Entry points only enqueue work:
+ *     no allocation, no synchronisation, no global mutable state -> usable under hipGraph capture
+ *     and re-entrant per stream.
+ *   - Return value: 0 = MATPBR_OK, negative = error (matpbr_strerror); nothing throws.
+ *   - `spp` (even, 2..MATPBR_MAX_SPP) is the reference's samples-per-pixel argument
+ *     (inverse_img_w_mi.py:59,69,625): here the size of the deterministic BSDF-sample set.
+ */
+#ifndef MATPBR_H
+#define MATPBR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MATPBR_VERSION 100 /* 0.1.0 */
+#define MATPBR_MAX_SPP 128
+#define MATPBR_NSH 25
+
+enum {
+    MATPBR_OK = 0,
+    MATPBR_ERR_INVALID_ARG = -1,
+    MATPBR_ERR_UNSUPPORTED = -2,
+    MATPBR_ERR_LAUNCH = -3,
+    MATPBR_ERR_WORKSPACE = -4,
+};
+
+enum { MATPBR_LIGHT_SH25 = 0 };
+
+/* Pinhole camera of the reference: camera at the origin looking down -z, +y up
+ * (inverse_img_w_mi.py:31-39, myutils/default_cam.json), focal = (W/2)/tan(fov_x/2),
+ * principal point ((W-1)/2, (H-1)/2) (myutils/mesh_recon.py:17-25). */
+typedef struct MatpbrCamera {
+    float fov_x_deg; /* 35 in the reference */
+} MatpbrCamera;
+
+int matpbr_version(void);
+const char* matpbr_strerror(int code);
+
+/* Forward render.  Replaces the forward half of
+ *   render_w_brdf(scene, albedo, roughness, metallic, normal, spp)   inverse_img_w_mi.py:69-80
+ *   render_envmap(scene, envmap, spp)                                inverse_img_w_mi.py:59-67
+ * i.e. mi.render(scene, params, spp) with MatDiffBSDF (myutils/mi_plugin.py:1229-1475) under the
+ * build's deterministic definition.  out_rgb[B,H,W,3] = linear radiance. */
+int matpbr_shade_fwd(const float* a, const float* r, const float* m, const float* n, const float* light,
+                     int light_kind, int n_light, float* out_rgb, int H, int W, int batch, int spp,
+                     const MatpbrCamera* cam, uint32_t flags, void* stream);
+
+/* Backward render.  Replaces the AD pass that `loss.backward()` drives through dr.wrap_ad / mi.render
+ * (inverse_img_w_mi.py:59,69,248,420,544).  Any of d_a/d_r/d_m (all three or none), d_n, d_light may be
+ * NULL to skip that gradient.  d_light[B,n_light,3] is overwritten (not accumulated); it needs
+ * `workspace` of matpbr_shade_bwd_workspace_bytes() bytes (device memory, contents undefined). */
+int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float* n, const float* light,
+                     int light_kind, int n_light, const float* d_out_rgb, float* d_a, float* d_r, float* d_m,
+                     float* d_n, float* d_light, void* workspace, size_t workspace_bytes, int H, int W, int batch,
+                     int spp, const MatpbrCamera* cam, uint32_t flags, void* stream);
+size_t matpbr_shade_bwd_workspace_bytes(int H, int W, int batch, int n_light);
+
+/* Plugin face, N independent lanes, AoS [N,3] vectors (the reference traces these over Dr.Jit arrays).
+ *   matpbr_eval_brdf   = MatDiffBSDF.eval_pdf / eval_brdf     myutils/mi_plugin.py:1372-1427,1449-1460
+ *                        (wi = light direction, wo = view direction; f already includes cos)
+ *   matpbr_sample_brdf = MatDiffBSDF.sample / sample_brdf     myutils/mi_plugin.py:1296-1341,1429-1446
+ *                        sample1[N] > 0.5 -> diffuse lobe; sample2[N,2]; weight = f/(pdf+1e-6) */
+int matpbr_eval_brdf(const float* wi, const float* wo, const float* n, const float* a, const float* r,
+                     const float* m, float* f, float* pdf, long N, void* stream);
+int matpbr_eval_brdf_bwd(const float* wi, const float* wo, const float* n, const float* a, const float* r,
+                         const float* m, const float* g /*[N,3] upstream*/, float* d_a, float* d_r, float* d_m,
+                         float* d_n, long N, void* stream);
+int matpbr_sample_brdf(const float* sample1, const float* sample2, const float* wo, const float* n, const float* a,
+                       const float* r, const float* m, float* wi, float* pdf, float* weight, long N, void* stream);
+
+/* Radiance of the SH light in N directions: L[N,3] = sum_k coef[k,:] Y_k(w)
+ * (myutils/computeSH.py:165-224 `projection`). */
+int matpbr_sh_eval(const float* w, const float* coef /*[25,3]*/, float* L, long N, void* stream);
+
+/* Scene preparation (replaces the depth->mesh->face-normal route of load_estimated_mesh,
+ * inverse_img_w_mi.py:30-56,721-727; myutils/mesh_recon.py:17-25,41-74): per-pixel geometric normal
+ * of the depth heightfield, out_n[B,H,W,3]. */
+int matpbr_normals_from_depth(const float* depth, float* out_n, int H, int W, int batch, const MatpbrCamera* cam,
+                              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATPBR_H */

@@ -1,0 +1,177 @@
+"""Torch-tensor front end of the C ABI: argument validation + pointer/stream plumbing only.
+PyTorch is used for device memory and streams; all arithmetic happens in libmatpbr.so."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import MatpbrCamera, MatpbrError
+
+LIGHT_SH25 = 0
+NSH = 25
+MAX_SPP = 128
+
+
+def _dev(t: torch.Tensor, name: str, shape_tail=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise MatpbrError(f"{name}: matpbr kernels run on the GPU only (tensor is on {t.device}); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if shape_tail is not None and tuple(t.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise ValueError(f"{name}: expected trailing shape {shape_tail}, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _bhw(a: torch.Tensor):
+    if a.ndim == 3:
+        return 1, a.shape[0], a.shape[1]
+    if a.ndim == 4:
+        return a.shape[0], a.shape[1], a.shape[2]
+    raise ValueError(f"maps must be [H,W,C] or [B,H,W,C], got {tuple(a.shape)}")
+
+
+def check_spp(spp: int) -> int:
+    spp = int(spp)
+    if spp < 2 or spp > MAX_SPP or spp % 2:
+        raise ValueError(f"spp must be even and in [2, {MAX_SPP}], got {spp}")
+    return spp
+
+
+def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0) -> torch.Tensor:
+    lib = _lib.load()
+    a = _dev(a, "albedo", (3,))
+    B, H, W = _bhw(a)
+    r = _dev(r, "roughness").reshape(B, H, W, 1)
+    m = _dev(m, "metallic").reshape(B, H, W, 1)
+    n = _dev(n, "normal", (3,))
+    light = _dev(light, "light", (NSH, 3))
+    if n.numel() != a.numel() or r.numel() * 3 != a.numel() or light.numel() != B * NSH * 3:
+        raise ValueError("shade_fwd: inconsistent map / light shapes")
+    out = torch.empty_like(a)
+    cam = MatpbrCamera(float(fov_x_deg))
+    with torch.cuda.device(a.device):
+        code = lib.matpbr_shade_fwd(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(out), H, W, B,
+                                    check_spp(spp), ctypes.byref(cam), 0, _stream(a))
+    _lib.check(code, "matpbr_shade_fwd")
+    return out
+
+
+def shade_bwd(a, r, m, n, light, d_out, spp: int, fov_x_deg: float = 35.0, want_mat=True, want_n=False, want_light=False,
+              workspace: Optional[torch.Tensor] = None):
+    """Returns (d_a, d_r, d_m, d_n, d_light); entries not requested are None."""
+    lib = _lib.load()
+    a = _dev(a, "albedo", (3,))
+    B, H, W = _bhw(a)
+    r = _dev(r, "roughness").reshape(B, H, W, 1)
+    m = _dev(m, "metallic").reshape(B, H, W, 1)
+    n = _dev(n, "normal", (3,))
+    light = _dev(light, "light", (NSH, 3))
+    d_out = _dev(d_out, "d_out", (3,))
+    if d_out.numel() != a.numel():
+        raise ValueError("shade_bwd: d_out shape mismatch")
+    d_a = torch.empty_like(a) if want_mat else None
+    d_r = torch.empty_like(r) if want_mat else None
+    d_m = torch.empty_like(m) if want_mat else None
+    d_n = torch.empty_like(n) if want_n else None
+    d_l = torch.empty_like(light) if want_light else None
+    ws_bytes = 0
+    if want_light:
+        ws_bytes = int(lib.matpbr_shade_bwd_workspace_bytes(H, W, B, NSH))
+        if workspace is None or workspace.numel() * workspace.element_size() < ws_bytes or workspace.device != a.device:
+            workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+    cam = MatpbrCamera(float(fov_x_deg))
+    with torch.cuda.device(a.device):
+        code = lib.matpbr_shade_bwd(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(d_out), _ptr(d_a),
+                                    _ptr(d_r), _ptr(d_m), _ptr(d_n), _ptr(d_l), _ptr(workspace), ws_bytes, H, W, B,
+                                    check_spp(spp), ctypes.byref(cam), 0, _stream(a))
+    _lib.check(code, "matpbr_shade_bwd")
+    return d_a, d_r, d_m, d_n, d_l
+
+
+def eval_brdf(wi, wo, n, a, r, m):
+    """MatDiffBSDF.eval_pdf over N lanes: returns (f*cos [N,3], pdf [N])."""
+    lib = _lib.load()
+    wi, wo, n, a = (_dev(t, k, (3,)) for t, k in ((wi, "wi"), (wo, "wo"), (n, "n"), (a, "a")))
+    r, m = _dev(r, "r").reshape(-1), _dev(m, "m").reshape(-1)
+    N = r.numel()
+    f = torch.empty((N, 3), dtype=torch.float32, device=r.device)
+    pdf = torch.empty(N, dtype=torch.float32, device=r.device)
+    with torch.cuda.device(r.device):
+        code = lib.matpbr_eval_brdf(_ptr(wi), _ptr(wo), _ptr(n), _ptr(a), _ptr(r), _ptr(m), _ptr(f), _ptr(pdf), N, _stream(r))
+    _lib.check(code, "matpbr_eval_brdf")
+    return f, pdf
+
+
+def eval_brdf_bwd(wi, wo, n, a, r, m, g):
+    lib = _lib.load()
+    wi, wo, n, a, g = (_dev(t, k, (3,)) for t, k in ((wi, "wi"), (wo, "wo"), (n, "n"), (a, "a"), (g, "g")))
+    r, m = _dev(r, "r").reshape(-1), _dev(m, "m").reshape(-1)
+    N = r.numel()
+    d_a = torch.empty((N, 3), dtype=torch.float32, device=r.device)
+    d_n = torch.empty((N, 3), dtype=torch.float32, device=r.device)
+    d_r = torch.empty(N, dtype=torch.float32, device=r.device)
+    d_m = torch.empty(N, dtype=torch.float32, device=r.device)
+    with torch.cuda.device(r.device):
+        code = lib.matpbr_eval_brdf_bwd(_ptr(wi), _ptr(wo), _ptr(n), _ptr(a), _ptr(r), _ptr(m), _ptr(g), _ptr(d_a), _ptr(d_r),
+                                        _ptr(d_m), _ptr(d_n), N, _stream(r))
+    _lib.check(code, "matpbr_eval_brdf_bwd")
+    return d_a, d_r, d_m, d_n
+
+
+def sample_brdf(sample1, sample2, wo, n, a, r, m):
+    """MatDiffBSDF.sample over N lanes: returns (wi [N,3], pdf [N], weight [N,3])."""
+    lib = _lib.load()
+    wo, n, a = (_dev(t, k, (3,)) for t, k in ((wo, "wo"), (n, "n"), (a, "a")))
+    sample2 = _dev(sample2, "sample2", (2,))
+    sample1, r, m = _dev(sample1, "sample1").reshape(-1), _dev(r, "r").reshape(-1), _dev(m, "m").reshape(-1)
+    N = r.numel()
+    wi = torch.empty((N, 3), dtype=torch.float32, device=r.device)
+    w = torch.empty((N, 3), dtype=torch.float32, device=r.device)
+    pdf = torch.empty(N, dtype=torch.float32, device=r.device)
+    with torch.cuda.device(r.device):
+        code = lib.matpbr_sample_brdf(_ptr(sample1), _ptr(sample2), _ptr(wo), _ptr(n), _ptr(a), _ptr(r), _ptr(m), _ptr(wi), _ptr(pdf),
+                                      _ptr(w), N, _stream(r))
+    _lib.check(code, "matpbr_sample_brdf")
+    return wi, pdf, w
+
+
+def sh_eval(w, coef):
+    lib = _lib.load()
+    w = _dev(w, "w", (3,))
+    coef = _dev(coef, "coef", (NSH, 3))
+    N = w.numel() // 3
+    L = torch.empty((N, 3), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        code = lib.matpbr_sh_eval(_ptr(w), _ptr(coef), _ptr(L), N, _stream(w))
+    _lib.check(code, "matpbr_sh_eval")
+    return L
+
+
+def normals_from_depth(depth, fov_x_deg: float = 35.0):
+    lib = _lib.load()
+    depth = _dev(depth, "depth")
+    if depth.ndim == 2:
+        B, (H, W) = 1, depth.shape
+    elif depth.ndim == 3:
+        B, H, W = depth.shape
+    else:
+        raise ValueError("depth must be [H,W] or [B,H,W]")
+    out = torch.empty(tuple(depth.shape) + (3,), dtype=torch.float32, device=depth.device)
+    cam = MatpbrCamera(float(fov_x_deg))
+    with torch.cuda.device(depth.device):
+        code = lib.matpbr_normals_from_depth(_ptr(depth), _ptr(out), H, W, B, ctypes.byref(cam), _stream(depth))
+    _lib.check(code, "matpbr_normals_from_depth")
+    return out

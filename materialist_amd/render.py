@@ -1,0 +1,183 @@
+"""Operator face of the hot path: `load_estimated_mesh` / `render_envmap` / `render_w_brdf` with the
+reference's signatures (inverse_img_w_mi.py:30-80) on top of libmatpbr.so.
+
+The reference keeps geometry, camera, current light and current materials inside a Mitsuba scene and
+mutates it through `mi.traverse(scene)` (keys `shape.bsdf.a|r|m|n`, `shape.bsdf.use_mesh_normal`,
+`emitter.data`; inverse_img_w_mi.py:63,73-77,217-219,334-339).  `Scene` below is the lightweight
+stand-in: same keys, same statefulness (the arguments of one render persist for the next).
+
+Lighting: the reference pushes a [16,32,3] texel map into the envmap emitter.  Here the light the
+kernels integrate is its order-4 SH projection (25 coefficients per channel, the convention of
+myutils/computeSH.py); `emitter.data` may be set either to texels [He,We,3] (projected with a fixed
+25 x He*We matrix, differentiable) or directly to SH coefficients [25,3].
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from . import sh as _sh
+
+DEFAULT_FOV = 35.0  # inverse_img_w_mi.py:32, myutils/default_cam.json
+
+
+class _ShadeFn(torch.autograd.Function):
+    """Differentiable R(a, r, m, n, light) -> rgb; stands in for dr.wrap_ad + mi.render (inverse_img_w_mi.py:59-80)."""
+
+    @staticmethod
+    def forward(ctx, a, r, m, n, light, spp, fov, workspace_holder):
+        a, r, m, n, light = (t.contiguous() for t in (a, r, m, n, light))
+        out = ops.shade_fwd(a, r, m, n, light, spp, fov)
+        ctx.save_for_backward(a, r, m, n, light)
+        ctx.spp, ctx.fov, ctx.ws = spp, fov, workspace_holder
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        a, r, m, n, light = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        want_mat = need[0] or need[1] or need[2]
+        want_n, want_light = need[3], need[4]
+        ws = ctx.ws.get("ws") if ctx.ws is not None else None
+        d_a, d_r, d_m, d_n, d_l = ops.shade_bwd(a, r, m, n, light, d_out.contiguous(), ctx.spp, ctx.fov, want_mat=want_mat,
+                                                want_n=want_n, want_light=want_light, workspace=ws)
+        return (d_a if need[0] else None, d_r.reshape(r.shape) if need[1] else None, d_m.reshape(m.shape) if need[2] else None,
+                d_n if need[3] else None, d_l if need[4] else None, None, None, None)
+
+
+class SceneParameters(dict):
+    """`mi.traverse(scene)` stand-in: assignment stores, `update()` is accepted for source compatibility."""
+
+    def __init__(self, scene: "Scene"):
+        super().__init__()
+        self._scene = scene
+        for k in Scene.KEYS:
+            dict.__setitem__(self, k, scene._get(k))
+
+    def __setitem__(self, key, value):
+        if key not in Scene.KEYS:
+            raise KeyError(f"unknown scene parameter {key!r}; valid keys: {Scene.KEYS}")
+        self._scene._set(key, value)
+        dict.__setitem__(self, key, value)
+
+    def update(self, *a, **k):  # params.update() after assignments (inverse_img_w_mi.py:64,78)
+        for key, val in dict(*a, **k).items():
+            self[key] = val
+        return []
+
+
+class Scene:
+    """Geometry (per-pixel geometric normal from depth), pinhole camera, current light and materials."""
+
+    KEYS = ("shape.bsdf.a", "shape.bsdf.r", "shape.bsdf.m", "shape.bsdf.n", "shape.bsdf.use_mesh_normal", "emitter.data")
+
+    def __init__(self, height: int, width: int, device, geo_normal: Optional[torch.Tensor] = None, use_mesh_normal: bool = True,
+                 fov_x_deg: float = DEFAULT_FOV, batch: int = 1, env_size=(16, 32)):
+        self.H, self.W, self.B = int(height), int(width), int(batch)
+        self.device = torch.device(device)
+        self.fov = float(fov_x_deg)
+        self.use_mesh_normal = bool(use_mesh_normal)
+        shp = (self.B, self.H, self.W) if self.B > 1 else (self.H, self.W)
+        full = lambda c, v: torch.full(shp + (c,), v, dtype=torch.float32, device=self.device)
+        # MatDiffBSDF defaults: every map 0.5 (myutils/mi_plugin.py:1238-1241)
+        self.a, self.r, self.m, self.n = full(3, 0.5), full(1, 0.5), full(1, 0.5), full(3, 0.5)
+        if geo_normal is None:
+            geo_normal = torch.zeros(shp + (3,), dtype=torch.float32, device=self.device)
+            geo_normal[..., 2] = 1.0  # fronto-parallel plane facing the camera
+        self.geo_normal = geo_normal.to(self.device, torch.float32).contiguous()
+        self.env_size = tuple(env_size)
+        self._proj: Dict[tuple, torch.Tensor] = {}
+        lshape = (self.B, _sh.NSH, 3) if self.B > 1 else (_sh.NSH, 3)
+        self.light = torch.zeros(lshape, dtype=torch.float32, device=self.device)
+        self.light[..., 0, :] = float(np.sqrt(4 * np.pi))  # unit white radiance until the caller sets emitter.data
+        self.emitter_data = self.light
+        self._ws = {"ws": None}
+
+    # -- mi.traverse face ----------------------------------------------------------------------------
+    def _get(self, key):
+        return {"shape.bsdf.a": self.a, "shape.bsdf.r": self.r, "shape.bsdf.m": self.m, "shape.bsdf.n": self.n,
+                "shape.bsdf.use_mesh_normal": self.use_mesh_normal, "emitter.data": self.emitter_data}[key]
+
+    def _set(self, key, value):
+        if key == "shape.bsdf.use_mesh_normal":
+            self.use_mesh_normal = bool(value)
+        elif key == "emitter.data":
+            self.emitter_data = value
+            self.light = self.light_from_emitter(value)
+        else:
+            setattr(self, key.rsplit(".", 1)[1], value)
+
+    # -- lighting ------------------------------------------------------------------------------------
+    def projection(self, He: int, We: int) -> torch.Tensor:
+        key = (He, We)
+        if key not in self._proj:
+            self._proj[key] = torch.from_numpy(_sh.envmap_to_sh_matrix(He, We)).to(self.device, torch.float32)
+        return self._proj[key]
+
+    def light_from_emitter(self, data: torch.Tensor) -> torch.Tensor:
+        """[He,We,3] texels -> SH25 by the fixed projection matrix (differentiable); [25,3] passes through."""
+        if data.shape[-2:] == (_sh.NSH, 3):
+            return data
+        if data.ndim < 3 or data.shape[-1] != 3:
+            raise ValueError(f"emitter.data must be [He,We,3] texels or [25,3] SH coefficients, got {tuple(data.shape)}")
+        He, We = data.shape[-3], data.shape[-2]
+        flat = data.reshape(data.shape[:-3] + (He * We, 3))
+        return self.projection(He, We) @ flat
+
+    # -- render --------------------------------------------------------------------------------------
+    def shading_normal(self) -> torch.Tensor:
+        # use_mesh_normal=True shades with the geometric normal, not the n map (F10; mi_plugin.py:1386-1389)
+        return self.geo_normal if self.use_mesh_normal else self.n
+
+    def render(self, spp: int) -> torch.Tensor:
+        shp = (self.B, self.H, self.W) if self.B > 1 else (self.H, self.W)
+        light = self.light
+        if self.B > 1 and light.ndim == 2:
+            light = light.unsqueeze(0).expand(self.B, -1, -1)
+        r = self.r.reshape(shp + (1,))
+        m = self.m.reshape(shp + (1,))
+        return _ShadeFn.apply(self.a, r, m, self.shading_normal(), light, int(spp), self.fov, self._ws)
+
+
+def traverse(scene: Scene) -> SceneParameters:
+    return SceneParameters(scene)
+
+
+def load_estimated_mesh(depth: Optional[torch.Tensor], use_mesh_normal: bool, max_path: int = 4, height: int = 512, width: int = 512,
+                        device="cuda", fov_x_deg: float = DEFAULT_FOV, batch: int = 1) -> Scene:
+    """Counterpart of load_estimated_mesh(mesh_path, use_mesh_normal, max_path) (inverse_img_w_mi.py:30-56).
+    The reference loads a .ply triangulated from depth; the per-pixel build needs only the geometric normal
+    of the heightfield, computed on the GPU from `depth` [H,W] (or [B,H,W]).  `max_path` is accepted for
+    signature compatibility: the deterministic render is direct lighting only."""
+    del max_path
+    geo = None
+    if depth is not None:
+        depth = depth.to(device, torch.float32)
+        height, width = depth.shape[-2], depth.shape[-1]
+        batch = depth.shape[0] if depth.ndim == 3 else 1
+        geo = ops.normals_from_depth(depth.contiguous(), fov_x_deg)
+    return Scene(height, width, device, geo, use_mesh_normal, fov_x_deg, batch)
+
+
+def render_envmap(scene: Scene, envmap: torch.Tensor, spp: int = 64) -> torch.Tensor:
+    """inverse_img_w_mi.py:59-67: set `emitter.data`, render with the materials already in the scene."""
+    params = traverse(scene)
+    params["emitter.data"] = envmap
+    params.update()
+    return scene.render(spp)
+
+
+def render_w_brdf(scene: Scene, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
+                  normal: Optional[torch.Tensor] = None, spp: int = 64) -> torch.Tensor:
+    """inverse_img_w_mi.py:69-80: set `shape.bsdf.a|r|m[|n]`, render with the light already in the scene."""
+    params = traverse(scene)
+    params["shape.bsdf.a"] = albedo
+    params["shape.bsdf.r"] = roughness
+    params["shape.bsdf.m"] = metallic
+    if normal is not None:
+        params["shape.bsdf.n"] = normal
+    params.update()
+    return scene.render(spp)

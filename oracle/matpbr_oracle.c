@@ -374,6 +374,15 @@ static void shade_pixel_bwd(const real wo[3], const real n[3], const real a[3], 
     }
 }
 
+/* The image-level render shades with the unit normal n/|n| of the stored map (the reference's geometric
+ * and MaterialNet normals are unit length already; dpt.py normalises its normal head). */
+static real unit_normal(const real n[3], real nh[3]) {
+    real l = sqrt(dot3(n, n));
+    if (!(l > R(0))) { nh[0] = R(0); nh[1] = R(0); nh[2] = R(1); return R(1); }
+    for (int c = 0; c < 3; ++c) nh[c] = n[c] / l;
+    return l;
+}
+
 /* Image-level entry points.  Layout = the reference's: row-major HWC float maps
  * a[H,W,3] r[H,W,1] m[H,W,1] n[H,W,3] (myutils/mi_plugin.py:1238-1241), light = SH coef [batch,25,3]. */
 void oracle_shade_fwd(const real* a, const real* r, const real* m, const real* n, const real* light, real* out,
@@ -383,9 +392,10 @@ void oracle_shade_fwd(const real* a, const real* r, const real* m, const real* n
     for (long idx = 0; idx < P * batch; ++idx) {
         long b = idx / P, p = idx % P;
         int i = (int)(p / W), j = (int)(p % W);
-        real wo[3];
+        real wo[3], nh[3];
         oracle_view_dir(i, j, H, W, fov_x_deg, wo);
-        shade_pixel(wo, n + idx * 3, a + idx * 3, r[idx], m[idx], light + b * MATPBR_NSH * 3, spp, out + idx * 3);
+        unit_normal(n + idx * 3, nh);
+        shade_pixel(wo, nh, a + idx * 3, r[idx], m[idx], light + b * MATPBR_NSH * 3, spp, out + idx * 3);
     }
 }
 void oracle_shade_bwd(const real* a, const real* r, const real* m, const real* n, const real* light,
@@ -403,10 +413,15 @@ void oracle_shade_bwd(const real* a, const real* r, const real* m, const real* n
             for (long p = 0; p < P; ++p) {
                 long idx = b * P + p;
                 int i = (int)(p / W), j = (int)(p % W);
-                real wo[3], ga[3], gr, gm, gn[3];
+                real wo[3], ga[3], gr, gm, gn[3], nh[3];
                 oracle_view_dir(i, j, H, W, fov_x_deg, wo);
-                shade_pixel_bwd(wo, n + idx * 3, a + idx * 3, r[idx], m[idx], light + b * MATPBR_NSH * 3, spp,
+                real nlen = unit_normal(n + idx * 3, nh);
+                shade_pixel_bwd(wo, nh, a + idx * 3, r[idx], m[idx], light + b * MATPBR_NSH * 3, spp,
                                 d_out + idx * 3, ga, &gr, &gm, gn, d_light ? acc : NULL);
+                {   /* through n_hat = n/|n|: d_n = (g - n_hat (n_hat.g)) / |n| */
+                    real pr = dot3(nh, gn);
+                    for (int c = 0; c < 3; ++c) gn[c] = (gn[c] - nh[c] * pr) / nlen;
+                }
                 if (d_a) for (int c = 0; c < 3; ++c) d_a[idx * 3 + c] = ga[c];
                 if (d_r) d_r[idx] = gr;
                 if (d_m) d_m[idx] = gm;
