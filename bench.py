@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: optimisation iterations/s of the PBR shading hot path at 512x512.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one optimisation iteration of hot loop B (inverse_img_w_mi.py:347-468, `--model_name none`):
+shade_fwd -> gamma-2.2 MSE/L1 loss with mean-ratio scaling -> shade_bwd -> Adam on the a/r/m maps, for every
+image of the rank's shard, inputs resident in HBM.  Images are independent, so ranks never communicate inside
+the timed region (weak scaling: `images_per_gpu` per rank).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_FWD = 44             # read a 12 + r 4 + m 4 + n 12, write rgb 12
+BYTES_BWD_ARM = 64         # read a,r,m,n 32 + d_rgb 12, write d_a 12 + d_r 4 + d_m 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel; the reference renders with spp=64 (inverse_img_w_mi.py:625)")
+    ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, spp, target_s):
+    """Time the fp32 OpenMP build of the CPU oracle (a port of the reference BRDF path, not Mitsuba) on a bounded
+    crop of the same synthetic workload: shade fwd + bwd (materials) of an n x n crop; it/s scaled by pixel count."""
+    import numpy as np
+
+    from materialist_amd import synthetic
+    from oracle.oracle import Oracle
+
+    o = Oracle(np.float32)
+    cores = len(os.sched_getaffinity(0))
+    sc = synthetic.make_scene(0, size, size)
+    n_full = Oracle(np.float64).normals_from_depth(sc.depth.astype(np.float64)).astype(np.float32)
+
+    def run(n):
+        sl = (slice(0, n), slice(0, n))
+        a, r, m, nn = sc.albedo[sl], sc.roughness[sl], sc.metallic[sl], n_full[sl]
+        t0 = time.perf_counter()
+        out = o.shade_fwd(a, r, m, nn, sc.light, spp)
+        o.shade_bwd(a, r, m, nn, sc.light, np.ones_like(out), spp, want_n=False, want_light=False)
+        return time.perf_counter() - t0
+
+    t_probe = run(32)
+    per_px = t_probe / (32 * 32)
+    n = int(min(size, max(32, (target_s / per_px) ** 0.5)))
+    n -= n % 8
+    t = run(n)
+    its = (n * n) / (size * size) / t
+    return {"value": its, "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"oracle f32+OpenMP shade fwd+bwd(arm) on a {n}x{n} crop of the {size}x{size} spp={spp} image, {t:.1f}s, scaled by pixels; "
+                      "CPU restatement of the reference BRDF path (not Mitsuba)"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from materialist_amd import loop, ops, render, synthetic
+    from materialist_amd.dist import shard_range
+
+    H = W = args.size
+    B = args.images_per_gpu
+    lo, hi = shard_range(world * B, world, rank)     # contiguous shard of independent images
+    scenes = [synthetic.make_scene(i, H, W) for i in range(lo, hi)]
+    t = lambda xs: torch.from_numpy(np.stack(xs) if B > 1 else xs[0]).to(dev)
+    depth = t([s.depth for s in scenes])
+    gt_a, gt_r, gt_m = t([s.albedo for s in scenes]), t([s.roughness for s in scenes]), t([s.metallic for s in scenes])
+    light = t([s.light for s in scenes])
+    scene = render.load_estimated_mesh(depth, use_mesh_normal=True)
+    scene._set("emitter.data", light)                # BRDF phase renders under the current best light (:317-334)
+    with torch.no_grad():
+        gt_image = render.render_w_brdf(scene, gt_a, gt_r, gt_m, None, args.spp)
+    phase = loop.BrdfPhase(scene, gt_image, t([s.init_albedo for s in scenes]), t([s.init_roughness for s in scenes]),
+                           t([s.init_metallic for s in scenes]), None, optimize_part="arm", spp=args.spp)
+    psnr0 = float(loop._loss.psnr(render.render_w_brdf(scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), gt_image).mean())
+
+    for _ in range(args.warmup):
+        phase.step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    with ops.KernelTimer() as kt:
+        for _ in range(args.steps):
+            phase.step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        ksum = kt.summary()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    total_units = args.steps * B * world
+    value = total_units / elapsed
+
+    m = phase.current_maps()
+    with torch.no_grad():
+        final = render.render_w_brdf(scene, m["albedo"].detach(), m["roughness"].detach(), m["metallic"].detach(), None, args.spp)
+    psnr1 = float(loop._loss.psnr(final, gt_image).mean())
+
+    if rank == 0:
+        px = H * W * B
+        ms_f = ksum.get("shade_fwd", (0, float("nan")))[1]
+        ms_b = ksum.get("shade_bwd", (0, float("nan")))[1]
+        ach_b = BYTES_BWD_ARM * px / (ms_b * 1e-3) / 1e9
+        ach_f = BYTES_FWD * px / (ms_f * 1e-3) / 1e9
+        ach_fb = (BYTES_FWD + BYTES_BWD_ARM) * px / ((ms_f + ms_b) * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"shade_bwd_{H}x{W}_b{B}_spp{args.spp}")
+            except Exception:
+                traffic = None
+        # VALU issue model: lane-instructions per pixel-sample counted from the ISA
+        out = {
+            "metric": "opt_iterations_per_sec_512x512", "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2-synthetic: {H}x{W} BRDF-phase optimisation iteration (shade_fwd + loss + shade_bwd + Adam on a/r/m maps), "
+                                   f"spp={args.spp}, --model_name none --opt_order arm, use_mesh_normal; PosMLP (SURVEY 8f2) not in the loop",
+                       "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25"},
+            "roofline": {"bound": "hbm", "kernel": "shade_bwd_kernel<mat>", "achieved": ach_b, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": ach_b / (HBM_PEAK / 1e9), "traffic": traffic,
+                         "bytes_per_pixel": BYTES_BWD_ARM, "avg_launch_ms": ms_b,
+                         "note": "VALU-bound at spp=64: ~600 lane-instructions per pixel-sample; see DESIGN.md section 4",
+                         "shade_fwd": {"achieved": ach_f, "frac": ach_f / (HBM_PEAK / 1e9), "avg_launch_ms": ms_f, "bytes_per_pixel": BYTES_FWD},
+                         "fwd+bwd": {"achieved": ach_fb, "frac": ach_fb / (HBM_PEAK / 1e9), "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM}},
+            "psnr_db": {"initial_guess": psnr0, "after_timed_steps": psnr1, "vs": "own HIP render of the synthetic ground truth (Mitsuba cannot run, SURVEY F3)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(H, args.spp, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 struct Pixel {
     PixelConst pc;
     float n[3], wo[3], s[3], t[3];
+    float vx, vy;   // view direction in the shading frame (its z component is pc.NoV_raw)
     float inv_len;  // 1/|n| of the stored normal
 };
 
@@ -95,12 +96,15 @@ __device__ __forceinline__ void load_pixel(Pixel& px, const float* __restrict__ 
     for (int c = 0; c < 3; ++c) px.n[c] = nv[c] * px.inv_len;
     view_dir(i, j, g.inv_f, g.cx, g.cy, px.wo);
     frame(px.n, px.s, px.t);
+    px.vx = dot3(px.s, px.wo);
+    px.vy = dot3(px.t, px.wo);
     pixel_const(px.pc, av, rv, mv, dot3(px.n, px.wo));
 }
 
 // One sample of the deterministic estimator: direction wi, the cosines and the GGX denominator.
 struct Sample {
-    float wi[3], h[3];
+    float wi[3];
+    float lwx, lwy, lhx, lhy;  // tangential (shading-frame x,y) components of wi and of the half vector h
     float NoL_raw, NoH, VoH, den;
     bool nh_pos;
 };
@@ -116,10 +120,13 @@ __device__ __forceinline__ void diffuse_sample(const Pixel& px, const float4 tab
     float nh = (tab.z + px.pc.NoV_raw) * il;
     sm.NoH = fmaxf(nh, 0.0f);
     sm.nh_pos = nh > 0.0f;
-    sm.den = ggx_den(px.pc, sm.NoH, -1.0f);
+    // 1 - NoH^2 = h_x^2 + h_y^2 in the shading frame: no cancellation when the sample lands on the GGX peak
+    float hx = tab.x + px.vx, hy = tab.y + px.vy;
+    float sin2 = sm.nh_pos ? fminf(fmaf(hx, hx, hy * hy) * il * il, 1.0f) : 1.0f;
+    sm.den = ggx_den(px.pc, sm.NoH, sin2);
     if (WANT_H) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) sm.h[c] = (sm.wi[c] + px.wo[c]) * il;
+        sm.lwx = tab.x; sm.lwy = tab.y;
+        sm.lhx = hx * il; sm.lhy = hy * il;
     }
 }
 
@@ -131,7 +138,8 @@ __device__ __forceinline__ void specular_sample(const Pixel& px, const float4 ta
     float sin2 = fmaxf(tab.x * px.pc.alpha2 * q, 0.0f);  // 1 - cos2 without cancellation
     float ct = fsqrt(cos2), st = fsqrt(sin2);
     float wh[3];
-    to_world(px.s, px.t, px.n, st * tab.y, st * tab.z, ct, wh);
+    const float whx = st * tab.y, why = st * tab.z;
+    to_world(px.s, px.t, px.n, whx, why, ct, wh);
     float d = dot3(px.wo, wh);
 #pragma unroll
     for (int c = 0; c < 3; ++c) sm.wi[c] = fmaf(2.0f * d, wh[c], -px.wo[c]);
@@ -143,8 +151,8 @@ __device__ __forceinline__ void specular_sample(const Pixel& px, const float4 ta
     sm.den = front ? ggx_den(px.pc, ct, sin2) : 1.0f + 1e-6f;
     if (WANT_H) {
         float sg = front ? 1.0f : -1.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) sm.h[c] = sg * wh[c];
+        sm.lhx = sg * whx; sm.lhy = sg * why;
+        sm.lwx = fmaf(2.0f * d, whx, -px.vx); sm.lwy = fmaf(2.0f * d, why, -px.vy);
     }
 }
 
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void shade_bwd_kernel(const float* __restri
 #pragma unroll
     for (int c = 0; c < 3; ++c) gr.d_a[c] = 0.0f;
     gr.d_r = gr.d_m = gr.dNoL = gr.dNoV = gr.dNoH = 0.0f;
-    float dn[3] = {0.0f, 0.0f, 0.0f};
+    float dnx = 0.0f, dny = 0.0f;  // gradient w.r.t. the unit normal, tangential components only (see below)
     float dc[WANT_LIGHT ? kNL : 1];
     if (WANT_LIGHT) {
 #pragma unroll
@@ -278,8 +286,8 @@ __global__ __launch_bounds__(kBlock) void shade_bwd_kernel(const float* __restri
                 float gl = sm.NoL_raw > 0.0f ? one.dNoL : 0.0f;
                 float gh = sm.nh_pos ? one.dNoH : 0.0f;
                 gr.dNoV += one.dNoV;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dn[c] = fmaf(gl, sm.wi[c], fmaf(gh, sm.h[c], dn[c]));
+                dnx = fmaf(gl, sm.lwx, fmaf(gh, sm.lhx, dnx));
+                dny = fmaf(gl, sm.lwy, fmaf(gh, sm.lhy, dny));
             }
         }
     }
@@ -292,13 +300,14 @@ __global__ __launch_bounds__(kBlock) void shade_bwd_kernel(const float* __restri
             d_m[idx] = gr.d_m;
         }
         if (WANT_N) {
+            // d/dn_hat = sum gl wi + gh h + gv wo.  Through n_hat = n/|n| only its tangential part survives:
+            // d_n = (g - n_hat (n_hat.g)) / |n|, so g is accumulated in the shading frame's (s,t) plane directly and the
+            // (huge, alternating-sign) radial parts of the GGX-peak terms never enter an fp32 sum.
             float gv = px.pc.NoV_raw > 0.0f ? gr.dNoV : 0.0f;
+            dnx = fmaf(gv, px.vx, dnx);
+            dny = fmaf(gv, px.vy, dny);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dn[c] = fmaf(gv, px.wo[c], dn[c]);
-            // through n_hat = n/|n|:  d_n = (g - n_hat (n_hat.g)) / |n|
-            float proj = dot3(px.n, dn);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) d_n[idx * 3 + c] = (dn[c] - px.n[c] * proj) * px.inv_len;
+            for (int c = 0; c < 3; ++c) d_n[idx * 3 + c] = fmaf(px.s[c], dnx, px.t[c] * dny) * px.inv_len;
         }
     }
 
@@ -418,6 +427,7 @@ __global__ __launch_bounds__(kBlock) void sample_brdf_kernel(const float* __rest
     frame(nv, s, t);
     float sp, cp;
     sincosf(2.0f * kPi * u1, &sp, &cp);
+    float sin2_h = -1.0f, cos_h = 0.0f;  // exact 1-NoH^2 of a GGX-sampled half vector (unit n assumed)
     if (sample1[k] > 0.5f) {  // diffuse lobe (mi_plugin.py:1328-1329)
         float st_ = fsqrt(fmaxf(u0, 0.0f)), ct = fsqrt(fmaxf(1.0f - u0, 0.0f));
         to_world(s, t, nv, st_ * cp, st_ * sp, ct, wiv);
@@ -433,9 +443,14 @@ __global__ __launch_bounds__(kBlock) void sample_brdf_kernel(const float* __rest
         float il = rsq(dot3(wiv, wiv));
 #pragma unroll
         for (int c = 0; c < 3; ++c) wiv[c] *= il;
+        if (d > 0.0f) { sin2_h = u0 * alpha2 * q; cos_h = ct; }
     }
     Lane ln;
     lane_setup(ln, wiv, wov, nv, av, rv, m[k]);
+    if (sin2_h >= 0.0f) {  // same value as the literal form, without the fp32 cancellation at the GGX peak
+        ln.NoH = cos_h;
+        ln.den = ggx_den(ln.pc, cos_h, sin2_h);
+    }
     BrdfState st;
     float fv[3], p;
     brdf_core(ln.pc, ln.NoL_raw, ln.NoH, ln.VoH, ln.den, st, fv, p);

@@ -1,0 +1,52 @@
+"""Sharding of independent images across ranks: contiguous shards, one process per
+GPU, no collective inside an optimisation iteration; one broadcast of the run configuration at start and one
+gather of per-image results at the end (RCCL when the backend is "nccl", gloo on CPU for tests)."""
+from __future__ import annotations
+
+from typing import Any, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of `n_items` for `rank`; the first n_items % world_size ranks get one extra item."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_config(cfg: Any, src: int = 0) -> Any:
+    """Rank `src`'s run configuration (any picklable object) to every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return cfg
+    box = [cfg if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def broadcast_tensor(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def gather_results(local: torch.Tensor, dst: int = 0) -> List[torch.Tensor]:
+    """Per-image result rows of every rank collected on `dst` (ranks may hold different numbers of rows).
+    Returns the list ordered by rank on `dst`, [] elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [local]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    cap = int(max(int(c.item()) for c in counts))
+    padded = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    bufs = [torch.zeros_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dst)
+    if rank != dst:
+        return []
+    return [b[: int(c.item())] for b, c in zip(bufs, counts)]

@@ -15,6 +15,48 @@ NSH = 25
 MAX_SPP = 128
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the shading launches, on the stream they are enqueued on.
+    `with KernelTimer() as t: ...` then `t.summary()` -> {"shade_fwd": (n, mean_ms), "shade_bwd": (n, mean_ms)}."""
+
+    active = None
+
+    def __init__(self):
+        self.events = {"shade_fwd": [], "shade_bwd": []}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for k, ev in self.events.items():
+            if ev:
+                ms = [a.elapsed_time(b) for a, b in ev]
+                out[k] = (len(ms), sum(ms) / len(ms))
+        return out
+
+
+class _timed:
+    def __init__(self, name):
+        self.name, self.t = name, KernelTimer.active
+
+    def __enter__(self):
+        if self.t is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            self.e1.record()
+            self.t.events[self.name].append((self.e0, self.e1))
+
+
 def _dev(t: torch.Tensor, name: str, shape_tail=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
@@ -62,7 +104,7 @@ def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0) -> torch.Ten
         raise ValueError("shade_fwd: inconsistent map / light shapes")
     out = torch.empty_like(a)
     cam = MatpbrCamera(float(fov_x_deg))
-    with torch.cuda.device(a.device):
+    with torch.cuda.device(a.device), _timed("shade_fwd"):
         code = lib.matpbr_shade_fwd(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(out), H, W, B,
                                     check_spp(spp), ctypes.byref(cam), 0, _stream(a))
     _lib.check(code, "matpbr_shade_fwd")
@@ -93,7 +135,7 @@ def shade_bwd(a, r, m, n, light, d_out, spp: int, fov_x_deg: float = 35.0, want_
         if workspace is None or workspace.numel() * workspace.element_size() < ws_bytes or workspace.device != a.device:
             workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
     cam = MatpbrCamera(float(fov_x_deg))
-    with torch.cuda.device(a.device):
+    with torch.cuda.device(a.device), _timed("shade_bwd"):
         code = lib.matpbr_shade_bwd(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(d_out), _ptr(d_a),
                                     _ptr(d_r), _ptr(d_m), _ptr(d_n), _ptr(d_l), _ptr(workspace), ws_bytes, H, W, B,
                                     check_spp(spp), ctypes.byref(cam), 0, _stream(a))
