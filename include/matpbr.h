@@ -65,7 +65,8 @@ int matpbr_shade_fwd(const float* a, const float* r, const float* m, const float
 /* Backward render.  Replaces the AD pass that `loss.backward()` drives through dr.wrap_ad / mi.render
  * (inverse_img_w_mi.py:59,69,248,420,544).  Any of d_a/d_r/d_m (all three or none), d_n, d_light may be
  * NULL to skip that gradient.  d_light[B,n_light,3] is overwritten (not accumulated); it needs
- * `workspace` of matpbr_shade_bwd_workspace_bytes() bytes (device memory, contents undefined). */
+ * `workspace` of matpbr_shade_bwd_workspace_bytes() bytes (device memory owned by the caller, contents
+ * undefined on entry and exit: per-workgroup partial sums of the light gradient). */
 int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float* n, const float* light,
                      int light_kind, int n_light, const float* d_out_rgb, float* d_a, float* d_r, float* d_m,
                      float* d_n, float* d_light, void* workspace, size_t workspace_bytes, int H, int W, int batch,

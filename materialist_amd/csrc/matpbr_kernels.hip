@@ -10,6 +10,7 @@
 //     [75]-float partial per workgroup and summed by a second tiny kernel: no atomics, bit-reproducible.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -25,10 +26,12 @@ constexpr int kBlock = 256;
 constexpr int kNL = kNSH * 3;  // 75 light scalars per image
 
 // Deterministic BSDF-sample set: n = spp/2 points per lobe,
-// u0_i = (i+.5)/n, u1_i = vdC2(i) + .5/m.  Values are computed on the host in double.
+// u0_i = (i+.5)/n, u1_i = vdC2(i) + .5/m.  Values are computed on the host in double.  The table travels in the
+// kernel-argument segment: wave-uniform scalar loads into SGPRs, which VALU instructions broadcast for free.
+constexpr int kMaxHalf = MATPBR_MAX_SPP / 2;
 struct SampleTable {
-    float4 diff[MATPBR_MAX_SPP / 2];  // local direction (x,y,z) of the cosine-weighted sample, (1-z)^5
-    float4 spec[MATPBR_MAX_SPP / 2];  // u0, cos(phi), sin(phi), 1-u0 of the GGX half-vector sample
+    float4 diff[kMaxHalf];  // cosine-weighted sample: local direction (x, y, z), unused
+    float4 spec[kMaxHalf];  // GGX half-vector sample: u0, cos(phi), sin(phi), 1-u0
 };
 
 double vdc2(uint32_t i) {
@@ -49,17 +52,17 @@ void fill_sample_table(int spp, SampleTable& t) {
         double u0 = (i + 0.5) / n, u1 = vdc2((uint32_t)i) + 0.5 / m;
         double phi = 2.0 * M_PI * u1;
         double st = std::sqrt(u0), ct = std::sqrt(1.0 - u0);  // theta = asin(sqrt(u0))  (mi_plugin.py:265)
-        t.diff[i] = make_float4((float)(st * std::cos(phi)), (float)(st * std::sin(phi)), (float)ct, (float)std::pow(1.0 - ct, 5.0));
+        t.diff[i] = make_float4((float)(st * std::cos(phi)), (float)(st * std::sin(phi)), (float)ct, 0.0f);
         t.spec[i] = make_float4((float)u0, (float)std::cos(phi), (float)std::sin(phi), (float)(1.0 - u0));
     }
 }
 
 struct Geom {
-    int H, W, half;
+    int H, W, half;  // half = spp/2 samples per lobe
     float inv_f, cx, cy, inv_spp;
 };
 
-// ---- wave64 sum with DPP: row_shr 1,2,3 / row_shr 4 / row_shr 8 -> row totals in lane 15 of each row of 16,
+// ---- wave64 sum with DPP: row_shr 1,2,4,8 -> row totals in lane 15 of each row of 16,
 // row_bcast:15 and row_bcast:31 fold the four rows; the total lands in lane 63.
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -76,238 +79,337 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-// Per-pixel set-up shared by forward and backward.
+// Per-lane set-up shared by forward and backward: TWO pixels (flattened indices 2q, 2q+1) in the halves of every f2.
 struct Pixel {
-    PixelConst pc;
-    float n[3], wo[3], s[3], t[3];
-    float vx, vy;   // view direction in the shading frame (its z component is pc.NoV_raw)
-    float inv_len;  // 1/|n| of the stored normal
+    PixelConst<f2> pc;
+    f2 n[3], wo[3], s[3], t[3];
+    f2 vx, vy;   // view direction in the shading frame (its z component is pc.NoV_raw)
+    f2 inv_len;  // 1/|n| of the stored normal
 };
 
 __device__ __forceinline__ void load_pixel(Pixel& px, const float* __restrict__ a, const float* __restrict__ r,
-                                           const float* __restrict__ m, const float* __restrict__ n, long idx, int i, int j,
+                                           const float* __restrict__ m, const float* __restrict__ n, long i0, long i1, int p0, int p1,
                                            const Geom& g) {
-    float av[3] = {a[idx * 3], a[idx * 3 + 1], a[idx * 3 + 2]};
-    float nv[3] = {n[idx * 3], n[idx * 3 + 1], n[idx * 3 + 2]};
-    float rv = r[idx], mv = m[idx];
+    f2 av[3], nv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        av[c] = f2{a[i0 * 3 + c], a[i1 * 3 + c]};
+        nv[c] = f2{n[i0 * 3 + c], n[i1 * 3 + c]};
+    }
+    f2 rv = f2{r[i0], r[i1]}, mv = f2{m[i0], m[i1]};
     // shading normal = normalize(n map); the geometric normals and MaterialNet's are unit already
-    px.inv_len = rsq(fmaxf(dot3(nv, nv), 1e-30f));
+    px.inv_len = rsq(vmax(dot3v(nv, nv), 1e-30f));
 #pragma unroll
     for (int c = 0; c < 3; ++c) px.n[c] = nv[c] * px.inv_len;
-    view_dir(i, j, g.inv_f, g.cx, g.cy, px.wo);
+    // view direction of pixel (i,j): wo = -p/|p|, p = ((j-cx)/f, -(i-cy)/f, -1)   
+    f2 fi = f2{(float)(p0 / g.W), (float)(p1 / g.W)}, fj = f2{(float)(p0 % g.W), (float)(p1 % g.W)};
+    f2 x = (g.cx - fj) * g.inv_f, y = (fi - g.cy) * g.inv_f;
+    f2 il = rsq(vfma(x, x, vfma(y, y, 1.0f)));
+    px.wo[0] = x * il; px.wo[1] = y * il; px.wo[2] = il;
     frame(px.n, px.s, px.t);
-    px.vx = dot3(px.s, px.wo);
-    px.vy = dot3(px.t, px.wo);
-    pixel_const(px.pc, av, rv, mv, dot3(px.n, px.wo));
+    px.vx = dot3v(px.s, px.wo);
+    px.vy = dot3v(px.t, px.wo);
+    pixel_const(px.pc, av, rv, mv, dot3v(px.n, px.wo));
 }
 
-// One sample of the deterministic estimator: direction wi, the cosines and the GGX denominator.
+// One sample of the deterministic estimator for both pixels of the lane: direction wi, cosines, GGX denominator
+// and, for the normal gradient, the tangential (shading-frame x,y) components of wi and of the half vector h.
 struct Sample {
-    float wi[3];
-    float lwx, lwy, lhx, lhy;  // tangential (shading-frame x,y) components of wi and of the half vector h
-    float NoL_raw, NoH, VoH, den;
-    bool nh_pos;
+    f2 wi[3];
+    f2 lwx, lwy, lhx, lhy;
+    f2 NoL_raw, NoH, VoH, den;
+    f2 nh_gate;  // > 0 where n.h > 0
 };
 
 template <bool WANT_H>
-__device__ __forceinline__ void diffuse_sample(const Pixel& px, const float4 tab, Sample& sm) {
+__device__ __forceinline__ void diffuse_sample(const Pixel& px, float lx, float ly, float lz, Sample& sm) {
     // mi_diffuse_sampler (mi_plugin.py:255-281): local (sin t cos p, sin t sin p, cos t) -> Frame3f(n).to_world
-    to_world(px.s, px.t, px.n, tab.x, tab.y, tab.z, sm.wi);
-    sm.NoL_raw = tab.z;  // n.wi for an orthonormal frame
-    float wiwo = dot3(sm.wi, px.wo);
-    float il = rsq(fmaxf(fmaf(2.0f, wiwo, 2.0f), 1e-30f));  // 1/|wi+wo|
-    sm.VoH = fmaxf((1.0f + wiwo) * il, 0.0f);
-    float nh = (tab.z + px.pc.NoV_raw) * il;
-    sm.NoH = fmaxf(nh, 0.0f);
-    sm.nh_pos = nh > 0.0f;
+    to_world(px.s, px.t, px.n, lx, ly, lz, sm.wi);
+    sm.NoL_raw = f2{lz, lz};  // n.wi for an orthonormal frame
+    f2 wiwo = vfma(px.pc.NoV_raw, lz, vfma(px.vy, ly, px.vx * lx));
+    f2 il = rsq(vmax(vfma(wiwo, 2.0f, 2.0f), 1e-30f));  // 1/|wi+wo|
+    sm.VoH = vmax((1.0f + wiwo) * il, 0.0f);
+    f2 nh = (px.pc.NoV_raw + lz) * il;
+    sm.NoH = vmax(nh, 0.0f);
+    sm.nh_gate = nh;
     // 1 - NoH^2 = h_x^2 + h_y^2 in the shading frame: no cancellation when the sample lands on the GGX peak
-    float hx = tab.x + px.vx, hy = tab.y + px.vy;
-    float sin2 = sm.nh_pos ? fminf(fmaf(hx, hx, hy * hy) * il * il, 1.0f) : 1.0f;
-    sm.den = ggx_den(px.pc, sm.NoH, sin2);
+    f2 hx = (px.vx + lx) * il, hy = (px.vy + ly) * il;
+    f2 sin2 = sel_pos(nh, vmin(vfma(hx, hx, hy * hy), 1.0f), 1.0f);
+    sm.den = ggx_den_stable(px.pc, sin2);
     if (WANT_H) {
-        sm.lwx = tab.x; sm.lwy = tab.y;
-        sm.lhx = hx * il; sm.lhy = hy * il;
+        sm.lwx = f2{lx, lx}; sm.lwy = f2{ly, ly};
+        sm.lhx = hx; sm.lhy = hy;
     }
 }
 
 template <bool WANT_H>
-__device__ __forceinline__ void specular_sample(const Pixel& px, const float4 tab, Sample& sm) {
+__device__ __forceinline__ void specular_sample(const Pixel& px, float u0, float cphi, float sphi, float omu0, Sample& sm) {
     // mi_specular_sampler (mi_plugin.py:217-253): cos^2 t_h = (1-u0)/(u0(alpha2-1)+1), wi = reflect(wo, wh)
-    float q = rcp(fmaf(tab.x, px.pc.am1, 1.0f));
-    float cos2 = fmaxf(tab.w * q, 0.0f);
-    float sin2 = fmaxf(tab.x * px.pc.alpha2 * q, 0.0f);  // 1 - cos2 without cancellation
-    float ct = fsqrt(cos2), st = fsqrt(sin2);
-    float wh[3];
-    const float whx = st * tab.y, why = st * tab.z;
-    to_world(px.s, px.t, px.n, whx, why, ct, wh);
-    float d = dot3(px.wo, wh);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) sm.wi[c] = fmaf(2.0f * d, wh[c], -px.wo[c]);
-    sm.NoL_raw = fmaf(2.0f * d, ct, -px.pc.NoV_raw);  // n.wi
-    sm.VoH = fabsf(d);                                 // wo.h with h = sign(d) wh
-    bool front = d > 0.0f;
-    sm.NoH = front ? ct : 0.0f;
-    sm.nh_pos = front && ct > 0.0f;
-    sm.den = front ? ggx_den(px.pc, ct, sin2) : 1.0f + 1e-6f;
+    f2 q = rcp(vfma(px.pc.am1, u0, 1.0f));
+    f2 cos2 = vmax(q * omu0, 0.0f);
+    f2 sin2 = vmax((px.pc.alpha2 * u0) * q, 0.0f);  // 1 - cos2 without cancellation
+    f2 ct = fsqrt(cos2), st = fsqrt(sin2);
+    const f2 whx = st * cphi, why = st * sphi;
+    f2 d = vfma(ct, px.pc.NoV_raw, vfma(why, px.vy, whx * px.vx));  // wo.wh in the shading frame
+    f2 d2 = 2.0f * d;
+    f2 wlx = vfma(d2, whx, -px.vx), wly = vfma(d2, why, -px.vy), wlz = vfma(d2, ct, -px.pc.NoV_raw);  // wi = 2(wo.wh)wh - wo
+    to_world(px.s, px.t, px.n, wlx, wly, wlz, sm.wi);
+    sm.NoL_raw = wlz;       // n.wi
+    sm.VoH = vabs(d);       // wo.h with h = sign(d) wh
+    sm.NoH = sel_pos(d, ct, 0.0f);
+    sm.nh_gate = sel_pos(d, ct, -1.0f);
+    sm.den = sel_pos(d, ggx_den_stable(px.pc, sin2), 1.0f + 1e-6f);
     if (WANT_H) {
-        float sg = front ? 1.0f : -1.0f;
+        f2 sg = sel_pos(d, 1.0f, -1.0f);
         sm.lhx = sg * whx; sm.lhy = sg * why;
-        sm.lwx = fmaf(2.0f * d, whx, -px.vx); sm.lwy = fmaf(2.0f * d, why, -px.vy);
+        sm.lwx = wlx; sm.lwy = wly;
     }
 }
 
-__device__ __forceinline__ void stage_light(float* s_c, const float* __restrict__ light, int b) {
-    if (threadIdx.x < kNL) s_c[threadIdx.x] = light[(long)b * kNL + threadIdx.x] * kShNorm[threadIdx.x / 3];
-    __syncthreads();
+// ---- SH coefficients: 75 wave-uniform scalars kept in 38 VGPR pairs ------------------------------------------
+// A packed FMA needs the scalar c'[k][c] in both halves of a 64-bit operand.  hipcc materialises such a splat with
+// a v_mov per use (VGPR) or spills the SGPR file (75 live scalars + sample table > 102 SGPRs), so the broadcast
+// is spelled out: VOP3P op_sel/op_sel_hi pick the low or the high half of a register pair for BOTH lanes of the
+// packed operation, letting one pair carry two different coefficients at zero extra instructions.
+constexpr int kNPairs = (kNL + 1) / 2;
+struct LightRegs { f2 c[kNPairs]; };
+
+// c'[k][c] = coefficient * basis normalisation, so that the per-sample radiance is 72 FMAs on raw polynomials
+__device__ __forceinline__ void load_light_regs(LightRegs& lr, const float* __restrict__ light) {
+#pragma unroll
+    for (int j = 0; j < kNPairs; ++j) {
+        const int q0 = 2 * j, q1 = 2 * j + 1 < kNL ? 2 * j + 1 : 2 * j;
+        lr.c[j] = f2{light[q0] * kShNorm[q0 / 3], light[q1] * kShNorm[q1 / 3]};
+        asm volatile("" : "+v"(lr.c[j]));  // pin in VGPRs for the whole kernel
+    }
 }
+template <int Q>
+__device__ __forceinline__ f2 bcast(const LightRegs& lr) {  // {c'_Q, c'_Q}
+    f2 out;
+    if (Q & 1) asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[1,0]" : "=v"(out) : "v"(lr.c[Q >> 1]));
+    else asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[0,0] op_sel_hi:[0,0]" : "=v"(out) : "v"(lr.c[Q >> 1]));
+    return out;
+}
+template <int Q>
+__device__ __forceinline__ void fma_bcast(f2& acc, f2 b, const LightRegs& lr) {  // acc += b * c'_Q (both halves)
+    if (Q & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(b), "v"(lr.c[Q >> 1]));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(b), "v"(lr.c[Q >> 1]));
+}
+template <int K>
+__device__ __forceinline__ void sh_term(const LightRegs& lr, f2 Bk, f2 L[3]) {
+    if (K == 0) {
+        L[0] = bcast<0>(lr); L[1] = bcast<1>(lr); L[2] = bcast<2>(lr);
+    } else {
+        fma_bcast<3 * K>(L[0], Bk, lr); fma_bcast<3 * K + 1>(L[1], Bk, lr); fma_bcast<3 * K + 2>(L[2], Bk, lr);
+    }
+}
+
+// Order-4 SH basis polynomials of wi (both pixels), each consumed the moment it is produced by `use.template operator()<k>(B_k)`:
+// only the ~14 shared monomials stay live, never 25 packed basis values.
+template <class F>
+__device__ __forceinline__ void sh_stream(const f2 w[3], F&& use) {
+    const f2 X = -w[2], Y = w[0], Z = w[1];
+    use.template operator()<0>(f2{1.0f, 1.0f});
+    use.template operator()<1>(Y); use.template operator()<2>(Z); use.template operator()<3>(X);
+    const f2 z2 = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z, y2 = Y * Y;
+    const f2 d = vfma(X, X, -y2);
+    use.template operator()<4>(xy); use.template operator()<5>(yz); use.template operator()<6>(vfma(z2, 3.0f, -1.0f));
+    use.template operator()<7>(xz); use.template operator()<8>(d);
+    const f2 t5 = vfma(z2, 5.0f, -1.0f);
+    const f2 s3 = Y * vfma(3.0f * X, X, -y2), c3 = X * vfma(X, X, -3.0f * y2);
+    use.template operator()<9>(s3); use.template operator()<10>(xy * Z); use.template operator()<11>(Y * t5);
+    use.template operator()<12>(Z * (t5 - 2.0f)); use.template operator()<13>(X * t5); use.template operator()<14>(d * Z);
+    use.template operator()<15>(c3);
+    const f2 t7 = vfma(z2, 7.0f, -1.0f), t73 = t7 - 2.0f;
+    use.template operator()<16>(xy * d); use.template operator()<17>(s3 * Z); use.template operator()<18>(xy * t7);
+    use.template operator()<19>(yz * t73); use.template operator()<20>(vfma(vfma(z2, 35.0f, -30.0f), z2, 3.0f));
+    use.template operator()<21>(xz * t73); use.template operator()<22>(d * t7); use.template operator()<23>(c3 * Z);
+    use.template operator()<24>(vfma(d, d, -4.0f * (xy * xy)));
+}
+
+// radiance of the SH light for the lane's two pixels: L[c] = sum_k c'[k][c] B_k(wi)
+struct RadianceUse {
+    const LightRegs& lr;
+    f2* L;
+    template <int K> __device__ __forceinline__ void operator()(f2 Bk) { sh_term<K>(lr, Bk, L); }
+};
+__device__ __forceinline__ void sh_radiance(const LightRegs& lr, const f2 wi[3], f2 L[3]) { sh_stream(wi, RadianceUse{lr, L}); }
 
 // =================================================================================================
 // forward
 // =================================================================================================
-__global__ __launch_bounds__(kBlock) void shade_fwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
-                                                           const float* __restrict__ m, const float* __restrict__ n,
-                                                           const float* __restrict__ light, float* __restrict__ out,
-                                                           const Geom g, const SampleTable tab) {
-    __shared__ float s_c[kNL + 1];
-    const int b = blockIdx.y;
-    stage_light(s_c, light, b);
-    const int P = g.H * g.W;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= P) return;
-    const long idx = (long)b * P + p;
-    Pixel px;
-    load_pixel(px, a, r, m, n, idx, p / g.W, p % g.W, g);
+__device__ __forceinline__ void fwd_accumulate(const Pixel& px, const Sample& sm, const LightRegs& lr, f2 acc[3]) {
+    BrdfState<f2> st;
+    f2 f[3], pdf;
+    brdf_core(px.pc, sm.NoL_raw, sm.NoH, sm.VoH, sm.den, st, f, pdf);
+    // sample_brdf weight (mi_plugin.py:1335-1339): f/(pdf+1e-6) where pdf > 1e-6
+    f2 ip = sel_pos(pdf - 1e-6f, rcp(pdf + 1e-6f), 0.0f);
+    f2 L[3];
+    sh_radiance(lr, sm.wi, L);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = vfma(f[c] * ip, L[c], acc[c]);
+}
 
-    float acc[3] = {0.0f, 0.0f, 0.0f};
-    const int spp = 2 * g.half;
-#pragma unroll 2
-    for (int s = 0; s < spp; ++s) {
+__global__ __launch_bounds__(kBlock, 2) void shade_fwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                              const float* __restrict__ m, const float* __restrict__ n,
+                                                              const float* __restrict__ light, float* __restrict__ out,
+                                                              const Geom g, const SampleTable tab) {
+    const int b = blockIdx.y;
+    const float* __restrict__ cp = light + (long)b * kNL;
+    const int P = g.H * g.W;
+    const int p0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
+    if (p0 >= P) return;
+    const bool two = p0 + 1 < P;
+    const int p1 = two ? p0 + 1 : p0;
+    const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
+    Pixel px;
+    load_pixel(px, a, r, m, n, i0, i1, p0, p1, g);
+    LightRegs lr;
+    load_light_regs(lr, cp);
+
+    f2 acc[3] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
+    for (int s = 0; s < g.half; ++s) {
         Sample sm;
-        if (s < g.half) diffuse_sample<false>(px, tab.diff[s], sm);
-        else specular_sample<false>(px, tab.spec[s - g.half], sm);
-        BrdfState st;
-        float f[3], pdf;
-        brdf_core(px.pc, sm.NoL_raw, sm.NoH, sm.VoH, sm.den, st, f, pdf);
-        // sample_brdf weight (mi_plugin.py:1335-1339): f/(pdf+1e-6) where pdf > 1e-6
-        float ip = pdf > 1e-6f ? rcp(pdf + 1e-6f) : 0.0f;
-        float B[kNSH];
-        sh_poly(sm.wi, B);
-        float L[3] = {s_c[0], s_c[1], s_c[2]};
-#pragma unroll
-        for (int k = 1; k < kNSH; ++k) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) L[c] = fmaf(s_c[k * 3 + c], B[k], L[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c] = fmaf(f[c] * ip, L[c], acc[c]);
+        const float4 t = tab.diff[s];
+        diffuse_sample<false>(px, t.x, t.y, t.z, sm);
+        fwd_accumulate(px, sm, lr, acc);
+    }
+    for (int s = 0; s < g.half; ++s) {
+        Sample sm;
+        const float4 t = tab.spec[s];
+        specular_sample<false>(px, t.x, t.y, t.z, t.w, sm);
+        fwd_accumulate(px, sm, lr, acc);
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[idx * 3 + c] = acc[c] * g.inv_spp;
+    for (int c = 0; c < 3; ++c) {
+        f2 v = acc[c] * g.inv_spp;
+        out[i0 * 3 + c] = v.x;
+        if (two) out[i1 * 3 + c] = v.y;
+    }
 }
 
 // =================================================================================================
 // backward (sample directions and pdf are constants: stop-gradient, as in the reference's torch
 // variants -- `D.data`, `alpha.data`, mi_plugin.py:179,366)
 // =================================================================================================
+template <bool WANT_LIGHT>
+struct BwdAcc {
+    BrdfGrad<f2> gr;
+    f2 dnx, dny;  // gradient w.r.t. the unit normal, tangential components only
+    float dc[WANT_LIGHT ? kNL : 1];
+};
+
+struct LightGradUse {   // dc[k][c] += gw[c] . B_k over the lane's two pixels, radiance alongside when materials need it
+    const LightRegs& lr;
+    const f2* gw;
+    float* dc;
+    f2* L;
+    template <int K> __device__ __forceinline__ void operator()(f2 Bk) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dc[K * 3 + c] = fmaf(gw[c].y, Bk.y, fmaf(gw[c].x, Bk.x, dc[K * 3 + c]));
+        if (L) sh_term<K>(lr, Bk, L);
+    }
+};
+
 template <bool WANT_MAT, bool WANT_N, bool WANT_LIGHT>
-__global__ __launch_bounds__(kBlock) void shade_bwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
-                                                           const float* __restrict__ m, const float* __restrict__ n,
-                                                           const float* __restrict__ light, const float* __restrict__ d_out,
-                                                           float* __restrict__ d_a, float* __restrict__ d_r,
-                                                           float* __restrict__ d_m, float* __restrict__ d_n,
-                                                           float* __restrict__ partials, const Geom g, const SampleTable tab) {
-    __shared__ float s_c[kNL + 1];
+__device__ __forceinline__ void bwd_accumulate(const Pixel& px, const Sample& sm, const LightRegs& lr, const f2 go[3],
+                                               BwdAcc<WANT_LIGHT>& A) {
+    BrdfState<f2> st;
+    f2 f[3], pdf;
+    brdf_core(px.pc, sm.NoL_raw, sm.NoH, sm.VoH, sm.den, st, f, pdf);
+    f2 ip = sel_pos(pdf - 1e-6f, rcp(pdf + 1e-6f), 0.0f);
+    f2 L[3];
+    if (WANT_LIGHT) {
+        f2 gw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gw[c] = (go[c] * f[c]) * ip;
+        sh_stream(sm.wi, LightGradUse{lr, gw, A.dc, (WANT_MAT || WANT_N) ? L : nullptr});
+    } else {
+        sh_radiance(lr, sm.wi, L);
+    }
+    if (WANT_MAT || WANT_N) {
+        f2 gg[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gg[c] = (go[c] * L[c]) * ip;
+        f2 gl, gh;
+        brdf_core_grad<f2, WANT_N>(px.pc, st, gg, A.gr, gl, gh);
+        if (WANT_N) {
+            // dr.maximum(x, 0) passes the gradient where x > 0 (mi_plugin.py:1393-1396)
+            gl = sel_pos(sm.NoL_raw, gl, 0.0f);
+            gh = sel_pos(sm.nh_gate, gh, 0.0f);
+            A.dnx = vfma(gl, sm.lwx, vfma(gh, sm.lhx, A.dnx));
+            A.dny = vfma(gl, sm.lwy, vfma(gh, sm.lhy, A.dny));
+        }
+    }
+}
+
+template <bool WANT_MAT, bool WANT_N, bool WANT_LIGHT>
+__global__ __launch_bounds__(kBlock, 2) void shade_bwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                              const float* __restrict__ m, const float* __restrict__ n,
+                                                              const float* __restrict__ light, const float* __restrict__ d_out,
+                                                              float* __restrict__ d_a, float* __restrict__ d_r,
+                                                              float* __restrict__ d_m, float* __restrict__ d_n,
+                                                              float* __restrict__ partials, const Geom g, const SampleTable tab) {
     __shared__ float s_red[4][kNL + 1];
     const int b = blockIdx.y;
-    stage_light(s_c, light, b);
+    const float* __restrict__ cp = light + (long)b * kNL;
     const int P = g.H * g.W;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = p < P;
-    const long idx = (long)b * P + (active ? p : P - 1);
+    const int q0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
+    const bool act0 = q0 < P, two = q0 + 1 < P;
+    const int p0 = act0 ? q0 : P - 1, p1 = two ? q0 + 1 : p0;
+    const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
     Pixel px;
-    load_pixel(px, a, r, m, n, idx, (active ? p : P - 1) / g.W, (active ? p : P - 1) % g.W, g);
-    float go[3];
+    load_pixel(px, a, r, m, n, i0, i1, p0, p1, g);
+    LightRegs lr;
+    if (WANT_MAT || WANT_N) load_light_regs(lr, cp);
+    f2 go[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) go[c] = active ? d_out[idx * 3 + c] * g.inv_spp : 0.0f;
+    for (int c = 0; c < 3; ++c) go[c] = f2{act0 ? d_out[i0 * 3 + c] * g.inv_spp : 0.0f, two ? d_out[i1 * 3 + c] * g.inv_spp : 0.0f};
 
-    BrdfGrad gr;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) gr.d_a[c] = 0.0f;
-    gr.d_r = gr.d_m = gr.dNoL = gr.dNoV = gr.dNoH = 0.0f;
-    float dnx = 0.0f, dny = 0.0f;  // gradient w.r.t. the unit normal, tangential components only (see below)
-    float dc[WANT_LIGHT ? kNL : 1];
+    BwdAcc<WANT_LIGHT> A;
+    brdf_grad_zero(A.gr);
+    A.dnx = A.dny = f2{0.0f, 0.0f};
     if (WANT_LIGHT) {
 #pragma unroll
-        for (int k = 0; k < kNL; ++k) dc[k] = 0.0f;
+        for (int k = 0; k < kNL; ++k) A.dc[k] = 0.0f;
     }
 
-    const int spp = 2 * g.half;
-    for (int s = 0; s < spp; ++s) {
+    for (int s = 0; s < g.half; ++s) {
         Sample sm;
-        if (s < g.half) diffuse_sample<WANT_N>(px, tab.diff[s], sm);
-        else specular_sample<WANT_N>(px, tab.spec[s - g.half], sm);
-        BrdfState st;
-        float f[3], pdf;
-        brdf_core(px.pc, sm.NoL_raw, sm.NoH, sm.VoH, sm.den, st, f, pdf);
-        float ip = pdf > 1e-6f ? rcp(pdf + 1e-6f) : 0.0f;
-        float B[kNSH];
-        sh_poly(sm.wi, B);
-        if (WANT_LIGHT) {
-            float gw[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gw[c] = go[c] * f[c] * ip;
-#pragma unroll
-            for (int k = 0; k < kNSH; ++k) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dc[k * 3 + c] = fmaf(gw[c], B[k], dc[k * 3 + c]);
-            }
-        }
-        if (WANT_MAT || WANT_N) {
-            float L[3] = {s_c[0], s_c[1], s_c[2]};
-#pragma unroll
-            for (int k = 1; k < kNSH; ++k) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) L[c] = fmaf(s_c[k * 3 + c], B[k], L[c]);
-            }
-            float gg[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gg[c] = go[c] * L[c] * ip;
-            BrdfGrad one;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) one.d_a[c] = 0.0f;
-            one.d_r = one.d_m = one.dNoL = one.dNoV = one.dNoH = 0.0f;
-            brdf_core_grad<WANT_N>(px.pc, st, gg, one);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gr.d_a[c] += one.d_a[c];
-            gr.d_r += one.d_r;
-            gr.d_m += one.d_m;
-            if (WANT_N) {
-                // dr.maximum(x, 0) passes the gradient where x > 0 (mi_plugin.py:1393-1396)
-                float gl = sm.NoL_raw > 0.0f ? one.dNoL : 0.0f;
-                float gh = sm.nh_pos ? one.dNoH : 0.0f;
-                gr.dNoV += one.dNoV;
-                dnx = fmaf(gl, sm.lwx, fmaf(gh, sm.lhx, dnx));
-                dny = fmaf(gl, sm.lwy, fmaf(gh, sm.lhy, dny));
-            }
-        }
+        const float4 t = tab.diff[s];
+        diffuse_sample<WANT_N>(px, t.x, t.y, t.z, sm);
+        bwd_accumulate<WANT_MAT, WANT_N, WANT_LIGHT>(px, sm, lr, go, A);
+    }
+    for (int s = 0; s < g.half; ++s) {
+        Sample sm;
+        const float4 t = tab.spec[s];
+        specular_sample<WANT_N>(px, t.x, t.y, t.z, t.w, sm);
+        bwd_accumulate<WANT_MAT, WANT_N, WANT_LIGHT>(px, sm, lr, go, A);
     }
 
-    if (active) {
+    if (act0) {
         if (WANT_MAT) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) d_a[idx * 3 + c] = gr.d_a[c];
-            d_r[idx] = gr.d_r;
-            d_m[idx] = gr.d_m;
+            for (int c = 0; c < 3; ++c) {
+                d_a[i0 * 3 + c] = A.gr.d_a[c].x;
+                if (two) d_a[i1 * 3 + c] = A.gr.d_a[c].y;
+            }
+            d_r[i0] = A.gr.d_r.x;
+            d_m[i0] = A.gr.d_m.x;
+            if (two) { d_r[i1] = A.gr.d_r.y; d_m[i1] = A.gr.d_m.y; }
         }
         if (WANT_N) {
             // d/dn_hat = sum gl wi + gh h + gv wo.  Through n_hat = n/|n| only its tangential part survives:
             // d_n = (g - n_hat (n_hat.g)) / |n|, so g is accumulated in the shading frame's (s,t) plane directly and the
             // (huge, alternating-sign) radial parts of the GGX-peak terms never enter an fp32 sum.
-            float gv = px.pc.NoV_raw > 0.0f ? gr.dNoV : 0.0f;
-            dnx = fmaf(gv, px.vx, dnx);
-            dny = fmaf(gv, px.vy, dny);
+            f2 gv = sel_pos(px.pc.NoV_raw, A.gr.dNoV, 0.0f);
+            f2 dnx = vfma(gv, px.vx, A.dnx), dny = vfma(gv, px.vy, A.dny);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) d_n[idx * 3 + c] = fmaf(px.s[c], dnx, px.t[c] * dny) * px.inv_len;
+            for (int c = 0; c < 3; ++c) {
+                f2 v = vfma(px.s[c], dnx, px.t[c] * dny) * px.inv_len;
+                d_n[i0 * 3 + c] = v.x;
+                if (two) d_n[i1 * 3 + c] = v.y;
+            }
         }
     }
 
@@ -315,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void shade_bwd_kernel(const float* __restri
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int k = 0; k < kNL; ++k) {
-            float v = wave_sum_to_lane63(dc[k]);
+            float v = wave_sum_to_lane63(A.dc[k]);
             if (lane == 63) s_red[wave][k] = v;
         }
         __syncthreads();
@@ -346,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void light_grad_finalize_kernel(const float
 // plugin face: N independent lanes (literal restatement: raw n, h = normalize(wi+wo), all dots)
 // =================================================================================================
 struct Lane {
-    PixelConst pc;
+    PixelConst<float> pc;
     float NoL_raw, NoH, VoH, den, nh_raw;
     float h[3];
 };
@@ -356,12 +458,12 @@ __device__ __forceinline__ void lane_setup(Lane& ln, const float wi[3], const fl
     float il = rsq(dot3(h, h));
 #pragma unroll
     for (int c = 0; c < 3; ++c) ln.h[c] = h[c] * il;
-    pixel_const(ln.pc, a, r, m, dot3(n, wo));
+    pixel_const<float>(ln.pc, a, r, m, dot3(n, wo));
     ln.NoL_raw = dot3(n, wi);
     ln.VoH = fmaxf(dot3(wo, ln.h), 0.0f);
     ln.nh_raw = dot3(n, ln.h);
     ln.NoH = fmaxf(ln.nh_raw, 0.0f);
-    ln.den = ggx_den(ln.pc, ln.NoH, -1.0f);
+    ln.den = ggx_den_literal(ln.pc, ln.NoH);
 }
 
 __global__ __launch_bounds__(kBlock) void eval_brdf_kernel(const float* __restrict__ wi, const float* __restrict__ wo,
@@ -374,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void eval_brdf_kernel(const float* __restri
     float nv[3] = {n[3 * k], n[3 * k + 1], n[3 * k + 2]}, av[3] = {a[3 * k], a[3 * k + 1], a[3 * k + 2]};
     Lane ln;
     lane_setup(ln, wiv, wov, nv, av, r[k], m[k]);
-    BrdfState st;
+    BrdfState<float> st;
     float fv[3], p;
     brdf_core(ln.pc, ln.NoL_raw, ln.NoH, ln.VoH, ln.den, st, fv, p);
 #pragma unroll
@@ -395,15 +497,16 @@ __global__ __launch_bounds__(kBlock) void eval_brdf_bwd_kernel(const float* __re
     float gv[3] = {g[3 * k], g[3 * k + 1], g[3 * k + 2]};
     Lane ln;
     lane_setup(ln, wiv, wov, nv, av, r[k], m[k]);
-    BrdfState st;
+    BrdfState<float> st;
     float fv[3], p;
     brdf_core(ln.pc, ln.NoL_raw, ln.NoH, ln.VoH, ln.den, st, fv, p);
-    BrdfGrad o;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o.d_a[c] = 0.0f;
-    o.d_r = o.d_m = o.dNoL = o.dNoV = o.dNoH = 0.0f;
-    brdf_core_grad<true>(ln.pc, st, gv, o);
-    float gl = ln.NoL_raw > 0.0f ? o.dNoL : 0.0f, gvv = ln.pc.NoV_raw > 0.0f ? o.dNoV : 0.0f, gh = ln.nh_raw > 0.0f ? o.dNoH : 0.0f;
+    BrdfGrad<float> o;
+    brdf_grad_zero(o);
+    float gl = 0.0f, gh = 0.0f;
+    brdf_core_grad<float, true>(ln.pc, st, gv, o, gl, gh);
+    gl = ln.NoL_raw > 0.0f ? gl : 0.0f;
+    gh = ln.nh_raw > 0.0f ? gh : 0.0f;
+    float gvv = ln.pc.NoV_raw > 0.0f ? o.dNoV : 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         d_a[3 * k + c] = o.d_a[c];
@@ -449,9 +552,9 @@ __global__ __launch_bounds__(kBlock) void sample_brdf_kernel(const float* __rest
     lane_setup(ln, wiv, wov, nv, av, rv, m[k]);
     if (sin2_h >= 0.0f) {  // same value as the literal form, without the fp32 cancellation at the GGX peak
         ln.NoH = cos_h;
-        ln.den = ggx_den(ln.pc, cos_h, sin2_h);
+        ln.den = ggx_den_stable(ln.pc, sin2_h);
     }
-    BrdfState st;
+    BrdfState<float> st;
     float fv[3], p;
     brdf_core(ln.pc, ln.NoL_raw, ln.NoH, ln.VoH, ln.den, st, fv, p);
     float ip = p > 1e-6f ? rcp(p + 1e-6f) : 0.0f;
@@ -466,7 +569,8 @@ __global__ __launch_bounds__(kBlock) void sample_brdf_kernel(const float* __rest
 __global__ __launch_bounds__(kBlock) void sh_eval_kernel(const float* __restrict__ w, const float* __restrict__ coef,
                                                          float* __restrict__ L, long N) {
     __shared__ float s_c[kNL + 1];
-    stage_light(s_c, coef, 0);
+    if (threadIdx.x < kNL) s_c[threadIdx.x] = coef[threadIdx.x] * kShNorm[threadIdx.x / 3];
+    __syncthreads();
     long k = (long)blockIdx.x * kBlock + threadIdx.x;
     if (k >= N) return;
     float wv[3] = {w[3 * k], w[3 * k + 1], w[3 * k + 2]};
@@ -527,6 +631,8 @@ bool make_geom(int H, int W, int spp, const MatpbrCamera* cam, Geom& g) {
     g.inv_spp = spp > 0 ? 1.0f / (float)spp : 0.0f;
     return true;
 }
+// two pixels per lane: a 256-thread workgroup covers 512 pixels
+int grid_blocks(int H, int W) { return (int)(((long)H * W + 2 * kBlock - 1) / (2 * kBlock)); }
 bool valid_spp(int spp) { return spp >= 2 && spp <= MATPBR_MAX_SPP && (spp % 2) == 0; }
 int launch_status() { return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH; }
 
@@ -545,7 +651,7 @@ const char* matpbr_strerror(int code) {
         case MATPBR_ERR_INVALID_ARG: return "invalid argument (null pointer, non-positive size, or unsupported light kind)";
         case MATPBR_ERR_UNSUPPORTED: return "unsupported spp (must be even, 2..128)";
         case MATPBR_ERR_LAUNCH: return "HIP kernel launch failed";
-        case MATPBR_ERR_WORKSPACE: return "workspace missing or too small for the light gradient";
+        case MATPBR_ERR_WORKSPACE: return "workspace missing or smaller than matpbr_shade_bwd_workspace_bytes() (needed for d_light)";
         default: return "unknown matpbr error";
     }
 }
@@ -561,15 +667,14 @@ int matpbr_shade_fwd(const float* a, const float* r, const float* m, const float
     if (!make_geom(H, W, spp, cam, g)) return MATPBR_ERR_INVALID_ARG;
     SampleTable tab;
     fill_sample_table(spp, tab);
-    dim3 grid((unsigned)((H * W + kBlock - 1) / kBlock), (unsigned)batch);
+    dim3 grid((unsigned)grid_blocks(H, W), (unsigned)batch);
     hipLaunchKernelGGL(shade_fwd_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a, r, m, n, light, out_rgb, g, tab);
     return launch_status();
 }
 
 size_t matpbr_shade_bwd_workspace_bytes(int H, int W, int batch, int n_light) {
     if (H <= 0 || W <= 0 || batch <= 0 || n_light <= 0) return 0;
-    size_t nblocks = ((size_t)H * W + kBlock - 1) / kBlock;
-    return nblocks * (size_t)batch * (size_t)n_light * 3 * sizeof(float);
+    return (size_t)grid_blocks(H, W) * (size_t)batch * (size_t)n_light * 3 * sizeof(float);
 }
 
 int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind,
@@ -590,21 +695,20 @@ int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float
         return MATPBR_ERR_WORKSPACE;
     SampleTable tab;
     fill_sample_table(spp, tab);
-    dim3 grid((unsigned)((H * W + kBlock - 1) / kBlock), (unsigned)batch);
+    dim3 grid((unsigned)grid_blocks(H, W), (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
 #define MATPBR_LAUNCH_BWD(MAT, NRM, LGT) \
     hipLaunchKernelGGL((shade_bwd_kernel<MAT, NRM, LGT>), grid, dim3(kBlock), 0, st, a, r, m, n, light, d_out_rgb, d_a, d_r, d_m, d_n, part, g, tab)
-    const int sel = (want_mat ? 4 : 0) | (want_n ? 2 : 0) | (want_light ? 1 : 0);
-    switch (sel) {
-        case 1: MATPBR_LAUNCH_BWD(false, false, true); break;
-        case 2: MATPBR_LAUNCH_BWD(false, true, false); break;
-        case 3: MATPBR_LAUNCH_BWD(false, true, true); break;
-        case 4: MATPBR_LAUNCH_BWD(true, false, false); break;
-        case 5: MATPBR_LAUNCH_BWD(true, false, true); break;
-        case 6: MATPBR_LAUNCH_BWD(true, true, false); break;
-        default: MATPBR_LAUNCH_BWD(true, true, true); break;
+    // The light gradient keeps 75 accumulators per lane and the material/normal gradients keep the 38 coefficient
+    // pairs: together they exceed the 256-VGPR budget of two waves per SIMD, so a call that wants both runs two launches.
+    switch ((want_mat ? 2 : 0) | (want_n ? 1 : 0)) {
+        case 1: MATPBR_LAUNCH_BWD(false, true, false); break;
+        case 2: MATPBR_LAUNCH_BWD(true, false, false); break;
+        case 3: MATPBR_LAUNCH_BWD(true, true, false); break;
+        default: break;
     }
+    if (want_light) MATPBR_LAUNCH_BWD(false, false, true);
 #undef MATPBR_LAUNCH_BWD
     if (hipGetLastError() != hipSuccess) return MATPBR_ERR_LAUNCH;
     if (want_light) {

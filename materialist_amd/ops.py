@@ -92,6 +92,15 @@ def check_spp(spp: int) -> int:
     return spp
 
 
+def workspace_for(a: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device scratch of matpbr_shade_bwd_workspace_bytes() for maps shaped like `a` ([H,W,3] or [B,H,W,3]); reuses `workspace` if it fits."""
+    B, H, W = _bhw(a)
+    need = int(_lib.load().matpbr_shade_bwd_workspace_bytes(H, W, B, NSH))
+    if workspace is not None and workspace.device == a.device and workspace.numel() * workspace.element_size() >= need:
+        return workspace
+    return torch.empty((need + 3) // 4, dtype=torch.float32, device=a.device)
+
+
 def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0) -> torch.Tensor:
     lib = _lib.load()
     a = _dev(a, "albedo", (3,))
@@ -131,9 +140,8 @@ def shade_bwd(a, r, m, n, light, d_out, spp: int, fov_x_deg: float = 35.0, want_
     d_l = torch.empty_like(light) if want_light else None
     ws_bytes = 0
     if want_light:
-        ws_bytes = int(lib.matpbr_shade_bwd_workspace_bytes(H, W, B, NSH))
-        if workspace is None or workspace.numel() * workspace.element_size() < ws_bytes or workspace.device != a.device:
-            workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+        workspace = workspace_for(a, workspace)
+        ws_bytes = workspace.numel() * 4
     cam = MatpbrCamera(float(fov_x_deg))
     with torch.cuda.device(a.device), _timed("shade_bwd"):
         code = lib.matpbr_shade_bwd(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(d_out), _ptr(d_a),

@@ -41,7 +41,9 @@ class _ShadeFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         want_mat = need[0] or need[1] or need[2]
         want_n, want_light = need[3], need[4]
-        ws = ctx.ws.get("ws") if ctx.ws is not None else None
+        ws = None
+        if want_light and ctx.ws is not None:
+            ws = ctx.ws["ws"] = ops.workspace_for(a, ctx.ws.get("ws"))
         d_a, d_r, d_m, d_n, d_l = ops.shade_bwd(a, r, m, n, light, d_out.contiguous(), ctx.spp, ctx.fov, want_mat=want_mat,
                                                 want_n=want_n, want_light=want_light, workspace=ws)
         return (d_a if need[0] else None, d_r.reshape(r.shape) if need[1] else None, d_m.reshape(m.shape) if need[2] else None,
