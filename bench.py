@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel; the reference renders with spp=64 (inverse_img_w_mi.py:625)")
     ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--mode", choices=["fused", "torch"], default="fused",
+                    help="fused: loss statistics / loss backward / Adam in libmatpbr.so; torch: same step composed from torch ops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -61,10 +63,13 @@ def cpu_baseline(size, spp, target_s):
     per_px = t_probe / (32 * 32)
     n = int(min(size, max(32, (target_s / per_px) ** 0.5)))
     n -= n % 8
-    t = run(n)
-    its = (n * n) / (size * size) / t
+    reps, t = 0, 0.0
+    while t < target_s and reps < 64:      # small crops finish early on many-core hosts: repeat up to the time budget
+        t += run(n)
+        reps += 1
+    its = reps * (n * n) / (size * size) / t
     return {"value": its, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"oracle f32+OpenMP shade fwd+bwd(arm) on a {n}x{n} crop of the {size}x{size} spp={spp} image, {t:.1f}s, scaled by pixels; "
+            "sample": f"oracle f32+OpenMP shade fwd+bwd(arm), {reps} x ({n}x{n} crop of the {size}x{size} spp={spp} image), {t:.1f}s, scaled by pixels; "
                       "CPU restatement of the reference BRDF path (not Mitsuba)"}
 
 
@@ -99,8 +104,11 @@ def main():
     scene._set("emitter.data", light)                # BRDF phase renders under the current best light (:317-334)
     with torch.no_grad():
         gt_image = render.render_w_brdf(scene, gt_a, gt_r, gt_m, None, args.spp)
-    phase = loop.BrdfPhase(scene, gt_image, t([s.init_albedo for s in scenes]), t([s.init_roughness for s in scenes]),
-                           t([s.init_metallic for s in scenes]), None, optimize_part="arm", spp=args.spp)
+    init = (t([s.init_albedo for s in scenes]), t([s.init_roughness for s in scenes]), t([s.init_metallic for s in scenes]))
+    if args.mode == "fused":
+        phase = loop.FusedBrdfPhase(scene, gt_image, *init, spp=args.spp)
+    else:
+        phase = loop.BrdfPhase(scene, gt_image, *init, None, optimize_part="arm", spp=args.spp)
     psnr0 = float(loop._loss.psnr(render.render_w_brdf(scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), gt_image).mean())
 
     for _ in range(args.warmup):
@@ -132,10 +140,29 @@ def main():
         final = render.render_w_brdf(scene, m["albedo"].detach(), m["roughness"].detach(), m["metallic"].detach(), None, args.spp)
     psnr1 = float(loop._loss.psnr(final, gt_image).mean())
 
+    # kernel durations for the roofline: 20 back-to-back launches between two HIP events on the launch stream (per-launch
+    # event pairs inside the loop also time the inter-launch gap; they are reported as *_inloop_ms for reference)
+    def back_to_back(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    mm = {k: v.detach().contiguous() for k, v in phase.current_maps().items() if v is not None}
+    nrm, lgt = scene.shading_normal(), (scene.light if scene.light.ndim == 3 or B == 1 else scene.light.unsqueeze(0).expand(B, -1, -1).contiguous())
+    d_probe = torch.randn_like(gt_image)
+    ms_f = back_to_back(lambda: ops.shade_fwd(mm["albedo"], mm["roughness"], mm["metallic"], nrm, lgt, args.spp))
+    ms_b = back_to_back(lambda: ops.shade_bwd(mm["albedo"], mm["roughness"], mm["metallic"], nrm, lgt, d_probe, args.spp, want_mat=True))
+
     if rank == 0:
         px = H * W * B
-        ms_f = ksum.get("shade_fwd", (0, float("nan")))[1]
-        ms_b = ksum.get("shade_bwd", (0, float("nan")))[1]
+        ms_f_in = ksum.get("shade_fwd", (0, float("nan")))[1]
+        ms_b_in = ksum.get("shade_bwd", (0, float("nan")))[1]
         ach_b = BYTES_BWD_ARM * px / (ms_b * 1e-3) / 1e9
         ach_f = BYTES_FWD * px / (ms_f * 1e-3) / 1e9
         ach_fb = (BYTES_FWD + BYTES_BWD_ARM) * px / ((ms_f + ms_b) * 1e-3) / 1e9
@@ -152,13 +179,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2-synthetic: {H}x{W} BRDF-phase optimisation iteration (shade_fwd + loss + shade_bwd + Adam on a/r/m maps), "
-                                   f"spp={args.spp}, --model_name none --opt_order arm, use_mesh_normal; PosMLP (SURVEY 8f2) not in the loop",
+                                   f"spp={args.spp}, --model_name none --opt_order arm, use_mesh_normal, step={args.mode}; PosMLP (SURVEY 8f2) not in the loop",
                        "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25"},
             "roofline": {"bound": "hbm", "kernel": "shade_bwd_kernel<mat>", "achieved": ach_b, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_b / (HBM_PEAK / 1e9), "traffic": traffic,
-                         "bytes_per_pixel": BYTES_BWD_ARM, "avg_launch_ms": ms_b,
-                         "note": "VALU-bound at spp=64: ~600 lane-instructions per pixel-sample; see DESIGN.md section 4",
-                         "shade_fwd": {"achieved": ach_f, "frac": ach_f / (HBM_PEAK / 1e9), "avg_launch_ms": ms_f, "bytes_per_pixel": BYTES_FWD},
+                         "bytes_per_pixel": BYTES_BWD_ARM, "avg_launch_ms": ms_b, "avg_launch_inloop_ms": ms_b_in,
+                         "note": "canonical unfused shade_bwd<mat> on the same maps; the kernel is VALU-issue-bound at spp=64 (DESIGN.md section 4)",
+                         "shade_fwd": {"achieved": ach_f, "frac": ach_f / (HBM_PEAK / 1e9), "avg_launch_ms": ms_f, "avg_launch_inloop_ms": ms_f_in,
+                                       "bytes_per_pixel": BYTES_FWD},
                          "fwd+bwd": {"achieved": ach_fb, "frac": ach_fb / (HBM_PEAK / 1e9), "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM}},
             "psnr_db": {"initial_guess": psnr0, "after_timed_steps": psnr1, "vs": "own HIP render of the synthetic ground truth (Mitsuba cannot run, SURVEY F3)"},
         }

@@ -43,6 +43,12 @@ enum {
 
 enum { MATPBR_LIGHT_SH25 = 0 };
 
+/* flags */
+#define MATPBR_FLAG_CLAMP_PARAMS 1u /* maps are raw optimiser parameters: render clamp(a,0,1), clamp(r,.07,1), clamp(m,0,1)
+                                       (inverse_img_w_mi.py:371-377) */
+#define MATPBR_STATS_STRIDE 16      /* floats per image in the loss statistics: ratio, mse, l1, l1/mse, L1(a), L1(r), L1(m), loss,
+                                       improved (0/1), best_mse (running, caller initialises to +inf), pad */
+
 /* Pinhole camera of the reference: camera at the origin looking down -z, +y up
  * (inverse_img_w_mi.py:31-39, myutils/default_cam.json), focal = (W/2)/tan(fov_x/2),
  * principal point ((W-1)/2, (H-1)/2) (myutils/mesh_recon.py:17-25). */
@@ -72,6 +78,27 @@ int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float
                      float* d_n, float* d_light, void* workspace, size_t workspace_bytes, int H, int W, int batch,
                      int spp, const MatpbrCamera* cam, uint32_t flags, void* stream);
 size_t matpbr_shade_bwd_workspace_bytes(int H, int W, int batch, int n_light);
+
+/* Fused pieces of hot loop B in `--model_name none` mode (inverse_img_w_mi.py:371-432): everything between the two
+ * renders of one optimisation iteration, without leaving the GPU.
+ *   matpbr_brdf_loss_stats     ratio = mean(gt)/mean(pred); MSE / L1 of (pred*ratio)^(1/2.2) against gt^(1/2.2); L1 of the clamped
+ *                              parameter maps against their initial values; loss = 3 (L1/MSE) MSE + L1 + scale_delta * sum(L1 reg)
+ *                              (:388-418); SaveBest's strict `<` on the MSE (myutils/misc.py:75) -> stats[B, MATPBR_STATS_STRIDE].
+ *   matpbr_shade_bwd_brdf_loss matpbr_shade_bwd with d loss/d pred formed in-kernel from those statistics, the regulariser
+ *                              gradients added, torch.clamp's gradient gating applied, and best_* (nullable) snapshotted when
+ *                              stats says the iteration improved.  pa/pr/pm are the raw (unclamped) parameter maps.
+ *   matpbr_adam_step           torch.optim.Adam update of one tensor (:359); `step` is the 1-based iteration count. */
+size_t matpbr_brdf_loss_workspace_bytes(int batch);
+int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr,
+                           const float* pm, const float* a0, const float* r0, const float* m0, float scale_delta,
+                           float* stats, void* workspace, size_t workspace_bytes, int H, int W, int batch, void* stream);
+int matpbr_shade_bwd_brdf_loss(const float* pa, const float* pr, const float* pm, const float* n, const float* light,
+                               int light_kind, int n_light, const float* pred, const float* gt_srgb, const float* stats,
+                               const float* a0, const float* r0, const float* m0, float scale_delta, float* d_a, float* d_r,
+                               float* d_m, float* best_a, float* best_r, float* best_m, float* best_img, int H, int W,
+                               int batch, int spp, const MatpbrCamera* cam, uint32_t flags, void* stream);
+int matpbr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                     int step, void* stream);
 
 /* Plugin face, N independent lanes, AoS [N,3] vectors (the reference traces these over Dr.Jit arrays).
  *   matpbr_eval_brdf   = MatDiffBSDF.eval_pdf / eval_brdf     myutils/mi_plugin.py:1372-1427,1449-1460

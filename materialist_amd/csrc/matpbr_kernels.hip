@@ -87,9 +87,15 @@ struct Pixel {
     f2 inv_len;  // 1/|n| of the stored normal
 };
 
+// CLAMP: the maps are the optimiser's raw parameters and the render uses clamp(a,0,1), clamp(r,.07,1), clamp(m,0,1)
+// (inverse_img_w_mi.py:371-377); the raw values are returned so the backward pass can gate the gradient like torch.clamp.
+struct RawParams { f2 a[3], r, m; };
+__device__ __forceinline__ f2 clamp2(f2 x, float lo, float hi) { return vmin(vmax(x, lo), hi); }
+
+template <bool CLAMP>
 __device__ __forceinline__ void load_pixel(Pixel& px, const float* __restrict__ a, const float* __restrict__ r,
                                            const float* __restrict__ m, const float* __restrict__ n, long i0, long i1, int p0, int p1,
-                                           const Geom& g) {
+                                           const Geom& g, RawParams* raw = nullptr) {
     f2 av[3], nv[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -97,6 +103,17 @@ __device__ __forceinline__ void load_pixel(Pixel& px, const float* __restrict__ 
         nv[c] = f2{n[i0 * 3 + c], n[i1 * 3 + c]};
     }
     f2 rv = f2{r[i0], r[i1]}, mv = f2{m[i0], m[i1]};
+    if (CLAMP) {
+        if (raw) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) raw->a[c] = av[c];
+            raw->r = rv; raw->m = mv;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) av[c] = clamp2(av[c], 0.0f, 1.0f);
+        rv = clamp2(rv, 0.07f, 1.0f);
+        mv = clamp2(mv, 0.0f, 1.0f);
+    }
     // shading normal = normalize(n map); the geometric normals and MaterialNet's are unit already
     px.inv_len = rsq(vmax(dot3v(nv, nv), 1e-30f));
 #pragma unroll
@@ -250,6 +267,7 @@ __device__ __forceinline__ void fwd_accumulate(const Pixel& px, const Sample& sm
     for (int c = 0; c < 3; ++c) acc[c] = vfma(f[c] * ip, L[c], acc[c]);
 }
 
+template <bool CLAMP>
 __global__ __launch_bounds__(kBlock, 2) void shade_fwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
                                                               const float* __restrict__ m, const float* __restrict__ n,
                                                               const float* __restrict__ light, float* __restrict__ out,
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(kBlock, 2) void shade_fwd_kernel(const float* __res
     const int p1 = two ? p0 + 1 : p0;
     const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
     Pixel px;
-    load_pixel(px, a, r, m, n, i0, i1, p0, p1, g);
+    load_pixel<CLAMP>(px, a, r, m, n, i0, i1, p0, p1, g);
     LightRegs lr;
     load_light_regs(lr, cp);
 
@@ -343,13 +361,32 @@ __device__ __forceinline__ void bwd_accumulate(const Pixel& px, const Sample& sm
     }
 }
 
-template <bool WANT_MAT, bool WANT_N, bool WANT_LIGHT>
+// Fused BRDF-phase loss (hot loop B, `model_name == 'none'`, inverse_img_w_mi.py:371-420).  With FUSED the kernel
+// takes the optimiser's raw parameter maps, forms d loss / d pred itself from the forward image, the gamma-2.2 target
+// and the per-image statistics of matpbr_brdf_loss_stats, adds the L1 regularisers towards the initial maps, gates
+// everything like torch.clamp's backward, and (when the statistics say this iteration is the best so far) snapshots
+// the clamped maps and the gamma-2.2 render -- SaveBest without a host round trip.
+struct FusedLoss {
+    const float* pred;      // [B,H,W,3] linear render of this iteration (matpbr_shade_fwd with MATPBR_FLAG_CLAMP_PARAMS)
+    const float* gt_srgb;   // [B,H,W,3] target ^ (1/2.2)
+    const float* stats;     // [B,kStatsStride] from matpbr_brdf_loss_stats
+    const float* a0; const float* r0; const float* m0;   // initial maps of the L1 regularisers (:398-409)
+    float* best_a; float* best_r; float* best_m; float* best_img;  // nullable snapshot targets
+    float scale_delta, inv_n3, inv_n1;
+};
+constexpr int kStatsStride = 16;  // ratio, mse, l1, l1/mse, L1(a), L1(r), L1(m), loss, improved, best_mse, (pad)
+constexpr float kLossEps = 1e-8f; // materialist_amd/loss.py _EPS: x^(1/2.2) has no gradient at exact zeros
+__device__ __forceinline__ float fsign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+__device__ __forceinline__ float pow_inv_gamma(float x) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.2f)); }
+
+template <bool WANT_MAT, bool WANT_N, bool WANT_LIGHT, bool FUSED = false>
 __global__ __launch_bounds__(kBlock, 2) void shade_bwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
                                                               const float* __restrict__ m, const float* __restrict__ n,
                                                               const float* __restrict__ light, const float* __restrict__ d_out,
                                                               float* __restrict__ d_a, float* __restrict__ d_r,
                                                               float* __restrict__ d_m, float* __restrict__ d_n,
-                                                              float* __restrict__ partials, const Geom g, const SampleTable tab) {
+                                                              float* __restrict__ partials, const Geom g, const SampleTable tab,
+                                                              const FusedLoss fl) {
     __shared__ float s_red[4][kNL + 1];
     const int b = blockIdx.y;
     const float* __restrict__ cp = light + (long)b * kNL;
@@ -359,12 +396,36 @@ __global__ __launch_bounds__(kBlock, 2) void shade_bwd_kernel(const float* __res
     const int p0 = act0 ? q0 : P - 1, p1 = two ? q0 + 1 : p0;
     const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
     Pixel px;
-    load_pixel(px, a, r, m, n, i0, i1, p0, p1, g);
+    RawParams raw;
+    load_pixel<FUSED>(px, a, r, m, n, i0, i1, p0, p1, g, &raw);
     LightRegs lr;
     if (WANT_MAT || WANT_N) load_light_regs(lr, cp);
     f2 go[3];
+    float xs_keep[6];
+    if (FUSED) {
+        // d loss / d pred of  3 (l1/mse) mse + l1  on  xs = max(pred*ratio, eps)^(1/2.2)   (:388-418)
+        const float ratio = fl.stats[b * kStatsStride + 0], sr = fl.stats[b * kStatsStride + 3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) go[c] = f2{act0 ? d_out[i0 * 3 + c] * g.inv_spp : 0.0f, two ? d_out[i1 * 3 + c] * g.inv_spp : 0.0f};
+        for (int c = 0; c < 3; ++c) {
+            float gv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const long ii = e ? i1 : i0;
+                const bool on = e ? two : act0;
+                float x = fl.pred[ii * 3 + c] * ratio;
+                float xc = fmaxf(x, kLossEps);
+                float xs = pow_inv_gamma(xc);
+                float d = xs - fl.gt_srgb[ii * 3 + c];
+                float dxs = x > kLossEps ? xs * rcp(xc) * (1.0f / 2.2f) : 0.0f;
+                gv[e] = on ? ratio * dxs * fmaf(6.0f * sr, d, fsign(d)) * fl.inv_n3 * g.inv_spp : 0.0f;
+                xs_keep[c * 2 + e] = xs;
+            }
+            go[c] = f2{gv[0], gv[1]};
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) go[c] = f2{act0 ? d_out[i0 * 3 + c] * g.inv_spp : 0.0f, two ? d_out[i1 * 3 + c] * g.inv_spp : 0.0f};
+    }
 
     BwdAcc<WANT_LIGHT> A;
     brdf_grad_zero(A.gr);
@@ -388,7 +449,29 @@ __global__ __launch_bounds__(kBlock, 2) void shade_bwd_kernel(const float* __res
     }
 
     if (act0) {
-        if (WANT_MAT) {
+        if (WANT_MAT && FUSED) {
+            const bool improved = fl.stats[b * kStatsStride + 8] > 0.5f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (e && !two) break;
+                const long ii = e ? i1 : i0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float pa = raw.a[c][e], ac = px.pc.a[c][e];
+                    float gsum = A.gr.d_a[c][e] + fl.scale_delta * fl.inv_n3 * fsign(ac - fl.a0[ii * 3 + c]);   // :398,418
+                    d_a[ii * 3 + c] = (pa >= 0.0f && pa <= 1.0f) ? gsum : 0.0f;                                 // clamp backward
+                    if (improved && fl.best_a) fl.best_a[ii * 3 + c] = ac;
+                    if (improved && fl.best_img) fl.best_img[ii * 3 + c] = xs_keep[c * 2 + e];
+                }
+                float pr = raw.r[e], rc = px.pc.r[e], pm = raw.m[e], mc = px.pc.m[e];
+                float gr_ = A.gr.d_r[e] + fl.scale_delta * fl.inv_n1 * fsign(rc - fl.r0[ii]);
+                float gm_ = A.gr.d_m[e] + fl.scale_delta * fl.inv_n1 * fsign(mc - fl.m0[ii]);
+                d_r[ii] = (pr >= 0.07f && pr <= 1.0f) ? gr_ : 0.0f;
+                d_m[ii] = (pm >= 0.0f && pm <= 1.0f) ? gm_ : 0.0f;
+                if (improved && fl.best_r) fl.best_r[ii] = rc;
+                if (improved && fl.best_m) fl.best_m[ii] = mc;
+            }
+        } else if (WANT_MAT) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 d_a[i0 * 3 + c] = A.gr.d_a[c].x;
@@ -425,6 +508,108 @@ __global__ __launch_bounds__(kBlock, 2) void shade_bwd_kernel(const float* __res
             float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
             partials[((long)b * gridDim.x + blockIdx.x) * kNL + threadIdx.x] = v;
         }
+    }
+}
+
+// =================================================================================================
+// BRDF-phase loss statistics (inverse_img_w_mi.py:388-418) and the Adam update (torch.optim.Adam, :359)
+// Two-pass reductions with fixed-order partial sums: bit-reproducible, no atomics.
+// =================================================================================================
+constexpr int kRedBlocks = 128;   // partial sums per image and pass
+
+__device__ __forceinline__ float block_sum(float v, float* s_buf) {   // all threads get the total
+    v = wave_sum_to_lane63(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 63) s_buf[wave] = v;
+    __syncthreads();
+    return (s_buf[0] + s_buf[1]) + (s_buf[2] + s_buf[3]);
+}
+
+// pass 1: sum(pred), sum(gt) -> ratio = mean(gt)/mean(pred)   (:388)
+__global__ __launch_bounds__(kBlock) void loss_sums1_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                            float* __restrict__ part, long n3) {
+    __shared__ float s_buf[4];
+    const int b = blockIdx.y;
+    const float* p = pred + b * n3;
+    const float* q = gt + b * n3;
+    float sp = 0.0f, sg = 0.0f;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (long)gridDim.x * kBlock) { sp += p[i]; sg += q[i]; }
+    sp = block_sum(sp, s_buf);
+    sg = block_sum(sg, s_buf);
+    if (threadIdx.x == 0) { part[((long)b * gridDim.x + blockIdx.x) * 2] = sp; part[((long)b * gridDim.x + blockIdx.x) * 2 + 1] = sg; }
+}
+__global__ __launch_bounds__(kBlock) void loss_final1_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk) {
+    __shared__ float s_buf[4];
+    const int b = blockIdx.x;
+    float sp = 0.0f, sg = 0.0f;
+    for (int i = threadIdx.x; i < nblk; i += kBlock) { sp += part[((long)b * nblk + i) * 2]; sg += part[((long)b * nblk + i) * 2 + 1]; }
+    sp = block_sum(sp, s_buf);
+    sg = block_sum(sg, s_buf);
+    if (threadIdx.x == 0) stats[b * kStatsStride + 0] = sg / sp;
+}
+// pass 2: sum (xs-gs)^2, sum |xs-gs| over [H,W,3]; sum |a-a0| over [H,W,3]; sum |r-r0|, |m-m0| over [H,W]
+__global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restrict__ pred, const float* __restrict__ gt_srgb,
+                                                            const float* __restrict__ stats, const float* __restrict__ pa,
+                                                            const float* __restrict__ a0, const float* __restrict__ pr,
+                                                            const float* __restrict__ r0, const float* __restrict__ pm,
+                                                            const float* __restrict__ m0, float* __restrict__ part, long n3, long n1) {
+    __shared__ float s_buf[4];
+    const int b = blockIdx.y;
+    const float ratio = stats[b * kStatsStride + 0];
+    float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (long)gridDim.x * kBlock) {
+        float xs = pow_inv_gamma(fmaxf(pred[b * n3 + i] * ratio, kLossEps));
+        float d = xs - gt_srgb[b * n3 + i];
+        s[0] = fmaf(d, d, s[0]);
+        s[1] += fabsf(d);
+        s[2] += fabsf(fminf(fmaxf(pa[b * n3 + i], 0.0f), 1.0f) - a0[b * n3 + i]);
+    }
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n1; i += (long)gridDim.x * kBlock) {
+        s[3] += fabsf(fminf(fmaxf(pr[b * n1 + i], 0.07f), 1.0f) - r0[b * n1 + i]);
+        s[4] += fabsf(fminf(fmaxf(pm[b * n1 + i], 0.0f), 1.0f) - m0[b * n1 + i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float v = block_sum(s[k], s_buf);
+        if (threadIdx.x == 0) part[((long)b * gridDim.x + blockIdx.x) * 5 + k] = v;
+    }
+}
+__global__ __launch_bounds__(kBlock) void loss_final2_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk,
+                                                             float inv_n3, float inv_n1, float scale_delta) {
+    __shared__ float s_buf[4];
+    const int b = blockIdx.x;
+    float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = threadIdx.x; i < nblk; i += kBlock) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[k] += part[((long)b * nblk + i) * 5 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] = block_sum(s[k], s_buf);
+    if (threadIdx.x == 0) {
+        float* st = stats + b * kStatsStride;
+        float mse = s[0] * inv_n3, l1 = s[1] * inv_n3, la = s[2] * inv_n3, lr = s[3] * inv_n1, lm = s[4] * inv_n1;
+        float sr = l1 / mse;                                   // scale_raito (:411), a constant of the backward pass
+        st[1] = mse; st[2] = l1; st[3] = sr; st[4] = la; st[5] = lr; st[6] = lm;
+        st[7] = 3.0f * sr * mse + l1 + scale_delta * (la + lr + lm);   // :412-414
+        float best = st[9];
+        bool improved = mse < best;                            // SaveBest.update: strict < (myutils/misc.py:75)
+        st[8] = improved ? 1.0f : 0.0f;
+        st[9] = improved ? mse : best;
+    }
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(kBlock) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, long n, float lr_over_bc1, float b1, float b2, float eps,
+                                                           float inv_sqrt_bc2) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        float gi = g[i];
+        float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+        float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / fmaf(fsqrt(vi), inv_sqrt_bc2, eps);
     }
 }
 
@@ -659,7 +844,6 @@ const char* matpbr_strerror(int code) {
 int matpbr_shade_fwd(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind,
                      int n_light, float* out_rgb, int H, int W, int batch, int spp, const MatpbrCamera* cam, uint32_t flags,
                      void* stream) {
-    (void)flags;
     if (!a || !r || !m || !n || !light || !out_rgb || batch <= 0) return MATPBR_ERR_INVALID_ARG;
     if (light_kind != MATPBR_LIGHT_SH25 || n_light != MATPBR_NSH) return MATPBR_ERR_INVALID_ARG;
     if (!valid_spp(spp)) return MATPBR_ERR_UNSUPPORTED;
@@ -668,7 +852,10 @@ int matpbr_shade_fwd(const float* a, const float* r, const float* m, const float
     SampleTable tab;
     fill_sample_table(spp, tab);
     dim3 grid((unsigned)grid_blocks(H, W), (unsigned)batch);
-    hipLaunchKernelGGL(shade_fwd_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a, r, m, n, light, out_rgb, g, tab);
+    if (flags & MATPBR_FLAG_CLAMP_PARAMS)
+        hipLaunchKernelGGL(shade_fwd_kernel<true>, grid, dim3(kBlock), 0, (hipStream_t)stream, a, r, m, n, light, out_rgb, g, tab);
+    else
+        hipLaunchKernelGGL(shade_fwd_kernel<false>, grid, dim3(kBlock), 0, (hipStream_t)stream, a, r, m, n, light, out_rgb, g, tab);
     return launch_status();
 }
 
@@ -699,7 +886,7 @@ int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
 #define MATPBR_LAUNCH_BWD(MAT, NRM, LGT) \
-    hipLaunchKernelGGL((shade_bwd_kernel<MAT, NRM, LGT>), grid, dim3(kBlock), 0, st, a, r, m, n, light, d_out_rgb, d_a, d_r, d_m, d_n, part, g, tab)
+    hipLaunchKernelGGL((shade_bwd_kernel<MAT, NRM, LGT>), grid, dim3(kBlock), 0, st, a, r, m, n, light, d_out_rgb, d_a, d_r, d_m, d_n, part, g, tab, FusedLoss{})
     // The light gradient keeps 75 accumulators per lane and the material/normal gradients keep the 38 coefficient
     // pairs: together they exceed the 256-VGPR budget of two waves per SIMD, so a call that wants both runs two launches.
     switch ((want_mat ? 2 : 0) | (want_n ? 1 : 0)) {
@@ -757,6 +944,59 @@ int matpbr_normals_from_depth(const float* depth, float* out_n, int H, int W, in
     if (!make_geom(H, W, 2, cam, g)) return MATPBR_ERR_INVALID_ARG;
     hipLaunchKernelGGL(normals_from_depth_kernel, dim3((unsigned)((H * W + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0,
                        (hipStream_t)stream, depth, out_n, g);
+    return launch_status();
+}
+
+size_t matpbr_brdf_loss_workspace_bytes(int batch) { return batch > 0 ? (size_t)batch * kRedBlocks * 5 * sizeof(float) : 0; }
+
+int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr, const float* pm,
+                           const float* a0, const float* r0, const float* m0, float scale_delta, float* stats, void* workspace,
+                           size_t workspace_bytes, int H, int W, int batch, void* stream) {
+    if (!pred || !gt || !gt_srgb || !pa || !pr || !pm || !a0 || !r0 || !m0 || !stats || H <= 0 || W <= 0 || batch <= 0)
+        return MATPBR_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < matpbr_brdf_loss_workspace_bytes(batch)) return MATPBR_ERR_WORKSPACE;
+    const long n1 = (long)H * W, n3 = n1 * 3;
+    float* part = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(kRedBlocks, (unsigned)batch);
+    hipLaunchKernelGGL(loss_sums1_kernel, grid, dim3(kBlock), 0, st, pred, gt, part, n3);
+    hipLaunchKernelGGL(loss_final1_kernel, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks);
+    hipLaunchKernelGGL(loss_sums2_kernel, grid, dim3(kBlock), 0, st, pred, gt_srgb, stats, pa, a0, pr, r0, pm, m0, part, n3, n1);
+    hipLaunchKernelGGL(loss_final2_kernel, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks, 1.0f / (float)n3,
+                       1.0f / (float)n1, scale_delta);
+    return launch_status();
+}
+
+int matpbr_shade_bwd_brdf_loss(const float* pa, const float* pr, const float* pm, const float* n, const float* light, int light_kind,
+                               int n_light, const float* pred, const float* gt_srgb, const float* stats, const float* a0,
+                               const float* r0, const float* m0, float scale_delta, float* d_a, float* d_r, float* d_m, float* best_a,
+                               float* best_r, float* best_m, float* best_img, int H, int W, int batch, int spp, const MatpbrCamera* cam,
+                               uint32_t flags, void* stream) {
+    (void)flags;
+    if (!pa || !pr || !pm || !n || !light || !pred || !gt_srgb || !stats || !a0 || !r0 || !m0 || !d_a || !d_r || !d_m || batch <= 0)
+        return MATPBR_ERR_INVALID_ARG;
+    if (light_kind != MATPBR_LIGHT_SH25 || n_light != MATPBR_NSH) return MATPBR_ERR_INVALID_ARG;
+    if (!valid_spp(spp)) return MATPBR_ERR_UNSUPPORTED;
+    Geom g;
+    if (!make_geom(H, W, spp, cam, g)) return MATPBR_ERR_INVALID_ARG;
+    SampleTable tab;
+    fill_sample_table(spp, tab);
+    FusedLoss fl{pred, gt_srgb, stats, a0, r0, m0, best_a, best_r, best_m, best_img, scale_delta, 1.0f / (3.0f * (float)H * (float)W),
+                 1.0f / ((float)H * (float)W)};
+    dim3 grid((unsigned)grid_blocks(H, W), (unsigned)batch);
+    hipLaunchKernelGGL((shade_bwd_kernel<true, false, false, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, pa, pr, pm, n, light,
+                       (const float*)nullptr, d_a, d_r, d_m, (float*)nullptr, (float*)nullptr, g, tab, fl);
+    return launch_status();
+}
+
+int matpbr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step,
+                     void* stream) {
+    if (!p || !g || !m || !v || n < 0 || step < 1) return MATPBR_ERR_INVALID_ARG;
+    if (n == 0) return MATPBR_OK;
+    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+    unsigned blocks = (unsigned)std::min<long>((n + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1), beta1, beta2,
+                       eps, (float)(1.0 / std::sqrt(bc2)));
     return launch_status();
 }
 

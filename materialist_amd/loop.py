@@ -174,3 +174,71 @@ class EnvPhase:
         self.opt.zero_grad(set_to_none=True)
         self.sched.step()
         return loss_mse.detach()
+
+
+class FusedBrdfPhase:
+    """Hot loop B in `model_name == 'none'` mode (inverse_img_w_mi.py:347-468) with every step between the parameter
+    maps and their Adam update executed by libmatpbr.so: render (clamp folded in), loss statistics, fused loss backward
+    with regularisers / clamp gating / SaveBest snapshot, Adam.  Same arithmetic as `BrdfPhase` (which composes the same
+    step from torch ops and serves as its parity reference); nothing returns to the host inside a step.
+
+    Early stopping needs the MSE on the host.  `history()` returns the per-iteration MSE recorded on the device, so
+    the caller can replay EarlyStopping every `k` iterations instead of synchronising on each one."""
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
+                 spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, stats: Optional[torch.Tensor] = None, history_len: int = 5000):
+        from . import ops
+
+        if not scene.use_mesh_normal:
+            raise NotImplementedError("FusedBrdfPhase optimises a/r/m under the geometric normal; use BrdfPhase for 'n'")
+        self.ops, self.scene, self.spp, self.scale_delta = ops, scene, int(spp), float(scale_delta)
+        self.gt = gt_image.contiguous()
+        self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
+        c = lambda t: t.detach().clone().contiguous()
+        self.p = {"albedo": c(albedo), "roughness": c(roughness), "metallic": c(metallic)}
+        self.orig = {k: c(v) for k, v in self.p.items()}
+        self.g = {k: torch.empty_like(v) for k, v in self.p.items()}
+        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.best = {k: c(v) for k, v in self.p.items()}
+        self.best_img = torch.zeros_like(self.gt)
+        self.pred = torch.empty_like(self.gt)
+        B = self.gt.shape[0] if self.gt.ndim == 4 else 1
+        self.stats = stats if stats is not None else ops.new_loss_stats(B, self.gt.device)
+        self.ws = torch.empty(int(_lib_ws(B)) // 4, dtype=torch.float32, device=self.gt.device)
+        self.hist = torch.zeros((history_len, B), dtype=torch.float32, device=self.gt.device)
+        self.lr, self.t = float(lr), 0
+
+    def step(self) -> None:
+        ops, sc, p = self.ops, self.scene, self.p
+        n, light = sc.shading_normal(), sc.light
+        B = self.stats.shape[0]
+        if B > 1 and light.ndim == 2:
+            light = light.unsqueeze(0).expand(B, -1, -1).contiguous()
+        ops.shade_fwd(p["albedo"], p["roughness"], p["metallic"], n, light, self.spp, sc.fov, clamp_params=True, out=self.pred)
+        ops.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, p["albedo"], p["roughness"], p["metallic"], self.orig["albedo"],
+                            self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws)
+        ops.shade_bwd_brdf_loss(p["albedo"], p["roughness"], p["metallic"], n, light, self.pred, self.gt_srgb, self.stats,
+                                self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.spp,
+                                self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
+                                self.best["metallic"], self.best_img, sc.fov)
+        if self.t < self.hist.shape[0]:
+            self.hist[self.t].copy_(self.stats[:, ops.STAT_MSE])
+        self.t += 1
+        for k in p:
+            ops.adam_step(p[k], self.g[k], self.m[k], self.v[k], self.lr, self.t)
+        if self.lr > 1.5e-4 and self.t % 100 == 0:      # StepLR(100, 0.8) stepped while lr > 1.5e-4 (:363-365,431-432)
+            self.lr *= 0.8
+
+    def history(self) -> torch.Tensor:
+        """[iterations so far, B] loss_mse of every iteration (device tensor)."""
+        return self.hist[: self.t]
+
+    def current_maps(self) -> Dict[str, torch.Tensor]:
+        return {"albedo": self.p["albedo"].clamp(0, 1), "roughness": self.p["roughness"].clamp(0.07, 1), "metallic": self.p["metallic"].clamp(0, 1)}
+
+
+def _lib_ws(batch: int) -> int:
+    from . import _lib
+
+    return _lib.load().matpbr_brdf_loss_workspace_bytes(int(batch))

@@ -13,6 +13,9 @@ from ._lib import MatpbrCamera, MatpbrError
 LIGHT_SH25 = 0
 NSH = 25
 MAX_SPP = 128
+FLAG_CLAMP_PARAMS = 1
+STATS_STRIDE = 16
+STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST = range(10)
 
 
 class KernelTimer:
@@ -101,7 +104,8 @@ def workspace_for(a: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> 
     return torch.empty((need + 3) // 4, dtype=torch.float32, device=a.device)
 
 
-def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0) -> torch.Tensor:
+def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0, clamp_params: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     a = _dev(a, "albedo", (3,))
     B, H, W = _bhw(a)
@@ -111,11 +115,12 @@ def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0) -> torch.Ten
     light = _dev(light, "light", (NSH, 3))
     if n.numel() != a.numel() or r.numel() * 3 != a.numel() or light.numel() != B * NSH * 3:
         raise ValueError("shade_fwd: inconsistent map / light shapes")
-    out = torch.empty_like(a)
+    if out is None:
+        out = torch.empty_like(a)
     cam = MatpbrCamera(float(fov_x_deg))
     with torch.cuda.device(a.device), _timed("shade_fwd"):
         code = lib.matpbr_shade_fwd(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(out), H, W, B,
-                                    check_spp(spp), ctypes.byref(cam), 0, _stream(a))
+                                    check_spp(spp), ctypes.byref(cam), FLAG_CLAMP_PARAMS if clamp_params else 0, _stream(a))
     _lib.check(code, "matpbr_shade_fwd")
     return out
 
@@ -225,3 +230,51 @@ def normals_from_depth(depth, fov_x_deg: float = 35.0):
         code = lib.matpbr_normals_from_depth(_ptr(depth), _ptr(out), H, W, B, ctypes.byref(cam), _stream(depth))
     _lib.check(code, "matpbr_normals_from_depth")
     return out
+
+
+def new_loss_stats(batch: int, device) -> torch.Tensor:
+    """Per-image statistics buffer of matpbr_brdf_loss_stats; best_mse starts at +inf (SaveBest.best_loss, misc.py:64)."""
+    st = torch.zeros((batch, STATS_STRIDE), dtype=torch.float32, device=device)
+    st[:, STAT_BEST] = float("inf")
+    return st
+
+
+def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: float, stats: torch.Tensor,
+                    workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fills `stats` [B, STATS_STRIDE] in place (ratio, mse, l1, l1/mse, regulariser L1s, loss, improved, best_mse)."""
+    lib = _lib.load()
+    pred = _dev(pred, "pred", (3,))
+    B, H, W = _bhw(pred)
+    ts = [_dev(t, k) for t, k in ((gt, "gt"), (gt_srgb, "gt_srgb"), (pa, "pa"), (pr, "pr"), (pm, "pm"), (a0, "a0"), (r0, "r0"), (m0, "m0"))]
+    need = int(lib.matpbr_brdf_loss_workspace_bytes(B))
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=pred.device)
+    with torch.cuda.device(pred.device):
+        code = lib.matpbr_brdf_loss_stats(_ptr(pred), *[_ptr(t) for t in ts], float(scale_delta), _ptr(stats), _ptr(workspace),
+                                          workspace.numel() * 4, H, W, B, _stream(pred))
+    _lib.check(code, "matpbr_brdf_loss_stats")
+    return stats
+
+
+def shade_bwd_brdf_loss(pa, pr, pm, n, light, pred, gt_srgb, stats, a0, r0, m0, scale_delta: float, spp: int, d_a, d_r, d_m,
+                        best_a=None, best_r=None, best_m=None, best_img=None, fov_x_deg: float = 35.0) -> None:
+    """Backward of the fused BRDF-phase loss into preallocated d_a/d_r/d_m (see include/matpbr.h)."""
+    lib = _lib.load()
+    pa = _dev(pa, "pa", (3,))
+    B, H, W = _bhw(pa)
+    cam = MatpbrCamera(float(fov_x_deg))
+    with torch.cuda.device(pa.device), _timed("shade_bwd"):
+        code = lib.matpbr_shade_bwd_brdf_loss(_ptr(pa), _ptr(pr), _ptr(pm), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(pred), _ptr(gt_srgb),
+                                              _ptr(stats), _ptr(a0), _ptr(r0), _ptr(m0), float(scale_delta), _ptr(d_a), _ptr(d_r), _ptr(d_m),
+                                              _ptr(best_a), _ptr(best_r), _ptr(best_m), _ptr(best_img), H, W, B, check_spp(spp),
+                                              ctypes.byref(cam), 0, _stream(pa))
+    _lib.check(code, "matpbr_shade_bwd_brdf_loss")
+
+
+def adam_step(p, g, m, v, lr: float, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """In-place torch.optim.Adam update of `p` (state m, v) with gradient g; `step` is 1-based."""
+    lib = _lib.load()
+    with torch.cuda.device(p.device):
+        code = lib.matpbr_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                    int(step), _stream(p))
+    _lib.check(code, "matpbr_adam_step")
