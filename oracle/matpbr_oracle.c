@@ -383,6 +383,41 @@ static real unit_normal(const real n[3], real nh[3]) {
     return l;
 }
 
+/* Forward with the sampling state frozen: directions and pdf come from (n_s, r_s), the BRDF value from (n, a, r, m).
+ * At (n_s, r_s) = (n, r) this equals shade_pixel; its derivative w.r.t. (a, r, m, n) at that point is what
+ * shade_pixel_bwd returns (stop-gradient through the samples), which the tests verify by finite differences. */
+static void shade_pixel_frozen(const real wo[3], const real n[3], const real a[3], real r, real m, const real n_s[3], real r_s,
+                               const real* coef, int spp, real out[3]) {
+    int half = spp / 2;
+    out[0] = out[1] = out[2] = R(0);
+    for (int s = 0; s < spp; ++s) {
+        real u0, u1, wi[3], f[3], fs[3], pdf, pdf_s, L[3];
+        oracle_sample_point(spp, s < half ? s : s - half, &u0, &u1);
+        if (s < half) oracle_diffuse_sampler(u0, u1, n_s, wi);
+        else oracle_specular_sampler(u0, u1, r_s, wo, n_s, wi);
+        oracle_eval_brdf(wi, wo, n_s, a, r_s, m, fs, &pdf_s);
+        if (!(pdf_s > R(1e-6))) continue;
+        oracle_eval_brdf(wi, wo, n, a, r, m, f, &pdf);
+        oracle_sh_eval(wi, coef, L);
+        for (int c = 0; c < 3; ++c) out[c] += f[c] / (pdf_s + R(1e-6)) * L[c];
+    }
+    for (int c = 0; c < 3; ++c) out[c] /= (real)spp;
+}
+void oracle_shade_fwd_frozen(const real* a, const real* r, const real* m, const real* n, const real* n_s, const real* r_s,
+                             const real* light, real* out, int H, int W, int batch, int spp, real fov_x_deg) {
+    const long P = (long)H * W;
+#pragma omp parallel for schedule(static)
+    for (long idx = 0; idx < P * batch; ++idx) {
+        long b = idx / P, p = idx % P;
+        int i = (int)(p / W), j = (int)(p % W);
+        real wo[3], nh[3], nsh[3];
+        oracle_view_dir(i, j, H, W, fov_x_deg, wo);
+        unit_normal(n + idx * 3, nh);
+        unit_normal(n_s + idx * 3, nsh);
+        shade_pixel_frozen(wo, nh, a + idx * 3, r[idx], m[idx], nsh, r_s[idx], light + b * MATPBR_NSH * 3, spp, out + idx * 3);
+    }
+}
+
 /* Image-level entry points.  Layout = the reference's: row-major HWC float maps
  * a[H,W,3] r[H,W,1] m[H,W,1] n[H,W,3] (myutils/mi_plugin.py:1238-1241), light = SH coef [batch,25,3]. */
 void oracle_shade_fwd(const real* a, const real* r, const real* m, const real* n, const real* light, real* out,

@@ -160,6 +160,15 @@ class Oracle:
                                   ctypes.c_int(spp), self._r(fov_deg))
         return out
 
+    def shade_fwd_frozen(self, a, r, m, n, n_s, r_s, light, spp, fov_deg=35.0):
+        """Forward with sample directions / pdf frozen at (n_s, r_s): the function whose gradient shade_bwd returns."""
+        a, r, m, n, n_s, r_s, light = map(self._a, (a, r, m, n, n_s, r_s, light))
+        B, H, W = self._bhw(a)
+        out = np.empty_like(a)
+        self.lib.oracle_shade_fwd_frozen(*map(self._p, (a, r, m, n, n_s, r_s, light, out)), ctypes.c_int(H), ctypes.c_int(W),
+                                         ctypes.c_int(B), ctypes.c_int(spp), self._r(fov_deg))
+        return out
+
     def shade_bwd(self, a, r, m, n, light, d_out, spp, fov_deg=35.0, want_n=True, want_light=True):
         a, r, m, n, light, d_out = map(self._a, (a, r, m, n, light, d_out))
         B, H, W = self._bhw(a)
