@@ -1,0 +1,36 @@
+"""Condense rocprofv3 CSV output into the small summaries committed under profiles/.
+usage: summarize_rocprof.py <dir with *kernel_stats.csv | *counter_collection.csv> [--filter substr]"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+d = sys.argv[1]
+flt = sys.argv[sys.argv.index("--filter") + 1] if "--filter" in sys.argv else None
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"# kernel stats ({os.path.relpath(f, d)}): total {tot / 1e6:.3f} ms over {sum(int(r['Calls']) for r in rows)} dispatches")
+    print("name,calls,avg_us,min_us,max_us,pct")
+    for r in rows[:14]:
+        print(f"{short(r['Name'])},{r['Calls']},{float(r['AverageNs']) / 1e3:.2f},{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f},{r['Percentage']}")
+for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if flt and flt not in k:
+            continue
+        agg[(k, r["Grid_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print(f"# counters ({os.path.relpath(f, d)})")
+    print("kernel,grid,vgpr,sgpr,scratch,counter,dispatches,mean,min,max")
+    for key, cs in agg.items():
+        for c, v in cs.items():
+            print(",".join(key) + f",{c},{len(v)},{sum(v) / len(v):.4f},{min(v):.4f},{max(v):.4f}")
