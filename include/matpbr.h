@@ -46,8 +46,14 @@ enum { MATPBR_LIGHT_SH25 = 0 };
 /* flags */
 #define MATPBR_FLAG_CLAMP_PARAMS 1u /* maps are raw optimiser parameters: render clamp(a,0,1), clamp(r,.07,1), clamp(m,0,1)
                                        (inverse_img_w_mi.py:371-377) */
-#define MATPBR_STATS_STRIDE 16      /* floats per image in the loss statistics: ratio, mse, l1, l1/mse, L1(a), L1(r), L1(m), loss,
-                                       improved (0/1), best_mse (running, caller initialises to +inf), pad */
+#define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
+#define MATPBR_PART_R 4u
+#define MATPBR_PART_M 8u
+/* floats per image in the loss statistics buffer (device memory, caller-owned, persistent across iterations):
+ *  0 ratio  1 mse  2 l1  3 l1/mse  4 L1(a)  5 L1(r)  6 L1(m)  7 loss  8 improved(0/1)  9 best_mse (init +inf)
+ * 10 early-stopping counter  11 early-stopping best  12 early-stopping has-best  13 stopped(0/1)  14 iterations run
+ * 15 sum(gt) over the image (set by the caller; used by matpbr_brdf_phase_step) */
+#define MATPBR_STATS_STRIDE 16
 
 /* Pinhole camera of the reference: camera at the origin looking down -z, +y up
  * (inverse_img_w_mi.py:31-39, myutils/default_cam.json), focal = (W/2)/tan(fov_x/2),
@@ -99,6 +105,34 @@ int matpbr_shade_bwd_brdf_loss(const float* pa, const float* pr, const float* pm
                                int batch, int spp, const MatpbrCamera* cam, uint32_t flags, void* stream);
 int matpbr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                      int step, void* stream);
+
+/* One whole iteration of hot loop B (`model_name == 'none'`, inverse_img_w_mi.py:371-432) enqueued by a single call:
+ * render(clamped params) -> loss statistics + SaveBest / EarlyStopping decisions -> fused loss backward -> Adam.
+ * All pointers are device memory owned by the caller.  EarlyStopping (myutils/misc.py:37-60, es_patience > 0) runs on the
+ * device: once stats[b][13] is set every kernel skips image b, so iterations may be enqueued ahead of the host's polling
+ * without changing any decision.  `t` is the 1-based Adam step, `lr` the learning rate of this iteration. */
+typedef struct MatpbrBrdfPhase {
+    float *pa, *pr, *pm;                  /* raw parameter maps [B,H,W,3|1|1], updated in place */
+    const float *n, *light;               /* shading-normal map [B,H,W,3], SH25 light [B,25,3] */
+    const float *gt_srgb;                 /* target ^ (1/2.2) [B,H,W,3]; sum(gt) per image sits in stats[b][15] */
+    const float *a0, *r0, *m0;            /* regulariser anchors = the maps at phase start (:196-201) */
+    float* pred;                          /* [B,H,W,3] the iteration's render (scratch / output) */
+    float *d_a, *d_r, *d_m;               /* gradients (scratch / output) */
+    float *adam_m[3], *adam_v[3];         /* Adam moments of a, r, m (needed for the maps in part_mask) */
+    float *best_a, *best_r, *best_m, *best_img; /* SaveBest snapshot targets, nullable */
+    float* stats;                         /* [B, MATPBR_STATS_STRIDE] */
+    float* history;                       /* [hist_len, B] loss_mse of every iteration, nullable */
+    void* workspace;
+    size_t workspace_bytes;               /* >= matpbr_brdf_phase_workspace_bytes() */
+    int H, W, batch, spp;
+    float fov_x_deg, scale_delta;         /* 35, 0.1 in the reference */
+    uint32_t part_mask;                   /* MATPBR_PART_A | _R | _M */
+    int es_patience;                      /* 200 // loop_num (:361); <= 0 disables early stopping */
+    float es_min_delta;                   /* 0.005 if 'a' in part else 0.001 (:360-363) */
+    int hist_len;
+} MatpbrBrdfPhase;
+size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
+int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);
 
 /* Plugin face, N independent lanes, AoS [N,3] vectors (the reference traces these over Dr.Jit arrays).
  *   matpbr_eval_brdf   = MatDiffBSDF.eval_pdf / eval_brdf     myutils/mi_plugin.py:1372-1427,1449-1460

@@ -15,6 +15,16 @@ class MatpbrCamera(ctypes.Structure):
     _fields_ = [("fov_x_deg", ctypes.c_float)]
 
 
+class MatpbrBrdfPhase(ctypes.Structure):
+    """Mirror of `MatpbrBrdfPhase` in include/matpbr.h (field order matters)."""
+    _fields_ = ([(k, ctypes.c_void_p) for k in ("pa", "pr", "pm", "n", "light", "gt_srgb", "a0", "r0", "m0", "pred", "d_a", "d_r", "d_m")] +
+                [("adam_m", ctypes.c_void_p * 3), ("adam_v", ctypes.c_void_p * 3)] +
+                [(k, ctypes.c_void_p) for k in ("best_a", "best_r", "best_m", "best_img", "stats", "history", "workspace")] +
+                [("workspace_bytes", ctypes.c_size_t), ("H", ctypes.c_int), ("W", ctypes.c_int), ("batch", ctypes.c_int), ("spp", ctypes.c_int),
+                 ("fov_x_deg", ctypes.c_float), ("scale_delta", ctypes.c_float), ("part_mask", ctypes.c_uint32), ("es_patience", ctypes.c_int),
+                 ("es_min_delta", ctypes.c_float), ("hist_len", ctypes.c_int)])
+
+
 class MatpbrError(RuntimeError):
     pass
 
@@ -35,6 +45,8 @@ SIGNATURES = {
     "matpbr_shade_bwd_brdf_loss": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float] + [_c_f] * 7 +
                                    [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera), ctypes.c_uint32,
                                     ctypes.c_void_p]),
+    "matpbr_brdf_phase_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "matpbr_brdf_phase_step": (ctypes.c_int, [ctypes.POINTER(MatpbrBrdfPhase), ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "matpbr_adam_step": (ctypes.c_int, [_c_f] * 4 + [ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                        ctypes.c_void_p]),
     "matpbr_eval_brdf": (ctypes.c_int, [_c_f] * 8 + [ctypes.c_long, ctypes.c_void_p]),

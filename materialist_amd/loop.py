@@ -177,22 +177,31 @@ class EnvPhase:
 
 
 class FusedBrdfPhase:
-    """Hot loop B in `model_name == 'none'` mode (inverse_img_w_mi.py:347-468) with every step between the parameter
-    maps and their Adam update executed by libmatpbr.so: render (clamp folded in), loss statistics, fused loss backward
-    with regularisers / clamp gating / SaveBest snapshot, Adam.  Same arithmetic as `BrdfPhase` (which composes the same
-    step from torch ops and serves as its parity reference); nothing returns to the host inside a step.
+    """Hot loop B in `model_name == 'none'` mode (inverse_img_w_mi.py:347-468), one `matpbr_brdf_phase_step` call per
+    iteration: render (clamp folded in), loss statistics, SaveBest and EarlyStopping decisions, fused loss backward
+    with regularisers / clamp gating / best-so-far snapshot, Adam -- all on the device.  Same arithmetic as `BrdfPhase`
+    (which composes the step from torch ops and is its parity reference).
 
-    Early stopping needs the MSE on the host.  `history()` returns the per-iteration MSE recorded on the device, so
-    the caller can replay EarlyStopping every `k` iterations instead of synchronising on each one."""
+    EarlyStopping (`patience` > 0) lives in the statistics buffer: after an image has stopped every kernel skips it, so
+    `run(k)` may enqueue k iterations blindly and `poll()` (one host sync) tells how far each image really got."""
+
+    PARTS = {"a": 2, "r": 4, "m": 8}
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
-                 spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, stats: Optional[torch.Tensor] = None, history_len: int = 5000):
-        from . import ops
+                 optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000):
+        import ctypes
 
-        if not scene.use_mesh_normal:
+        from . import _lib, ops
+
+        if not scene.use_mesh_normal or "n" in optimize_part:
             raise NotImplementedError("FusedBrdfPhase optimises a/r/m under the geometric normal; use BrdfPhase for 'n'")
-        self.ops, self.scene, self.spp, self.scale_delta = ops, scene, int(spp), float(scale_delta)
+        self._ct, self._libmod, self.ops = ctypes, _lib, ops
+        self.scene, self.spp, self.scale_delta, self.part = scene, int(spp), float(scale_delta), optimize_part
         self.gt = gt_image.contiguous()
+        dev = self.gt.device
+        B = self.gt.shape[0] if self.gt.ndim == 4 else 1
+        self.B, self.H, self.W = B, self.gt.shape[-3], self.gt.shape[-2]
         self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
         c = lambda t: t.detach().clone().contiguous()
         self.p = {"albedo": c(albedo), "roughness": c(roughness), "metallic": c(metallic)}
@@ -203,42 +212,65 @@ class FusedBrdfPhase:
         self.best = {k: c(v) for k, v in self.p.items()}
         self.best_img = torch.zeros_like(self.gt)
         self.pred = torch.empty_like(self.gt)
-        B = self.gt.shape[0] if self.gt.ndim == 4 else 1
-        self.stats = stats if stats is not None else ops.new_loss_stats(B, self.gt.device)
-        self.ws = torch.empty(int(_lib_ws(B)) // 4, dtype=torch.float32, device=self.gt.device)
-        self.hist = torch.zeros((history_len, B), dtype=torch.float32, device=self.gt.device)
-        self.lr, self.t = float(lr), 0
+        self.stats = ops.new_loss_stats(B, dev)
+        if best_mse is not None:   # SaveBest.best_loss is global across phases and never reset (F11)
+            self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
+        self.stats[:, ops.STAT_GT_SUM] = self.gt.reshape(B, -1).sum(dim=1)
+        lib = _lib.load()
+        self.ws = torch.empty(int(lib.matpbr_brdf_phase_workspace_bytes(self.H, self.W, B)) // 4 + 1, dtype=torch.float32, device=dev)
+        self.hist = torch.zeros((history_len, B), dtype=torch.float32, device=dev)
+        self.n = scene.shading_normal().contiguous()
+        light = scene.light.detach()
+        self.light = (light.unsqueeze(0).expand(B, -1, -1) if (B > 1 and light.ndim == 2) else light).contiguous()
+        self.base_lr, self.t = float(lr), 0
+        ph = _lib.MatpbrBrdfPhase()
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        ph.pa, ph.pr, ph.pm = P(self.p["albedo"]), P(self.p["roughness"]), P(self.p["metallic"])
+        ph.n, ph.light, ph.gt_srgb = P(self.n), P(self.light), P(self.gt_srgb)
+        ph.a0, ph.r0, ph.m0 = P(self.orig["albedo"]), P(self.orig["roughness"]), P(self.orig["metallic"])
+        ph.pred = P(self.pred)
+        ph.d_a, ph.d_r, ph.d_m = P(self.g["albedo"]), P(self.g["roughness"]), P(self.g["metallic"])
+        for i, k in enumerate(("albedo", "roughness", "metallic")):
+            ph.adam_m[i], ph.adam_v[i] = self.m[k].data_ptr(), self.v[k].data_ptr()
+        ph.best_a, ph.best_r, ph.best_m, ph.best_img = P(self.best["albedo"]), P(self.best["roughness"]), P(self.best["metallic"]), P(self.best_img)
+        ph.stats, ph.history, ph.workspace = P(self.stats), P(self.hist), P(self.ws)
+        ph.workspace_bytes = self.ws.numel() * 4
+        ph.H, ph.W, ph.batch, ph.spp = self.H, self.W, B, self.spp
+        ph.fov_x_deg, ph.scale_delta = scene.fov, self.scale_delta
+        ph.part_mask = sum(self.PARTS[ch] for ch in optimize_part)
+        ph.es_patience, ph.es_min_delta, ph.hist_len = int(patience), float(min_delta), int(history_len)
+        self._ph, self._lib = ph, lib
+
+    def lr_at(self, t0: int) -> float:
+        """Learning rate of the iteration with 0-based index t0: StepLR(100, 0.8) stepped only while lr > 1.5e-4 (:363-365,431-432)."""
+        lr, k = self.base_lr, 0
+        while lr > 1.5e-4 and (k + 1) * 100 <= t0:
+            lr *= 0.8
+            k += 1
+        return lr
 
     def step(self) -> None:
-        ops, sc, p = self.ops, self.scene, self.p
-        n, light = sc.shading_normal(), sc.light
-        B = self.stats.shape[0]
-        if B > 1 and light.ndim == 2:
-            light = light.unsqueeze(0).expand(B, -1, -1).contiguous()
-        ops.shade_fwd(p["albedo"], p["roughness"], p["metallic"], n, light, self.spp, sc.fov, clamp_params=True, out=self.pred)
-        ops.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, p["albedo"], p["roughness"], p["metallic"], self.orig["albedo"],
-                            self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws)
-        ops.shade_bwd_brdf_loss(p["albedo"], p["roughness"], p["metallic"], n, light, self.pred, self.gt_srgb, self.stats,
-                                self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.spp,
-                                self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
-                                self.best["metallic"], self.best_img, sc.fov)
-        if self.t < self.hist.shape[0]:
-            self.hist[self.t].copy_(self.stats[:, ops.STAT_MSE])
+        ct = self._ct
+        with torch.cuda.device(self.gt.device), self.ops._timed("brdf_phase_step"):
+            code = self._lib.matpbr_brdf_phase_step(ct.byref(self._ph), self.t + 1, self.lr_at(self.t),
+                                                    ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
+        self._libmod.check(code, "matpbr_brdf_phase_step")
         self.t += 1
-        for k in p:
-            ops.adam_step(p[k], self.g[k], self.m[k], self.v[k], self.lr, self.t)
-        if self.lr > 1.5e-4 and self.t % 100 == 0:      # StepLR(100, 0.8) stepped while lr > 1.5e-4 (:363-365,431-432)
-            self.lr *= 0.8
+
+    def run(self, n: int) -> None:
+        for _ in range(n):
+            self.step()
+
+    def poll(self) -> Dict[str, torch.Tensor]:
+        """One host synchronisation: per-image stop flags, iterations actually executed, best / last MSE."""
+        st = self.stats.cpu()
+        o = self.ops
+        return {"stopped": st[:, o.STAT_STOPPED] > 0.5, "iters": st[:, o.STAT_ITERS].to(torch.int64), "best_mse": st[:, o.STAT_BEST],
+                "mse": st[:, o.STAT_MSE], "loss": st[:, o.STAT_LOSS]}
 
     def history(self) -> torch.Tensor:
-        """[iterations so far, B] loss_mse of every iteration (device tensor)."""
+        """[iterations enqueued so far, B] loss_mse of every executed iteration (device tensor; rows past an image's stop are 0)."""
         return self.hist[: self.t]
 
     def current_maps(self) -> Dict[str, torch.Tensor]:
         return {"albedo": self.p["albedo"].clamp(0, 1), "roughness": self.p["roughness"].clamp(0.07, 1), "metallic": self.p["metallic"].clamp(0, 1)}
-
-
-def _lib_ws(batch: int) -> int:
-    from . import _lib
-
-    return _lib.load().matpbr_brdf_loss_workspace_bytes(int(batch))

@@ -15,7 +15,9 @@ NSH = 25
 MAX_SPP = 128
 FLAG_CLAMP_PARAMS = 1
 STATS_STRIDE = 16
-STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST = range(10)
+(STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
+ STAT_ES_HAS, STAT_STOPPED, STAT_ITERS, STAT_GT_SUM) = range(16)
+PART_A, PART_R, PART_M = 2, 4, 8
 
 
 class KernelTimer:
@@ -25,7 +27,7 @@ class KernelTimer:
     active = None
 
     def __init__(self):
-        self.events = {"shade_fwd": [], "shade_bwd": []}
+        self.events = {"shade_fwd": [], "shade_bwd": [], "brdf_phase_step": []}
 
     def __enter__(self):
         KernelTimer.active = self

@@ -333,6 +333,62 @@ def test_fused_brdf_phase_matches_torch_composition():
         assert_close(fused.best[k], ref.saver.best[k].cpu().numpy(), rtol=1e-4, what=f"best {k}")
     assert_close(fused.best_img, ref.saver.best["rendered_img"].cpu().numpy(), rtol=1e-3, what="best render")
     assert fused.history().shape == (5, 1)
+    assert fused.poll()["iters"].tolist() == [5]
+
+
+def test_fused_phase_parts_and_device_early_stopping():
+    """optimize_part masks (only the part's maps move, only its regularisers count) and the on-device EarlyStopping:
+    identical stop iteration to the host state machine fed with the recorded losses, nothing changes after the stop."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    H = W = 48
+    spp = 8
+    sc = synthetic.make_scene(6, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    # part 'rm': albedo must not move; reference composition with the same part
+    ref = loop.BrdfPhase(scene, gt, *init, None, optimize_part="rm", spp=spp)
+    fused = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp)
+    for _ in range(3):
+        mse_ref = ref.step()
+        fused.step()
+        assert float(fused.stats[0, ops.STAT_LOSS]) == pytest.approx(float(ref.last["loss"]), rel=2e-4)
+    assert torch.equal(fused.p["albedo"], init[0])
+    assert (fused.p["roughness"] - ref.params["roughness"].detach()).abs().max().item() < 3e-5
+    assert float(fused.stats[0, ops.STAT_LA]) == 0.0 and float(fused.stats[0, ops.STAT_LR]) > 0.0
+    # early stopping: huge min_delta -> every iteration after the first is a miss -> stops after 1 + patience iterations
+    es = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="arm", spp=spp, patience=4, min_delta=0.5)
+    es.run(12)
+    info = es.poll()
+    assert info["stopped"].tolist() == [True] and info["iters"].tolist() == [5]
+    host = loop.EarlyStopping(patience=4, min_delta=0.5)
+    hist = es.history()[:, 0].cpu().tolist()
+    stop_at = None
+    for i, v in enumerate(hist[:5]):
+        host(v)
+        if host.early_stop:
+            stop_at = i + 1
+            break
+    assert stop_at == 5
+    assert all(v == 0.0 for v in hist[5:])            # iterations after the stop did not execute
+    frozen = {k: v.clone() for k, v in es.p.items()}
+    es.run(3)
+    assert all(torch.equal(frozen[k], es.p[k]) for k in frozen)
+    # batch of two images with independent stop flags: image 1's target equals its initial render -> flat loss -> stops early
+    scb = render.load_estimated_mesh(_t(np.stack([sc.depth, sc.depth]), dev), use_mesh_normal=True)
+    scb._set("emitter.data", _t(np.stack([sc.light, sc.light]), dev))
+    initb = [torch.stack([x, x]).contiguous() for x in init]
+    with torch.no_grad():
+        pred0 = render.render_w_brdf(scb, initb[0].clamp(0, 1), initb[1].clamp(0.07, 1), initb[2].clamp(0, 1), None, spp)
+    gtb = torch.stack([gt, pred0[1]]).contiguous()
+    fb = loop.FusedBrdfPhase(scb, gtb, *initb, optimize_part="arm", spp=spp, patience=3, min_delta=0.3)
+    fb.run(10)
+    ib = fb.poll()
+    assert ib["iters"][0].item() >= ib["iters"][1].item() and ib["stopped"][1].item()
 
 
 def test_adam_step_matches_torch():
