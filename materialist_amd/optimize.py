@@ -1,0 +1,114 @@
+"""`optimize_envmap_ARMN` (inverse_img_w_mi.py:106-599) on the HIP render, `--model_name none` mode: the alternating
+env / BRDF optimisation of one image (or a batch of independent images) driven by `schedule.run_schedule`.
+
+Differences from the reference, all forced by scope:
+  * the envmap MLP (`PosMLP(output_type='envmap')`, :117-124) is f2/next; until it exists the light is optimised directly as
+    16x32 texels through a softplus (the MLP's own output activation; zero-initialised parameters give ln 2 everywhere,
+    exactly what the zero-initialised last layer of the MLP produces at the first epoch);
+  * no frame dumps / mp4 / file outputs here (f1); the function returns tensors and the decision trace.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import loop as _loop
+from . import loss as _loss
+from . import render as _render
+from .schedule import TraceEvent, run_schedule
+
+ROUGHNESS_SHIFT, METALLIC_SHIFT = 0.7, 0.05   # :183-184
+
+
+def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], optimize_order: Sequence[str] = ("arm",), spp: int = 64,
+                         opt_env_from: int = 0, opt_src: str = "arm", scale_delta: float = 0.1, num_epochs: int = 5000,
+                         sync_every: int = 25, env_size=(16, 32), log=None) -> Dict[str, object]:
+    """mat: albedo [H,W,3], roughness [H,W,1], metallic [H,W,1], normal [H,W,3], gt_image [H,W,3] (optionally gt_envmap).
+    Returns the best maps / envmap / render, the final PSNR and the schedule trace."""
+    dev = mat["gt_image"].device
+    gt = mat["gt_image"].contiguous()
+    mat = dict(mat)
+    if "r" not in opt_src:                                                         # :185-188
+        mat["roughness"] = torch.full_like(mat["roughness"], ROUGHNESS_SHIFT)
+    if "m" not in opt_src:
+        mat["metallic"] = torch.full_like(mat["metallic"], METALLIC_SHIFT)
+    params = _render.traverse(scene)                                               # :216-220
+    params["shape.bsdf.a"], params["shape.bsdf.r"], params["shape.bsdf.m"] = mat["albedo"], mat["roughness"], mat["metallic"]
+
+    saver = _loop.DeviceSaveBest()
+    env_raw = torch.zeros(tuple(env_size) + (3,), dtype=torch.float32, device=dev, requires_grad=True)
+    state = {"env_opt": None, "final_envmap": None, "phase": None, "last_mse": None}
+    say = log if log is not None else (lambda *_: None)
+
+    # ------------------------------------------------------------------ hot loop A (:236-254)
+    def env_step(loop_num: int, epoch: int, lr: float) -> float:
+        if epoch == 0:
+            state["env_opt"] = torch.optim.Adam([env_raw], lr=lr)                   # fresh Adam per loop (:225-229)
+        for gp in state["env_opt"].param_groups:
+            gp["lr"] = lr
+        envmap = torch.nn.functional.softplus(env_raw)
+        pred = _render.render_envmap(scene, envmap, spp)
+        total, mse, _ = _loss.env_loss(pred, gt)
+        total.backward()
+        saver.update(mse, albedo=mat["albedo"], roughness=mat["roughness"], metallic=mat["metallic"], envmap=envmap, rendered_img=pred)
+        state["env_opt"].step()
+        state["env_opt"].zero_grad(set_to_none=True)
+        state["last_mse"] = float(mse.detach())                                              # the reference syncs here too (:247,250)
+        return state["last_mse"]
+
+    def on_env_phase_end(loop_num: int, save: bool) -> None:
+        state["final_envmap"] = saver.best["envmap"].detach().clone()              # :296
+        say(f"loop {loop_num}: env phase done, mse {state['last_mse']:.5f}")
+
+    def on_brdf_phase_begin(loop_num: int, which: str) -> None:                    # :317-342
+        if which == "gt_or_ones":
+            env = mat["gt_envmap"] if "gt_envmap" in mat else torch.ones(tuple(env_size) + (3,), device=dev)
+        else:
+            env = state["final_envmap"]
+        params["emitter.data"] = env.detach()
+        state["envmap4render"] = env.detach()
+
+    # ------------------------------------------------------------------ hot loop B (:347-468), device-resident
+    def brdf_part_runner(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
+        ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], optimize_part=part, spp=spp,
+                                  scale_delta=scale_delta, patience=patience, min_delta=min_delta,
+                                  best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs)
+        done, stop = 0, "num_epochs"
+        while done < n_epochs:
+            k = min(sync_every, n_epochs - done)
+            ph.run(k)
+            done += k
+            info = ph.poll()
+            if bool(info["stopped"].all()):
+                stop = "early_stop"
+                break
+        info = ph.poll()
+        iters = int(info["iters"].max())
+        improved = info["best_mse"].to(dev) < (saver.best_loss if saver.best_loss is not None else float("inf"))
+        if bool(improved.any()):                                                    # SaveBest is global across phases (F11)
+            saver.best_loss = torch.minimum(info["best_mse"].to(dev).reshape(saver.best_loss.shape), saver.best_loss) \
+                if saver.best_loss is not None else info["best_mse"].to(dev)
+            for k_, v in (("albedo", ph.best["albedo"]), ("roughness", ph.best["roughness"]), ("metallic", ph.best["metallic"]),
+                          ("rendered_img", ph.best_img)):
+                saver.best[k_] = v.clone()
+            saver.best["envmap"] = state["envmap4render"].clone()
+        say(f"loop {loop_num}: part {part!r} ran {iters} iterations ({stop}), best mse {float(info['best_mse'].min()):.5f}")
+        return iters - 1, ph.lr_at(max(iters - 1, 0)), stop
+
+    def on_brdf_part_end(loop_num: int, part: str) -> None:                        # :460-463: every map comes back from the saver
+        for key in ("albedo", "roughness", "metallic"):
+            mat[key] = saver.best[key].detach().clone()
+        params["shape.bsdf.a"], params["shape.bsdf.r"], params["shape.bsdf.m"] = mat["albedo"], mat["roughness"], mat["metallic"]
+
+    trace: List[TraceEvent] = run_schedule(list(optimize_order), env_step, None, opt_src=opt_src, opt_env_from=opt_env_from,
+                                           num_epochs=num_epochs, on_env_phase_end=on_env_phase_end,
+                                           on_brdf_phase_begin=on_brdf_phase_begin, on_brdf_part_end=on_brdf_part_end,
+                                           brdf_part_runner=brdf_part_runner)
+    with torch.no_grad():
+        params["emitter.data"] = saver.best["envmap"]
+        final = _render.render_w_brdf(scene, saver.best["albedo"], saver.best["roughness"], saver.best["metallic"], None, spp)
+        ratio = gt.mean() / final.mean()
+    return {"albedo": saver.best["albedo"], "roughness": saver.best["roughness"], "metallic": saver.best["metallic"],
+            "envmap": saver.best["envmap"], "rendered_img": saver.best["rendered_img"], "final_render": final,
+            "psnr": float(_loss.psnr(final * ratio, gt)), "best_loss": float(saver.best_loss.min()), "trace": trace}

@@ -64,7 +64,10 @@ def run_schedule(optimize_order: Sequence[str], env_step: Callable[[int, int, fl
                  num_epochs: int = NUM_EPOCHS, on_env_phase_end: Optional[Callable[[int, bool], None]] = None,
                  on_brdf_phase_begin: Optional[Callable[[int, str], None]] = None,
                  on_brdf_part_begin: Optional[Callable[[int, str], None]] = None,
-                 on_brdf_part_end: Optional[Callable[[int, str], None]] = None, trace: Optional[List[TraceEvent]] = None) -> List[TraceEvent]:
+                 on_brdf_part_end: Optional[Callable[[int, str], None]] = None, trace: Optional[List[TraceEvent]] = None,
+                 brdf_part_runner: Optional[Callable[[int, str, int, float, int], tuple]] = None) -> List[TraceEvent]:
+    """`brdf_part_runner(loop, part, patience, min_delta, num_epochs) -> (last_epoch, last_lr, stop)` may replace the
+    per-epoch BRDF loop with one that keeps the EarlyStopping state machine on the device (FusedBrdfPhase)."""
     trace = [] if trace is None else trace
     early_stopping_all = EarlyStopping(patience=2, min_delta=0.025)                    # :222
     loop_num = 0
@@ -112,6 +115,12 @@ def run_schedule(optimize_order: Sequence[str], env_step: Callable[[int, int, fl
                 continue
             if on_brdf_part_begin is not None:
                 on_brdf_part_begin(loop_num, part)
+            if brdf_part_runner is not None:
+                epoch, lr, stop = brdf_part_runner(loop_num, part, brdf_patience(loop_num), brdf_min_delta(part), num_epochs)
+                trace.append(TraceEvent(loop_num, "brdf", part, epoch, lr, stop))
+                if on_brdf_part_end is not None:
+                    on_brdf_part_end(loop_num, part)
+                continue
             sched = StepLR(BRDF_LR)
             early_stopping = EarlyStopping(patience=brdf_patience(loop_num), min_delta=brdf_min_delta(part))
             stop, epoch, lr = "num_epochs", -1, BRDF_LR
