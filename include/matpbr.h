@@ -134,6 +134,16 @@ typedef struct MatpbrBrdfPhase {
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);
 
+/* One evaluation of hot loop A (inverse_img_w_mi.py:238-250) for a candidate light: render, loss = MSE + L1 on x^(1/2.2),
+ * SaveBest / EarlyStopping decisions in `stats` (same layout; ratio = 1), d loss / d light -> d_light[B,25,3].  The light's own
+ * parameterisation (envmap MLP or texels through softplus, then the SH projection) and its optimiser stay with the caller,
+ * who back-propagates d_light through them.  `pred` receives the render; `best_img` (nullable) the best-so-far linear render. */
+size_t matpbr_env_phase_workspace_bytes(int H, int W, int batch);
+int matpbr_env_phase_step(const float* a, const float* r, const float* m, const float* n, const float* light,
+                          const float* gt_srgb, float* pred, float* d_light, float* stats, float* best_img, float* history,
+                          int hist_len, int es_patience, float es_min_delta, void* workspace, size_t workspace_bytes, int H,
+                          int W, int batch, int spp, const MatpbrCamera* cam, void* stream);
+
 /* Plugin face, N independent lanes, AoS [N,3] vectors (the reference traces these over Dr.Jit arrays).
  *   matpbr_eval_brdf   = MatDiffBSDF.eval_pdf / eval_brdf     myutils/mi_plugin.py:1372-1427,1449-1460
  *                        (wi = light direction, wo = view direction; f already includes cos)

@@ -516,6 +516,14 @@ __global__ __launch_bounds__(kBlock, 2) void shade_bwd_kernel(const float* __res
         }
     }
 
+    if (FUSED && !WANT_MAT && act0 && fl.best_img && fl.stats[b * kStatsStride + kStImproved] > 0.5f) {
+        // env phase: SaveBest keeps the linear render (inverse_img_w_mi.py:247)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            fl.best_img[i0 * 3 + c] = fl.pred[i0 * 3 + c];
+            if (two) fl.best_img[i1 * 3 + c] = fl.pred[i1 * 3 + c];
+        }
+    }
     if (WANT_LIGHT) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void loss_final1_kernel(const float* __rest
 }
 // pass 2: sum (xs-gs)^2, sum |xs-gs| over [H,W,3]; sum |a-a0| over [H,W,3]; sum |r-r0|, |m-m0| over [H,W]
 // FROM_FWD: ratio is formed here from the forward kernel's per-workgroup sums and the stored sum(gt) (no pass 1).
-template <bool FROM_FWD>
+template <int MODE>   // 0: ratio from stats (piecewise API); 1: BRDF phase step (ratio from the forward sums); 2: env phase (ratio 1)
 __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restrict__ pred, const float* __restrict__ gt_srgb,
                                                             const float* __restrict__ stats, const float* __restrict__ pa,
                                                             const float* __restrict__ a0, const float* __restrict__ pr,
@@ -579,13 +587,13 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
                                                             const float* __restrict__ fwd_sums, int n_fwd) {
     __shared__ float s_buf[4];
     const int b = blockIdx.y;
-    float ratio;
-    if (FROM_FWD) {
-        if (stats[b * kStatsStride + kStStopped] > 0.5f) return;
+    float ratio = 1.0f;
+    if (MODE >= 1 && stats[b * kStatsStride + kStStopped] > 0.5f) return;
+    if (MODE == 1) {
         float sp = 0.0f;
         for (int i = threadIdx.x; i < n_fwd; i += kBlock) sp += fwd_sums[(long)b * n_fwd + i];
         ratio = stats[b * kStatsStride + kStGtSum] / block_sum(sp, s_buf);
-    } else {
+    } else if (MODE == 0) {
         ratio = stats[b * kStatsStride + kStRatio];
     }
     float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -594,11 +602,13 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
         float d = xs - gt_srgb[b * n3 + i];
         s[0] = fmaf(d, d, s[0]);
         s[1] += fabsf(d);
-        s[2] += fabsf(fminf(fmaxf(pa[b * n3 + i], 0.0f), 1.0f) - a0[b * n3 + i]);
+        if (MODE != 2) s[2] += fabsf(fminf(fmaxf(pa[b * n3 + i], 0.0f), 1.0f) - a0[b * n3 + i]);
     }
-    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n1; i += (long)gridDim.x * kBlock) {
-        s[3] += fabsf(fminf(fmaxf(pr[b * n1 + i], 0.07f), 1.0f) - r0[b * n1 + i]);
-        s[4] += fabsf(fminf(fmaxf(pm[b * n1 + i], 0.0f), 1.0f) - m0[b * n1 + i]);
+    if (MODE != 2) {
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n1; i += (long)gridDim.x * kBlock) {
+            s[3] += fabsf(fminf(fmaxf(pr[b * n1 + i], 0.07f), 1.0f) - r0[b * n1 + i]);
+            s[4] += fabsf(fminf(fmaxf(pm[b * n1 + i], 0.0f), 1.0f) - m0[b * n1 + i]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
 // Per-image scalars of the iteration, SaveBest's decision, and (es_patience > 0) the EarlyStopping state machine of
 // myutils/misc.py:37-60 kept on the device: once an image has stopped, every later kernel of the fused step skips it, so
 // the host may enqueue iterations ahead and read the flag occasionally without changing any decision.
-template <bool FROM_FWD>
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void loss_final2_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk,
                                                              float inv_n3, float inv_n1, float scale_delta, unsigned part_mask,
                                                              int es_patience, float es_min_delta, const float* __restrict__ fwd_sums,
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void loss_final2_kernel(const float* __rest
     __shared__ float s_buf[4];
     const int b = blockIdx.x;
     float* st = stats + b * kStatsStride;
-    if (FROM_FWD && st[kStStopped] > 0.5f) return;
+    if (MODE >= 1 && st[kStStopped] > 0.5f) return;
     float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = threadIdx.x; i < nblk; i += kBlock) {
 #pragma unroll
@@ -626,17 +636,19 @@ __global__ __launch_bounds__(kBlock) void loss_final2_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 5; ++k) s[k] = block_sum(s[k], s_buf);
     float sp = 0.0f;
-    if (FROM_FWD) {
+    if (MODE == 1) {
         for (int i = threadIdx.x; i < n_fwd; i += kBlock) sp += fwd_sums[(long)b * n_fwd + i];
         sp = block_sum(sp, s_buf);
     }
     if (threadIdx.x == 0) {
-        if (FROM_FWD) st[kStRatio] = st[kStGtSum] / sp;
+        if (MODE == 1) st[kStRatio] = st[kStGtSum] / sp;
+        if (MODE == 2) st[kStRatio] = 1.0f;
         float mse = s[0] * inv_n3, l1 = s[1] * inv_n3;
         float la = (part_mask & MATPBR_PART_A) ? s[2] * inv_n3 : 0.0f;
         float lr = (part_mask & MATPBR_PART_R) ? s[3] * inv_n1 : 0.0f;
         float lm = (part_mask & MATPBR_PART_M) ? s[4] * inv_n1 : 0.0f;
-        float sr = l1 / mse;                                   // scale_raito (:411), a constant of the backward pass
+        // scale_raito (:411), a constant of the backward pass; the env phase's loss is MSE + L1 (:244) = 3 (1/3) MSE + L1
+        float sr = MODE == 2 ? (1.0f / 3.0f) : l1 / mse;
         st[kStMse] = mse; st[kStL1] = l1; st[kStSr] = sr; st[kStLa] = la; st[kStLr] = lr; st[kStLm] = lm;
         st[kStLoss] = 3.0f * sr * mse + l1 + scale_delta * (la + lr + lm);   // :412-414
         float best = st[kStBest];
@@ -692,9 +704,13 @@ __global__ __launch_bounds__(kBlock) void adam3_kernel(const Adam3 t, const floa
 
 // d_light[b][k][c] = kShNorm[k] * sum over the image's workgroups of partials (fixed order -> reproducible)
 __global__ __launch_bounds__(kBlock) void light_grad_finalize_kernel(const float* __restrict__ partials, float* __restrict__ d_light,
-                                                                     int nblocks) {
+                                                                     int nblocks, const float* __restrict__ stats) {
     __shared__ float s_red[kBlock];
     const int b = blockIdx.y, k = blockIdx.x;  // one workgroup per light scalar
+    if (stats && stats[b * kStatsStride + kStStopped] > 0.5f) {   // a stopped image contributes no gradient
+        if (threadIdx.x == 0) d_light[(long)b * kNL + k] = 0.0f;
+        return;
+    }
     float v = 0.0f;
     for (int i = threadIdx.x; i < nblocks; i += kBlock) v += partials[((long)b * nblocks + i) * kNL + k];
     s_red[threadIdx.x] = v;
@@ -978,7 +994,8 @@ int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float
 #undef MATPBR_LAUNCH_BWD
     if (hipGetLastError() != hipSuccess) return MATPBR_ERR_LAUNCH;
     if (want_light) {
-        hipLaunchKernelGGL(light_grad_finalize_kernel, dim3(kNL, (unsigned)batch), dim3(kBlock), 0, st, part, d_light, (int)grid.x);
+        hipLaunchKernelGGL(light_grad_finalize_kernel, dim3(kNL, (unsigned)batch), dim3(kBlock), 0, st, part, d_light, (int)grid.x,
+                           (const float*)nullptr);
     }
     return launch_status();
 }
@@ -1040,9 +1057,9 @@ int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_s
     dim3 grid(kRedBlocks, (unsigned)batch);
     hipLaunchKernelGGL(loss_sums1_kernel, grid, dim3(kBlock), 0, st, pred, gt, part, n3);
     hipLaunchKernelGGL(loss_final1_kernel, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks);
-    hipLaunchKernelGGL(loss_sums2_kernel<false>, grid, dim3(kBlock), 0, st, pred, gt_srgb, stats, pa, a0, pr, r0, pm, m0, part, n3, n1,
+    hipLaunchKernelGGL(loss_sums2_kernel<0>, grid, dim3(kBlock), 0, st, pred, gt_srgb, stats, pa, a0, pr, r0, pm, m0, part, n3, n1,
                        (const float*)nullptr, 0);
-    hipLaunchKernelGGL(loss_final2_kernel<false>, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks, 1.0f / (float)n3,
+    hipLaunchKernelGGL(loss_final2_kernel<0>, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks, 1.0f / (float)n3,
                        1.0f / (float)n1, scale_delta, (unsigned)(MATPBR_PART_A | MATPBR_PART_R | MATPBR_PART_M), 0, 0.0f,
                        (const float*)nullptr, 0, (float*)nullptr, 0, batch);
     return launch_status();
@@ -1100,9 +1117,9 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     hipLaunchKernelGGL((shade_fwd_kernel<true, true>), grid, dim3(kBlock), 0, st, q.pa, q.pr, q.pm, q.n, q.light, q.pred, g, tab, q.stats,
                        fwd_sums);
     // 2. loss statistics, SaveBest / EarlyStopping decisions (:388-418, misc.py:37-97)
-    hipLaunchKernelGGL(loss_sums2_kernel<true>, dim3(kRedBlocks, (unsigned)q.batch), dim3(kBlock), 0, st, q.pred, q.gt_srgb, q.stats, q.pa, q.a0,
+    hipLaunchKernelGGL(loss_sums2_kernel<1>, dim3(kRedBlocks, (unsigned)q.batch), dim3(kBlock), 0, st, q.pred, q.gt_srgb, q.stats, q.pa, q.a0,
                        q.pr, q.r0, q.pm, q.m0, part, n3, n1, fwd_sums, nfwd);
-    hipLaunchKernelGGL(loss_final2_kernel<true>, dim3((unsigned)q.batch), dim3(kBlock), 0, st, part, q.stats, kRedBlocks, 1.0f / (float)n3,
+    hipLaunchKernelGGL(loss_final2_kernel<1>, dim3((unsigned)q.batch), dim3(kBlock), 0, st, part, q.stats, kRedBlocks, 1.0f / (float)n3,
                        1.0f / (float)n1, q.scale_delta, q.part_mask, q.es_patience, q.es_min_delta, fwd_sums, nfwd, q.history, q.hist_len,
                        q.batch);
     // 3. backward of the loss through the render (:420), regularisers, clamp gating, best-so-far snapshot
@@ -1117,6 +1134,45 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
              {n3, n1, n1}};
     hipLaunchKernelGGL(adam3_kernel, dim3(128, (unsigned)q.batch, 3), dim3(kBlock), 0, st, ad, q.stats, q.part_mask, (float)(lr / bc1), b1, b2,
                        eps, (float)(1.0 / std::sqrt(bc2)));
+    return launch_status();
+}
+
+size_t matpbr_env_phase_workspace_bytes(int H, int W, int batch) {
+    if (H <= 0 || W <= 0 || batch <= 0) return 0;
+    return ((size_t)batch * grid_blocks(H, W) * kNL + (size_t)batch * kRedBlocks * 5) * sizeof(float);
+}
+
+int matpbr_env_phase_step(const float* a, const float* r, const float* m, const float* n, const float* light, const float* gt_srgb,
+                          float* pred, float* d_light, float* stats, float* best_img, float* history, int hist_len, int es_patience,
+                          float es_min_delta, void* workspace, size_t workspace_bytes, int H, int W, int batch, int spp,
+                          const MatpbrCamera* cam, void* stream) {
+    if (!a || !r || !m || !n || !light || !gt_srgb || !pred || !d_light || !stats || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+    if (!valid_spp(spp)) return MATPBR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < matpbr_env_phase_workspace_bytes(H, W, batch)) return MATPBR_ERR_WORKSPACE;
+    Geom g;
+    if (!make_geom(H, W, spp, cam, g)) return MATPBR_ERR_INVALID_ARG;
+    SampleTable tab;
+    fill_sample_table(spp, tab);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = grid_blocks(H, W);
+    float* lpart = (float*)workspace;
+    float* part = lpart + (size_t)batch * nblk * kNL;
+    const long n1 = (long)H * W, n3 = n1 * 3;
+    dim3 grid((unsigned)nblk, (unsigned)batch);
+    // render under the candidate light (:240); images whose EarlyStopping fired are skipped by every kernel
+    hipLaunchKernelGGL((shade_fwd_kernel<false, true>), grid, dim3(kBlock), 0, st, a, r, m, n, light, pred, g, tab, (const float*)stats, lpart);
+    // loss = MSE + L1 on x^(1/2.2) (:241-245); SaveBest / EarlyStopping decisions (:247,250)
+    hipLaunchKernelGGL(loss_sums2_kernel<2>, dim3(kRedBlocks, (unsigned)batch), dim3(kBlock), 0, st, (const float*)pred, gt_srgb,
+                       (const float*)stats, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, part, n3, n1, (const float*)nullptr, 0);
+    hipLaunchKernelGGL(loss_final2_kernel<2>, dim3((unsigned)batch), dim3(kBlock), 0, st, (const float*)part, stats, kRedBlocks,
+                       1.0f / (float)n3, 1.0f / (float)n1, 0.0f, 0u, es_patience, es_min_delta, (const float*)nullptr, 0, history, hist_len, batch);
+    // d loss / d light through the render (:248)
+    FusedLoss fl{pred, gt_srgb, stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, best_img, 0.0f, 1.0f / (float)n3, 1.0f / (float)n1, 0u, 1};
+    hipLaunchKernelGGL((shade_bwd_kernel<false, false, true, true>), grid, dim3(kBlock), 0, st, a, r, m, n, light, (const float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, lpart, g, tab, fl);
+    hipLaunchKernelGGL(light_grad_finalize_kernel, dim3(kNL, (unsigned)batch), dim3(kBlock), 0, st, (const float*)lpart, d_light, nblk,
+                       (const float*)stats);
     return launch_status();
 }
 

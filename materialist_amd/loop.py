@@ -274,3 +274,76 @@ class FusedBrdfPhase:
 
     def current_maps(self) -> Dict[str, torch.Tensor]:
         return {"albedo": self.p["albedo"].clamp(0, 1), "roughness": self.p["roughness"].clamp(0.07, 1), "metallic": self.p["metallic"].clamp(0, 1)}
+
+
+class FusedEnvPhase:
+    """Hot loop A (inverse_img_w_mi.py:236-254) with render, loss statistics, SaveBest / EarlyStopping decisions and the light
+    gradient in one `matpbr_env_phase_step` call.  `head()` produces `emitter.data` ([He,We,3] texels or [25,3] SH
+    coefficients) from its own torch parameters (the envmap MLP in the reference, `envmap_net(start_envmap)`, :238-239);
+    its backward and the optimiser step stay in torch, fed with d loss / d light from the device."""
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, head, optimizer: torch.optim.Optimizer, spp: int = 64,
+                 patience: int = 0, min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000):
+        import ctypes
+
+        from . import _lib, ops
+
+        self._ct, self._libmod, self.ops = ctypes, _lib, ops
+        self.scene, self.head, self.opt, self.spp = scene, head, optimizer, int(spp)
+        self.gt = gt_image.contiguous()
+        dev = self.gt.device
+        self.B = self.gt.shape[0] if self.gt.ndim == 4 else 1
+        self.H, self.W = self.gt.shape[-3], self.gt.shape[-2]
+        self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
+        self.pred = torch.empty_like(self.gt)
+        self.best_img = torch.zeros_like(self.gt)
+        self.best_env: Optional[torch.Tensor] = None
+        self.stats = ops.new_loss_stats(self.B, dev)
+        if best_mse is not None:
+            self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
+        self.lib = _lib.load()
+        self.ws = torch.empty(int(self.lib.matpbr_env_phase_workspace_bytes(self.H, self.W, self.B)) // 4 + 1, dtype=torch.float32, device=dev)
+        self.hist = torch.zeros((history_len, self.B), dtype=torch.float32, device=dev)
+        self.d_light = torch.zeros((self.B, 25, 3) if self.B > 1 else (25, 3), dtype=torch.float32, device=dev)
+        self.patience, self.min_delta, self.t = int(patience), float(min_delta), 0
+        self._prev_best = self.stats[:, ops.STAT_BEST].clone()
+
+    def step(self) -> None:
+        ct, sc, ops = self._ct, self.scene, self.ops
+        data = self.head()
+        light = sc.light_from_emitter(data)
+        lc = light.detach()
+        if self.B > 1 and lc.ndim == 2:
+            lc = lc.unsqueeze(0).expand(self.B, -1, -1)
+        lc = lc.contiguous()
+        shp = (self.B, self.H, self.W) if self.B > 1 else (self.H, self.W)
+        P = lambda t: None if t is None else ct.c_void_p(t.data_ptr())
+        cam = self._libmod.MatpbrCamera(sc.fov)
+        a, r, m, n = (t.contiguous() for t in (sc.a, sc.r.reshape(shp + (1,)), sc.m.reshape(shp + (1,)), sc.shading_normal()))
+        with torch.cuda.device(self.gt.device), ops._timed("env_phase_step"):
+            code = self.lib.matpbr_env_phase_step(P(a), P(r), P(m), P(n), P(lc), P(self.gt_srgb), P(self.pred), P(self.d_light), P(self.stats),
+                                                  P(self.best_img), P(self.hist), self.hist.shape[0], self.patience, self.min_delta, P(self.ws),
+                                                  self.ws.numel() * 4, self.H, self.W, self.B, self.spp, ct.byref(cam),
+                                                  ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
+        self._libmod.check(code, "matpbr_env_phase_step")
+        # SaveBest keeps the envmap of the best iteration (:247): device-side select on the improved flag, no host sync
+        improved = self.stats[:, ops.STAT_IMPROVED] > 0.5
+        d = data.detach()
+        if self.best_env is None:
+            self.best_env = d.clone()
+        else:
+            sel = improved.reshape((self.B,) + (1,) * (d.ndim - 1)) if (self.B > 1 and d.ndim == self.best_env.ndim and d.shape[0] == self.B) else improved.any()
+            self.best_env = torch.where(sel, d, self.best_env)
+        g = self.d_light if light.shape == self.d_light.shape else self.d_light.sum(0)
+        light.backward(g)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        self.t += 1
+
+    def poll(self) -> Dict[str, torch.Tensor]:
+        st, o = self.stats.cpu(), self.ops
+        return {"stopped": st[:, o.STAT_STOPPED] > 0.5, "iters": st[:, o.STAT_ITERS].to(torch.int64), "best_mse": st[:, o.STAT_BEST],
+                "mse": st[:, o.STAT_MSE], "loss": st[:, o.STAT_LOSS]}
+
+    def history(self) -> torch.Tensor:
+        return self.hist[: self.t]

@@ -27,7 +27,7 @@ class KernelTimer:
     active = None
 
     def __init__(self):
-        self.events = {"shade_fwd": [], "shade_bwd": [], "brdf_phase_step": []}
+        self.events = {"shade_fwd": [], "shade_bwd": [], "brdf_phase_step": [], "env_phase_step": []}
 
     def __enter__(self):
         KernelTimer.active = self

@@ -38,24 +38,37 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
 
     saver = _loop.DeviceSaveBest()
     env_raw = torch.zeros(tuple(env_size) + (3,), dtype=torch.float32, device=dev, requires_grad=True)
-    state = {"env_opt": None, "final_envmap": None, "phase": None, "last_mse": None}
+    state = {"final_envmap": None, "last_mse": None}
     say = log if log is not None else (lambda *_: None)
 
-    # ------------------------------------------------------------------ hot loop A (:236-254)
-    def env_step(loop_num: int, epoch: int, lr: float) -> float:
-        if epoch == 0:
-            state["env_opt"] = torch.optim.Adam([env_raw], lr=lr)                   # fresh Adam per loop (:225-229)
-        for gp in state["env_opt"].param_groups:
-            gp["lr"] = lr
-        envmap = torch.nn.functional.softplus(env_raw)
-        pred = _render.render_envmap(scene, envmap, spp)
-        total, mse, _ = _loss.env_loss(pred, gt)
-        total.backward()
-        saver.update(mse, albedo=mat["albedo"], roughness=mat["roughness"], metallic=mat["metallic"], envmap=envmap, rendered_img=pred)
-        state["env_opt"].step()
-        state["env_opt"].zero_grad(set_to_none=True)
-        state["last_mse"] = float(mse.detach())                                              # the reference syncs here too (:247,250)
-        return state["last_mse"]
+    # ------------------------------------------------------------------ hot loop A (:236-254), device-resident
+    def env_phase_runner(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
+        opt = torch.optim.Adam([env_raw], lr=lr_of(0))                              # fresh Adam per loop (:225-229)
+        ph = _loop.FusedEnvPhase(scene, gt, lambda: torch.nn.functional.softplus(env_raw), opt, spp=spp, patience=patience,
+                                 min_delta=min_delta, best_mse=saver.best_loss, history_len=max_epochs)
+        done, stop = 0, "num_epochs"
+        while done < max_epochs:
+            k = min(sync_every, max_epochs - done)
+            for _ in range(k):
+                for gp in opt.param_groups:
+                    gp["lr"] = lr_of(done)
+                ph.step()
+                done += 1
+            info = ph.poll()
+            if bool(info["stopped"].all()):
+                stop = "early_stop"
+                break
+        info = ph.poll()
+        iters = int(info["iters"].max())
+        prev = saver.best_loss if saver.best_loss is not None else torch.full_like(info["best_mse"].to(dev), float("inf"))
+        if bool((info["best_mse"].to(dev) < prev).any()):                           # SaveBest.update on improvement (:247)
+            saver.best_loss = torch.minimum(info["best_mse"].to(dev), prev)
+            saver.best.update(albedo=mat["albedo"].detach().clone(), roughness=mat["roughness"].detach().clone(),
+                              metallic=mat["metallic"].detach().clone(), envmap=ph.best_env.clone(), rendered_img=ph.best_img.clone())
+        elif "envmap" not in saver.best:
+            saver.best["envmap"] = ph.best_env.clone()
+        state["last_mse"] = float(ph.history()[iters - 1].max()) if iters > 0 else float("nan")
+        return iters - 1, stop, state["last_mse"]
 
     def on_env_phase_end(loop_num: int, save: bool) -> None:
         state["final_envmap"] = saver.best["envmap"].detach().clone()              # :296
@@ -101,10 +114,10 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             mat[key] = saver.best[key].detach().clone()
         params["shape.bsdf.a"], params["shape.bsdf.r"], params["shape.bsdf.m"] = mat["albedo"], mat["roughness"], mat["metallic"]
 
-    trace: List[TraceEvent] = run_schedule(list(optimize_order), env_step, None, opt_src=opt_src, opt_env_from=opt_env_from,
+    trace: List[TraceEvent] = run_schedule(list(optimize_order), None, None, opt_src=opt_src, opt_env_from=opt_env_from,
                                            num_epochs=num_epochs, on_env_phase_end=on_env_phase_end,
                                            on_brdf_phase_begin=on_brdf_phase_begin, on_brdf_part_end=on_brdf_part_end,
-                                           brdf_part_runner=brdf_part_runner)
+                                           brdf_part_runner=brdf_part_runner, env_phase_runner=env_phase_runner)
     with torch.no_grad():
         params["emitter.data"] = saver.best["envmap"]
         final = _render.render_w_brdf(scene, saver.best["albedo"], saver.best["roughness"], saver.best["metallic"], None, spp)

@@ -65,9 +65,12 @@ def run_schedule(optimize_order: Sequence[str], env_step: Callable[[int, int, fl
                  on_brdf_phase_begin: Optional[Callable[[int, str], None]] = None,
                  on_brdf_part_begin: Optional[Callable[[int, str], None]] = None,
                  on_brdf_part_end: Optional[Callable[[int, str], None]] = None, trace: Optional[List[TraceEvent]] = None,
-                 brdf_part_runner: Optional[Callable[[int, str, int, float, int], tuple]] = None) -> List[TraceEvent]:
-    """`brdf_part_runner(loop, part, patience, min_delta, num_epochs) -> (last_epoch, last_lr, stop)` may replace the
-    per-epoch BRDF loop with one that keeps the EarlyStopping state machine on the device (FusedBrdfPhase)."""
+                 brdf_part_runner: Optional[Callable[[int, str, int, float, int], tuple]] = None,
+                 env_phase_runner: Optional[Callable[[int, Callable[[int], float], int, float, int], tuple]] = None) -> List[TraceEvent]:
+    """`brdf_part_runner(loop, part, patience, min_delta, num_epochs) -> (last_epoch, last_lr, stop)` and
+    `env_phase_runner(loop, lr_of_epoch, patience, min_delta, max_epochs) -> (last_epoch, stop, last_loss_mse)` may replace the
+    per-epoch loops with ones that keep the EarlyStopping state machine on the device (FusedBrdfPhase / FusedEnvPhase);
+    `max_epochs` is 1 where the reference breaks after the first epoch."""
     trace = [] if trace is None else trace
     early_stopping_all = EarlyStopping(patience=2, min_delta=0.025)                    # :222
     loop_num = 0
@@ -78,7 +81,15 @@ def run_schedule(optimize_order: Sequence[str], env_step: Callable[[int, int, fl
         patience_env = 500 if opt_src == "skip" else 100                               # :231-234
         early_stopping = EarlyStopping(patience=patience_env, min_delta=0.01)          # :235
         loss_mse, stop, epoch, lr = float("nan"), "num_epochs", -1, ENV_LR_LATER
-        for epoch in range(num_epochs):
+        single = "loop<opt_env_from" if loop_num < opt_env_from else (
+            "rm not in opt_src" if ("rm" not in opt_src and loop_num == 1 and opt_src != "skip") else "")
+        if env_phase_runner is not None:
+            lr_of = (lambda e: ENV_LR_FIRST * LR_GAMMA ** (e // LR_STEP)) if loop_num == 1 else (lambda e: ENV_LR_LATER)
+            epoch, stop, loss_mse = env_phase_runner(loop_num, lr_of, patience_env, 0.01, 1 if single else num_epochs)
+            lr = lr_of(max(epoch, 0))
+            if stop != "early_stop" and single:
+                stop = single
+        for epoch in (range(num_epochs) if env_phase_runner is None else ()):
             lr = sched.lr if sched is not None else ENV_LR_LATER
             loss_mse = env_step(loop_num, epoch, lr)
             early_stopping(loss_mse)                                                   # :250

@@ -435,3 +435,47 @@ def test_optimize_envmap_ARMN_smoke():
     # 60 epochs at the reference learning rates (1e-3 / 3e-4) only start the fit; it must move in the right direction
     assert out["psnr"] > psnr0 + 0.3, (psnr0, out["psnr"])
     assert out["albedo"].shape == (H, W, 3) and out["envmap"].shape == (16, 32, 3)
+
+
+def test_fused_env_phase_matches_torch_composition():
+    """FusedEnvPhase (one matpbr_env_phase_step per iteration) against EnvPhase (autograd render + torch loss): texel light
+    through softplus + SH projection, Adam in torch on both sides."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    H = W = 48
+    spp = 8
+    sc = synthetic.make_scene(8, H, W)
+
+    def make_scene():
+        s = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+        p = render.traverse(s)
+        p["shape.bsdf.a"], p["shape.bsdf.r"], p["shape.bsdf.m"] = _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev)
+        return s
+
+    s_gt = make_scene()
+    with torch.no_grad():
+        gt = render.render_envmap(s_gt, _t(sc.light, dev), spp).clone()
+    torch.manual_seed(1)
+    raw0 = torch.randn(16, 32, 3, device=dev) * 0.3
+    # reference composition: parameters -> softplus -> render_envmap (projection inside the scene) -> env_loss -> backward
+    raw_a = raw0.clone().requires_grad_(True)
+    opt_a = torch.optim.Adam([raw_a], lr=1e-2)
+    sa = make_scene()
+    raw_b = raw0.clone().requires_grad_(True)
+    opt_b = torch.optim.Adam([raw_b], lr=1e-2)
+    fused = loop.FusedEnvPhase(make_scene(), gt, lambda: torch.nn.functional.softplus(raw_b), opt_b, spp=spp)
+    for it in range(4):
+        pred = render.render_envmap(sa, torch.nn.functional.softplus(raw_a), spp)
+        total, mse, l1 = loop._loss.env_loss(pred, gt)
+        total.backward()
+        opt_a.step()
+        opt_a.zero_grad()
+        fused.step()
+        st = fused.stats[0].cpu().numpy()
+        assert st[ops.STAT_MSE] == pytest.approx(float(mse.detach()), rel=2e-4), it
+        assert st[ops.STAT_LOSS] == pytest.approx(float(total.detach()), rel=2e-4), it
+    assert (raw_a - raw_b).abs().max().item() < 2e-4       # 4 Adam steps of 1e-2
+    assert fused.poll()["iters"].tolist() == [4]
+    assert fused.best_env.shape == (16, 32, 3)
+    assert_close(fused.pred, pred.detach().cpu().numpy(), rtol=5e-3, what="last render")
