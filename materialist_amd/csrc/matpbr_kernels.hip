@@ -201,21 +201,27 @@ __device__ __forceinline__ void load_light_regs(LightRegs& lr, const float* __re
     }
 }
 template <int Q>
-__device__ __forceinline__ f2 bcast(const LightRegs& lr) {  // {c'_Q, c'_Q}
-    f2 out;
-    if (Q & 1) asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[1,0]" : "=v"(out) : "v"(lr.c[Q >> 1]));
-    else asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[0,0] op_sel_hi:[0,0]" : "=v"(out) : "v"(lr.c[Q >> 1]));
-    return out;
-}
-template <int Q>
 __device__ __forceinline__ void fma_bcast(f2& acc, f2 b, const LightRegs& lr) {  // acc += b * c'_Q (both halves)
     if (Q & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(b), "v"(lr.c[Q >> 1]));
     else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(b), "v"(lr.c[Q >> 1]));
 }
+// out = b * c'_Q1 + c'_Q0 : opens the sum with the constant (k = 0) term at no extra instruction
+template <int Q1, int Q0>
+__device__ __forceinline__ f2 fma_bcast_init(f2 b, const LightRegs& lr) {
+    f2 out;
+    constexpr int s1 = Q1 & 1, s0 = Q0 & 1;
+    if (s1 == 0 && s0 == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(b), "v"(lr.c[Q1 >> 1]), "v"(lr.c[Q0 >> 1]));
+    if (s1 == 0 && s0 == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(out) : "v"(b), "v"(lr.c[Q1 >> 1]), "v"(lr.c[Q0 >> 1]));
+    if (s1 == 1 && s0 == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(out) : "v"(b), "v"(lr.c[Q1 >> 1]), "v"(lr.c[Q0 >> 1]));
+    if (s1 == 1 && s0 == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(out) : "v"(b), "v"(lr.c[Q1 >> 1]), "v"(lr.c[Q0 >> 1]));
+    return out;
+}
 template <int K>
 __device__ __forceinline__ void sh_term(const LightRegs& lr, f2 Bk, f2 L[3]) {
     if (K == 0) {
-        L[0] = bcast<0>(lr); L[1] = bcast<1>(lr); L[2] = bcast<2>(lr);
+        // B_0 = 1: its term is the addend of the k = 1 FMA below
+    } else if (K == 1) {
+        L[0] = fma_bcast_init<3, 0>(Bk, lr); L[1] = fma_bcast_init<4, 1>(Bk, lr); L[2] = fma_bcast_init<5, 2>(Bk, lr);
     } else {
         fma_bcast<3 * K>(L[0], Bk, lr); fma_bcast<3 * K + 1>(L[1], Bk, lr); fma_bcast<3 * K + 2>(L[2], Bk, lr);
     }
@@ -296,17 +302,21 @@ __global__ __launch_bounds__(kBlock, 2) void shade_fwd_kernel(const float* __res
     load_light_regs(lr, cp);
 
     f2 acc[3] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
+    // the table entry of sample s+1 is fetched (scalar load) while sample s is evaluated
+    float4 t = tab.diff[0];
     for (int s = 0; s < g.half; ++s) {
         Sample sm;
-        const float4 t = tab.diff[s];
+        const float4 tn = s + 1 < g.half ? tab.diff[s + 1] : tab.spec[0];
         diffuse_sample<false>(px, t.x, t.y, t.z, sm);
         fwd_accumulate(px, sm, lr, acc);
+        t = tn;
     }
     for (int s = 0; s < g.half; ++s) {
         Sample sm;
-        const float4 t = tab.spec[s];
+        const float4 tn = tab.spec[s + 1 < g.half ? s + 1 : s];
         specular_sample<false>(px, t.x, t.y, t.z, t.w, sm);
         fwd_accumulate(px, sm, lr, acc);
+        t = tn;
     }
     float tot = 0.0f;
 #pragma unroll
@@ -455,17 +465,20 @@ __global__ __launch_bounds__(kBlock, 2) void shade_bwd_kernel(const float* __res
         for (int k = 0; k < kNL; ++k) A.dc[k] = 0.0f;
     }
 
+    float4 t = tab.diff[0];
     for (int s = 0; s < g.half; ++s) {
         Sample sm;
-        const float4 t = tab.diff[s];
+        const float4 tn = s + 1 < g.half ? tab.diff[s + 1] : tab.spec[0];
         diffuse_sample<WANT_N>(px, t.x, t.y, t.z, sm);
         bwd_accumulate<WANT_MAT, WANT_N, WANT_LIGHT>(px, sm, lr, go, A);
+        t = tn;
     }
     for (int s = 0; s < g.half; ++s) {
         Sample sm;
-        const float4 t = tab.spec[s];
+        const float4 tn = tab.spec[s + 1 < g.half ? s + 1 : s];
         specular_sample<WANT_N>(px, t.x, t.y, t.z, t.w, sm);
         bwd_accumulate<WANT_MAT, WANT_N, WANT_LIGHT>(px, sm, lr, go, A);
+        t = tn;
     }
 
     if (act0) {
@@ -543,7 +556,7 @@ __global__ __launch_bounds__(kBlock, 2) void shade_bwd_kernel(const float* __res
 // BRDF-phase loss statistics (inverse_img_w_mi.py:388-418) and the Adam update (torch.optim.Adam, :359)
 // Two-pass reductions with fixed-order partial sums: bit-reproducible, no atomics.
 // =================================================================================================
-constexpr int kRedBlocks = 128;   // partial sums per image and pass
+constexpr int kRedBlocks = 768;   // partial sums per image and pass (3 workgroups per CU: the passes are latency-bound)
 
 __device__ __forceinline__ float block_sum(float v, float* s_buf) {   // all threads get the total
     v = wave_sum_to_lane63(v);
@@ -1132,7 +1145,7 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     const double bc1 = 1.0 - std::pow((double)b1, t), bc2 = 1.0 - std::pow((double)b2, t);
     Adam3 ad{{q.pa, q.pr, q.pm}, {q.d_a, q.d_r, q.d_m}, {q.adam_m[0], q.adam_m[1], q.adam_m[2]}, {q.adam_v[0], q.adam_v[1], q.adam_v[2]},
              {n3, n1, n1}};
-    hipLaunchKernelGGL(adam3_kernel, dim3(128, (unsigned)q.batch, 3), dim3(kBlock), 0, st, ad, q.stats, q.part_mask, (float)(lr / bc1), b1, b2,
+    hipLaunchKernelGGL(adam3_kernel, dim3(768, (unsigned)q.batch, 3), dim3(kBlock), 0, st, ad, q.stats, q.part_mask, (float)(lr / bc1), b1, b2,
                        eps, (float)(1.0 / std::sqrt(bc2)));
     return launch_status();
 }
