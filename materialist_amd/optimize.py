@@ -23,9 +23,12 @@ ROUGHNESS_SHIFT, METALLIC_SHIFT = 0.7, 0.05   # :183-184
 
 def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], optimize_order: Sequence[str] = ("arm",), spp: int = 64,
                          opt_env_from: int = 0, opt_src: str = "arm", scale_delta: float = 0.1, num_epochs: int = 5000,
-                         sync_every: int = 25, env_size=(16, 32), log=None) -> Dict[str, object]:
+                         sync_every: int = 25, env_size=(16, 32), log=None, frames=None, results_dir: Optional[str] = None,
+                         shading_normal: Optional[torch.Tensor] = None) -> Dict[str, object]:
     """mat: albedo [H,W,3], roughness [H,W,1], metallic [H,W,1], normal [H,W,3], gt_image [H,W,3] (optionally gt_envmap).
-    Returns the best maps / envmap / render, the final PSNR and the schedule trace."""
+    Returns the best maps / envmap / render, the final PSNR and the schedule trace.  `frames` (pipeline.FrameWriter) and
+    `results_dir` switch on the reference's file outputs: a frame at every host poll (the reference: every 10 epochs,
+    :257,438,559) and best_results/ after each phase (:302-303,465,590)."""
     dev = mat["gt_image"].device
     gt = mat["gt_image"].contiguous()
     mat = dict(mat)
@@ -55,6 +58,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 ph.step()
                 done += 1
             info = ph.poll()
+            if frames is not None and gt.ndim == 3:
+                frames.env_frame(loop_num, done - 1, gt, ph.pred, torch.nn.functional.softplus(env_raw).detach())
             if bool(info["stopped"].all()):
                 stop = "early_stop"
                 break
@@ -70,8 +75,20 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         state["last_mse"] = float(ph.history()[iters - 1].max()) if iters > 0 else float("nan")
         return iters - 1, stop, state["last_mse"]
 
+    def _save_results() -> None:
+        if results_dir is not None and gt.ndim == 3:
+            from .pipeline import save_results
+
+            nrm = mat.get("normal", shading_normal if shading_normal is not None else scene.shading_normal())
+            save_results(results_dir, saver.best, nrm)
+
     def on_env_phase_end(loop_num: int, save: bool) -> None:
         state["final_envmap"] = saver.best["envmap"].detach().clone()              # :296
+        if frames is not None and gt.ndim == 3 and "rendered_img" in saver.best:
+            frames.env_frame(loop_num, 9999, gt, saver.best["rendered_img"] if saver.best["rendered_img"].shape == gt.shape else gt,
+                             state["final_envmap"], final=True)                     # opt_env_img.png (:298)
+        if save:
+            _save_results()                                                         # :302-303
         say(f"loop {loop_num}: env phase done, mse {state['last_mse']:.5f}")
 
     def on_brdf_phase_begin(loop_num: int, which: str) -> None:                    # :317-342
@@ -93,6 +110,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             ph.run(k)
             done += k
             info = ph.poll()
+            if frames is not None and gt.ndim == 3:
+                frames.mat_frame(loop_num, part, done - 1, gt, _loss.linear_to_srgb((ph.pred * ph.stats[0, 0]).clamp_min(1e-8)),
+                                 ph.current_maps(), shading_normal if shading_normal is not None else scene.shading_normal())
             if bool(info["stopped"].all()):
                 stop = "early_stop"
                 break
@@ -113,6 +133,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         for key in ("albedo", "roughness", "metallic"):
             mat[key] = saver.best[key].detach().clone()
         params["shape.bsdf.a"], params["shape.bsdf.r"], params["shape.bsdf.m"] = mat["albedo"], mat["roughness"], mat["metallic"]
+        _save_results()                                                             # :465,590
 
     trace: List[TraceEvent] = run_schedule(list(optimize_order), None, None, opt_src=opt_src, opt_env_from=opt_env_from,
                                            num_epochs=num_epochs, on_env_phase_end=on_env_phase_end,

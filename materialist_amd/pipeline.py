@@ -1,0 +1,232 @@
+"""Pipeline head and output layout of `inverse_img_w_mi.py` (inverse_image :623-770, get_output_dir :82-104, the
+writers of optimize_envmap_ARMN :257-303,588-599) on top of `optimize.optimize_envmap_ARMN`.  SURVEY.md section 8(f1).
+
+What is NOT here yet: MaterialNet (f3).  The initial maps therefore come from `pred_dir` (files in the layout the
+reference writes: albedoPred.exr, normalPred.exr, roughnessPred.png, metallicPred.png, depthPred.exr) or, failing
+that, from a flat prior (albedo = the linearised image, roughness 0.5, metallic 0, fronto-parallel plane).  Video
+encoding (env_optimization.mp4 / mat_optimization.mp4) needs an encoder this image does not have; frames are kept.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+import warnings
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import loss as _loss
+from .imageio_exr import read_exr, write_exr
+from .imageio_hdr import read_hdr, write_hdr
+
+BASE_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT_DIR = os.path.join(BASE_DIR, "output_imgs")        # global_config.py:1-4
+
+
+def get_output_dir(save_name: str, save_path: Optional[str] = None) -> str:
+    """inverse_img_w_mi.py:82-104."""
+    if save_path:
+        if os.path.isabs(save_path):
+            return os.path.join(save_path, save_name)
+        return os.path.join(OUT_DIR, save_path, save_name)
+    return save_name if os.path.isabs(save_name) else os.path.join(OUT_DIR, save_name)
+
+
+def center_crop_and_resize(arr: np.ndarray, target_size=(512, 512)) -> np.ndarray:
+    """myutils/misc.py:10-34: centre crop to a square, drop alpha, uint8 -> [0,1], bilinear resize (align_corners=True)."""
+    h, w, _ = arr.shape
+    d = min(h, w)
+    sh, sw = (h - d) // 2, (w - d) // 2
+    crop = arr[sh:sh + d, sw:sw + d, :3]
+    if arr.dtype == np.uint8:
+        crop = crop.astype(np.float32) / 255.0
+    elif arr.dtype in (np.float32, np.float16):
+        crop = crop.astype(np.float32)
+    else:
+        raise ValueError("Unsupported data type, only uint8 and float16/32 are supported.")
+    t = torch.from_numpy(np.ascontiguousarray(crop)).permute(2, 0, 1).unsqueeze(0).to(torch.float32)
+    t = F.interpolate(t, size=tuple(target_size), mode="bilinear", align_corners=True)
+    return t.squeeze(0).permute(1, 2, 0).numpy()
+
+
+def load_image(path: str) -> np.ndarray:
+    if path.endswith(".exr"):
+        return read_exr(path)
+    if path.endswith(".hdr"):
+        return read_hdr(path)
+    from PIL import Image
+
+    return np.array(Image.open(path))
+
+
+def _srgb_encode(x: np.ndarray) -> np.ndarray:
+    """True sRGB transfer curve, what a PNG written from linear data carries (mi.util.write_bitmap, :677-678)."""
+    x = np.clip(x, 0.0, 1.0)
+    return np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1 / 2.4) - 0.055)
+
+
+def write_png(path: str, img: np.ndarray, linear: bool = False) -> None:
+    from PIL import Image
+
+    img = np.asarray(img, dtype=np.float32)
+    if img.ndim == 3 and img.shape[2] == 1:
+        img = img[..., 0]
+    if linear:
+        img = _srgb_encode(img)
+    Image.fromarray((np.clip(img, 0, 1) * 255.0 + 0.5).astype(np.uint8)).save(path)
+
+
+def flat_prior(img_linear: np.ndarray) -> Dict[str, np.ndarray]:
+    """Stand-in for MaterialNet.infer_image (dpt.py:219-241) until f3: no learned prior."""
+    H, W, _ = img_linear.shape
+    normal = np.zeros((H, W, 3), np.float32)
+    normal[..., 2] = 1.0
+    return {"albedo": np.clip(img_linear, 0, 1).astype(np.float32), "normal": normal, "roughness": np.full((H, W), 0.5, np.float32),
+            "metallic": np.zeros((H, W), np.float32), "depth": np.full((H, W), 2.0, np.float32)}
+
+
+def load_predictions(pred_dir: str, size) -> Dict[str, np.ndarray]:
+    g = lambda n: os.path.join(pred_dir, n)
+    from PIL import Image
+
+    gray = lambda p: np.asarray(Image.open(p).convert("L"), dtype=np.float32) / 255.0
+    out = {"albedo": read_exr(g("albedoPred.exr")), "normal": read_exr(g("normalPred.exr")), "roughness": gray(g("roughnessPred.png")),
+           "metallic": gray(g("metallicPred.png")), "depth": read_exr(g("depthPred.exr"))[..., 0]}
+    for k, v in out.items():
+        if v.shape[:2] != tuple(size):
+            vv = v if v.ndim == 3 else v[..., None]
+            vv = center_crop_and_resize(vv.astype(np.float32), size)
+            out[k] = vv if v.ndim == 3 else vv[..., 0]
+    return out
+
+
+class FrameWriter:
+    """env.png / env_frames / mat_frames / opt_env_img.png (inverse_img_w_mi.py:257-284,438-446,559-566)."""
+
+    def __init__(self, output_dir: str):
+        self.dir = output_dir
+        self.env_dir = os.path.join(output_dir, "env_frames")
+        self.mat_dir = os.path.join(output_dir, "mat_frames")
+        os.makedirs(self.env_dir, exist_ok=True)
+        os.makedirs(self.mat_dir, exist_ok=True)
+        self.env_frames: List[str] = []
+        self.mat_frames: List[str] = []
+
+    @staticmethod
+    def _env_panel(gt_srgb: torch.Tensor, pred_srgb: torch.Tensor, envmap: torch.Tensor) -> np.ndarray:
+        H, W, _ = gt_srgb.shape
+        canvas = torch.zeros_like(gt_srgb)
+        h, w = envmap.shape[:2]
+        dh = min(h * 3, H // 2)
+        dw = min(int(dh * (w / h)), W)
+        e = F.interpolate(envmap.permute(2, 0, 1).unsqueeze(0), size=(dh, dw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+        sh, sw = (H - dh) // 2, (W - dw) // 2
+        canvas[sh:sh + dh, sw:sw + dw] = e
+        return torch.cat([gt_srgb, pred_srgb, canvas], dim=1).clamp(0, 1).cpu().numpy()
+
+    def env_frame(self, loop_num: int, epoch: int, gt: torch.Tensor, pred: torch.Tensor, envmap: torch.Tensor, final: bool = False) -> None:
+        g = _loss.linear_to_srgb(gt.clamp_min(0))
+        p = _loss.linear_to_srgb(pred.clamp_min(0))
+        panel = self._env_panel(g, p, envmap)
+        write_png(os.path.join(self.dir, "env.png"), envmap.clamp(0, 1).cpu().numpy())
+        path = os.path.join(self.env_dir, f"opt_env_frame_{loop_num}_{epoch:04d}.png")
+        write_png(path, panel)
+        self.env_frames.append(path)
+        if final:
+            write_png(os.path.join(self.dir, "opt_env_img.png"), panel)
+
+    def mat_frame(self, loop_num: int, part: str, epoch: int, gt: torch.Tensor, pred_srgb: torch.Tensor, maps: Dict[str, torch.Tensor],
+                  normal: torch.Tensor) -> None:
+        tiles = [_loss.linear_to_srgb(gt.clamp_min(0)), pred_srgb, maps["albedo"], maps["roughness"].expand(-1, -1, 3),
+                 maps["metallic"].expand(-1, -1, 3), normal]
+        rows = [torch.cat(tiles[:3], dim=1), torch.cat(tiles[3:], dim=1)]           # make_grid(nrow=3) without padding
+        path = os.path.join(self.mat_dir, f"mat_frame_{loop_num}_{part}_{epoch:04d}.png")
+        write_png(path, torch.cat(rows, dim=0).clamp(0, 1).cpu().numpy())
+        self.mat_frames.append(path)
+
+
+def save_results(path: str, best: Dict[str, torch.Tensor], normal: torch.Tensor) -> None:
+    """SaveBest.save_results (myutils/misc.py:99-111): best_results/{envmap.hdr, albedo/roughness/metallic/rendered_img/normal.exr}."""
+    os.makedirs(path, exist_ok=True)
+    np_ = lambda t: t.detach().cpu().numpy()
+    if "envmap" in best:
+        write_hdr(os.path.join(path, "envmap.hdr"), np_(best["envmap"]))
+    write_exr(os.path.join(path, "albedo.exr"), np_(best["albedo"]))
+    write_exr(os.path.join(path, "roughness.exr"), np_(best["roughness"]))
+    write_exr(os.path.join(path, "metallic.exr"), np_(best["metallic"]))
+    if "rendered_img" in best:
+        write_exr(os.path.join(path, "rendered_img.exr"), np_(best["rendered_img"]))
+    write_exr(os.path.join(path, "normal.exr"), np_(normal))
+
+
+def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", opt_order: Sequence[str] = ("arm",), use_mask: bool = False,
+                  opt_env_from: int = 0, save_path: Optional[str] = None, model_name: str = "none", size: int = 512, spp: int = 64,
+                  num_epochs: int = 5000, pred_dir: Optional[str] = None, device: str = "cuda", sync_every: int = 10,
+                  log=print) -> Dict[str, object]:
+    """inverse_img_w_mi.py:623-770 (resolution-generic: `size`; `model_name` is honoured, F4)."""
+    from . import optimize, render
+
+    if model_name != "none":
+        raise NotImplementedError("--model_name pos_mlp needs PosMLP (SURVEY.md section 8 f2, not built yet); use --model_name none")
+    if "n" in "".join(opt_order):
+        raise NotImplementedError("optimising the normal map ('n' in --opt_order) is not wired into the fused loop yet")
+    if use_mask:
+        warnings.warn("--use_mask is not supported yet; continuing without mask", UserWarning)
+    log(f"Inverse image {img_inverse_path}")
+    output_dir = get_output_dir(save_name, save_path)
+    os.makedirs(os.path.join(output_dir, "best_results"), exist_ok=True)
+
+    img = center_crop_and_resize(load_image(img_inverse_path), (size, size))                      # :641-642
+    if not img_inverse_path.endswith(".exr"):
+        warnings.warn("The input image is in PNG/JPG format, assume it is sRGB, will convert to linear", UserWarning)
+        img = np.asarray(_loss.srgb_to_linear(torch.from_numpy(img)).numpy(), dtype=np.float32)  # :643-645
+
+    mat: Dict[str, torch.Tensor] = {}
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+    if opt_src != "skip" or list(opt_order) != ["skip"]:
+        pred = load_predictions(pred_dir, (size, size)) if pred_dir else flat_prior(img)
+        mat["gt_image"] = t(img)                                                                 # :663-670
+        mat["albedo"] = t(pred["albedo"]).clamp(0, 1)
+        mat["normal"] = t(pred["normal"])
+        mat["roughness"] = t(pred["roughness"]).unsqueeze(-1).clamp(0.07, 1)
+        mat["metallic"] = t(pred["metallic"]).unsqueeze(-1).clamp(0, 1)
+        depth = pred["depth"]
+        write_exr(os.path.join(output_dir, "albedoPred.exr"), pred["albedo"])                    # :672-678
+        write_exr(os.path.join(output_dir, "normalPred.exr"), pred["normal"])
+        write_png(os.path.join(output_dir, "roughnessPred.png"), pred["roughness"])
+        write_png(os.path.join(output_dir, "metallicPred.png"), pred["metallic"])
+        write_exr(os.path.join(output_dir, "depthPred.exr"), depth)
+        write_exr(os.path.join(output_dir, "gt_image.exr"), img)
+        write_png(os.path.join(output_dir, "gt_image.png"), img, linear=True)
+        config = {"img_path": img_inverse_path, "save_name": save_name, "opt_src": opt_src, "opt_order": list(opt_order),
+                  "use_mask": use_mask, "opt_env_from": opt_env_from, "model_name": model_name,
+                  "timestamp": time.strftime("%Y-%m-%d %H:%M:%S"), "image_size": list(img.shape[:2]), "spp": spp,
+                  "output_type": "armn" if "n" in str(list(opt_order)) else "arm", "use_mesh_normal": "n" not in str(list(opt_order))}
+        with open(os.path.join(output_dir, "config.json"), "w") as f:                            # :679-696
+            json.dump(config, f, indent=4)
+        depth = 2 * depth.max() - depth                                                          # :722 (MaterialNet predicts inverse depth)
+        if opt_env_from > 1:                                                                     # :729-735
+            p = os.path.join(output_dir, "best_results", "envmap.hdr")
+            if os.path.exists(p):
+                mat["gt_envmap"] = t(read_hdr(p))
+    else:                                                                                        # :737-749 resume from best_results
+        br = os.path.join(output_dir, "best_results")
+        mat["albedo"] = t(read_exr(os.path.join(br, "albedo.exr"))).clamp(0, 1)
+        mat["roughness"] = t(read_exr(os.path.join(br, "roughness.exr"))[..., :1]).clamp(0.07, 1)
+        mat["metallic"] = t(read_exr(os.path.join(br, "metallic.exr"))[..., :1]).clamp(0, 1)
+        mat["normal"] = t(read_exr(os.path.join(br, "normal.exr")))
+        mat["gt_image"] = t(img)
+        depth = read_exr(os.path.join(output_dir, "depthPred.exr"))[..., 0]
+        depth = 2 * depth.max() - depth
+
+    scene = render.load_estimated_mesh(t(depth), use_mesh_normal=True, device=device)           # :751-759
+    frames = FrameWriter(output_dir)
+    res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
+                                        num_epochs=num_epochs, sync_every=sync_every, log=log, frames=frames,
+                                        results_dir=os.path.join(output_dir, "best_results"), shading_normal=scene.geo_normal)
+    write_hdr(os.path.join(output_dir, "final_envmap.hdr"), res["envmap"].detach().cpu().numpy())   # :297
+    res["output_dir"] = output_dir
+    return res

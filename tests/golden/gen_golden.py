@@ -19,6 +19,7 @@ What each fixture pins (SURVEY.md §8c "golden vectors to commit"):
   world_to_screen.npz     perspective_projection_matrix + mi_world_to_screen   myutils/mi_plugin.py:585-595,645-671
   sh.npz                  computeK, basis via projection(), reconstImageFromSH myutils/computeSH.py:13-68,165-240
   misc.npz                EarlyStopping / SaveBest decisions, gamma           myutils/misc.py:37-111,163-170
+  misc_resize.npz         center_crop_and_resize                              myutils/misc.py:10-34
   envmaps.npz             decoded envmaps/0.hdr and output_imgs/*/best_results/envmap.hdr (data files)
 
 [ext] caveat: `mi.Frame3f(n).to_world` is Mitsuba's `coordinate_system` (Duff et al. 2017 branchless
@@ -380,6 +381,13 @@ def main():
     es_out["linear_to_srgb"] = _np(M.linear_to_srgb(x))
     es_out["srgb_to_linear"] = _np(M.srgb_to_linear(x))
     np.savez(os.path.join(OUT, "misc.npz"), **es_out)
+
+    # ---------------------------------------------------------------- center_crop_and_resize (pipeline head, misc.py:10-34)
+    rr = np.random.default_rng(11)
+    im_u8 = rr.integers(0, 256, (37, 53, 4), dtype=np.uint8)      # RGBA like examples/indoor1.png: alpha dropped, centre crop
+    im_f32 = rr.random((41, 29, 3), dtype=np.float32)
+    np.savez(os.path.join(OUT, "misc_resize.npz"), im_u8=im_u8, out_u8=M.center_crop_and_resize(im_u8, (16, 16)),
+             im_f32=im_f32, out_f32=M.center_crop_and_resize(im_f32, (24, 24)))
 
     # ---------------------------------------------------------------- envmap data files (RGBE decode is ours)
     sys.path.insert(0, os.path.join(OUT, "..", ".."))

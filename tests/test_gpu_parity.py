@@ -16,6 +16,7 @@ RTOL = 1e-3
 def _cuda():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    torch.manual_seed(20250629)   # every test draws its random tensors from a fixed stream
     return torch.device("cuda:0")
 
 
@@ -479,3 +480,36 @@ def test_fused_env_phase_matches_torch_composition():
     assert fused.poll()["iters"].tolist() == [4]
     assert fused.best_env.shape == (16, 32, 3)
     assert_close(fused.pred, pred.detach().cpu().numpy(), rtol=5e-3, what="last render")
+
+
+def test_inverse_image_writes_the_reference_output_layout(tmp_path):
+    """f1: the pipeline head + writers produce output_imgs/<name>/ as SURVEY.md App. D lists it (minus .ply / mp4)."""
+    from PIL import Image
+
+    from materialist_amd import pipeline
+
+    _cuda()
+    rng = np.random.default_rng(4)
+    img = (rng.random((40, 56, 3)) * 255).astype(np.uint8)
+    src = str(tmp_path / "in.png")
+    Image.fromarray(img).save(src)
+    res = pipeline.inverse_image(src, "case", opt_src="arm", opt_order=["rm", "a"], opt_env_from=0, save_path=str(tmp_path), size=32, spp=8,
+                                 num_epochs=12, sync_every=6, log=lambda *_: None)
+    out = res["output_dir"]
+    assert out == str(tmp_path / "case")
+    for name in ("albedoPred.exr", "normalPred.exr", "roughnessPred.png", "metallicPred.png", "depthPred.exr", "gt_image.exr", "gt_image.png",
+                 "config.json", "env.png", "final_envmap.hdr", "opt_env_img.png"):
+        assert os.path.exists(os.path.join(out, name)), name
+    assert sorted(os.listdir(os.path.join(out, "best_results"))) == ["albedo.exr", "envmap.hdr", "metallic.exr", "normal.exr",
+                                                                     "rendered_img.exr", "roughness.exr"]
+    assert len(os.listdir(os.path.join(out, "env_frames"))) >= 2 and len(os.listdir(os.path.join(out, "mat_frames"))) >= 2
+    import json
+
+    cfg = json.load(open(os.path.join(out, "config.json")))
+    assert set(cfg) == {"img_path", "save_name", "opt_src", "opt_order", "use_mask", "opt_env_from", "model_name", "timestamp", "image_size",
+                        "spp", "output_type", "use_mesh_normal"}
+    assert Image.open(os.path.join(out, "opt_env_img.png")).size == (96, 32)        # three panels side by side
+    # resume path (--opt_src skip, :737-749) reads what was written
+    res2 = pipeline.inverse_image(src, "case", opt_src="skip", opt_order=["skip"], save_path=str(tmp_path), size=32, spp=8, num_epochs=5,
+                                  sync_every=5, log=lambda *_: None)
+    assert res2["trace"][-1].stop == "skip"

@@ -237,3 +237,52 @@ def test_shard_range_partitions_exactly():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert shard_range(64, 8, 3) == (24, 32)   # BASELINE config 3: 8 images per GPU
+
+
+# ---------------------------------------------------------------------------------------- f1: pipeline head (host part)
+def test_center_crop_and_resize_matches_reference(golden_dir):
+    from materialist_amd.pipeline import center_crop_and_resize
+
+    g = np.load(os.path.join(golden_dir, "misc_resize.npz"))
+    np.testing.assert_allclose(center_crop_and_resize(g["im_u8"], (16, 16)), g["out_u8"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(center_crop_and_resize(g["im_f32"], (24, 24)), g["out_f32"], rtol=0, atol=1e-7)
+    with pytest.raises(ValueError):
+        center_crop_and_resize(np.zeros((4, 4, 3), np.float64), (2, 2))
+
+
+def test_output_dir_rules_and_writers(tmp_path):
+    from materialist_amd import pipeline
+    from materialist_amd.imageio_exr import read_exr, write_exr
+
+    # inverse_img_w_mi.py:82-104
+    assert pipeline.get_output_dir("x") == os.path.join(pipeline.OUT_DIR, "x")
+    assert pipeline.get_output_dir("/abs/x") == "/abs/x"
+    assert pipeline.get_output_dir("x", "sub") == os.path.join(pipeline.OUT_DIR, "sub", "x")
+    assert pipeline.get_output_dir("x", "/abs") == "/abs/x"
+    rng = np.random.default_rng(2)
+    for comp in ("none", "zips", "zip"):
+        for shape in ((19, 23, 3), (8, 8), (5, 7, 1)):
+            x = rng.normal(size=shape).astype(np.float32)
+            p = str(tmp_path / f"{comp}.exr")
+            write_exr(p, x, comp)
+            y = read_exr(p)
+            assert np.array_equal(y if x.ndim == 3 else y[..., 0], x)
+    best = {k: torch.rand(6, 6, c) for k, c in (("albedo", 3), ("roughness", 1), ("metallic", 1), ("rendered_img", 3))}
+    best["envmap"] = torch.rand(16, 32, 3)
+    pipeline.save_results(str(tmp_path / "best_results"), best, torch.rand(6, 6, 3))
+    assert sorted(os.listdir(tmp_path / "best_results")) == ["albedo.exr", "envmap.hdr", "metallic.exr", "normal.exr", "rendered_img.exr",
+                                                             "roughness.exr"]
+    np.testing.assert_array_equal(read_exr(str(tmp_path / "best_results" / "roughness.exr"))[..., 0], best["roughness"][..., 0].numpy())
+    pipeline.write_png(str(tmp_path / "a.png"), rng.random((4, 5, 3)), linear=True)
+    pr = pipeline.flat_prior(rng.random((6, 6, 3)).astype(np.float32))
+    assert pr["normal"][0, 0].tolist() == [0, 0, 1] and pr["depth"].shape == (6, 6)
+
+
+def test_cli_parses_the_reference_flags():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("cli", os.path.join(ROOT, "inverse_img_w_mi.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    a = cli.parse_args(["--img_inverse_path", "x.png", "--save_name", "s", "--opt_src", "arm", "--opt_order", "rm", "a", "--opt_env_from", "2"])
+    assert a.opt_order == ["rm", "a"] and a.opt_env_from == 2 and a.model_name == "none" and not a.use_mask
