@@ -97,7 +97,8 @@ size_t matpbr_shade_bwd_workspace_bytes(int H, int W, int batch, int n_light);
 size_t matpbr_brdf_loss_workspace_bytes(int batch);
 int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr,
                            const float* pm, const float* a0, const float* r0, const float* m0, float scale_delta,
-                           float* stats, void* workspace, size_t workspace_bytes, int H, int W, int batch, void* stream);
+                           float* stats, void* workspace, size_t workspace_bytes, int H, int W, int batch, uint32_t flags,
+                           void* stream);   /* flags: MATPBR_PART_* of the maps being optimised (none set = all three) */
 int matpbr_shade_bwd_brdf_loss(const float* pa, const float* pr, const float* pm, const float* n, const float* light,
                                int light_kind, int n_light, const float* pred, const float* gt_srgb, const float* stats,
                                const float* a0, const float* r0, const float* m0, float scale_delta, float* d_a, float* d_r,

@@ -41,7 +41,7 @@ SIGNATURES = {
     "matpbr_shade_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "matpbr_brdf_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_brdf_loss_stats": (ctypes.c_int, [_c_f] * 9 + [ctypes.c_float, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
-                                             ctypes.c_int, ctypes.c_void_p]),
+                                             ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]),
     "matpbr_shade_bwd_brdf_loss": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float] + [_c_f] * 7 +
                                    [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera), ctypes.c_uint32,
                                     ctypes.c_void_p]),

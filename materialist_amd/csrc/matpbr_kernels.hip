@@ -1058,9 +1058,14 @@ int matpbr_normals_from_depth(const float* depth, float* out_n, int H, int W, in
 
 size_t matpbr_brdf_loss_workspace_bytes(int batch) { return batch > 0 ? (size_t)batch * kRedBlocks * 5 * sizeof(float) : 0; }
 
+static unsigned part_mask_of(uint32_t flags) {
+    const unsigned all = MATPBR_PART_A | MATPBR_PART_R | MATPBR_PART_M;
+    return (flags & all) ? (flags & all) : all;   // no part bit = all three maps (optimize_part 'arm')
+}
+
 int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr, const float* pm,
                            const float* a0, const float* r0, const float* m0, float scale_delta, float* stats, void* workspace,
-                           size_t workspace_bytes, int H, int W, int batch, void* stream) {
+                           size_t workspace_bytes, int H, int W, int batch, uint32_t flags, void* stream) {
     if (!pred || !gt || !gt_srgb || !pa || !pr || !pm || !a0 || !r0 || !m0 || !stats || H <= 0 || W <= 0 || batch <= 0)
         return MATPBR_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < matpbr_brdf_loss_workspace_bytes(batch)) return MATPBR_ERR_WORKSPACE;
@@ -1073,7 +1078,7 @@ int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_s
     hipLaunchKernelGGL(loss_sums2_kernel<0>, grid, dim3(kBlock), 0, st, pred, gt_srgb, stats, pa, a0, pr, r0, pm, m0, part, n3, n1,
                        (const float*)nullptr, 0);
     hipLaunchKernelGGL(loss_final2_kernel<0>, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks, 1.0f / (float)n3,
-                       1.0f / (float)n1, scale_delta, (unsigned)(MATPBR_PART_A | MATPBR_PART_R | MATPBR_PART_M), 0, 0.0f,
+                       1.0f / (float)n1, scale_delta, part_mask_of(flags), 0, 0.0f,
                        (const float*)nullptr, 0, (float*)nullptr, 0, batch);
     return launch_status();
 }
@@ -1083,7 +1088,6 @@ int matpbr_shade_bwd_brdf_loss(const float* pa, const float* pr, const float* pm
                                const float* r0, const float* m0, float scale_delta, float* d_a, float* d_r, float* d_m, float* best_a,
                                float* best_r, float* best_m, float* best_img, int H, int W, int batch, int spp, const MatpbrCamera* cam,
                                uint32_t flags, void* stream) {
-    (void)flags;
     if (!pa || !pr || !pm || !n || !light || !pred || !gt_srgb || !stats || !a0 || !r0 || !m0 || !d_a || !d_r || !d_m || batch <= 0)
         return MATPBR_ERR_INVALID_ARG;
     if (light_kind != MATPBR_LIGHT_SH25 || n_light != MATPBR_NSH) return MATPBR_ERR_INVALID_ARG;
@@ -1093,7 +1097,7 @@ int matpbr_shade_bwd_brdf_loss(const float* pa, const float* pr, const float* pm
     SampleTable tab;
     fill_sample_table(spp, tab);
     FusedLoss fl{pred, gt_srgb, stats, a0, r0, m0, best_a, best_r, best_m, best_img, scale_delta, 1.0f / (3.0f * (float)H * (float)W),
-                 1.0f / ((float)H * (float)W), (unsigned)(MATPBR_PART_A | MATPBR_PART_R | MATPBR_PART_M), 0};
+                 1.0f / ((float)H * (float)W), part_mask_of(flags), 0};
     dim3 grid((unsigned)grid_blocks(H, W), (unsigned)batch);
     hipLaunchKernelGGL((shade_bwd_kernel<true, false, false, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, pa, pr, pm, n, light,
                        (const float*)nullptr, d_a, d_r, d_m, (float*)nullptr, (float*)nullptr, g, tab, fl);

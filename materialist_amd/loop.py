@@ -347,3 +347,96 @@ class FusedEnvPhase:
 
     def history(self) -> torch.Tensor:
         return self.hist[: self.t]
+
+
+class PosMlpBrdfPhase:
+    """Hot loop B in the reference's default `pos_mlp` mode (inverse_img_w_mi.py:470-590): the material maps are the output of
+    a residual coordinate MLP (`brdf_net(start_arm)`, :493-506); everything downstream of the maps -- render, loss
+    statistics, loss backward with regularisers / clamp gating, SaveBest decision -- runs in libmatpbr.so, and the
+    gradients w.r.t. the maps are handed back to torch to traverse the MLP.  AdamW + StepLR as in :470-471,553-554."""
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_arm: torch.Tensor, fixed: Dict[str, torch.Tensor],
+                 optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000):
+        from . import ops
+
+        if not scene.use_mesh_normal or "n" in optimize_part:
+            raise NotImplementedError("PosMlpBrdfPhase covers output_type 'arm' (geometric normals)")
+        self.ops, self.scene, self.net, self.part = ops, scene, net, optimize_part
+        self.spp, self.scale_delta = int(spp), float(scale_delta)
+        self.gt = gt_image.contiguous()
+        self.H, self.W = self.gt.shape[0], self.gt.shape[1]
+        self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
+        self.start_arm = start_arm.detach()
+        # maps that this part does not optimise keep the values they had when the part started (:497-504)
+        self.fixed = {k: v.detach().contiguous() for k, v in fixed.items()}
+        # regulariser anchors: albedo_ori / roughness_ori / metallic_ori (:189-201)
+        self.orig = {"albedo": self.start_arm[:, 0:3].reshape(self.H, self.W, 3).contiguous(),
+                     "roughness": (self.start_arm[:, 3:4]).reshape(self.H, self.W, 1).contiguous(),
+                     "metallic": self.start_arm[:, 4:5].reshape(self.H, self.W, 1).contiguous()}
+        self.opt = torch.optim.AdamW(net.parameters(), lr=lr)
+        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)
+        dev = self.gt.device
+        self.stats = ops.new_loss_stats(1, dev)
+        if best_mse is not None:
+            self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
+        self.es = EarlyStopping(patience, min_delta) if patience > 0 else None
+        self.pred = torch.empty_like(self.gt)
+        self.g = {"albedo": torch.empty(self.H, self.W, 3, device=dev), "roughness": torch.empty(self.H, self.W, 1, device=dev),
+                  "metallic": torch.empty(self.H, self.W, 1, device=dev)}
+        self.best = {k: v.clone() for k, v in self.fixed.items()}
+        self.best_img = torch.zeros_like(self.gt)
+        self.best_weights = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        self.hist = torch.zeros((history_len, 1), dtype=torch.float32, device=dev)
+        self.ws = None
+        self.t = 0
+
+    def maps_from_net(self):
+        arm = self.net(self.start_arm)                                                   # :493
+        H, W = self.H, self.W
+        raw = {"albedo": arm[:, 0:3].reshape(H, W, 3), "roughness": (arm[:, 3:4] * 0.93 + 0.07).reshape(H, W, 1),
+               "metallic": arm[:, 4:5].reshape(H, W, 1)}                                 # :494-496 (the clamps run inside the kernels)
+        keys = {"a": "albedo", "r": "roughness", "m": "metallic"}
+        live = [keys[c] for c in self.part if c in keys]
+        maps = {k: (raw[k].contiguous() if k in live else self.fixed[k]) for k in raw}
+        return maps, live
+
+    def step(self) -> None:
+        ops, sc = self.ops, self.scene
+        maps, live = self.maps_from_net()
+        d = {k: v.detach() for k, v in maps.items()}
+        n, light = sc.shading_normal(), sc.light.detach().contiguous()
+        ops.shade_fwd(d["albedo"], d["roughness"], d["metallic"], n, light, self.spp, sc.fov, clamp_params=True, out=self.pred)
+        if self.ws is None:
+            self.ws = torch.empty(int(_lib_ws(1)) // 4, dtype=torch.float32, device=self.gt.device)
+        ops.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
+                            self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part)
+        ops.shade_bwd_brdf_loss(d["albedo"], d["roughness"], d["metallic"], n, light, self.pred, self.gt_srgb, self.stats,
+                                self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.spp,
+                                self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
+                                self.best["metallic"], self.best_img, sc.fov, optimize_part=self.part)
+        torch.autograd.backward([maps[k] for k in live], [self.g[k] for k in live])      # :544
+        improved = self.stats[0, ops.STAT_IMPROVED] > 0.5                                 # SaveBest keeps the weights too (:546-547)
+        for k, v in self.net.state_dict().items():
+            self.best_weights[k] = torch.where(improved, v.detach(), self.best_weights[k])
+        if self.t < self.hist.shape[0]:
+            self.hist[self.t].copy_(self.stats[:, ops.STAT_MSE])
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        if self.opt.param_groups[0]["lr"] > 1.5e-4:                                       # :553-554
+            self.sched.step()
+        self.t += 1
+
+    def step_and_check(self) -> bool:
+        """One iteration followed by the host EarlyStopping check of the reference (:550); True when the part should stop."""
+        self.step()
+        if self.es is None:
+            return False
+        self.es(float(self.stats[0, self.ops.STAT_MSE]))
+        return self.es.early_stop
+
+
+def _lib_ws(batch: int) -> int:
+    from . import _lib
+
+    return _lib.load().matpbr_brdf_loss_workspace_bytes(int(batch))

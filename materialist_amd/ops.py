@@ -241,8 +241,12 @@ def new_loss_stats(batch: int, device) -> torch.Tensor:
     return st
 
 
+def part_mask(optimize_part: str) -> int:
+    return sum({"a": PART_A, "r": PART_R, "m": PART_M}.get(ch, 0) for ch in optimize_part)
+
+
 def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: float, stats: torch.Tensor,
-                    workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    workspace: Optional[torch.Tensor] = None, optimize_part: str = "arm") -> torch.Tensor:
     """Fills `stats` [B, STATS_STRIDE] in place (ratio, mse, l1, l1/mse, regulariser L1s, loss, improved, best_mse)."""
     lib = _lib.load()
     pred = _dev(pred, "pred", (3,))
@@ -253,13 +257,13 @@ def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: floa
         workspace = torch.empty(need // 4, dtype=torch.float32, device=pred.device)
     with torch.cuda.device(pred.device):
         code = lib.matpbr_brdf_loss_stats(_ptr(pred), *[_ptr(t) for t in ts], float(scale_delta), _ptr(stats), _ptr(workspace),
-                                          workspace.numel() * 4, H, W, B, _stream(pred))
+                                          workspace.numel() * 4, H, W, B, part_mask(optimize_part), _stream(pred))
     _lib.check(code, "matpbr_brdf_loss_stats")
     return stats
 
 
 def shade_bwd_brdf_loss(pa, pr, pm, n, light, pred, gt_srgb, stats, a0, r0, m0, scale_delta: float, spp: int, d_a, d_r, d_m,
-                        best_a=None, best_r=None, best_m=None, best_img=None, fov_x_deg: float = 35.0) -> None:
+                        best_a=None, best_r=None, best_m=None, best_img=None, fov_x_deg: float = 35.0, optimize_part: str = "arm") -> None:
     """Backward of the fused BRDF-phase loss into preallocated d_a/d_r/d_m (see include/matpbr.h)."""
     lib = _lib.load()
     pa = _dev(pa, "pa", (3,))
@@ -269,7 +273,7 @@ def shade_bwd_brdf_loss(pa, pr, pm, n, light, pred, gt_srgb, stats, a0, r0, m0, 
         code = lib.matpbr_shade_bwd_brdf_loss(_ptr(pa), _ptr(pr), _ptr(pm), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(pred), _ptr(gt_srgb),
                                               _ptr(stats), _ptr(a0), _ptr(r0), _ptr(m0), float(scale_delta), _ptr(d_a), _ptr(d_r), _ptr(d_m),
                                               _ptr(best_a), _ptr(best_r), _ptr(best_m), _ptr(best_img), H, W, B, check_spp(spp),
-                                              ctypes.byref(cam), 0, _stream(pa))
+                                              ctypes.byref(cam), part_mask(optimize_part), _stream(pa))
     _lib.check(code, "matpbr_shade_bwd_brdf_loss")
 
 

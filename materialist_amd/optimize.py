@@ -24,7 +24,7 @@ ROUGHNESS_SHIFT, METALLIC_SHIFT = 0.7, 0.05   # :183-184
 def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], optimize_order: Sequence[str] = ("arm",), spp: int = 64,
                          opt_env_from: int = 0, opt_src: str = "arm", scale_delta: float = 0.1, num_epochs: int = 5000,
                          sync_every: int = 25, env_size=(16, 32), log=None, frames=None, results_dir: Optional[str] = None,
-                         shading_normal: Optional[torch.Tensor] = None) -> Dict[str, object]:
+                         shading_normal: Optional[torch.Tensor] = None, model_name: str = "none") -> Dict[str, object]:
     """mat: albedo [H,W,3], roughness [H,W,1], metallic [H,W,1], normal [H,W,3], gt_image [H,W,3] (optionally gt_envmap).
     Returns the best maps / envmap / render, the final PSNR and the schedule trace.  `frames` (pipeline.FrameWriter) and
     `results_dir` switch on the reference's file outputs: a frame at every host poll (the reference: every 10 epochs,
@@ -40,14 +40,30 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
     params["shape.bsdf.a"], params["shape.bsdf.r"], params["shape.bsdf.m"] = mat["albedo"], mat["roughness"], mat["metallic"]
 
     saver = _loop.DeviceSaveBest()
-    env_raw = torch.zeros(tuple(env_size) + (3,), dtype=torch.float32, device=dev, requires_grad=True)
     state = {"final_envmap": None, "last_mse": None}
+    if model_name == "pos_mlp":                                                     # :114-124,159-172,179-207
+        from . import posmlp
+
+        if gt.ndim != 3:
+            raise NotImplementedError("pos_mlp mode optimises one image per call")
+        env_net = posmlp.envmap_net().to(dev)
+        start_envmap = torch.ones(env_size[0] * env_size[1], 3, device=dev)
+        env_params = list(env_net.parameters())
+        env_head = lambda: env_net(start_envmap).reshape(tuple(env_size) + (3,))
+        brdf_net = posmlp.brdf_net("arm").to(dev)
+        start_arm = torch.cat([mat["albedo"].reshape(-1, 3), mat["roughness"].reshape(-1, 1), mat["metallic"].reshape(-1, 1)], dim=-1).clamp(0, 1)
+    elif model_name == "none":
+        env_raw = torch.zeros(tuple(env_size) + (3,), dtype=torch.float32, device=dev, requires_grad=True)
+        env_params = [env_raw]
+        env_head = lambda: torch.nn.functional.softplus(env_raw)
+    else:
+        raise ValueError("model_name should be 'none' or 'pos_mlp'")
     say = log if log is not None else (lambda *_: None)
 
     # ------------------------------------------------------------------ hot loop A (:236-254), device-resident
     def env_phase_runner(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
-        opt = torch.optim.Adam([env_raw], lr=lr_of(0))                              # fresh Adam per loop (:225-229)
-        ph = _loop.FusedEnvPhase(scene, gt, lambda: torch.nn.functional.softplus(env_raw), opt, spp=spp, patience=patience,
+        opt = torch.optim.Adam(env_params, lr=lr_of(0))                             # fresh Adam per loop (:225-229)
+        ph = _loop.FusedEnvPhase(scene, gt, env_head, opt, spp=spp, patience=patience,
                                  min_delta=min_delta, best_mse=saver.best_loss, history_len=max_epochs)
         done, stop = 0, "num_epochs"
         while done < max_epochs:
@@ -59,7 +75,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 done += 1
             info = ph.poll()
             if frames is not None and gt.ndim == 3:
-                frames.env_frame(loop_num, done - 1, gt, ph.pred, torch.nn.functional.softplus(env_raw).detach())
+                frames.env_frame(loop_num, done - 1, gt, ph.pred, env_head().detach())
             if bool(info["stopped"].all()):
                 stop = "early_stop"
                 break
@@ -100,7 +116,34 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         state["envmap4render"] = env.detach()
 
     # ------------------------------------------------------------------ hot loop B (:347-468), device-resident
+    def brdf_part_runner_mlp(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
+        ph = _loop.PosMlpBrdfPhase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in ("albedo", "roughness", "metallic")},
+                                   optimize_part=part, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
+                                   best_mse=saver.best_loss, history_len=n_epochs)
+        stop, it = "num_epochs", 0
+        for it in range(n_epochs):
+            if ph.step_and_check():                                                 # per-epoch host check, as the reference (:550)
+                stop = "early_stop"
+                break
+            if frames is not None and it % 10 == 0:
+                frames.mat_frame(loop_num, part, it, gt, _loss.linear_to_srgb((ph.pred * ph.stats[0, 0]).clamp_min(1e-8)),
+                                 {k: ph.best[k] for k in ("albedo", "roughness", "metallic")},
+                                 shading_normal if shading_normal is not None else scene.shading_normal())
+        best = ph.stats[:, ph.ops.STAT_BEST].clone()
+        prev = saver.best_loss if saver.best_loss is not None else torch.full_like(best, float("inf"))
+        if bool((best < prev).any()):
+            saver.best_loss = torch.minimum(best, prev)
+            for k_ in ("albedo", "roughness", "metallic"):
+                saver.best[k_] = ph.best[k_].clone()
+            saver.best["rendered_img"] = ph.best_img.clone()
+            saver.best["envmap"] = state["envmap4render"].clone()
+            brdf_net.load_state_dict(ph.best_weights)                               # :586-587
+        say(f"loop {loop_num}: part {part!r} (pos_mlp) ran {it + 1} iterations ({stop}), best mse {float(best.min()):.5f}")
+        return it, ph.opt.param_groups[0]["lr"], stop
+
     def brdf_part_runner(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
+        if model_name == "pos_mlp":
+            return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
         ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], optimize_part=part, spp=spp,
                                   scale_delta=scale_delta, patience=patience, min_delta=min_delta,
                                   best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs)

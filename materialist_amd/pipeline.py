@@ -169,8 +169,8 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
     """inverse_img_w_mi.py:623-770 (resolution-generic: `size`; `model_name` is honoured, F4)."""
     from . import optimize, render
 
-    if model_name != "none":
-        raise NotImplementedError("--model_name pos_mlp needs PosMLP (SURVEY.md section 8 f2, not built yet); use --model_name none")
+    if model_name not in ("none", "pos_mlp"):
+        raise ValueError("model_name should be 'none' or 'pos_mlp'")
     if "n" in "".join(opt_order):
         raise NotImplementedError("optimising the normal map ('n' in --opt_order) is not wired into the fused loop yet")
     if use_mask:
@@ -226,7 +226,8 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
     frames = FrameWriter(output_dir)
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
                                         num_epochs=num_epochs, sync_every=sync_every, log=log, frames=frames,
-                                        results_dir=os.path.join(output_dir, "best_results"), shading_normal=scene.geo_normal)
+                                        results_dir=os.path.join(output_dir, "best_results"), shading_normal=scene.geo_normal,
+                                        model_name=model_name)
     write_hdr(os.path.join(output_dir, "final_envmap.hdr"), res["envmap"].detach().cpu().numpy())   # :297
     res["output_dir"] = output_dir
     return res

@@ -20,6 +20,7 @@ What each fixture pins (SURVEY.md §8c "golden vectors to commit"):
   sh.npz                  computeK, basis via projection(), reconstImageFromSH myutils/computeSH.py:13-68,165-240
   misc.npz                EarlyStopping / SaveBest decisions, gamma           myutils/misc.py:37-111,163-170
   misc_resize.npz         center_crop_and_resize                              myutils/misc.py:10-34
+  posmlp.npz              PosMLP forward + gradients for fixed weights        mymodels/mlps.py:129-251
   envmaps.npz             decoded envmaps/0.hdr and output_imgs/*/best_results/envmap.hdr (data files)
 
 [ext] caveat: `mi.Frame3f(n).to_world` is Mitsuba's `coordinate_system` (Duff et al. 2017 branchless
@@ -381,6 +382,29 @@ def main():
     es_out["linear_to_srgb"] = _np(M.linear_to_srgb(x))
     es_out["srgb_to_linear"] = _np(M.srgb_to_linear(x))
     np.savez(os.path.join(OUT, "misc.npz"), **es_out)
+
+    # ---------------------------------------------------------------- PosMLP (f2, mymodels/mlps.py:129-251)
+    import mymodels.mlps as ML  # noqa: E402
+
+    pos = {}
+    for tag, kw, npts, cin in (("env", dict(in_dims=5, out_dims=3, multires_view=2, output_type="envmap", color_ch=3), 512, 3),
+                               ("arm", dict(in_dims=7, out_dims=5, multires_view=2, output_type="arm", color_ch=5), 576, 5),
+                               ("armn", dict(in_dims=10, out_dims=8, multires_view=0, output_type="armn", color_ch=8), 576, 8)):
+        torch.manual_seed(hash(tag) % 1000 if False else {"env": 1, "arm": 2, "armn": 3}[tag])
+        net = ML.PosMLP(dims=[64] * 4, skip_connection=[1, 3], weight_norm=False, **kw)   # width 64 keeps the fixture small
+        net.lin4.weight.data.normal_(0, 0.05)      # the zero-initialised last layer would make the test vacuous
+        net.lin4.bias.data.normal_(0, 0.05)
+        img_in = torch.rand(npts, cin, generator=g).requires_grad_(True)
+        out = net(img_in)
+        wgt = torch.randn(out.shape, generator=g)
+        (out * wgt).sum().backward()
+        for k_, v_ in net.state_dict().items():
+            pos[f"{tag}.sd.{k_}"] = _np(v_)
+        pos[f"{tag}.in"], pos[f"{tag}.out"], pos[f"{tag}.w"] = _np(img_in), _np(out), _np(wgt)
+        pos[f"{tag}.d_in"] = _np(img_in.grad)
+        pos[f"{tag}.d_lin0_w"] = _np(net.lin0.linear.weight.grad)
+        pos[f"{tag}.d_lin4_b"] = _np(net.lin4.bias.grad)
+    np.savez_compressed(os.path.join(OUT, "posmlp.npz"), **pos)
 
     # ---------------------------------------------------------------- center_crop_and_resize (pipeline head, misc.py:10-34)
     rr = np.random.default_rng(11)

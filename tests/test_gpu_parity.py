@@ -513,3 +513,42 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     res2 = pipeline.inverse_image(src, "case", opt_src="skip", opt_order=["skip"], save_path=str(tmp_path), size=32, spp=8, num_epochs=5,
                                   sync_every=5, log=lambda *_: None)
     assert res2["trace"][-1].stop == "skip"
+
+
+def test_pos_mlp_phase_matches_torch_composition():
+    """f2 in the loop: PosMlpBrdfPhase (maps from the residual MLP, render/loss/backward in libmatpbr.so, gradients handed back
+    to torch) against the same iteration composed from torch ops around the autograd render (inverse_img_w_mi.py:493-554)."""
+    import copy
+
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+
+    dev = _cuda()
+    H = W = 32          # 1024 points: a square image for PosMLP
+    spp = 8
+    sc = synthetic.make_scene(9, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp).clone()
+    a0, r0, m0 = _t(sc.init_albedo, dev), _t(sc.init_roughness, dev), _t(sc.init_metallic, dev)
+    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).clamp(0, 1)
+    net_a = posmlp.brdf_net("arm", hidden=(64, 64, 64, 64)).to(dev)
+    net_a.lin4.weight.data.normal_(0, 0.02)
+    net_b = copy.deepcopy(net_a)
+    ph = loop.PosMlpBrdfPhase(scene, gt, net_b, start_arm, {"albedo": a0, "roughness": r0, "metallic": m0}, optimize_part="rm", spp=spp)
+    opt = torch.optim.AdamW(net_a.parameters(), lr=3e-4)
+    orig = {"roughness": start_arm[:, 3:4].reshape(H, W, 1), "metallic": start_arm[:, 4:5].reshape(H, W, 1)}
+    for it in range(3):
+        arm = net_a(start_arm)
+        r = (arm[:, 3:4] * 0.93 + 0.07).clamp(0, 1).reshape(H, W, 1)
+        m = arm[:, 4:5].clamp(0, 1).reshape(H, W, 1)
+        pred = render.render_w_brdf(scene, a0, r, m, None, spp)
+        total, mse, _, _ = loop._loss.brdf_loss(pred, gt, {"roughness": r, "metallic": m}, orig, 0.1)
+        total.backward()
+        opt.step()
+        opt.zero_grad()
+        ph.step()
+        assert float(ph.stats[0, ops.STAT_MSE]) == pytest.approx(float(mse.detach()), rel=3e-4), it
+        assert float(ph.stats[0, ops.STAT_LOSS]) == pytest.approx(float(total.detach()), rel=3e-4), it
+    for (ka, va), (kb, vb) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+        assert (va - vb).abs().max().item() < 2e-5, ka
