@@ -145,6 +145,11 @@ int matpbr_env_phase_step(const float* a, const float* r, const float* m, const 
                           int hist_len, int es_patience, float es_min_delta, void* workspace, size_t workspace_bytes, int H,
                           int W, int batch, int spp, const MatpbrCamera* cam, void* stream);
 
+/* Column sums of a row-major [M, N] fp32 matrix -> out[N]: the bias gradient of the PosMLP layers over M = H*W points
+ * (mymodels/mlps.py:102-103 under autograd).  Deterministic two-pass; workspace of matpbr_column_sum_workspace_bytes(N). */
+size_t matpbr_column_sum_workspace_bytes(int N);
+int matpbr_column_sum(const float* x, float* out, long M, int N, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Plugin face, N independent lanes, AoS [N,3] vectors (the reference traces these over Dr.Jit arrays).
  *   matpbr_eval_brdf   = MatDiffBSDF.eval_pdf / eval_brdf     myutils/mi_plugin.py:1372-1427,1449-1460
  *                        (wi = light direction, wo = view direction; f already includes cos)

@@ -715,6 +715,41 @@ __global__ __launch_bounds__(kBlock) void adam3_kernel(const Adam3 t, const floa
     }
 }
 
+// Column sums of a row-major [M, N] matrix (N <= 1024): the bias gradient of a Linear layer over M = H*W points.
+// Pass 1: workgroup b sums rows [b*rows_per, ...) with thread t owning columns t, t+256, ... (coalesced row reads);
+// pass 2 adds the per-workgroup partials in fixed order.  PyTorch's reduce_kernel and rocBLAS gemv both take
+// milliseconds on this shape (262144 x 256); this is bandwidth-bound.
+__global__ __launch_bounds__(kBlock) void colsum_pass1_kernel(const float* __restrict__ x, float* __restrict__ part, long M, int N,
+                                                              long rows_per) {
+    const long r0 = (long)blockIdx.x * rows_per, r1 = r0 + rows_per < M ? r0 + rows_per : M;
+    for (int c = threadIdx.x; c < N; c += kBlock) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        long r = r0;
+        for (; r + 3 < r1; r += 4) {
+            a0 += x[r * N + c]; a1 += x[(r + 1) * N + c]; a2 += x[(r + 2) * N + c]; a3 += x[(r + 3) * N + c];
+        }
+        for (; r < r1; ++r) a0 += x[r * N + c];
+        part[(long)blockIdx.x * N + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+// pass 2: a workgroup owns 32 columns; its 8 thread rows split the partials, LDS folds them in fixed order
+__global__ __launch_bounds__(kBlock) void colsum_pass2_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N) {
+    __shared__ float s_acc[8][33];
+    const int cx = threadIdx.x & 31, cy = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    float a = 0.0f;
+    if (c < N)
+        for (int b = cy; b < nblk; b += 8) a += part[(long)b * N + c];
+    s_acc[cy][cx] = a;
+    __syncthreads();
+    if (cy == 0 && c < N) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_acc[k][cx];
+        out[c] = t;
+    }
+}
+
 // d_light[b][k][c] = kShNorm[k] * sum over the image's workgroups of partials (fixed order -> reproducible)
 __global__ __launch_bounds__(kBlock) void light_grad_finalize_kernel(const float* __restrict__ partials, float* __restrict__ d_light,
                                                                      int nblocks, const float* __restrict__ stats) {
@@ -1190,6 +1225,21 @@ int matpbr_env_phase_step(const float* a, const float* r, const float* m, const 
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, lpart, g, tab, fl);
     hipLaunchKernelGGL(light_grad_finalize_kernel, dim3(kNL, (unsigned)batch), dim3(kBlock), 0, st, (const float*)lpart, d_light, nblk,
                        (const float*)stats);
+    return launch_status();
+}
+
+constexpr int kColsumBlocks = 512;
+size_t matpbr_column_sum_workspace_bytes(int N) { return N > 0 ? (size_t)kColsumBlocks * N * sizeof(float) : 0; }
+
+int matpbr_column_sum(const float* x, float* out, long M, int N, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !out || M <= 0 || N <= 0) return MATPBR_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < matpbr_column_sum_workspace_bytes(N)) return MATPBR_ERR_WORKSPACE;
+    const long rows_per = (M + kColsumBlocks - 1) / kColsumBlocks;
+    const int nblk = (int)((M + rows_per - 1) / rows_per);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_pass1_kernel, dim3((unsigned)nblk), dim3(kBlock), 0, st, x, (float*)workspace, M, N, rows_per);
+    hipLaunchKernelGGL(colsum_pass2_kernel, dim3((unsigned)((N + 31) / 32)), dim3(kBlock), 0, st, (const float*)workspace, out,
+                       nblk, N);
     return launch_status();
 }
 

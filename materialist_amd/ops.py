@@ -284,3 +284,24 @@ def adam_step(p, g, m, v, lr: float, step: int, beta1: float = 0.9, beta2: float
         code = lib.matpbr_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                     int(step), _stream(p))
     _lib.check(code, "matpbr_adam_step")
+
+
+_colsum_ws = {}
+
+
+def column_sum(x: torch.Tensor) -> torch.Tensor:
+    """Sum over the rows of a contiguous [M, N] fp32 CUDA tensor -> [N] (bias gradients of the PosMLP layers)."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    if x.ndim != 2:
+        raise ValueError("column_sum expects [M, N]")
+    M, N = x.shape
+    key = (x.device, N)
+    if key not in _colsum_ws:
+        _colsum_ws[key] = torch.empty(int(lib.matpbr_column_sum_workspace_bytes(N)) // 4, dtype=torch.float32, device=x.device)
+    ws = _colsum_ws[key]
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        code = lib.matpbr_column_sum(_ptr(x), _ptr(out), M, N, _ptr(ws), ws.numel() * 4, _stream(x))
+    _lib.check(code, "matpbr_column_sum")
+    return out

@@ -22,13 +22,63 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _split_k_tn(g: torch.Tensor, x: torch.Tensor, chunks: int = 64) -> torch.Tensor:
+    """g.T @ x for g [M, n], x [M, k] with M >> n, k: the reduction dimension is split into `chunks` batched GEMMs whose
+    partial products are then added -- a plain [n, M] x [M, k] call lands on a 32x64 macro-tile kernel at 40 TFLOP/s."""
+    M = g.shape[0]
+    if M % chunks or M < 64 * chunks:
+        return g.t() @ x
+    return torch.bmm(g.view(chunks, M // chunks, -1).transpose(1, 2), x.view(chunks, M // chunks, -1)).sum(0)
+
+
+def _column_sum(g: torch.Tensor) -> torch.Tensor:
+    if g.is_cuda and g.dtype == torch.float32:
+        from . import ops
+
+        return ops.column_sum(g)
+    return g.sum(0)
+
+
+class _LinearSin(torch.autograd.Function):
+    """y = sin(x @ W[:, :k].T + x0 @ W[:, k:].T + b) with a backward pass made only of GEMMs / GEMVs.
+
+    Two things PyTorch's stock composition does badly at M = 262 144 rows: the bias gradient is a column reduction of a
+    [M, 256] tensor (`reduce_kernel`, 2-4 ms each on MI355X, 45 % of an iteration) -- here it is a GEMV with a ones vector;
+    and the skip connection materialises cat(x, x0) (a 268 MB copy per skip layer, forward and backward) -- here the weight
+    is split by columns instead, so x and x0 are multiplied separately into the same output."""
+
+    @staticmethod
+    def forward(ctx, x, x0, weight, bias, apply_sin):
+        k = x.shape[1]
+        pre = torch.addmm(bias, x, weight[:, :k].t())
+        if x0 is not None:
+            pre.addmm_(x0, weight[:, k:].t())
+        ctx.save_for_backward(x, x0, weight, pre if apply_sin else None)
+        ctx.apply_sin = apply_sin
+        return torch.sin(pre) if apply_sin else pre
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, x0, weight, pre = ctx.saved_tensors
+        k = x.shape[1]
+        g = grad * torch.cos(pre) if ctx.apply_sin else grad
+        g = g.contiguous()
+        d_w, d_x0 = _split_k_tn(g, x), None
+        if x0 is not None:
+            d_w = torch.cat([d_w, _split_k_tn(g, x0)], dim=1)        # [out, k + len(x0)]: small
+            d_x0 = g @ weight[:, k:] if ctx.needs_input_grad[1] else None
+        d_b = _column_sum(g)
+        d_x = g @ weight[:, :k] if ctx.needs_input_grad[0] else None
+        return d_x, d_x0, d_w, d_b, None
+
+
 class _Sine(nn.Module):
     def __init__(self, n_in: int, n_out: int):
         super().__init__()
         self.linear = nn.Linear(n_in, n_out)      # default PyTorch init; the SIREN init is commented out in the reference (:86)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return torch.sin(self.linear(x))
+    def forward(self, x: torch.Tensor, x0=None) -> torch.Tensor:
+        return _LinearSin.apply(x, x0, self.linear.weight, self.linear.bias, True)
 
 
 def grid_shape(n_rows: int) -> Tuple[int, int]:
@@ -87,9 +137,12 @@ class PosMLP(nn.Module):
         x0 = self._points(img)
         x = x0
         for l in range(self.n_layers):
-            if l in self.skip:
-                x = torch.cat([x, x0], dim=-1)
-            x = getattr(self, f"lin{l}")(x)
+            layer = getattr(self, f"lin{l}")
+            skip_in = x0 if l in self.skip else None          # cat(x, x0) without the copy: the weight is split by columns
+            if l < self.n_layers - 1:
+                x = layer(x, skip_in)
+            else:
+                x = _LinearSin.apply(x, skip_in, layer.weight, layer.bias, False)
         if self.output_type == "envmap":
             return F.softplus(x)
         if self.output_type == "arm":

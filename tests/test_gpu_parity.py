@@ -552,3 +552,15 @@ def test_pos_mlp_phase_matches_torch_composition():
         assert float(ph.stats[0, ops.STAT_LOSS]) == pytest.approx(float(total.detach()), rel=3e-4), it
     for (ka, va), (kb, vb) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
         assert (va - vb).abs().max().item() < 2e-5, ka
+
+
+def test_column_sum():
+    from materialist_amd import ops
+
+    dev = _cuda()
+    for M, N in ((262144, 256), (1000, 241), (7, 5), (4096, 1024)):
+        x = torch.randn(M, N, device=dev)
+        got = ops.column_sum(x)
+        ref = x.double().sum(0)
+        assert (got.double() - ref).abs().max().item() <= 1e-5 * (x.abs().double().sum(0).max().item())
+        assert torch.equal(got, ops.column_sum(x))      # fixed-order reduction: bit-reproducible
