@@ -4,9 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one optimisation iteration of hot loop B (inverse_img_w_mi.py:347-468, `--model_name none`):
-shade_fwd -> gamma-2.2 MSE/L1 loss with mean-ratio scaling -> shade_bwd -> Adam on the a/r/m maps, for every
-image of the rank's shard, inputs resident in HBM.  Images are independent, so ranks never communicate inside
+One "step" = one optimisation iteration (epoch) of hot loop B of BASELINE config 2 (`--model_name pos_mlp --opt_order 'rm a'`,
+inverse_img_w_mi.py:470-590): material maps from the residual PosMLP (PyTorch-ROCm GEMMs) -> shade_fwd -> gamma-2.2 MSE/L1
+loss with mean-ratio scaling -> shade_bwd -> AdamW, everything downstream of the maps in libmatpbr.so, inputs resident in
+HBM.  `--mode fused` times the same loop in `--model_name none` mode (maps optimised directly, whole iteration in
+libmatpbr.so); both rates are reported in every run (`modes`).  Images are independent, so ranks never communicate inside
 the timed region (weak scaling: `images_per_gpu` per rank).  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -31,7 +33,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel; the reference renders with spp=64 (inverse_img_w_mi.py:625)")
     ap.add_argument("--images-per-gpu", type=int, default=1)
-    ap.add_argument("--mode", choices=["fused", "torch", "pos_mlp"], default="fused",
+    ap.add_argument("--mode", choices=["fused", "torch", "pos_mlp"], default="pos_mlp",
                     help="fused: --model_name none, whole iteration in libmatpbr.so; torch: same step composed from torch ops; "
                          "pos_mlp: the reference's default mode (maps from the residual PosMLP on PyTorch-ROCm, render/loss/backward in libmatpbr.so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,24 +108,33 @@ def main():
     with torch.no_grad():
         gt_image = render.render_w_brdf(scene, gt_a, gt_r, gt_m, None, args.spp)
     init = (t([s.init_albedo for s in scenes]), t([s.init_roughness for s in scenes]), t([s.init_metallic for s in scenes]))
-    if args.mode == "fused":
-        phase = loop.FusedBrdfPhase(scene, gt_image, *init, spp=args.spp)
-    elif args.mode == "pos_mlp":
-        from materialist_amd import posmlp
+    if args.mode == "pos_mlp" and B > 1:
+        args.mode = "fused"                      # the MLP modes optimise one image per process; a batch runs the none-mode loop
 
-        assert B == 1, "pos_mlp mode optimises one image per process"
-        net = posmlp.brdf_net("arm").to(dev)
-        start_arm = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1)], -1).clamp(0, 1)
-        phase = loop.PosMlpBrdfPhase(scene, gt_image, net, start_arm, {"albedo": init[0], "roughness": init[1], "metallic": init[2]},
-                                     optimize_part="arm", spp=args.spp)
-        phase.current_maps = lambda: {k: v.detach() for k, v in zip(("albedo", "roughness", "metallic"),
-                                                                     (lambda m: (m["albedo"].clamp(0, 1), m["roughness"].clamp(0.07, 1), m["metallic"].clamp(0, 1)))(phase.maps_from_net()[0]))}
-    else:
-        phase = loop.BrdfPhase(scene, gt_image, *init, None, optimize_part="arm", spp=args.spp)
-    psnr0 = float(loop._loss.psnr(render.render_w_brdf(scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), gt_image).mean())
+    def make_phase(mode):
+        if mode == "fused":
+            return loop.FusedBrdfPhase(scene, gt_image, *init, optimize_part="rm", spp=args.spp)
+        if mode == "pos_mlp":
+            from materialist_amd import posmlp
 
-    for _ in range(args.warmup):
-        phase.step()
+            net = posmlp.brdf_net("arm").to(dev)
+            start_arm = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1)], -1).clamp(0, 1)
+            ph = loop.PosMlpBrdfPhase(scene, gt_image, net, start_arm, {"albedo": init[0], "roughness": init[1], "metallic": init[2]},
+                                      optimize_part="rm", spp=args.spp)
+            ph.current_maps = lambda: (lambda m: {"albedo": m["albedo"].detach().clamp(0, 1), "roughness": m["roughness"].detach().clamp(0.07, 1),
+                                                  "metallic": m["metallic"].detach().clamp(0, 1)})(ph.maps_from_net()[0])
+            return ph
+        if mode == "env":
+            from materialist_amd import posmlp
+
+            s_env = render.load_estimated_mesh(depth, use_mesh_normal=True)
+            pr = render.traverse(s_env)
+            pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = gt_a, gt_r, gt_m
+            enet = posmlp.envmap_net().to(dev)
+            ones = torch.ones(512, 3, device=dev)
+            return loop.FusedEnvPhase(s_env, gt_image if B == 1 else gt_image, lambda: enet(ones).reshape(16, 32, 3), torch.optim.Adam(enet.parameters(), lr=1e-3),
+                                      spp=args.spp)
+        return loop.BrdfPhase(scene, gt_image, *init, None, optimize_part="rm", spp=args.spp)
 
     def fence():
         torch.cuda.synchronize()
@@ -131,18 +142,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    with ops.KernelTimer() as kt:
-        for _ in range(args.steps):
-            phase.step()
+    def timed(ph, warmup, steps):
+        for _ in range(warmup):
+            ph.step()
         fence()
-        elapsed = time.perf_counter() - t0
-        ksum = kt.summary()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+        t0 = time.perf_counter()
+        with ops.KernelTimer() as kt:
+            for _ in range(steps):
+                ph.step()
+            fence()
+            el_ = time.perf_counter() - t0
+            ks = kt.summary()
+        el = torch.tensor([el_], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), ks
+
+    phase = make_phase(args.mode)
+    psnr0 = float(loop._loss.psnr(render.render_w_brdf(scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), gt_image).mean())
+    elapsed, ksum = timed(phase, args.warmup, args.steps)
     total_units = args.steps * B * world
     value = total_units / elapsed
 
@@ -150,6 +168,18 @@ def main():
     with torch.no_grad():
         final = render.render_w_brdf(scene, m["albedo"].detach(), m["roughness"].detach(), m["metallic"].detach(), None, args.spp)
     psnr1 = float(loop._loss.psnr(final, gt_image).mean())
+
+    # the other loops of the same pipeline, short runs, for the record (same fences; whole-job rates)
+    modes = {args.mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3}}
+    for extra in ("fused", "pos_mlp", "env"):
+        if extra == args.mode or (extra != "fused" and B > 1) or args.mode == "torch":
+            continue
+        e_el, _ = timed(make_phase(extra), 5, 40)
+        modes[extra] = {"it_per_s": 40 * B * world / e_el, "ms_per_step": e_el / 40 * 1e3}
+    mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so)",
+                  "pos_mlp": "hot loop B, --model_name pos_mlp (PosMLP on PyTorch-ROCm + libmatpbr.so)",
+                  "env": "hot loop A, envmap PosMLP head + matpbr_env_phase_step", "torch": "hot loop B composed from torch ops"}
+    modes = {k: dict(v, what=mode_names[k]) for k, v in modes.items()}
 
     # kernel durations for the roofline: 20 back-to-back launches between two HIP events on the launch stream (per-launch
     # event pairs inside the loop also time the inter-launch gap; they are reported as *_inloop_ms for reference)
@@ -170,6 +200,17 @@ def main():
     ms_f = back_to_back(lambda: ops.shade_fwd(mm["albedo"], mm["roughness"], mm["metallic"], nrm, lgt, args.spp))
     ms_b = back_to_back(lambda: ops.shade_bwd(mm["albedo"], mm["roughness"], mm["metallic"], nrm, lgt, d_probe, args.spp, want_mat=True))
 
+    # the PosMLP side of the pos_mlp iteration is hipBLASLt fp32 GEMMs (MFMA 16x16x4 f32, exact fp32): rate of its hidden layer
+    gemm = None
+    if B == 1:
+        xg = torch.randn(H * W, 256, device=dev)
+        wg = torch.randn(256, 256, device=dev)
+        ms_g = back_to_back(lambda: torch.mm(xg, wg))
+        gemm = {"bound": "mfma", "kernel": "hipBLASLt f32 GEMM [H*W,256]x[256,256] (PosMLP hidden layer, PyTorch-ROCm)", "achieved": 2.0 * H * W * 256 * 256 / (ms_g * 1e-3) / 1e12,
+                "peak": 157.3, "unit": "TFLOP/s", "avg_launch_ms": ms_g}
+        gemm["frac"] = gemm["achieved"] / gemm["peak"]
+        del xg, wg
+
     if rank == 0:
         px = H * W * B
         ms_f_in = ksum.get("shade_fwd", (0, float("nan")))[1]
@@ -189,16 +230,19 @@ def main():
             "metric": "opt_iterations_per_sec_512x512", "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2-synthetic: {H}x{W} BRDF-phase optimisation iteration (shade_fwd + loss + shade_bwd + Adam on a/r/m maps), "
-                                   f"spp={args.spp}, --model_name none --opt_order arm, use_mesh_normal, step={args.mode}; PosMLP (SURVEY 8f2) not in the loop",
-                       "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25"},
+            "config": {"workload": f"C2-synthetic (BASELINE configs[1]): {H}x{W}, one epoch of hot loop B, part 'rm' of --opt_order 'rm a', "
+                                   f"{'--model_name pos_mlp' if args.mode == 'pos_mlp' else '--model_name none'} "
+                                   f"(maps -> shade_fwd -> gamma-2.2 MSE/L1 loss -> shade_bwd -> Adam(W)), spp={args.spp}, geometric normals, SH25 light",
+                       "mode": args.mode, "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25"},
+            "modes": modes,
             "roofline": {"bound": "hbm", "kernel": "shade_bwd_kernel<mat>", "achieved": ach_b, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_b / (HBM_PEAK / 1e9), "traffic": traffic,
                          "bytes_per_pixel": BYTES_BWD_ARM, "avg_launch_ms": ms_b, "avg_launch_inloop_ms": ms_b_in,
                          "note": "canonical unfused shade_bwd<mat> on the same maps; the kernel is VALU-issue-bound at spp=64 (DESIGN.md section 4)",
                          "shade_fwd": {"achieved": ach_f, "frac": ach_f / (HBM_PEAK / 1e9), "avg_launch_ms": ms_f, "avg_launch_inloop_ms": ms_f_in,
                                        "bytes_per_pixel": BYTES_FWD},
-                         "fwd+bwd": {"achieved": ach_fb, "frac": ach_fb / (HBM_PEAK / 1e9), "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM}},
+                         "fwd+bwd": {"achieved": ach_fb, "frac": ach_fb / (HBM_PEAK / 1e9), "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM},
+                         "posmlp_gemm": gemm},
             "psnr_db": {"initial_guess": psnr0, "after_timed_steps": psnr1, "vs": "own HIP render of the synthetic ground truth (Mitsuba cannot run, SURVEY F3)"},
         }
         if not args.no_cpu_baseline and world == 1:
