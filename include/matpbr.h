@@ -150,6 +150,16 @@ int matpbr_env_phase_step(const float* a, const float* r, const float* m, const 
 size_t matpbr_column_sum_workspace_bytes(int N);
 int matpbr_column_sum(const float* x, float* out, long M, int N, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Forward-only relighting (render_final.py:148-203 `render_w_mi`, :290-418 `rotate_envmap` / `render_rolling_envmap`).
+ * The render is linear in the light, R = sum_k light[k] * T[k]:
+ *   matpbr_shade_transfer  per-pixel transfer of the current materials into T (matpbr_transfer_bytes(); 300 B/pixel, tiled
+ *                          [B][ceil(H*W/256)][75][256]: 75 = 25 coefficients x rgb; opaque to the caller), computed once
+ *   matpbr_relight         out[F,H,W,3] for F lights [F,25,3] against one image's T (HBM-bound; 8 lights per pass) */
+size_t matpbr_transfer_bytes(int H, int W, int batch);
+int matpbr_shade_transfer(const float* a, const float* r, const float* m, const float* n, float* T, int H, int W, int batch,
+                          int spp, const MatpbrCamera* cam, uint32_t flags, void* stream);
+int matpbr_relight(const float* T, const float* lights, float* out_rgb, int H, int W, int n_frames, void* stream);
+
 /* Plugin face, N independent lanes, AoS [N,3] vectors (the reference traces these over Dr.Jit arrays).
  *   matpbr_eval_brdf   = MatDiffBSDF.eval_pdf / eval_brdf     myutils/mi_plugin.py:1372-1427,1449-1460
  *                        (wi = light direction, wo = view direction; f already includes cos)

@@ -53,6 +53,10 @@ SIGNATURES = {
                                             ctypes.c_void_p]),
     "matpbr_column_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_column_sum": (ctypes.c_int, [_c_f, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "matpbr_shade_transfer": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),
+                                            ctypes.c_uint32, ctypes.c_void_p]),
+    "matpbr_transfer_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "matpbr_relight": (ctypes.c_int, [_c_f] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_adam_step": (ctypes.c_int, [_c_f] * 4 + [ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                        ctypes.c_void_p]),
     "matpbr_eval_brdf": (ctypes.c_int, [_c_f] * 8 + [ctypes.c_long, ctypes.c_void_p]),

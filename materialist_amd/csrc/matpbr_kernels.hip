@@ -335,6 +335,108 @@ __global__ __launch_bounds__(kBlock, 2) void shade_fwd_kernel(const float* __res
 }
 
 // =================================================================================================
+// precomputed radiance transfer (forward-only relighting, render_final.py:148-203,300-418)
+// The render is linear in the light: R[c] = sum_k light[k][c] * T[k][c] with the per-pixel transfer
+//   T[k][c] = kShNorm[k]/spp * sum_s w_s[c] * B_k(wi_s).
+// T is computed once per material state (one pass per group of 9/8/8 basis functions keeps the 27 packed accumulators
+// in registers); every relit frame is then 75 FMAs per pixel over 300 bytes -- HBM-bound, and with F lights per launch the
+// T reads are amortised down to the 12-byte pixel write per frame.
+// =================================================================================================
+// Transfer layout: tiles of 256 consecutive pixels, each tile a contiguous [75][256] block (75 KB): the relight workgroup
+// reads one contiguous block with lane-consecutive addresses (coalesced AND page-local; 75 planes 16 MB apart thrash the TLB).
+__host__ __device__ inline long transfer_tiles(long P) { return (P + 255) / 256; }
+__device__ __forceinline__ long transfer_index(int b, long p, int j, long P) {
+    return (((long)b * transfer_tiles(P) + (p >> 8)) * kNL + j) * 256 + (p & 255);
+}
+
+template <int K0, int K1>
+struct TransferUse {
+    const f2* w;       // f*ip per channel for the two pixels
+    f2* acc;           // [(K1-K0)*3]
+    template <int K> __device__ __forceinline__ void operator()(f2 Bk) {
+        if (K >= K0 && K < K1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[(K - K0) * 3 + c] = vfma(w[c], Bk, acc[(K - K0) * 3 + c]);
+        }
+    }
+};
+
+template <int K0, int K1>
+__global__ __launch_bounds__(kBlock, 2) void shade_transfer_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                                   const float* __restrict__ m, const float* __restrict__ n,
+                                                                   float* __restrict__ T, const Geom g, const SampleTable tab) {
+    const int b = blockIdx.y;
+    const int P = g.H * g.W;
+    const int p0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
+    if (p0 >= P) return;
+    const bool two = p0 + 1 < P;
+    const int p1 = two ? p0 + 1 : p0;
+    const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
+    Pixel px;
+    load_pixel<false>(px, a, r, m, n, i0, i1, p0, p1, g);
+    constexpr int NK = K1 - K0;
+    f2 acc[NK * 3];
+#pragma unroll
+    for (int k = 0; k < NK * 3; ++k) acc[k] = f2{0.0f, 0.0f};
+    float4 t = tab.diff[0];
+    for (int s = 0; s < 2 * g.half; ++s) {
+        Sample sm;
+        const float4 tn = s + 1 < g.half ? tab.diff[s + 1] : tab.spec[s + 1 < 2 * g.half ? s + 1 - g.half : g.half - 1];
+        if (s < g.half) diffuse_sample<false>(px, t.x, t.y, t.z, sm);
+        else specular_sample<false>(px, t.x, t.y, t.z, t.w, sm);
+        BrdfState<f2> st;
+        f2 f[3], pdf;
+        brdf_core(px.pc, sm.NoL_raw, sm.NoH, sm.VoH, sm.den, st, f, pdf);
+        f2 ip = sel_pos(pdf - 1e-6f, rcp(pdf + 1e-6f), 0.0f);
+        f2 w[3] = {f[0] * ip, f[1] * ip, f[2] * ip};
+        sh_stream(sm.wi, TransferUse<K0, K1>{w, acc});
+        t = tn;
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const float sc = kShNorm[K0 + k] * g.inv_spp;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f2 v = acc[k * 3 + c] * sc;
+            const int j = (K0 + k) * 3 + c;
+            T[transfer_index(b, p0, j, P)] = v.x;
+            if (two) T[transfer_index(b, p1, j, P)] = v.y;
+        }
+    }
+}
+
+// out[f][p][c] = sum_k T[p][k][c] * light[f][k][c] for up to kRelightFrames lights per launch (lights in LDS, T read once)
+constexpr int kRelightFrames = 8;
+// the lights are read at wave-uniform addresses: scalar loads, SGPR operands of the FMAs (lights of frames >= n_frames must be readable)
+__global__ __launch_bounds__(kBlock) void relight_kernel(const float* __restrict__ T, const float* __restrict__ L, float* __restrict__ out,
+                                                         long P, int n_frames) {
+    const long p = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    float acc[kRelightFrames][3];
+#pragma unroll
+    for (int f = 0; f < kRelightFrames; ++f) acc[f][0] = acc[f][1] = acc[f][2] = 0.0f;
+    const float* tp = T + transfer_index(0, p, 0, P);
+#pragma unroll 5
+    for (int k = 0; k < kNSH; ++k) {
+        const float t0 = tp[(k * 3) * 256], t1 = tp[(k * 3 + 1) * 256], t2 = tp[(k * 3 + 2) * 256];
+#pragma unroll
+        for (int f = 0; f < kRelightFrames; ++f) {
+            const int fi = f < n_frames ? f : 0;     // uniform: stays a scalar load
+            acc[f][0] = fmaf(t0, L[fi * kNL + k * 3], acc[f][0]);
+            acc[f][1] = fmaf(t1, L[fi * kNL + k * 3 + 1], acc[f][1]);
+            acc[f][2] = fmaf(t2, L[fi * kNL + k * 3 + 2], acc[f][2]);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < kRelightFrames; ++f) {
+        if (f < n_frames) {
+            float* o = out + ((long)f * P + p) * 3;
+            o[0] = acc[f][0]; o[1] = acc[f][1]; o[2] = acc[f][2];
+        }
+    }
+}
+
+// =================================================================================================
 // backward (sample directions and pdf are constants: stop-gradient, as in the reference's torch
 // variants -- `D.data`, `alpha.data`, mi_plugin.py:179,366)
 // =================================================================================================
@@ -1225,6 +1327,40 @@ int matpbr_env_phase_step(const float* a, const float* r, const float* m, const 
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, lpart, g, tab, fl);
     hipLaunchKernelGGL(light_grad_finalize_kernel, dim3(kNL, (unsigned)batch), dim3(kBlock), 0, st, (const float*)lpart, d_light, nblk,
                        (const float*)stats);
+    return launch_status();
+}
+
+int matpbr_shade_transfer(const float* a, const float* r, const float* m, const float* n, float* T, int H, int W, int batch, int spp,
+                          const MatpbrCamera* cam, uint32_t flags, void* stream) {
+    (void)flags;
+    if (!a || !r || !m || !n || !T || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+    if (!valid_spp(spp)) return MATPBR_ERR_UNSUPPORTED;
+    Geom g;
+    if (!make_geom(H, W, spp, cam, g)) return MATPBR_ERR_INVALID_ARG;
+    SampleTable tab;
+    fill_sample_table(spp, tab);
+    dim3 grid((unsigned)grid_blocks(H, W), (unsigned)batch);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((shade_transfer_kernel<0, 9>), grid, dim3(kBlock), 0, st, a, r, m, n, T, g, tab);
+    hipLaunchKernelGGL((shade_transfer_kernel<9, 17>), grid, dim3(kBlock), 0, st, a, r, m, n, T, g, tab);
+    hipLaunchKernelGGL((shade_transfer_kernel<17, 25>), grid, dim3(kBlock), 0, st, a, r, m, n, T, g, tab);
+    return launch_status();
+}
+
+size_t matpbr_transfer_bytes(int H, int W, int batch) {
+    if (H <= 0 || W <= 0 || batch <= 0) return 0;
+    return (size_t)batch * transfer_tiles((long)H * W) * kNL * 256 * sizeof(float);
+}
+
+int matpbr_relight(const float* T, const float* lights, float* out_rgb, int H, int W, int n_frames, void* stream) {
+    if (!T || !lights || !out_rgb || H <= 0 || W <= 0 || n_frames <= 0) return MATPBR_ERR_INVALID_ARG;
+    const long P = (long)H * W;
+    hipStream_t st = (hipStream_t)stream;
+    for (int f0 = 0; f0 < n_frames; f0 += kRelightFrames) {
+        const int nf = n_frames - f0 < kRelightFrames ? n_frames - f0 : kRelightFrames;
+        hipLaunchKernelGGL(relight_kernel, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, T, lights + (long)f0 * kNL,
+                           out_rgb + (long)f0 * P * 3, P, nf);
+    }
     return launch_status();
 }
 

@@ -27,7 +27,7 @@ class KernelTimer:
     active = None
 
     def __init__(self):
-        self.events = {"shade_fwd": [], "shade_bwd": [], "brdf_phase_step": [], "env_phase_step": []}
+        self.events = {"shade_fwd": [], "shade_bwd": [], "brdf_phase_step": [], "env_phase_step": [], "relight": []}
 
     def __enter__(self):
         KernelTimer.active = self
@@ -304,4 +304,35 @@ def column_sum(x: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(x.device):
         code = lib.matpbr_column_sum(_ptr(x), _ptr(out), M, N, _ptr(ws), ws.numel() * 4, _stream(x))
     _lib.check(code, "matpbr_column_sum")
+    return out
+
+
+def shade_transfer(a, r, m, n, spp: int, fov_x_deg: float = 35.0) -> torch.Tensor:
+    """Per-pixel radiance transfer of the materials (opaque tiled buffer, matpbr_transfer_bytes): `relight(T, lights, H, W)`
+    reproduces shade_fwd for every light without re-evaluating the BRDF."""
+    lib = _lib.load()
+    a = _dev(a, "albedo", (3,))
+    B, H, W = _bhw(a)
+    r, m, n = _dev(r, "roughness").reshape(B, H, W, 1), _dev(m, "metallic").reshape(B, H, W, 1), _dev(n, "normal", (3,))
+    T = torch.empty(int(lib.matpbr_transfer_bytes(H, W, B)) // 4, dtype=torch.float32, device=a.device)
+    cam = MatpbrCamera(float(fov_x_deg))
+    with torch.cuda.device(a.device):
+        code = lib.matpbr_shade_transfer(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(T), H, W, B, check_spp(spp), ctypes.byref(cam), 0, _stream(a))
+    _lib.check(code, "matpbr_shade_transfer")
+    return T
+
+
+def relight(T, lights, H: int, W: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """T = shade_transfer(...) of ONE [H,W] image, lights [F,25,3] -> [F,H,W,3]."""
+    lib = _lib.load()
+    T = _dev(T, "T")
+    lights = _dev(lights, "lights", (NSH, 3)).reshape(-1, NSH, 3)
+    if T.numel() * 4 < int(lib.matpbr_transfer_bytes(H, W, 1)):
+        raise ValueError("relight: T is smaller than matpbr_transfer_bytes(H, W, 1)")
+    F_ = lights.shape[0]
+    if out is None:
+        out = torch.empty((F_, H, W, 3), dtype=torch.float32, device=T.device)
+    with torch.cuda.device(T.device), _timed("relight"):
+        code = lib.matpbr_relight(_ptr(T), _ptr(lights), _ptr(out), H, W, F_, _stream(T))
+    _lib.check(code, "matpbr_relight")
     return out

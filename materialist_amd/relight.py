@@ -1,0 +1,134 @@
+"""Forward-only re-rendering of an optimised scene under new lighting: the `render_final.py` side of the reference
+(`render_w_mi` :148-203, `render_real` :241-260, `rotate_envmap` :290-298, `render_rolling_envmap` :300-418).  SURVEY.md 8(f4).
+
+The reference re-traces the scene for every light (10 x spp 64 + OptiX denoise, or spp 32 per rolling frame).  The
+deterministic render is linear in the light, so the per-pixel transfer is computed once (`matpbr_shade_transfer`) and each
+frame is a 75-term dot product per pixel (`matpbr_relight`, HBM-bound).  Rolling the envmap by whole texel columns is the
+SH rotation about +y by the same angle (`sh.rotate_y_matrix`), so no envmap is ever re-projected or written to disk.
+Object insertion (`--mode oi`, :100-141,207-237) needs extra meshes and is not part of this build.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import loss as _loss
+from . import ops
+from . import sh as _sh
+from .imageio_exr import read_exr, write_exr
+from .imageio_hdr import read_hdr
+from .pipeline import OUT_DIR, load_image, write_png
+
+
+def load_estimated_brdf(root_dir: str, device="cuda") -> Dict[str, torch.Tensor]:
+    """myutils/mi_plugin.py:701-739: best_results/{albedo,roughness,metallic,normal}.exr (+ envmap.hdr); roughness is rescaled
+    `r * 0.95 + 0.05` on reload (:716)."""
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+    mat = {"albedo": t(read_exr(os.path.join(root_dir, "albedo.exr"))),
+           "roughness": t(read_exr(os.path.join(root_dir, "roughness.exr"))[..., :1]) * 0.95 + 0.05,
+           "metallic": t(read_exr(os.path.join(root_dir, "metallic.exr"))[..., :1]),
+           "normal": t(read_exr(os.path.join(root_dir, "normal.exr")))}
+    p = os.path.join(root_dir, "envmap.hdr")
+    if os.path.exists(p):
+        mat["envmap"] = t(read_hdr(p))
+    return mat
+
+
+def find_envmap(save_name: str, env_path: Optional[str], input_path: Optional[str]) -> str:
+    """render_final.py:243-259 / :304-321: explicit path, else <input_path>/<name>/best_results/envmap.hdr, else the default tree."""
+    if env_path is not None:
+        return env_path
+    cands = []
+    if input_path is not None:
+        cands.append(os.path.join(input_path, save_name, "best_results", "envmap.hdr"))
+    cands.append(os.path.join(OUT_DIR, save_name, "best_results", "envmap.hdr"))
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    raise ValueError("No envmap found")
+
+
+def envmap_to_light(env: np.ndarray) -> np.ndarray:
+    He, We = env.shape[:2]
+    return _sh.envmap_to_sh_matrix(He, We) @ env.reshape(He * We, 3).astype(np.float64)
+
+
+class Relighter:
+    """Transfer of one optimised scene; `frames(lights)` renders any number of lights."""
+
+    def __init__(self, mat: Dict[str, torch.Tensor], shading_normal: torch.Tensor, spp: int = 64, fov_x_deg: float = 35.0):
+        self.H, self.W = mat["albedo"].shape[0], mat["albedo"].shape[1]
+        self.T = ops.shade_transfer(mat["albedo"].contiguous(), mat["roughness"].contiguous(), mat["metallic"].contiguous(),
+                                    shading_normal.contiguous(), spp, fov_x_deg)
+
+    def frames(self, lights) -> torch.Tensor:
+        L = torch.as_tensor(np.asarray(lights, dtype=np.float32)).reshape(-1, 25, 3).to(self.T.device)
+        return ops.relight(self.T, L, self.H, self.W)
+
+
+def _scene_normal(scene_dir: str, mat: Dict[str, torch.Tensor], save_name: str, device) -> torch.Tensor:
+    if "mn" in save_name:                                            # 'mn' in the name = optimised normals (:155-160)
+        return mat["normal"]
+    depth = read_exr(os.path.join(scene_dir, "depthPred.exr"))[..., 0]
+    depth = 2 * depth.max() - depth                                  # inverse_img_w_mi.py:722
+    return ops.normals_from_depth(torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32)).to(device))
+
+
+def render_real(save_name: str, env_path: Optional[str] = None, input_path: Optional[str] = None, save_path: Optional[str] = None,
+                spp: int = 64, device="cuda") -> str:
+    """render_final.py:148-203,241-260: one re-render under `env_path` -> mi_<name>_<env>_.exr / .png."""
+    scene_dir = os.path.join(input_path if input_path is not None else OUT_DIR, save_name)
+    env_path = find_envmap(save_name, env_path, input_path)
+    mat = load_estimated_brdf(os.path.join(scene_dir, "best_results"), device)
+    rl = Relighter(mat, _scene_normal(scene_dir, mat, save_name, device), spp)
+    img = rl.frames(envmap_to_light(load_image(env_path))[None])[0]
+    env_id = os.path.basename(env_path)[:-4]
+    out_dir = os.path.join(save_path if save_path else OUT_DIR, save_name)
+    os.makedirs(out_dir, exist_ok=True)
+    base = os.path.join(out_dir, f"mi_{save_name}_{env_id}_")          # empty edit flag (:199-202)
+    write_exr(base + ".exr", img.cpu().numpy())
+    write_png(base + ".png", _loss.linear_to_srgb(img.clamp_min(0)).cpu().numpy())
+    return base + ".png"
+
+
+def render_rolling_envmap(save_name: str, env_path: Optional[str], frames: int = 36, rotation_step: float = 10.0,
+                          input_path: Optional[str] = None, save_path: Optional[str] = None, spp: int = 64, device="cuda",
+                          write_frames: bool = True) -> Dict[str, object]:
+    """render_final.py:300-418: `frames` renders, the envmap rolled by int(angle/360*W) columns per frame."""
+    scene_dir = os.path.join(input_path if input_path is not None else OUT_DIR, save_name)
+    env_path = find_envmap(save_name, env_path, input_path)
+    env = load_image(env_path)
+    We = env.shape[1]
+    light0 = envmap_to_light(env)
+    lights = []
+    for f in range(frames):
+        shift = int((f * rotation_step / 360.0) * We)                # rotate_envmap (:290-298)
+        lights.append(_sh.rotate_y_matrix(2 * np.pi * shift / We) @ light0)
+    mat = load_estimated_brdf(os.path.join(scene_dir, "best_results"), device)
+    rl = Relighter(mat, _scene_normal(scene_dir, mat, save_name, device), spp)
+    out_dir = os.path.join(save_path if save_path else OUT_DIR, save_name)
+    anim_dir = os.path.join(out_dir, "rolling_envmap_animation")
+    os.makedirs(anim_dir, exist_ok=True)
+    env_id = os.path.basename(env_path)[:-4]
+    paths: List[str] = []
+    imgs = []
+    for f0 in range(0, frames, 8):
+        batch = rl.frames(np.stack(lights[f0:f0 + 8]))
+        if write_frames:
+            srgb = _loss.linear_to_srgb(batch.clamp_min(0)).clamp(0, 1).cpu().numpy()
+            for k in range(srgb.shape[0]):
+                path = os.path.join(anim_dir, f"frame_{f0 + k:04d}.png")
+                write_png(path, srgb[k])
+                paths.append(path)
+                imgs.append((srgb[k] * 255 + 0.5).astype(np.uint8))
+    gif_path = None
+    if imgs:
+        from PIL import Image
+
+        gif_path = os.path.join(out_dir, f"rolling_envmap_{save_name}_{env_id}.gif")
+        pil = [Image.fromarray(i) for i in imgs]
+        pil[0].save(gif_path, save_all=True, append_images=pil[1:], duration=100, loop=0)
+    return {"animation_dir": anim_dir, "frames": paths, "gif": gif_path}

@@ -513,6 +513,14 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     res2 = pipeline.inverse_image(src, "case", opt_src="skip", opt_order=["skip"], save_path=str(tmp_path), size=32, spp=8, num_epochs=5,
                                   sync_every=5, log=lambda *_: None)
     assert res2["trace"][-1].stop == "skip"
+    # f4: re-render the optimised scene under its own envmap and as a rolling animation (render_final.py)
+    from materialist_amd import relight
+
+    png = relight.render_real("case", None, input_path=str(tmp_path), save_path=str(tmp_path), spp=8)
+    assert png.endswith("mi_case_envmap_.png") and os.path.exists(png) and os.path.exists(png[:-4] + ".exr")
+    roll = relight.render_rolling_envmap("case", None, frames=10, rotation_step=36.0, input_path=str(tmp_path), save_path=str(tmp_path), spp=8)
+    assert len(roll["frames"]) == 10 and os.path.basename(roll["frames"][3]) == "frame_0003.png"
+    assert os.path.exists(roll["gif"]) and os.path.basename(roll["gif"]) == "rolling_envmap_case_envmap.gif"
 
 
 def test_pos_mlp_phase_matches_torch_composition():
@@ -564,3 +572,31 @@ def test_column_sum():
         ref = x.double().sum(0)
         assert (got.double() - ref).abs().max().item() <= 1e-5 * (x.abs().double().sum(0).max().item())
         assert torch.equal(got, ops.column_sum(x))      # fixed-order reduction: bit-reproducible
+
+
+def test_transfer_relight_equals_direct_render():
+    """f4: the render is linear in the light; relighting through the precomputed transfer reproduces shade_fwd, and the SH
+    y-rotation reproduces rolling the envmap columns (render_final.py:290-298)."""
+    from materialist_amd import ops, sh, synthetic
+
+    dev = _cuda()
+    H, W, spp = 40, 56, 16
+    sc, n = _scene_arrays(H, W, image_id=10)
+    a, r, m, nn = (_t(x, dev) for x in (sc.albedo, sc.roughness, sc.metallic, n))
+    T = ops.shade_transfer(a, r, m, nn, spp)
+    rng = np.random.default_rng(2)
+    env = rng.random((16, 32, 3)) + 0.1
+    P = sh.envmap_to_sh_matrix(16, 32)
+    lights = []
+    for shift in range(11):                      # more than one 8-light pass
+        lights.append(P @ np.roll(env, shift, axis=1).reshape(512, 3))
+    L = _t(np.stack(lights), dev)
+    out = ops.relight(T, L, H, W)
+    for f in (0, 3, 10):
+        direct = ops.shade_fwd(a, r, m, nn, L[f].contiguous(), spp)
+        assert (out[f] - direct).abs().max().item() <= 2e-5 * direct.abs().max().item()
+    # rolling the envmap by whole columns == rotating the SH light about +y
+    c0 = P @ env.reshape(512, 3)
+    for shift in (1, 5):
+        rot = sh.rotate_y_matrix(2 * np.pi * shift / 32) @ c0
+        np.testing.assert_allclose(rot, lights[shift], atol=1e-10)
