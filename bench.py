@@ -37,6 +37,7 @@ def parse():
                     help="fused: --model_name none, whole iteration in libmatpbr.so; torch: same step composed from torch ops; "
                          "pos_mlp: the reference's default mode (maps from the residual PosMLP on PyTorch-ROCm, render/loss/backward in libmatpbr.so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-relight", action="store_true", help="skip the 2048x2048 relighting measurement (1.3 GB transfer buffer)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -211,6 +212,32 @@ def main():
         gemm["frac"] = gemm["achieved"] / gemm["peak"]
         del xg, wg
 
+    # BASELINE configs[4]: forward-only relighting, 2048x2048, 360 lights, through the precomputed transfer (HBM-bound kernel)
+    relight = None
+    if B == 1 and not args.no_relight:
+        RS = 2048
+        scr = synthetic.make_scene(lo, RS, RS)
+        tr = lambda x: torch.from_numpy(x).to(dev)
+        n_r = ops.normals_from_depth(tr(scr.depth))
+        T_r = ops.shade_transfer(tr(scr.albedo), tr(scr.roughness), tr(scr.metallic), n_r, args.spp)
+        L_r = torch.randn(360, 25, 3, device=dev) * 0.1
+        L_r[:, 0] += 3.5
+        out_r = torch.empty(8, RS, RS, 3, device=dev)
+        ops.relight(T_r, L_r[:8].contiguous(), RS, RS, out_r)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for f0 in range(0, 360, 8):
+            ops.relight(T_r, L_r[f0:f0 + 8], RS, RS, out_r)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_r = e0.elapsed_time(e1)
+        bytes_r = 45 * (300 + 8 * 12) * RS * RS       # per 8-light pass: transfer read once (300 B/px) + 8 rgb writes
+        relight = {"bound": "hbm", "kernel": "relight_kernel (2048x2048, 8 lights per pass)", "achieved": bytes_r / (ms_r * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                   "unit": "GB/s", "frames_per_s": 360 / (ms_r * 1e-3), "avg_launch_ms": ms_r / 45, "bytes_per_pixel_per_pass": 396}
+        relight["frac"] = relight["achieved"] / relight["peak"]
+        del T_r, out_r, L_r
+
     if rank == 0:
         px = H * W * B
         ms_f_in = ksum.get("shade_fwd", (0, float("nan")))[1]
@@ -242,7 +269,7 @@ def main():
                          "shade_fwd": {"achieved": ach_f, "frac": ach_f / (HBM_PEAK / 1e9), "avg_launch_ms": ms_f, "avg_launch_inloop_ms": ms_f_in,
                                        "bytes_per_pixel": BYTES_FWD},
                          "fwd+bwd": {"achieved": ach_fb, "frac": ach_fb / (HBM_PEAK / 1e9), "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM},
-                         "posmlp_gemm": gemm},
+                         "posmlp_gemm": gemm, "relight": relight},
             "psnr_db": {"initial_guess": psnr0, "after_timed_steps": psnr1, "vs": "own HIP render of the synthetic ground truth (Mitsuba cannot run, SURVEY F3)"},
         }
         if not args.no_cpu_baseline and world == 1:
