@@ -145,7 +145,8 @@ class BrdfPhase:
         parts = {k: m[k] for k in self.opt_keys}
         loss, loss_mse, pred_srgb, _ = _loss.brdf_loss(pred, self.gt, parts, self.originals, self.scale_delta, self.gt_srgb)
         loss.backward()                                                                                          # :420
-        self.saver.update(loss_mse, albedo=m["albedo"], roughness=m["roughness"], metallic=m["metallic"], rendered_img=pred_srgb)
+        extra = {} if self.scene.use_mesh_normal else {"normal": m["normal"]}
+        self.saver.update(loss_mse, albedo=m["albedo"], roughness=m["roughness"], metallic=m["metallic"], rendered_img=pred_srgb, **extra)
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         if self.opt.param_groups[0]["lr"] > 1.5e-4:                                                              # :431-432

@@ -38,6 +38,11 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         mat["metallic"] = torch.full_like(mat["metallic"], METALLIC_SHIFT)
     params = _render.traverse(scene)                                               # :216-220
     params["shape.bsdf.a"], params["shape.bsdf.r"], params["shape.bsdf.m"] = mat["albedo"], mat["roughness"], mat["metallic"]
+    if not scene.use_mesh_normal:                                                  # 'n' in opt_order: shade with the predicted normal map (:335-340)
+        if model_name == "pos_mlp":
+            raise NotImplementedError("output_type 'armn' (normals through the PosMLP) is not wired yet; use --model_name none for 'n'")
+        mat["normal"] = torch.nn.functional.normalize(mat["normal"], p=2, dim=-1)  # :193
+        params["shape.bsdf.n"] = mat["normal"]
 
     saver = _loop.DeviceSaveBest()
     state = {"final_envmap": None, "last_mse": None}
@@ -141,9 +146,37 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         say(f"loop {loop_num}: part {part!r} (pos_mlp) ran {it + 1} iterations ({stop}), best mse {float(best.min()):.5f}")
         return it, ph.opt.param_groups[0]["lr"], stop
 
+    def brdf_part_runner_normal(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
+        """Parts that optimise the normal map (output_type 'armn', use_mesh_normal False; :335-340,378-379,406-409): the
+        autograd render with the torch-composed loss (BrdfPhase) and the reference's per-epoch host EarlyStopping."""
+        ph = _loop.BrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mat["normal"], optimize_part=part, spp=spp,
+                             scale_delta=scale_delta, saver=_loop.DeviceSaveBest())
+        if saver.best_loss is not None:
+            ph.saver.best_loss = saver.best_loss.clone().reshape(())
+        es = _loop.EarlyStopping(patience, min_delta)
+        stop, it = "num_epochs", 0
+        for it in range(n_epochs):
+            es(float(ph.step()))
+            if es.early_stop:
+                stop = "early_stop"
+                break
+        new_best = ph.saver.best_loss.reshape(-1)
+        prev = saver.best_loss if saver.best_loss is not None else torch.full_like(new_best, float("inf"))
+        if bool((new_best < prev).any()) and "albedo" in ph.saver.best:
+            saver.best_loss = torch.minimum(new_best, prev)
+            for k_ in ("albedo", "roughness", "metallic", "rendered_img"):
+                saver.best[k_] = ph.saver.best[k_].clone()
+            saver.best["normal"] = ph.saver.best["normal"].clone()
+            saver.best["envmap"] = state["envmap4render"].clone()
+            mat["normal"] = saver.best["normal"]
+        say(f"loop {loop_num}: part {part!r} (with normals) ran {it + 1} iterations ({stop})")
+        return it, ph.opt.param_groups[0]["lr"], stop
+
     def brdf_part_runner(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
         if model_name == "pos_mlp":
             return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
+        if "n" in part or not scene.use_mesh_normal:
+            return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
         ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], optimize_part=part, spp=spp,
                                   scale_delta=scale_delta, patience=patience, min_delta=min_delta,
                                   best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs)
@@ -176,6 +209,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         for key in ("albedo", "roughness", "metallic"):
             mat[key] = saver.best[key].detach().clone()
         params["shape.bsdf.a"], params["shape.bsdf.r"], params["shape.bsdf.m"] = mat["albedo"], mat["roughness"], mat["metallic"]
+        if not scene.use_mesh_normal and "normal" in saver.best:
+            mat["normal"] = saver.best["normal"].detach().clone()
+            params["shape.bsdf.n"] = mat["normal"]
         _save_results()                                                             # :465,590
 
     trace: List[TraceEvent] = run_schedule(list(optimize_order), None, None, opt_src=opt_src, opt_env_from=opt_env_from,
@@ -184,8 +220,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                                            brdf_part_runner=brdf_part_runner, env_phase_runner=env_phase_runner)
     with torch.no_grad():
         params["emitter.data"] = saver.best["envmap"]
-        final = _render.render_w_brdf(scene, saver.best["albedo"], saver.best["roughness"], saver.best["metallic"], None, spp)
+        final = _render.render_w_brdf(scene, saver.best["albedo"], saver.best["roughness"], saver.best["metallic"],
+                                      None if scene.use_mesh_normal else mat["normal"], spp)
         ratio = gt.mean() / final.mean()
-    return {"albedo": saver.best["albedo"], "roughness": saver.best["roughness"], "metallic": saver.best["metallic"],
+    return {"albedo": saver.best["albedo"], "roughness": saver.best["roughness"], "metallic": saver.best["metallic"], "normal": mat.get("normal"),
             "envmap": saver.best["envmap"], "rendered_img": saver.best["rendered_img"], "final_render": final,
             "psnr": float(_loss.psnr(final * ratio, gt)), "best_loss": float(saver.best_loss.min()), "trace": trace}

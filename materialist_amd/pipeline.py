@@ -171,8 +171,6 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
 
     if model_name not in ("none", "pos_mlp"):
         raise ValueError("model_name should be 'none' or 'pos_mlp'")
-    if "n" in "".join(opt_order):
-        raise NotImplementedError("optimising the normal map ('n' in --opt_order) is not wired into the fused loop yet")
     if use_mask:
         warnings.warn("--use_mask is not supported yet; continuing without mask", UserWarning)
     log(f"Inverse image {img_inverse_path}")
@@ -222,11 +220,13 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
         depth = read_exr(os.path.join(output_dir, "depthPred.exr"))[..., 0]
         depth = 2 * depth.max() - depth
 
-    scene = render.load_estimated_mesh(t(depth), use_mesh_normal=True, device=device)           # :751-759
+    use_mesh_normal = "n" not in str(list(opt_order))                                            # :751-758
+    scene = render.load_estimated_mesh(t(depth), use_mesh_normal=use_mesh_normal, device=device)
     frames = FrameWriter(output_dir)
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
                                         num_epochs=num_epochs, sync_every=sync_every, log=log, frames=frames,
-                                        results_dir=os.path.join(output_dir, "best_results"), shading_normal=scene.geo_normal,
+                                        results_dir=os.path.join(output_dir, "best_results"),
+                                        shading_normal=scene.geo_normal if use_mesh_normal else None,
                                         model_name=model_name)
     write_hdr(os.path.join(output_dir, "final_envmap.hdr"), res["envmap"].detach().cpu().numpy())   # :297
     res["output_dir"] = output_dir

@@ -513,6 +513,12 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     res2 = pipeline.inverse_image(src, "case", opt_src="skip", opt_order=["skip"], save_path=str(tmp_path), size=32, spp=8, num_epochs=5,
                                   sync_every=5, log=lambda *_: None)
     assert res2["trace"][-1].stop == "skip"
+    # 'n' in --opt_order: shade with (and optimise) the normal map (inverse_img_w_mi.py:751-758,378-379)
+    res3 = pipeline.inverse_image(src, "case_mn", opt_src="arm", opt_order=["arm", "n"], save_path=str(tmp_path), size=32, spp=8, num_epochs=6,
+                                  sync_every=6, log=lambda *_: None)
+    assert [t.part for t in res3["trace"] if t.phase == "brdf" and t.loop == 1] == ["arm", "n"]
+    assert res3["normal"] is not None and abs(float(res3["normal"].norm(dim=-1).mean()) - 1.0) < 1e-4
+    assert json.load(open(os.path.join(res3["output_dir"], "config.json")))["use_mesh_normal"] is False
     # f4: re-render the optimised scene under its own envmap and as a rolling animation (render_final.py)
     from materialist_amd import relight
 
