@@ -23,6 +23,7 @@ def parse_args(argv=None):
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--num_epochs", type=int, default=5000)
     ap.add_argument("--pred_dir", type=str, default=None, help="directory with *Pred.exr/png initial maps (MaterialNet output layout)")
+    ap.add_argument("--matnet_weights", type=str, default=None, help="matnet_weights.pth (Lez/MatNet on the HF hub) for the MaterialNet initial guess")
     return ap.parse_args(argv)
 
 
@@ -31,7 +32,8 @@ def main(argv=None):
     from materialist_amd.pipeline import inverse_image
 
     res = inverse_image(args.img_inverse_path, args.save_name, args.opt_src, args.opt_order, args.use_mask, args.opt_env_from,
-                        args.save_path, args.model_name, size=args.size, spp=args.spp, num_epochs=args.num_epochs, pred_dir=args.pred_dir)
+                        args.save_path, args.model_name, size=args.size, spp=args.spp, num_epochs=args.num_epochs, pred_dir=args.pred_dir,
+                        matnet_weights=args.matnet_weights)
     print(f"done: PSNR {res['psnr']:.2f} dB, best loss_mse {res['best_loss']:.6f}, outputs in {res['output_dir']}")
 
 

@@ -1,9 +1,10 @@
 """Pipeline head and output layout of `inverse_img_w_mi.py` (inverse_image :623-770, get_output_dir :82-104, the
 writers of optimize_envmap_ARMN :257-303,588-599) on top of `optimize.optimize_envmap_ARMN`.  SURVEY.md section 8(f1).
 
-What is NOT here yet: MaterialNet (f3).  The initial maps therefore come from `pred_dir` (files in the layout the
-reference writes: albedoPred.exr, normalPred.exr, roughnessPred.png, metallicPred.png, depthPred.exr) or, failing
-that, from a flat prior (albedo = the linearised image, roughness 0.5, metallic 0, fronto-parallel plane).  Video
+The initial maps come from MaterialNet (`matnet_weights` = the reference's `matnet_weights.pth`, which the reference
+downloads from the HF hub, :648-654; there is no network here), or from `pred_dir` (files in the layout the reference
+writes: albedoPred.exr, normalPred.exr, roughnessPred.png, metallicPred.png, depthPred.exr), or, failing both, from a
+flat prior (albedo = the linearised image, roughness 0.5, metallic 0, fronto-parallel plane).  Video
 encoding (env_optimization.mp4 / mat_optimization.mp4) needs an encoder this image does not have; frames are kept.
 """
 from __future__ import annotations
@@ -165,7 +166,7 @@ def save_results(path: str, best: Dict[str, torch.Tensor], normal: torch.Tensor)
 def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", opt_order: Sequence[str] = ("arm",), use_mask: bool = False,
                   opt_env_from: int = 0, save_path: Optional[str] = None, model_name: str = "none", size: int = 512, spp: int = 64,
                   num_epochs: int = 5000, pred_dir: Optional[str] = None, device: str = "cuda", sync_every: int = 10,
-                  log=print) -> Dict[str, object]:
+                  log=print, matnet_weights: Optional[str] = None) -> Dict[str, object]:
     """inverse_img_w_mi.py:623-770 (resolution-generic: `size`; `model_name` is honoured, F4)."""
     from . import optimize, render
 
@@ -185,7 +186,15 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
     mat: Dict[str, torch.Tensor] = {}
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
     if opt_src != "skip" or list(opt_order) != ["skip"]:
-        pred = load_predictions(pred_dir, (size, size)) if pred_dir else flat_prior(img)
+        if matnet_weights:                                                                       # :648-661
+            from .materialnet import MaterialNet
+
+            matnet = MaterialNet()
+            matnet.load_state_dict(torch.load(matnet_weights, map_location="cpu", weights_only=True))
+            pred = matnet.to(device).eval().infer_image(img)
+            del matnet
+        else:
+            pred = load_predictions(pred_dir, (size, size)) if pred_dir else flat_prior(img)
         mat["gt_image"] = t(img)                                                                 # :663-670
         mat["albedo"] = t(pred["albedo"]).clamp(0, 1)
         mat["normal"] = t(pred["normal"])

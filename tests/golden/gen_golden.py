@@ -21,6 +21,7 @@ What each fixture pins (SURVEY.md §8c "golden vectors to commit"):
   misc.npz                EarlyStopping / SaveBest decisions, gamma           myutils/misc.py:37-111,163-170
   misc_resize.npz         center_crop_and_resize                              myutils/misc.py:10-34
   posmlp.npz              PosMLP forward + gradients for fixed weights        mymodels/mlps.py:129-251
+  materialnet.npz         MaterialNet forward for name-seeded weights, Resize sizes Material_net/dpt.py:175-217, util/transform.py:58-100
   envmaps.npz             decoded envmaps/0.hdr and output_imgs/*/best_results/envmap.hdr (data files)
 
 [ext] caveat: `mi.Frame3f(n).to_world` is Mitsuba's `coordinate_system` (Duff et al. 2017 branchless
@@ -178,6 +179,7 @@ def _np(x):
 
 
 def main():
+    sys.path.insert(0, os.path.normpath(os.path.join(OUT, "..", "..")))   # the build's own package (RGBE reader, name-seeded init)
     mi, dr = _install_shim()
     import myutils.mi_plugin as P  # noqa: E402  (reference module, read-only)
     import myutils.computeSH as SH  # noqa: E402
@@ -405,6 +407,35 @@ def main():
         pos[f"{tag}.d_lin0_w"] = _np(net.lin0.linear.weight.grad)
         pos[f"{tag}.d_lin4_b"] = _np(net.lin4.bias.grad)
     np.savez_compressed(os.path.join(OUT, "posmlp.npz"), **pos)
+
+    # ---------------------------------------------------------------- MaterialNet (f3, Material_net/dpt.py:175-217)
+    # 108 M parameters cannot be committed: every tensor of the state_dict is (re)initialised from its NAME
+    # (materialist_amd.materialnet.init_from_names), so the test rebuilds the same weights and only inputs/outputs are stored.
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvt.Compose = lambda fns: (lambda s: [s := f(s) for f in fns][-1])
+    tv.transforms = tvt
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt})
+    sys.modules["cv2"].INTER_AREA, sys.modules["cv2"].INTER_CUBIC, sys.modules["cv2"].INTER_NEAREST = 3, 2, 0
+    from Material_net.dpt import MaterialNet as RefNet  # noqa: E402
+    from Material_net.util.transform import Resize as RefResize  # noqa: E402
+    from materialist_amd.materialnet import init_from_names  # noqa: E402
+
+    ref = RefNet(encoder="vitb", features=128, out_channels=[96, 192, 384, 768], use_bn=False, use_clstoken=False).double().eval()
+    init_from_names(ref)
+    x_in = torch.rand(1, 3, 70, 98, generator=g)
+    with torch.no_grad():
+        out_ref = ref(x_in)
+        feats = ref.pretrained.get_intermediate_layers(x_in, [2, 5, 8, 11], return_class_token=True)
+    rs = RefResize(width=518, height=518, resize_target=False, keep_aspect_ratio=True, ensure_multiple_of=14, resize_method="lower_bound",
+                   image_interpolation_method=2)
+    sizes_in = [(512, 512), (427, 423), (384, 512), (1024, 1024), (640, 480), (100, 300)]
+    np.savez_compressed(os.path.join(OUT, "materialnet.npz"), x=_np(x_in), names=np.array(sorted(ref.state_dict().keys())),
+                        n_params=sum(p.numel() for p in ref.parameters()),
+                        feat3_patch=_np(feats[3][0]), feat0_cls=_np(feats[0][1]),
+                        sizes_in=np.array(sizes_in), sizes_out=np.array([rs.get_size(w, h) for (w, h) in sizes_in]),
+                        **{k: _np(v) for k, v in out_ref.items()})
+    del ref
 
     # ---------------------------------------------------------------- center_crop_and_resize (pipeline head, misc.py:10-34)
     rr = np.random.default_rng(11)

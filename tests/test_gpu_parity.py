@@ -606,3 +606,24 @@ def test_transfer_relight_equals_direct_render():
     for shift in (1, 5):
         rot = sh.rotate_y_matrix(2 * np.pi * shift / 32) @ c0
         np.testing.assert_allclose(rot, lights[shift], atol=1e-10)
+
+
+def test_materialnet_runs_on_the_gpu(tmp_path):
+    """f3 on PyTorch-ROCm: random-weight MaterialNet through the pipeline's initial-guess path (SDPA attention on the GPU)."""
+    from PIL import Image
+
+    from materialist_amd import pipeline
+    from materialist_amd.materialnet import MaterialNet
+
+    dev = _cuda()
+    net = MaterialNet().to(dev).eval()
+    img = (np.random.default_rng(1).random((64, 80, 3)) * 255).astype(np.uint8)
+    out = net.infer_image(img, input_size=140)
+    assert out["albedo"].shape == (64, 80, 3) and np.isfinite(out["depth"]).all() and (out["roughness"] >= 0).all()
+    wpath = str(tmp_path / "w.pth")
+    torch.save(net.state_dict(), wpath)
+    src = str(tmp_path / "in.png")
+    Image.fromarray(img).save(src)
+    res = pipeline.inverse_image(src, "mn_case", opt_src="arm", opt_order=["arm"], save_path=str(tmp_path), size=32, spp=8, num_epochs=4,
+                                 sync_every=4, log=lambda *_: None, matnet_weights=wpath)
+    assert os.path.exists(os.path.join(res["output_dir"], "albedoPred.exr"))
