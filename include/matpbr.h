@@ -147,6 +147,8 @@ int matpbr_env_phase_step(const float* a, const float* r, const float* m, const 
 
 /* Column sums of a row-major [M, N] fp32 matrix -> out[N]: the bias gradient of the PosMLP layers over M = H*W points
  * (mymodels/mlps.py:102-103 under autograd).  Deterministic two-pass; workspace of matpbr_column_sum_workspace_bytes(N). */
+int matpbr_sin_bwd(const float* d_y, long ld_d, const float* pre, long ld_p, float* out, long M, int n, void* stream);
+    /* out[M,n] (contiguous) = d_y[M,n (row stride ld_d)] * cos(pre[M,n (row stride ld_p)]): backward of the PosMLP sine layers */
 size_t matpbr_column_sum_workspace_bytes(int N);
 int matpbr_column_sum(const float* x, float* out, long M, int N, void* workspace, size_t workspace_bytes, void* stream);
 

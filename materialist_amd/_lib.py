@@ -51,6 +51,7 @@ SIGNATURES = {
     "matpbr_env_phase_step": (ctypes.c_int, [_c_f] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),
                                             ctypes.c_void_p]),
+    "matpbr_sin_bwd": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_column_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_column_sum": (ctypes.c_int, [_c_f, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "matpbr_shade_transfer": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),

@@ -852,6 +852,19 @@ __global__ __launch_bounds__(kBlock) void colsum_pass2_kernel(const float* __res
     }
 }
 
+// Backward of y = sin(pre): out[i][j] = d_y[i*ld_d + j] * cos(pre[i*ld_p + j]), contiguous [M, n] result
+// (PosMLP hidden layers, mymodels/mlps.py:102-103; replaces a cos kernel + a mul kernel and takes the row-strided views
+// that the skip-connection buffers produce).
+__global__ __launch_bounds__(kBlock) void sin_bwd_kernel(const float* __restrict__ d_y, long ld_d, const float* __restrict__ pre, long ld_p,
+                                                         float* __restrict__ out, long M, int n) {
+    const long total = M * n;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const long r = i / n;
+        const int c = (int)(i - r * n);
+        out[i] = d_y[r * ld_d + c] * cosf(pre[r * ld_p + c]);
+    }
+}
+
 // d_light[b][k][c] = kShNorm[k] * sum over the image's workgroups of partials (fixed order -> reproducible)
 __global__ __launch_bounds__(kBlock) void light_grad_finalize_kernel(const float* __restrict__ partials, float* __restrict__ d_light,
                                                                      int nblocks, const float* __restrict__ stats) {
@@ -1361,6 +1374,14 @@ int matpbr_relight(const float* T, const float* lights, float* out_rgb, int H, i
         hipLaunchKernelGGL(relight_kernel, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, T, lights + (long)f0 * kNL,
                            out_rgb + (long)f0 * P * 3, P, nf);
     }
+    return launch_status();
+}
+
+int matpbr_sin_bwd(const float* d_y, long ld_d, const float* pre, long ld_p, float* out, long M, int n, void* stream) {
+    if (!d_y || !pre || !out || M <= 0 || n <= 0 || ld_d < n || ld_p < n) return MATPBR_ERR_INVALID_ARG;
+    const long total = M * n;
+    unsigned blocks = (unsigned)std::min<long>((total + kBlock - 1) / kBlock, 256L * 16);
+    hipLaunchKernelGGL(sin_bwd_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, d_y, ld_d, pre, ld_p, out, M, n);
     return launch_status();
 }
 

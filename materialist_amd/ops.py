@@ -336,3 +336,16 @@ def relight(T, lights, H: int, W: int, out: Optional[torch.Tensor] = None) -> to
         code = lib.matpbr_relight(_ptr(T), _ptr(lights), _ptr(out), H, W, F_, _stream(T))
     _lib.check(code, "matpbr_relight")
     return out
+
+
+def sin_bwd(d_y: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
+    """d_y * cos(pre) for [M, n] fp32 CUDA tensors whose rows may be strided views (stride(1) == 1); contiguous result."""
+    lib = _lib.load()
+    if d_y.shape != pre.shape or d_y.ndim != 2 or d_y.stride(1) != 1 or pre.stride(1) != 1 or not d_y.is_cuda or d_y.dtype != torch.float32:
+        raise ValueError("sin_bwd expects matching [M, n] fp32 CUDA tensors with unit column stride")
+    M, n = d_y.shape
+    out = torch.empty((M, n), dtype=torch.float32, device=d_y.device)
+    with torch.cuda.device(d_y.device):
+        code = lib.matpbr_sin_bwd(_ptr(d_y), d_y.stride(0), _ptr(pre), pre.stride(0), _ptr(out), M, n, _stream(d_y))
+    _lib.check(code, "matpbr_sin_bwd")
+    return out

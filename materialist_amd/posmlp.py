@@ -39,46 +39,85 @@ def _column_sum(g: torch.Tensor) -> torch.Tensor:
     return g.sum(0)
 
 
-class _LinearSin(torch.autograd.Function):
-    """y = sin(x @ W[:, :k].T + x0 @ W[:, k:].T + b) with a backward pass made only of GEMMs / GEMVs.
+def _sin_bwd(d_y: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
+    if d_y.is_cuda and d_y.dtype == torch.float32:
+        from . import ops
 
-    Two things PyTorch's stock composition does badly at M = 262 144 rows: the bias gradient is a column reduction of a
-    [M, 256] tensor (`reduce_kernel`, 2-4 ms each on MI355X, 45 % of an iteration) -- here it is a GEMV with a ones vector;
-    and the skip connection materialises cat(x, x0) (a 268 MB copy per skip layer, forward and backward) -- here the weight
-    is split by columns instead, so x and x0 are multiplied separately into the same output."""
+        return ops.sin_bwd(d_y, pre)
+    return d_y * torch.cos(pre)
+
+
+class _PosMlpFn(torch.autograd.Function):
+    """The whole coordinate MLP as one autograd node, laid out for the hardware:
+
+    * a layer that feeds a skip layer writes sin(pre) straight into the first columns of the next layer's [M, 256] input
+      buffer whose last columns already hold x0 -- `cat(x, x0)` (:223-224) costs no copy and no split GEMM (the reference
+      narrows those layers to 256 - len(x0) for exactly this reason);
+    * backward = GEMMs (weight gradients 64-way split-K), one fused `d_y * cos(pre)` pass per layer on the strided views,
+      HIP column sums for the bias gradients.  PyTorch's stock composition spends 45 % of an iteration in `reduce_kernel`."""
 
     @staticmethod
-    def forward(ctx, x, x0, weight, bias, apply_sin):
-        k = x.shape[1]
-        pre = torch.addmm(bias, x, weight[:, :k].t())
-        if x0 is not None:
-            pre.addmm_(x0, weight[:, k:].t())
-        ctx.save_for_backward(x, x0, weight, pre if apply_sin else None)
-        ctx.apply_sin = apply_sin
-        return torch.sin(pre) if apply_sin else pre
+    def forward(ctx, x0, skip, n_hidden, *wb):
+        L = len(wb) // 2
+        weights, biases = wb[0::2], wb[1::2]
+        d0 = x0.shape[1]
+        inp, inps, pres = x0, [], []
+        for l in range(L):
+            W, b = weights[l], biases[l]
+            inps.append(inp)
+            pre = torch.addmm(b, inp, W.t())
+            if l == L - 1:
+                out = pre
+                break
+            pres.append(pre)
+            n_out = W.shape[0]
+            if (l + 1) in skip:
+                buf = torch.empty((x0.shape[0], n_out + d0), dtype=x0.dtype, device=x0.device)
+                torch.sin(pre, out=buf[:, :n_out])
+                buf[:, n_out:] = x0
+                inp = buf
+            else:
+                inp = torch.sin(pre)
+        ctx.save_for_backward(x0, *weights, *inps[1:], *pres)
+        ctx.skip, ctx.L = tuple(skip), L
+        return out
 
     @staticmethod
-    def backward(ctx, grad):
-        x, x0, weight, pre = ctx.saved_tensors
-        k = x.shape[1]
-        g = grad * torch.cos(pre) if ctx.apply_sin else grad
-        g = g.contiguous()
-        d_w, d_x0 = _split_k_tn(g, x), None
-        if x0 is not None:
-            d_w = torch.cat([d_w, _split_k_tn(g, x0)], dim=1)        # [out, k + len(x0)]: small
-            d_x0 = g @ weight[:, k:] if ctx.needs_input_grad[1] else None
-        d_b = _column_sum(g)
-        d_x = g @ weight[:, :k] if ctx.needs_input_grad[0] else None
-        return d_x, d_x0, d_w, d_b, None
+    def backward(ctx, grad_out):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        x0, weights = saved[0], saved[1:1 + L]
+        inps = (x0,) + tuple(saved[1 + L:1 + L + (L - 1)])
+        pres = saved[1 + L + (L - 1):]
+        d0 = x0.shape[1]
+        need_x0 = ctx.needs_input_grad[0]
+        d_x0 = torch.zeros_like(x0) if need_x0 else None
+        grads = [None] * (2 * L)
+        g = grad_out.contiguous()
+        for l in range(L - 1, -1, -1):
+            grads[2 * l] = _split_k_tn(g, inps[l])
+            grads[2 * l + 1] = _column_sum(g)
+            if l == 0:
+                if need_x0:
+                    d_x0 += g @ weights[0]
+                break
+            d_inp = g @ weights[l]                                   # [M, in_l]
+            n_prev = weights[l - 1].shape[0]
+            if need_x0 and l in ctx.skip:
+                d_x0 += d_inp[:, n_prev:]
+            g = _sin_bwd(d_inp[:, :n_prev], pres[l - 1])             # through sin of layer l-1, contiguous [M, n_prev]
+        return (d_x0, None, None, *grads)
 
 
 class _Sine(nn.Module):
+    """Hidden layer: Linear followed by sin (the reference's SineLayer applies no omega_0, mymodels/mlps.py:102-103)."""
+
     def __init__(self, n_in: int, n_out: int):
         super().__init__()
         self.linear = nn.Linear(n_in, n_out)      # default PyTorch init; the SIREN init is commented out in the reference (:86)
 
-    def forward(self, x: torch.Tensor, x0=None) -> torch.Tensor:
-        return _LinearSin.apply(x, x0, self.linear.weight, self.linear.bias, True)
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.sin(self.linear(x))
 
 
 def grid_shape(n_rows: int) -> Tuple[int, int]:
@@ -135,14 +174,12 @@ class PosMLP(nn.Module):
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         x0 = self._points(img)
-        x = x0
+        wb = []
         for l in range(self.n_layers):
             layer = getattr(self, f"lin{l}")
-            skip_in = x0 if l in self.skip else None          # cat(x, x0) without the copy: the weight is split by columns
-            if l < self.n_layers - 1:
-                x = layer(x, skip_in)
-            else:
-                x = _LinearSin.apply(x, skip_in, layer.weight, layer.bias, False)
+            lin = layer.linear if l < self.n_layers - 1 else layer
+            wb += [lin.weight, lin.bias]
+        x = _PosMlpFn.apply(x0, self.skip, self.n_layers - 1, *wb)
         if self.output_type == "envmap":
             return F.softplus(x)
         if self.output_type == "arm":
