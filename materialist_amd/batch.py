@@ -1,0 +1,63 @@
+"""Batches of independent images across the GPUs of one node (BASELINE config 3).
+
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N run_batch.py ...`): rank 0 broadcasts the run
+configuration, every rank optimises its contiguous shard of the image list with no communication in between, and the
+per-image result rows (loss, PSNR, iterations) are gathered on rank 0 at the end.  The reference processes images one
+after another in a shell loop (run_inverse_pipeline.sh:16-28).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .dist import broadcast_config, gather_results, shard_range
+
+
+def init_distributed(backend: str | None = None) -> tuple:
+    """(rank, world, local_rank); initialises torch.distributed from the torchrun environment when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def run_batch(image_paths: Sequence[str], config: Dict, process_image: Callable[[int, str, Dict], Sequence[float]], device=None) -> List[Dict]:
+    """`process_image(image_id, path, config) -> [loss_mse, psnr, ...]` runs on the rank that owns the image.
+    Returns on rank 0 one dict per image in list order ({"image_id", "path", "rank", "values"}), [] elsewhere."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    cfg = broadcast_config({"paths": list(image_paths), "config": dict(config)} if rank == 0 else None)
+    paths = cfg["paths"]
+    lo, hi = shard_range(len(paths), world, rank)
+    rows = []
+    for i in range(lo, hi):
+        vals = [float(v) for v in process_image(i, paths[i], cfg["config"])]
+        rows.append([float(i), float(rank)] + vals)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.is_initialized()
+                                                                        and dist.get_backend() == "nccl") else torch.device("cpu")
+    width = max([len(r) for r in rows], default=2)
+    if dist.is_initialized():                     # ranks with an empty shard still need the row width for the gather
+        wt = torch.tensor([width], device=device)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        width = int(wt.item())
+    local = torch.tensor(rows, dtype=torch.float64, device=device).reshape(-1, width)
+    parts = gather_results(local, dst=0)
+    if rank != 0:
+        return []
+    out = []
+    for part in parts:
+        for row in part.cpu().tolist():
+            out.append({"image_id": int(row[0]), "path": paths[int(row[0])], "rank": int(row[1]), "values": row[2:]})
+    return out

@@ -64,3 +64,43 @@ def test_two_rank_shard_and_gather(n_images):
         sc = synthetic.make_scene(i, 16, 16)
         want.append([float(i), float(sc.albedo.mean()), float(sc.light[1, 0])])
     np.testing.assert_array_equal(res, np.array(want))
+
+
+def _batch_worker(rank, world, port, n_images, out_q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from materialist_amd import batch
+
+    r, w, _ = batch.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    seen = []
+
+    def process(i, path, cfg):
+        seen.append(i)
+        return [cfg["scale"] * i, float(len(path))]
+
+    rows = batch.run_batch([f"img_{k}.png" for k in range(n_images)] if rank == 0 else [], {"scale": 0.5} if rank == 0 else {}, process)
+    out_q.put((rank, seen, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images", [1, 5])
+def test_run_batch_shards_and_gathers(n_images):
+    """materialist_amd.batch: config comes from rank 0 only, each image is processed exactly once by its owner, rank 0 gets
+    every row in image order (also when a rank's shard is empty)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, seen0, rows0), (r1, seen1, rows1) = got
+    assert sorted(seen0 + seen1) == list(range(n_images)) and not (set(seen0) & set(seen1))
+    assert rows1 == []
+    assert [r["image_id"] for r in rows0] == list(range(n_images))
+    assert all(r["values"] == [0.5 * r["image_id"], float(len(r["path"]))] for r in rows0)
+    assert all(r["rank"] == (0 if r["image_id"] in seen0 else 1) for r in rows0)
