@@ -172,6 +172,9 @@ int matpbr_eval_brdf(const float* wi, const float* wo, const float* n, const flo
 int matpbr_eval_brdf_bwd(const float* wi, const float* wo, const float* n, const float* a, const float* r,
                          const float* m, const float* g /*[N,3] upstream*/, float* d_a, float* d_r, float* d_m,
                          float* d_n, long N, void* stream);
+/* a1-a3 over N lanes -> out[N,4] = { D_GGX(cos1, r), G1_GGX_Schlick(cos1, r), G_Smith(cos1, cos2, r), fresnelSchlick(cos1, f0) }
+ * (myutils/mi_plugin.py:89-97, 60-68, 70-76, 78-81). */
+int matpbr_brdf_terms(const float* cos1, const float* cos2, const float* r, const float* f0, float* out, long N, void* stream);
 int matpbr_sample_brdf(const float* sample1, const float* sample2, const float* wo, const float* n, const float* a,
                        const float* r, const float* m, float* wi, float* pdf, float* weight, long N, void* stream);
 

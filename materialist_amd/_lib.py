@@ -62,6 +62,7 @@ SIGNATURES = {
                                        ctypes.c_void_p]),
     "matpbr_eval_brdf": (ctypes.c_int, [_c_f] * 8 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_eval_brdf_bwd": (ctypes.c_int, [_c_f] * 11 + [ctypes.c_long, ctypes.c_void_p]),
+    "matpbr_brdf_terms": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_sample_brdf": (ctypes.c_int, [_c_f] * 10 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_sh_eval": (ctypes.c_int, [_c_f] * 3 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_normals_from_depth": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),

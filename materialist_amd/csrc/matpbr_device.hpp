@@ -230,29 +230,4 @@ __device__ __forceinline__ void sh_poly(const T w[3], T B[kNSH]) {
     B[21] = xz * t73; B[22] = d * t7; B[23] = c3 * Z; B[24] = vfma(d, d, -4.0f * (xy * xy));
 }
 
-// Streaming form for the image kernels: every basis polynomial is consumed the moment it is produced, so only the
-// ~14 shared monomials stay live instead of 25 packed values (50 VGPRs).  `use(k, B_k)` is called for k = 0..24.
-template <class T, class F>
-__device__ __forceinline__ void sh_poly_stream(const T w[3], F&& use) {
-    const T X = -w[2], Y = w[0], Z = w[1];
-    use(0, T(1.0f));
-    use(1, Y); use(2, Z); use(3, X);
-    const T z2 = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z, y2 = Y * Y;
-    const T d = vfma(X, X, -y2);
-    use(4, xy); use(5, yz); use(6, vfma(z2, 3.0f, -1.0f)); use(7, xz); use(8, d);
-    const T t5 = vfma(z2, 5.0f, -1.0f);
-    const T s3 = Y * vfma(3.0f * X, X, -y2), c3 = X * vfma(X, X, -3.0f * y2);
-    use(9, s3); use(10, xy * Z); use(11, Y * t5); use(12, Z * (t5 - 2.0f)); use(13, X * t5); use(14, d * Z); use(15, c3);
-    const T t7 = vfma(z2, 7.0f, -1.0f), t73 = t7 - 2.0f;
-    use(16, xy * d); use(17, s3 * Z); use(18, xy * t7); use(19, yz * t73); use(20, vfma(vfma(z2, 35.0f, -30.0f), z2, 3.0f));
-    use(21, xz * t73); use(22, d * t7); use(23, c3 * Z); use(24, vfma(d, d, -4.0f * (xy * xy)));
-}
-
-// ---- view direction of pixel (i,j): wo = -p/|p|, p = ((j-cx)/f, -(i-cy)/f, -1)    ---------
-__device__ __forceinline__ void view_dir(int i, int j, float inv_f, float cx, float cy, float wo[3]) {
-    float x = (cx - (float)j) * inv_f, y = ((float)i - cy) * inv_f;
-    float il = rsq(fmaf(x, x, fmaf(y, y, 1.0f)));
-    wo[0] = x * il; wo[1] = y * il; wo[2] = il;
-}
-
 }  // namespace matpbr

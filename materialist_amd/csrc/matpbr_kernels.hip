@@ -957,6 +957,19 @@ __global__ __launch_bounds__(kBlock) void eval_brdf_bwd_kernel(const float* __re
     d_m[k] = o.d_m;
 }
 
+// a1-a3 as N-lane functions (myutils/mi_plugin.py:60-97): D_GGX(cos_h, r), G1_GGX_Schlick(cos, r), G_Smith(cos, cos2, r),
+// fresnelSchlick(cos, f0) -> out[N,4]
+__global__ __launch_bounds__(kBlock) void brdf_terms_kernel(const float* __restrict__ cos1, const float* __restrict__ cos2,
+                                                            const float* __restrict__ r, const float* __restrict__ f0, float* __restrict__ out,
+                                                            long N) {
+    long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= N) return;
+    out[4 * k + 0] = D_GGX(cos1[k], r[k]);
+    out[4 * k + 1] = G1_GGX_Schlick(cos1[k], r[k]);
+    out[4 * k + 2] = G_Smith(cos1[k], cos2[k], r[k]);
+    out[4 * k + 3] = fresnelSchlick(cos1[k], f0[k]);
+}
+
 __global__ __launch_bounds__(kBlock) void sample_brdf_kernel(const float* __restrict__ sample1, const float* __restrict__ sample2,
                                                              const float* __restrict__ wo, const float* __restrict__ n,
                                                              const float* __restrict__ a, const float* __restrict__ r,
@@ -1178,6 +1191,14 @@ int matpbr_eval_brdf_bwd(const float* wi, const float* wo, const float* n, const
     if (N == 0) return MATPBR_OK;
     hipLaunchKernelGGL(eval_brdf_bwd_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, wi, wo,
                        n, a, r, m, g, d_a, d_r, d_m, d_n, N);
+    return launch_status();
+}
+
+int matpbr_brdf_terms(const float* cos1, const float* cos2, const float* r, const float* f0, float* out, long N, void* stream) {
+    if (!cos1 || !cos2 || !r || !f0 || !out || N < 0) return MATPBR_ERR_INVALID_ARG;
+    if (N == 0) return MATPBR_OK;
+    hipLaunchKernelGGL(brdf_terms_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, cos1, cos2, r, f0,
+                       out, N);
     return launch_status();
 }
 

@@ -349,3 +349,15 @@ def sin_bwd(d_y: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
         code = lib.matpbr_sin_bwd(_ptr(d_y), d_y.stride(0), _ptr(pre), pre.stride(0), _ptr(out), M, n, _stream(d_y))
     _lib.check(code, "matpbr_sin_bwd")
     return out
+
+
+def brdf_terms(cos1, cos2, r, f0) -> torch.Tensor:
+    """[N,4] = D_GGX(cos1, r), G1_GGX_Schlick(cos1, r), G_Smith(cos1, cos2, r), fresnelSchlick(cos1, f0) over N lanes."""
+    lib = _lib.load()
+    cos1, cos2, r, f0 = (_dev(t, k).reshape(-1) for t, k in ((cos1, "cos1"), (cos2, "cos2"), (r, "r"), (f0, "f0")))
+    N = cos1.numel()
+    out = torch.empty((N, 4), dtype=torch.float32, device=cos1.device)
+    with torch.cuda.device(cos1.device):
+        code = lib.matpbr_brdf_terms(_ptr(cos1), _ptr(cos2), _ptr(r), _ptr(f0), _ptr(out), N, _stream(cos1))
+    _lib.check(code, "matpbr_brdf_terms")
+    return out

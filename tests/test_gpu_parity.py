@@ -80,6 +80,25 @@ def test_eval_brdf_matches_reference_golden(golden_dir, name):
         assert_close(d_m, g[f"d_m_ch{ch}"], what=f"d_m ch{ch}")
 
 
+# ------------------------------------------------------------------------------------------------ a1-a3
+def test_brdf_terms_match_reference_grids(golden_dir):
+    from materialist_amd import ops
+
+    dev = _cuda()
+    g = np.load(os.path.join(golden_dir, "brdf_scalar_grids.npz"))
+    R, C = np.meshgrid(g["r"], g["c"], indexing="ij")
+    out = ops.brdf_terms(_t(C.reshape(-1), dev), _t(np.full(C.size, 0.5), dev), _t(R.reshape(-1), dev), _t(np.full(C.size, 0.04), dev)).cpu().numpy()
+    # D_GGX near cos = 1 at small r is the ill-conditioned literal form (condition number 1/alpha^2): 1e-3 away from the peak, 2e-2 on it
+    D = g["D"].reshape(-1)
+    peak = (R.reshape(-1) < 0.15) & (C.reshape(-1) > 0.95)
+    errD = np.abs(out[:, 0] - D) / np.maximum(np.abs(D), 1e-12)
+    assert errD[~peak].max() < 1e-3 and errD[peak].max() < 2e-2
+    np.testing.assert_allclose(out[:, 1], g["G1"].reshape(-1), rtol=1e-5)
+    np.testing.assert_allclose(out[:, 2], g["Gs"][2].reshape(-1), rtol=1e-5)       # Gs_nol[2] = 0.5
+    fr = ops.brdf_terms(_t(g["c"], dev), _t(g["c"], dev), _t(np.full(33, 0.5), dev), _t(np.full(33, 0.5), dev)).cpu().numpy()
+    np.testing.assert_allclose(fr[:, 3], g["Fr"][1], rtol=1e-5)                     # F0 = 0.5
+
+
 # ------------------------------------------------------------------------------------------------ a5
 def test_sample_brdf_matches_reference_golden(golden_dir):
     from materialist_amd import ops
