@@ -133,8 +133,8 @@ def main():
             pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = gt_a, gt_r, gt_m
             enet = posmlp.envmap_net().to(dev)
             ones = torch.ones(512, 3, device=dev)
-            return loop.FusedEnvPhase(s_env, gt_image if B == 1 else gt_image, lambda: enet(ones).reshape(16, 32, 3), torch.optim.Adam(enet.parameters(), lr=1e-3),
-                                      spp=args.spp)
+            return loop.FusedEnvPhase(s_env, gt_image, lambda: enet(ones).reshape(16, 32, 3), loop.capturable_adam(enet.parameters(), 1e-3),
+                                      spp=args.spp, use_graph=True)     # whole iteration replayed from a hipGraph after 3 eager ones
         return loop.BrdfPhase(scene, gt_image, *init, None, optimize_part="rm", spp=args.spp)
 
     def fence():

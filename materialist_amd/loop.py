@@ -284,11 +284,17 @@ class FusedEnvPhase:
     its backward and the optimiser step stay in torch, fed with d loss / d light from the device."""
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, head, optimizer: torch.optim.Optimizer, spp: int = 64,
-                 patience: int = 0, min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000):
+                 patience: int = 0, min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
+                 use_graph: bool = False):
+        """`use_graph`: capture one whole iteration (head forward, SH projection, the five kernels of matpbr_env_phase_step,
+        head backward, optimiser step) into a hipGraph after three eager iterations and replay it afterwards.  The envmap
+        MLP works on 512 points, so the eager iteration is bound by ~60 kernel launches from Python (1.0 ms for 0.17 ms of GPU
+        work); the optimiser must then be built by `capturable_adam` (tensor learning rate, set with `set_lr`)."""
         import ctypes
 
         from . import _lib, ops
 
+        self.use_graph, self._graph, self._warm = bool(use_graph), None, 0
         self._ct, self._libmod, self.ops = ctypes, _lib, ops
         self.scene, self.head, self.opt, self.spp = scene, head, optimizer, int(spp)
         self.gt = gt_image.contiguous()
@@ -310,6 +316,25 @@ class FusedEnvPhase:
         self._prev_best = self.stats[:, ops.STAT_BEST].clone()
 
     def step(self) -> None:
+        if not self.use_graph:
+            self._body()
+        elif self._graph is not None:
+            self._graph.replay()
+        elif self._warm < 3:                      # eager iterations first: allocator warm-up, lazy initialisations
+            self._body()
+            self.opt.zero_grad(set_to_none=True)
+            self._warm += 1
+        else:
+            self.opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._body()
+            self._graph = graph                   # the capture itself does not execute: replay it for this iteration
+            graph.replay()
+        self.t += 1
+
+    def _body(self) -> None:
         ct, sc, ops = self._ct, self.scene, self.ops
         data = self.head()
         light = sc.light_from_emitter(data)
@@ -334,12 +359,12 @@ class FusedEnvPhase:
             self.best_env = d.clone()
         else:
             sel = improved.reshape((self.B,) + (1,) * (d.ndim - 1)) if (self.B > 1 and d.ndim == self.best_env.ndim and d.shape[0] == self.B) else improved.any()
-            self.best_env = torch.where(sel, d, self.best_env)
+            self.best_env.copy_(torch.where(sel, d, self.best_env))
         g = self.d_light if light.shape == self.d_light.shape else self.d_light.sum(0)
         light.backward(g)
         self.opt.step()
-        self.opt.zero_grad(set_to_none=True)
-        self.t += 1
+        if not self.use_graph:
+            self.opt.zero_grad(set_to_none=True)
 
     def poll(self) -> Dict[str, torch.Tensor]:
         st, o = self.stats.cpu(), self.ops
@@ -441,3 +466,18 @@ def _lib_ws(batch: int) -> int:
     from . import _lib
 
     return _lib.load().matpbr_brdf_loss_workspace_bytes(int(batch))
+
+
+def capturable_adam(params, lr: float) -> torch.optim.Optimizer:
+    """Adam whose step can live inside a hipGraph: device-side step counter and a tensor learning rate (see `set_lr`)."""
+    params = list(params)
+    dev = params[0].device
+    return torch.optim.Adam(params, lr=torch.tensor(float(lr), device=dev), capturable=True, foreach=True)
+
+
+def set_lr(opt: torch.optim.Optimizer, lr: float) -> None:
+    for gp in opt.param_groups:
+        if isinstance(gp["lr"], torch.Tensor):
+            gp["lr"].fill_(float(lr))
+        else:
+            gp["lr"] = float(lr)

@@ -67,15 +67,15 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
 
     # ------------------------------------------------------------------ hot loop A (:236-254), device-resident
     def env_phase_runner(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
-        opt = torch.optim.Adam(env_params, lr=lr_of(0))                             # fresh Adam per loop (:225-229)
+        graph = max_epochs > 8 and gt.is_cuda
+        opt = _loop.capturable_adam(env_params, lr_of(0)) if graph else torch.optim.Adam(env_params, lr=lr_of(0))   # fresh Adam per loop (:225-229)
         ph = _loop.FusedEnvPhase(scene, gt, env_head, opt, spp=spp, patience=patience,
-                                 min_delta=min_delta, best_mse=saver.best_loss, history_len=max_epochs)
+                                 min_delta=min_delta, best_mse=saver.best_loss, history_len=max_epochs, use_graph=graph)
         done, stop = 0, "num_epochs"
         while done < max_epochs:
             k = min(sync_every, max_epochs - done)
             for _ in range(k):
-                for gp in opt.param_groups:
-                    gp["lr"] = lr_of(done)
+                _loop.set_lr(opt, lr_of(done))
                 ph.step()
                 done += 1
             info = ph.poll()

@@ -498,6 +498,22 @@ def test_fused_env_phase_matches_torch_composition():
     assert (raw_a - raw_b).abs().max().item() < 2e-4       # 4 Adam steps of 1e-2
     assert fused.poll()["iters"].tolist() == [4]
     assert fused.best_env.shape == (16, 32, 3)
+    # the same iterations replayed from a hipGraph (3 eager + captured): identical trajectory
+    raw_c = raw0.clone().requires_grad_(True)
+    opt_c = loop.capturable_adam([raw_c], 1e-2)
+    gph = loop.FusedEnvPhase(make_scene(), gt, lambda: torch.nn.functional.softplus(raw_c), opt_c, spp=spp, use_graph=True)
+    raw_d = raw0.clone().requires_grad_(True)
+    eag = loop.FusedEnvPhase(make_scene(), gt, lambda: torch.nn.functional.softplus(raw_d), loop.capturable_adam([raw_d], 1e-2), spp=spp)
+    for it in range(8):
+        if it == 5:
+            loop.set_lr(opt_c, 5e-3)
+            loop.set_lr(eag.opt, 5e-3)
+        gph.step()
+        eag.step()
+    assert gph._graph is not None
+    assert gph.poll()["iters"].tolist() == [8]
+    assert (raw_c - raw_d).abs().max().item() < 1e-6
+    assert torch.allclose(gph.history(), eag.history(), rtol=1e-5)
     assert_close(fused.pred, pred.detach().cpu().numpy(), rtol=5e-3, what="last render")
 
 
