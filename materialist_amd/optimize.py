@@ -63,7 +63,10 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         env_head = lambda: torch.nn.functional.softplus(env_raw)
     else:
         raise ValueError("model_name should be 'none' or 'pos_mlp'")
-    say = log if log is not None else (lambda *_: None)
+    import time
+
+    t_start = time.perf_counter()
+    say = (lambda msg: log(f"[{time.perf_counter() - t_start:7.2f} s] {msg}")) if log is not None else (lambda *_: None)
 
     # ------------------------------------------------------------------ hot loop A (:236-254), device-resident
     def env_phase_runner(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
@@ -79,7 +82,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 ph.step()
                 done += 1
             info = ph.poll()
-            if frames is not None and gt.ndim == 3:
+            if frames is not None and gt.ndim == 3 and frames.due("env"):
                 frames.env_frame(loop_num, done - 1, gt, ph.pred, env_head().detach())
             if bool(info["stopped"].all()):
                 stop = "early_stop"
@@ -130,7 +133,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             if ph.step_and_check():                                                 # per-epoch host check, as the reference (:550)
                 stop = "early_stop"
                 break
-            if frames is not None and it % 10 == 0:
+            if frames is not None and it % 10 == 0 and frames.due("mat"):
                 frames.mat_frame(loop_num, part, it, gt, _loss.linear_to_srgb((ph.pred * ph.stats[0, 0]).clamp_min(1e-8)),
                                  {k: ph.best[k] for k in ("albedo", "roughness", "metallic")},
                                  shading_normal if shading_normal is not None else scene.shading_normal())
@@ -186,7 +189,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             ph.run(k)
             done += k
             info = ph.poll()
-            if frames is not None and gt.ndim == 3:
+            if frames is not None and gt.ndim == 3 and frames.due("mat"):
                 frames.mat_frame(loop_num, part, done - 1, gt, _loss.linear_to_srgb((ph.pred * ph.stats[0, 0]).clamp_min(1e-8)),
                                  ph.current_maps(), shading_normal if shading_normal is not None else scene.shading_normal())
             if bool(info["stopped"].all()):
