@@ -106,13 +106,23 @@ def _make_adam(params, lr):
         return torch.optim.Adam(params, lr=lr)
 
 
+def masked_mean_fill(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """`x[mask] = x[mask].mean()` of `--use_mask` (inverse_img_w_mi.py:379-381,509-511), out of place and without boolean
+    indexing (no host synchronisation): every masked entry becomes the masked mean, so its gradient is the mean of the masked
+    gradients, as autograd gives for the reference's in-place form.  x [H,W,C], mask [H,W] bool."""
+    w = mask.to(x.dtype).reshape(mask.shape + (1,) * (x.ndim - mask.ndim))
+    mean = (x * w).sum() / (w.sum() * (x.numel() // w.numel())).clamp_min(1.0)
+    return x * (1.0 - w) + mean * w
+
+
 class BrdfPhase:
     """Hot loop B, `model_name == 'none'` (inverse_img_w_mi.py:347-468)."""
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
                  normal: Optional[torch.Tensor] = None, optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4,
-                 scale_delta: float = 0.1, saver: Optional[DeviceSaveBest] = None):
+                 scale_delta: float = 0.1, saver: Optional[DeviceSaveBest] = None, mask: Optional[torch.Tensor] = None):
         self.scene, self.gt, self.spp, self.scale_delta = scene, gt_image, spp, scale_delta
+        self.mask = mask
         self.part = optimize_part
         self.maps = {"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": normal}
         self.originals = {k: v.detach().clone() for k, v in self.maps.items() if v is not None}
@@ -136,6 +146,9 @@ class BrdfPhase:
             m["metallic"] = p["metallic"].clamp(0, 1)                # :377
         if "normal" in p:
             m["normal"] = torch.nn.functional.normalize(p["normal"], p=2, dim=-1)   # :379
+        if self.mask is not None:                                    # :379-381
+            m["roughness"] = masked_mean_fill(m["roughness"], self.mask)
+            m["metallic"] = masked_mean_fill(m["metallic"], self.mask)
         return m
 
     def step(self) -> torch.Tensor:
@@ -383,12 +396,14 @@ class PosMlpBrdfPhase:
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_arm: torch.Tensor, fixed: Dict[str, torch.Tensor],
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
-                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000):
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
+                 mask: Optional[torch.Tensor] = None):
         from . import ops
 
         if not scene.use_mesh_normal or "n" in optimize_part:
             raise NotImplementedError("PosMlpBrdfPhase covers output_type 'arm' (geometric normals)")
         self.ops, self.scene, self.net, self.part = ops, scene, net, optimize_part
+        self.mask = mask
         self.spp, self.scale_delta = int(spp), float(scale_delta)
         self.gt = gt_image.contiguous()
         self.H, self.W = self.gt.shape[0], self.gt.shape[1]
@@ -425,6 +440,10 @@ class PosMlpBrdfPhase:
         keys = {"a": "albedo", "r": "roughness", "m": "metallic"}
         live = [keys[c] for c in self.part if c in keys]
         maps = {k: (raw[k].contiguous() if k in live else self.fixed[k]) for k in raw}
+        if self.mask is not None:                                                        # :509-511, after the clamps of :493-495
+            for k in ("roughness", "metallic"):
+                maps[k] = masked_mean_fill(maps[k].clamp(0, 1), self.mask).contiguous()
+            live = [k for k in live]                                                     # gradients reach the net through the fill
         return maps, live
 
     def step(self) -> None:

@@ -24,7 +24,7 @@ ROUGHNESS_SHIFT, METALLIC_SHIFT = 0.7, 0.05   # :183-184
 def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], optimize_order: Sequence[str] = ("arm",), spp: int = 64,
                          opt_env_from: int = 0, opt_src: str = "arm", scale_delta: float = 0.1, num_epochs: int = 5000,
                          sync_every: int = 25, env_size=(16, 32), log=None, frames=None, results_dir: Optional[str] = None,
-                         shading_normal: Optional[torch.Tensor] = None, model_name: str = "none") -> Dict[str, object]:
+                         shading_normal: Optional[torch.Tensor] = None, model_name: str = "none", use_mask: bool = False) -> Dict[str, object]:
     """mat: albedo [H,W,3], roughness [H,W,1], metallic [H,W,1], normal [H,W,3], gt_image [H,W,3] (optionally gt_envmap).
     Returns the best maps / envmap / render, the final PSNR and the schedule trace.  `frames` (pipeline.FrameWriter) and
     `results_dir` switch on the reference's file outputs: a frame at every host poll (the reference: every 10 epochs,
@@ -44,6 +44,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         mat["normal"] = torch.nn.functional.normalize(mat["normal"], p=2, dim=-1)  # :193
         params["shape.bsdf.n"] = mat["normal"]
 
+    mask = mat.get("mask") if use_mask else None                                   # --use_mask (:379-381,509-511,702-711)
+    if use_mask and mask is None:
+        raise ValueError("use_mask needs mat['mask'] ([H,W] bool)")
     saver = _loop.DeviceSaveBest()
     state = {"final_envmap": None, "last_mse": None}
     if model_name == "pos_mlp":                                                     # :114-124,159-172,179-207
@@ -127,7 +130,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
     def brdf_part_runner_mlp(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
         ph = _loop.PosMlpBrdfPhase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in ("albedo", "roughness", "metallic")},
                                    optimize_part=part, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
-                                   best_mse=saver.best_loss, history_len=n_epochs)
+                                   best_mse=saver.best_loss, history_len=n_epochs, mask=mask)
         stop, it = "num_epochs", 0
         for it in range(n_epochs):
             if ph.step_and_check():                                                 # per-epoch host check, as the reference (:550)
@@ -150,10 +153,10 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         return it, ph.opt.param_groups[0]["lr"], stop
 
     def brdf_part_runner_normal(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
-        """Parts that optimise the normal map (output_type 'armn', use_mesh_normal False; :335-340,378-379,406-409): the
-        autograd render with the torch-composed loss (BrdfPhase) and the reference's per-epoch host EarlyStopping."""
-        ph = _loop.BrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mat["normal"], optimize_part=part, spp=spp,
-                             scale_delta=scale_delta, saver=_loop.DeviceSaveBest())
+        """Parts that optimise the normal map (output_type 'armn', use_mesh_normal False; :335-340,378-379,406-409) or run under
+        `--use_mask`: the autograd render with the torch-composed loss (BrdfPhase) and the reference's per-epoch host EarlyStopping."""
+        ph = _loop.BrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], None if scene.use_mesh_normal else mat["normal"],
+                             optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask)
         if saver.best_loss is not None:
             ph.saver.best_loss = saver.best_loss.clone().reshape(())
         es = _loop.EarlyStopping(patience, min_delta)
@@ -169,16 +172,17 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             saver.best_loss = torch.minimum(new_best, prev)
             for k_ in ("albedo", "roughness", "metallic", "rendered_img"):
                 saver.best[k_] = ph.saver.best[k_].clone()
-            saver.best["normal"] = ph.saver.best["normal"].clone()
+            if "normal" in ph.saver.best:
+                saver.best["normal"] = ph.saver.best["normal"].clone()
+                mat["normal"] = saver.best["normal"]
             saver.best["envmap"] = state["envmap4render"].clone()
-            mat["normal"] = saver.best["normal"]
         say(f"loop {loop_num}: part {part!r} (with normals) ran {it + 1} iterations ({stop})")
         return it, ph.opt.param_groups[0]["lr"], stop
 
     def brdf_part_runner(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
         if model_name == "pos_mlp":
             return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
-        if "n" in part or not scene.use_mesh_normal:
+        if "n" in part or not scene.use_mesh_normal or mask is not None:
             return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
         ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], optimize_part=part, spp=spp,
                                   scale_delta=scale_delta, patience=patience, min_delta=min_delta,

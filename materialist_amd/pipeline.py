@@ -242,8 +242,6 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
 
     if model_name not in ("none", "pos_mlp"):
         raise ValueError("model_name should be 'none' or 'pos_mlp'")
-    if use_mask:
-        warnings.warn("--use_mask is not supported yet; continuing without mask", UserWarning)
     log(f"Inverse image {img_inverse_path}")
     output_dir = get_output_dir(save_name, save_path)
     os.makedirs(os.path.join(output_dir, "best_results"), exist_ok=True)
@@ -285,6 +283,18 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
         with open(os.path.join(output_dir, "config.json"), "w") as f:                            # :679-696
             json.dump(config, f, indent=4)
         depth = 2 * depth.max() - depth                                                          # :722 (MaterialNet predicts inverse depth)
+        if use_mask:                                                                             # :702-711
+            p = os.path.join(output_dir, "best_results", "mask.png")
+            if os.path.exists(p):
+                from PIL import Image
+
+                mk = np.asarray(Image.open(p))
+                mat["mask"] = torch.from_numpy(np.ascontiguousarray((mk[..., 0] if mk.ndim == 3 else mk) > 0)).to(device)
+                if tuple(mat["mask"].shape) != (size, size):
+                    raise ValueError(f"{p}: mask is {tuple(mat['mask'].shape)}, the run is {size}x{size}")
+            else:
+                warnings.warn("No mask found, continuing without mask", UserWarning)
+                use_mask = False
         if opt_env_from > 1:                                                                     # :729-735
             p = os.path.join(output_dir, "best_results", "envmap.hdr")
             if os.path.exists(p):
@@ -306,7 +316,7 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
                                         num_epochs=num_epochs, sync_every=sync_every, log=log, frames=frames,
                                         results_dir=os.path.join(output_dir, "best_results"),
                                         shading_normal=scene.geo_normal if use_mesh_normal else None,
-                                        model_name=model_name)
+                                        model_name=model_name, use_mask=use_mask and "mask" in mat)
     frames.close()
     write_hdr(os.path.join(output_dir, "final_envmap.hdr"), res["envmap"].detach().cpu().numpy())   # :297
     res["output_dir"] = output_dir

@@ -5,7 +5,8 @@ The reference re-traces the scene for every light (10 x spp 64 + OptiX denoise, 
 deterministic render is linear in the light, so the per-pixel transfer is computed once (`matpbr_shade_transfer`) and each
 frame is a 75-term dot product per pixel (`matpbr_relight`, HBM-bound).  Rolling the envmap by whole texel columns is the
 SH rotation about +y by the same angle (`sh.rotate_y_matrix`), so no envmap is ever re-projected or written to disk.
-Object insertion (`--mode oi`, :100-141,207-237) needs extra meshes and is not part of this build.
+Material editing inside `best_results/mask.png` (`edit=` of `render_w_mi`, :143-181) is applied to the maps before the
+transfer is computed.  Object insertion (`--mode oi`, :100-141,207-237) needs extra meshes and is not part of this build.
 """
 from __future__ import annotations
 
@@ -34,7 +35,63 @@ def load_estimated_brdf(root_dir: str, device="cuda") -> Dict[str, torch.Tensor]
     p = os.path.join(root_dir, "envmap.hdr")
     if os.path.exists(p):
         mat["envmap"] = t(read_hdr(p))
+    p = os.path.join(root_dir, "mask.png")                            # "load mask for Material editing" (:729-733)
+    if os.path.exists(p):
+        from PIL import Image
+
+        m = np.asarray(Image.open(p))
+        mat["mask"] = torch.from_numpy(np.ascontiguousarray((m[..., 0] if m.ndim == 3 else m) > 0)).to(device)
     return mat
+
+
+def rgb_to_hsv(rgb: np.ndarray) -> np.ndarray:
+    """[...,3] in [0,1] -> h, s, v in [0,1] (the convention of skimage.color.rgb2hsv the reference edits with, :143-146)."""
+    rgb = np.asarray(rgb, dtype=np.float64)
+    v = rgb.max(-1)
+    delta = v - rgb.min(-1)
+    s = np.where(v > 0, delta / np.where(v > 0, v, 1), 0.0)
+    d = np.where(delta > 0, delta, 1.0)
+    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    h = np.where(v == r, (g - b) / d, np.where(v == g, 2.0 + (b - r) / d, 4.0 + (r - g) / d))
+    h = np.where(delta > 0, (h / 6.0) % 1.0, 0.0)
+    return np.stack([h, s, v], -1)
+
+
+def hsv_to_rgb(hsv: np.ndarray) -> np.ndarray:
+    hsv = np.asarray(hsv, dtype=np.float64)
+    h, s, v = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+    i = np.floor(h * 6.0)
+    f = h * 6.0 - i
+    p, q, t = v * (1 - s), v * (1 - f * s), v * (1 - (1 - f) * s)
+    i = i.astype(np.int64) % 6
+    r = np.choose(i, [v, q, p, p, t, v])
+    g = np.choose(i, [t, v, v, q, p, p])
+    b = np.choose(i, [p, p, t, v, v, q])
+    return np.stack([r, g, b], -1)
+
+
+def apply_edit(mat: Dict[str, torch.Tensor], edit: Optional[Dict[str, object]]) -> str:
+    """render_final.py:143-181: inside the mask, shift the albedo in HSV (`edit['albedo']` = [dh, ds, dv], clipped to [0,1]) and/or
+    overwrite roughness / metallic with a constant.  Returns the reference's file-name flag (`_r_0.2`, ...); the albedo flag carries
+    the first shift component (the reference's own expression for it, `edit[key].tolist()[0,0]`, raises a TypeError)."""
+    flag = ""
+    for key in ("albedo", "roughness", "metallic"):
+        val = (edit or {}).get(key)
+        if val is None:
+            continue
+        if "mask" not in mat:
+            raise FileNotFoundError("Unable to edit img, no mask found")
+        mask = mat["mask"]
+        if key == "albedo":
+            shift = np.asarray(val, dtype=np.float64).reshape(-1)[:3]
+            sel = mat[key][mask].cpu().numpy()
+            out = hsv_to_rgb(np.clip(rgb_to_hsv(sel) + shift, 0, 1))
+            mat[key][mask] = torch.from_numpy(out.astype(np.float32)).to(mat[key].device)
+            flag += f"_a_{shift[0]}"
+        else:
+            mat[key][mask] = float(val)
+            flag += f"_{key[:1]}_{val}"
+    return flag
 
 
 def find_envmap(save_name: str, env_path: Optional[str], input_path: Optional[str]) -> str:
@@ -78,17 +135,18 @@ def _scene_normal(scene_dir: str, mat: Dict[str, torch.Tensor], save_name: str, 
 
 
 def render_real(save_name: str, env_path: Optional[str] = None, input_path: Optional[str] = None, save_path: Optional[str] = None,
-                spp: int = 64, device="cuda") -> str:
-    """render_final.py:148-203,241-260: one re-render under `env_path` -> mi_<name>_<env>_.exr / .png."""
+                spp: int = 64, device="cuda", edit: Optional[Dict[str, object]] = None) -> str:
+    """render_final.py:148-203,241-260: one re-render under `env_path` -> mi_<name>_<env>_<edit flag>.exr / .png."""
     scene_dir = os.path.join(input_path if input_path is not None else OUT_DIR, save_name)
     env_path = find_envmap(save_name, env_path, input_path)
     mat = load_estimated_brdf(os.path.join(scene_dir, "best_results"), device)
+    edit_flag = apply_edit(mat, edit)
     rl = Relighter(mat, _scene_normal(scene_dir, mat, save_name, device), spp)
     img = rl.frames(envmap_to_light(load_image(env_path))[None])[0]
     env_id = os.path.basename(env_path)[:-4]
     out_dir = os.path.join(save_path if save_path else OUT_DIR, save_name)
     os.makedirs(out_dir, exist_ok=True)
-    base = os.path.join(out_dir, f"mi_{save_name}_{env_id}_")          # empty edit flag (:199-202)
+    base = os.path.join(out_dir, f"mi_{save_name}_{env_id}_{edit_flag}")   # (:199-202)
     write_exr(base + ".exr", img.cpu().numpy())
     write_png(base + ".png", _loss.linear_to_srgb(img.clamp_min(0)).cpu().numpy())
     return base + ".png"
@@ -96,7 +154,7 @@ def render_real(save_name: str, env_path: Optional[str] = None, input_path: Opti
 
 def render_rolling_envmap(save_name: str, env_path: Optional[str], frames: int = 36, rotation_step: float = 10.0,
                           input_path: Optional[str] = None, save_path: Optional[str] = None, spp: int = 64, device="cuda",
-                          write_frames: bool = True) -> Dict[str, object]:
+                          write_frames: bool = True, edit: Optional[Dict[str, object]] = None) -> Dict[str, object]:
     """render_final.py:300-418: `frames` renders, the envmap rolled by int(angle/360*W) columns per frame."""
     scene_dir = os.path.join(input_path if input_path is not None else OUT_DIR, save_name)
     env_path = find_envmap(save_name, env_path, input_path)
@@ -108,6 +166,7 @@ def render_rolling_envmap(save_name: str, env_path: Optional[str], frames: int =
         shift = int((f * rotation_step / 360.0) * We)                # rotate_envmap (:290-298)
         lights.append(_sh.rotate_y_matrix(2 * np.pi * shift / We) @ light0)
     mat = load_estimated_brdf(os.path.join(scene_dir, "best_results"), device)
+    apply_edit(mat, edit)
     rl = Relighter(mat, _scene_normal(scene_dir, mat, save_name, device), spp)
     out_dir = os.path.join(save_path if save_path else OUT_DIR, save_name)
     anim_dir = os.path.join(out_dir, "rolling_envmap_animation")

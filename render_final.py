@@ -18,6 +18,10 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=36)
     ap.add_argument("--rotation_step", type=float, default=10.0)
     ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--edit_albedo", type=float, nargs=3, default=None, metavar=("DH", "DS", "DV"),
+                    help="HSV shift of the albedo inside best_results/mask.png (the reference's `edit` dict, hard-wired to None in its CLI)")
+    ap.add_argument("--edit_roughness", type=float, default=None, help="constant roughness inside the mask")
+    ap.add_argument("--edit_metallic", type=float, default=None, help="constant metallic inside the mask")
     return ap.parse_args(argv)
 
 
@@ -25,10 +29,11 @@ def main(argv=None):
     a = parse_args(argv)
     from materialist_amd import relight
 
+    edit = {"albedo": a.edit_albedo, "roughness": a.edit_roughness, "metallic": a.edit_metallic}
     if a.mode == "real":
-        print("Wrote file to", relight.render_real(a.save_name, a.env_path, a.input_path, a.save_path, a.spp))
+        print("Wrote file to", relight.render_real(a.save_name, a.env_path, a.input_path, a.save_path, a.spp, edit=edit))
     elif a.mode == "rolling":
-        res = relight.render_rolling_envmap(a.save_name, a.env_path, a.frames, a.rotation_step, a.input_path, a.save_path, a.spp)
+        res = relight.render_rolling_envmap(a.save_name, a.env_path, a.frames, a.rotation_step, a.input_path, a.save_path, a.spp, edit=edit)
         print(f"Animation saved to {res['gif']}\nIndividual frames saved to {res['animation_dir']}")
     elif a.mode == "oi":
         raise NotImplementedError("object insertion (render_final.py:100-141,207-237) is not part of this build")

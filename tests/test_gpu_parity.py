@@ -564,6 +564,31 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     assert os.path.exists(roll["gif"]) and os.path.basename(roll["gif"]) == "rolling_envmap_case_envmap.gif"
 
 
+@pytest.mark.parametrize("model_name", ["none", "pos_mlp"])
+def test_use_mask_keeps_roughness_and_metallic_uniform_inside_the_mask(tmp_path, model_name):
+    """--use_mask (inverse_img_w_mi.py:379-381,509-511,702-711): best_results/mask.png marks one material region."""
+    from PIL import Image
+
+    from materialist_amd import pipeline
+    from materialist_amd.imageio_exr import read_exr
+
+    _cuda()
+    rng = np.random.default_rng(7)
+    src = str(tmp_path / "in.png")
+    Image.fromarray((rng.random((32, 32, 3)) * 255).astype(np.uint8)).save(src)
+    os.makedirs(tmp_path / "case" / "best_results")
+    mk = np.zeros((32, 32, 3), np.uint8)
+    mk[8:20, 4:28] = 255
+    Image.fromarray(mk).save(str(tmp_path / "case" / "best_results" / "mask.png"))
+    pipeline.inverse_image(src, "case", opt_src="arm", opt_order=["rm", "a"], use_mask=True, opt_env_from=0, save_path=str(tmp_path), size=32,
+                           spp=8, num_epochs=6, sync_every=3, log=lambda *_: None, model_name=model_name)
+    for name in ("roughness", "metallic"):
+        x = read_exr(str(tmp_path / "case" / "best_results" / f"{name}.exr"))[..., 0]
+        inside, outside = x[8:20, 4:28], np.concatenate([x[:8].ravel(), x[20:].ravel()])
+        assert inside.max() - inside.min() < 1e-6, name
+        assert outside.max() - outside.min() > 1e-4 or name == "metallic"      # the flat prior's metallic starts uniform
+
+
 def test_pos_mlp_phase_matches_torch_composition():
     """f2 in the loop: PosMlpBrdfPhase (maps from the residual MLP, render/loss/backward in libmatpbr.so, gradients handed back
     to torch) against the same iteration composed from torch ops around the autograd render (inverse_img_w_mi.py:493-554)."""

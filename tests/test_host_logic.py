@@ -286,3 +286,52 @@ def test_cli_parses_the_reference_flags():
     spec.loader.exec_module(cli)
     a = cli.parse_args(["--img_inverse_path", "x.png", "--save_name", "s", "--opt_src", "arm", "--opt_order", "rm", "a", "--opt_env_from", "2"])
     assert a.opt_order == ["rm", "a"] and a.opt_env_from == 2 and a.model_name == "none" and not a.use_mask
+
+
+def test_hsv_round_trip_and_material_edit_flags():
+    """render_final.py:143-181: HSV edit of the albedo and constant roughness / metallic inside the mask; file-name flags."""
+    import colorsys
+
+    import torch
+
+    from materialist_amd import relight
+
+    rng = np.random.default_rng(0)
+    rgb = rng.random((200, 3))
+    rgb[:5] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 0], [0, 0, 1]]
+    hsv = relight.rgb_to_hsv(rgb)
+    np.testing.assert_allclose(hsv, np.array([colorsys.rgb_to_hsv(*c) for c in rgb]), atol=1e-12)
+    np.testing.assert_allclose(relight.hsv_to_rgb(hsv), rgb, atol=1e-12)
+    mask = torch.zeros(4, 6, dtype=torch.bool)
+    mask[1:3, 2:5] = True
+    mat = {"albedo": torch.full((4, 6, 3), 0.25), "roughness": torch.full((4, 6, 1), 0.5), "metallic": torch.zeros(4, 6, 1), "mask": mask}
+    mat["albedo"][..., 0] = 0.75
+    flag = relight.apply_edit(mat, {"albedo": [0.5, 0.0, 0.0], "roughness": 0.2, "metallic": None})
+    assert flag == "_a_0.5_r_0.2"
+    assert torch.all(mat["roughness"][mask] == 0.2) and torch.all(mat["roughness"][~mask] == 0.5)
+    np.testing.assert_allclose(mat["albedo"][1, 2].numpy(), [0.25, 0.75, 0.75], atol=1e-6)      # red shifted by half a turn = cyan
+    np.testing.assert_allclose(mat["albedo"][0, 0].numpy(), [0.75, 0.25, 0.25], atol=1e-6)
+    assert relight.apply_edit(mat, {"albedo": None, "roughness": None, "metallic": None}) == ""
+    del mat["mask"]
+    with pytest.raises(FileNotFoundError):
+        relight.apply_edit(mat, {"metallic": 1.0})
+
+
+def test_masked_mean_fill_is_the_reference_in_place_form():
+    """--use_mask (inverse_img_w_mi.py:379-381): `x[mask] = x[mask].mean()` on a non-leaf tensor, values and autograd gradients."""
+    import torch
+
+    from materialist_amd.loop import masked_mean_fill
+
+    torch.manual_seed(0)
+    mask = torch.rand(9, 7) > 0.6
+    p_ref = torch.rand(9, 7, 1, dtype=torch.float64, requires_grad=True)
+    p_new = p_ref.detach().clone().requires_grad_(True)
+    w = torch.rand(9, 7, 1, dtype=torch.float64)
+    x = p_ref.clamp(0.07, 1)
+    x[mask] = x[mask].mean()                       # the reference's statement
+    (x * w).sum().backward()
+    y = masked_mean_fill(p_new.clamp(0.07, 1), mask)
+    (y * w).sum().backward()
+    assert torch.allclose(x, y, atol=1e-14) and torch.allclose(p_ref.grad, p_new.grad, atol=1e-14)
+    assert torch.equal(masked_mean_fill(p_new.detach(), torch.zeros(9, 7, dtype=torch.bool)), p_new.detach())
