@@ -152,6 +152,27 @@ int matpbr_sin_bwd(const float* d_y, long ld_d, const float* pre, long ld_p, flo
 size_t matpbr_column_sum_workspace_bytes(int N);
 int matpbr_column_sum(const float* x, float* out, long M, int N, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sine layers of the PosMLP (mymodels/mlps.py:102-103 `sin(linear(x))`, layer loop :216-229) and their backward, on the exact-f32
+ * MFMA with the element-wise work in the GEMM epilogues (materialist_amd/csrc/posmlp_kernels.hip).  Row-major fp32; every
+ * leading dimension is a multiple of 4 floats and every base pointer 16-byte aligned; N, K <= 256; M = H*W points.
+ *   matpbr_mlp_layer_fwd         s_out = sin(x w^T + bias), c_out = cos(same) [both M x N, row stride ldo]; c_out == NULL: s_out = x w^T + bias
+ *                                x [M, K] (stride ldx), w [N, K] (stride ldw) = the layer's `linear.weight`
+ *   matpbr_mlp_layer_bwd_input   g_prev[M, n_prev] = (g wt^T) * c_prev;  g [M, n_red] (stride ldg) = dL/d pre of this layer,
+ *                                wt [n_prev, n_red] (stride ldwt) = weight^T restricted to the inputs that come from the layer below,
+ *                                c_prev = that layer's c_out (stride ldo, as g_prev); d_bias_prev[n_prev] (optional) = column sums of g_prev
+ *   matpbr_mlp_layer_bwd_weight  d_w[N, K] (stride ldw) = g^T x;  g [M, N] (stride ldg), x [M, K] (stride ldx); deterministic (slab partials)
+ *   matpbr_mlp_sincos / _mul     the same epilogues as stand-alone passes for the layers whose product stays in the BLAS */
+int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo, long M,
+                         int N, int K, void* stream);
+size_t matpbr_mlp_bwd_input_workspace_bytes(long M);
+int matpbr_mlp_layer_bwd_input(const float* g, int ldg, const float* wt, int ldwt, const float* c_prev, float* g_prev, int ldo,
+                               float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream);
+size_t matpbr_mlp_bwd_weight_workspace_bytes(long M);
+int matpbr_mlp_layer_bwd_weight(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
+                                size_t workspace_bytes, long M, int N, int K, void* stream);
+int matpbr_mlp_sincos(const float* pre, long ldp, float* s_out, long lds, float* c_out, long ldc, long M, int n, void* stream);
+int matpbr_mlp_mul(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long M, int n, void* stream);
+
 /* Forward-only relighting (render_final.py:148-203 `render_w_mi`, :290-418 `rotate_envmap` / `render_rolling_envmap`).
  * The render is linear in the light, R = sum_k light[k] * T[k]:
  *   matpbr_shade_transfer  per-pixel transfer of the current materials into T (matpbr_transfer_bytes(); 300 B/pixel, tiled

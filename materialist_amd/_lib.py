@@ -52,6 +52,16 @@ SIGNATURES = {
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),
                                             ctypes.c_void_p]),
     "matpbr_sin_bwd": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_fwd": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_bwd_input_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long]),
+    "matpbr_mlp_layer_bwd_input": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_void_p,
+                                                 ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_bwd_weight_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long]),
+    "matpbr_mlp_layer_bwd_weight": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                  ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_sincos": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_mul": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_column_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_column_sum": (ctypes.c_int, [_c_f, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "matpbr_shade_transfer": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),

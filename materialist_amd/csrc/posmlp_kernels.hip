@@ -1,0 +1,703 @@
+// Sine-layer GEMMs of the PosMLP (mymodels/mlps.py:102-103 `SineLayer.forward = sin(linear(x))`, :216-229 the layer loop,
+// and their autograd backward), hand-written for gfx950 on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// The coordinate MLP of hot loop B runs over M = H*W points (262 144 at 512x512) with layers of width <= 256: nine
+// [M,256]x[256,256] products per iteration (311 GFLOP) plus, in a stock composition, one full pass over an [M,256] matrix for
+// every sin, every d_y*cos(pre) and every bias gradient.  Here those passes live in the GEMM epilogues:
+//
+//   mlp_gemm_nt<EPI_SINCOS>   S, C = sin, cos(X W^T + b)         forward of one sine layer; C is kept for the backward, pre is not
+//   mlp_gemm_nt<EPI_MULC>     G' = (G Wt^T) * C'  (+ column sums of G' per workgroup: the bias gradient of the layer below)
+//   mlp_wgrad_tn              dW partials = G^T X over a slab of rows; mlp_wgrad_reduce adds the slabs (fixed order)
+//
+// All matrices are row-major fp32 with a leading dimension that is a multiple of 4 floats (activations: 256, padded).
+// Tiling of the NT products: a 256-thread workgroup owns 128 rows x 128 columns (2x2 waves of 64x64 = 2x2 MFMA tiles, 64
+// accumulator registers), two workgroups per CU, persistent over (row tile, column half) work items; K <= 256 in k-tiles of 32
+// through double-buffered LDS (one barrier per k-tile), global -> registers -> LDS with the fetch one k-tile ahead.  A 32x32x2 MFMA
+// takes one f32 per lane for A and one for B (lane l: A[row l&31][k l>>5], B[k l>>5][col l&31]).
+// Measured at M = 512x512 (tools/mlp_bench.py): forward layer 416 us (BLAS product + sin pass: 424), dL/d input 356 us (BLAS + the
+// d_y cos(pre) pass + the bias-gradient pass: 555), weight gradient 303 + 21 us (split-K BLAS: 308); the MFMA pipe is busy
+// 57-77 % of the time, the waves otherwise wait for their operand fetches (4800-cycle waits per 4200-cycle k-tile).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "../../include/matpbr.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 128, kBN = 128, kBK = 32;
+constexpr int kPersistent = 512;   // two workgroups per CU x 256 CUs
+constexpr int EPI_SINCOS = 0, EPI_MULC = 1, EPI_BIAS = 2;
+
+// sin and cos of x in f32 to 1.5 ulp (|error| <= 9e-8) for |x| < 1e5: three-constant Cody-Waite reduction to [-pi/4, pi/4] by
+// fma, degree-7 / degree-8 polynomials, quadrant fix-up by sign bits -- 22 VALU instructions and no scratch (the library sincosf
+// carries a Payne-Hanek path with a stack array).  Pre-activations here are O(10): pixel coordinates <= 4096 times O(0.1) weights.
+__device__ __forceinline__ void sincos_cw(float x, float& s_out, float& c_out) {
+  const float k = __builtin_rintf(x * 0.6366197466850281f);
+  float r = __builtin_fmaf(k, -1.5707963705062866f, x);
+  r = __builtin_fmaf(k, 4.371138828673793e-08f, r);
+  r = __builtin_fmaf(k, 1.7151245100058819e-15f, r);
+  const float r2 = r * r;
+  const float ps = __builtin_fmaf(__builtin_fmaf(-0.00019587950373534113f, r2, 0.008332748897373676f), r2, -0.166666641831398f);
+  const float pc = __builtin_fmaf(__builtin_fmaf(2.4547991415602155e-05f, r2, -0.001388830365613103f), r2, 0.0416666641831398f);
+  const float s = __builtin_fmaf(r * r2, ps, r);
+  const float c = __builtin_fmaf(r2 * r2, pc, __builtin_fmaf(r2, -0.5f, 1.0f));
+  const unsigned q = (unsigned)(int)k;
+  const bool swap = q & 1u;
+  const float ss = swap ? c : s, cc = swap ? s : c;
+  s_out = __uint_as_float(__float_as_uint(ss) ^ ((q & 2u) << 30));
+  c_out = __uint_as_float(__float_as_uint(cc) ^ (((q + 1u) & 2u) << 30));
+}
+
+struct NtArgs {
+  const float* A;      // [M, lda]   rows = points
+  const float* B;      // [N, ldb]   rows = output features, k contiguous
+  const float* bias;   // [N]                     (EPI_SINCOS / EPI_BIAS)
+  const float* cmul;   // [M, ldo]   cos(pre) of the layer below (EPI_MULC)
+  float* out0;         // [M, ldo]   S | G' | pre
+  float* out1;         // [M, ldo]   C            (EPI_SINCOS)
+  float* colsum;       // [gridDim.x, 256] per-workgroup column sums of out0 (EPI_MULC), may be null
+  int M;
+  int N, K, lda, ldb, ldo;
+};
+
+// LDS image of a k-tile: [row][k] with a pitch of 36 floats: 16-byte writes and 16-byte reads are both conflict-free (8 lanes x
+// 4 banks cover the 32 banks; SQ_LDS_BANK_CONFLICT = 0).  Lane half h of an MFMA takes k = 16 h + step inside the tile (A and
+// B agree, so the sum over k is unchanged), which makes a lane's 16 operands of a k-tile four consecutive float4.
+constexpr int kLd = 36;
+constexpr int kTileFloats = kBM * kLd;
+
+// Global -> register fetch of one k-tile (4 row chunks of A, 4 of B per thread: 16 bytes each).  NO predicates and no branches:
+// addresses are clamped into the matrix and the out-of-range elements are zeroed later, in `stash`, when the data has arrived.
+// A predicate (or a select on the loaded value) next to the load makes the compiler wait for the fetch it has just issued -- and a
+// load inside a branch makes every later s_waitcnt a vmcnt(0): measured 4800-7000 stall cycles per 4200-cycle k-tile.
+__device__ __forceinline__ void fetch_a(const NtArgs& p, float4 (&ra)[4], int row0, int kslot, int crow, int ck) {
+  int k = kslot * kBK + ck;
+  const int kmax = ((p.K + 3) & ~3) - 4;
+  k = k < kmax ? k : kmax;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int m = row0 + crow + 32 * q;
+    m = m < p.M ? m : p.M - 1;
+    ra[q] = *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + k);
+  }
+}
+
+__device__ __forceinline__ void fetch_b(const NtArgs& p, float4 (&rb)[4], int col0, int kslot, int crow, int ck) {
+  int k = kslot * kBK + ck;
+  const int kmax = ((p.K + 3) & ~3) - 4;
+  k = k < kmax ? k : kmax;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int n = col0 + crow + 32 * q;
+    n = n < p.N ? n : p.N - 1;
+    rb[q] = *reinterpret_cast<const float4*>(p.B + (size_t)n * p.ldb + k);
+  }
+}
+
+__device__ __forceinline__ float4 kmask(float4 v, int k, int K, bool keep) {
+  v.x = (keep && k < K) ? v.x : 0.f;
+  v.y = (keep && k + 1 < K) ? v.y : 0.f;
+  v.z = (keep && k + 2 < K) ? v.z : 0.f;
+  v.w = (keep && k + 3 < K) ? v.w : 0.f;
+  return v;
+}
+
+template <bool ROWS_FULL>
+__device__ __forceinline__ void stash(const NtArgs& p, const float4 (&ra)[4], const float4 (&rb)[4], float* sA, float* sB, int row0, int col0,
+                                      int kslot, int crow, int ck) {
+  const int k = kslot * kBK + ck;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool mrow = ROWS_FULL || (row0 + crow + 32 * q < p.M);
+    *reinterpret_cast<float4*>(sA + (crow + 32 * q) * kLd + ck) = kmask(ra[q], k, p.K, mrow);
+    *reinterpret_cast<float4*>(sB + (crow + 32 * q) * kLd + ck) = kmask(rb[q], k, p.K, col0 + crow + 32 * q < p.N);
+  }
+}
+
+// 64 MFMAs of one k-tile on a wave's 64x64 block; `mid(j)` runs after each of the four operand groups
+template <class Mid>
+__device__ __forceinline__ void nt_tile_mma(f32x16 (&acc)[2][2], const float* pa, const float* pb, Mid&& mid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float4 a4[2], b4[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a4[mi] = *reinterpret_cast<const float4*>(pa + mi * 32 * kLd + 4 * j);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) b4[ni] = *reinterpret_cast<const float4*>(pb + ni * 32 * kLd + 4 * j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float av = e == 0 ? a4[mi].x : e == 1 ? a4[mi].y : e == 2 ? a4[mi].z : a4[mi].w;
+          const float bv = e == 0 ? b4[ni].x : e == 1 ? b4[ni].y : e == 2 ? b4[ni].z : b4[ni].w;
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+        }
+    mid(j);
+  }
+}
+
+// Work items are (row tile, 128-column half).  Ids b and b + 8 sit on the same XCD (ids are dealt round-robin over the 8 XCDs) and
+// take the two halves of one row tile, so its A rows cross the fabric once and the second read hits that XCD's L2.  A workgroup
+// keeps one column half over its persistent loop (gridDim.x is a multiple of 16 whenever there are two halves).
+struct TileMap {
+  int halves, half, col0, my_count;
+  __device__ TileMap(int rtiles, int N) {
+    halves = (N + kBN - 1) / kBN;
+    const int ntiles = (halves == 2) ? ((rtiles + 7) / 8) * 16 : rtiles;
+    half = (halves == 2) ? (int)((blockIdx.x >> 3) & 1) : 0;
+    col0 = half * kBN;
+    my_count = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    // the last group of 16 ids may name row tiles past the end; a workgroup's tiles ascend, so those are a suffix of its list
+    while (my_count > 0 && row_of(my_count - 1) >= rtiles * kBM) --my_count;
+  }
+  __device__ int row_of(int j) const {                 // first row of this workgroup's j-th tile (may lie past M: an empty tile)
+    const int id = (int)blockIdx.x + j * (int)gridDim.x;
+    return ((halves == 2) ? (id >> 4) * 8 + (id & 7) : id) * kBM;
+  }
+};
+
+// General shapes (K <= 224: the first layer, the backward of the 5-wide output layer, narrow networks; and the ragged last row
+// tile of every layer): one tile at a time, double-buffered LDS, one barrier per k-tile, predicated epilogue.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void mlp_gemm_nt(NtArgs p) {
+  __shared__ __attribute__((aligned(16))) float sA[2][kTileFloats];
+  __shared__ __attribute__((aligned(16))) float sB[2][kTileFloats];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int crow = tid >> 3, ck = (tid & 7) * 4;   // staging: 4 consecutive k of one row per chunk, 8 chunks per 32-wide row
+  const int nk = (p.K + kBK - 1) / kBK;
+  const int aoff = (wm * 64 + li) * kLd + 16 * lh, boff = (wn * 64 + li) * kLd + 16 * lh;
+  const TileMap tm((p.M + kBM - 1) / kBM, p.N);
+  const int col0 = tm.col0;
+  float csum[2] = {0.f, 0.f};
+
+  for (int j = 0; j < tm.my_count; ++j) {
+    const int row0 = tm.row_of(j);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    __syncthreads();                                // the previous tile's readers are done with both buffers
+    fetch_a(p, ra, row0, 0, crow, ck);
+    fetch_b(p, rb, col0, 0, crow, ck);
+    stash<false>(p, ra, rb, sA[0], sB[0], row0, col0, 0, crow, ck);
+    fetch_a(p, ra, row0, nk > 1 ? 1 : 0, crow, ck);
+    fetch_b(p, rb, col0, nk > 1 ? 1 : 0, crow, ck);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      nt_tile_mma(acc, sA[cur] + aoff, sB[cur] + boff, [](int) {});
+      const int k1 = kt + 1 < nk ? kt + 1 : kt, k2 = kt + 2 < nk ? kt + 2 : nk - 1;   // past the end: harmless re-fetch / re-stash
+      stash<false>(p, ra, rb, sA[cur ^ 1], sB[cur ^ 1], row0, col0, k1, crow, ck);
+      fetch_a(p, ra, row0, k2, crow, ck);
+      fetch_b(p, rb, col0, k2, crow, ck);
+      __syncthreads();
+    }
+
+    // epilogue: accumulator register r of lane (li, lh) is row (r&3) + 8 (r>>2) + 4 lh, column li of its 32x32 tile.
+    // gfx950 retires loads and stores through one in-order counter, so every load of the tile is issued (clamped addresses,
+    // no branch) before its first store.
+    int ncol[2];
+    bool nok[2];
+    float bn[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = col0 + wn * 64 + ni * 32 + li;
+      nok[ni] = n < p.N;
+      ncol[ni] = nok[ni] ? n : p.N - 1;
+      bn[ni] = (EPI != EPI_MULC) ? p.bias[ncol[ni]] : 0.f;
+    }
+    float cv[2][2][16];
+    if (EPI == EPI_MULC) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int m = row0 + wm * 64 + mi * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+            m = m < p.M ? m : p.M - 1;
+            cv[mi][ni][r] = p.cmul[(size_t)m * p.ldo + ncol[ni]];
+          }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int mb = row0 + wm * 64 + mi * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          float v0, v1 = 0.f;
+          if (EPI == EPI_SINCOS) {
+            sincos_cw(acc[mi][ni][r] + bn[ni], v0, v1);
+          } else if (EPI == EPI_BIAS) {
+            v0 = acc[mi][ni][r] + bn[ni];
+          } else {
+            v0 = acc[mi][ni][r] * cv[mi][ni][r];
+          }
+          if (nok[ni] && m < p.M) {
+            const size_t o = (size_t)m * p.ldo + ncol[ni];
+            p.out0[o] = v0;
+            if (EPI == EPI_SINCOS) p.out1[o] = v1;
+            if (EPI == EPI_MULC) csum[ni] += v0;
+          }
+        }
+      }
+  }
+  if (EPI == EPI_MULC && p.colsum != nullptr) {
+    // column sums over every row this workgroup produced (it keeps one column half): 2 lane halves x 2 row-waves -> LDS, fixed order
+    float* red = sA[0];   // [4][128]: slot = wm*2 + lh
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) red[(wm * 2 + lh) * 128 + wn * 64 + ni * 32 + li] = csum[ni];
+    __syncthreads();
+    const int c = tid & 127;
+    const float v = (red[c] + red[128 + c]) + (red[256 + c] + red[384 + c]);
+    p.colsum[(size_t)blockIdx.x * 256 + tid] = ((tid >> 7) == tm.half) ? v : 0.f;
+  }
+}
+
+// The hot shape: 224 < K <= 256 (8 k-tiles: every hidden layer), M a multiple of 128 (the host sends a ragged last tile to
+// mlp_gemm_nt), output row stride >= 128 x halves (every column of a half exists; columns N.. of the outputs are scratch).
+//   * no branch and no predicate anywhere in the steady state, so every s_waitcnt carries an exact count;
+//   * the k-tiles of consecutive row tiles form one stream through the two LDS buffers: A rows (HBM) are fetched two k-tiles
+//     ahead into alternating register sets, the weights (L2) one ahead, B before A so that waiting for B does not wait for A;
+//   * the epilogue of tile t (sincos / * cos, stores) is cut into 8 pieces that ride inside the 8 k-tile steps of tile t+1: one
+//     wave keeps the matrix pipe (4 MFMAs = 256 cycles per step, 8 of them holding the issue port) and the VALU + store path
+//     busy together, and the output leaves as a steady stream.  The cos factors of piece j are loaded at the top of step j, ahead of
+//     that step's stores (loads and stores retire through one in-order counter on gfx950).
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void mlp_gemm_nt_pipe(NtArgs p) {
+  __shared__ __attribute__((aligned(16))) float sA[2][kTileFloats];
+  __shared__ __attribute__((aligned(16))) float sB[2][kTileFloats];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int crow = tid >> 3, ck = (tid & 7) * 4;
+  const int aoff = (wm * 64 + li) * kLd + 16 * lh, boff = (wn * 64 + li) * kLd + 16 * lh;
+  const TileMap tm(p.M / kBM, p.N);
+  const int col0 = tm.col0;
+  if (tm.my_count == 0) {                            // uniform; such a workgroup still owes its (zero) column-sum row
+    if (EPI == EPI_MULC && p.colsum != nullptr) p.colsum[(size_t)blockIdx.x * 256 + tid] = 0.f;
+    return;
+  }
+  const int last = tm.my_count - 1;
+
+  // addressing: one 32-bit per-lane offset per stream, everything else uniform (scalar base + immediate), rows >= N of the
+  // weights clamped once for the whole kernel
+  const int a_lane = crow * p.lda + ck;
+  int b_lane[4];
+  bool b_keep[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = col0 + crow + 32 * q;
+    b_keep[q] = n < p.N;
+    b_lane[q] = (b_keep[q] ? n : p.N - 1) * p.ldb + ck;
+  }
+  const int st_lane = crow * kLd + ck;
+  int o_lane[2];
+  float bn[2], csum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = col0 + wn * 64 + ni * 32 + li;
+    o_lane[ni] = (wm * 64 + 4 * lh) * p.ldo + n;
+    bn[ni] = (EPI != EPI_MULC) ? p.bias[n < p.N ? n : p.N - 1] : 0.f;
+  }
+
+  auto fetchA = [&](float4 (&ra)[4], int row0, int kslot) {
+    const float* base = p.A + (size_t)row0 * p.lda + kslot * kBK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const float4*>(base + (size_t)(32 * q) * p.lda + a_lane);
+  };
+  auto fetchB = [&](float4 (&rb)[4], int kslot) {
+    const float* base = p.B + kslot * kBK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const float4*>(base + b_lane[q]);
+  };
+  auto stashAB = [&](const float4 (&ra)[4], const float4 (&rb)[4], float* dA, float* dB, int kslot) {
+    const int k = kslot * kBK + ck;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4*>(dA + 32 * q * kLd + st_lane) = kmask(ra[q], k, p.K, true);
+      *reinterpret_cast<float4*>(dB + 32 * q * kLd + st_lane) = kmask(rb[q], k, p.K, b_keep[q]);
+    }
+  };
+
+  f32x16 prev[2][2];
+  int prev_row0 = 0;
+  // one eighth of the previous tile's epilogue: tile (mi, ni) = (j>>2, (j>>1)&1), registers 8 (j&1) .. +8
+  auto piece_load = [&](int j, float (&cv)[8]) {
+    if (EPI != EPI_MULC) return;
+    const int mi = j >> 2, ni = (j >> 1) & 1, r0 = (j & 1) * 8;
+    const float* base = p.cmul + (size_t)(prev_row0 + mi * 32) * p.ldo;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = r0 + q;
+      cv[q] = base[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo + o_lane[ni]];
+    }
+  };
+  // ... stored two values at a time (quarter h of piece j), one quarter after each operand group of the running k-tile, fenced
+  // so that the scheduler does not merge the sincos chains of a whole piece (that needs ~50 more registers and spills)
+  auto piece_store = [&](int j, int h, const float (&cv)[8]) {
+    const int mi = j >> 2, ni = (j >> 1) & 1, r0 = (j & 1) * 8;
+    float* base0 = p.out0 + (size_t)(prev_row0 + mi * 32) * p.ldo;
+    float* base1 = (EPI == EPI_SINCOS) ? p.out1 + (size_t)(prev_row0 + mi * 32) * p.ldo : nullptr;
+#pragma unroll
+    for (int q = 2 * h; q < 2 * h + 2; ++q) {
+      const int r = r0 + q;
+      const size_t o = (size_t)((r & 3) + 8 * (r >> 2)) * p.ldo + o_lane[ni];
+      const float v = prev[mi][ni][r];
+      if (EPI == EPI_SINCOS) {
+        float sv, cs;
+        sincos_cw(v + bn[ni], sv, cs);
+        base0[o] = sv;
+        base1[o] = cs;
+      } else if (EPI == EPI_BIAS) {
+        base0[o] = v + bn[ni];
+      } else {
+        const float g = v * cv[q];
+        base0[o] = g;
+        csum[ni] += g;
+      }
+    }
+  };
+
+  // k-tiles are walked in an order rotated by the row-tile index, so that workgroups do not all pull the same 128-byte column
+  // slot of their 1-KB rows at the same time
+  auto slot = [&](int row0, int kt) { return (kt + (row0 >> 7)) & 7; };
+
+  float4 ra[4], rb[4];
+  {
+    const int r0 = tm.row_of(0);
+    fetchA(ra, r0, slot(r0, 0));
+    fetchB(rb, slot(r0, 0));
+    stashAB(ra, rb, sA[0], sB[0], slot(r0, 0));
+    fetchB(rb, slot(r0, 1));
+    fetchA(ra, r0, slot(r0, 1));
+  }
+  __syncthreads();
+
+  auto tile = [&](int j, auto with_prev) {
+    constexpr bool kPrev = decltype(with_prev)::value;
+    const int row0 = tm.row_of(j), row1 = tm.row_of(j < last ? j + 1 : last);   // past the end: re-read the last tile (unused)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      const int cur = kt & 1;                        // 8 k-tiles per row tile: the buffer parity restarts with every tile
+      float cv[8];
+      if (kPrev) piece_load(kt, cv);
+      nt_tile_mma(acc, sA[cur] + aoff, sB[cur] + boff, [&](int h) {
+        if (kPrev) piece_store(kt, h, cv);
+      });
+      const int rs = kt < 7 ? row0 : row1, r2 = kt < 6 ? row0 : row1;
+      stashAB(ra, rb, sA[cur ^ 1], sB[cur ^ 1], slot(rs, (kt + 1) & 7));
+      fetchB(rb, slot(r2, (kt + 2) & 7));
+      fetchA(ra, r2, slot(r2, (kt + 2) & 7));
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) prev[mi][ni] = acc[mi][ni];
+    prev_row0 = row0;
+  };
+
+  tile(0, std::false_type{});
+  for (int j = 1; j <= last; ++j) tile(j, std::true_type{});
+  // drain: the last tile's epilogue
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float cv[8];
+    piece_load(j, cv);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) piece_store(j, h, cv);
+  }
+  if (EPI == EPI_MULC && p.colsum != nullptr) {
+    float* red = sA[0];   // [4][128]: slot = wm*2 + lh
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) red[(wm * 2 + lh) * 128 + wn * 64 + ni * 32 + li] = csum[ni];
+    __syncthreads();
+    const int c = tid & 127;
+    const float v = (red[c] + red[128 + c]) + (red[256 + c] + red[384 + c]);
+    p.colsum[(size_t)blockIdx.x * 256 + tid] = ((tid >> 7) == tm.half) ? v : 0.f;
+  }
+}
+
+// dW[n][k] partial over a slab of rows: grid (slabs, 2 halves of n).  G [M, ldg] (columns n), X [M, ldx] (columns k).
+constexpr int kWM = 32;   // rows (reduction) per LDS tile
+__global__ __launch_bounds__(256, 2) void mlp_wgrad_tn(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                       float* __restrict__ partial, long M, long rows_per_slab, int K) {
+  __shared__ float sG[kWM * 128];
+  __shared__ float sX[kWM * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 128;
+  const long m_begin = (long)blockIdx.x * rows_per_slab;
+  const long m_end = (m_begin + rows_per_slab < M) ? m_begin + rows_per_slab : M;
+
+  float4 rg[4], rx[8];
+  // G tile: 32 rows x 128 cols = 1024 float4, 32 per row; X tile: 32 x 256 = 2048 float4, 64 per row
+  auto gload = [&](long m0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = tid + 256 * q;
+      const long m = m0 + (c >> 5);
+      const int n = n0 + (c & 31) * 4;          // columns at or past ldg do not exist; those past N are computed and dropped
+      rg[q] = (m < m_end && n < ldg) ? *reinterpret_cast<const float4*>(G + m * ldg + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = tid + 256 * q;
+      const long m = m0 + (c >> 6);
+      const int k = (c & 63) * 4;
+      rx[q] = (m < m_end && k < K) ? *reinterpret_cast<const float4*>(X + m * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sG + (tid + 256 * q) * 4) = rg[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(sX + (tid + 256 * q) * 4) = rx[q];
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  if (m_begin < m_end) {
+    gload(m_begin);
+    sstore();
+    __syncthreads();
+    const float* pa = sG + lh * 128 + wm * 64 + li;
+    const float* pb = sX + lh * 256 + wn * 128 + li;
+    for (long m0 = m_begin; m0 < m_end; m0 += kWM) {
+      const bool more = m0 + kWM < m_end;
+      if (more) gload(m0 + kWM);
+#pragma unroll
+      for (int kk = 0; kk < kWM / 2; ++kk) {
+        float a[2], b[4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi] = pa[2 * kk * 128 + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b[ni] = pb[2 * kk * 256 + ni * 32];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        sstore();
+        __syncthreads();
+      }
+    }
+  }
+  float* out = partial + (long)blockIdx.x * 256 * 256;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int k = wn * 128 + ni * 32 + li;
+        out[n * 256 + k] = acc[mi][ni][r];
+      }
+}
+
+__global__ __launch_bounds__(256) void mlp_wgrad_reduce(const float* __restrict__ partial, int slabs, float* __restrict__ dW, int N, int K,
+                                                        int ldw) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // over 256 x 256
+  const int n = idx >> 8, k = idx & 255;
+  if (n >= N || k >= K) return;   // rows n >= 128 exist only when the launch had a second n-half, i.e. N > 128
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 3 < slabs; c += 4) {
+    s0 += partial[(long)(c + 0) * 65536 + idx];
+    s1 += partial[(long)(c + 1) * 65536 + idx];
+    s2 += partial[(long)(c + 2) * 65536 + idx];
+    s3 += partial[(long)(c + 3) * 65536 + idx];
+  }
+  for (; c < slabs; ++c) s0 += partial[(long)c * 65536 + idx];
+  dW[(long)n * ldw + k] = (s0 + s1) + (s2 + s3);
+}
+
+// column sums of the per-workgroup partials [groups, 256] -> out[n]: one workgroup per column, fixed-order tree
+__global__ __launch_bounds__(256) void mlp_colsum_reduce(const float* __restrict__ part, int groups, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int col = blockIdx.x;
+  float s = 0.f;
+  for (int g = threadIdx.x; g < groups; g += 256) s += part[(long)g * 256 + col];
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[col] = red[0];
+}
+
+// S = sin(pre), C = cos(pre) over [M, n] with independent row strides (the first layer, whose K = 15 product stays in the BLAS)
+__global__ __launch_bounds__(256) void mlp_sincos_kernel(const float* __restrict__ pre, long ldp, float* __restrict__ S, long lds,
+                                                         float* __restrict__ C, long ldc, long M, int n) {
+  const long total = M * n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / n;
+    const int j = (int)(i - m * n);
+    float s, c;
+    sincos_cw(pre[m * ldp + j], s, c);
+    S[m * lds + j] = s;
+    C[m * ldc + j] = c;
+  }
+}
+
+// out = a * b over [M, n] with row strides (G = d_inp * C for the layer fed by the BLAS product)
+__global__ __launch_bounds__(256) void mlp_mul_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                      float* __restrict__ out, long ldo, long M, int n) {
+  const long total = M * n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / n;
+    const int j = (int)(i - m * n);
+    out[m * ldo + j] = a[m * lda + j] * b[m * ldb + j];
+  }
+}
+
+// (row tile, column half) work items; a workgroup must keep one column half across its persistent loop: grid multiple of 16
+inline unsigned nt_grid(long M, int N) {
+  const long rt = (M + kBM - 1) / kBM;
+  const long items = N > kBN ? ((rt + 7) / 8) * 16 : rt;
+  static const long cap = getenv("MATPBR_MLP_GRID") ? atol(getenv("MATPBR_MLP_GRID")) : kPersistent;   // tuning knob (multiple of 16)
+  return (unsigned)(items < cap ? items : cap);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Launches the product over all M rows: the pipelined kernel over the full 128-row tiles when the shape allows it, the general
+// kernel over the ragged rest (or over everything).  Returns the number of column-sum rows written to p.colsum.
+template <int EPI>
+int launch_nt(NtArgs p, long M, hipStream_t stream) {
+  const int halves = (p.N + kBN - 1) / kBN;
+  const bool pipe = p.K > 224 && p.ldo >= halves * kBN && p.lda >= 256 && p.ldb >= 256 && M >= kBM;
+  int groups = 0;
+  long done = 0;
+  if (pipe) {
+    done = M / kBM * kBM;
+    p.M = (int)done;
+    const unsigned grid = nt_grid(done, p.N);
+    hipLaunchKernelGGL(mlp_gemm_nt_pipe<EPI>, dim3(grid), dim3(256), 0, stream, p);
+    groups += (int)grid;
+  }
+  if (done < M) {
+    NtArgs q = p;
+    q.A = p.A + (size_t)done * p.lda;
+    q.out0 = p.out0 + (size_t)done * p.ldo;
+    if (p.out1) q.out1 = p.out1 + (size_t)done * p.ldo;
+    if (p.cmul) q.cmul = p.cmul + (size_t)done * p.ldo;
+    if (p.colsum) q.colsum = p.colsum + (size_t)groups * 256;
+    q.M = (int)(M - done);
+    const unsigned grid = nt_grid(M - done, p.N);
+    hipLaunchKernelGGL(mlp_gemm_nt<EPI>, dim3(grid), dim3(256), 0, stream, q);
+    groups += (int)grid;
+  }
+  return groups;
+}
+
+}  // namespace
+
+extern "C" {
+
+int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo, long M,
+                         int N, int K, void* stream) {
+  if (!x || !w || !bias || !s_out || M <= 0 || M > 0x7fffff00L || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
+  if ((ldx & 3) || (ldw & 3) || ldx < ((K + 3) & ~3) || ldw < ((K + 3) & ~3) || ldo < N || !aligned16(x) || !aligned16(w))
+    return MATPBR_ERR_INVALID_ARG;
+  NtArgs p{x, w, bias, nullptr, s_out, c_out, nullptr, 0, N, K, ldx, ldw, ldo};
+  if (c_out)
+    launch_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
+  else
+    launch_nt<EPI_BIAS>(p, M, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+size_t matpbr_mlp_bwd_input_workspace_bytes(long M) { (void)M; return (size_t)(kPersistent + 16) * 256 * sizeof(float); }
+
+int matpbr_mlp_layer_bwd_input(const float* g, int ldg, const float* wt, int ldwt, const float* c_prev, float* g_prev, int ldo,
+                               float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
+  if (!g || !wt || !c_prev || !g_prev || M <= 0 || M > 0x7fffff00L || n_prev <= 0 || n_prev > 256 || n_red <= 0 || n_red > 256)
+    return MATPBR_ERR_INVALID_ARG;
+  if ((ldg & 3) || (ldwt & 3) || ldg < ((n_red + 3) & ~3) || ldwt < ((n_red + 3) & ~3) || ldo < n_prev || !aligned16(g) || !aligned16(wt))
+    return MATPBR_ERR_INVALID_ARG;
+  if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
+  NtArgs p{g, wt, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, 0, n_prev, n_red, ldg, ldwt, ldo};
+  const int groups = launch_nt<EPI_MULC>(p, M, (hipStream_t)stream);
+  if (d_bias_prev)
+    hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+static int wgrad_slabs(long M) {
+  long s = (M + 1023) / 1024;   // >= 1024 rows per slab
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+size_t matpbr_mlp_bwd_weight_workspace_bytes(long M) { return (size_t)wgrad_slabs(M) * 256 * 256 * sizeof(float); }
+
+int matpbr_mlp_layer_bwd_weight(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
+                                size_t workspace_bytes, long M, int N, int K, void* stream) {
+  if (!g || !x || !d_w || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
+  if ((ldg & 3) || (ldx & 3) || ldg < N || ldx < ((K + 3) & ~3) || ldw < K || !aligned16(g) || !aligned16(x)) return MATPBR_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < matpbr_mlp_bwd_weight_workspace_bytes(M)) return MATPBR_ERR_WORKSPACE;
+  const int slabs = wgrad_slabs(M);
+  long rows = (M + slabs - 1) / slabs;
+  rows = (rows + kWM - 1) / kWM * kWM;
+  hipLaunchKernelGGL(mlp_wgrad_tn, dim3(slabs, (N + 127) / 128), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, K);
+  hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_sincos(const float* pre, long ldp, float* s_out, long lds, float* c_out, long ldc, long M, int n, void* stream) {
+  if (!pre || !s_out || !c_out || M <= 0 || n <= 0) return MATPBR_ERR_INVALID_ARG;
+  long blocks = (M * n + 255) / 256;
+  if (blocks > 256L * 32) blocks = 256L * 32;
+  hipLaunchKernelGGL(mlp_sincos_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pre, ldp, s_out, lds, c_out, ldc, M, n);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_mul(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long M, int n, void* stream) {
+  if (!a || !b || !out || M <= 0 || n <= 0) return MATPBR_ERR_INVALID_ARG;
+  long blocks = (M * n + 255) / 256;
+  if (blocks > 256L * 32) blocks = 256L * 32;
+  hipLaunchKernelGGL(mlp_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, M, n);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -3,7 +3,7 @@ PyTorch is used for device memory and streams; all arithmetic happens in libmatp
 from __future__ import annotations
 
 import ctypes
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 
@@ -349,6 +349,67 @@ def sin_bwd(d_y: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
         code = lib.matpbr_sin_bwd(_ptr(d_y), d_y.stride(0), _ptr(pre), pre.stride(0), _ptr(out), M, n, _stream(d_y))
     _lib.check(code, "matpbr_sin_bwd")
     return out
+
+
+def _mat2(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float32 and t.ndim == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+        raise ValueError(f"{name}: expected a [rows, cols] fp32 CUDA matrix with unit column stride, a row stride that is a multiple "
+                         f"of 4 floats and a 16-byte aligned base (got shape {tuple(t.shape)}, strides {t.stride()})")
+    return t
+
+
+_mlp_ws: Dict[tuple, torch.Tensor] = {}
+
+
+def _mlp_workspace(kind: str, M: int, device, nbytes: int) -> torch.Tensor:
+    key = (kind, M, device)
+    if key not in _mlp_ws:
+        _mlp_ws[key] = torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=device)
+    return _mlp_ws[key]
+
+
+def mlp_layer_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: Optional[torch.Tensor], K: int) -> None:
+    """s_out[:, :N] = sin(x[:, :K] w[:, :K]^T + bias), c_out[:, :N] = cos(same) (c_out None: no activation).  x [M, >=K], w [N, >=K];
+    s_out / c_out are [M, >=N] with the same row stride.  One MFMA kernel (posmlp_kernels.hip)."""
+    lib = _lib.load()
+    x, w, s_out = _mat2(x, "x"), _mat2(w, "w"), _mat2(s_out, "s_out")
+    M, N = x.shape[0], w.shape[0]
+    if c_out is not None and (c_out.stride(0) != s_out.stride(0) or not c_out.is_cuda):
+        raise ValueError("c_out must share s_out's row stride")
+    with torch.cuda.device(x.device):
+        code = lib.matpbr_mlp_layer_fwd(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(bias.contiguous()), _ptr(s_out),
+                                        _ptr(c_out) if c_out is not None else None, s_out.stride(0), M, N, K, _stream(x))
+    _lib.check(code, "matpbr_mlp_layer_fwd")
+
+
+def mlp_layer_bwd_input(g: torch.Tensor, wt: torch.Tensor, c_prev: torch.Tensor, g_prev: torch.Tensor, n_prev: int, n_red: int,
+                        d_bias_prev: Optional[torch.Tensor]) -> None:
+    """g_prev[:, :n_prev] = (g[:, :n_red] wt[:n_prev, :n_red]^T) * c_prev[:, :n_prev]; d_bias_prev = column sums of g_prev."""
+    lib = _lib.load()
+    g, wt = _mat2(g, "g"), _mat2(wt, "wt")
+    M = g.shape[0]
+    if c_prev.stride(0) != g_prev.stride(0):
+        raise ValueError("c_prev and g_prev must share their row stride")
+    ws = _mlp_workspace("bwd_input", M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
+    with torch.cuda.device(g.device):
+        code = lib.matpbr_mlp_layer_bwd_input(_ptr(g), g.stride(0), _ptr(wt), wt.stride(0), _ptr(c_prev), _ptr(g_prev), g_prev.stride(0),
+                                              _ptr(d_bias_prev) if d_bias_prev is not None else None, _ptr(ws), ws.numel() * 4, M, n_prev,
+                                              n_red, _stream(g))
+    _lib.check(code, "matpbr_mlp_layer_bwd_input")
+
+
+def mlp_layer_bwd_weight(g: torch.Tensor, x: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """d_w [N, K] = g[:, :N]^T x[:, :K] over all rows (deterministic slab partials)."""
+    lib = _lib.load()
+    g, x = _mat2(g, "g"), _mat2(x, "x")
+    M = g.shape[0]
+    ws = _mlp_workspace("bwd_weight", M, g.device, lib.matpbr_mlp_bwd_weight_workspace_bytes(M))
+    d_w = torch.empty((N, K), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        code = lib.matpbr_mlp_layer_bwd_weight(_ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(d_w), K, _ptr(ws), ws.numel() * 4, M, N, K,
+                                               _stream(g))
+    _lib.check(code, "matpbr_mlp_layer_bwd_weight")
+    return d_w
 
 
 def brdf_terms(cos1, cos2, r, f0) -> torch.Tensor:

@@ -109,6 +109,102 @@ class _PosMlpFn(torch.autograd.Function):
         return (d_x0, None, None, *grads)
 
 
+def _ceil4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def _pad_cols(t: torch.Tensor, cols: int) -> torch.Tensor:
+    """[rows, n] -> contiguous [rows, cols] with zero padding (row stride a multiple of 4 floats for the MFMA kernels)."""
+    if t.shape[1] == cols and t.is_contiguous():
+        return t
+    out = t.new_zeros((t.shape[0], cols))
+    out[:, :t.shape[1]] = t
+    return out
+
+
+class _PosMlpHipFn(torch.autograd.Function):
+    """The coordinate MLP on the hand-written exact-f32 MFMA kernels of libmatpbr.so (csrc/posmlp_kernels.hip): one launch per sine
+    layer forward (`sin`/`cos` in the GEMM epilogue; the pre-activation is never stored), one per layer for dL/d input (the `* cos`
+    and the bias-gradient column sums in the epilogue) and one slab-split launch per weight gradient.  The zero-initialised
+    output layer ([M,256] x [256,5]) stays a BLAS call; its backward into the last sine layer goes through the fused kernel.
+    Same buffer trick as `_PosMlpFn` for the skip layers: the producer writes the first columns of a 256-wide buffer whose tail
+    holds x0.  The input x0 gets no gradient here (it is the constant `start_arm` of the optimisation loop)."""
+
+    MIN_ROWS = 8192
+
+    @staticmethod
+    def supported(x0: torch.Tensor, skip, weights) -> bool:
+        L = len(weights)
+        if not (x0.is_cuda and x0.dtype == torch.float32 and not x0.requires_grad and L >= 2):
+            return False
+        if x0.shape[0] < _PosMlpHipFn.MIN_ROWS:          # a 16x32 envmap is 4 row tiles: launch-latency territory, BLAS is fine
+            return False
+        d0, k = x0.shape[1], x0.shape[1]
+        for l in range(L - 1):
+            n = weights[l].shape[0]
+            if weights[l].shape[1] != k or n > 256 or k > 256:
+                return False
+            k = n + d0 if (l + 1) in skip else n
+            if k % 4:
+                return False
+        return weights[L - 1].shape[1] == k and k <= 256
+
+    @staticmethod
+    def forward(ctx, x0, skip, *wb):
+        from . import ops
+
+        L = len(wb) // 2
+        weights, biases = wb[0::2], wb[1::2]
+        M, d0 = x0.shape
+        inp, K = _pad_cols(x0, _ceil4(d0)), d0
+        inps, coss = [], []
+        for l in range(L - 1):
+            W, b = weights[l], biases[l]
+            n = W.shape[0]
+            width = n + d0 if (l + 1) in skip else n
+            buf = torch.empty((M, width), dtype=torch.float32, device=x0.device)
+            cbuf = torch.empty((M, width), dtype=torch.float32, device=x0.device)
+            inps.append(inp)
+            ops.mlp_layer_fwd(inp, _pad_cols(W, _ceil4(K)), b, buf, cbuf, K)
+            if width != n:
+                buf[:, n:] = x0
+            coss.append(cbuf)
+            inp, K = buf, width
+        inps.append(inp)
+        out = torch.addmm(biases[L - 1], inp, weights[L - 1].t())
+        ctx.save_for_backward(x0, *weights, *inps, *coss)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import ops
+
+        L = ctx.L
+        saved = ctx.saved_tensors
+        x0, weights = saved[0], saved[1:1 + L]
+        inps = saved[1 + L:1 + 2 * L]
+        coss = saved[1 + 2 * L:]
+        grads = [None] * (2 * L)
+        g = grad_out.contiguous()
+        n_out = g.shape[1]
+        grads[2 * (L - 1)] = _split_k_tn(g, inps[L - 1])
+        grads[2 * (L - 1) + 1] = _column_sum(g)
+        g, n_red = _pad_cols(g, _ceil4(n_out)), n_out
+        for l in range(L - 1, 0, -1):                  # g = dL/d pre of layer l  ->  dL/d pre of layer l-1, its bias gradient
+            n_prev = weights[l - 1].shape[0]
+            wt = _pad_cols(weights[l][:, :n_prev].t(), _ceil4(n_red))
+            g_prev = torch.empty_like(coss[l - 1])
+            d_b = torch.empty(n_prev, dtype=torch.float32, device=g.device)
+            ops.mlp_layer_bwd_input(g, wt, coss[l - 1], g_prev, n_prev, n_red, d_b)
+            grads[2 * (l - 1) + 1] = d_b
+            g, n_red = g_prev, n_prev
+            if l - 1 >= 1:
+                grads[2 * (l - 1)] = ops.mlp_layer_bwd_weight(g, inps[l - 1], n_prev, weights[l - 1].shape[1])
+        grads[0] = _split_k_tn(g[:, :n_red], x0)        # K = 15: a BLAS product
+        return (None, None, *grads)
+
+
 class _Sine(nn.Module):
     """Hidden layer: Linear followed by sin (the reference's SineLayer applies no omega_0, mymodels/mlps.py:102-103)."""
 
@@ -179,7 +275,10 @@ class PosMLP(nn.Module):
             layer = getattr(self, f"lin{l}")
             lin = layer.linear if l < self.n_layers - 1 else layer
             wb += [lin.weight, lin.bias]
-        x = _PosMlpFn.apply(x0, self.skip, self.n_layers - 1, *wb)
+        if _PosMlpHipFn.supported(x0, self.skip, wb[0::2]):
+            x = _PosMlpHipFn.apply(x0, self.skip, *wb)
+        else:
+            x = _PosMlpFn.apply(x0, self.skip, self.n_layers - 1, *wb)
         if self.output_type == "envmap":
             return F.softplus(x)
         if self.output_type == "arm":

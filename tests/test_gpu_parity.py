@@ -711,3 +711,37 @@ def test_real_image_run_lands_where_the_reference_run_did(tmp_path):
         assert d["final_vs_reference_final"] < bound < d["initial_vs_reference_final"], (k, d)
     for name in ("best_results/albedo.exr", "best_results/envmap.hdr", "opt_env_img.png", "final_envmap.hdr", "config.json"):
         assert os.path.exists(os.path.join(str(tmp_path), "indoor2", name)), name
+
+
+@pytest.mark.parametrize("M,hidden,skip,d0,n_out", [(4096, (256, 256, 256, 256), (1, 3), 15, 5), (1000, (64, 128, 64), (2,), 12, 3),
+                                                   (2 * 128 + 7, (256, 256), (), 10, 8)])
+def test_posmlp_mfma_kernels_match_the_torch_composition(M, hidden, skip, d0, n_out):
+    """f2: the hand-written f32-MFMA sine layers (forward with sin/cos epilogue, dL/d input with the cos and bias-gradient
+    epilogue, slab-split weight gradient) against the torch/BLAS composition of the same network: outputs and every gradient.
+    fp32 both sides; tolerance = accumulated rounding of K <= 256 dot products and M-row reductions."""
+    from materialist_amd import posmlp
+
+    dev = _cuda()
+    dims = [d0] + list(hidden) + [n_out]
+    wb = []
+    for l in range(len(dims) - 1):
+        n = dims[l + 1] - d0 if (l + 1) in skip else dims[l + 1]
+        k = dims[l]
+        wb += [(torch.rand(n, k, device=dev) * 2 - 1) / k ** 0.5, (torch.rand(n, device=dev) * 2 - 1) / k ** 0.5]
+    x0 = torch.randn(M, d0, device=dev)
+    x0[:, 0] = torch.arange(M, device=dev) % 512          # pixel coordinates: pre-activations of a few hundred radians
+    posmlp._PosMlpHipFn.MIN_ROWS = 1
+    assert posmlp._PosMlpHipFn.supported(x0, skip, wb[0::2])
+    posmlp._PosMlpHipFn.MIN_ROWS = 8192
+    go = torch.randn(M, n_out, device=dev)
+    res = []
+    for fn in ("hip", "torch"):
+        ps = [t.clone().requires_grad_(True) for t in wb]
+        out = posmlp._PosMlpHipFn.apply(x0, skip, *ps) if fn == "hip" else posmlp._PosMlpFn.apply(x0, skip, len(dims) - 2, *ps)
+        out.backward(go)
+        res.append((out.detach(), [p.grad for p in ps]))
+    (o_h, g_h), (o_t, g_t) = res
+    assert (o_h - o_t).abs().max().item() <= 2e-5 * max(1.0, o_t.abs().max().item())
+    for i, (a, b) in enumerate(zip(g_h, g_t)):
+        scale = b.abs().max().item() + 1e-6
+        assert (a - b).abs().max().item() <= 3e-4 * scale, (i, (a - b).abs().max().item(), scale)
