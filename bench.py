@@ -201,16 +201,29 @@ def main():
     ms_f = back_to_back(lambda: ops.shade_fwd(mm["albedo"], mm["roughness"], mm["metallic"], nrm, lgt, args.spp))
     ms_b = back_to_back(lambda: ops.shade_bwd(mm["albedo"], mm["roughness"], mm["metallic"], nrm, lgt, d_probe, args.spp, want_mat=True))
 
-    # the PosMLP side of the pos_mlp iteration is hipBLASLt fp32 GEMMs (MFMA 16x16x4 f32, exact fp32): rate of its hidden layer
+    # the PosMLP side of the pos_mlp iteration: nine [H*W,256]x[256,256] products per iteration on the exact-f32 MFMA, in the
+    # hand-written kernels of libmatpbr.so (epilogues included); the BLAS product of the same shape is timed beside them
     gemm = None
     if B == 1:
-        xg = torch.randn(H * W, 256, device=dev)
-        wg = torch.randn(256, 256, device=dev)
+        Mg = H * W
+        xg, gg = torch.randn(Mg, 256, device=dev), torch.randn(Mg, 256, device=dev)
+        wg, bg = torch.randn(256, 256, device=dev) / 16, torch.randn(256, device=dev)
+        sg, cg, gp = (torch.empty(Mg, 256, device=dev) for _ in range(3))
+        dbg = torch.empty(256, device=dev)
+        flop = 2.0 * Mg * 256 * 256
+        ms_fwd = back_to_back(lambda: ops.mlp_layer_fwd(xg, wg, bg, sg, cg, 256))
+        ms_din = back_to_back(lambda: ops.mlp_layer_bwd_input(gg, wg, cg, gp, 256, 256, dbg))
+        ms_dw = back_to_back(lambda: ops.mlp_layer_bwd_weight(gg, xg, 256, 256))
         ms_g = back_to_back(lambda: torch.mm(xg, wg))
-        gemm = {"bound": "mfma", "kernel": "hipBLASLt f32 GEMM [H*W,256]x[256,256] (PosMLP hidden layer, PyTorch-ROCm)", "achieved": 2.0 * H * W * 256 * 256 / (ms_g * 1e-3) / 1e12,
-                "peak": 157.3, "unit": "TFLOP/s", "avg_launch_ms": ms_g}
+        tf = lambda ms: flop / (ms * 1e-3) / 1e12
+        gemm = {"bound": "mfma", "kernel": "mlp_gemm_nt_pipe<sincos> / <mul cos> / mlp_wgrad_tn: [H*W,256]x[256,256] on v_mfma_f32_32x32x2_f32",
+                "achieved": 3 * flop / ((ms_fwd + ms_din + ms_dw) * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                "forward_sincos": {"avg_launch_ms": ms_fwd, "achieved": tf(ms_fwd)},
+                "bwd_input_mulcos_colsum": {"avg_launch_ms": ms_din, "achieved": tf(ms_din)},
+                "bwd_weight": {"avg_launch_ms": ms_dw, "achieved": tf(ms_dw)},
+                "blas_product_same_shape": {"avg_launch_ms": ms_g, "achieved": tf(ms_g), "kernel": "hipBLASLt f32 (PyTorch-ROCm), no epilogue"}}
         gemm["frac"] = gemm["achieved"] / gemm["peak"]
-        del xg, wg
+        del xg, gg, wg, sg, cg, gp
 
     # BASELINE configs[4]: forward-only relighting, 2048x2048, 360 lights, through the precomputed transfer (HBM-bound kernel)
     relight = None

@@ -115,6 +115,14 @@ def masked_mean_fill(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return x * (1.0 - w) + mean * w
 
 
+def _make_adamw(params, lr):
+    params = list(params)
+    try:
+        return torch.optim.AdamW(params, lr=lr, fused=True)
+    except (RuntimeError, TypeError, ValueError):
+        return torch.optim.AdamW(params, lr=lr)
+
+
 class BrdfPhase:
     """Hot loop B, `model_name == 'none'` (inverse_img_w_mi.py:347-468)."""
 
@@ -415,7 +423,7 @@ class PosMlpBrdfPhase:
         self.orig = {"albedo": self.start_arm[:, 0:3].reshape(self.H, self.W, 3).contiguous(),
                      "roughness": (self.start_arm[:, 3:4]).reshape(self.H, self.W, 1).contiguous(),
                      "metallic": self.start_arm[:, 4:5].reshape(self.H, self.W, 1).contiguous()}
-        self.opt = torch.optim.AdamW(net.parameters(), lr=lr)
+        self.opt = _make_adamw(net.parameters(), lr)       # one fused launch instead of eight foreach passes
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)
         dev = self.gt.device
         self.stats = ops.new_loss_stats(1, dev)
