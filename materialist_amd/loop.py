@@ -489,6 +489,62 @@ class PosMlpBrdfPhase:
         return self.es.early_stop
 
 
+class PosMlpNormalPhase:
+    """Hot loop B in `pos_mlp` mode with output_type 'armn' (inverse_img_w_mi.py:165-172,493-506,516-554): the coordinate MLP
+    also predicts the shading normal (`'n'` in --opt_order, predicted normals instead of geometric ones).  Maps from the net
+    (clamps of :493-496, `normalize` of :497), the autograd render, the torch-composed loss with the L1 anchor on every live part
+    (:522-537), AdamW + StepLR.  The normal gradient needs the `d n` variant of the backward kernel, so this phase goes through
+    the operator face (`render_w_brdf`) rather than the fused loss kernels."""
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_armn: torch.Tensor,
+                 fixed: Dict[str, torch.Tensor], optimize_part: str = "armn", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1,
+                 saver: Optional[DeviceSaveBest] = None, mask: Optional[torch.Tensor] = None):
+        self.scene, self.gt, self.net, self.part = scene, gt_image, net, optimize_part
+        self.spp, self.scale_delta, self.mask = int(spp), float(scale_delta), mask
+        self.H, self.W = gt_image.shape[0], gt_image.shape[1]
+        self.gt_srgb = _loss.linear_to_srgb(gt_image)
+        self.start = start_armn.detach()
+        self.fixed = {k: v.detach() for k, v in fixed.items()}
+        H, W = self.H, self.W
+        self.orig = {"albedo": self.start[:, 0:3].reshape(H, W, 3), "roughness": self.start[:, 3:4].reshape(H, W, 1),
+                     "metallic": self.start[:, 4:5].reshape(H, W, 1), "normal": self.start[:, 5:8].reshape(H, W, 3)}
+        self.opt = _make_adamw(net.parameters(), lr)
+        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)
+        self.saver = saver if saver is not None else DeviceSaveBest()
+        self.best_weights = {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    def maps_from_net(self):
+        arm = self.net(self.start)                                                       # :493
+        H, W = self.H, self.W
+        raw = {"albedo": arm[:, 0:3].clamp(0, 1).reshape(H, W, 3), "roughness": (arm[:, 3:4] * 0.93 + 0.07).clamp(0, 1).reshape(H, W, 1),
+               "metallic": arm[:, 4:5].clamp(0, 1).reshape(H, W, 1),
+               "normal": torch.nn.functional.normalize(arm[:, 5:8], p=2, dim=1).reshape(H, W, 3)}   # :494-497
+        keys = {"a": "albedo", "r": "roughness", "m": "metallic", "n": "normal"}
+        live = [keys[c] for c in self.part if c in keys]
+        maps = {k: (raw[k] if k in live else self.fixed[k]) for k in raw}
+        if self.mask is not None:                                                        # :509-511
+            maps["roughness"] = masked_mean_fill(maps["roughness"], self.mask)
+            maps["metallic"] = masked_mean_fill(maps["metallic"], self.mask)
+        return maps, live
+
+    def step(self) -> torch.Tensor:
+        maps, live = self.maps_from_net()
+        pred = _render.render_w_brdf(self.scene, maps["albedo"], maps["roughness"], maps["metallic"], maps["normal"], self.spp)   # :515
+        loss, loss_mse, pred_srgb, _ = _loss.brdf_loss(pred, self.gt, {k: maps[k] for k in live}, self.orig, self.scale_delta, self.gt_srgb)
+        loss.backward()                                                                  # :544
+        before = self.saver.best_loss.clone() if self.saver.best_loss is not None else torch.full_like(loss_mse.detach(), float("inf"))
+        self.saver.update(loss_mse, albedo=maps["albedo"], roughness=maps["roughness"], metallic=maps["metallic"], normal=maps["normal"],
+                          rendered_img=pred_srgb)
+        flag = (self.saver.best_loss < before).reshape(())
+        for k, v in self.net.state_dict().items():                                       # SaveBest keeps the weights too (:546-547)
+            self.best_weights[k] = torch.where(flag, v.detach(), self.best_weights[k])
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        if self.opt.param_groups[0]["lr"] > 1.5e-4:                                      # :553-554
+            self.sched.step()
+        return loss_mse.detach()
+
+
 def _lib_ws(batch: int) -> int:
     from . import _lib
 

@@ -39,8 +39,6 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
     params = _render.traverse(scene)                                               # :216-220
     params["shape.bsdf.a"], params["shape.bsdf.r"], params["shape.bsdf.m"] = mat["albedo"], mat["roughness"], mat["metallic"]
     if not scene.use_mesh_normal:                                                  # 'n' in opt_order: shade with the predicted normal map (:335-340)
-        if model_name == "pos_mlp":
-            raise NotImplementedError("output_type 'armn' (normals through the PosMLP) is not wired yet; use --model_name none for 'n'")
         mat["normal"] = torch.nn.functional.normalize(mat["normal"], p=2, dim=-1)  # :193
         params["shape.bsdf.n"] = mat["normal"]
 
@@ -58,8 +56,10 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         start_envmap = torch.ones(env_size[0] * env_size[1], 3, device=dev)
         env_params = list(env_net.parameters())
         env_head = lambda: env_net(start_envmap).reshape(tuple(env_size) + (3,))
-        brdf_net = posmlp.brdf_net("arm").to(dev)
-        start_arm = torch.cat([mat["albedo"].reshape(-1, 3), mat["roughness"].reshape(-1, 1), mat["metallic"].reshape(-1, 1)], dim=-1).clamp(0, 1)
+        armn = not scene.use_mesh_normal                                            # output_type (:159-172,203-206)
+        brdf_net = posmlp.brdf_net("armn" if armn else "arm").to(dev)
+        start_arm = torch.cat([mat["albedo"].reshape(-1, 3), mat["roughness"].reshape(-1, 1), mat["metallic"].reshape(-1, 1)], dim=-1)
+        start_arm = torch.cat([start_arm, mat["normal"].reshape(-1, 3)], dim=-1) if armn else start_arm.clamp(0, 1)
     elif model_name == "none":
         env_raw = torch.zeros(tuple(env_size) + (3,), dtype=torch.float32, device=dev, requires_grad=True)
         env_params = [env_raw]
@@ -179,7 +179,34 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         say(f"loop {loop_num}: part {part!r} (with normals) ran {it + 1} iterations ({stop})")
         return it, ph.opt.param_groups[0]["lr"], stop
 
+    def brdf_part_runner_mlp_normal(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
+        """pos_mlp with output_type 'armn' (:165-172,493-506): the net predicts the normal map as well."""
+        ph = _loop.PosMlpNormalPhase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in ("albedo", "roughness", "metallic", "normal")},
+                                     optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask)
+        if saver.best_loss is not None:
+            ph.saver.best_loss = saver.best_loss.clone().reshape(())
+        es = _loop.EarlyStopping(patience, min_delta)
+        stop, it = "num_epochs", 0
+        for it in range(n_epochs):
+            es(float(ph.step()))                                                    # per-epoch host check, as the reference (:550)
+            if es.early_stop:
+                stop = "early_stop"
+                break
+        new_best = ph.saver.best_loss.reshape(-1)
+        prev = saver.best_loss if saver.best_loss is not None else torch.full_like(new_best, float("inf"))
+        if bool((new_best < prev).any()) and "albedo" in ph.saver.best:
+            saver.best_loss = torch.minimum(new_best, prev)
+            for k_ in ("albedo", "roughness", "metallic", "normal", "rendered_img"):
+                saver.best[k_] = ph.saver.best[k_].clone()
+            saver.best["envmap"] = state["envmap4render"].clone()
+            mat["normal"] = saver.best["normal"]
+            brdf_net.load_state_dict(ph.best_weights)                               # :586-587
+        say(f"loop {loop_num}: part {part!r} (pos_mlp, armn) ran {it + 1} iterations ({stop})")
+        return it, ph.opt.param_groups[0]["lr"], stop
+
     def brdf_part_runner(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
+        if model_name == "pos_mlp" and not scene.use_mesh_normal:
+            return brdf_part_runner_mlp_normal(loop_num, part, patience, min_delta, n_epochs)
         if model_name == "pos_mlp":
             return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
         if "n" in part or not scene.use_mesh_normal or mask is not None:

@@ -589,6 +589,30 @@ def test_use_mask_keeps_roughness_and_metallic_uniform_inside_the_mask(tmp_path,
         assert outside.max() - outside.min() > 1e-4 or name == "metallic"      # the flat prior's metallic starts uniform
 
 
+def test_pos_mlp_with_predicted_normals_runs_and_improves(tmp_path):
+    """'n' in --opt_order under --model_name pos_mlp: output_type 'armn' (inverse_img_w_mi.py:165-172,493-506), the MLP predicts the
+    normal map too; the loop must lower the loss and write best_results/normal.exr with unit normals."""
+    from PIL import Image
+
+    from materialist_amd import pipeline
+    from materialist_amd.imageio_exr import read_exr
+
+    _cuda()
+    torch.manual_seed(3)
+    rng = np.random.default_rng(11)
+    src = str(tmp_path / "in.png")
+    Image.fromarray((rng.random((32, 32, 3)) * 255).astype(np.uint8)).save(src)
+    lines = []
+    res = pipeline.inverse_image(src, "case", opt_src="arm", opt_order=["armn"], opt_env_from=0, save_path=str(tmp_path), size=32, spp=8,
+                                 num_epochs=25, sync_every=5, log=lines.append, model_name="pos_mlp")
+    assert any("armn" in ln for ln in lines)
+    n = read_exr(str(tmp_path / "case" / "best_results" / "normal.exr"))
+    assert np.abs(np.linalg.norm(n, axis=-1) - 1).max() < 1e-4
+    cfg = __import__("json").load(open(tmp_path / "case" / "config.json"))
+    assert cfg["output_type"] == "armn" and cfg["use_mesh_normal"] is False
+    assert res["best_loss"] < 0.2 and np.isfinite(res["psnr"])
+
+
 def test_pos_mlp_phase_matches_torch_composition():
     """f2 in the loop: PosMlpBrdfPhase (maps from the residual MLP, render/loss/backward in libmatpbr.so, gradients handed back
     to torch) against the same iteration composed from torch ops around the autograd render (inverse_img_w_mi.py:493-554)."""
