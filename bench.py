@@ -5,7 +5,7 @@
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one optimisation iteration (epoch) of hot loop B of BASELINE config 2 (`--model_name pos_mlp --opt_order 'rm a'`,
-inverse_img_w_mi.py:470-590): material maps from the residual PosMLP (PyTorch-ROCm GEMMs) -> shade_fwd -> gamma-2.2 MSE/L1
+inverse_img_w_mi.py:470-590): material maps from the residual PosMLP (f32-MFMA sine-layer kernels of libmatpbr.so) -> shade_fwd -> gamma-2.2 MSE/L1
 loss with mean-ratio scaling -> shade_bwd -> AdamW, everything downstream of the maps in libmatpbr.so, inputs resident in
 HBM.  `--mode fused` times the same loop in `--model_name none` mode (maps optimised directly, whole iteration in
 libmatpbr.so); both rates are reported in every run (`modes`).  Images are independent, so ranks never communicate inside
@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--mode", choices=["fused", "torch", "pos_mlp"], default="pos_mlp",
                     help="fused: --model_name none, whole iteration in libmatpbr.so; torch: same step composed from torch ops; "
-                         "pos_mlp: the reference's default mode (maps from the residual PosMLP on PyTorch-ROCm, render/loss/backward in libmatpbr.so)")
+                         "pos_mlp: the reference's default mode (maps from the residual PosMLP, its sine layers + render/loss/backward in libmatpbr.so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-relight", action="store_true", help="skip the 2048x2048 relighting measurement (1.3 GB transfer buffer)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
@@ -178,7 +178,7 @@ def main():
         e_el, _ = timed(make_phase(extra), 5, 40)
         modes[extra] = {"it_per_s": 40 * B * world / e_el, "ms_per_step": e_el / 40 * 1e3}
     mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so)",
-                  "pos_mlp": "hot loop B, --model_name pos_mlp (PosMLP on PyTorch-ROCm + libmatpbr.so)",
+                  "pos_mlp": "hot loop B, --model_name pos_mlp (PosMLP sine layers, render, loss, backward in libmatpbr.so; autograd glue in torch)",
                   "env": "hot loop A, envmap PosMLP head + matpbr_env_phase_step", "torch": "hot loop B composed from torch ops"}
     modes = {k: dict(v, what=mode_names[k]) for k, v in modes.items()}
 

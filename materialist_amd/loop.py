@@ -435,7 +435,20 @@ class PosMlpBrdfPhase:
                   "metallic": torch.empty(self.H, self.W, 1, device=dev)}
         self.best = {k: v.clone() for k, v in self.fixed.items()}
         self.best_img = torch.zeros_like(self.gt)
-        self.best_weights = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        # all parameters as views of one flat buffer: the SaveBest snapshot of the weights is one select instead of one per tensor
+        self._names = [k for k, _ in net.named_parameters()]
+        params = [p for _, p in net.named_parameters()]
+        al = lambda n: (n + 3) // 4 * 4                               # every view 16-byte aligned (the MFMA kernels load float4)
+        self._flat = torch.zeros(sum(al(p.numel()) for p in params), dtype=torch.float32, device=dev)
+        off = 0
+        self._shapes = []
+        for p in params:
+            view = self._flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.detach())
+            p.data = view
+            self._shapes.append((p.shape, p.numel(), off))
+            off += al(p.numel())
+        self._best_flat = self._flat.clone()
         self.hist = torch.zeros((history_len, 1), dtype=torch.float32, device=dev)
         self.ws = None
         self.t = 0
@@ -470,8 +483,7 @@ class PosMlpBrdfPhase:
                                 self.best["metallic"], self.best_img, sc.fov, optimize_part=self.part)
         torch.autograd.backward([maps[k] for k in live], [self.g[k] for k in live])      # :544
         improved = self.stats[0, ops.STAT_IMPROVED] > 0.5                                 # SaveBest keeps the weights too (:546-547)
-        for k, v in self.net.state_dict().items():
-            self.best_weights[k] = torch.where(improved, v.detach(), self.best_weights[k])
+        self._best_flat = torch.where(improved, self._flat, self._best_flat)
         if self.t < self.hist.shape[0]:
             self.hist[self.t].copy_(self.stats[:, ops.STAT_MSE])
         self.opt.step()
@@ -479,6 +491,10 @@ class PosMlpBrdfPhase:
         if self.opt.param_groups[0]["lr"] > 1.5e-4:                                       # :553-554
             self.sched.step()
         self.t += 1
+
+    @property
+    def best_weights(self) -> Dict[str, torch.Tensor]:
+        return {name: self._best_flat[off:off + n].view(shape).clone() for name, (shape, n, off) in zip(self._names, self._shapes)}
 
     def step_and_check(self) -> bool:
         """One iteration followed by the host EarlyStopping check of the reference (:550); True when the part should stop."""

@@ -260,13 +260,20 @@ class PosMLP(nn.Module):
                 nn.init.zeros_(layer.bias)
             setattr(self, f"lin{l}", layer)
         self._code: Dict[tuple, torch.Tensor] = {}
+        self._x0_cache = None
 
     def _points(self, img: torch.Tensor) -> torch.Tensor:
         h, w = grid_shape(img.shape[0])
         key = (h, w, img.device, img.dtype)
         if key not in self._code:
             self._code[key] = positional_code(h, w, self.multires, img.device, img.dtype)
-        return torch.cat([self._code[key], img], dim=1)
+        # the optimisation loops feed the same constant tensor every iteration: keep its [code | img] matrix
+        tag = (img.data_ptr(), img._version, tuple(img.shape))
+        if not img.requires_grad and self._x0_cache is not None and self._x0_cache[0] == tag:
+            return self._x0_cache[1]
+        x0 = torch.cat([self._code[key], img], dim=1)
+        self._x0_cache = (tag, x0) if not img.requires_grad else None
+        return x0
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         x0 = self._points(img)
