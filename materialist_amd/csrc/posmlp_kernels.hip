@@ -14,9 +14,11 @@
 // accumulator registers), two workgroups per CU, persistent over (row tile, column half) work items; K <= 256 in k-tiles of 32
 // through double-buffered LDS (one barrier per k-tile), global -> registers -> LDS with the fetch one k-tile ahead.  A 32x32x2 MFMA
 // takes one f32 per lane for A and one for B (lane l: A[row l&31][k l>>5], B[k l>>5][col l&31]).
-// Measured at M = 512x512 (tools/mlp_bench.py): forward layer 416 us (BLAS product + sin pass: 424), dL/d input 356 us (BLAS + the
+// Measured at M = 512x512 (tools/mlp_bench.py): forward layer 371 us (BLAS product + sin pass: 424), dL/d input 349 us (BLAS + the
 // d_y cos(pre) pass + the bias-gradient pass: 555), weight gradient 303 + 21 us (split-K BLAS: 308); the MFMA pipe is busy
-// 57-77 % of the time.  Ablation of the forward kernel (bias epilogue): MFMA + LDS reads + barriers + stores alone 298 us (the
+// 57-77 % of the time.  Three kernels implement the NT product: mlp_gemm_nt_wide (128x256 tile, the default for 256-wide layers),
+// mlp_gemm_nt_pipe (128x128 tiles with the previous tile's epilogue interleaved; layers of <= 128 outputs) and mlp_gemm_nt (any
+// shape, ragged rows).  Ablation of the forward kernel (bias epilogue): MFMA + LDS reads + barriers + stores alone 298 us (the
 // floor of 8.4 M MFMAs x 64 cycles on 1024 SIMDs is 238 us at 2.2 GHz), + LDS writes 319, + weight fetch 327, + activation fetch
 // 375; the sin/cos epilogue adds 35 us although it rides inside the next tile's MFMA stream.
 #include <hip/hip_runtime.h>
@@ -446,6 +448,155 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt_pipe(NtArgs p) {
   }
 }
 
+// Full-width variant: a workgroup owns 128 rows x 256 columns (2x2 waves of 64x128 = 2x4 MFMA tiles, 128 accumulator registers),
+// the tiling of mlp_wgrad_tn: 128 MFMAs per wave between barriers instead of 64 and each activation row fetched once instead of
+// once per column half.  No room for the previous tile's accumulators, so the epilogue is not interleaved with the next tile: it
+// overlaps with the co-resident workgroup's products instead.  Same preconditions as mlp_gemm_nt_pipe, N > 128.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void mlp_gemm_nt_wide(NtArgs p) {
+  __shared__ __attribute__((aligned(16))) float sA[kBM * kLd];
+  __shared__ __attribute__((aligned(16))) float sB[256 * kLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int crow = tid >> 3, ck = (tid & 7) * 4;
+  const float* pa = sA + (wm * 64 + li) * kLd + 16 * lh;
+  const float* pb = sB + (wn * 128 + li) * kLd + 16 * lh;
+  const int rtiles = p.M / kBM;
+  const int nk = (p.K + kBK - 1) / kBK;
+  const int my_count = ((int)blockIdx.x < rtiles) ? (rtiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  if (my_count == 0) {
+    if (EPI == EPI_MULC && p.colsum != nullptr) p.colsum[(size_t)blockIdx.x * 256 + tid] = 0.f;
+    return;
+  }
+  auto row_of = [&](int j) { return ((int)blockIdx.x + (j < my_count ? j : my_count - 1) * (int)gridDim.x) * kBM; };
+  auto slot = [&](int row0, int kt) { return (kt + (row0 >> 7)) % nk; };
+
+  const int a_lane = crow * p.lda + ck;
+  int b_lane[8];
+  bool b_keep[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int n = crow + 32 * q;
+    b_keep[q] = n < p.N;
+    b_lane[q] = (b_keep[q] ? n : p.N - 1) * p.ldb + ck;
+  }
+  const int st_lane = crow * kLd + ck;
+  int o_lane[4];
+  float bn[4], csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = wn * 128 + ni * 32 + li;
+    o_lane[ni] = (wm * 64 + 4 * lh) * p.ldo + n;
+    bn[ni] = (EPI != EPI_MULC) ? p.bias[n < p.N ? n : p.N - 1] : 0.f;
+  }
+
+  float4 ra[4], rb[8];
+  auto fetch = [&](int row0, int kslot) {
+    const float* ba = p.A + (size_t)row0 * p.lda + kslot * kBK;
+    const float* bb = p.B + kslot * kBK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const float4*>(ba + (size_t)(32 * q) * p.lda + a_lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rb[q] = *reinterpret_cast<const float4*>(bb + b_lane[q]);
+  };
+  auto stash_all = [&](int kslot) {
+    const int k = kslot * kBK + ck;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sA + 32 * q * kLd + st_lane) = kmask(ra[q], k, p.K, true);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(sB + 32 * q * kLd + st_lane) = kmask(rb[q], k, p.K, b_keep[q]);
+  };
+
+  {
+    const int r0 = row_of(0);
+    fetch(r0, slot(r0, 0));
+    stash_all(slot(r0, 0));
+  }
+  __syncthreads();
+  for (int j = 0; j < my_count; ++j) {
+    const int row0 = row_of(j), row1 = row_of(j + 1);
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int rn = kt + 1 < nk ? row0 : row1, kn = kt + 1 < nk ? kt + 1 : 0;   // the stream continues into the next tile
+      fetch(rn, slot(rn, kn));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 a4[2], b4[4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a4[mi] = *reinterpret_cast<const float4*>(pa + mi * 32 * kLd + 4 * g);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b4[ni] = *reinterpret_cast<const float4*>(pb + ni * 32 * kLd + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              const float av = e == 0 ? a4[mi].x : e == 1 ? a4[mi].y : e == 2 ? a4[mi].z : a4[mi].w;
+              const float bv = e == 0 ? b4[ni].x : e == 1 ? b4[ni].y : e == 2 ? b4[ni].z : b4[ni].w;
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+            }
+      }
+      __syncthreads();
+      stash_all(slot(rn, kn));
+      __syncthreads();
+    }
+    // epilogue; for the cos factors: all 32 loads of a column tile pair before its stores (in-order load/store counter)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      float* base0 = p.out0 + (size_t)(row0 + mi * 32) * p.ldo;
+      float* base1 = (EPI == EPI_SINCOS) ? p.out1 + (size_t)(row0 + mi * 32) * p.ldo : nullptr;
+      const float* basec = (EPI == EPI_MULC) ? p.cmul + (size_t)(row0 + mi * 32) * p.ldo : nullptr;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        float cv[2][16];
+        if (EPI == EPI_MULC) {
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cv[n2][r] = basec[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo + o_lane[nh * 2 + n2]];
+        }
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int ni = nh * 2 + n2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const size_t o = (size_t)((r & 3) + 8 * (r >> 2)) * p.ldo + o_lane[ni];
+            const float v = acc[mi][ni][r];
+            if (EPI == EPI_SINCOS) {
+              float sv, cs;
+              sincos_cw(v + bn[ni], sv, cs);
+              base0[o] = sv;
+              base1[o] = cs;
+            } else if (EPI == EPI_BIAS) {
+              base0[o] = v + bn[ni];
+            } else {
+              const float g = v * cv[n2][r];
+              base0[o] = g;
+              csum[ni] += g;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (EPI == EPI_MULC && p.colsum != nullptr) {
+    float* red = sB;   // [4][256]: slot = wm*2 + lh
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) red[(wm * 2 + lh) * 256 + wn * 128 + ni * 32 + li] = csum[ni];
+    __syncthreads();
+    p.colsum[(size_t)blockIdx.x * 256 + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  }
+}
+
 // dW[n][k] partial over a slab of rows: grid (slabs, 2 halves of n).  G [M, ldg] (columns n), X [M, ldx] (columns k).
 constexpr int kWM = 32;   // rows (reduction) per LDS tile
 __global__ __launch_bounds__(256, 2) void mlp_wgrad_tn(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
@@ -609,7 +760,17 @@ int launch_nt(NtArgs p, long M, hipStream_t stream) {
   const bool pipe = p.K > 224 && p.ldo >= halves * kBN && p.lda >= 256 && p.ldb >= 256 && M >= kBM;
   int groups = 0;
   long done = 0;
-  if (pipe) {
+  // bit EPI set: 256-wide outputs go to the full-width kernel (measured at M = 512x512: forward 371 vs 416 us, dL/d input 349 vs
+  // 356 us, whole pos_mlp iteration 3.86 vs 4.04 ms); the pipelined kernel keeps the layers of at most 128 outputs
+  static const int wide_mask = getenv("MATPBR_MLP_WIDE") ? atoi(getenv("MATPBR_MLP_WIDE")) : 7;
+  if (pipe && halves == 2 && ((wide_mask >> EPI) & 1)) {
+    done = M / kBM * kBM;
+    p.M = (int)done;
+    const long rt = done / kBM;
+    const unsigned grid = (unsigned)(rt < kPersistent ? rt : kPersistent);
+    hipLaunchKernelGGL(mlp_gemm_nt_wide<EPI>, dim3(grid), dim3(256), 0, stream, p);
+    groups += (int)grid;
+  } else if (pipe) {
     done = M / kBM * kBM;
     p.M = (int)done;
     const unsigned grid = nt_grid(done, p.N);
