@@ -769,3 +769,32 @@ def test_posmlp_mfma_kernels_match_the_torch_composition(M, hidden, skip, d0, n_
     for i, (a, b) in enumerate(zip(g_h, g_t)):
         scale = b.abs().max().item() + 1e-6
         assert (a - b).abs().max().item() <= 3e-4 * scale, (i, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("tag,kw", [("arm", dict(color_ch=5, out_dims=5, multires_view=2, output_type="arm")),
+                                    ("armn", dict(color_ch=8, out_dims=8, multires_view=0, output_type="armn")),
+                                    ("env", dict(color_ch=3, out_dims=3, multires_view=2, output_type="envmap"))])
+def test_posmlp_mfma_path_matches_the_reference_module(golden_dir, tag, kw):
+    """f2 pinned to the reference itself on the GPU: the networks of tests/golden/posmlp.npz (weights, inputs, outputs and gradients
+    recorded from mymodels/mlps.py in fp64) through the hand-written MFMA sine layers in fp32."""
+    from materialist_amd import posmlp
+
+    dev = _cuda()
+    g = np.load(os.path.join(golden_dir, "posmlp.npz"))
+    net = posmlp.PosMLP(hidden=(64, 64, 64, 64), skip=(1, 3), **kw)
+    net.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g[k]).float() for k in g.files if k.startswith(f"{tag}.sd.")})
+    net = net.to(dev)
+    x = torch.from_numpy(g[f"{tag}.in"]).float().to(dev)
+    posmlp._PosMlpHipFn.MIN_ROWS = 1
+    try:
+        wb = [t for l in range(net.n_layers) for t in ((getattr(net, f"lin{l}").linear if l < net.n_layers - 1 else getattr(net, f"lin{l}")).weight,)]
+        assert posmlp._PosMlpHipFn.supported(net._points(x), net.skip, wb)
+        out = net(x)
+        (out * torch.from_numpy(g[f"{tag}.w"]).float().to(dev)).sum().backward()
+    finally:
+        posmlp._PosMlpHipFn.MIN_ROWS = 8192
+    ref = g[f"{tag}.out"]
+    assert np.abs(out.detach().cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    for got, key in ((net.lin0.linear.weight.grad, "d_lin0_w"), (net.lin4.bias.grad, "d_lin4_b")):
+        r = g[f"{tag}.{key}"]
+        assert np.abs(got.cpu().numpy() - r).max() <= 2e-4 * (np.abs(r).max() + 1e-9), key
