@@ -161,7 +161,9 @@ int matpbr_column_sum(const float* x, float* out, long M, int N, void* workspace
  *                                wt [n_prev, n_red] (stride ldwt) = weight^T restricted to the inputs that come from the layer below,
  *                                c_prev = that layer's c_out (stride ldo, as g_prev); d_bias_prev[n_prev] (optional) = column sums of g_prev
  *   matpbr_mlp_layer_bwd_weight  d_w[N, K] (stride ldw) = g^T x;  g [M, N] (stride ldg), x [M, K] (stride ldx); deterministic (slab partials)
- *   matpbr_mlp_sincos / _mul     the same epilogues as stand-alone passes for the layers whose product stays in the BLAS */
+ *   matpbr_mlp_sincos / _mul     the same epilogues as stand-alone passes for the layers whose product stays in the BLAS
+ * Output columns N .. min(ldo, 128 ceil(N/128)) of s_out / c_out / g_prev are scratch: the kernels may overwrite them (a skip
+ * layer's x0 tail is therefore copied in after the call).  Pre-activations up to |x| ~ 1e5 keep sin/cos at 1.5 ulp. */
 int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo, long M,
                          int N, int K, void* stream);
 size_t matpbr_mlp_bwd_input_workspace_bytes(long M);
