@@ -198,6 +198,29 @@ class EnvPhase:
         return loss_mse.detach()
 
 
+class EnvHeadPhase:
+    """Hot loop A composed on the operator face (inverse_img_w_mi.py:236-254): `head()` -> `render_envmap` -> MSE + L1 on the
+    gamma-2.2 images -> autograd -> optimiser.  Used when the scene has pixels without geometry (`Scene.set_mesh_mask`), which the
+    fused `matpbr_env_phase_step` does not model; same SaveBest / EarlyStopping semantics, checked on the host per epoch."""
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, head, optimizer: torch.optim.Optimizer, spp: int = 64,
+                 saver: Optional[DeviceSaveBest] = None):
+        self.scene, self.gt, self.head, self.opt, self.spp = scene, gt_image, head, optimizer, int(spp)
+        self.saver = saver if saver is not None else DeviceSaveBest()
+        self.pred = None
+
+    def step(self) -> torch.Tensor:
+        data = self.head()
+        pred = _render.render_envmap(self.scene, data, self.spp)                          # :240
+        loss, loss_mse, _ = _loss.env_loss(pred, self.gt)                                 # :241-245
+        loss.backward()
+        self.saver.update(loss_mse, envmap=data, rendered_img=pred)                       # :247
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        self.pred = pred.detach()
+        return loss_mse.detach()
+
+
 class FusedBrdfPhase:
     """Hot loop B in `model_name == 'none'` mode (inverse_img_w_mi.py:347-468), one `matpbr_brdf_phase_step` call per
     iteration: render (clamp folded in), loss statistics, SaveBest and EarlyStopping decisions, fused loss backward
@@ -522,8 +545,11 @@ class PosMlpNormalPhase:
         self.start = start_armn.detach()
         self.fixed = {k: v.detach() for k, v in fixed.items()}
         H, W = self.H, self.W
+        self.armn = self.start.shape[1] >= 8               # 'arm' networks (5 channels) run here too: scenes with a mesh mask
         self.orig = {"albedo": self.start[:, 0:3].reshape(H, W, 3), "roughness": self.start[:, 3:4].reshape(H, W, 1),
-                     "metallic": self.start[:, 4:5].reshape(H, W, 1), "normal": self.start[:, 5:8].reshape(H, W, 3)}
+                     "metallic": self.start[:, 4:5].reshape(H, W, 1)}
+        if self.armn:
+            self.orig["normal"] = self.start[:, 5:8].reshape(H, W, 3)
         self.opt = _make_adamw(net.parameters(), lr)
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)
         self.saver = saver if saver is not None else DeviceSaveBest()
@@ -533,11 +559,13 @@ class PosMlpNormalPhase:
         arm = self.net(self.start)                                                       # :493
         H, W = self.H, self.W
         raw = {"albedo": arm[:, 0:3].clamp(0, 1).reshape(H, W, 3), "roughness": (arm[:, 3:4] * 0.93 + 0.07).clamp(0, 1).reshape(H, W, 1),
-               "metallic": arm[:, 4:5].clamp(0, 1).reshape(H, W, 1),
-               "normal": torch.nn.functional.normalize(arm[:, 5:8], p=2, dim=1).reshape(H, W, 3)}   # :494-497
+               "metallic": arm[:, 4:5].clamp(0, 1).reshape(H, W, 1)}
+        if self.armn:
+            raw["normal"] = torch.nn.functional.normalize(arm[:, 5:8], p=2, dim=1).reshape(H, W, 3)   # :494-497
         keys = {"a": "albedo", "r": "roughness", "m": "metallic", "n": "normal"}
-        live = [keys[c] for c in self.part if c in keys]
+        live = [keys[c] for c in self.part if c in keys and keys[c] in raw]
         maps = {k: (raw[k] if k in live else self.fixed[k]) for k in raw}
+        maps.setdefault("normal", None)
         if self.mask is not None:                                                        # :509-511
             maps["roughness"] = masked_mean_fill(maps["roughness"], self.mask)
             maps["metallic"] = masked_mean_fill(maps["metallic"], self.mask)
@@ -549,8 +577,8 @@ class PosMlpNormalPhase:
         loss, loss_mse, pred_srgb, _ = _loss.brdf_loss(pred, self.gt, {k: maps[k] for k in live}, self.orig, self.scale_delta, self.gt_srgb)
         loss.backward()                                                                  # :544
         before = self.saver.best_loss.clone() if self.saver.best_loss is not None else torch.full_like(loss_mse.detach(), float("inf"))
-        self.saver.update(loss_mse, albedo=maps["albedo"], roughness=maps["roughness"], metallic=maps["metallic"], normal=maps["normal"],
-                          rendered_img=pred_srgb)
+        extra = {"normal": maps["normal"]} if maps["normal"] is not None else {}
+        self.saver.update(loss_mse, albedo=maps["albedo"], roughness=maps["roughness"], metallic=maps["metallic"], rendered_img=pred_srgb, **extra)
         flag = (self.saver.best_loss < before).reshape(())
         for k, v in self.net.state_dict().items():                                       # SaveBest keeps the weights too (:546-547)
             self.best_weights[k] = torch.where(flag, v.detach(), self.best_weights[k])

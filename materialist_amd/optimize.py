@@ -72,7 +72,42 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
     say = (lambda msg: log(f"[{time.perf_counter() - t_start:7.2f} s] {msg}")) if log is not None else (lambda *_: None)
 
     # ------------------------------------------------------------------ hot loop A (:236-254), device-resident
+    background = scene.bg_mask is not None                                          # mesh_mask.png: operator-face phases only
+
+    def env_phase_runner_background(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
+        """Hot loop A on the operator face (scenes with pixels that see the environment directly)."""
+        opt = torch.optim.Adam(env_params, lr=lr_of(0))
+        ph = _loop.EnvHeadPhase(scene, gt, env_head, opt, spp=spp, saver=_loop.DeviceSaveBest())
+        if saver.best_loss is not None:
+            ph.saver.best_loss = saver.best_loss.clone().reshape(())
+        es = _loop.EarlyStopping(patience, min_delta) if patience > 0 else None
+        done, stop, mse = 0, "num_epochs", float("nan")
+        while done < max_epochs:
+            _loop.set_lr(opt, lr_of(done))
+            mse = float(ph.step())
+            done += 1
+            if frames is not None and done % sync_every == 0 and frames.due("env"):
+                frames.env_frame(loop_num, done - 1, gt, ph.pred, env_head().detach())
+            if es is not None:
+                es(mse)
+                if es.early_stop:
+                    stop = "early_stop"
+                    break
+        new_best = ph.saver.best_loss.reshape(-1)
+        prev = saver.best_loss if saver.best_loss is not None else torch.full_like(new_best, float("inf"))
+        if bool((new_best < prev).any()):
+            saver.best_loss = torch.minimum(new_best, prev)
+            saver.best.update(albedo=mat["albedo"].detach().clone(), roughness=mat["roughness"].detach().clone(),
+                              metallic=mat["metallic"].detach().clone(), envmap=ph.saver.best["envmap"].clone(),
+                              rendered_img=ph.saver.best["rendered_img"].clone())
+        elif "envmap" not in saver.best:
+            saver.best["envmap"] = ph.saver.best["envmap"].clone()
+        state["last_mse"] = mse
+        return done - 1, stop, mse
+
     def env_phase_runner(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
+        if background:
+            return env_phase_runner_background(loop_num, lr_of, patience, min_delta, max_epochs)
         graph = max_epochs > 8 and gt.is_cuda
         opt = _loop.capturable_adam(env_params, lr_of(0)) if graph else torch.optim.Adam(env_params, lr=lr_of(0))   # fresh Adam per loop (:225-229)
         ph = _loop.FusedEnvPhase(scene, gt, env_head, opt, spp=spp, patience=patience,
@@ -181,7 +216,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
 
     def brdf_part_runner_mlp_normal(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
         """pos_mlp with output_type 'armn' (:165-172,493-506): the net predicts the normal map as well."""
-        ph = _loop.PosMlpNormalPhase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in ("albedo", "roughness", "metallic", "normal")},
+        fixed_keys = ("albedo", "roughness", "metallic") + (() if scene.use_mesh_normal else ("normal",))
+        ph = _loop.PosMlpNormalPhase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in fixed_keys},
                                      optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask)
         if saver.best_loss is not None:
             ph.saver.best_loss = saver.best_loss.clone().reshape(())
@@ -196,20 +232,22 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         prev = saver.best_loss if saver.best_loss is not None else torch.full_like(new_best, float("inf"))
         if bool((new_best < prev).any()) and "albedo" in ph.saver.best:
             saver.best_loss = torch.minimum(new_best, prev)
-            for k_ in ("albedo", "roughness", "metallic", "normal", "rendered_img"):
+            for k_ in ("albedo", "roughness", "metallic", "rendered_img"):
                 saver.best[k_] = ph.saver.best[k_].clone()
+            if "normal" in ph.saver.best:
+                saver.best["normal"] = ph.saver.best["normal"].clone()
+                mat["normal"] = saver.best["normal"]
             saver.best["envmap"] = state["envmap4render"].clone()
-            mat["normal"] = saver.best["normal"]
             brdf_net.load_state_dict(ph.best_weights)                               # :586-587
         say(f"loop {loop_num}: part {part!r} (pos_mlp, armn) ran {it + 1} iterations ({stop})")
         return it, ph.opt.param_groups[0]["lr"], stop
 
     def brdf_part_runner(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
-        if model_name == "pos_mlp" and not scene.use_mesh_normal:
+        if model_name == "pos_mlp" and (not scene.use_mesh_normal or background):
             return brdf_part_runner_mlp_normal(loop_num, part, patience, min_delta, n_epochs)
         if model_name == "pos_mlp":
             return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
-        if "n" in part or not scene.use_mesh_normal or mask is not None:
+        if "n" in part or not scene.use_mesh_normal or mask is not None or background:
             return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
         ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], optimize_part=part, spp=spp,
                                   scale_delta=scale_delta, patience=patience, min_delta=min_delta,

@@ -310,7 +310,17 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
         depth = 2 * depth.max() - depth
 
     use_mesh_normal = "n" not in str(list(opt_order))                                            # :751-758
-    scene = render.load_estimated_mesh(t(depth), use_mesh_normal=use_mesh_normal, device=device)
+    mesh_mask = None
+    mm_path = os.path.join(output_dir, "mesh_mask.png")                                          # :713-724: pixels without geometry
+    if os.path.exists(mm_path):
+        from PIL import Image
+
+        mk = np.asarray(Image.open(mm_path))
+        mesh_mask = torch.from_numpy(np.ascontiguousarray((mk[..., 0] if mk.ndim == 3 else mk) > 0))
+        if tuple(mesh_mask.shape) != (size, size):
+            raise ValueError(f"{mm_path}: mask is {tuple(mesh_mask.shape)}, the run is {size}x{size}")
+        log(f"Applied mask from {mm_path}: {int(mesh_mask.sum())} pixels see the environment directly")
+    scene = render.load_estimated_mesh(t(depth), use_mesh_normal=use_mesh_normal, device=device, mesh_mask=mesh_mask)
     frames = FrameWriter(output_dir, min_interval=frame_interval)
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
                                         num_epochs=num_epochs, sync_every=sync_every, log=log, frames=frames,

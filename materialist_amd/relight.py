@@ -116,14 +116,37 @@ def envmap_to_light(env: np.ndarray) -> np.ndarray:
 class Relighter:
     """Transfer of one optimised scene; `frames(lights)` renders any number of lights."""
 
-    def __init__(self, mat: Dict[str, torch.Tensor], shading_normal: torch.Tensor, spp: int = 64, fov_x_deg: float = 35.0):
+    def __init__(self, mat: Dict[str, torch.Tensor], shading_normal: torch.Tensor, spp: int = 64, fov_x_deg: float = 35.0,
+                 mesh_mask: Optional[torch.Tensor] = None):
         self.H, self.W = mat["albedo"].shape[0], mat["albedo"].shape[1]
         self.T = ops.shade_transfer(mat["albedo"].contiguous(), mat["roughness"].contiguous(), mat["metallic"].contiguous(),
                                     shading_normal.contiguous(), spp, fov_x_deg)
+        self.bg = None
+        if mesh_mask is not None and bool(mesh_mask.any()):        # pixels without geometry show the environment (mesh_mask.png)
+            from .render import Scene
+
+            sc = Scene(self.H, self.W, self.T.device, fov_x_deg=fov_x_deg)
+            sc.set_mesh_mask(mesh_mask)
+            self.bg = (sc.bg_mask, sc.bg_basis)
 
     def frames(self, lights) -> torch.Tensor:
         L = torch.as_tensor(np.asarray(lights, dtype=np.float32)).reshape(-1, 25, 3).to(self.T.device)
-        return ops.relight(self.T, L, self.H, self.W)
+        out = ops.relight(self.T, L, self.H, self.W)
+        if self.bg is not None:
+            mask, basis = self.bg
+            bg = torch.einsum("pk,fkc->fpc", basis, L).reshape(-1, self.H, self.W, 3)
+            out = torch.where(mask[None, :, :, None], bg, out)
+        return out
+
+
+def _mesh_mask(scene_dir: str) -> Optional[torch.Tensor]:
+    p = os.path.join(scene_dir, "mesh_mask.png")
+    if not os.path.exists(p):
+        return None
+    from PIL import Image
+
+    mk = np.asarray(Image.open(p))
+    return torch.from_numpy(np.ascontiguousarray((mk[..., 0] if mk.ndim == 3 else mk) > 0))
 
 
 def _scene_normal(scene_dir: str, mat: Dict[str, torch.Tensor], save_name: str, device) -> torch.Tensor:
@@ -141,7 +164,7 @@ def render_real(save_name: str, env_path: Optional[str] = None, input_path: Opti
     env_path = find_envmap(save_name, env_path, input_path)
     mat = load_estimated_brdf(os.path.join(scene_dir, "best_results"), device)
     edit_flag = apply_edit(mat, edit)
-    rl = Relighter(mat, _scene_normal(scene_dir, mat, save_name, device), spp)
+    rl = Relighter(mat, _scene_normal(scene_dir, mat, save_name, device), spp, mesh_mask=_mesh_mask(scene_dir))
     img = rl.frames(envmap_to_light(load_image(env_path))[None])[0]
     env_id = os.path.basename(env_path)[:-4]
     out_dir = os.path.join(save_path if save_path else OUT_DIR, save_name)
@@ -167,7 +190,7 @@ def render_rolling_envmap(save_name: str, env_path: Optional[str], frames: int =
         lights.append(_sh.rotate_y_matrix(2 * np.pi * shift / We) @ light0)
     mat = load_estimated_brdf(os.path.join(scene_dir, "best_results"), device)
     apply_edit(mat, edit)
-    rl = Relighter(mat, _scene_normal(scene_dir, mat, save_name, device), spp)
+    rl = Relighter(mat, _scene_normal(scene_dir, mat, save_name, device), spp, mesh_mask=_mesh_mask(scene_dir))
     out_dir = os.path.join(save_path if save_path else OUT_DIR, save_name)
     anim_dir = os.path.join(out_dir, "rolling_envmap_animation")
     os.makedirs(anim_dir, exist_ok=True)

@@ -97,6 +97,30 @@ class Scene:
         self.light[..., 0, :] = float(np.sqrt(4 * np.pi))  # unit white radiance until the caller sets emitter.data
         self.emitter_data = self.light
         self._ws = {"ws": None}
+        self.bg_mask: Optional[torch.Tensor] = None      # [H,W] bool: pixels without geometry (mesh_mask.png)
+        self.bg_basis: Optional[torch.Tensor] = None     # [H*W,25]: Y_k(camera ray) on those pixels, 0 elsewhere
+
+    # -- pixels without geometry ---------------------------------------------------------------------
+    def set_mesh_mask(self, mask: Optional[torch.Tensor]) -> None:
+        """`mesh_mask.png` (inverse_img_w_mi.py:713-724: `depth[mesh_mask] = 0`, no triangles there): the camera ray of such a
+        pixel leaves the scene and sees the environment emitter.  With SH lighting that radiance is sum_k light[k] Y_k(ray), linear
+        in the light: the render composes it over the shaded image with `torch.where`, so the light receives its gradient from
+        these pixels and the materials none.  Supported for single images on the operator face (`render_envmap`/`render_w_brdf`);
+        the fused C-ABI loops do not know about it and the drivers route such scenes through the operator face."""
+        if mask is None or not bool(mask.any()):
+            self.bg_mask = self.bg_basis = None
+            return
+        if self.B > 1:
+            raise NotImplementedError("mesh masks are supported for single-image scenes")
+        mask = mask.to(self.device).bool().reshape(self.H, self.W)
+        f = (self.W / 2.0) / np.tan(np.radians(self.fov) / 2.0)       # pinhole of the kernels (SURVEY App. E)
+        cx, cy = (self.W - 1) / 2.0, (self.H - 1) / 2.0
+        i, j = np.meshgrid(np.arange(self.H, dtype=np.float64), np.arange(self.W, dtype=np.float64), indexing="ij")
+        ray = np.stack([(j - cx) / f, -(i - cy) / f, -np.ones_like(i)], -1)
+        ray /= np.linalg.norm(ray, axis=-1, keepdims=True)
+        Y = _sh.sh_basis(ray).reshape(self.H * self.W, _sh.NSH) * mask.cpu().numpy().reshape(-1, 1)
+        self.bg_mask = mask
+        self.bg_basis = torch.from_numpy(Y).to(self.device, torch.float32)
 
     # -- mi.traverse face ----------------------------------------------------------------------------
     def _get(self, key):
@@ -141,7 +165,11 @@ class Scene:
             light = light.unsqueeze(0).expand(self.B, -1, -1)
         r = self.r.reshape(shp + (1,))
         m = self.m.reshape(shp + (1,))
-        return _ShadeFn.apply(self.a, r, m, self.shading_normal(), light, int(spp), self.fov, self._ws)
+        img = _ShadeFn.apply(self.a, r, m, self.shading_normal(), light, int(spp), self.fov, self._ws)
+        if self.bg_mask is not None:
+            bg = (self.bg_basis @ light).reshape(self.H, self.W, 3)
+            img = torch.where(self.bg_mask.unsqueeze(-1), bg, img)
+        return img
 
 
 def traverse(scene: Scene) -> SceneParameters:
@@ -149,7 +177,7 @@ def traverse(scene: Scene) -> SceneParameters:
 
 
 def load_estimated_mesh(depth: Optional[torch.Tensor], use_mesh_normal: bool, max_path: int = 4, height: int = 512, width: int = 512,
-                        device="cuda", fov_x_deg: float = DEFAULT_FOV, batch: int = 1) -> Scene:
+                        device="cuda", fov_x_deg: float = DEFAULT_FOV, batch: int = 1, mesh_mask: Optional[torch.Tensor] = None) -> Scene:
     """Counterpart of load_estimated_mesh(mesh_path, use_mesh_normal, max_path) (inverse_img_w_mi.py:30-56).
     The reference loads a .ply triangulated from depth; the per-pixel build needs only the geometric normal
     of the heightfield, computed on the GPU from `depth` [H,W] (or [B,H,W]).  `max_path` is accepted for
@@ -161,7 +189,10 @@ def load_estimated_mesh(depth: Optional[torch.Tensor], use_mesh_normal: bool, ma
         height, width = depth.shape[-2], depth.shape[-1]
         batch = depth.shape[0] if depth.ndim == 3 else 1
         geo = ops.normals_from_depth(depth.contiguous(), fov_x_deg)
-    return Scene(height, width, device, geo, use_mesh_normal, fov_x_deg, batch)
+    scene = Scene(height, width, device, geo, use_mesh_normal, fov_x_deg, batch)
+    if mesh_mask is not None:
+        scene.set_mesh_mask(mesh_mask)
+    return scene
 
 
 def render_envmap(scene: Scene, envmap: torch.Tensor, spp: int = 64) -> torch.Tensor:

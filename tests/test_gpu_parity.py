@@ -589,6 +589,62 @@ def test_use_mask_keeps_roughness_and_metallic_uniform_inside_the_mask(tmp_path,
         assert outside.max() - outside.min() > 1e-4 or name == "metallic"      # the flat prior's metallic starts uniform
 
 
+def test_mesh_mask_pixels_show_the_environment_and_feed_the_light(tmp_path):
+    """mesh_mask.png (inverse_img_w_mi.py:713-724): pixels without geometry see the emitter along the camera ray; linear in the
+    light, no material gradient; the drivers route such scenes through the operator face in both model modes."""
+    from PIL import Image
+
+    from materialist_amd import ops, pipeline, render, sh, synthetic
+
+    dev = _cuda()
+    H, W, spp = 40, 56, 8
+    sc = synthetic.make_scene(12, H, W)
+    mask = torch.zeros(H, W, dtype=torch.bool)
+    mask[:11] = True
+    mask[20:24, 30:40] = True
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True, mesh_mask=mask)
+    plain = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    a = _t(sc.albedo, dev).requires_grad_(True)
+    light = _t(sc.light, dev).requires_grad_(True)
+    for s_ in (scene, plain):
+        s_._set("emitter.data", light)
+    img = render.render_w_brdf(scene, a, _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
+    ref = render.render_w_brdf(plain, a.detach(), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
+    m = mask.to(dev)
+    assert torch.equal(img[~m], ref[~m])
+    # camera rays of the masked pixels, the pinhole of the kernels (wo = -ray)
+    f = (W / 2.0) / np.tan(np.radians(35.0) / 2.0)
+    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    ray = np.stack([(jj - (W - 1) / 2) / f, -(ii - (H - 1) / 2) / f, -np.ones_like(ii, dtype=np.float64)], -1)
+    ray /= np.linalg.norm(ray, axis=-1, keepdims=True)
+    expect = sh.sh_basis(ray[mask.numpy()]) @ sc.light.astype(np.float64)
+    assert np.abs(img[m].detach().cpu().numpy() - expect).max() < 1e-5
+    via_kernel = ops.sh_eval(_t(ray[mask.numpy()], dev), light.detach())
+    assert (via_kernel - img[m].detach()).abs().max().item() < 1e-5
+    img.sum().backward()
+    assert float(a.grad[m].abs().max()) == 0.0 and float(a.grad[~m].abs().max()) > 0
+    # forward-only relighting shows the same background
+    from materialist_amd.relight import Relighter
+
+    rl = Relighter({"albedo": a.detach(), "roughness": _t(sc.roughness, dev), "metallic": _t(sc.metallic, dev)}, scene.geo_normal, spp, mesh_mask=mask)
+    fr = rl.frames(sc.light[None])[0]
+    assert (fr - img.detach()).abs().max().item() <= 2e-5 * float(img.detach().abs().max())
+    # drivers: a run with mesh_mask.png in the output directory, both model modes
+    rng = np.random.default_rng(5)
+    src = str(tmp_path / "in.png")
+    Image.fromarray((rng.random((32, 32, 3)) * 255).astype(np.uint8)).save(src)
+    for model_name in ("none", "pos_mlp"):
+        os.makedirs(tmp_path / model_name, exist_ok=True)
+        mk = np.zeros((32, 32), np.uint8)
+        mk[:9] = 255
+        Image.fromarray(mk).save(str(tmp_path / model_name / "mesh_mask.png"))
+        lines = []
+        res = pipeline.inverse_image(src, model_name, opt_src="arm", opt_order=["rm", "a"], opt_env_from=0, save_path=str(tmp_path), size=32,
+                                     spp=8, num_epochs=5, sync_every=5, log=lines.append, model_name=model_name)
+        assert any("see the environment directly" in ln for ln in lines)
+        assert np.isfinite(res["psnr"]) and os.path.exists(os.path.join(res["output_dir"], "best_results", "envmap.hdr"))
+
+
 def test_pos_mlp_with_predicted_normals_runs_and_improves(tmp_path):
     """'n' in --opt_order under --model_name pos_mlp: output_type 'armn' (inverse_img_w_mi.py:165-172,493-506), the MLP predicts the
     normal map too; the loop must lower the loss and write best_results/normal.exr with unit normals."""
