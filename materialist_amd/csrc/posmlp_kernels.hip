@@ -23,8 +23,6 @@
 // 375; the sin/cos epilogue adds 35 us although it rides inside the next tile's MFMA stream.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "../../include/matpbr.h"
@@ -746,8 +744,7 @@ __global__ __launch_bounds__(256) void mlp_mul_kernel(const float* __restrict__ 
 inline unsigned nt_grid(long M, int N) {
   const long rt = (M + kBM - 1) / kBM;
   const long items = N > kBN ? ((rt + 7) / 8) * 16 : rt;
-  static const long cap = getenv("MATPBR_MLP_GRID") ? atol(getenv("MATPBR_MLP_GRID")) : kPersistent;   // tuning knob (multiple of 16)
-  return (unsigned)(items < cap ? items : cap);
+  return (unsigned)(items < kPersistent ? items : kPersistent);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -760,10 +757,9 @@ int launch_nt(NtArgs p, long M, hipStream_t stream) {
   const bool pipe = p.K > 224 && p.ldo >= halves * kBN && p.lda >= 256 && p.ldb >= 256 && M >= kBM;
   int groups = 0;
   long done = 0;
-  // bit EPI set: 256-wide outputs go to the full-width kernel (measured at M = 512x512: forward 371 vs 416 us, dL/d input 349 vs
-  // 356 us, whole pos_mlp iteration 3.86 vs 4.04 ms); the pipelined kernel keeps the layers of at most 128 outputs
-  static const int wide_mask = getenv("MATPBR_MLP_WIDE") ? atoi(getenv("MATPBR_MLP_WIDE")) : 7;
-  if (pipe && halves == 2 && ((wide_mask >> EPI) & 1)) {
+  // 256-wide outputs go to the full-width kernel (measured at M = 512x512: forward 371 vs 416 us, dL/d input 349 vs 356 us, whole
+  // pos_mlp iteration 3.86 vs 4.04 ms); the pipelined kernel keeps the layers of at most 128 outputs
+  if (pipe && halves == 2) {
     done = M / kBM * kBM;
     p.M = (int)done;
     const long rt = done / kBM;
