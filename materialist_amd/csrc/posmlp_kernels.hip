@@ -10,17 +10,23 @@
 //   mlp_wgrad_tn              dW partials = G^T X over a slab of rows; mlp_wgrad_reduce adds the slabs (fixed order)
 //
 // All matrices are row-major fp32 with a leading dimension that is a multiple of 4 floats (activations: 256, padded).
-// Tiling of the NT products: a 256-thread workgroup owns 128 rows x 128 columns (2x2 waves of 64x64 = 2x2 MFMA tiles, 64
-// accumulator registers), two workgroups per CU, persistent over (row tile, column half) work items; K <= 256 in k-tiles of 32
-// through double-buffered LDS (one barrier per k-tile), global -> registers -> LDS with the fetch one k-tile ahead.  A 32x32x2 MFMA
-// takes one f32 per lane for A and one for B (lane l: A[row l&31][k l>>5], B[k l>>5][col l&31]).
+// A 32x32x2 MFMA takes one f32 per lane for A and one for B (lane l: A[row l&31][k l>>5], B[k l>>5][col l&31]); K <= 256 runs in
+// k-tiles of 32 through LDS, global -> registers -> LDS with the fetch one k-tile ahead.  Three kernels implement the NT product:
+//   mlp_gemm_nt_wide   128 rows x 256 columns per 256-thread workgroup (2x2 waves of 64x128), 2 per CU: the 256-wide layers
+//   mlp_gemm_nt_pipe   128 x 128 tiles, double-buffered LDS, the previous tile's epilogue interleaved: layers of <= 128 outputs
+//   mlp_gemm_nt        any shape, ragged rows
 // Measured at M = 512x512 (tools/mlp_bench.py): forward layer 371 us (BLAS product + sin pass: 424), dL/d input 349 us (BLAS + the
 // d_y cos(pre) pass + the bias-gradient pass: 555), weight gradient 303 + 21 us (split-K BLAS: 308); the MFMA pipe is busy
-// 57-77 % of the time.  Three kernels implement the NT product: mlp_gemm_nt_wide (128x256 tile, the default for 256-wide layers),
-// mlp_gemm_nt_pipe (128x128 tiles with the previous tile's epilogue interleaved; layers of <= 128 outputs) and mlp_gemm_nt (any
-// shape, ragged rows).  Ablation of the forward kernel (bias epilogue): MFMA + LDS reads + barriers + stores alone 298 us (the
-// floor of 8.4 M MFMAs x 64 cycles on 1024 SIMDs is 238 us at 2.2 GHz), + LDS writes 319, + weight fetch 327, + activation fetch
-// 375; the sin/cos epilogue adds 35 us although it rides inside the next tile's MFMA stream.
+// 57-77 % of the time (the floor of 8.4 M MFMAs x 64 cycles on 1024 SIMDs is 238 us at 2.2 GHz).
+// What was tried on top of mlp_gemm_nt_wide and did not pay (bias-only epilogue, 347 us): cycle stamps give 470 (fetch issue) + 8280
+// (128 MFMAs) + 1250 (mask + 12 ds_write_b128) + 180 (two barriers) cycles per k-tile for a workgroup alone on its CU, and two
+// co-resident workgroups run in lock-step (both multiplying at half rate, then both stashing), so the pair is no faster than one.
+// Offsetting half of the workgroups with s_sleep, s_setprio by block index or by hardware wave slot: no change.  One 512-thread
+// workgroup per CU with both k-tile buffers in LDS (stash and fetch free of barriers against the products): 366 us.  Writing 1/16 of
+// the outputs: 310 us, i.e. the 4-byte stores of the MFMA register layout cost 37 us per output matrix (wider stores through an LDS
+// transpose are the next thing to try) and the k-loop itself sits at the 303 us of mlp_wgrad_tn.  Ablation of mlp_gemm_nt_pipe
+// (bias epilogue): MFMA + LDS reads + barriers + stores 298 us, + LDS writes 319, + weight fetch 327, + activation fetch 375; its
+// sin/cos epilogue adds 35 us although it rides inside the next tile's MFMA stream.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
