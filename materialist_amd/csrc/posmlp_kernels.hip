@@ -15,7 +15,7 @@
 //   mlp_gemm_nt_wide   128 rows x 256 columns per 256-thread workgroup (2x2 waves of 64x128), 2 per CU: the 256-wide layers
 //   mlp_gemm_nt_pipe   128 x 128 tiles, double-buffered LDS, the previous tile's epilogue interleaved: layers of <= 128 outputs
 //   mlp_gemm_nt        any shape, ragged rows
-// Measured at M = 512x512 (tools/mlp_bench.py): forward layer 371 us (BLAS product + sin pass: 424), dL/d input 349 us (BLAS + the
+// Measured at M = 512x512 (tools/mlp_bench.py): forward layer 369 us (BLAS product + sin pass: 424), dL/d input 327 us (BLAS + the
 // d_y cos(pre) pass + the bias-gradient pass: 555), weight gradient 303 + 21 us (split-K BLAS: 308); the MFMA pipe is busy
 // 57-77 % of the time (the floor of 8.4 M MFMAs x 64 cycles on 1024 SIMDs is 238 us at 2.2 GHz).
 // What was tried on top of mlp_gemm_nt_wide and did not pay (bias-only epilogue, 347 us): cycle stamps give 470 (fetch issue) + 8280
@@ -23,8 +23,9 @@
 // co-resident workgroups run in lock-step (both multiplying at half rate, then both stashing), so the pair is no faster than one.
 // Offsetting half of the workgroups with s_sleep, s_setprio by block index or by hardware wave slot: no change.  One 512-thread
 // workgroup per CU with both k-tile buffers in LDS (stash and fetch free of barriers against the products): 366 us.  Writing 1/16 of
-// the outputs: 310 us, i.e. the 4-byte stores of the MFMA register layout cost 37 us per output matrix (wider stores through an LDS
-// transpose are the next thing to try) and the k-loop itself sits at the 303 us of mlp_wgrad_tn.  Ablation of mlp_gemm_nt_pipe
+// the outputs: 310 us, i.e. the 4-byte stores of the MFMA register layout cost 37 us per output matrix, and the k-loop itself sits
+// at the 303 us of mlp_wgrad_tn.  The epilogue now goes through a per-wave LDS transpose (16-byte stores and 16-byte loads of the cos
+// factors): dL/d input 349 -> 327 us, the forward unchanged (371 -> 369 us).  Ablation of mlp_gemm_nt_pipe
 // (bias epilogue): MFMA + LDS reads + barriers + stores 298 us, + LDS writes 319, + weight fetch 327, + activation fetch 375; its
 // sin/cos epilogue adds 35 us although it rides inside the next tile's MFMA stream.
 #include <hip/hip_runtime.h>
@@ -460,6 +461,7 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_nt_wide(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float sA[kBM * kLd];
   __shared__ __attribute__((aligned(16))) float sB[256 * kLd];
+  __shared__ __attribute__((aligned(16))) float sScr[4 * 32 * kLd];   // per-wave transpose scratch of the epilogue
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -486,13 +488,13 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt_wide(NtArgs p) {
     b_lane[q] = (b_keep[q] ? n : p.N - 1) * p.ldb + ck;
   }
   const int st_lane = crow * kLd + ck;
-  int o_lane[4];
-  float bn[4], csum[4] = {0.f, 0.f, 0.f, 0.f};
+  float bn[4];
+  float4 csum4[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int n = wn * 128 + ni * 32 + li;
-    o_lane[ni] = (wm * 64 + 4 * lh) * p.ldo + n;
     bn[ni] = (EPI != EPI_MULC) ? p.bias[n < p.N ? n : p.N - 1] : 0.f;
+    csum4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   float4 ra[4], rb[8];
@@ -552,52 +554,74 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt_wide(NtArgs p) {
       stash_all(slot(rn, kn));
       __syncthreads();
     }
-    // epilogue; for the cos factors: all 32 loads of a column tile pair before its stores (in-order load/store counter)
+    // Epilogue through a per-wave LDS transpose.  The MFMA layout gives a lane one column and 16 scattered rows of a 32x32 tile:
+    // stored as is, that is 16 four-byte store instructions per tile and output (the epilogue was store-issue-bound: 37 us per
+    // output matrix).  Each tile goes to a [32][36] scratch image instead (conflict-free both ways) and comes back as 4 float4
+    // per lane along the rows: 16-byte stores, 16-byte loads of the cos factors, a quarter of the memory instructions.
+    // For the cos factors: the loads of a column-tile pair are all issued before its stores (in-order load/store counter).
+    float* scr = sScr + wave * (32 * kLd);
+    const int t_row = lane >> 3, t_col = (lane & 7) * 4;              // float4 position in the transposed image: rows t_row + 8 pass
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      float* base0 = p.out0 + (size_t)(row0 + mi * 32) * p.ldo;
-      float* base1 = (EPI == EPI_SINCOS) ? p.out1 + (size_t)(row0 + mi * 32) * p.ldo : nullptr;
-      const float* basec = (EPI == EPI_MULC) ? p.cmul + (size_t)(row0 + mi * 32) * p.ldo : nullptr;
+      const size_t tile_row = (size_t)(row0 + wm * 64 + mi * 32 + t_row) * p.ldo;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
-        float cv[2][16];
+        float4 cv[2][4];
         if (EPI == EPI_MULC) {
 #pragma unroll
           for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cv[n2][r] = basec[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo + o_lane[nh * 2 + n2]];
+            for (int ps = 0; ps < 4; ++ps)
+              cv[n2][ps] = *reinterpret_cast<const float4*>(p.cmul + tile_row + (size_t)(8 * ps) * p.ldo + wn * 128 + (nh * 2 + n2) * 32 + t_col);
         }
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
           const int ni = nh * 2 + n2;
+          const size_t o0 = tile_row + wn * 128 + ni * 32 + t_col;
+          float second[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const size_t o = (size_t)((r & 3) + 8 * (r >> 2)) * p.ldo + o_lane[ni];
-            const float v = acc[mi][ni][r];
+            float v = acc[mi][ni][r];
             if (EPI == EPI_SINCOS) {
-              float sv, cs;
-              sincos_cw(v + bn[ni], sv, cs);
-              base0[o] = sv;
-              base1[o] = cs;
+              sincos_cw(v + bn[ni], v, second[r]);
             } else if (EPI == EPI_BIAS) {
-              base0[o] = v + bn[ni];
-            } else {
-              const float g = v * cv[n2][r];
-              base0[o] = g;
-              csum[ni] += g;
+              v += bn[ni];
             }
+            scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
+          }
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+            if (EPI == EPI_MULC) {
+              v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
+              csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
+            }
+            *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+          }
+          if (EPI == EPI_SINCOS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+              *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
           }
         }
       }
     }
   }
   if (EPI == EPI_MULC && p.colsum != nullptr) {
-    float* red = sB;   // [4][256]: slot = wm*2 + lh
+    // a lane holds 4 columns x (its 8 row slots of every tile): 8 lanes per column group x 2 row-waves -> LDS, fixed-order sum
+    float* red = sB;   // [16][256]: slot = wm*8 + t_row
     __syncthreads();
+    const int t_row = lane >> 3, t_col = (lane & 7) * 4;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) red[(wm * 2 + lh) * 256 + wn * 128 + ni * 32 + li] = csum[ni];
+    for (int ni = 0; ni < 4; ++ni)
+      *reinterpret_cast<float4*>(red + (wm * 8 + t_row) * 256 + wn * 128 + ni * 32 + t_col) = csum4[ni];
     __syncthreads();
-    p.colsum[(size_t)blockIdx.x * 256 + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) t += red[sl * 256 + tid];
+    p.colsum[(size_t)blockIdx.x * 256 + tid] = t;
   }
 }
 
