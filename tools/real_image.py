@@ -37,6 +37,58 @@ def unpack_fixture(dst: str):
     return z
 
 
+def unpack_jinjya(dst: str, out_dir: str):
+    """The outdoor sample (tests/golden/jinjya256.npz, 256x256): linear photograph, predictions, and the sky mask, which goes
+    where the reference keeps it: <output dir>/mesh_mask.png (inverse_img_w_mi.py:713-724)."""
+    from PIL import Image
+
+    from materialist_amd.imageio_exr import write_exr
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "jinjya256.npz"))
+    os.makedirs(dst, exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
+    write_exr(os.path.join(dst, "jinjya.exr"), z["gt_linear_f16"].astype(np.float32))
+    write_exr(os.path.join(dst, "albedoPred.exr"), z["albedo_pred_f16"].astype(np.float32))
+    H, W = z["depth_pred_f32"].shape
+    up = np.zeros((H, W, 3), np.float32)
+    up[..., 2] = 1
+    write_exr(os.path.join(dst, "normalPred.exr"), up)
+    Image.fromarray(z["roughness_pred_u8"]).save(os.path.join(dst, "roughnessPred.png"))
+    Image.fromarray(z["metallic_pred_u8"]).save(os.path.join(dst, "metallicPred.png"))
+    write_exr(os.path.join(dst, "depthPred.exr"), z["depth_pred_f32"])
+    Image.fromarray((z["mesh_mask"] * 255).astype(np.uint8)).save(os.path.join(out_dir, "mesh_mask.png"))
+    return z
+
+
+def run_jinjya(args):
+    """`--model_name none --opt_order rm a --opt_env_from 2 --opt_src a` (the reference's config.json for this sample)."""
+    import torch
+
+    from materialist_amd.pipeline import inverse_image
+
+    args.out = os.path.abspath(args.out)
+    tmp = tempfile.mkdtemp(prefix="jinjya_")
+    z = unpack_jinjya(tmp, os.path.join(args.out, "jinjya"))
+    gt = z["gt_linear_f16"].astype(np.float32)
+    lines = []
+    t0 = time.time()
+    res = inverse_image(os.path.join(tmp, "jinjya.exr"), "jinjya", opt_src="a", opt_order=args.opt_order, opt_env_from=args.opt_env_from,
+                        save_path=args.out, model_name=args.model_name, size=256, spp=64, num_epochs=args.num_epochs, pred_dir=tmp,
+                        log=lambda s: lines.append(s))
+    torch.cuda.synchronize()
+    mine = res["final_render"].detach().cpu().numpy()
+    ref = z["ref_render_f16"].astype(np.float32)
+    sky = z["mesh_mask"]
+    return {"config": f"jinjya 256x256 (sky mask {sky.mean():.0%}), --model_name {args.model_name} --opt_order {' '.join(args.opt_order)} "
+                      f"--opt_env_from {args.opt_env_from} --opt_src a, spp 64",
+            "wall_s": round(time.time() - t0, 2),
+            "psnr_vs_photo": {"this_build_final_render": round(psnr(mine * (gt.mean() / mine.mean()), gt), 2),
+                              "this_build_ground_only": round(psnr((mine * (gt.mean() / mine.mean()))[~sky], gt[~sky]), 2),
+                              "this_build_sky_only": round(psnr((mine * (gt.mean() / mine.mean()))[sky], gt[sky]), 2),
+                              "reference_shipped_render": round(psnr(ref * (gt.mean() / ref.mean()), gt), 2)},
+            "log": lines}
+
+
 def psnr(a, b):
     g = lambda x: np.clip(x, 0, 1) ** (1 / 2.2)
     return float(-10 * np.log10(np.mean((g(a) - g(b)) ** 2)))
@@ -44,6 +96,9 @@ def psnr(a, b):
 
 def run(args):
     import torch
+
+    if args.model_name is None:
+        args.model_name = "pos_mlp"
 
     from materialist_amd import loss as _loss
     from materialist_amd.pipeline import inverse_image
@@ -81,7 +136,8 @@ def run(args):
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model_name", default="pos_mlp")
+    ap.add_argument("--sample", default="indoor2", choices=["indoor2", "jinjya"])
+    ap.add_argument("--model_name", default=None, help="default: pos_mlp for indoor2, none for jinjya (the reference's own configs)")
     ap.add_argument("--opt_order", nargs="+", default=["rm", "a"])
     ap.add_argument("--opt_env_from", type=int, default=2)
     ap.add_argument("--num_epochs", type=int, default=5000)
@@ -91,10 +147,13 @@ def parse(argv=None):
 
 def main():
     args = parse()
-    out = run(args)
+    args.out = os.path.abspath(args.out)        # a relative --save_path would land under output_imgs/ (inverse_img_w_mi.py:82-104)
+    if args.model_name is None:
+        args.model_name = "pos_mlp" if args.sample == "indoor2" else "none"
+    out = run(args) if args.sample == "indoor2" else run_jinjya(args)
     print(json.dumps(out, indent=1))
     os.makedirs(args.out, exist_ok=True)
-    with open(os.path.join(args.out, f"real_image_{args.model_name}.json"), "w") as fh:
+    with open(os.path.join(args.out, f"real_image_{args.model_name}.json" if args.sample == "indoor2" else f"real_image_jinjya_{args.model_name}.json"), "w") as fh:
         json.dump(out, fh, indent=1)
 
 
