@@ -193,7 +193,7 @@ class _PosMlpHipFn(torch.autograd.Function):
         g, n_red = _pad_cols(g, _ceil4(n_out)), n_out
         for l in range(L - 1, 0, -1):                  # g = dL/d pre of layer l  ->  dL/d pre of layer l-1, its bias gradient
             n_prev = weights[l - 1].shape[0]
-            wt = _pad_cols(weights[l][:, :n_prev].t(), _ceil4(n_red))
+            wt = _pad_cols(weights[l][:, :n_prev].t(), 256 if n_red > 224 else _ceil4(n_red))   # 256-wide rows: the fast kernels' precondition
             g_prev = torch.empty_like(coss[l - 1])
             d_b = torch.empty(n_prev, dtype=torch.float32, device=g.device)
             ops.mlp_layer_bwd_input(g, wt, coss[l - 1], g_prev, n_prev, n_red, d_b)
