@@ -794,10 +794,12 @@ def test_real_image_run_lands_where_the_reference_run_did(tmp_path):
 
 
 @pytest.mark.parametrize("M,hidden,skip,d0,n_out", [(4096, (256, 256, 256, 256), (1, 3), 15, 5), (1000, (64, 128, 64), (2,), 12, 3),
-                                                   (2 * 128 + 7, (256, 256), (), 10, 8)])
+                                                   (2 * 128 + 7, (256, 256), (), 10, 8), (1024 + 40, (256, 128, 256), (), 12, 4)])
 def test_posmlp_mfma_kernels_match_the_torch_composition(M, hidden, skip, d0, n_out):
     """f2: the hand-written f32-MFMA sine layers (forward with sin/cos epilogue, dL/d input with the cos and bias-gradient
     epilogue, slab-split weight gradient) against the torch/BLAS composition of the same network: outputs and every gradient.
+    The four shapes reach every kernel: full-width (256 outputs), pipelined (128 outputs, K = 256), general (narrow layers, K = 15
+    and K = 5) and the ragged last row tile.
     fp32 both sides; tolerance = accumulated rounding of K <= 256 dot products and M-row reductions."""
     from materialist_amd import posmlp
 
