@@ -201,6 +201,33 @@ def test_shade_bwd_matches_oracle(oracle64, spp):
                 assert g_ is None
 
 
+def test_extreme_materials_and_back_facing_normals(oracle64):
+    """Edge cases the reference's known-answer vectors hold at lane level (App. C: back-facing / zero cases), here at image level:
+    parameter maps on their clamp boundaries (roughness 0.07 / 1, metallic 0 / 1, albedo 0 / 1) and normals over the whole
+    sphere, half of them facing away from the camera (n.wo < 0: NoV clamps to zero, :1391-1397, the lobes are sampled around n all the same)."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    H, W, spp = 36, 44, 16
+    rng = np.random.default_rng(21)
+    sc, _ = _scene_arrays(H, W, image_id=3)
+    a = rng.choice([0.0, 1.0, 0.5], size=(H, W, 3)).astype(np.float32)
+    r = rng.choice([0.07, 1.0, 0.3], size=(H, W, 1)).astype(np.float32)
+    m = rng.choice([0.0, 1.0], size=(H, W, 1)).astype(np.float32)
+    n = rng.normal(size=(H, W, 3))
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    n = n.astype(np.float32)
+    d_out = rng.normal(size=(H, W, 3)).astype(np.float32)
+    ref_f = oracle64.shade_fwd(a, r, m, n, sc.light, spp)
+    ref_b = oracle64.shade_bwd(a, r, m, n, sc.light, d_out, spp)
+    assert ((n * np.array([0, 0, 1.0])).sum(-1) < 0).mean() > 0.3   # (wo is within 18 degrees of +z: these normals face away)
+    args = [_t(x, dev) for x in (a, r, m, n, sc.light)]
+    assert_close(ops.shade_fwd(*args, spp), ref_f, what="fwd, extreme maps")
+    got = ops.shade_bwd(*args, _t(d_out, dev), spp, want_mat=True, want_n=True, want_light=True)
+    for nm, g_, rf in zip(("d_a", "d_r", "d_m", "d_n", "d_light"), got, ref_b):
+        assert_close(g_, rf, rtol=3e-3 if nm in ("d_r", "d_n") else RTOL, what=f"{nm}, extreme maps")
+
+
 def test_non_unit_normal_map_is_normalised(oracle64):
     from materialist_amd import ops
 
