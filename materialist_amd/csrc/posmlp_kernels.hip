@@ -229,43 +229,112 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt(NtArgs p) {
       ncol[ni] = nok[ni] ? n : p.N - 1;
       bn[ni] = (EPI != EPI_MULC) ? p.bias[ncol[ni]] : 0.f;
     }
-    float cv[2][2][16];
-    if (EPI == EPI_MULC) {
+    if (row0 + kBM <= p.M && p.ldo >= col0 + kBN) {
+      // interior tile whose 128 columns all exist (those past N are scratch): the per-wave LDS transpose of mlp_gemm_nt_wide, 16-byte
+      // stores and 16-byte loads of the cos factors.  Both k-tile buffers are idle here (the next tile starts with a barrier).
+      float* scr = sA[0] + wave * (32 * kLd);
+      const int t_row = lane >> 3, t_col = (lane & 7) * 4;
+      float4 cs4[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi) {
+        const size_t tile_row = (size_t)(row0 + wm * 64 + mi * 32 + t_row) * p.ldo;
+        float4 cv4[2][4];
+        if (EPI == EPI_MULC) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+              cv4[ni][ps] = *reinterpret_cast<const float4*>(p.cmul + tile_row + (size_t)(8 * ps) * p.ldo + col0 + wn * 64 + ni * 32 + t_col);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const size_t o0 = tile_row + col0 + wn * 64 + ni * 32 + t_col;
+          float second[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            int m = row0 + wm * 64 + mi * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
-            m = m < p.M ? m : p.M - 1;
-            cv[mi][ni][r] = p.cmul[(size_t)m * p.ldo + ncol[ni]];
+            float v = acc[mi][ni][r];
+            if (EPI == EPI_SINCOS) {
+              sincos_cw(v + bn[ni], v, second[r]);
+            } else if (EPI == EPI_BIAS) {
+              v += bn[ni];
+            }
+            scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
           }
-    }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int mb = row0 + wm * 64 + mi * 32 + 4 * lh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          float v0, v1 = 0.f;
+          for (int ps = 0; ps < 4; ++ps) {
+            float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+            if (EPI == EPI_MULC) {
+              v.x *= cv4[ni][ps].x; v.y *= cv4[ni][ps].y; v.z *= cv4[ni][ps].z; v.w *= cv4[ni][ps].w;
+              cs4[ni].x += v.x; cs4[ni].y += v.y; cs4[ni].z += v.z; cs4[ni].w += v.w;
+            }
+            *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+          }
           if (EPI == EPI_SINCOS) {
-            sincos_cw(acc[mi][ni][r] + bn[ni], v0, v1);
-          } else if (EPI == EPI_BIAS) {
-            v0 = acc[mi][ni][r] + bn[ni];
-          } else {
-            v0 = acc[mi][ni][r] * cv[mi][ni][r];
-          }
-          if (nok[ni] && m < p.M) {
-            const size_t o = (size_t)m * p.ldo + ncol[ni];
-            p.out0[o] = v0;
-            if (EPI == EPI_SINCOS) p.out1[o] = v1;
-            if (EPI == EPI_MULC) csum[ni] += v0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+              *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
           }
         }
       }
+      if (EPI == EPI_MULC) {
+        // fold the transposed column sums (4 columns x 8 row slots per lane) back to the per-column accumulators of the lane layout:
+        // through the same scratch, one row per row slot
+        __syncthreads();
+        float* fold = sB[0];            // [4 waves][8][64]
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) *reinterpret_cast<float4*>(fold + (wave * 8 + t_row) * 64 + ni * 32 + t_col) = cs4[ni];
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          float t = 0.f;
+          if (lh == 0) {
+#pragma unroll
+            for (int rs = 0; rs < 8; ++rs) t += fold[(wave * 8 + rs) * 64 + ni * 32 + li];
+          }
+          csum[ni] += nok[ni] ? t : 0.f;
+        }
+      }
+    } else {
+      float cv[2][2][16];
+      if (EPI == EPI_MULC) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              int m = row0 + wm * 64 + mi * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+              m = m < p.M ? m : p.M - 1;
+              cv[mi][ni][r] = p.cmul[(size_t)m * p.ldo + ncol[ni]];
+            }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int mb = row0 + wm * 64 + mi * 32 + 4 * lh;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            float v0, v1 = 0.f;
+            if (EPI == EPI_SINCOS) {
+              sincos_cw(acc[mi][ni][r] + bn[ni], v0, v1);
+            } else if (EPI == EPI_BIAS) {
+              v0 = acc[mi][ni][r] + bn[ni];
+            } else {
+              v0 = acc[mi][ni][r] * cv[mi][ni][r];
+            }
+            if (nok[ni] && m < p.M) {
+              const size_t o = (size_t)m * p.ldo + ncol[ni];
+              p.out0[o] = v0;
+              if (EPI == EPI_SINCOS) p.out1[o] = v1;
+              if (EPI == EPI_MULC) csum[ni] += v0;
+            }
+          }
+        }
+    }
   }
   if (EPI == EPI_MULC && p.colsum != nullptr) {
     // column sums over every row this workgroup produced (it keeps one column half): 2 lane halves x 2 row-waves -> LDS, fixed order
