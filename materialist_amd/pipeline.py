@@ -4,8 +4,9 @@ writers of optimize_envmap_ARMN :257-303,588-599) on top of `optimize.optimize_e
 The initial maps come from MaterialNet (`matnet_weights` = the reference's `matnet_weights.pth`, which the reference
 downloads from the HF hub, :648-654; there is no network here), or from `pred_dir` (files in the layout the reference
 writes: albedoPred.exr, normalPred.exr, roughnessPred.png, metallicPred.png, depthPred.exr), or, failing both, from a
-flat prior (albedo = the linearised image, roughness 0.5, metallic 0, fronto-parallel plane).  Video
-encoding (env_optimization.mp4 / mat_optimization.mp4) needs an encoder this image does not have; frames are kept.
+flat prior (albedo = the linearised image, roughness 0.5, metallic 0, fronto-parallel plane).  The reference turns the
+collected frames into env_optimization.mp4 / mat_optimization.mp4 (`create_video_from_frames`, :593-599) through OpenCV; no video
+encoder exists in this image, so the same frames become env_optimization.gif / mat_optimization.gif (Pillow), the PNGs are kept.
 """
 from __future__ import annotations
 
@@ -219,6 +220,28 @@ class FrameWriter:
         self.mat_frames.append(path)
 
 
+def create_animation_from_frames(frame_paths: Sequence[str], out_path: str, fps: int = 10, max_frames: int = 80, max_side: int = 768) -> Optional[str]:
+    """Stand-in for create_video_from_frames (inverse_img_w_mi.py:593-599; mp4 through OpenCV there): an animated GIF of at most
+    `max_frames` evenly spaced frames, the long side reduced to `max_side` pixels."""
+    from PIL import Image
+
+    paths = [p for p in frame_paths if os.path.exists(p)]
+    if not paths:
+        return None
+    if len(paths) > max_frames:
+        idx = np.linspace(0, len(paths) - 1, max_frames).round().astype(int)
+        paths = [paths[i] for i in idx]
+    ims = []
+    for p in paths:
+        im = Image.open(p).convert("RGB")
+        k = max_side / max(im.size)
+        if k < 1:
+            im = im.resize((max(1, int(im.size[0] * k)), max(1, int(im.size[1] * k))), Image.BILINEAR)
+        ims.append(im)
+    ims[0].save(out_path, save_all=True, append_images=ims[1:], duration=int(1000 / fps), loop=0)
+    return out_path
+
+
 def save_results(path: str, best: Dict[str, torch.Tensor], normal: torch.Tensor) -> None:
     """SaveBest.save_results (myutils/misc.py:99-111): best_results/{envmap.hdr, albedo/roughness/metallic/rendered_img/normal.exr}."""
     os.makedirs(path, exist_ok=True)
@@ -328,6 +351,8 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
                                         shading_normal=scene.geo_normal if use_mesh_normal else None,
                                         model_name=model_name, use_mask=use_mask and "mask" in mat)
     frames.close()
+    create_animation_from_frames(frames.env_frames, os.path.join(output_dir, "env_optimization.gif"))   # :593-599
+    create_animation_from_frames(frames.mat_frames, os.path.join(output_dir, "mat_optimization.gif"))
     write_hdr(os.path.join(output_dir, "final_envmap.hdr"), res["envmap"].detach().cpu().numpy())   # :297
     res["output_dir"] = output_dir
     return res
