@@ -220,9 +220,10 @@ class FrameWriter:
         self.mat_frames.append(path)
 
 
-def create_animation_from_frames(frame_paths: Sequence[str], out_path: str, fps: int = 10, max_frames: int = 80, max_side: int = 768) -> Optional[str]:
+def create_animation_from_frames(frame_paths: Sequence[str], out_path: str, fps: int = 10, max_frames: int = 40, max_side: int = 480) -> Optional[str]:
     """Stand-in for create_video_from_frames (inverse_img_w_mi.py:593-599; mp4 through OpenCV there): an animated GIF of at most
-    `max_frames` evenly spaced frames, the long side reduced to `max_side` pixels."""
+    `max_frames` evenly spaced frames, the long side reduced to `max_side` pixels (GIF encoding is slow: 80 frames at 768 pixels cost
+    7 s, a third of a whole pos_mlp inversion; these defaults cost about 1.5 s)."""
     from PIL import Image
 
     paths = [p for p in frame_paths if os.path.exists(p)]
