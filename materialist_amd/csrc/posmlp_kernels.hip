@@ -25,7 +25,12 @@
 // workgroup per CU with both k-tile buffers in LDS (stash and fetch free of barriers against the products): 366 us.  Writing 1/16 of
 // the outputs: 310 us, i.e. the 4-byte stores of the MFMA register layout cost 37 us per output matrix, and the k-loop itself sits
 // at the 303 us of mlp_wgrad_tn.  The epilogue now goes through a per-wave LDS transpose (16-byte stores and 16-byte loads of the cos
-// factors): dL/d input 349 -> 327 us, the forward unchanged (371 -> 369 us).  Ablation of mlp_gemm_nt_pipe
+// factors): dL/d input 349 -> 327 us, the forward unchanged (371 -> 369 us).  Also without effect: stripping the k-loop from 350
+// to 110 non-MFMA instructions (no k masks, no modulo, scalar-base addressing), a one-workgroup-per-CU variant with both k-tile
+// buffers in LDS and the staging interleaved with the MFMA groups (9750 instead of 10 200 cycles per k-tile; slower overall),
+// iglp_opt / sched_group_barrier orderings, explicit double-buffered operand fragments (hipcc re-orders them anyway), running the
+// weight gradient on a second stream.  Cycle stamps per workgroup show the two co-resident workgroups entering together and each
+// k-tile step taking 12.5-20.7 thousand cycles while both are active (10.2 thousand alone), epilogues 13-43 thousand (4.2 alone).  Ablation of mlp_gemm_nt_pipe
 // (bias epilogue): MFMA + LDS reads + barriers + stores 298 us, + LDS writes 319, + weight fetch 327, + activation fetch 375; its
 // sin/cos epilogue adds 35 us although it rides inside the next tile's MFMA stream.
 #include <hip/hip_runtime.h>
