@@ -29,7 +29,8 @@
 // to 110 non-MFMA instructions (no k masks, no modulo, scalar-base addressing), a one-workgroup-per-CU variant with both k-tile
 // buffers in LDS and the staging interleaved with the MFMA groups (9750 instead of 10 200 cycles per k-tile; slower overall),
 // iglp_opt / sched_group_barrier orderings, explicit double-buffered operand fragments (hipcc re-orders them anyway), running the
-// weight gradient on a second stream.  Cycle stamps per workgroup show the two co-resident workgroups entering together and each
+// weight gradient on a second stream, and one workgroup per CU with 512 registers, both LDS buffers and the fetch TWO k-tiles ahead
+// (exact vmcnt counts in the loop: 389 us).  Cycle stamps per workgroup show the two co-resident workgroups entering together and each
 // k-tile step taking 12.5-20.7 thousand cycles while both are active (10.2 thousand alone), epilogues 13-43 thousand (4.2 alone).  Ablation of mlp_gemm_nt_pipe
 // (bias epilogue): MFMA + LDS reads + barriers + stores 298 us, + LDS writes 319, + weight fetch 327, + activation fetch 375; its
 // sin/cos epilogue adds 35 us although it rides inside the next tile's MFMA stream.
