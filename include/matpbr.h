@@ -17,7 +17,9 @@
  *     and re-entrant per stream.
  *   - Return value: 0 = MATPBR_OK, negative = error (matpbr_strerror); nothing throws.
  *   - `spp` (even, 2..MATPBR_MAX_SPP) is the reference's samples-per-pixel argument
- *     (inverse_img_w_mi.py:59,69,625): here the size of the deterministic BSDF-sample set.
+ *     (inverse_img_w_mi.py:59,69,625): here it sizes the deterministic quadrature rules of the two BRDF lobes
+ *     (spp = 64 -> 4 x 4 GGX half vectors + 3 x 6 cosine-weighted directions), chosen so that the
+ *     error against the converged integral is below that of spp random BSDF samples.
  */
 #ifndef MATPBR_H
 #define MATPBR_H
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MATPBR_VERSION 100 /* 0.1.0 */
+#define MATPBR_VERSION 200 /* 0.2.0 */
 #define MATPBR_MAX_SPP 128
 #define MATPBR_NSH 25
 
@@ -51,7 +53,9 @@ enum { MATPBR_LIGHT_SH25 = 0 };
 #define MATPBR_PART_M 8u
 /* floats per image in the loss statistics buffer (device memory, caller-owned, persistent across iterations):
  *  0 ratio  1 mse  2 l1  3 l1/mse  4 L1(a)  5 L1(r)  6 L1(m)  7 loss  8 improved(0/1)  9 best_mse (init +inf)
- * 10 early-stopping counter  11 early-stopping best  12 early-stopping has-best  13 stopped(0/1)  14 iterations run
+ * 10 early-stopping counter  11 early-stopping best  12 early-stopping has-best
+ * 13 stopped: 0 running, 1 EarlyStopping fired in the last executed iteration (which still ran to its end, as the reference's loop
+ *    does), 2 stopped before the last enqueued iteration (host test: > 0.5)  14 iterations run
  * 15 sum(gt) over the image (set by the caller; used by matpbr_brdf_phase_step) */
 #define MATPBR_STATS_STRIDE 16
 
@@ -69,10 +73,24 @@ const char* matpbr_strerror(int code);
  *   render_w_brdf(scene, albedo, roughness, metallic, normal, spp)   inverse_img_w_mi.py:69-80
  *   render_envmap(scene, envmap, spp)                                inverse_img_w_mi.py:59-67
  * i.e. mi.render(scene, params, spp) with MatDiffBSDF (myutils/mi_plugin.py:1229-1475) under the
- * build's deterministic definition.  out_rgb[B,H,W,3] = linear radiance. */
+ * build's deterministic definition.  out_rgb[B,H,W,3] = linear radiance.
+ *
+ * matpbr_shade_fwd_ex additionally takes / produces two per-pixel plane buffers ([9][B*H*W] floats, matpbr_plane9_bytes()):
+ *   dcache (nullable, input)  the diffuse-lobe coefficients A0, A1, A2 (rgb each) of matpbr_diffuse_cache(): the diffuse lobe
+ *                             integrates to a(1-m)(A0 + r A1 + r^2 A2) with coefficients that depend on (n, view, light) only, so
+ *                             while light and geometric normals are fixed (a whole BRDF phase, inverse_img_w_mi.py:317-342) the
+ *                             render evaluates the GGX-lobe samples only;
+ *   jac (nullable, output)    P_c, S0_c - S1_c, d out_c / d r: what matpbr_shade_bwd_jac / matpbr_brdf_loss_bwd_jac need to form
+ *                             the material gradients of THIS forward pass without walking any sample again. */
 int matpbr_shade_fwd(const float* a, const float* r, const float* m, const float* n, const float* light,
                      int light_kind, int n_light, float* out_rgb, int H, int W, int batch, int spp,
                      const MatpbrCamera* cam, uint32_t flags, void* stream);
+size_t matpbr_plane9_bytes(int H, int W, int batch);
+int matpbr_shade_fwd_ex(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind,
+                        int n_light, const float* dcache, float* out_rgb, float* jac, int H, int W, int batch, int spp,
+                        const MatpbrCamera* cam, uint32_t flags, void* stream);
+int matpbr_diffuse_cache(const float* n, const float* light, int light_kind, int n_light, float* dcache, int H, int W, int batch,
+                         int spp, const MatpbrCamera* cam, void* stream);
 
 /* Backward render.  Replaces the AD pass that `loss.backward()` drives through dr.wrap_ad / mi.render
  * (inverse_img_w_mi.py:59,69,248,420,544).  Any of d_a/d_r/d_m (all three or none), d_n, d_light may be
@@ -84,31 +102,34 @@ int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float
                      float* d_n, float* d_light, void* workspace, size_t workspace_bytes, int H, int W, int batch,
                      int spp, const MatpbrCamera* cam, uint32_t flags, void* stream);
 size_t matpbr_shade_bwd_workspace_bytes(int H, int W, int batch, int n_light);
+/* The material gradients of a forward pass that wrote `jac`: one streaming pass, no samples (same a, r, m as that pass). */
+int matpbr_shade_bwd_jac(const float* a, const float* r, const float* m, const float* jac, const float* d_out_rgb, float* d_a,
+                         float* d_r, float* d_m, int H, int W, int batch, void* stream);
 
 /* Fused pieces of hot loop B in `--model_name none` mode (inverse_img_w_mi.py:371-432): everything between the two
  * renders of one optimisation iteration, without leaving the GPU.
  *   matpbr_brdf_loss_stats     ratio = mean(gt)/mean(pred); MSE / L1 of (pred*ratio)^(1/2.2) against gt^(1/2.2); L1 of the clamped
  *                              parameter maps against their initial values; loss = 3 (L1/MSE) MSE + L1 + scale_delta * sum(L1 reg)
  *                              (:388-418); SaveBest's strict `<` on the MSE (myutils/misc.py:75) -> stats[B, MATPBR_STATS_STRIDE].
- *   matpbr_shade_bwd_brdf_loss matpbr_shade_bwd with d loss/d pred formed in-kernel from those statistics, the regulariser
+ *   matpbr_brdf_loss_bwd_jac   matpbr_shade_bwd_jac with d loss/d pred formed in-kernel from those statistics, the regulariser
  *                              gradients added, torch.clamp's gradient gating applied, and best_* (nullable) snapshotted when
- *                              stats says the iteration improved.  pa/pr/pm are the raw (unclamped) parameter maps.
+ *                              stats says the iteration improved.  pa/pr/pm are the raw (unclamped) parameter maps that
+ *                              matpbr_shade_fwd_ex rendered with MATPBR_FLAG_CLAMP_PARAMS; `jac` is that render's.
  *   matpbr_adam_step           torch.optim.Adam update of one tensor (:359); `step` is the 1-based iteration count. */
 size_t matpbr_brdf_loss_workspace_bytes(int batch);
 int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr,
                            const float* pm, const float* a0, const float* r0, const float* m0, float scale_delta,
                            float* stats, void* workspace, size_t workspace_bytes, int H, int W, int batch, uint32_t flags,
                            void* stream);   /* flags: MATPBR_PART_* of the maps being optimised (none set = all three) */
-int matpbr_shade_bwd_brdf_loss(const float* pa, const float* pr, const float* pm, const float* n, const float* light,
-                               int light_kind, int n_light, const float* pred, const float* gt_srgb, const float* stats,
-                               const float* a0, const float* r0, const float* m0, float scale_delta, float* d_a, float* d_r,
-                               float* d_m, float* best_a, float* best_r, float* best_m, float* best_img, int H, int W,
-                               int batch, int spp, const MatpbrCamera* cam, uint32_t flags, void* stream);
+int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, const float* jac, const float* pred,
+                             const float* gt_srgb, const float* stats, const float* a0, const float* r0, const float* m0,
+                             float scale_delta, float* d_a, float* d_r, float* d_m, float* best_a, float* best_r, float* best_m,
+                             float* best_img, int H, int W, int batch, uint32_t flags, void* stream);
 int matpbr_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                      int step, void* stream);
 
 /* One whole iteration of hot loop B (`model_name == 'none'`, inverse_img_w_mi.py:371-432) enqueued by a single call:
- * render(clamped params) -> loss statistics + SaveBest / EarlyStopping decisions -> fused loss backward -> Adam.
+ * render(clamped params, + jac) -> loss statistics + SaveBest / EarlyStopping decisions -> streaming loss backward + Adam.
  * All pointers are device memory owned by the caller.  EarlyStopping (myutils/misc.py:37-60, es_patience > 0) runs on the
  * device: once stats[b][13] is set every kernel skips image b, so iterations may be enqueued ahead of the host's polling
  * without changing any decision.  `t` is the 1-based Adam step, `lr` the learning rate of this iteration. */
@@ -117,8 +138,10 @@ typedef struct MatpbrBrdfPhase {
     const float *n, *light;               /* shading-normal map [B,H,W,3], SH25 light [B,25,3] */
     const float *gt_srgb;                 /* target ^ (1/2.2) [B,H,W,3]; sum(gt) per image sits in stats[b][15] */
     const float *a0, *r0, *m0;            /* regulariser anchors = the maps at phase start (:196-201) */
+    const float* dcache;                  /* matpbr_diffuse_cache(n, light) planes; NULL: recomputed inside every render */
     float* pred;                          /* [B,H,W,3] the iteration's render (scratch / output) */
-    float *d_a, *d_r, *d_m;               /* gradients (scratch / output) */
+    float* jac;                           /* matpbr_plane9_bytes() scratch */
+    float *d_a, *d_r, *d_m;               /* gradients (output, nullable: the Adam update happens in the same pass) */
     float *adam_m[3], *adam_v[3];         /* Adam moments of a, r, m (needed for the maps in part_mask) */
     float *best_a, *best_r, *best_m, *best_img; /* SaveBest snapshot targets, nullable */
     float* stats;                         /* [B, MATPBR_STATS_STRIDE] */
@@ -135,15 +158,17 @@ typedef struct MatpbrBrdfPhase {
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);
 
-/* One evaluation of hot loop A (inverse_img_w_mi.py:238-250) for a candidate light: render, loss = MSE + L1 on x^(1/2.2),
- * SaveBest / EarlyStopping decisions in `stats` (same layout; ratio = 1), d loss / d light -> d_light[B,25,3].  The light's own
- * parameterisation (envmap MLP or texels through softplus, then the SH projection) and its optimiser stay with the caller,
- * who back-propagates d_light through them.  `pred` receives the render; `best_img` (nullable) the best-so-far linear render. */
+/* One evaluation of hot loop A (inverse_img_w_mi.py:238-250) for a candidate light.  Materials and normals are fixed during the
+ * phase (:216-220) and the render is linear in the light, so the phase works on the radiance transfer T of
+ * matpbr_shade_transfer() (computed once at phase start): pred = T.light, loss = MSE + L1 on x^(1/2.2), SaveBest / EarlyStopping
+ * decisions in `stats` (same layout; ratio = 1) and d loss / d light = T^T (d loss / d pred) -> d_light[B,25,3] in ONE pass over
+ * T (300 B/pixel, HBM-bound).  The light's own parameterisation (envmap MLP or texels through softplus, then the SH projection)
+ * and its optimiser stay with the caller, who back-propagates d_light through them.  `pred` (nullable) receives the render; the
+ * best-so-far render is matpbr_relight(T, best light). */
 size_t matpbr_env_phase_workspace_bytes(int H, int W, int batch);
-int matpbr_env_phase_step(const float* a, const float* r, const float* m, const float* n, const float* light,
-                          const float* gt_srgb, float* pred, float* d_light, float* stats, float* best_img, float* history,
-                          int hist_len, int es_patience, float es_min_delta, void* workspace, size_t workspace_bytes, int H,
-                          int W, int batch, int spp, const MatpbrCamera* cam, void* stream);
+int matpbr_env_phase_step(const float* T, const float* light, const float* gt_srgb, float* pred, float* d_light, float* stats,
+                          float* history, int hist_len, int es_patience, float es_min_delta, void* workspace,
+                          size_t workspace_bytes, int H, int W, int batch, void* stream);
 
 /* Column sums of a row-major [M, N] fp32 matrix -> out[N]: the bias gradient of the PosMLP layers over M = H*W points
  * (mymodels/mlps.py:102-103 under autograd).  Deterministic two-pass; workspace of matpbr_column_sum_workspace_bytes(N). */
@@ -177,7 +202,7 @@ int matpbr_mlp_mul(const float* a, long lda, const float* b, long ldb, float* ou
 
 /* Forward-only relighting (render_final.py:148-203 `render_w_mi`, :290-418 `rotate_envmap` / `render_rolling_envmap`).
  * The render is linear in the light, R = sum_k light[k] * T[k]:
- *   matpbr_shade_transfer  per-pixel transfer of the current materials into T (matpbr_transfer_bytes(); 300 B/pixel, tiled
+ *   matpbr_shade_transfer  per-pixel transfer (d render / d light, both lobes) of the current materials into T (matpbr_transfer_bytes(); 300 B/pixel, tiled
  *                          [B][ceil(H*W/256)][75][256]: 75 = 25 coefficients x rgb; opaque to the caller), computed once
  *   matpbr_relight         out[F,H,W,3] for F lights [F,25,3] against one image's T (HBM-bound; 8 lights per pass) */
 size_t matpbr_transfer_bytes(int H, int W, int batch);

@@ -17,7 +17,8 @@ class MatpbrCamera(ctypes.Structure):
 
 class MatpbrBrdfPhase(ctypes.Structure):
     """Mirror of `MatpbrBrdfPhase` in include/matpbr.h (field order matters)."""
-    _fields_ = ([(k, ctypes.c_void_p) for k in ("pa", "pr", "pm", "n", "light", "gt_srgb", "a0", "r0", "m0", "pred", "d_a", "d_r", "d_m")] +
+    _fields_ = ([(k, ctypes.c_void_p) for k in ("pa", "pr", "pm", "n", "light", "gt_srgb", "a0", "r0", "m0", "dcache", "pred", "jac", "d_a",
+                                                "d_r", "d_m")] +
                 [("adam_m", ctypes.c_void_p * 3), ("adam_v", ctypes.c_void_p * 3)] +
                 [(k, ctypes.c_void_p) for k in ("best_a", "best_r", "best_m", "best_img", "stats", "history", "workspace")] +
                 [("workspace_bytes", ctypes.c_size_t), ("H", ctypes.c_int), ("W", ctypes.c_int), ("batch", ctypes.c_int), ("spp", ctypes.c_int),
@@ -39,18 +40,22 @@ SIGNATURES = {
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),
                                        ctypes.c_uint32, ctypes.c_void_p]),
     "matpbr_shade_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "matpbr_plane9_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "matpbr_shade_fwd_ex": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.POINTER(MatpbrCamera), ctypes.c_uint32, ctypes.c_void_p]),
+    "matpbr_diffuse_cache": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(MatpbrCamera), ctypes.c_void_p]),
+    "matpbr_shade_bwd_jac": (ctypes.c_int, [_c_f] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_brdf_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_brdf_loss_stats": (ctypes.c_int, [_c_f] * 9 + [ctypes.c_float, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]),
-    "matpbr_shade_bwd_brdf_loss": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float] + [_c_f] * 7 +
-                                   [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera), ctypes.c_uint32,
-                                    ctypes.c_void_p]),
+    "matpbr_brdf_loss_bwd_jac": (ctypes.c_int, [_c_f] * 10 + [ctypes.c_float] + [_c_f] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                                              ctypes.c_uint32, ctypes.c_void_p]),
     "matpbr_brdf_phase_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "matpbr_brdf_phase_step": (ctypes.c_int, [ctypes.POINTER(MatpbrBrdfPhase), ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "matpbr_env_phase_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
-    "matpbr_env_phase_step": (ctypes.c_int, [_c_f] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
-                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),
-                                            ctypes.c_void_p]),
+    "matpbr_env_phase_step": (ctypes.c_int, [_c_f] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_sin_bwd": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_layer_fwd": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_void_p]),

@@ -128,12 +128,16 @@ class BrdfPhase:
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
                  normal: Optional[torch.Tensor] = None, optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4,
-                 scale_delta: float = 0.1, saver: Optional[DeviceSaveBest] = None, mask: Optional[torch.Tensor] = None):
+                 scale_delta: float = 0.1, saver: Optional[DeviceSaveBest] = None, mask: Optional[torch.Tensor] = None,
+                 originals: Optional[Dict[str, torch.Tensor]] = None):
+        """`originals`: the regulariser anchors albedo_ori / roughness_ori / metallic_ori / normal_ori, captured once before the
+        loops (inverse_img_w_mi.py:189-201); default: this phase's start maps."""
         self.scene, self.gt, self.spp, self.scale_delta = scene, gt_image, spp, scale_delta
         self.mask = mask
         self.part = optimize_part
         self.maps = {"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": normal}
-        self.originals = {k: v.detach().clone() for k, v in self.maps.items() if v is not None}
+        self.originals = {k: (originals[k] if originals is not None and k in originals else v).detach().clone()
+                          for k, v in self.maps.items() if v is not None}
         self.gt_srgb = _loss.linear_to_srgb(gt_image)
         keys = {"a": "albedo", "r": "roughness", "m": "metallic", "n": "normal"}
         self.opt_keys = [keys[c] for c in optimize_part if c in keys and not (c == "n" and scene.use_mesh_normal)]
@@ -223,9 +227,11 @@ class EnvHeadPhase:
 
 class FusedBrdfPhase:
     """Hot loop B in `model_name == 'none'` mode (inverse_img_w_mi.py:347-468), one `matpbr_brdf_phase_step` call per
-    iteration: render (clamp folded in), loss statistics, SaveBest and EarlyStopping decisions, fused loss backward
-    with regularisers / clamp gating / best-so-far snapshot, Adam -- all on the device.  Same arithmetic as `BrdfPhase`
-    (which composes the step from torch ops and is its parity reference).
+    iteration: render (clamp folded in; GGX-lobe samples only, the diffuse-lobe coefficients are cached at phase start because
+    light and geometric normals are fixed, :317-342), loss statistics, SaveBest and EarlyStopping decisions, streaming loss
+    backward with regularisers / clamp gating / best-so-far snapshot / Adam -- all on the device.  Same arithmetic as `BrdfPhase`
+    (which composes the step from torch ops and is its parity reference).  `originals` are the regulariser anchors
+    albedo_ori / roughness_ori / metallic_ori (:189-201), captured once before the loops; default: the start maps.
 
     EarlyStopping (`patience` > 0) lives in the statistics buffer: after an image has stopped every kernel skips it, so
     `run(k)` may enqueue k iterations blindly and `poll()` (one host sync) tells how far each image really got."""
@@ -234,7 +240,8 @@ class FusedBrdfPhase:
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
-                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000):
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
+                 originals: Optional[Dict[str, torch.Tensor]] = None, keep_grads: bool = False):
         import ctypes
 
         from . import _lib, ops
@@ -250,8 +257,8 @@ class FusedBrdfPhase:
         self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
         c = lambda t: t.detach().clone().contiguous()
         self.p = {"albedo": c(albedo), "roughness": c(roughness), "metallic": c(metallic)}
-        self.orig = {k: c(v) for k, v in self.p.items()}
-        self.g = {k: torch.empty_like(v) for k, v in self.p.items()}
+        self.orig = {k: c(originals[k] if originals is not None and k in originals else v).reshape(v.shape) for k, v in self.p.items()}
+        self.g = {k: torch.empty_like(v) for k, v in self.p.items()} if keep_grads else None
         self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
         self.best = {k: c(v) for k, v in self.p.items()}
@@ -268,13 +275,17 @@ class FusedBrdfPhase:
         light = scene.light.detach()
         self.light = (light.unsqueeze(0).expand(B, -1, -1) if (B > 1 and light.ndim == 2) else light).contiguous()
         self.base_lr, self.t = float(lr), 0
+        # light and shading normals do not change during the phase: the diffuse lobe reduces to 9 coefficients per pixel
+        self.dcache = ops.diffuse_cache(self.n, self.light, self.spp, scene.fov)
+        self.jac = ops.plane9(self.p["albedo"])
         ph = _lib.MatpbrBrdfPhase()
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         ph.pa, ph.pr, ph.pm = P(self.p["albedo"]), P(self.p["roughness"]), P(self.p["metallic"])
         ph.n, ph.light, ph.gt_srgb = P(self.n), P(self.light), P(self.gt_srgb)
         ph.a0, ph.r0, ph.m0 = P(self.orig["albedo"]), P(self.orig["roughness"]), P(self.orig["metallic"])
-        ph.pred = P(self.pred)
-        ph.d_a, ph.d_r, ph.d_m = P(self.g["albedo"]), P(self.g["roughness"]), P(self.g["metallic"])
+        ph.dcache, ph.pred, ph.jac = P(self.dcache), P(self.pred), P(self.jac)
+        if self.g is not None:
+            ph.d_a, ph.d_r, ph.d_m = P(self.g["albedo"]), P(self.g["roughness"]), P(self.g["metallic"])
         for i, k in enumerate(("albedo", "roughness", "metallic")):
             ph.adam_m[i], ph.adam_v[i] = self.m[k].data_ptr(), self.v[k].data_ptr()
         ph.best_a, ph.best_r, ph.best_m, ph.best_img = P(self.best["albedo"]), P(self.best["roughness"]), P(self.best["metallic"]), P(self.best_img)
@@ -322,18 +333,20 @@ class FusedBrdfPhase:
 
 
 class FusedEnvPhase:
-    """Hot loop A (inverse_img_w_mi.py:236-254) with render, loss statistics, SaveBest / EarlyStopping decisions and the light
-    gradient in one `matpbr_env_phase_step` call.  `head()` produces `emitter.data` ([He,We,3] texels or [25,3] SH
+    """Hot loop A (inverse_img_w_mi.py:236-254).  Materials and normals are fixed while the light is optimised (:216-220) and the
+    render is linear in the light, so the phase computes the per-pixel radiance transfer once (`matpbr_shade_transfer`) and
+    every iteration is one `matpbr_env_phase_step`: render = T.light, loss statistics, SaveBest / EarlyStopping decisions and
+    d loss / d light in a single HBM-bound pass over T.  `head()` produces `emitter.data` ([He,We,3] texels or [25,3] SH
     coefficients) from its own torch parameters (the envmap MLP in the reference, `envmap_net(start_envmap)`, :238-239);
     its backward and the optimiser step stay in torch, fed with d loss / d light from the device."""
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, head, optimizer: torch.optim.Optimizer, spp: int = 64,
                  patience: int = 0, min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
-                 use_graph: bool = False):
-        """`use_graph`: capture one whole iteration (head forward, SH projection, the five kernels of matpbr_env_phase_step,
+                 use_graph: bool = False, keep_pred: bool = True):
+        """`use_graph`: capture one whole iteration (head forward, SH projection, the two kernels of matpbr_env_phase_step,
         head backward, optimiser step) into a hipGraph after three eager iterations and replay it afterwards.  The envmap
-        MLP works on 512 points, so the eager iteration is bound by ~60 kernel launches from Python (1.0 ms for 0.17 ms of GPU
-        work); the optimiser must then be built by `capturable_adam` (tensor learning rate, set with `set_lr`)."""
+        MLP works on 512 points, so the eager iteration is bound by kernel launches from Python; the optimiser must then be
+        built by `capturable_adam` (tensor learning rate, set with `set_lr`)."""
         import ctypes
 
         from . import _lib, ops
@@ -346,8 +359,7 @@ class FusedEnvPhase:
         self.B = self.gt.shape[0] if self.gt.ndim == 4 else 1
         self.H, self.W = self.gt.shape[-3], self.gt.shape[-2]
         self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
-        self.pred = torch.empty_like(self.gt)
-        self.best_img = torch.zeros_like(self.gt)
+        self.pred = torch.empty_like(self.gt) if keep_pred else None
         self.best_env: Optional[torch.Tensor] = None
         self.stats = ops.new_loss_stats(self.B, dev)
         if best_mse is not None:
@@ -357,7 +369,10 @@ class FusedEnvPhase:
         self.hist = torch.zeros((history_len, self.B), dtype=torch.float32, device=dev)
         self.d_light = torch.zeros((self.B, 25, 3) if self.B > 1 else (25, 3), dtype=torch.float32, device=dev)
         self.patience, self.min_delta, self.t = int(patience), float(min_delta), 0
-        self._prev_best = self.stats[:, ops.STAT_BEST].clone()
+        shp = (self.B, self.H, self.W) if self.B > 1 else (self.H, self.W)
+        sc = scene
+        self.T = ops.shade_transfer(sc.a.contiguous(), sc.r.reshape(shp + (1,)).contiguous(), sc.m.reshape(shp + (1,)).contiguous(),
+                                    sc.shading_normal().contiguous(), self.spp, sc.fov)
 
     def step(self) -> None:
         if not self.use_graph:
@@ -386,17 +401,14 @@ class FusedEnvPhase:
         if self.B > 1 and lc.ndim == 2:
             lc = lc.unsqueeze(0).expand(self.B, -1, -1)
         lc = lc.contiguous()
-        shp = (self.B, self.H, self.W) if self.B > 1 else (self.H, self.W)
         P = lambda t: None if t is None else ct.c_void_p(t.data_ptr())
-        cam = self._libmod.MatpbrCamera(sc.fov)
-        a, r, m, n = (t.contiguous() for t in (sc.a, sc.r.reshape(shp + (1,)), sc.m.reshape(shp + (1,)), sc.shading_normal()))
         with torch.cuda.device(self.gt.device), ops._timed("env_phase_step"):
-            code = self.lib.matpbr_env_phase_step(P(a), P(r), P(m), P(n), P(lc), P(self.gt_srgb), P(self.pred), P(self.d_light), P(self.stats),
-                                                  P(self.best_img), P(self.hist), self.hist.shape[0], self.patience, self.min_delta, P(self.ws),
-                                                  self.ws.numel() * 4, self.H, self.W, self.B, self.spp, ct.byref(cam),
-                                                  ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
+            code = self.lib.matpbr_env_phase_step(P(self.T), P(lc), P(self.gt_srgb), P(self.pred), P(self.d_light), P(self.stats), P(self.hist),
+                                                  self.hist.shape[0], self.patience, self.min_delta, P(self.ws), self.ws.numel() * 4, self.H,
+                                                  self.W, self.B, ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
         self._libmod.check(code, "matpbr_env_phase_step")
-        # SaveBest keeps the envmap of the best iteration (:247): device-side select on the improved flag, no host sync
+        # SaveBest keeps the envmap of the best iteration (:247): device-side select on the improved flag, no host sync.  The flag
+        # is cleared for images whose EarlyStopping fired earlier, and their d_light is zero.
         improved = self.stats[:, ops.STAT_IMPROVED] > 0.5
         d = data.detach()
         if self.best_env is None:
@@ -406,9 +418,21 @@ class FusedEnvPhase:
             self.best_env.copy_(torch.where(sel, d, self.best_env))
         g = self.d_light if light.shape == self.d_light.shape else self.d_light.sum(0)
         light.backward(g)
+        # after an image has stopped its d_light is zero and its `improved` flag stays clear, so best_env keeps the light of the
+        # best iteration whatever the optimiser's momentum does to the head until the host polls and leaves the loop
         self.opt.step()
         if not self.use_graph:
             self.opt.zero_grad(set_to_none=True)
+
+    @property
+    def best_img(self) -> torch.Tensor:
+        """Linear render under the best-so-far light (SaveBest.rendered_img of the env phase, :247): T . light(best_env)."""
+        light = self.scene.light_from_emitter(self.best_env).detach()
+        if self.B == 1:
+            return self.ops.relight(self.T, light.reshape(1, 25, 3), self.H, self.W)[0]
+        lights = light if light.ndim == 3 else light.unsqueeze(0).expand(self.B, -1, -1)
+        per = self.T.numel() // self.B
+        return torch.stack([self.ops.relight(self.T[b * per:(b + 1) * per], lights[b:b + 1].contiguous(), self.H, self.W)[0] for b in range(self.B)])
 
     def poll(self) -> Dict[str, torch.Tensor]:
         st, o = self.stats.cpu(), self.ops
@@ -475,6 +499,11 @@ class PosMlpBrdfPhase:
         self.hist = torch.zeros((history_len, 1), dtype=torch.float32, device=dev)
         self.ws = None
         self.t = 0
+        # light and geometric normals are fixed during the phase: cached diffuse-lobe coefficients + jac scratch
+        self._n = scene.shading_normal().contiguous()
+        self._light = scene.light.detach().contiguous()
+        self.dcache = ops.diffuse_cache(self._n, self._light, self.spp, scene.fov)
+        self.jac = ops.plane9(self.gt)
 
     def maps_from_net(self):
         arm = self.net(self.start_arm)                                                   # :493
@@ -494,16 +523,16 @@ class PosMlpBrdfPhase:
         ops, sc = self.ops, self.scene
         maps, live = self.maps_from_net()
         d = {k: v.detach() for k, v in maps.items()}
-        n, light = sc.shading_normal(), sc.light.detach().contiguous()
-        ops.shade_fwd(d["albedo"], d["roughness"], d["metallic"], n, light, self.spp, sc.fov, clamp_params=True, out=self.pred)
+        ops.shade_fwd(d["albedo"], d["roughness"], d["metallic"], self._n, self._light, self.spp, sc.fov, clamp_params=True, out=self.pred,
+                      dcache=self.dcache, jac=self.jac)
         if self.ws is None:
             self.ws = torch.empty(int(_lib_ws(1)) // 4, dtype=torch.float32, device=self.gt.device)
         ops.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
                             self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part)
-        ops.shade_bwd_brdf_loss(d["albedo"], d["roughness"], d["metallic"], n, light, self.pred, self.gt_srgb, self.stats,
-                                self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.spp,
-                                self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
-                                self.best["metallic"], self.best_img, sc.fov, optimize_part=self.part)
+        ops.brdf_loss_bwd_jac(d["albedo"], d["roughness"], d["metallic"], self.jac, self.pred, self.gt_srgb, self.stats,
+                              self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta,
+                              self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
+                              self.best["metallic"], self.best_img, optimize_part=self.part)
         torch.autograd.backward([maps[k] for k in live], [self.g[k] for k in live])      # :544
         improved = self.stats[0, ops.STAT_IMPROVED] > 0.5                                 # SaveBest keeps the weights too (:546-547)
         self._best_flat = torch.where(improved, self._flat, self._best_flat)

@@ -106,8 +106,16 @@ def workspace_for(a: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> 
     return torch.empty((need + 3) // 4, dtype=torch.float32, device=a.device)
 
 
+def plane9(a: torch.Tensor) -> torch.Tensor:
+    """Scratch for the per-pixel plane buffers (diffuse cache / jac) of maps shaped like `a`: [9, B, H, W]."""
+    B, H, W = _bhw(a)
+    return torch.empty((9, B, H, W), dtype=torch.float32, device=a.device)
+
+
 def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0, clamp_params: bool = False,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, dcache: Optional[torch.Tensor] = None, jac: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Render.  `dcache` = diffuse_cache(n, light, spp) skips the diffuse-lobe samples (valid while n and light are unchanged);
+    `jac` ([9,B,H,W], filled) lets shade_bwd_jac / brdf_loss_bwd_jac form the material gradients of this pass."""
     lib = _lib.load()
     a = _dev(a, "albedo", (3,))
     B, H, W = _bhw(a)
@@ -117,14 +125,50 @@ def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0, clamp_params
     light = _dev(light, "light", (NSH, 3))
     if n.numel() != a.numel() or r.numel() * 3 != a.numel() or light.numel() != B * NSH * 3:
         raise ValueError("shade_fwd: inconsistent map / light shapes")
+    for t, k in ((dcache, "dcache"), (jac, "jac")):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != 3 * a.numel()):
+            raise ValueError(f"shade_fwd: {k} must be a contiguous fp32 CUDA tensor of 9*B*H*W floats")
     if out is None:
         out = torch.empty_like(a)
     cam = MatpbrCamera(float(fov_x_deg))
     with torch.cuda.device(a.device), _timed("shade_fwd"):
-        code = lib.matpbr_shade_fwd(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(out), H, W, B,
-                                    check_spp(spp), ctypes.byref(cam), FLAG_CLAMP_PARAMS if clamp_params else 0, _stream(a))
-    _lib.check(code, "matpbr_shade_fwd")
+        code = lib.matpbr_shade_fwd_ex(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(dcache), _ptr(out), _ptr(jac),
+                                       H, W, B, check_spp(spp), ctypes.byref(cam), FLAG_CLAMP_PARAMS if clamp_params else 0, _stream(a))
+    _lib.check(code, "matpbr_shade_fwd_ex")
     return out
+
+
+def diffuse_cache(n, light, spp: int, fov_x_deg: float = 35.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-pixel coefficients of the diffuse lobe, a(1-m)(A0 + r A1 + r^2 A2): [9, B, H, W] planes, constants while the shading
+    normals and the light stay fixed (a whole BRDF phase, inverse_img_w_mi.py:317-342)."""
+    lib = _lib.load()
+    n = _dev(n, "normal", (3,))
+    B, H, W = _bhw(n)
+    light = _dev(light, "light", (NSH, 3))
+    if light.numel() != B * NSH * 3:
+        raise ValueError("diffuse_cache: one [25,3] light per image expected")
+    if out is None:
+        out = plane9(n)
+    cam = MatpbrCamera(float(fov_x_deg))
+    with torch.cuda.device(n.device):
+        code = lib.matpbr_diffuse_cache(_ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(out), H, W, B, check_spp(spp), ctypes.byref(cam), _stream(n))
+    _lib.check(code, "matpbr_diffuse_cache")
+    return out
+
+
+def shade_bwd_jac(a, r, m, jac, d_out):
+    """Material gradients (d_a, d_r, d_m) of the forward pass that filled `jac` (same a, r, m): one streaming pass, no samples."""
+    lib = _lib.load()
+    a = _dev(a, "albedo", (3,))
+    B, H, W = _bhw(a)
+    r = _dev(r, "roughness").reshape(B, H, W, 1)
+    m = _dev(m, "metallic").reshape(B, H, W, 1)
+    d_out = _dev(d_out, "d_out", (3,))
+    d_a, d_r, d_m = torch.empty_like(a), torch.empty_like(r), torch.empty_like(m)
+    with torch.cuda.device(a.device), _timed("shade_bwd"):
+        code = lib.matpbr_shade_bwd_jac(_ptr(a), _ptr(r), _ptr(m), _ptr(jac), _ptr(d_out), _ptr(d_a), _ptr(d_r), _ptr(d_m), H, W, B, _stream(a))
+    _lib.check(code, "matpbr_shade_bwd_jac")
+    return d_a, d_r, d_m
 
 
 def shade_bwd(a, r, m, n, light, d_out, spp: int, fov_x_deg: float = 35.0, want_mat=True, want_n=False, want_light=False,
@@ -262,19 +306,18 @@ def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: floa
     return stats
 
 
-def shade_bwd_brdf_loss(pa, pr, pm, n, light, pred, gt_srgb, stats, a0, r0, m0, scale_delta: float, spp: int, d_a, d_r, d_m,
-                        best_a=None, best_r=None, best_m=None, best_img=None, fov_x_deg: float = 35.0, optimize_part: str = "arm") -> None:
-    """Backward of the fused BRDF-phase loss into preallocated d_a/d_r/d_m (see include/matpbr.h)."""
+def brdf_loss_bwd_jac(pa, pr, pm, jac, pred, gt_srgb, stats, a0, r0, m0, scale_delta: float, d_a, d_r, d_m,
+                      best_a=None, best_r=None, best_m=None, best_img=None, optimize_part: str = "arm") -> None:
+    """Backward of the fused BRDF-phase loss into preallocated d_a/d_r/d_m from the jac planes of the forward pass that rendered
+    pa/pr/pm with clamp_params=True (see include/matpbr.h)."""
     lib = _lib.load()
     pa = _dev(pa, "pa", (3,))
     B, H, W = _bhw(pa)
-    cam = MatpbrCamera(float(fov_x_deg))
     with torch.cuda.device(pa.device), _timed("shade_bwd"):
-        code = lib.matpbr_shade_bwd_brdf_loss(_ptr(pa), _ptr(pr), _ptr(pm), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(pred), _ptr(gt_srgb),
-                                              _ptr(stats), _ptr(a0), _ptr(r0), _ptr(m0), float(scale_delta), _ptr(d_a), _ptr(d_r), _ptr(d_m),
-                                              _ptr(best_a), _ptr(best_r), _ptr(best_m), _ptr(best_img), H, W, B, check_spp(spp),
-                                              ctypes.byref(cam), part_mask(optimize_part), _stream(pa))
-    _lib.check(code, "matpbr_shade_bwd_brdf_loss")
+        code = lib.matpbr_brdf_loss_bwd_jac(_ptr(pa), _ptr(pr), _ptr(pm), _ptr(jac), _ptr(pred), _ptr(gt_srgb), _ptr(stats), _ptr(a0), _ptr(r0),
+                                            _ptr(m0), float(scale_delta), _ptr(d_a), _ptr(d_r), _ptr(d_m), _ptr(best_a), _ptr(best_r),
+                                            _ptr(best_m), _ptr(best_img), H, W, B, part_mask(optimize_part), _stream(pa))
+    _lib.check(code, "matpbr_brdf_loss_bwd_jac")
 
 
 def adam_step(p, g, m, v, lr: float, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:

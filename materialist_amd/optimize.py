@@ -42,11 +42,17 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         mat["normal"] = torch.nn.functional.normalize(mat["normal"], p=2, dim=-1)  # :193
         params["shape.bsdf.n"] = mat["normal"]
 
+    # regulariser anchors albedo_ori / roughness_ori / metallic_ori / normal_ori: captured ONCE, before the loops (:189-201), and
+    # used by every part of every loop (:398-409) -- not the previous part's best maps
+    originals = {k: mat[k].detach().clone() for k in ("albedo", "roughness", "metallic")}
+    if not scene.use_mesh_normal:
+        originals["normal"] = mat["normal"].detach().clone()
+
     mask = mat.get("mask") if use_mask else None                                   # --use_mask (:379-381,509-511,702-711)
     if use_mask and mask is None:
         raise ValueError("use_mask needs mat['mask'] ([H,W] bool)")
     saver = _loop.DeviceSaveBest()
-    state = {"final_envmap": None, "last_mse": None}
+    state = {"final_envmap": None, "last_mse": None, "best_brdf_weights": None}
     if model_name == "pos_mlp":                                                     # :114-124,159-172,179-207
         from . import posmlp
 
@@ -183,7 +189,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 saver.best[k_] = ph.best[k_].clone()
             saver.best["rendered_img"] = ph.best_img.clone()
             saver.best["envmap"] = state["envmap4render"].clone()
-            brdf_net.load_state_dict(ph.best_weights)                               # :586-587
+            state["best_brdf_weights"] = ph.best_weights
+        if state["best_brdf_weights"] is not None:
+            brdf_net.load_state_dict(state["best_brdf_weights"])                    # :586-587: reloaded after every part
         say(f"loop {loop_num}: part {part!r} (pos_mlp) ran {it + 1} iterations ({stop}), best mse {float(best.min()):.5f}")
         return it, ph.opt.param_groups[0]["lr"], stop
 
@@ -191,7 +199,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         """Parts that optimise the normal map (output_type 'armn', use_mesh_normal False; :335-340,378-379,406-409) or run under
         `--use_mask`: the autograd render with the torch-composed loss (BrdfPhase) and the reference's per-epoch host EarlyStopping."""
         ph = _loop.BrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], None if scene.use_mesh_normal else mat["normal"],
-                             optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask)
+                             optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask,
+                             originals=originals)
         if saver.best_loss is not None:
             ph.saver.best_loss = saver.best_loss.clone().reshape(())
         es = _loop.EarlyStopping(patience, min_delta)
@@ -238,7 +247,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 saver.best["normal"] = ph.saver.best["normal"].clone()
                 mat["normal"] = saver.best["normal"]
             saver.best["envmap"] = state["envmap4render"].clone()
-            brdf_net.load_state_dict(ph.best_weights)                               # :586-587
+            state["best_brdf_weights"] = {k: v.clone() for k, v in ph.best_weights.items()}
+        if state["best_brdf_weights"] is not None:
+            brdf_net.load_state_dict(state["best_brdf_weights"])                    # :586-587: reloaded after every part
         say(f"loop {loop_num}: part {part!r} (pos_mlp, armn) ran {it + 1} iterations ({stop})")
         return it, ph.opt.param_groups[0]["lr"], stop
 
@@ -251,7 +262,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
         ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], optimize_part=part, spp=spp,
                                   scale_delta=scale_delta, patience=patience, min_delta=min_delta,
-                                  best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs)
+                                  best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs,
+                                  originals=originals)
         done, stop = 0, "num_epochs"
         while done < n_epochs:
             k = min(sync_every, n_epochs - done)

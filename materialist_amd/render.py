@@ -30,9 +30,12 @@ class _ShadeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, r, m, n, light, spp, fov, workspace_holder):
         a, r, m, n, light = (t.contiguous() for t in (a, r, m, n, light))
-        out = ops.shade_fwd(a, r, m, n, light, spp, fov)
+        # the material gradients are closed forms of sums the forward pass forms anyway: keep them (9 floats per pixel) and the
+        # backward pass is one streaming kernel
+        jac = ops.plane9(a) if any(ctx.needs_input_grad[:3]) else None
+        out = ops.shade_fwd(a, r, m, n, light, spp, fov, jac=jac)
         ctx.save_for_backward(a, r, m, n, light)
-        ctx.spp, ctx.fov, ctx.ws = spp, fov, workspace_holder
+        ctx.spp, ctx.fov, ctx.ws, ctx.jac = spp, fov, workspace_holder, jac
         return out
 
     @staticmethod
@@ -41,11 +44,16 @@ class _ShadeFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         want_mat = need[0] or need[1] or need[2]
         want_n, want_light = need[3], need[4]
-        ws = None
-        if want_light and ctx.ws is not None:
-            ws = ctx.ws["ws"] = ops.workspace_for(a, ctx.ws.get("ws"))
-        d_a, d_r, d_m, d_n, d_l = ops.shade_bwd(a, r, m, n, light, d_out.contiguous(), ctx.spp, ctx.fov, want_mat=want_mat,
-                                                want_n=want_n, want_light=want_light, workspace=ws)
+        d_out = d_out.contiguous()
+        d_a = d_r = d_m = d_n = d_l = None
+        if want_mat:
+            d_a, d_r, d_m = ops.shade_bwd_jac(a, r, m, ctx.jac, d_out)
+        if want_n or want_light:
+            ws = None
+            if want_light and ctx.ws is not None:
+                ws = ctx.ws["ws"] = ops.workspace_for(a, ctx.ws.get("ws"))
+            _, _, _, d_n, d_l = ops.shade_bwd(a, r, m, n, light, d_out, ctx.spp, ctx.fov, want_mat=False, want_n=want_n,
+                                              want_light=want_light, workspace=ws)
         return (d_a if need[0] else None, d_r.reshape(r.shape) if need[1] else None, d_m.reshape(m.shape) if need[2] else None,
                 d_n if need[3] else None, d_l if need[4] else None, None, None, None)
 

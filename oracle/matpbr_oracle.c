@@ -303,9 +303,16 @@ void oracle_sh_eval(const real w[3], const real* coef /*[25][3]*/, real L[3]) {
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Deterministic sample set (the build's replacement for Mitsuba's `independent` sampler):
- *   n = spp/2 points per lobe, u0_i = (i+0.5)/n, u1_i = vdC_2(i) + 0.5/m, m = 2^ceil(log2 n).
- *   Samples [0, n) use the diffuse sampler (reference: sample1 > 0.5), [n, 2n) the specular one.
+ * Sample sets.
+ *  (1) Reference-literal estimator ("MIS", kept as the yardstick the production estimator is measured
+ *      against): n = spp/2 points per lobe, u0_i = (i+0.5)/n, u1_i = vdC_2(i) + 0.5/m, m = 2^ceil(log2 n);
+ *      samples [0, n) use the diffuse sampler (reference: sample1 > 0.5), [n, 2n) the specular one.
+ *  (2) Production rule: per lobe a product rule over the sampler's own (u0, u1)
+ *      square -- nu Gauss-Legendre nodes x nphi equally spaced azimuths, ring k rotated by vdC_2(k)/nphi;
+ *      the specular lobe places its nodes v_k through u0 = 1 - (1 - v)^2 (weight 2 (1 - v)), which removes the
+ *      square-root end-point behaviour of the integrand at u0 -> 1 (grazing half vectors).  Sizes follow `spp`:
+ *      at the reference's spp = 64 (4 x 4 specular, 3 x 6 diffuse nodes) its error against the converged integral
+ *      is below the reference-literal estimator's at the same spp (tests/test_estimator_accuracy.py).
  * ---------------------------------------------------------------------------------------------- */
 static real vdc2(uint32_t i) {
     i = (i << 16) | (i >> 16);
@@ -323,14 +330,88 @@ void oracle_sample_point(int spp, int i, real* u0, real* u1) {
     *u1 = vdc2((uint32_t)i) + R(0.5) / (real)m;
 }
 
+#define ORACLE_MAX_RULE 96
+/* Gauss-Legendre nodes / weights on [0,1] (Newton iteration on P_n, ascending nodes, weights sum to 1) */
+static void gauss_legendre01(int n, double* x, double* w) {
+    for (int i = 0; i < n; ++i) {
+        double z = cos(3.14159265358979323846 * ((double)i + 0.75) / ((double)n + 0.5)), pp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 0; j < n; ++j) {
+                double p3 = p2;
+                p2 = p1;
+                p1 = ((2.0 * j + 1.0) * z * p2 - (double)j * p3) / ((double)j + 1.0);
+            }
+            pp = (double)n * (z * p1 - p2) / (z * z - 1.0);
+            double z1 = z;
+            z = z1 - p1 / pp;
+            if (fabs(z - z1) < 1e-15) break;
+        }
+        x[n - 1 - i] = 0.5 * (z + 1.0);
+        w[n - 1 - i] = 1.0 / ((1.0 - z * z) * pp * pp);
+    }
+}
+/* spp -> (nu, nphi) of the specular (lobe 1) and diffuse (lobe 0) rules; spp = 64 -> 4 x 4 and 3 x 6 */
+static double g_rule_power = 2.0;    /* specular lobe: u0 = 1 - (1-v)^2 at the Gauss-Legendre nodes v (other powers: studies only) */
+void oracle_rule_power(double p) { g_rule_power = p; }
+static int g_rule_override[2][2];   /* quadrature studies only (tools/quadrature_study.py): 0 = use the production sizes */
+void oracle_rule_override(int lobe, int nu, int nphi) { g_rule_override[lobe][0] = nu; g_rule_override[lobe][1] = nphi; }
+void oracle_rule_dims(int spp, int lobe, int* nu, int* nphi) {
+    double q = 0.25 * (double)spp, s = sqrt(q);
+    if (g_rule_override[lobe][0] > 0) { *nu = g_rule_override[lobe][0]; *nphi = g_rule_override[lobe][1]; return; }
+    if (lobe) {
+        *nu = (int)floor(s + 0.5);
+        if (*nu < 1) *nu = 1;
+        *nphi = (int)ceil(q / (double)*nu - 1e-9);
+        if (*nphi < 1) *nphi = 1;
+    } else {
+        *nu = (int)floor(0.75 * s + 0.5);
+        if (*nu < 1) *nu = 1;
+        *nphi = 2 * *nu;
+    }
+}
+int oracle_rule(int spp, int lobe, real* u0, real* u1, real* w) {
+    int nu, nphi;
+    double x[ORACLE_MAX_RULE], wx[ORACLE_MAX_RULE];
+    oracle_rule_dims(spp, lobe, &nu, &nphi);
+    if (nu * nphi > ORACLE_MAX_RULE) return -1;
+    gauss_legendre01(nu, x, wx);
+    int c = 0;
+    for (int k = 0; k < nu; ++k) {
+        double off = (double)vdc2((uint32_t)k) / (double)nphi;
+        for (int j = 0; j < nphi; ++j, ++c) {
+            double v = ((double)j + 0.5) / (double)nphi + off;
+            u0[c] = (real)x[k];
+            u1[c] = (real)(v - floor(v));
+            w[c] = (real)(wx[k] / (double)nphi);
+            if (lobe && g_rule_power != 1.0) {
+                u0[c] = (real)(1.0 - pow(1.0 - x[k], g_rule_power));
+                w[c] = (real)(wx[k] * g_rule_power * pow(1.0 - x[k], g_rule_power - 1.0) / (double)nphi);
+            }
+        }
+    }
+    return c;
+}
+
+typedef struct Rules {   /* both lobes' rules of one spp, built once per image-level call */
+    int nd, ns;
+    real du0[ORACLE_MAX_RULE], du1[ORACLE_MAX_RULE], dw[ORACLE_MAX_RULE];
+    real su0[ORACLE_MAX_RULE], su1[ORACLE_MAX_RULE], sw[ORACLE_MAX_RULE];
+} Rules;
+static void rules_init(Rules* q, int spp) {
+    q->nd = oracle_rule(spp, 0, q->du0, q->du1, q->dw);
+    q->ns = oracle_rule(spp, 1, q->su0, q->su1, q->sw);
+}
+
 /* ------------------------------------------------------------------------------------------------
- * a8/a2(Mitsuba): the deterministic render  R(a, r, m, n; light)  for one pixel
+ * Reference-literal estimator for one pixel (the round-1 definition of the render, now the yardstick):
  *   L_o = (1/spp) sum_s  w_s * L_SH(wi_s),   (wi_s, w_s) = sample_brdf(lobe_s, u_s; wo, n, a, r, m)
  * i.e. the BSDF-sampling arm of a depth-1 path (direct light from the environment, unshadowed) with
  * the one-sample-model mixture pdf of eval_brdf (:1398-1401) and the MC weight of sample_brdf (:1335-1341).
+ * For spp -> infinity it converges to  I = integral of eval_brdf(wi) L(wi) dwi  over the hemisphere.
  * ---------------------------------------------------------------------------------------------- */
-static void shade_pixel(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef,
-                        int spp, real out[3]) {
+static void mis_pixel(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef,
+                      int spp, real out[3]) {
     int half = spp / 2;
     out[0] = out[1] = out[2] = R(0);
     for (int s = 0; s < spp; ++s) {
@@ -342,12 +423,11 @@ static void shade_pixel(const real wo[3], const real n[3], const real a[3], real
     }
     for (int c = 0; c < 3; ++c) out[c] /= (real)spp;
 }
-
-/* Backward of shade_pixel with sample directions and pdf treated as constants (stop-gradient), the
- * convention of the reference's torch variants (`D.data`, `alpha.data`: myutils/mi_plugin.py:366,179). */
-static void shade_pixel_bwd(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef,
-                            int spp, const real g_out[3], real d_a[3], real* d_r, real* d_m, real d_n[3],
-                            real* d_coef /*[25][3] accumulated, may be NULL*/) {
+/* Its backward with sample directions and pdf treated as constants (stop-gradient), the convention of the
+ * reference's torch variants (`D.data`, `alpha.data`: myutils/mi_plugin.py:366,179): a consistent estimator of dI. */
+static void mis_pixel_bwd(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef,
+                          int spp, const real g_out[3], real d_a[3], real* d_r, real* d_m, real d_n[3],
+                          real* d_coef /*[25][3] accumulated, may be NULL*/) {
     int half = spp / 2;
     d_a[0] = d_a[1] = d_a[2] = R(0);
     *d_r = R(0); *d_m = R(0);
@@ -374,6 +454,194 @@ static void shade_pixel_bwd(const real wo[3], const real n[3], const real a[3], 
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * a8: the production render  R(a, r, m, n; light)  for one pixel -- the same integral I, with the two
+ * lobes of eval_brdf (:1405-1415) integrated separately, each with its own sampler of sample_brdf:
+ *
+ *   diffuse (:1405-1409), cosine-weighted directions wi_j (mi_diffuse_sampler, pdf = NoL/pi, weights w_j):
+ *     I_d[c] = a_c (1-m) * sum_j w_j F_out F_in L_c(wi_j),   F_x = 1 + (F_D90 - 1)(1 - x)^5,
+ *     F_D90 - 1 = 2 VoH^2 r - 1/2 = r (1 + wi.wo) - 1/2   (VoH^2 = (1 + wi.wo)/2 for h = normalize(wi + wo))
+ *     => I_d[c] = a_c (1-m) (A0_c + r A1_c + r^2 A2_c): a quadratic in r whose coefficients depend on (n, wo, light)
+ *     only.  With light and geometric normals fixed during a BRDF phase (F10) they are constants of the phase.
+ *   specular (:1410-1414), GGX half vectors (mi_specular_sampler, pdf = D NoH / (4 VoH)): D cancels between the
+ *     value and the pdf,  f cos / pdf = G1(NoL) G1(NoV) F_m NoL VoH / NoH,  F_m = C0 + (1 - C0)(1 - VoH)^5:
+ *     I_s[c] = C0_c S0_c + (1 - C0_c) S1_c,  S0 = sum_j w_j g_j L(wi_j),  S1 = sum_j w_j g_j (1-VoH_j)^5 L(wi_j),
+ *     g = G1(NoL) G1(NoV) NoL VoH / NoH on samples with wo.h > 0 and NoL > 0.
+ * Backward: sample directions and pdfs are constants (stop-gradient), as before; then
+ *     d ln(f_s)/dr at a fixed direction = 4/r - 8 r^3 NoH^2/den + d ln G / dr   (= (4/r)(2 u0 - 1) + d ln G/dr up to D_GGX's 1e-6)
+ * so the material gradients are closed forms of {A, S0, S1, dS0/dr, dS1/dr}.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct SplitState {
+    real P[3], dP[3];        /* A0 + r A1 + r^2 A2 and its r-derivative */
+    real S0[3], S1[3], dS0[3], dS1[3];
+} SplitState;
+
+static void diffuse_local(real u0, real u1, real l[3]) {      /* mi_diffuse_sampler :255-281, local frame */
+    real theta = asin(sqrt(rmax(u0, R(0))));
+    real phi = R(2) * O_PI * u1;
+    l[0] = sin(theta) * cos(phi); l[1] = sin(theta) * sin(phi); l[2] = cos(theta);
+}
+static real pow4r(real x) { real x2 = x * x; return x2 * x2; }
+
+/* A0, A1, A2 of the diffuse lobe (per channel) */
+static void diffuse_coef(const real wo[3], const real n[3], const real* coef, const Rules* q, real A[9]) {
+    const real *u0 = q->du0, *u1 = q->du1, *w = q->dw;
+    const int nd = q->nd;
+    real s[3], t[3];
+    oracle_frame(n, s, t);
+    real po = pow5(R(1) - rmax(dot3(n, wo), R(0)));
+    real M[5][3];
+    memset(M, 0, sizeof(M));
+    for (int j = 0; j < nd; ++j) {
+        real l[3], wi[3], L[3];
+        diffuse_local(u0[j], u1[j], l);
+        to_world(s, t, n, l, wi);
+        oracle_sh_eval(wi, coef, L);
+        real u = R(1) + dot3(wi, wo), p5 = pow5(R(1) - l[2]);
+        for (int c = 0; c < 3; ++c) {
+            real x = w[j] * L[c];
+            M[0][c] += x; M[1][c] += x * p5; M[2][c] += x * u; M[3][c] += x * u * p5; M[4][c] += x * u * u * p5;
+        }
+    }
+    for (int c = 0; c < 3; ++c) {
+        A[c] = M[0][c] * (R(1) - R(0.5) * po) + M[1][c] * (R(0.25) * po - R(0.5));
+        A[3 + c] = po * M[2][c] + (R(1) - po) * M[3][c];
+        A[6 + c] = po * M[4][c];
+    }
+}
+
+/* GGX-sampled specular sample j in the shading frame of n: returns 0 when the sample carries no weight */
+typedef struct SpecSample { real wi[3], wh[3], NoL, VoH, NoH, g1l, wgt, x5, lam; } SpecSample;
+static int spec_sample(real u0, real u1, real w, const real wo[3], const real n[3], const real s[3], const real t[3], real r,
+                       real g1v, real NoV, SpecSample* sp) {
+    real alpha2 = pow4r(r);
+    real q = R(1) / (u0 * (alpha2 - R(1)) + R(1));
+    real ct = sqrt(rmax((R(1) - u0) * q, R(0))), st = sqrt(rmax(alpha2 * u0 * q, R(0)));   /* :232-233 */
+    real phi = R(2) * O_PI * u1;
+    real l[3] = {st * cos(phi), st * sin(phi), ct};
+    to_world(s, t, n, l, sp->wh);
+    real d = dot3(wo, sp->wh);
+    for (int i = 0; i < 3; ++i) sp->wi[i] = R(2) * d * sp->wh[i] - wo[i];                     /* reflect, :245 */
+    real nl = dot3(n, sp->wi);
+    if (!(d > R(0)) || !(nl > R(0))) return 0;
+    real k = (r + R(1)) * (r + R(1)) / R(8);
+    sp->NoL = nl; sp->VoH = d; sp->NoH = ct;
+    sp->g1l = oracle_G1_GGX_Schlick(nl, r);
+    sp->wgt = w * sp->g1l * g1v * nl * d / ct;
+    sp->x5 = pow5(R(1) - d);
+    /* d ln(D G)/dr at a fixed direction; D = D_GGX of :89-97 including its 1e-6 regulariser:
+     * d ln D/dr = 4/r - 8 r^3 NoH^2 / den  (= (4/r)(2 u0 - 1) up to the regulariser, since den = alpha2/(1 + u0 (alpha2 - 1)) here) */
+    real den = ct * ct * (alpha2 - R(1)) + R(1) + R(1e-6);
+    sp->lam = R(4) / r - R(8) * r * r * r * ct * ct / den - (r + R(1)) / R(4) * (sp->g1l * (R(1) - nl) + g1v * (R(1) - NoV));
+    (void)k;
+    return 1;
+}
+
+static void split_pixel_state(const real wo[3], const real n[3], real r, const real* coef, const Rules* q, const real* A_cached,
+                              SplitState* st) {
+    real A[9];
+    if (A_cached) memcpy(A, A_cached, sizeof(A));
+    else diffuse_coef(wo, n, coef, q, A);
+    for (int c = 0; c < 3; ++c) {
+        st->P[c] = A[c] + r * A[3 + c] + r * r * A[6 + c];
+        st->dP[c] = A[3 + c] + R(2) * r * A[6 + c];
+        st->S0[c] = st->S1[c] = st->dS0[c] = st->dS1[c] = R(0);
+    }
+    const real *u0 = q->su0, *u1 = q->su1, *w = q->sw;
+    const int ns = q->ns;
+    real s[3], t[3];
+    oracle_frame(n, s, t);
+    real NoV = rmax(dot3(n, wo), R(0)), g1v = oracle_G1_GGX_Schlick(NoV, r);
+    for (int j = 0; j < ns; ++j) {
+        SpecSample sp;
+        real L[3];
+        if (!spec_sample(u0[j], u1[j], w[j], wo, n, s, t, r, g1v, NoV, &sp)) continue;
+        oracle_sh_eval(sp.wi, coef, L);
+        for (int c = 0; c < 3; ++c) {
+            real x = sp.wgt * L[c];
+            st->S0[c] += x; st->S1[c] += x * sp.x5;
+            st->dS0[c] += x * sp.lam; st->dS1[c] += x * sp.lam * sp.x5;
+        }
+    }
+}
+static void split_pixel(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef, const Rules* q,
+                        const real* A_cached, real out[3]) {
+    SplitState st;
+    split_pixel_state(wo, n, r, coef, q, A_cached, &st);
+    for (int c = 0; c < 3; ++c) {
+        real C0 = (R(1) - m) * R(0.04) + m * a[c];                                            /* :1412 */
+        out[c] = a[c] * (R(1) - m) * st.P[c] + C0 * st.S0[c] + (R(1) - C0) * st.S1[c];
+    }
+}
+
+/* Backward of split_pixel (stop-gradient through directions and pdfs).  d_n is the gradient w.r.t. the unit normal in world
+ * space (its radial part is removed by the caller); d_coef[25][3] is accumulated when not NULL. */
+static void split_pixel_bwd(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef, const Rules* q,
+                            const real g_out[3], real d_a[3], real* d_r, real* d_m, real d_n[3], real* d_coef) {
+    SplitState st;
+    split_pixel_state(wo, n, r, coef, q, NULL, &st);
+    *d_r = R(0); *d_m = R(0);
+    d_n[0] = d_n[1] = d_n[2] = R(0);
+    real C0[3];
+    for (int c = 0; c < 3; ++c) {
+        C0[c] = (R(1) - m) * R(0.04) + m * a[c];
+        real SD = st.S0[c] - st.S1[c];
+        d_a[c] = g_out[c] * ((R(1) - m) * st.P[c] + m * SD);
+        *d_m += g_out[c] * (-a[c] * st.P[c] + (a[c] - R(0.04)) * SD);
+        *d_r += g_out[c] * (a[c] * (R(1) - m) * st.dP[c] + C0[c] * st.dS0[c] + (R(1) - C0[c]) * st.dS1[c]);
+    }
+    /* per-sample parts: normal and light gradients */
+    const real *u0 = q->du0, *u1 = q->du1, *w = q->dw;
+    real s[3], t[3];
+    oracle_frame(n, s, t);
+    real nv = dot3(n, wo), NoV = rmax(nv, R(0)), po = pow5(R(1) - NoV);
+    real k = (r + R(1)) * (r + R(1)) / R(8), alpha2 = pow4r(r);
+    const int nd = q->nd;
+    for (int j = 0; j < nd; ++j) {
+        real l[3], wi[3], Y[MATPBR_NSH], L[3] = {0, 0, 0};
+        diffuse_local(u0[j], u1[j], l);
+        to_world(s, t, n, l, wi);
+        oracle_sh_basis_dir(wi, Y);
+        for (int kk = 0; kk < MATPBR_NSH; ++kk)
+            for (int c = 0; c < 3; ++c) L[c] += coef[kk * 3 + c] * Y[kk];
+        real q = r * (R(1) + dot3(wi, wo)) - R(0.5);
+        real p5 = pow5(R(1) - l[2]);
+        real Fo = R(1) + q * po, Fi = R(1) + q * p5;
+        real dFi = -R(5) * q * pow4r(R(1) - l[2]);
+        real dFo = nv > R(0) ? -R(5) * q * pow4r(R(1) - NoV) : R(0);
+        real sc = R(0);
+        for (int c = 0; c < 3; ++c) sc += g_out[c] * a[c] * (R(1) - m) * L[c];
+        sc *= w[j];
+        real gl = Fo * (dFi + Fi / l[2]), gv = dFo * Fi;
+        for (int i = 0; i < 3; ++i) d_n[i] += sc * (gl * wi[i] + gv * wo[i]);
+        if (d_coef)
+            for (int kk = 0; kk < MATPBR_NSH; ++kk)
+                for (int c = 0; c < 3; ++c) d_coef[kk * 3 + c] += g_out[c] * a[c] * (R(1) - m) * w[j] * Fo * Fi * Y[kk];
+    }
+    const int ns = q->ns;
+    u0 = q->su0; u1 = q->su1; w = q->sw;
+    real g1v = oracle_G1_GGX_Schlick(NoV, r);
+    for (int j = 0; j < ns; ++j) {
+        SpecSample sp;
+        real Y[MATPBR_NSH], L[3] = {0, 0, 0};
+        if (!spec_sample(u0[j], u1[j], w[j], wo, n, s, t, r, g1v, NoV, &sp)) continue;
+        oracle_sh_basis_dir(sp.wi, Y);
+        for (int kk = 0; kk < MATPBR_NSH; ++kk)
+            for (int c = 0; c < 3; ++c) L[c] += coef[kk * 3 + c] * Y[kk];
+        real sc = R(0);
+        for (int c = 0; c < 3; ++c) sc += g_out[c] * (C0[c] + (R(1) - C0[c]) * sp.x5) * L[c];
+        sc *= sp.wgt;
+        real den = sp.NoH * sp.NoH * (alpha2 - R(1)) + R(1) + R(1e-6);                       /* :95 */
+        real gl = R(1) / sp.NoL - sp.g1l * (R(1) - k);
+        real gv = nv > R(0) ? -g1v * (R(1) - k) : R(0);
+        real gh = -R(4) * sp.NoH * (alpha2 - R(1)) / den;
+        for (int i = 0; i < 3; ++i) d_n[i] += sc * (gl * sp.wi[i] + gv * wo[i] + gh * sp.wh[i]);
+        if (d_coef)
+            for (int kk = 0; kk < MATPBR_NSH; ++kk)
+                for (int c = 0; c < 3; ++c) d_coef[kk * 3 + c] += g_out[c] * sp.wgt * (C0[c] + (R(1) - C0[c]) * sp.x5) * Y[kk];
+    }
+}
+
 /* The image-level render shades with the unit normal n/|n| of the stored map (the reference's geometric
  * and MaterialNet normals are unit length already; dpt.py normalises its normal head). */
 static real unit_normal(const real n[3], real nh[3]) {
@@ -383,61 +651,86 @@ static real unit_normal(const real n[3], real nh[3]) {
     return l;
 }
 
-/* Forward with the sampling state frozen: directions and pdf come from (n_s, r_s), the BRDF value from (n, a, r, m).
- * At (n_s, r_s) = (n, r) this equals shade_pixel; its derivative w.r.t. (a, r, m, n) at that point is what
- * shade_pixel_bwd returns (stop-gradient through the samples), which the tests verify by finite differences. */
-static void shade_pixel_frozen(const real wo[3], const real n[3], const real a[3], real r, real m, const real n_s[3], real r_s,
-                               const real* coef, int spp, real out[3]) {
-    int half = spp / 2;
+/* Forward with the sampling state frozen: directions and pdfs come from (n_s, r_s), the BRDF value from (n, a, r, m),
+ * evaluated lobe by lobe with the literal formulas (no closed forms).  At (n_s, r_s) = (n, r) this equals split_pixel;
+ * its derivative w.r.t. (a, r, m, n) at that point is what split_pixel_bwd returns, which the tests verify by finite
+ * differences -- so the closed forms of the backward pass are checked against an independent evaluation. */
+static void split_pixel_frozen(const real wo[3], const real n[3], const real a[3], real r, real m, const real n_s[3], real r_s,
+                               const real* coef, const Rules* rq, real out[3]) {
+    const real *u0 = rq->du0, *u1 = rq->du1, *w = rq->dw;
+    real s[3], t[3];
+    oracle_frame(n_s, s, t);
+    real NoV = rmax(dot3(n, wo), R(0)), po = pow5(R(1) - NoV);
     out[0] = out[1] = out[2] = R(0);
-    for (int s = 0; s < spp; ++s) {
-        real u0, u1, wi[3], f[3], fs[3], pdf, pdf_s, L[3];
-        oracle_sample_point(spp, s < half ? s : s - half, &u0, &u1);
-        if (s < half) oracle_diffuse_sampler(u0, u1, n_s, wi);
-        else oracle_specular_sampler(u0, u1, r_s, wo, n_s, wi);
-        oracle_eval_brdf(wi, wo, n_s, a, r_s, m, fs, &pdf_s);
-        if (!(pdf_s > R(1e-6))) continue;
-        oracle_eval_brdf(wi, wo, n, a, r, m, f, &pdf);
+    const int nd = rq->nd;
+    for (int j = 0; j < nd; ++j) {
+        real l[3], wi[3], L[3];
+        diffuse_local(u0[j], u1[j], l);
+        to_world(s, t, n_s, l, wi);
         oracle_sh_eval(wi, coef, L);
-        for (int c = 0; c < 3; ++c) out[c] += f[c] / (pdf_s + R(1e-6)) * L[c];
+        real NoL = rmax(dot3(n, wi), R(0));
+        real h[3] = {wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2]};
+        real hl = sqrt(dot3(h, h));
+        real VoH = rmax(dot3(wo, h) / hl, R(0));
+        real FD90 = R(0.5) + R(2) * VoH * VoH * r;                                           /* :1406 */
+        real Fo = R(1) + (FD90 - R(1)) * po, Fi = R(1) + (FD90 - R(1)) * pow5(R(1) - NoL);  /* :1407-1408 */
+        for (int c = 0; c < 3; ++c) {
+            real val = a[c] * (R(1) - m) / O_PI * Fo * Fi * NoL;                              /* :1409 */
+            out[c] += w[j] * val / (l[2] / O_PI) * L[c];                                      /* pdf_diff = NoL_s / pi, :1400 */
+        }
     }
-    for (int c = 0; c < 3; ++c) out[c] /= (real)spp;
-}
-void oracle_shade_fwd_frozen(const real* a, const real* r, const real* m, const real* n, const real* n_s, const real* r_s,
-                             const real* light, real* out, int H, int W, int batch, int spp, real fov_x_deg) {
-    const long P = (long)H * W;
-#pragma omp parallel for schedule(static)
-    for (long idx = 0; idx < P * batch; ++idx) {
-        long b = idx / P, p = idx % P;
-        int i = (int)(p / W), j = (int)(p % W);
-        real wo[3], nh[3], nsh[3];
-        oracle_view_dir(i, j, H, W, fov_x_deg, wo);
-        unit_normal(n + idx * 3, nh);
-        unit_normal(n_s + idx * 3, nsh);
-        shade_pixel_frozen(wo, nh, a + idx * 3, r[idx], m[idx], nsh, r_s[idx], light + b * MATPBR_NSH * 3, spp, out + idx * 3);
+    const int ns = rq->ns;
+    u0 = rq->su0; u1 = rq->su1; w = rq->sw;
+    real a2s = pow4r(r_s);
+    for (int j = 0; j < ns; ++j) {
+        real q = R(1) / (u0[j] * (a2s - R(1)) + R(1));
+        real ct = sqrt(rmax((R(1) - u0[j]) * q, R(0))), st = sqrt(rmax(a2s * u0[j] * q, R(0)));
+        real phi = R(2) * O_PI * u1[j];
+        real l[3] = {st * cos(phi), st * sin(phi), ct}, wh[3], wi[3], L[3];
+        to_world(s, t, n_s, l, wh);
+        real d = dot3(wo, wh);
+        for (int i = 0; i < 3; ++i) wi[i] = R(2) * d * wh[i] - wo[i];
+        if (!(d > R(0)) || !(dot3(n_s, wi) > R(0))) continue;
+        real pdf = oracle_D_GGX(ct, r_s) * ct / (R(4) * d);                                         /* :1399 */
+        oracle_sh_eval(wi, coef, L);
+        real NoL = rmax(dot3(n, wi), R(0)), NoH = rmax(dot3(n, wh), R(0));
+        real G = oracle_G_Smith(NoV, NoL, r);
+        real x5 = pow5(R(1) - d);
+        for (int c = 0; c < 3; ++c) {
+            real C0 = (R(1) - m) * R(0.04) + m * a[c];
+            real val = oracle_D_GGX(NoH, r) * G * (C0 + (R(1) - C0) * x5) / R(4) * NoL;            /* :1413-1414 */
+            out[c] += w[j] * val / pdf * L[c];
+        }
     }
 }
 
-/* Image-level entry points.  Layout = the reference's: row-major HWC float maps
- * a[H,W,3] r[H,W,1] m[H,W,1] n[H,W,3] (myutils/mi_plugin.py:1238-1241), light = SH coef [batch,25,3]. */
-void oracle_shade_fwd(const real* a, const real* r, const real* m, const real* n, const real* light, real* out,
-                      int H, int W, int batch, int spp, real fov_x_deg) {
-    const long P = (long)H * W;
+/* ---- image-level drivers.  Layout = the reference's: row-major HWC float maps a[H,W,3] r[H,W,1] m[H,W,1] n[H,W,3]
+ * (myutils/mi_plugin.py:1238-1241), light = SH coef [batch,25,3].  A window (h x w at (i0, j0) of an H x W image) or explicit
+ * per-lane view directions select where the view direction comes from. */
+typedef struct View { int H, W, i0, j0, w; real fov; const real* wo; } View;
+static void view_of(const View* v, long p, real wo[3]) {
+    if (v->wo) { for (int c = 0; c < 3; ++c) wo[c] = v->wo[p * 3 + c]; return; }
+    oracle_view_dir(v->i0 + (int)(p / v->w), v->j0 + (int)(p % v->w), v->H, v->W, v->fov, wo);
+}
+static void fwd_driver(const real* a, const real* r, const real* m, const real* n, const real* light, real* out, long P, int batch,
+                       int spp, const View* v, int kind, const real* dcache) {
+    Rules q;
+    rules_init(&q, spp);
 #pragma omp parallel for schedule(static)
     for (long idx = 0; idx < P * batch; ++idx) {
         long b = idx / P, p = idx % P;
-        int i = (int)(p / W), j = (int)(p % W);
         real wo[3], nh[3];
-        oracle_view_dir(i, j, H, W, fov_x_deg, wo);
+        view_of(v, v->wo ? idx : p, wo);
         unit_normal(n + idx * 3, nh);
-        shade_pixel(wo, nh, a + idx * 3, r[idx], m[idx], light + b * MATPBR_NSH * 3, spp, out + idx * 3);
+        const real* coef = light + b * MATPBR_NSH * 3;
+        if (kind == 1) mis_pixel(wo, nh, a + idx * 3, r[idx], m[idx], coef, spp, out + idx * 3);
+        else split_pixel(wo, nh, a + idx * 3, r[idx], m[idx], coef, &q, dcache ? dcache + idx * 9 : NULL, out + idx * 3);
     }
 }
-void oracle_shade_bwd(const real* a, const real* r, const real* m, const real* n, const real* light,
-                      const real* d_out, real* d_a, real* d_r, real* d_m, real* d_n /*nullable*/,
-                      real* d_light /*nullable, [batch,25,3], overwritten*/, int H, int W, int batch, int spp,
-                      real fov_x_deg) {
-    const long P = (long)H * W;
+static void bwd_driver(const real* a, const real* r, const real* m, const real* n, const real* light, const real* d_out, real* d_a,
+                       real* d_r, real* d_m, real* d_n, real* d_light, long P, int batch, int spp, const View* v, int kind) {
+    Rules q;
+    rules_init(&q, spp);
     if (d_light) memset(d_light, 0, sizeof(real) * (size_t)batch * MATPBR_NSH * 3);
     for (long b = 0; b < batch; ++b) {
 #pragma omp parallel
@@ -447,12 +740,12 @@ void oracle_shade_bwd(const real* a, const real* r, const real* m, const real* n
 #pragma omp for schedule(static)
             for (long p = 0; p < P; ++p) {
                 long idx = b * P + p;
-                int i = (int)(p / W), j = (int)(p % W);
                 real wo[3], ga[3], gr, gm, gn[3], nh[3];
-                oracle_view_dir(i, j, H, W, fov_x_deg, wo);
+                view_of(v, v->wo ? idx : p, wo);
                 real nlen = unit_normal(n + idx * 3, nh);
-                shade_pixel_bwd(wo, nh, a + idx * 3, r[idx], m[idx], light + b * MATPBR_NSH * 3, spp,
-                                d_out + idx * 3, ga, &gr, &gm, gn, d_light ? acc : NULL);
+                const real* coef = light + b * MATPBR_NSH * 3;
+                if (kind == 1) mis_pixel_bwd(wo, nh, a + idx * 3, r[idx], m[idx], coef, spp, d_out + idx * 3, ga, &gr, &gm, gn, d_light ? acc : NULL);
+                else split_pixel_bwd(wo, nh, a + idx * 3, r[idx], m[idx], coef, &q, d_out + idx * 3, ga, &gr, &gm, gn, d_light ? acc : NULL);
                 {   /* through n_hat = n/|n|: d_n = (g - n_hat (n_hat.g)) / |n| */
                     real pr = dot3(nh, gn);
                     for (int c = 0; c < 3; ++c) gn[c] = (gn[c] - nh[c] * pr) / nlen;
@@ -467,6 +760,102 @@ void oracle_shade_bwd(const real* a, const real* r, const real* m, const real* n
                 for (int k = 0; k < MATPBR_NSH * 3; ++k) d_light[b * MATPBR_NSH * 3 + k] += acc[k];
             }
         }
+    }
+}
+
+/* kind: 0 = production estimator, 1 = reference-literal MIS estimator */
+void oracle_shade_fwd_kind(const real* a, const real* r, const real* m, const real* n, const real* light, real* out,
+                           int H, int W, int batch, int spp, real fov_x_deg, int kind) {
+    View v = {H, W, 0, 0, W, fov_x_deg, NULL};
+    fwd_driver(a, r, m, n, light, out, (long)H * W, batch, spp, &v, kind, NULL);
+}
+void oracle_shade_fwd(const real* a, const real* r, const real* m, const real* n, const real* light, real* out,
+                      int H, int W, int batch, int spp, real fov_x_deg) {
+    oracle_shade_fwd_kind(a, r, m, n, light, out, H, W, batch, spp, fov_x_deg, 0);
+}
+/* The same render for an h x w window whose top-left pixel is (i0, j0) of an H x W image: view directions are those of
+ * the full image (used to check large renders on a crop in seconds). */
+void oracle_shade_fwd_win(const real* a, const real* r, const real* m, const real* n, const real* light, real* out,
+                          int h, int w, int batch, int spp, real fov_x_deg, int H, int W, int i0, int j0, int kind) {
+    View v = {H, W, i0, j0, w, fov_x_deg, NULL};
+    fwd_driver(a, r, m, n, light, out, (long)h * w, batch, spp, &v, kind, NULL);
+}
+/* N independent lanes with explicit view directions and one light (quadrature studies, stress cases). */
+void oracle_shade_fwd_lanes(const real* a, const real* r, const real* m, const real* n, const real* wo, const real* light,
+                            real* out, long N, int spp, int kind) {
+    View v = {0, 0, 0, 0, 1, R(0), wo};
+    fwd_driver(a, r, m, n, light, out, N, 1, spp, &v, kind, NULL);
+}
+void oracle_shade_bwd_kind(const real* a, const real* r, const real* m, const real* n, const real* light,
+                           const real* d_out, real* d_a, real* d_r, real* d_m, real* d_n /*nullable*/,
+                           real* d_light /*nullable, [batch,25,3], overwritten*/, int H, int W, int batch, int spp,
+                           real fov_x_deg, int kind) {
+    View v = {H, W, 0, 0, W, fov_x_deg, NULL};
+    bwd_driver(a, r, m, n, light, d_out, d_a, d_r, d_m, d_n, d_light, (long)H * W, batch, spp, &v, kind);
+}
+void oracle_shade_bwd(const real* a, const real* r, const real* m, const real* n, const real* light,
+                      const real* d_out, real* d_a, real* d_r, real* d_m, real* d_n, real* d_light, int H, int W, int batch, int spp,
+                      real fov_x_deg) {
+    oracle_shade_bwd_kind(a, r, m, n, light, d_out, d_a, d_r, d_m, d_n, d_light, H, W, batch, spp, fov_x_deg, 0);
+}
+void oracle_shade_bwd_lanes(const real* a, const real* r, const real* m, const real* n, const real* wo, const real* light,
+                            const real* d_out, real* d_a, real* d_r, real* d_m, real* d_n, real* d_light, long N, int spp, int kind) {
+    View v = {0, 0, 0, 0, 1, R(0), wo};
+    bwd_driver(a, r, m, n, light, d_out, d_a, d_r, d_m, d_n, d_light, N, 1, spp, &v, kind);
+}
+/* The diffuse-lobe coefficients A0, A1, A2 (rgb each) per pixel, dcache[B,H,W,9], and the render from them. */
+void oracle_diffuse_cache(const real* n, const real* light, real* dcache, int H, int W, int batch, int spp, real fov_x_deg) {
+    const long P = (long)H * W;
+    Rules q;
+    rules_init(&q, spp);
+#pragma omp parallel for schedule(static)
+    for (long idx = 0; idx < P * batch; ++idx) {
+        long b = idx / P, p = idx % P;
+        real wo[3], nh[3];
+        oracle_view_dir((int)(p / W), (int)(p % W), H, W, fov_x_deg, wo);
+        unit_normal(n + idx * 3, nh);
+        diffuse_coef(wo, nh, light + b * MATPBR_NSH * 3, &q, dcache + idx * 9);
+    }
+}
+void oracle_shade_fwd_cached(const real* a, const real* r, const real* m, const real* n, const real* light, const real* dcache,
+                             real* out, int H, int W, int batch, int spp, real fov_x_deg) {
+    View v = {H, W, 0, 0, W, fov_x_deg, NULL};
+    fwd_driver(a, r, m, n, light, out, (long)H * W, batch, spp, &v, 0, dcache);
+}
+void oracle_shade_fwd_frozen(const real* a, const real* r, const real* m, const real* n, const real* n_s, const real* r_s,
+                             const real* light, real* out, int H, int W, int batch, int spp, real fov_x_deg) {
+    const long P = (long)H * W;
+    Rules q;
+    rules_init(&q, spp);
+#pragma omp parallel for schedule(static)
+    for (long idx = 0; idx < P * batch; ++idx) {
+        long b = idx / P, p = idx % P;
+        int i = (int)(p / W), j = (int)(p % W);
+        real wo[3], nh[3], nsh[3];
+        oracle_view_dir(i, j, H, W, fov_x_deg, wo);
+        unit_normal(n + idx * 3, nh);
+        unit_normal(n_s + idx * 3, nsh);
+        split_pixel_frozen(wo, nh, a + idx * 3, r[idx], m[idx], nsh, r_s[idx], light + b * MATPBR_NSH * 3, &q, out + idx * 3);
+    }
+}
+/* Per-pixel radiance transfer of the production estimator: R[c] = sum_k light[k][c] T[k][c]; T[B,H,W,25,3]. */
+void oracle_shade_transfer(const real* a, const real* r, const real* m, const real* n, real* T, int H, int W, int batch, int spp,
+                           real fov_x_deg) {
+    const long P = (long)H * W;
+    real zero[MATPBR_NSH * 3];
+    memset(zero, 0, sizeof(zero));
+    Rules q;
+    rules_init(&q, spp);
+#pragma omp parallel for schedule(static)
+    for (long idx = 0; idx < P * batch; ++idx) {
+        long p = idx % P;
+        real wo[3], nh[3], ga[3], gr, gm, gn[3];
+        oracle_view_dir((int)(p / W), (int)(p % W), H, W, fov_x_deg, wo);
+        unit_normal(n + idx * 3, nh);
+        real* Tp = T + idx * MATPBR_NSH * 3;
+        memset(Tp, 0, sizeof(real) * MATPBR_NSH * 3);
+        const real one[3] = {R(1), R(1), R(1)};
+        split_pixel_bwd(wo, nh, a + idx * 3, r[idx], m[idx], zero, &q, one, ga, &gr, &gm, gn, Tp);
     }
 }
 
@@ -527,4 +916,5 @@ void oracle_sh_basis_dir_batch(long N, const real* w, real* Y) {
 void oracle_sample_table(int spp, real* u /*[spp/2,2]*/) {
     for (int i = 0; i < spp / 2; ++i) oracle_sample_point(spp, i, u + 2 * i, u + 2 * i + 1);
 }
+int oracle_rule_max(void) { return ORACLE_MAX_RULE; }
 int oracle_sizeof_real(void) { return (int)sizeof(real); }

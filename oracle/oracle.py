@@ -152,13 +152,41 @@ class Oracle:
         return u
 
     # -- image level ---------------------------------------------------------------------------
-    def shade_fwd(self, a, r, m, n, light, spp, fov_deg=35.0):
+    # kind: 0 = the production estimator, 1 = the reference-literal MIS estimator (yardstick)
+    def shade_fwd(self, a, r, m, n, light, spp, fov_deg=35.0, kind=0):
         a, r, m, n, light = map(self._a, (a, r, m, n, light))
         B, H, W = self._bhw(a)
         out = np.empty_like(a)
-        self.lib.oracle_shade_fwd(*map(self._p, (a, r, m, n, light, out)), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(B),
-                                  ctypes.c_int(spp), self._r(fov_deg))
+        self.lib.oracle_shade_fwd_kind(*map(self._p, (a, r, m, n, light, out)), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(B),
+                                       ctypes.c_int(spp), self._r(fov_deg), ctypes.c_int(kind))
         return out
+
+    def shade_fwd_win(self, a, r, m, n, light, spp, H, W, i0, j0, fov_deg=35.0, kind=0):
+        """Render of the h x w window at (i0, j0) of an H x W image (maps are the window's)."""
+        a, r, m, n, light = map(self._a, (a, r, m, n, light))
+        B, h, w = self._bhw(a)
+        out = np.empty_like(a)
+        self.lib.oracle_shade_fwd_win(*map(self._p, (a, r, m, n, light, out)), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(B),
+                                      ctypes.c_int(spp), self._r(fov_deg), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(i0),
+                                      ctypes.c_int(j0), ctypes.c_int(kind))
+        return out
+
+    def shade_fwd_lanes(self, a, r, m, n, wo, light, spp, kind=0):
+        """N lanes with explicit view directions wo[N,3] under one light[25,3]."""
+        a, r, m, n, wo, light = map(self._a, (a, r, m, n, wo, light))
+        out = np.empty_like(a)
+        self.lib.oracle_shade_fwd_lanes(*map(self._p, (a, r, m, n, wo, light, out)), ctypes.c_long(a.shape[0]), ctypes.c_int(spp),
+                                        ctypes.c_int(kind))
+        return out
+
+    def shade_bwd_lanes(self, a, r, m, n, wo, light, d_out, spp, kind=0):
+        a, r, m, n, wo, light, d_out = map(self._a, (a, r, m, n, wo, light, d_out))
+        d_a, d_n = np.empty_like(a), np.empty_like(n)
+        d_r, d_m = np.empty_like(r), np.empty_like(m)
+        d_l = np.empty_like(light)
+        self.lib.oracle_shade_bwd_lanes(*map(self._p, (a, r, m, n, wo, light, d_out, d_a, d_r, d_m, d_n, d_l)), ctypes.c_long(a.shape[0]),
+                                        ctypes.c_int(spp), ctypes.c_int(kind))
+        return d_a, d_r, d_m, d_n, d_l
 
     def shade_fwd_frozen(self, a, r, m, n, n_s, r_s, light, spp, fov_deg=35.0):
         """Forward with sample directions / pdf frozen at (n_s, r_s): the function whose gradient shade_bwd returns."""
@@ -169,7 +197,7 @@ class Oracle:
                                          ctypes.c_int(B), ctypes.c_int(spp), self._r(fov_deg))
         return out
 
-    def shade_bwd(self, a, r, m, n, light, d_out, spp, fov_deg=35.0, want_n=True, want_light=True):
+    def shade_bwd(self, a, r, m, n, light, d_out, spp, fov_deg=35.0, want_n=True, want_light=True, kind=0):
         a, r, m, n, light, d_out = map(self._a, (a, r, m, n, light, d_out))
         B, H, W = self._bhw(a)
         d_a = np.empty_like(a)
@@ -177,9 +205,42 @@ class Oracle:
         d_m = np.empty_like(m)
         d_n = np.empty_like(n) if want_n else None
         d_l = np.empty_like(light) if want_light else None
-        self.lib.oracle_shade_bwd(*map(self._p, (a, r, m, n, light, d_out, d_a, d_r, d_m, d_n, d_l)), ctypes.c_int(H),
-                                  ctypes.c_int(W), ctypes.c_int(B), ctypes.c_int(spp), self._r(fov_deg))
+        self.lib.oracle_shade_bwd_kind(*map(self._p, (a, r, m, n, light, d_out, d_a, d_r, d_m, d_n, d_l)), ctypes.c_int(H),
+                                       ctypes.c_int(W), ctypes.c_int(B), ctypes.c_int(spp), self._r(fov_deg), ctypes.c_int(kind))
         return d_a, d_r, d_m, d_n, d_l
+
+    def diffuse_cache(self, n, light, spp, fov_deg=35.0):
+        """A0, A1, A2 (rgb each) of the diffuse lobe per pixel: [..., 9]."""
+        n, light = self._a(n), self._a(light)
+        B, H, W = self._bhw(n)
+        out = np.empty(n.shape[:-1] + (9,), self.dtype)
+        self.lib.oracle_diffuse_cache(self._p(n), self._p(light), self._p(out), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(B),
+                                      ctypes.c_int(spp), self._r(fov_deg))
+        return out
+
+    def shade_fwd_cached(self, a, r, m, n, light, dcache, spp, fov_deg=35.0):
+        a, r, m, n, light, dcache = map(self._a, (a, r, m, n, light, dcache))
+        B, H, W = self._bhw(a)
+        out = np.empty_like(a)
+        self.lib.oracle_shade_fwd_cached(*map(self._p, (a, r, m, n, light, dcache, out)), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(B),
+                                         ctypes.c_int(spp), self._r(fov_deg))
+        return out
+
+    def shade_transfer(self, a, r, m, n, spp, fov_deg=35.0):
+        """Per-pixel radiance transfer T[..., 25, 3]: render = sum_k light[k] * T[k]."""
+        a, r, m, n = map(self._a, (a, r, m, n))
+        B, H, W = self._bhw(a)
+        T = np.empty(a.shape[:-1] + (NSH, 3), self.dtype)
+        self.lib.oracle_shade_transfer(*map(self._p, (a, r, m, n, T)), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(B), ctypes.c_int(spp),
+                                       self._r(fov_deg))
+        return T
+
+    def rule(self, spp, lobe):
+        """(u0, u1, w) of the production quadrature rule of lobe 0 (diffuse) / 1 (specular)."""
+        nmax = self.lib.oracle_rule_max()
+        u0, u1, w = (np.empty(nmax, self.dtype) for _ in range(3))
+        n = self.lib.oracle_rule(ctypes.c_int(spp), ctypes.c_int(lobe), self._p(u0), self._p(u1), self._p(w))
+        return u0[:n].copy(), u1[:n].copy(), w[:n].copy()
 
     def normals_from_depth(self, depth, fov_deg=35.0):
         depth = self._a(depth)
