@@ -18,7 +18,7 @@
  *   - Return value: 0 = MATPBR_OK, negative = error (matpbr_strerror); nothing throws.
  *   - `spp` (even, 2..MATPBR_MAX_SPP) is the reference's samples-per-pixel argument
  *     (inverse_img_w_mi.py:59,69,625): here it sizes the deterministic quadrature rules of the two BRDF lobes
- *     (spp = 64 -> 4 x 4 GGX half vectors + 3 x 6 cosine-weighted directions), chosen so that the
+ *     (spp = 64 -> 5 x 4 GGX half vectors + 3 x 6 cosine-weighted directions), chosen so that the
  *     error against the converged integral is below that of spp random BSDF samples.
  */
 #ifndef MATPBR_H

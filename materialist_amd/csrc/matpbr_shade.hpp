@@ -68,11 +68,11 @@ inline void gauss_legendre01(int n, double* x, double* w) {   // ascending nodes
         w[n - 1 - i] = 1.0 / ((1.0 - z * z) * pp * pp);
     }
 }
-inline void rule_dims(int spp, int lobe, int& nu, int& nphi) {   // spp = 64 -> 4 x 4 specular, 3 x 6 diffuse
+inline void rule_dims(int spp, int lobe, int& nu, int& nphi) {   // spp = 64 -> 5 x 4 specular, 3 x 6 diffuse
     const double q = 0.25 * spp, s = std::sqrt(q);
     if (lobe) {
-        nu = std::max(1, (int)std::floor(s + 0.5));
-        nphi = std::max(1, (int)std::ceil(q / nu - 1e-9));
+        nu = (int)std::floor(s + 1.5);
+        nphi = std::max(1, (int)std::floor(s + 0.5));
     } else {
         nu = std::max(1, (int)std::floor(0.75 * s + 0.5));
         nphi = 2 * nu;

@@ -311,7 +311,7 @@ void oracle_sh_eval(const real w[3], const real* coef /*[25][3]*/, real L[3]) {
  *      square -- nu Gauss-Legendre nodes x nphi equally spaced azimuths, ring k rotated by vdC_2(k)/nphi;
  *      the specular lobe places its nodes v_k through u0 = 1 - (1 - v)^2 (weight 2 (1 - v)), which removes the
  *      square-root end-point behaviour of the integrand at u0 -> 1 (grazing half vectors).  Sizes follow `spp`:
- *      at the reference's spp = 64 (4 x 4 specular, 3 x 6 diffuse nodes) its error against the converged integral
+ *      at the reference's spp = 64 (5 x 4 specular, 3 x 6 diffuse nodes) its error against the converged integral
  *      is below the reference-literal estimator's at the same spp (tests/test_estimator_accuracy.py).
  * ---------------------------------------------------------------------------------------------- */
 static real vdc2(uint32_t i) {
@@ -351,7 +351,7 @@ static void gauss_legendre01(int n, double* x, double* w) {
         w[n - 1 - i] = 1.0 / ((1.0 - z * z) * pp * pp);
     }
 }
-/* spp -> (nu, nphi) of the specular (lobe 1) and diffuse (lobe 0) rules; spp = 64 -> 4 x 4 and 3 x 6 */
+/* spp -> (nu, nphi) of the specular (lobe 1) and diffuse (lobe 0) rules; spp = 64 -> 5 x 4 and 3 x 6 */
 static double g_rule_power = 2.0;    /* specular lobe: u0 = 1 - (1-v)^2 at the Gauss-Legendre nodes v (other powers: studies only) */
 void oracle_rule_power(double p) { g_rule_power = p; }
 static int g_rule_override[2][2];   /* quadrature studies only (tools/quadrature_study.py): 0 = use the production sizes */
@@ -360,9 +360,8 @@ void oracle_rule_dims(int spp, int lobe, int* nu, int* nphi) {
     double q = 0.25 * (double)spp, s = sqrt(q);
     if (g_rule_override[lobe][0] > 0) { *nu = g_rule_override[lobe][0]; *nphi = g_rule_override[lobe][1]; return; }
     if (lobe) {
-        *nu = (int)floor(s + 0.5);
-        if (*nu < 1) *nu = 1;
-        *nphi = (int)ceil(q / (double)*nu - 1e-9);
+        *nu = (int)floor(s + 1.5);
+        *nphi = (int)floor(s + 0.5);
         if (*nphi < 1) *nphi = 1;
     } else {
         *nu = (int)floor(0.75 * s + 0.5);
