@@ -2,18 +2,25 @@
 """Headline benchmark: optimisation iterations/s of the PBR shading hot path at 512x512.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one optimisation iteration (epoch) of hot loop B of BASELINE config 2 (`--model_name pos_mlp --opt_order 'rm a'`,
-inverse_img_w_mi.py:470-590): material maps from the residual PosMLP (f32-MFMA sine-layer kernels of libmatpbr.so) -> shade_fwd -> gamma-2.2 MSE/L1
-loss with mean-ratio scaling -> shade_bwd -> AdamW, everything downstream of the maps in libmatpbr.so, inputs resident in
-HBM.  `--mode fused` times the same loop in `--model_name none` mode (maps optimised directly, whole iteration in
-libmatpbr.so); both rates are reported in every run (`modes`).  Images are independent, so ranks never communicate inside
-the timed region (weak scaling: `images_per_gpu` per rank).  Rank 0 prints ONE JSON line.
+With N > 1 and no torchrun environment, this process only LAUNCHES the ranks (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`, one rank per GPU over RCCL) and exits with their code; it never
+touches the GPU itself.  Under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank.
+
+One "step" = one optimisation iteration (epoch) of hot loop B of BASELINE configs[1] (`--model_name pos_mlp --opt_order 'rm a'`,
+inverse_img_w_mi.py:470-590): material maps from the residual PosMLP (f32-MFMA sine-layer kernels of libmatpbr.so) -> render
+(GGX-lobe samples; diffuse-lobe coefficients cached for the phase) -> gamma-2.2 MSE/L1 loss with mean-ratio scaling ->
+streaming backward -> AdamW, everything downstream of the maps in libmatpbr.so, inputs resident in HBM.  `modes` reports the
+other loops of the pipeline measured in the same run: `fused` (`--model_name none`, whole iteration in libmatpbr.so), `fused_b8`
+(BASELINE configs[2]'s per-GPU shard: 8 images x 512x512 in the kernels' batch dimension), `env` (hot loop A on the radiance
+transfer).  Images are independent, so ranks never communicate inside the timed region (weak scaling: `images_per_gpu` per rank).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,23 +30,41 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_FWD = 44             # read a 12 + r 4 + m 4 + n 12, write rgb 12
 BYTES_BWD_ARM = 64         # read a,r,m,n 32 + d_rgb 12, write d_a 12 + d_r 4 + d_m 4
+BYTES_ENV = 312            # hot loop A on the transfer: read T 300 + gt 12 per pixel (pred not written)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel; the reference renders with spp=64 (inverse_img_w_mi.py:625)")
     ap.add_argument("--images-per-gpu", type=int, default=1)
-    ap.add_argument("--mode", choices=["fused", "torch", "pos_mlp"], default="pos_mlp",
-                    help="fused: --model_name none, whole iteration in libmatpbr.so; torch: same step composed from torch ops; "
-                         "pos_mlp: the reference's default mode (maps from the residual PosMLP, its sine layers + render/loss/backward in libmatpbr.so)")
+    ap.add_argument("--mode", choices=["fused", "torch", "pos_mlp"], default=None,
+                    help="default: pos_mlp (the reference's default mode: maps from the residual PosMLP) for one image per GPU, fused "
+                         "(--model_name none, whole iteration in libmatpbr.so) for a batch; torch: the none-mode step composed from torch ops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-relight", action="store_true", help="skip the 2048x2048 relighting measurement (1.3 GB transfer buffer)")
+    ap.add_argument("--no-extras", action="store_true", help="headline mode only (no other loops, no kernel roofline legs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="exercise the launcher and the timing protocol with a CPU stand-in step over gloo (tests/test_bench_launcher.py)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Start one rank per GPU under torch.distributed.run as a CHILD process (never exec: this process may not touch the GPU, and
+    a process that did must not be replaced) and return its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(size, spp, target_s):
@@ -74,11 +99,70 @@ def cpu_baseline(size, spp, target_s):
     its = reps * (n * n) / (size * size) / t
     return {"value": its, "unit": "it/s", "cores": cores, "kind": "port",
             "sample": f"oracle f32+OpenMP shade fwd+bwd(arm), {reps} x ({n}x{n} crop of the {size}x{size} spp={spp} image), {t:.1f}s, scaled by pixels; "
-                      "CPU restatement of the reference BRDF path (not Mitsuba)"}
+                      "CPU restatement of the reference BRDF path (same estimator as the kernels; not Mitsuba)"}
 
 
-def main():
-    args = parse()
+class _Protocol:
+    """The timing contract: W untimed steps, then EXACTLY K steps between barrier + synchronize fences, MAX over ranks."""
+
+    def __init__(self, dist, world, device, sync):
+        self.dist, self.world, self.device, self.sync = dist, world, device, sync
+
+    def fence(self):
+        self.sync()
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
+
+    def timed(self, step, warmup, steps):
+        import torch
+
+        for _ in range(warmup):
+            step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        mine = time.perf_counter() - t0
+        el = torch.tensor([mine], dtype=torch.float64, device=self.device)
+        per_rank = [mine]
+        if self.world > 1:
+            bufs = [torch.zeros_like(el) for _ in range(self.world)]
+            self.dist.all_gather(bufs, el)
+            per_rank = [float(b.item()) for b in bufs]
+        return max(per_rank), per_rank
+
+
+def selftest_cpu(args):
+    """The launcher + protocol on CPU (gloo): a numpy stand-in for the step.  Not a benchmark."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = np.random.default_rng(rank).random((64, 64))
+    proto = _Protocol(dist, world, torch.device("cpu"), lambda: None)
+    elapsed, per_rank = proto.timed(lambda: x @ x, args.warmup, args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "selftest_cpu_steps_per_sec", "value": args.steps * world / elapsed, "unit": "it/s", "n_gpus": world,
+                          "world_size": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+                          "ranks": [{"rank": r, "it_per_s": args.steps / t} for r, t in enumerate(per_rank)]}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))          # before anything touches the GPU in this process
+    if args.selftest_cpu:
+        return selftest_cpu(args)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -86,6 +170,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the CPU baseline runs BEFORE the GPU legs (rank 0, N = 1 only): the GPU work then sits at the end of the run
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(args.size, args.spp, args.cpu_seconds)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -97,94 +185,89 @@ def main():
     from materialist_amd.dist import shard_range
 
     H = W = args.size
-    B = args.images_per_gpu
-    lo, hi = shard_range(world * B, world, rank)     # contiguous shard of independent images
-    scenes = [synthetic.make_scene(i, H, W) for i in range(lo, hi)]
-    t = lambda xs: torch.from_numpy(np.stack(xs) if B > 1 else xs[0]).to(dev)
-    depth = t([s.depth for s in scenes])
-    gt_a, gt_r, gt_m = t([s.albedo for s in scenes]), t([s.roughness for s in scenes]), t([s.metallic for s in scenes])
-    light = t([s.light for s in scenes])
-    scene = render.load_estimated_mesh(depth, use_mesh_normal=True)
-    scene._set("emitter.data", light)                # BRDF phase renders under the current best light (:317-334)
-    with torch.no_grad():
-        gt_image = render.render_w_brdf(scene, gt_a, gt_r, gt_m, None, args.spp)
-    init = (t([s.init_albedo for s in scenes]), t([s.init_roughness for s in scenes]), t([s.init_metallic for s in scenes]))
-    if args.mode == "pos_mlp" and B > 1:
-        args.mode = "fused"                      # the MLP modes optimise one image per process; a batch runs the none-mode loop
+    proto = _Protocol(dist, world, dev, torch.cuda.synchronize)
+    mode = args.mode or ("pos_mlp" if args.images_per_gpu == 1 else "fused")
+    if mode == "pos_mlp" and args.images_per_gpu > 1:
+        raise SystemExit("--mode pos_mlp optimises one image per process (use --mode fused for --images-per-gpu > 1)")
 
-    def make_phase(mode):
-        if mode == "fused":
-            return loop.FusedBrdfPhase(scene, gt_image, *init, optimize_part="rm", spp=args.spp)
-        if mode == "pos_mlp":
-            from materialist_amd import posmlp
+    class Workload:
+        """B independent synthetic images of this rank's shard, resident in HBM, and the phases that iterate on them."""
 
-            net = posmlp.brdf_net("arm").to(dev)
-            start_arm = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1)], -1).clamp(0, 1)
-            ph = loop.PosMlpBrdfPhase(scene, gt_image, net, start_arm, {"albedo": init[0], "roughness": init[1], "metallic": init[2]},
-                                      optimize_part="rm", spp=args.spp)
-            ph.current_maps = lambda: (lambda m: {"albedo": m["albedo"].detach().clamp(0, 1), "roughness": m["roughness"].detach().clamp(0.07, 1),
-                                                  "metallic": m["metallic"].detach().clamp(0, 1)})(ph.maps_from_net()[0])
-            return ph
-        if mode == "env":
-            from materialist_amd import posmlp
+        def __init__(self, B):
+            self.B = B
+            lo, hi = shard_range(world * B, world, rank)     # contiguous shard of independent images (SURVEY.md 8e)
+            self.lo = lo
+            scenes = [synthetic.make_scene(i, H, W) for i in range(lo, hi)]
+            t = lambda xs: torch.from_numpy(np.stack(xs) if B > 1 else xs[0]).to(dev)
+            self.depth = t([s.depth for s in scenes])
+            self.gt = tuple(t([getattr(s, k) for s in scenes]) for k in ("albedo", "roughness", "metallic"))
+            self.light = t([s.light for s in scenes])
+            self.scene = render.load_estimated_mesh(self.depth, use_mesh_normal=True)
+            self.scene._set("emitter.data", self.light)      # BRDF phase renders under the current best light (:317-334)
+            with torch.no_grad():
+                self.gt_image = render.render_w_brdf(self.scene, *self.gt, None, args.spp)
+            self.init = tuple(t([getattr(s, k) for s in scenes]) for k in ("init_albedo", "init_roughness", "init_metallic"))
 
-            s_env = render.load_estimated_mesh(depth, use_mesh_normal=True)
-            pr = render.traverse(s_env)
-            pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = gt_a, gt_r, gt_m
-            enet = posmlp.envmap_net().to(dev)
-            ones = torch.ones(512, 3, device=dev)
-            return loop.FusedEnvPhase(s_env, gt_image, lambda: enet(ones).reshape(16, 32, 3), loop.capturable_adam(enet.parameters(), 1e-3),
-                                      spp=args.spp, use_graph=True)     # whole iteration replayed from a hipGraph after 3 eager ones
-        return loop.BrdfPhase(scene, gt_image, *init, None, optimize_part="rm", spp=args.spp)
+        def phase(self, mode):
+            if mode == "fused":
+                return loop.FusedBrdfPhase(self.scene, self.gt_image, *self.init, optimize_part="rm", spp=args.spp)
+            if mode == "pos_mlp":
+                from materialist_amd import posmlp
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+                net = posmlp.brdf_net("arm").to(dev)
+                init = self.init
+                start_arm = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1)], -1).clamp(0, 1)
+                ph = loop.PosMlpBrdfPhase(self.scene, self.gt_image, net, start_arm, {"albedo": init[0], "roughness": init[1], "metallic": init[2]},
+                                          optimize_part="rm", spp=args.spp)
+                ph.current_maps = lambda: (lambda m: {"albedo": m["albedo"].detach().clamp(0, 1), "roughness": m["roughness"].detach().clamp(0.07, 1),
+                                                      "metallic": m["metallic"].detach().clamp(0, 1)})(ph.maps_from_net()[0])
+                return ph
+            if mode == "env":
+                from materialist_amd import posmlp
 
-    def timed(ph, warmup, steps):
-        for _ in range(warmup):
-            ph.step()
-        fence()
-        t0 = time.perf_counter()
-        with ops.KernelTimer() as kt:
-            for _ in range(steps):
-                ph.step()
-            fence()
-            el_ = time.perf_counter() - t0
-            ks = kt.summary()
-        el = torch.tensor([el_], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        return float(el.item()), ks
+                s_env = render.load_estimated_mesh(self.depth, use_mesh_normal=True)
+                pr = render.traverse(s_env)
+                pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = self.gt
+                enet = posmlp.envmap_net().to(dev)
+                ones = torch.ones(512, 3, device=dev)
+                return loop.FusedEnvPhase(s_env, self.gt_image, lambda: enet(ones).reshape(16, 32, 3), loop.capturable_adam(enet.parameters(), 1e-3),
+                                          spp=args.spp, use_graph=True, keep_pred=False)     # whole iteration replayed from a hipGraph after 3 eager ones
+            return loop.BrdfPhase(self.scene, self.gt_image, *self.init, None, optimize_part="rm", spp=args.spp)
 
-    phase = make_phase(args.mode)
-    psnr0 = float(loop._loss.psnr(render.render_w_brdf(scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), gt_image).mean())
-    elapsed, ksum = timed(phase, args.warmup, args.steps)
-    total_units = args.steps * B * world
-    value = total_units / elapsed
-
+    wl = Workload(args.images_per_gpu)
+    B = wl.B
+    phase = wl.phase(mode)
+    psnr0 = float(loop._loss.psnr(render.render_w_brdf(wl.scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), wl.gt_image).mean())
+    elapsed, per_rank = proto.timed(phase.step, args.warmup, args.steps)
+    value = args.steps * B * world / elapsed
     m = phase.current_maps()
     with torch.no_grad():
-        final = render.render_w_brdf(scene, m["albedo"].detach(), m["roughness"].detach(), m["metallic"].detach(), None, args.spp)
-    psnr1 = float(loop._loss.psnr(final, gt_image).mean())
+        final = render.render_w_brdf(wl.scene, m["albedo"].detach(), m["roughness"].detach(), m["metallic"].detach(), None, args.spp)
+    psnr1 = float(loop._loss.psnr(final, wl.gt_image).mean())
 
-    # the other loops of the same pipeline, short runs, for the record (same fences; whole-job rates)
-    modes = {args.mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3}}
-    for extra in ("fused", "pos_mlp", "env"):
-        if extra == args.mode or (extra != "fused" and B > 1) or args.mode == "torch":
-            continue
-        e_el, _ = timed(make_phase(extra), 5, 40)
-        modes[extra] = {"it_per_s": 40 * B * world / e_el, "ms_per_step": e_el / 40 * 1e3}
-    mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so)",
+    # the other loops of the same pipeline, for the record (same fences; whole-job rates over all ranks)
+    modes = {mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3, "images_per_gpu": B}}
+    wl8 = None
+    if not args.no_extras and mode != "torch":
+        for extra, steps in (("fused", 2000), ("pos_mlp", 100), ("env", 500)):
+            if extra == mode or (extra != "fused" and B > 1):
+                continue
+            e_el, _ = proto.timed(wl.phase(extra).step, 10, steps)
+            modes[extra] = {"it_per_s": steps * B * world / e_el, "ms_per_step": e_el / steps * 1e3, "images_per_gpu": B}
+        if B != 8 and H * W <= 512 * 512:
+            wl8 = Workload(8)                 # BASELINE configs[2]: 64 images, 8 per GPU; this is one GPU's shard (every rank runs its own)
+            e_el, _ = proto.timed(wl8.phase("fused").step, 10, 300)
+            modes["fused_b8"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
+    mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so: render+jac, loss statistics, streaming backward+Adam)",
+                  "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
                   "pos_mlp": "hot loop B, --model_name pos_mlp (PosMLP sine layers, render, loss, backward in libmatpbr.so; autograd glue in torch)",
-                  "env": "hot loop A, envmap PosMLP head + matpbr_env_phase_step", "torch": "hot loop B composed from torch ops"}
+                  "env": "hot loop A, envmap PosMLP head (torch, hipGraph) + matpbr_env_phase_step on the radiance transfer",
+                  "torch": "hot loop B composed from torch ops"}
     modes = {k: dict(v, what=mode_names[k]) for k, v in modes.items()}
 
-    # kernel durations for the roofline: 20 back-to-back launches between two HIP events on the launch stream (per-launch
-    # event pairs inside the loop also time the inter-launch gap; they are reported as *_inloop_ms for reference)
-    def back_to_back(fn, reps=20):
+    # kernel durations for the roofline: back-to-back launches between two HIP events on the launch stream (torch's current
+    # stream, the one the C ABI is handed)
+    def back_to_back(fn, reps=50):
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -195,26 +278,95 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    mm = {k: v.detach().contiguous() for k, v in phase.current_maps().items() if v is not None}
-    nrm, lgt = scene.shading_normal(), (scene.light if scene.light.ndim == 3 or B == 1 else scene.light.unsqueeze(0).expand(B, -1, -1).contiguous())
-    d_probe = torch.randn_like(gt_image)
-    ms_f = back_to_back(lambda: ops.shade_fwd(mm["albedo"], mm["roughness"], mm["metallic"], nrm, lgt, args.spp))
-    ms_b = back_to_back(lambda: ops.shade_bwd(mm["albedo"], mm["roughness"], mm["metallic"], nrm, lgt, d_probe, args.spp, want_mat=True))
+    roof = None
+    if not args.no_extras:
+        def kernel_times(w):
+            """The BRDF fwd / bwd kernels on workload w: in-loop pair (cached diffuse lobe + jac, streaming loss backward) and the
+            stand-alone operator pair (everything in-kernel)."""
+            mm = [x.contiguous() for x in w.init]
+            nrm = w.scene.shading_normal().contiguous()
+            lgt = (w.scene.light if (w.scene.light.ndim == 3 or w.B == 1) else w.scene.light.unsqueeze(0).expand(w.B, -1, -1)).contiguous()
+            dcache, jac = ops.diffuse_cache(nrm, lgt, args.spp), ops.plane9(mm[0])
+            pred = torch.empty_like(w.gt_image)
+            gt_srgb = loop._loss.linear_to_srgb(w.gt_image).contiguous()
+            stats = ops.new_loss_stats(w.B, dev)
+            g = [torch.empty_like(x) for x in mm]
+            d_probe = torch.randn_like(w.gt_image)
+            ops.shade_fwd(*mm, nrm, lgt, args.spp, clamp_params=True, out=pred, dcache=dcache, jac=jac)
+            ops.brdf_loss_stats(pred, w.gt_image, gt_srgb, *mm, *mm, 0.1, stats, None, optimize_part="rm")
+            t = {"fwd_loop": back_to_back(lambda: ops.shade_fwd(*mm, nrm, lgt, args.spp, clamp_params=True, out=pred, dcache=dcache, jac=jac)),
+                 "bwd_loop": back_to_back(lambda: ops.brdf_loss_bwd_jac(*mm, jac, pred, gt_srgb, stats, *mm, 0.1, *g, optimize_part="rm")),
+                 "fwd_op": back_to_back(lambda: ops.shade_fwd(*mm, nrm, lgt, args.spp, out=pred), 20),
+                 "bwd_op": back_to_back(lambda: ops.shade_bwd(*mm, nrm, lgt, d_probe, args.spp, want_mat=True), 20),
+                 "diffuse_cache": back_to_back(lambda: ops.diffuse_cache(nrm, lgt, args.spp, out=dcache), 20)}
+            return t
+
+        def entry(px, t_f, t_b, note):
+            ach = lambda nbytes, ms: nbytes * px / (ms * 1e-3) / 1e9
+            e = {"achieved": ach(BYTES_FWD + BYTES_BWD_ARM, t_f + t_b), "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM, "avg_launch_ms": t_f + t_b,
+                 "fwd": {"achieved": ach(BYTES_FWD, t_f), "frac": ach(BYTES_FWD, t_f) / (HBM_PEAK / 1e9), "avg_launch_ms": t_f, "bytes_per_pixel": BYTES_FWD},
+                 "bwd": {"achieved": ach(BYTES_BWD_ARM, t_b), "frac": ach(BYTES_BWD_ARM, t_b) / (HBM_PEAK / 1e9), "avg_launch_ms": t_b,
+                         "bytes_per_pixel": BYTES_BWD_ARM}, "note": note}
+            e["frac"] = e["achieved"] / (HBM_PEAK / 1e9)
+            return e
+
+        wr = wl8 if wl8 is not None else wl
+        tk = kernel_times(wr)
+        px = H * W * wr.B
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"brdf_fwd+bwd_{H}x{W}_b{wr.B}_spp{args.spp}")
+                tsrc = tj.get("source")
+            except Exception:
+                traffic = None
+        roof = entry(px, tk["fwd_loop"], tk["bwd_loop"],
+                     "the in-loop pair of hot loop B: shade_kernel<jac> with the phase's cached diffuse-lobe coefficients (20 GGX samples per pixel) "
+                     "and jac_bwd_kernel<fused> (streaming; no samples); algorithmic bytes = SURVEY 8d's 44 + 64 B/pixel, the kernels also move "
+                     "the 9-float dcache / jac planes (traffic).  The forward is VALU-issue-bound (DESIGN.md section 4)")
+        roof.update({"bound": "hbm", "kernel": "shade_kernel<jac> + jac_bwd_kernel<fused>", "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
+                     "traffic": traffic, "traffic_source": tsrc,
+                     "operator_face": entry(px, tk["fwd_op"], tk["bwd_op"],
+                                            "stand-alone matpbr_shade_fwd / matpbr_shade_bwd<mat>: both lobes sampled in-kernel (18 + 20 directions)"),
+                     "diffuse_cache_ms": tk["diffuse_cache"]})
+        if wr is not wl:
+            tk1 = kernel_times(wl)
+            roof["single_image"] = entry(H * W * wl.B, tk1["fwd_loop"], tk1["bwd_loop"], f"the same in-loop pair on {wl.B} x {H}x{W}")
+        # hot loop A: one pass over the radiance transfer per iteration (HBM-bound by construction)
+        ph_e = wl.phase("env") if B == 1 else None
+        if ph_e is not None:
+            lc = wl.light.contiguous()
+            P_ = lambda t: None if t is None else __import__("ctypes").c_void_p(t.data_ptr())
+            from materialist_amd import _lib
+            lib = _lib.load()
+
+            def env_call():
+                lib.matpbr_env_phase_step(P_(ph_e.T), P_(lc), P_(ph_e.gt_srgb), None, P_(ph_e.d_light), P_(ph_e.stats), None, 0, 0, 0.0, P_(ph_e.ws),
+                                          ph_e.ws.numel() * 4, H, W, 1, __import__("ctypes").c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            ms_e = back_to_back(env_call)
+            roof["env_prt"] = {"bound": "hbm", "kernel": "env_prt_kernel + env_final_kernel (render, loss, d_light in one pass over T)",
+                               "achieved": BYTES_ENV * H * W / (ms_e * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "avg_launch_ms": ms_e,
+                               "bytes_per_pixel": BYTES_ENV}
+            roof["env_prt"]["frac"] = roof["env_prt"]["achieved"] / roof["env_prt"]["peak"]
+            del ph_e
 
     # the PosMLP side of the pos_mlp iteration: nine [H*W,256]x[256,256] products per iteration on the exact-f32 MFMA, in the
     # hand-written kernels of libmatpbr.so (epilogues included); the BLAS product of the same shape is timed beside them
     gemm = None
-    if B == 1:
+    if B == 1 and not args.no_extras:
         Mg = H * W
         xg, gg = torch.randn(Mg, 256, device=dev), torch.randn(Mg, 256, device=dev)
         wg, bg = torch.randn(256, 256, device=dev) / 16, torch.randn(256, device=dev)
         sg, cg, gp = (torch.empty(Mg, 256, device=dev) for _ in range(3))
         dbg = torch.empty(256, device=dev)
         flop = 2.0 * Mg * 256 * 256
-        ms_fwd = back_to_back(lambda: ops.mlp_layer_fwd(xg, wg, bg, sg, cg, 256))
-        ms_din = back_to_back(lambda: ops.mlp_layer_bwd_input(gg, wg, cg, gp, 256, 256, dbg))
-        ms_dw = back_to_back(lambda: ops.mlp_layer_bwd_weight(gg, xg, 256, 256))
-        ms_g = back_to_back(lambda: torch.mm(xg, wg))
+        ms_fwd = back_to_back(lambda: ops.mlp_layer_fwd(xg, wg, bg, sg, cg, 256), 20)
+        ms_din = back_to_back(lambda: ops.mlp_layer_bwd_input(gg, wg, cg, gp, 256, 256, dbg), 20)
+        ms_dw = back_to_back(lambda: ops.mlp_layer_bwd_weight(gg, xg, 256, 256), 20)
+        ms_g = back_to_back(lambda: torch.mm(xg, wg), 20)
         tf = lambda ms: flop / (ms * 1e-3) / 1e12
         gemm = {"bound": "mfma", "kernel": "mlp_gemm_nt_pipe<sincos> / <mul cos> / mlp_wgrad_tn: [H*W,256]x[256,256] on v_mfma_f32_32x32x2_f32",
                 "achieved": 3 * flop / ((ms_fwd + ms_din + ms_dw) * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
@@ -227,9 +379,9 @@ def main():
 
     # BASELINE configs[4]: forward-only relighting, 2048x2048, 360 lights, through the precomputed transfer (HBM-bound kernel)
     relight = None
-    if B == 1 and not args.no_relight:
+    if B == 1 and not args.no_relight and not args.no_extras:
         RS = 2048
-        scr = synthetic.make_scene(lo, RS, RS)
+        scr = synthetic.make_scene(wl.lo, RS, RS)
         tr = lambda x: torch.from_numpy(x).to(dev)
         n_r = ops.normals_from_depth(tr(scr.depth))
         T_r = ops.shade_transfer(tr(scr.albedo), tr(scr.roughness), tr(scr.metallic), n_r, args.spp)
@@ -252,41 +404,24 @@ def main():
         del T_r, out_r, L_r
 
     if rank == 0:
-        px = H * W * B
-        ms_f_in = ksum.get("shade_fwd", (0, None))[1]      # None (JSON null) when the mode issues no stand-alone launch of that kernel
-        ms_b_in = ksum.get("shade_bwd", (0, None))[1]
-        ach_b = BYTES_BWD_ARM * px / (ms_b * 1e-3) / 1e9
-        ach_f = BYTES_FWD * px / (ms_f * 1e-3) / 1e9
-        ach_fb = (BYTES_FWD + BYTES_BWD_ARM) * px / ((ms_f + ms_b) * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"shade_bwd_{H}x{W}_b{B}_spp{args.spp}")
-            except Exception:
-                traffic = None
-        # VALU issue model: lane-instructions per pixel-sample counted from the ISA
         out = {
-            "metric": "opt_iterations_per_sec_512x512", "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+            "metric": "opt_iterations_per_sec_512x512", "value": value, "unit": "it/s", "n_gpus": world,
+            "world_size": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2-synthetic (BASELINE configs[1]): {H}x{W}, one epoch of hot loop B, part 'rm' of --opt_order 'rm a', "
-                                   f"{'--model_name pos_mlp' if args.mode == 'pos_mlp' else '--model_name none'} "
-                                   f"(maps -> shade_fwd -> gamma-2.2 MSE/L1 loss -> shade_bwd -> Adam(W)), spp={args.spp}, geometric normals, SH25 light",
-                       "mode": args.mode, "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25"},
+                                   f"{'--model_name pos_mlp' if mode == 'pos_mlp' else '--model_name none'} "
+                                   f"(maps -> render -> gamma-2.2 MSE/L1 loss -> backward -> Adam(W)), spp={args.spp}, geometric normals, SH25 light",
+                       "mode": mode, "mode_requested": args.mode, "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25"},
+            "ranks": [{"rank": r, "it_per_s": args.steps * B / t} for r, t in enumerate(per_rank)],
             "modes": modes,
-            "roofline": {"bound": "hbm", "kernel": "shade_bwd_kernel<mat>", "achieved": ach_b, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach_b / (HBM_PEAK / 1e9), "traffic": traffic,
-                         "bytes_per_pixel": BYTES_BWD_ARM, "avg_launch_ms": ms_b, "avg_launch_inloop_ms": ms_b_in,
-                         "note": "canonical unfused shade_bwd<mat> on the same maps; the kernel is VALU-issue-bound at spp=64 (DESIGN.md section 4)",
-                         "shade_fwd": {"achieved": ach_f, "frac": ach_f / (HBM_PEAK / 1e9), "avg_launch_ms": ms_f, "avg_launch_inloop_ms": ms_f_in,
-                                       "bytes_per_pixel": BYTES_FWD},
-                         "fwd+bwd": {"achieved": ach_fb, "frac": ach_fb / (HBM_PEAK / 1e9), "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM},
-                         "posmlp_gemm": gemm, "relight": relight},
             "psnr_db": {"initial_guess": psnr0, "after_timed_steps": psnr1, "vs": "own HIP render of the synthetic ground truth (Mitsuba cannot run, SURVEY F3)"},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(H, args.spp, args.cpu_seconds)
+        if roof is not None:
+            roof["posmlp_gemm"], roof["relight"] = gemm, relight
+            out["roofline"] = roof
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

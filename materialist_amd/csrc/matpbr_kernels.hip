@@ -162,10 +162,11 @@ __global__ __launch_bounds__(kBlock) void loss_final2_kernel(const float* __rest
 
 // Hot loop A: folds env_prt_kernel's per-workgroup partials (fixed order) into d_light and the statistics; the env phase's
 // loss is MSE + L1 (:244) = 3 (1/3) MSE + L1, ratio 1.
-__global__ __launch_bounds__(kBlock) void env_final_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                           float* __restrict__ d_light, int nblk, float inv_n3, int es_patience,
-                                                           float es_min_delta, float* __restrict__ history, int hist_len, int batch) {
-    __shared__ float s_red[3][kEnvPart];
+constexpr int kEnvFinalSlices = 13, kEnvFinalThreads = 1024;   // 13 x 77 = 1001 threads: partial rows are folded 13-way in parallel
+__global__ __launch_bounds__(kEnvFinalThreads) void env_final_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                                     float* __restrict__ d_light, int nblk, float inv_n3, int es_patience,
+                                                                     float es_min_delta, float* __restrict__ history, int hist_len, int batch) {
+    __shared__ float s_red[kEnvFinalSlices][kEnvPart];
     __shared__ int s_skip;
     const int b = blockIdx.x;
     float* st = stats + b * kStatsStride;
@@ -175,15 +176,25 @@ __global__ __launch_bounds__(kBlock) void env_final_kernel(const float* __restri
         if (threadIdx.x < kNL) d_light[(long)b * kNL + threadIdx.x] = 0.0f;
         return;
     }
-    const int col = threadIdx.x % kEnvPart, slice = threadIdx.x / kEnvPart;   // 3 slices of the partial rows x 77 columns
-    if (slice < 3) {
-        float v = 0.0f;
-        for (int i = slice; i < nblk; i += 3) v += part[((long)b * nblk + i) * kEnvPart + col];
-        s_red[slice][col] = v;
+    const int col = threadIdx.x % kEnvPart, slice = threadIdx.x / kEnvPart;
+    if (slice < kEnvFinalSlices) {
+        const float* __restrict__ p = part + (long)b * nblk * kEnvPart + col;
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+        int i = slice;
+        for (; i + 3 * kEnvFinalSlices < nblk; i += 4 * kEnvFinalSlices) {   // four independent loads in flight
+            v0 += p[(long)i * kEnvPart];
+            v1 += p[(long)(i + kEnvFinalSlices) * kEnvPart];
+            v2 += p[(long)(i + 2 * kEnvFinalSlices) * kEnvPart];
+            v3 += p[(long)(i + 3 * kEnvFinalSlices) * kEnvPart];
+        }
+        for (; i < nblk; i += kEnvFinalSlices) v0 += p[(long)i * kEnvPart];
+        s_red[slice][col] = (v0 + v1) + (v2 + v3);
     }
     __syncthreads();
     if (threadIdx.x < kEnvPart) {
-        const float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x];
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kEnvFinalSlices; ++k) v += s_red[k][threadIdx.x];
         if (threadIdx.x < kNL) d_light[(long)b * kNL + threadIdx.x] = v;
         s_red[0][threadIdx.x] = v;
     }
@@ -499,11 +510,11 @@ int matpbr_shade_fwd_ex(const float* a, const float* r, const float* m, const fl
     if (!make_geom(H, W, cam, g)) return MATPBR_ERR_INVALID_ARG;
     if (!fill_rule_table(spp, tab)) return MATPBR_ERR_UNSUPPORTED;
     ShadeArgs q{};
-    q.a = a; q.r = r; q.m = m; q.n = n; q.light = light; q.dcache = dcache; q.out = out_rgb; q.jac = jac;
+    q.a = a; q.r = r; q.m = m; q.n = n; q.dcache = dcache; q.out = out_rgb; q.jac = jac;
     q.clamp = (flags & MATPBR_FLAG_CLAMP_PARAMS) ? 1 : 0;
     dim3 grid((unsigned)grid_blocks(H, W), (unsigned)batch);
-    if (jac) hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, (hipStream_t)stream, q, g, tab);
-    else hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(kBlock), 0, (hipStream_t)stream, q, g, tab);
+    if (jac) hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, (hipStream_t)stream, q, light, g, tab);
+    else hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(kBlock), 0, (hipStream_t)stream, q, light, g, tab);
     return launch_status();
 }
 
@@ -557,8 +568,8 @@ int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float
     // walks the samples of both lobes; the light gradient keeps 75 accumulators per lane and runs as its own launch.
     if (want_mat) {
         ShadeArgs q{};
-        q.a = a; q.r = r; q.m = m; q.n = n; q.light = light; q.d_out = d_out_rgb; q.d_a = d_a; q.d_r = d_r; q.d_m = d_m;
-        hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, q, g, tab);
+        q.a = a; q.r = r; q.m = m; q.n = n; q.d_out = d_out_rgb; q.d_a = d_a; q.d_r = d_r; q.d_m = d_m;
+        hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, q, light, g, tab);
     }
     if (want_n)
         hipLaunchKernelGGL((shade_bwd_nl_kernel<true, false>), grid, dim3(kBlock), 0, st, a, r, m, n, light, d_out_rgb, d_n, (float*)nullptr, g, tab);
@@ -710,9 +721,9 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     // 1. render with the clamped parameters (:371-386): specular samples only when the diffuse coefficients are cached;
     //    writes the jac planes and per-workgroup sums for mean(pred)
     ShadeArgs sa{};
-    sa.a = q.pa; sa.r = q.pr; sa.m = q.pm; sa.n = q.n; sa.light = q.light; sa.dcache = q.dcache; sa.out = q.pred; sa.jac = q.jac;
+    sa.a = q.pa; sa.r = q.pr; sa.m = q.pm; sa.n = q.n; sa.dcache = q.dcache; sa.out = q.pred; sa.jac = q.jac;
     sa.stats = q.stats; sa.block_sums = fwd_sums; sa.clamp = 1;
-    hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, sa, g, tab);
+    hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, sa, q.light, g, tab);
     // 2. loss statistics, SaveBest / EarlyStopping decisions (:388-418, misc.py:37-97)
     hipLaunchKernelGGL(loss_sums2_kernel<1>, dim3(kRedBlocks, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                        (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
@@ -756,7 +767,7 @@ int matpbr_env_phase_step(const float* T, const float* light, const float* gt_sr
     hipLaunchKernelGGL(env_prt_kernel, dim3((unsigned)nblk, (unsigned)batch), dim3(kBlock), 0, st, T, light, gt_srgb, pred, (const float*)stats,
                        (float*)workspace, P, inv_n3);
     // SaveBest / EarlyStopping decisions (:247,250) and the folded light gradient
-    hipLaunchKernelGGL(env_final_kernel, dim3((unsigned)batch), dim3(kBlock), 0, st, (const float*)workspace, stats, d_light, nblk, inv_n3,
+    hipLaunchKernelGGL(env_final_kernel, dim3((unsigned)batch), dim3(kEnvFinalThreads), 0, st, (const float*)workspace, stats, d_light, nblk, inv_n3,
                        es_patience, es_min_delta, history, hist_len, batch);
     return launch_status();
 }

@@ -41,6 +41,23 @@ struct RuleTable {
     float2 saz[kMaxRings][kMaxAz];   // (cos phi, sin phi) of the half vector
 };
 
+// The per-sample table entries (azimuths) are read by every lane ONCE, lane i holding entry [i / kMaxAz][i % kMaxAz] of both
+// lobes (kMaxRings * kMaxAz = 64 = one wave), and broadcast per sample with v_readlane: a scalar load per sample would expose
+// its latency inside the sample loop (hipcc sinks such a load to its first use).
+// MUST be loaded while every lane of the wave is still active (first statement of a kernel): v_readlane reads the register of
+// a lane whatever EXEC says, so a lane that left early would otherwise hold garbage.
+struct RuleRegs { float2 daz, saz; };
+__device__ __forceinline__ void load_rule_regs(const RuleTable& tab, RuleRegs& rr) {
+    static_assert(kMaxRings * kMaxAz == 64, "one table entry per lane of a wave64");
+    const int lane = threadIdx.x & 63;
+    rr.daz = (&tab.daz[0][0])[lane];
+    rr.saz = (&tab.saz[0][0])[lane];
+}
+__device__ __forceinline__ float2 rule_entry(float2 v, int idx) {   // idx wave-uniform
+    return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), idx)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.y), idx)));
+}
+
 inline double vdc2_host(uint32_t i) {
     i = (i << 16) | (i >> 16);
     i = ((i & 0x55555555u) << 1) | ((i & 0xAAAAAAAAu) >> 1);
@@ -213,13 +230,20 @@ constexpr int kNPairs = (kNL + 1) / 2;
 struct LightRegs { f2 c[kNPairs]; };
 
 // c'[k][c] = coefficient * basis normalisation, so that the per-sample radiance is 72 FMAs on raw polynomials
+// `light` must be a `const float* __restrict__` kernel parameter: the 75 wave-uniform reads then become scalar loads (five
+// s_load_dwordx16) instead of 38 vector loads, and all of them are issued before the first value is pinned.
 __device__ __forceinline__ void load_light_regs(LightRegs& lr, const float* __restrict__ light) {
+    float raw[kNL + 1];
+#pragma unroll
+    for (int q = 0; q < kNL; ++q) raw[q] = light[q];
+    raw[kNL] = raw[kNL - 1];
 #pragma unroll
     for (int j = 0; j < kNPairs; ++j) {
         const int q0 = 2 * j, q1 = 2 * j + 1 < kNL ? 2 * j + 1 : 2 * j;
-        lr.c[j] = f2{light[q0] * kShNorm[q0 / 3], light[q1] * kShNorm[q1 / 3]};
-        asm volatile("" : "+v"(lr.c[j]));  // pin in VGPRs for the whole kernel
+        lr.c[j] = f2{raw[q0] * kShNorm[q0 / 3], raw[2 * j + 1] * kShNorm[q1 / 3]};
     }
+#pragma unroll
+    for (int j = 0; j < kNPairs; ++j) asm volatile("" : "+v"(lr.c[j]));  // pin in VGPRs for the whole kernel
 }
 template <int Q>
 __device__ __forceinline__ void fma_bcast(f2& acc, f2 b, const LightRegs& lr) {  // acc += b * c'_Q (both halves)
@@ -287,7 +311,7 @@ struct DiffuseCoef { f2 A0[3], A1[3], A2[3]; };
 // A0, A1, A2 of the diffuse lobe: moments of the radiance over the cosine-weighted directions
 //   M0 = sum w L, M1 = sum w p5 L, M2 = sum w u L, M3 = sum w u p5 L, M4 = sum w u^2 p5 L;  u = 1 + wi.wo, p5 = (1 - NoL)^5
 //   F_out F_in = (1 + q po)(1 + q p5), q = r u - 1/2  =>  A0 = M0 (1 - po/2) + M1 (po/4 - 1/2), A1 = po M2 + (1-po) M3, A2 = po M4
-__device__ __forceinline__ void diffuse_coef(const Pixel& px, const LightRegs& lr, const RuleTable& tab, DiffuseCoef& A) {
+__device__ __forceinline__ void diffuse_coef(const Pixel& px, const LightRegs& lr, const RuleTable& tab, const RuleRegs& rr, DiffuseCoef& A) {
     f2 M[5][3];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -296,7 +320,7 @@ __device__ __forceinline__ void diffuse_coef(const Pixel& px, const LightRegs& l
     for (int k = 0; k < tab.nu_d; ++k) {
         const float4 rg = tab.dring[k];
         for (int j = 0; j < tab.nphi_d; ++j) {
-            const float2 az = tab.daz[k][j];
+            const float2 az = rule_entry(rr.daz, k * kMaxAz + j);
             f2 wi[3], L[3];
             to_world(px.s, px.t, px.n, az.x, az.y, rg.x, wi);
             sh_radiance(lr, wi, L);
@@ -360,7 +384,8 @@ template <bool JAC>
 struct SpecAcc { f2 S0[3], S1[3], dS0[JAC ? 3 : 1], dS1[JAC ? 3 : 1]; };
 
 template <bool JAC>
-__device__ __forceinline__ void spec_accumulate(const Pixel& px, const LightRegs& lr, const RuleTable& tab, SpecAcc<JAC>& A) {
+__device__ __forceinline__ void spec_accumulate(const Pixel& px, const LightRegs& lr, const RuleTable& tab, const RuleRegs& rr,
+                                                SpecAcc<JAC>& A) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         A.S0[c] = A.S1[c] = f2{0.0f, 0.0f};
@@ -377,7 +402,7 @@ __device__ __forceinline__ void spec_accumulate(const Pixel& px, const LightRegs
         if (JAC) lam0 = vfma(four_over_r, vfma(R.q * R.idq, -2.0f * rg.y, 1.0f), -cv);
         for (int j = 0; j < tab.nphi_s; ++j) {
             SpecSample sm;
-            spec_sample(px, R, tab.saz[k][j], sm);
+            spec_sample(px, R, rule_entry(rr.saz, k * kMaxAz + j), sm);
             const f2 wgt = (R.ringw * sm.g1l) * (sm.NoL * sm.dpos);   // f cos / pdf without F_m: G1(NoL) G1(NoV) NoL VoH / NoH
             f2 L[3];
             sh_radiance(lr, sm.wi, L);
@@ -416,7 +441,7 @@ __device__ __forceinline__ bool img_stopped_before(const float* stats, int b) { 
 //   d out_c / d a_c = (1-m) P_c + m SD_c;   d out_c / d m = -a_c P_c + (a_c - 0.04) SD_c
 // dcache planes [9][B*P]: A0 rgb, A1 rgb, A2 rgb
 struct ShadeArgs {
-    const float *a, *r, *m, *n, *light;
+    const float *a, *r, *m, *n;
     const float* dcache;      // nullable: diffuse coefficients computed in-kernel
     float* out;               // [B,H,W,3] linear radiance (forward)
     float* jac;               // nullable
@@ -428,8 +453,11 @@ struct ShadeArgs {
 };
 
 template <bool JAC>
-__global__ __launch_bounds__(kBlock, 2) void shade_kernel(const ShadeArgs q, const Geom g, const RuleTable tab) {
+__global__ __launch_bounds__(kBlock, 2) void shade_kernel(const ShadeArgs q, const float* __restrict__ light, const Geom g,
+                                                          const RuleTable tab) {
     __shared__ float s_sum[4];
+    RuleRegs rr;
+    load_rule_regs(tab, rr);
     const int b = blockIdx.y;
     if (q.stats && img_stopped(q.stats, b)) return;
     const int P = g.H * g.W;
@@ -442,7 +470,7 @@ __global__ __launch_bounds__(kBlock, 2) void shade_kernel(const ShadeArgs q, con
     Pixel px;
     load_pixel(px, q.a, q.r, q.m, q.n, i0, i1, p0, p1, g, q.clamp != 0);
     LightRegs lr;
-    load_light_regs(lr, q.light + (long)b * kNL);
+    load_light_regs(lr, light + (long)b * kNL);
 
     DiffuseCoef A;
     if (q.dcache) {
@@ -453,10 +481,10 @@ __global__ __launch_bounds__(kBlock, 2) void shade_kernel(const ShadeArgs q, con
             A.A2[c] = f2{q.dcache[(6 + c) * BP + i0], q.dcache[(6 + c) * BP + i1]};
         }
     } else {
-        diffuse_coef(px, lr, tab, A);
+        diffuse_coef(px, lr, tab, rr, A);
     }
     SpecAcc<JAC> S;
-    spec_accumulate<JAC>(px, lr, tab, S);
+    spec_accumulate<JAC>(px, lr, tab, rr, S);
 
     const f2 omm = 1.0f - px.m;
     f2 rgb[3], Pc[3], SD[3], JR[3];
@@ -508,6 +536,8 @@ __global__ __launch_bounds__(kBlock, 2) void shade_kernel(const ShadeArgs q, con
 // the diffuse coefficients of every pixel -> dcache planes [9][B*P] (once per BRDF phase)
 __global__ __launch_bounds__(kBlock, 2) void diffuse_cache_kernel(const float* __restrict__ n, const float* __restrict__ light,
                                                                   float* __restrict__ dcache, const Geom g, const RuleTable tab) {
+    RuleRegs rr;
+    load_rule_regs(tab, rr);
     const int b = blockIdx.y;
     const int P = g.H * g.W;
     const long BP = (long)gridDim.y * P;
@@ -535,7 +565,7 @@ __global__ __launch_bounds__(kBlock, 2) void diffuse_cache_kernel(const float* _
     LightRegs lr;
     load_light_regs(lr, light + (long)b * kNL);
     DiffuseCoef A;
-    diffuse_coef(px, lr, tab, A);
+    diffuse_coef(px, lr, tab, rr, A);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         dcache[c * BP + i0] = A.A0[c].x; dcache[(3 + c) * BP + i0] = A.A1[c].x; dcache[(6 + c) * BP + i0] = A.A2[c].x;
@@ -678,8 +708,8 @@ struct TransferUse {    // acc[(k-K0)*3+c] += w[c] B_k per pixel
 //   d/dn_hat = sum gl wi + gh h + gv wo.  Through n_hat = n/|n| only its tangential part survives, so it is accumulated in the
 //   (s,t) plane directly and the (huge, alternating-sign) radial parts of the GGX-peak terms never enter an fp32 sum.
 template <bool WANT_N, bool WANT_W, class Use>
-__device__ __forceinline__ void walk_samples(const Pixel& px, const LightRegs& lr, const RuleTable& tab, const f2 go[3], Use&& use, f2& dnx,
-                                             f2& dny) {
+__device__ __forceinline__ void walk_samples(const Pixel& px, const LightRegs& lr, const RuleTable& tab, const RuleRegs& rr, const f2 go[3],
+                                             Use&& use, f2& dnx, f2& dny) {
     const f2 omm = 1.0f - px.m;
     f2 kd[3], C0[3], ga[3], gC[3], gD[3];
 #pragma unroll
@@ -694,7 +724,7 @@ __device__ __forceinline__ void walk_samples(const Pixel& px, const LightRegs& l
         const float4 rg = tab.dring[k];
         const float4 rg2 = tab.dring2[k];
         for (int j = 0; j < tab.nphi_d; ++j) {
-            const float2 az = tab.daz[k][j];
+            const float2 az = rule_entry(rr.daz, k * kMaxAz + j);
             f2 wi[3];
             to_world(px.s, px.t, px.n, az.x, az.y, rg.x, wi);
             const f2 u = vfma(px.vz, rg.x, vfma(px.vy, az.y, vfma(px.vx, az.x, 1.0f)));
@@ -727,7 +757,7 @@ __device__ __forceinline__ void walk_samples(const Pixel& px, const LightRegs& l
         if (WANT_N) gh = (-4.0f * R.ct) * px.am1 * (ia2 * R.idq);           // d ln D/dNoH = -4 NoH (alpha2-1)/den
         for (int j = 0; j < tab.nphi_s; ++j) {
             SpecSample sm;
-            spec_sample(px, R, tab.saz[k][j], sm);
+            spec_sample(px, R, rule_entry(rr.saz, k * kMaxAz + j), sm);
             const f2 wgt0 = (R.ringw * sm.g1l) * sm.dpos;                   // weight / NoL
             if (WANT_W) {
                 const f2 wgt = wgt0 * sm.NoL;
@@ -780,6 +810,8 @@ __global__ __launch_bounds__(kBlock, 2) void shade_bwd_nl_kernel(const float* __
                                                                  float* __restrict__ d_n, float* __restrict__ partials, const Geom g,
                                                                  const RuleTable tab) {
     __shared__ float s_red[4][kNL + 1];
+    RuleRegs rr;
+    load_rule_regs(tab, rr);
     const int b = blockIdx.y;
     const int P = g.H * g.W;
     const int q0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
@@ -798,9 +830,9 @@ __global__ __launch_bounds__(kBlock, 2) void shade_bwd_nl_kernel(const float* __
     if (WANT_LIGHT) {
 #pragma unroll
         for (int k = 0; k < kNL; ++k) dc[k] = 0.0f;
-        walk_samples<WANT_N, true>(px, lr, tab, go, LightUse{dc, go}, dnx, dny);
+        walk_samples<WANT_N, true>(px, lr, tab, rr, go, LightUse{dc, go}, dnx, dny);
     } else {
-        walk_samples<WANT_N, false>(px, lr, tab, go, NoUse{}, dnx, dny);
+        walk_samples<WANT_N, false>(px, lr, tab, rr, go, NoUse{}, dnx, dny);
     }
     if (WANT_N && act0) {
 #pragma unroll
@@ -866,6 +898,8 @@ template <int K0, int K1>
 __global__ __launch_bounds__(kBlock, 2) void shade_transfer_kernel(const float* __restrict__ a, const float* __restrict__ r,
                                                                    const float* __restrict__ m, const float* __restrict__ n,
                                                                    float* __restrict__ T, const Geom g, const RuleTable tab) {
+    RuleRegs rr;
+    load_rule_regs(tab, rr);
     const int b = blockIdx.y;
     const int P = g.H * g.W;
     const int p0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
@@ -881,7 +915,7 @@ __global__ __launch_bounds__(kBlock, 2) void shade_transfer_kernel(const float* 
     for (int k = 0; k < NK * 3; ++k) acc[k] = f2{0.0f, 0.0f};
     LightRegs lr;   // unused (no radiance is evaluated)
     f2 go[3], dnx, dny;
-    walk_samples<false, true>(px, lr, tab, go, TransferWalk<K0, K1>{acc}, dnx, dny);
+    walk_samples<false, true>(px, lr, tab, rr, go, TransferWalk<K0, K1>{acc}, dnx, dny);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const float sc = kShNorm[K0 + k];
