@@ -21,6 +21,12 @@ PATCH = 14
 EMBED, DEPTH, HEADS = 768, 12, 12            # vit_base (dinov2.py:355-366)
 TAPS = (2, 5, 8, 11)                         # intermediate_layer_idx['vitb'] (dpt.py:186-188)
 POS_GRID = 37                                # img_size 518 / patch 14
+# Encoders.  The reference wires 'vitb' only (dpt.py:186-188: the one entry of intermediate_layer_idx); 'vitl' is the
+# configs[3] throughput variant (dinov2.py:367-378 vit_large: 1024 wide, 24 blocks, 16 heads) with the DPT head at its own
+# defaults (dpt.py:42-44: features 256, out_channels [256, 512, 1024, 1024]) and evenly spaced taps -- random weights only, no
+# checkpoint of that shape exists in the reference.
+ENCODERS = {"vitb": {"embed": 768, "depth": 12, "heads": 12, "taps": (2, 5, 8, 11), "features": 128, "out_channels": (96, 192, 384, 768)},
+            "vitl": {"embed": 1024, "depth": 24, "heads": 16, "taps": (4, 11, 17, 23), "features": 256, "out_channels": (256, 512, 1024, 1024)}}
 
 
 class _Attention(nn.Module):
@@ -76,30 +82,32 @@ class _PatchEmbed(nn.Module):
         return self.proj(x).flatten(2).transpose(1, 2)
 
 
-class DinoV2B(nn.Module):
-    def __init__(self):
+class DinoV2(nn.Module):
+    def __init__(self, embed: int = EMBED, depth: int = DEPTH, heads: int = HEADS, taps: Sequence[int] = TAPS):
         super().__init__()
-        self.embed_dim = EMBED
-        self.patch_embed = _PatchEmbed(EMBED)
-        self.cls_token = nn.Parameter(torch.zeros(1, 1, EMBED))
-        self.pos_embed = nn.Parameter(torch.zeros(1, POS_GRID * POS_GRID + 1, EMBED))
-        self.mask_token = nn.Parameter(torch.zeros(1, EMBED))          # unused at inference; kept so the state_dict matches
-        self.blocks = nn.ModuleList(_Block(EMBED, HEADS) for _ in range(DEPTH))
-        self.norm = nn.LayerNorm(EMBED, eps=1e-6)
+        self.embed_dim, self.default_taps = embed, tuple(taps)
+        self.patch_embed = _PatchEmbed(embed)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed))
+        self.pos_embed = nn.Parameter(torch.zeros(1, POS_GRID * POS_GRID + 1, embed))
+        self.mask_token = nn.Parameter(torch.zeros(1, embed))          # unused at inference; kept so the state_dict matches
+        self.blocks = nn.ModuleList(_Block(embed, heads) for _ in range(depth))
+        self.norm = nn.LayerNorm(embed, eps=1e-6)
 
     def _pos(self, n_patches: int, h: int, w: int) -> torch.Tensor:
         """Bicubic resampling of the 37x37 position grid with DINOv2's +0.1 offset (dinov2.py:179-210)."""
         if n_patches == POS_GRID * POS_GRID and h == w:
             return self.pos_embed
         pe = self.pos_embed.float()
-        grid = pe[:, 1:].reshape(1, POS_GRID, POS_GRID, EMBED).permute(0, 3, 1, 2)
+        E = self.embed_dim
+        grid = pe[:, 1:].reshape(1, POS_GRID, POS_GRID, E).permute(0, 3, 1, 2)
         h0, w0 = h // PATCH + 0.1, w // PATCH + 0.1
         grid = F.interpolate(grid, scale_factor=(h0 / POS_GRID, w0 / POS_GRID), mode="bicubic", antialias=False)
         assert grid.shape[-2:] == (int(h0), int(w0))
-        return torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, EMBED)], dim=1).to(self.pos_embed.dtype)
+        return torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, E)], dim=1).to(self.pos_embed.dtype)
 
-    def taps(self, x: torch.Tensor, which: Sequence[int] = TAPS) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    def taps(self, x: torch.Tensor, which: Sequence[int] = None) -> List[Tuple[torch.Tensor, torch.Tensor]]:
         """get_intermediate_layers(x, which, return_class_token=True, norm=True) (dinov2.py:297-321)."""
+        which = self.default_taps if which is None else which
         B, _, h, w = x.shape
         t = self.patch_embed(x)
         t = torch.cat([self.cls_token.expand(B, -1, -1), t], dim=1)
@@ -189,12 +197,19 @@ def network_input_size(width: int, height: int, target: int = 518, multiple: int
     return fit(scale * width), fit(scale * height)
 
 
+DinoV2B = DinoV2   # the reference's encoder (vit_base)
+
+
 class MaterialNet(nn.Module):
-    def __init__(self, features: int = 128, out_channels: Sequence[int] = (96, 192, 384, 768)):
+    def __init__(self, features: int = None, out_channels: Sequence[int] = None, encoder: str = "vitb"):
         super().__init__()
-        self.pretrained = DinoV2B()
-        self.depth_head = DPTHead(EMBED, features, out_channels, "depth")
-        self.material_head = DPTHead(EMBED, features, out_channels, "material")
+        cfg = ENCODERS[encoder]
+        features = cfg["features"] if features is None else features
+        out_channels = cfg["out_channels"] if out_channels is None else out_channels
+        self.encoder = encoder
+        self.pretrained = DinoV2(cfg["embed"], cfg["depth"], cfg["heads"], cfg["taps"])
+        self.depth_head = DPTHead(cfg["embed"], features, out_channels, "depth")
+        self.material_head = DPTHead(cfg["embed"], features, out_channels, "material")
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         ph, pw = x.shape[-2] // PATCH, x.shape[-1] // PATCH

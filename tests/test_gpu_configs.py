@@ -1,0 +1,205 @@
+"""BASELINE.json's configurations at their full sizes on the GPU (the parity tests proper run at sizes the oracle finishes in
+seconds; here the full-size runs are tied back to them through crops, size-independent properties and trace shapes).
+
+  configs[0]  256x256, --model_name none --opt_order arm (plumbing)
+  configs[2]  batch of 8 x 512x512 per GPU: the kernels' batch dimension
+  configs[3]  1024x1024 image through MaterialNet (ViT-B as shipped; ViT-L as the random-weight throughput variant)
+  configs[4]  2048x2048 rolling relight, 360 envmap frames
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    torch.manual_seed(20250629)
+    return torch.device("cuda:0")
+
+
+def _t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+
+
+def _close(got, ref, rtol, what):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, np.float64).reshape(got.shape)
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).mean() + 1e-30)
+    assert err.max() <= rtol, f"{what}: max scaled rel err {err.max():.3e}"
+
+
+# ---------------------------------------------------------------------------------------------- configs[2]
+def test_batch_of_8_at_512_matches_stand_alone_renders_and_the_oracle_on_a_crop(oracle64):
+    """The C3 per-GPU shard: 8 independent 512x512 images in one launch.  Every image equals its stand-alone render bit for
+    bit (forward, jac-based material gradients, cached-diffuse variant); a 64x64 window of one of them equals the fp64 oracle
+    evaluated with the full image's view directions; one fused optimisation iteration on the batch equals the single-image one."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    B, H, W, spp = 8, 512, 512, 64
+    scs = [synthetic.make_scene(i, H, W) for i in range(B)]
+    st = lambda k: _t(np.stack([getattr(s, k) for s in scs]), dev)
+    depth = st("depth")
+    n = ops.normals_from_depth(depth)
+    a, r, m, light = st("albedo"), st("roughness"), st("metallic"), st("light")
+    out = ops.shade_fwd(a, r, m, n, light, spp)
+    dcache = ops.diffuse_cache(n, light, spp)
+    jac = ops.plane9(a)
+    out_c = ops.shade_fwd(a, r, m, n, light, spp, dcache=dcache, jac=jac)
+    d_out = torch.randn_like(out)
+    g = ops.shade_bwd_jac(a, r, m, jac, d_out)
+    for b in (0, 3, 7):
+        one = ops.shade_fwd(a[b], r[b], m[b], n[b], light[b], spp)
+        assert torch.equal(out[b], one), f"image {b}: batched render differs from the stand-alone one"
+        dc1 = ops.diffuse_cache(n[b], light[b], spp)
+        j1 = ops.plane9(a[b])
+        assert torch.equal(out_c[b], ops.shade_fwd(a[b], r[b], m[b], n[b], light[b], spp, dcache=dc1, jac=j1))
+        g1 = ops.shade_bwd_jac(a[b], r[b], m[b], j1, d_out[b].contiguous())
+        assert all(torch.equal(x[b], y.reshape(x[b].shape)) for x, y in zip(g, g1))
+    # cached diffuse lobe == in-kernel diffuse lobe (the same arithmetic up to fp32 contraction order)
+    assert (out - out_c).abs().max().item() <= 2e-6 * out.abs().max().item()
+    # oracle on a 64x64 window of image 5, view directions of the full image
+    b, i0, j0, w = 5, 301, 77, 64
+    sl = (slice(i0, i0 + w), slice(j0, j0 + w))
+    n5 = n[b].cpu().numpy().astype(np.float64)
+    ref = oracle64.shade_fwd_win(scs[b].albedo[sl], scs[b].roughness[sl], scs[b].metallic[sl], n5[sl], scs[b].light, spp, H, W, i0, j0)
+    _close(out[b][sl], ref, 1e-3, "512x512 render vs oracle on a 64x64 window")
+    # one fused iteration of hot loop B on the batch == the same iteration on image 2 alone
+    scene_b = render.load_estimated_mesh(depth, use_mesh_normal=True)
+    scene_b._set("emitter.data", light)
+    init = [st(k) for k in ("init_albedo", "init_roughness", "init_metallic")]
+    gt = out
+    fb = loop.FusedBrdfPhase(scene_b, gt, *init, optimize_part="rm", spp=spp)
+    fb.run(2)
+    scene_1 = render.load_estimated_mesh(depth[2], use_mesh_normal=True)
+    scene_1._set("emitter.data", light[2])
+    f1 = loop.FusedBrdfPhase(scene_1, gt[2], *[x[2] for x in init], optimize_part="rm", spp=spp)
+    f1.run(2)
+    for k in ("roughness", "metallic"):
+        assert torch.equal(fb.p[k][2], f1.p[k]), k
+    assert fb.poll()["iters"].tolist() == [2] * B
+    assert float(fb.stats[2, ops.STAT_MSE]) == float(f1.stats[0, ops.STAT_MSE])
+
+
+# ---------------------------------------------------------------------------------------------- configs[4]
+def test_rolling_relight_2048_360_frames():
+    """render_final.py --mode rolling at 2048x2048, 360 frames of 1 degree: frames {0, 179, 359} through the precomputed transfer
+    equal the direct render under the rotated light; rotating the SH light about +y equals rolling the envmap columns."""
+    from materialist_amd import ops, sh, synthetic
+
+    dev = _cuda()
+    S, spp = 2048, 64
+    sc = synthetic.make_scene(0, S, S)
+    n = ops.normals_from_depth(_t(sc.depth, dev))
+    a, r, m = _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev)
+    T = ops.shade_transfer(a, r, m, n, spp)
+    c0 = sc.light.astype(np.float64)
+    lights = np.stack([sh.rotate_y_matrix(np.radians(f)) @ c0 for f in range(360)])
+    L = _t(lights, dev)
+    out8 = torch.empty(8, S, S, 3, device=dev)
+    for f in (0, 179, 359):
+        f0 = (f // 8) * 8
+        ops.relight(T, L[f0:f0 + 8].contiguous(), S, S, out8)
+        direct = ops.shade_fwd(a, r, m, n, L[f].contiguous(), spp)
+        assert (out8[f - f0] - direct).abs().max().item() <= 3e-5 * direct.abs().max().item(), f"frame {f}"
+        assert torch.isfinite(out8[f - f0]).all()
+    # all 360 frames in 45 passes: finite, and the mean radiance is invariant under rotations about the pole up to the
+    # view-dependence of the image (sanity: within 20 % of frame 0)
+    means = []
+    for f0 in range(0, 360, 8):
+        ops.relight(T, L[f0:f0 + 8].contiguous(), S, S, out8)
+        means.append(out8.mean(dim=(1, 2, 3)).cpu())
+    means = torch.cat(means)
+    assert torch.isfinite(means).all() and float((means / means[0] - 1).abs().max()) < 0.2
+    # rotate_y == column roll of the 16x32 envmap (render_final.py:290-298), whole columns: 360/32 = 11.25 degrees
+    rng = np.random.default_rng(2)
+    env = rng.random((16, 32, 3)) + 0.1
+    P = sh.envmap_to_sh_matrix(16, 32)
+    for shift in (1, 7, 31):
+        np.testing.assert_allclose(sh.rotate_y_matrix(2 * np.pi * shift / 32) @ (P @ env.reshape(512, 3)),
+                                   P @ np.roll(env, shift, axis=1).reshape(512, 3), atol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------- configs[3]
+def test_materialnet_on_the_gpu_matches_the_reference_golden_and_runs_at_1024(golden_dir):
+    """f3 on PyTorch-ROCm (SDPA attention, hipBLASLt / MIOpen): fp32 on the GPU against the reference module's recorded fp64
+    outputs (tests/golden/materialnet.npz, name-seeded weights), and a 1024x1024 input against the same module in fp64 on the host."""
+    from materialist_amd.materialnet import MaterialNet, init_from_names, network_input_size
+
+    dev = _cuda()
+    g = np.load(os.path.join(golden_dir, "materialnet.npz"))
+    net64 = init_from_names(MaterialNet().double().eval())
+    net = init_from_names(MaterialNet().eval()).to(dev)
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        out = net(x.float().to(dev))
+    for k in ("depth", "albedo", "roughness", "metallic", "normal"):
+        ref = g[k]
+        err = np.abs(out[k].cpu().numpy() - ref).max() / (np.abs(ref).mean() + 1e-12)
+        assert err < 2e-3, f"{k}: fp32 GPU vs reference fp64 golden: {err:.2e}"
+    # BASELINE configs[3] shape: 1024x1024 image -> network input 518x518 (1369 tokens)
+    nw, nh = network_input_size(1024, 1024)
+    assert (nw, nh) == (518, 518)
+    xs = torch.rand(1, 3, nh, nw, dtype=torch.float64)
+    with torch.no_grad():
+        ref = net64(xs)
+        got = net(xs.float().to(dev))
+    for k in ref:
+        r_ = ref[k].numpy()
+        err = np.abs(got[k].cpu().numpy() - r_).max() / (np.abs(r_).mean() + 1e-12)
+        assert err < 5e-3, f"{k} at 518x518: {err:.2e}"
+    img = (np.random.default_rng(0).random((1024, 1024, 3)) * 255).astype(np.uint8)
+    maps = net.infer_image(img)
+    assert maps["albedo"].shape == (1024, 1024, 3) and maps["depth"].shape == (1024, 1024) and np.isfinite(maps["normal"]).all()
+    assert np.linalg.norm(maps["normal"], axis=-1).max() <= 1.0 + 1e-4                   # bilinear upsampling of unit normals
+
+
+def test_materialnet_vit_large_variant_runs():
+    """configs[3]'s DINOv2-L variant (random weights; the reference wires ViT-B only): 304 M-parameter encoder, same interface."""
+    from materialist_amd.materialnet import MaterialNet
+
+    dev = _cuda()
+    net = MaterialNet(encoder="vitl").to(dev).eval()
+    enc = sum(p.numel() for p in net.pretrained.parameters())
+    assert 300e6 < enc < 310e6
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(torch.rand(1, 3, 518, 518, device=dev))
+    assert out["albedo"].shape == (1, 3, 518, 518) and out["depth"].shape == (1, 1, 518, 518)
+    assert all(torch.isfinite(v.float()).all() for v in out.values())
+
+
+# ---------------------------------------------------------------------------------------------- configs[0]
+def test_config0_256_none_arm_schedule_trace():
+    """256x256, --model_name none --opt_order arm: the alternating schedule runs end to end on the fused loops and emits the
+    phase / part / stop-reason sequence of inverse_img_w_mi.py:211-235,288-312,425-432 (three loops: env, brdf 'arm'; end)."""
+    from materialist_amd import loss, optimize, render, synthetic
+
+    dev = _cuda()
+    H = W = 256
+    spp = 64
+    sc = synthetic.make_scene(0, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp).clone()
+    mat = {"albedo": _t(sc.init_albedo, dev), "roughness": _t(sc.init_roughness, dev), "metallic": _t(sc.init_metallic, dev), "gt_image": gt}
+    scene0 = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    with torch.no_grad():
+        first = render.render_w_brdf(scene0, mat["albedo"], mat["roughness"], mat["metallic"], None, spp)
+        psnr0 = float(loss.psnr(first * (gt.mean() / first.mean()), gt))
+    out = optimize.optimize_envmap_ARMN(scene0, mat, optimize_order=("arm",), spp=spp, opt_env_from=0, opt_src="arm", num_epochs=400,
+                                        sync_every=50, model_name="none")
+    tr = out["trace"]
+    assert [(t.loop, t.phase, t.part) for t in tr] == [(1, "env", ""), (1, "brdf", "arm"), (2, "env", ""), (2, "brdf", "arm"),
+                                                       (3, "env", ""), (3, "end", "")]
+    assert all(t.stop in ("num_epochs", "early_stop") for t in tr[:-1]) and tr[-1].stop in ("loop>=3", "early_stopping_all")
+    assert all(0 <= t.epoch < 400 for t in tr[:-1])
+    assert tr[0].lr == pytest.approx(1e-3 * 0.8 ** (tr[0].epoch // 100), rel=1e-6)      # env loop 1: StepLR(100, 0.8) from 1e-3
+    assert tr[2].lr == pytest.approx(1e-4)                                              # later loops: 1e-4
+    assert out["psnr"] > psnr0 + 3.0, (psnr0, out["psnr"])
+    assert out["albedo"].shape == (H, W, 3) and out["envmap"].shape == (16, 32, 3)
