@@ -126,3 +126,26 @@ def test_sh_orthonormal(oracle64):
     Y = oracle64.sh_basis_angles(T.reshape(-1), Pp.reshape(-1))
     gram = (Y * Wt[:, None]).T @ Y
     np.testing.assert_allclose(gram, np.eye(25), atol=1e-12)
+
+
+def test_attached_sampling_gradient_of_sample_brdf(golden_dir, oracle64):
+    """a5, gradient convention: the live reference differentiates THROUGH the sampled direction and the pdf
+    (myutils/mi_plugin.py:227-230,1335-1341).  tests/golden/sample_brdf_grad.npz holds its torch-autograd d weight / d r and
+    d wi / d r; the oracle's sample_brdf reproduces them by central differences in r (fp64), i.e. the oracle function is the
+    same differentiable function of r, lane by lane.  The image kernels use the detached convention instead (DESIGN.md
+    section 1); tests/test_estimator_accuracy.py quantifies the difference at image level."""
+    g = np.load(os.path.join(golden_dir, "sample_brdf.npz"))
+    gg = np.load(os.path.join(golden_dir, "sample_brdf_grad.npz"))
+    h = 1e-6
+    args = lambda r: (g["sample1"], g["sample2"].T, g["wo"].T, g["n"].T, g["a"].T, r, g["m"])
+    wi_p, pdf_p, w_p = oracle64.sample_brdf(*args(g["r"] + h))
+    wi_m, pdf_m, w_m = oracle64.sample_brdf(*args(g["r"] - h))
+    ok = (g["r"] > 0.07 + 2 * h) & (g["r"] < 1 - 2 * h) & (pdf_p > 2e-6) & (pdf_m > 2e-6)      # away from the pdf > 1e-6 mask (:1338)
+    assert ok.mean() > 0.95
+    fd_w, fd_wi = (w_p - w_m) / (2 * h), (wi_p - wi_m) / (2 * h)
+    ref_w, ref_wi = gg["dweight_dr"].T, gg["dwi_dr"].T
+    scale_w, scale_wi = np.abs(ref_w[ok]).mean(), np.abs(ref_wi[ok]).mean()
+    assert np.abs(fd_w[ok] - ref_w[ok]).max() <= 2e-5 * max(scale_w, np.abs(ref_w[ok]).max())
+    assert np.abs(fd_wi[ok] - ref_wi[ok]).max() <= 1e-6 * max(scale_wi, 1.0)
+    diffuse = g["sample1"] > 0.5
+    assert np.abs(ref_wi[diffuse]).max() == 0.0        # only GGX-sampled directions move with r
