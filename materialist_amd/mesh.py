@@ -1,0 +1,80 @@
+"""`<save_name>.ply` of the output layout: the depth heightfield as a triangle mesh in the renderer's frame.
+
+The reference builds it with Python loops over every pixel (`depth_file_to_mesh`, myutils/mesh_recon.py:41-74,86-331; minutes at
+512x512) and shades with its face normals.  The kernels here need only the per-pixel geometric normal (`matpbr_normals_from_depth`);
+the mesh is written for tools that expect the file.  Vectorised restatement of the regular part of the reference's triangulation:
+  * vertex (i, j) = K^-1 [j, i, 1] depth[i, j], rotated 180 degrees about x (inverse_img_w_mi.py:727): ((j-cx)/f d, -(i-cy)/f d, -d);
+  * two triangles per 2x2 cell with the reference's vertex order (:190-193,250-254): (i,j),(i+1,j),(i,j+1) and (i,j+1),(i+1,j),(i+1,j+1);
+  * cells touching a zero depth (mesh_mask.png, inverse_img_w_mi.py:723) carry no triangle (:187-188).
+NOT restated: the reference's gap closing at depth discontinuities (it overwrites the depth of foreground boundary pixels with the
+farther neighbour's and duplicates vertices, :86-170,196-246); at such edges this mesh keeps the stretched triangles.  Away from
+depth edges the area-weighted vertex normals of the two meshes agree to 0.14 degrees (tests/test_oracle_golden.py).
+"""
+from __future__ import annotations
+
+import math
+import struct
+from typing import Tuple
+
+import numpy as np
+
+
+def depth_to_mesh(depth: np.ndarray, fov_x_deg: float = 35.0) -> Tuple[np.ndarray, np.ndarray]:
+    """depth [H,W] (the array handed to load_estimated_mesh, i.e. 2 max - prediction) -> (vertices [H*W,3] float64, triangles [T,3] int32)."""
+    depth = np.asarray(depth, dtype=np.float64)
+    H, W = depth.shape
+    f = (W / 2.0) / math.tan(math.radians(fov_x_deg) / 2.0)
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    i, j = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    V = np.stack([(j - cx) / f * depth, -(i - cy) / f * depth, -depth], -1).reshape(-1, 3)
+    idx = np.arange(H * W, dtype=np.int64).reshape(H, W)
+    a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[:-1, 1:], idx[1:, 1:]       # (i,j), (i+1,j), (i,j+1), (i+1,j+1)
+    valid = depth.reshape(-1) != 0
+    # the reference emits the two triangles of a cell together, row by row (:176-254): keep that order
+    T = np.stack([np.stack([a, b, c], -1), np.stack([c, b, d], -1)], axis=2).reshape(-1, 3)
+    return V, T[valid[T].all(1)].astype(np.int32)
+
+
+def write_ply(path: str, vertices: np.ndarray, triangles: np.ndarray) -> None:
+    """Binary little-endian PLY, the layout open3d's write_triangle_mesh produces (double vertices, uchar-counted int faces)."""
+    V = np.ascontiguousarray(vertices, dtype="<f8")
+    T = np.ascontiguousarray(triangles, dtype="<i4")
+    header = ("ply\nformat binary_little_endian 1.0\ncomment materialist_amd depth heightfield\n"
+              f"element vertex {V.shape[0]}\nproperty double x\nproperty double y\nproperty double z\n"
+              f"element face {T.shape[0]}\nproperty list uchar int vertex_indices\nend_header\n")
+    faces = np.empty(T.shape[0], dtype=[("n", "u1"), ("v", "<i4", (3,))])
+    faces["n"], faces["v"] = 3, T
+    with open(path, "wb") as fh:
+        fh.write(header.encode("ascii"))
+        fh.write(V.tobytes())
+        fh.write(faces.tobytes())
+
+
+def read_ply(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """Reader for the files `write_ply` produces (tests, resume path)."""
+    with open(path, "rb") as fh:
+        nv = nt = None
+        while True:
+            line = fh.readline().decode("ascii").strip()
+            if line.startswith("element vertex"):
+                nv = int(line.split()[-1])
+            elif line.startswith("element face"):
+                nt = int(line.split()[-1])
+            elif line == "end_header":
+                break
+        V = np.frombuffer(fh.read(nv * 24), dtype="<f8").reshape(nv, 3)
+        raw = fh.read(nt * 13)
+    faces = np.frombuffer(raw, dtype=[("n", "u1"), ("v", "<i4", (3,))])
+    return V.copy(), faces["v"].copy()
+
+
+def vertex_normals(vertices: np.ndarray, triangles: np.ndarray) -> np.ndarray:
+    """Area-weighted mean of the adjacent face normals per vertex, oriented towards the camera at the origin."""
+    V, T = np.asarray(vertices, np.float64), np.asarray(triangles, np.int64)
+    fn = np.cross(V[T[:, 1]] - V[T[:, 0]], V[T[:, 2]] - V[T[:, 0]])
+    acc = np.zeros_like(V)
+    for k in range(3):
+        np.add.at(acc, T[:, k], fn)
+    sign = np.where((acc * V).sum(-1, keepdims=True) > 0, -1.0, 1.0)
+    ln = np.linalg.norm(acc, axis=-1, keepdims=True)
+    return np.where(ln > 0, sign * acc / np.maximum(ln, 1e-30), 0.0)

@@ -344,6 +344,14 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
         if tuple(mesh_mask.shape) != (size, size):
             raise ValueError(f"{mm_path}: mask is {tuple(mesh_mask.shape)}, the run is {size}x{size}")
         log(f"Applied mask from {mm_path}: {int(mesh_mask.sum())} pixels see the environment directly")
+    mesh_path = os.path.join(output_dir, f"{save_name}.ply")                                     # :712,721-727
+    if not os.path.exists(mesh_path):
+        from . import mesh as _mesh
+
+        d_mesh = np.array(depth, dtype=np.float64)
+        if mesh_mask is not None:
+            d_mesh[mesh_mask.numpy()] = 0.0                                                      # :723
+        _mesh.write_ply(mesh_path, *_mesh.depth_to_mesh(d_mesh, render.DEFAULT_FOV))
     scene = render.load_estimated_mesh(t(depth), use_mesh_normal=use_mesh_normal, device=device, mesh_mask=mesh_mask)
     frames = FrameWriter(output_dir, min_interval=frame_interval)
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,

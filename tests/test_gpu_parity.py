@@ -545,7 +545,7 @@ def test_fused_env_phase_matches_torch_composition():
 
 
 def test_inverse_image_writes_the_reference_output_layout(tmp_path):
-    """f1: the pipeline head + writers produce output_imgs/<name>/ as SURVEY.md App. D lists it (minus .ply / mp4)."""
+    """f1: the pipeline head + writers produce output_imgs/<name>/ as SURVEY.md App. D lists it (the mp4 files are GIFs)."""
     from PIL import Image
 
     from materialist_amd import pipeline
@@ -560,7 +560,7 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     out = res["output_dir"]
     assert out == str(tmp_path / "case")
     for name in ("albedoPred.exr", "normalPred.exr", "roughnessPred.png", "metallicPred.png", "depthPred.exr", "gt_image.exr", "gt_image.png",
-                 "config.json", "env.png", "final_envmap.hdr", "opt_env_img.png", "env_optimization.gif", "mat_optimization.gif"):
+                 "config.json", "env.png", "final_envmap.hdr", "opt_env_img.png", "env_optimization.gif", "mat_optimization.gif", "case.ply"):
         assert os.path.exists(os.path.join(out, name)), name
     assert sorted(os.listdir(os.path.join(out, "best_results"))) == ["albedo.exr", "envmap.hdr", "metallic.exr", "normal.exr",
                                                                      "rendered_img.exr", "roughness.exr"]
