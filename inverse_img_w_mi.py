@@ -17,8 +17,8 @@ def parse_args(argv=None):
     ap.add_argument("--use_mask", action="store_true")
     ap.add_argument("--opt_env_from", type=int, default=0)
     ap.add_argument("--save_path", type=str, default=None)
-    ap.add_argument("--model_name", type=str, default="none", choices=["pos_mlp", "none"],
-                    help="the reference parses and ignores this flag (always pos_mlp, F4); here it is honoured")
+    ap.add_argument("--model_name", type=str, default="pos_mlp", choices=["pos_mlp", "none"],
+                    help="the reference parses and ignores this flag (it always runs pos_mlp, F4); here it is honoured, default pos_mlp")
     ap.add_argument("--size", type=int, default=512, help="render resolution (the reference hard-codes 512)")
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--num_epochs", type=int, default=5000)

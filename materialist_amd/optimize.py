@@ -52,6 +52,16 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
     if use_mask and mask is None:
         raise ValueError("use_mask needs mat['mask'] ([H,W] bool)")
     saver = _loop.DeviceSaveBest()
+
+    def keep_best(key: str, new: torch.Tensor, improved: torch.Tensor) -> None:
+        """SaveBest per image: images of a batch whose best loss did not improve keep their earlier snapshot."""
+        old = saver.best.get(key)
+        if old is None or old.shape != new.shape or gt.ndim != 4:
+            saver.best[key] = new.clone()
+        else:
+            sel = improved.to(new.device).reshape((-1,) + (1,) * (new.ndim - 1))
+            saver.best[key] = torch.where(sel, new, old)
+
     state = {"final_envmap": None, "last_mse": None, "best_brdf_weights": None}
     if model_name == "pos_mlp":                                                     # :114-124,159-172,179-207
         from . import posmlp
@@ -67,7 +77,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         start_arm = torch.cat([mat["albedo"].reshape(-1, 3), mat["roughness"].reshape(-1, 1), mat["metallic"].reshape(-1, 1)], dim=-1)
         start_arm = torch.cat([start_arm, mat["normal"].reshape(-1, 3)], dim=-1) if armn else start_arm.clamp(0, 1)
     elif model_name == "none":
-        env_raw = torch.zeros(tuple(env_size) + (3,), dtype=torch.float32, device=dev, requires_grad=True)
+        # one light per image: a batch of independent images ([B,H,W,3] target) optimises B envmaps side by side
+        lead = (gt.shape[0],) if gt.ndim == 4 else ()
+        env_raw = torch.zeros(lead + tuple(env_size) + (3,), dtype=torch.float32, device=dev, requires_grad=True)
         env_params = [env_raw]
         env_head = lambda: torch.nn.functional.softplus(env_raw)
     else:
@@ -134,10 +146,12 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         info = ph.poll()
         iters = int(info["iters"].max())
         prev = saver.best_loss if saver.best_loss is not None else torch.full_like(info["best_mse"].to(dev), float("inf"))
-        if bool((info["best_mse"].to(dev) < prev).any()):                           # SaveBest.update on improvement (:247)
+        imp = info["best_mse"].to(dev) < prev
+        if bool(imp.any()):                                                          # SaveBest.update on improvement (:247)
             saver.best_loss = torch.minimum(info["best_mse"].to(dev), prev)
-            saver.best.update(albedo=mat["albedo"].detach().clone(), roughness=mat["roughness"].detach().clone(),
-                              metallic=mat["metallic"].detach().clone(), envmap=ph.best_env.clone(), rendered_img=ph.best_img.clone())
+            for k_, v in (("albedo", mat["albedo"].detach()), ("roughness", mat["roughness"].detach()), ("metallic", mat["metallic"].detach()),
+                          ("envmap", ph.best_env), ("rendered_img", ph.best_img)):
+                keep_best(k_, v, imp)
         elif "envmap" not in saver.best:
             saver.best["envmap"] = ph.best_env.clone()
         state["last_mse"] = float(ph.history()[iters - 1].max()) if iters > 0 else float("nan")
@@ -284,8 +298,11 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 if saver.best_loss is not None else info["best_mse"].to(dev)
             for k_, v in (("albedo", ph.best["albedo"]), ("roughness", ph.best["roughness"]), ("metallic", ph.best["metallic"]),
                           ("rendered_img", ph.best_img)):
-                saver.best[k_] = v.clone()
-            saver.best["envmap"] = state["envmap4render"].clone()
+                keep_best(k_, v, improved)
+            env4 = state["envmap4render"]
+            if gt.ndim == 4 and env4.ndim == 3:
+                env4 = env4.unsqueeze(0).expand((gt.shape[0],) + tuple(env4.shape))
+            keep_best("envmap", env4.contiguous(), improved)
         say(f"loop {loop_num}: part {part!r} ran {iters} iterations ({stop}), best mse {float(info['best_mse'].min()):.5f}")
         return iters - 1, ph.lr_at(max(iters - 1, 0)), stop
 
@@ -306,7 +323,10 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         params["emitter.data"] = saver.best["envmap"]
         final = _render.render_w_brdf(scene, saver.best["albedo"], saver.best["roughness"], saver.best["metallic"],
                                       None if scene.use_mesh_normal else mat["normal"], spp)
-        ratio = gt.mean() / final.mean()
+        red = (-3, -2, -1) if gt.ndim == 4 else None                                # per image for a batch
+        ratio = gt.mean(dim=red, keepdim=True) / final.mean(dim=red, keepdim=True) if red else gt.mean() / final.mean()
+        psnr_each = _loss.psnr(final * ratio, gt).reshape(-1)
     return {"albedo": saver.best["albedo"], "roughness": saver.best["roughness"], "metallic": saver.best["metallic"], "normal": mat.get("normal"),
             "envmap": saver.best["envmap"], "rendered_img": saver.best["rendered_img"], "final_render": final,
-            "psnr": float(_loss.psnr(final * ratio, gt)), "best_loss": float(saver.best_loss.min()), "trace": trace}
+            "psnr": float(psnr_each.mean()), "psnr_per_image": psnr_each.tolist(), "best_loss": float(saver.best_loss.min()),
+            "best_loss_per_image": saver.best_loss.reshape(-1).tolist(), "trace": trace}

@@ -81,6 +81,10 @@ def write_png(path: str, img: np.ndarray, linear: bool = False) -> None:
     Image.fromarray((np.clip(img, 0, 1) * 255.0 + 0.5).astype(np.uint8)).save(path)
 
 
+def _srgb_decode(x: np.ndarray) -> np.ndarray:
+    return np.where(x <= 0.04045, x / 12.92, np.power((x + 0.055) / 1.055, 2.4)).astype(np.float32)
+
+
 def flat_prior(img_linear: np.ndarray) -> Dict[str, np.ndarray]:
     """Stand-in for MaterialNet.infer_image (dpt.py:219-241) until f3: no learned prior."""
     H, W, _ = img_linear.shape
@@ -94,7 +98,9 @@ def load_predictions(pred_dir: str, size) -> Dict[str, np.ndarray]:
     g = lambda n: os.path.join(pred_dir, n)
     from PIL import Image
 
-    gray = lambda p: np.asarray(Image.open(p).convert("L"), dtype=np.float32) / 255.0
+    # roughnessPred.png / metallicPred.png are written with mi.util.write_bitmap (inverse_img_w_mi.py:675-676), which sRGB-encodes
+    # 8-bit output: decode, so that a --pred_dir produced by the reference (or by this pipeline) reads back as linear values
+    gray = lambda p: _srgb_decode(np.asarray(Image.open(p).convert("L"), dtype=np.float32) / 255.0)
     out = {"albedo": read_exr(g("albedoPred.exr")), "normal": read_exr(g("normalPred.exr")), "roughness": gray(g("roughnessPred.png")),
            "metallic": gray(g("metallicPred.png")), "depth": read_exr(g("depthPred.exr"))[..., 0]}
     for k, v in out.items():
@@ -258,7 +264,7 @@ def save_results(path: str, best: Dict[str, torch.Tensor], normal: torch.Tensor)
 
 
 def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", opt_order: Sequence[str] = ("arm",), use_mask: bool = False,
-                  opt_env_from: int = 0, save_path: Optional[str] = None, model_name: str = "none", size: int = 512, spp: int = 64,
+                  opt_env_from: int = 0, save_path: Optional[str] = None, model_name: str = "pos_mlp", size: int = 512, spp: int = 64,
                   num_epochs: int = 5000, pred_dir: Optional[str] = None, device: str = "cuda", sync_every: int = 10,
                   log=print, matnet_weights: Optional[str] = None, frame_interval: float = 0.2) -> Dict[str, object]:
     """inverse_img_w_mi.py:623-770 (resolution-generic: `size`; `model_name` is honoured, F4)."""
@@ -285,8 +291,12 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
             matnet.load_state_dict(torch.load(matnet_weights, map_location="cpu", weights_only=True))
             pred = matnet.to(device).eval().infer_image(img)
             del matnet
+        elif pred_dir:
+            pred = load_predictions(pred_dir, (size, size))
         else:
-            pred = load_predictions(pred_dir, (size, size)) if pred_dir else flat_prior(img)
+            warnings.warn("neither --matnet_weights nor --pred_dir given: starting from a FLAT prior (albedo = image, roughness 0.5, "
+                          "metallic 0, planar depth) instead of MaterialNet's prediction (inverse_img_w_mi.py:648-661)", UserWarning)
+            pred = flat_prior(img)
         mat["gt_image"] = t(img)                                                                 # :663-670
         mat["albedo"] = t(pred["albedo"]).clamp(0, 1)
         mat["normal"] = t(pred["normal"])
@@ -295,8 +305,8 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
         depth = pred["depth"]
         write_exr(os.path.join(output_dir, "albedoPred.exr"), pred["albedo"])                    # :672-678
         write_exr(os.path.join(output_dir, "normalPred.exr"), pred["normal"])
-        write_png(os.path.join(output_dir, "roughnessPred.png"), pred["roughness"])
-        write_png(os.path.join(output_dir, "metallicPred.png"), pred["metallic"])
+        write_png(os.path.join(output_dir, "roughnessPred.png"), pred["roughness"], linear=True)   # sRGB-encoded, as write_bitmap does
+        write_png(os.path.join(output_dir, "metallicPred.png"), pred["metallic"], linear=True)
         write_exr(os.path.join(output_dir, "depthPred.exr"), depth)
         write_exr(os.path.join(output_dir, "gt_image.exr"), img)
         write_png(os.path.join(output_dir, "gt_image.png"), img, linear=True)

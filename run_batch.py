@@ -20,7 +20,9 @@ def main(argv=None):
     ap.add_argument("--opt_src", type=str, default="arm")
     ap.add_argument("--opt_order", type=str, nargs="+", default=["arm"])
     ap.add_argument("--opt_env_from", type=int, default=0)
-    ap.add_argument("--model_name", type=str, default="none", choices=["none", "pos_mlp"])
+    ap.add_argument("--model_name", type=str, default="pos_mlp", choices=["none", "pos_mlp"],
+                    help="pos_mlp: the reference's behaviour (inverse_img_w_mi.py:782 always runs it); none: optimise the maps directly "
+                         "(a rank's synthetic shard then runs as ONE batch in the kernels' batch dimension)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--num_epochs", type=int, default=5000)
@@ -52,12 +54,32 @@ def main(argv=None):
                                          size=cfg["size"], spp=cfg["spp"], num_epochs=cfg["num_epochs"], device=str(dev), log=lambda *_: None)
         return [res["best_loss"], res["psnr"], float(sum(max(t.epoch, 0) + 1 for t in res["trace"] if t.phase != "end"))]
 
+    def process_shard(ids, shard_paths, cfg):
+        """`--model_name none` on synthetic scenes: the rank's whole shard as one batch (B images in the kernels' batch dimension,
+        per-image lights, SaveBest and EarlyStopping per image on the device)."""
+        scs = [synthetic.make_scene(int(p.split(":")[1]), cfg["size"], cfg["size"]) for p in shard_paths]
+        st = lambda k: torch.from_numpy(np.stack([getattr(s, k) for s in scs])).to(dev)
+        depth = st("depth")
+        scene = render.load_estimated_mesh(depth, use_mesh_normal=True, device=dev)
+        scene._set("emitter.data", st("light"))
+        with torch.no_grad():
+            gt = render.render_w_brdf(scene, st("albedo"), st("roughness"), st("metallic"), None, cfg["spp"]).clone()
+        mat = {"albedo": st("init_albedo"), "roughness": st("init_roughness"), "metallic": st("init_metallic"), "gt_image": gt}
+        scene = render.load_estimated_mesh(depth, use_mesh_normal=True, device=dev)
+        res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=cfg["opt_order"], spp=cfg["spp"], opt_env_from=cfg["opt_env_from"],
+                                            opt_src=cfg["opt_src"], num_epochs=cfg["num_epochs"], model_name="none")
+        its = float(sum(max(t.epoch, 0) + 1 for t in res["trace"] if t.phase != "end"))
+        return [[bl, ps, its] for bl, ps in zip(res["best_loss_per_image"], res["psnr_per_image"])]
+
     cfg = {"save_path": a.save_path, "opt_src": a.opt_src, "opt_order": a.opt_order, "opt_env_from": a.opt_env_from, "model_name": a.model_name,
            "size": a.size, "spp": a.spp, "num_epochs": a.num_epochs}
-    rows = batch.run_batch(paths, cfg, process)
+    batched = a.model_name == "none" and paths and all(p.startswith("synthetic:") for p in paths)
+    rows = batch.run_batch(paths, cfg, process, process_shard=process_shard if batched else None)
     if rank == 0:
         for r in rows:
-            print(json.dumps({"image": r["path"], "rank": r["rank"], "best_loss_mse": r["values"][0], "psnr_db": r["values"][1], "iterations": int(r["values"][2])}))
+            v = r["values"] + [float("nan")] * 3
+            print(json.dumps({"image": r["path"], "rank": r["rank"], "best_loss_mse": v[0], "psnr_db": v[1],
+                              "iterations": int(v[2]) if v[2] == v[2] else None, "error": r["error"]}))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

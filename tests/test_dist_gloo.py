@@ -104,3 +104,47 @@ def test_run_batch_shards_and_gathers(n_images):
     assert [r["image_id"] for r in rows0] == list(range(n_images))
     assert all(r["values"] == [0.5 * r["image_id"], float(len(r["path"]))] for r in rows0)
     assert all(r["rank"] == (0 if r["image_id"] in seen0 else 1) for r in rows0)
+
+
+def _shard_worker(rank, world, port, n_images, fail_rank, out_q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from materialist_amd import batch
+
+    batch.init_distributed("gloo")
+    calls = []
+
+    def process_shard(ids, paths, cfg):
+        calls.append(list(ids))
+        if rank == fail_rank:
+            raise RuntimeError("boom")
+        return [[cfg["scale"] * i, float(len(p))] for i, p in zip(ids, paths)]
+
+    rows = batch.run_batch([f"synthetic:{k}" for k in range(n_images)] if rank == 0 else [], {"scale": 2.0} if rank == 0 else {}, None,
+                           process_shard=process_shard)
+    out_q.put((rank, calls, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_run_batch_hands_a_rank_its_whole_shard_and_survives_a_failing_rank(fail_rank):
+    """BASELINE configs[2]: a rank's contiguous shard is processed as ONE batch (process_shard called once per rank); an
+    exception on one rank yields NaN rows + an error message for its images while every rank still reaches the collectives."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, 5, fail_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, calls0, rows0), (_, calls1, rows1) = got
+    assert calls0 == [[0, 1, 2]] and calls1 == [[3, 4]] and rows1 == []
+    assert [r["image_id"] for r in rows0] == [0, 1, 2, 3, 4]
+    for r in rows0:
+        if fail_rank == 1 and r["image_id"] >= 3:
+            assert r["error"] == "RuntimeError: boom" and all(np.isnan(v) for v in r["values"])
+        else:
+            assert r["error"] is None and r["values"] == [2.0 * r["image_id"], float(len(r["path"]))]

@@ -556,7 +556,7 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     src = str(tmp_path / "in.png")
     Image.fromarray(img).save(src)
     res = pipeline.inverse_image(src, "case", opt_src="arm", opt_order=["rm", "a"], opt_env_from=0, save_path=str(tmp_path), size=32, spp=8,
-                                 num_epochs=12, sync_every=6, log=lambda *_: None, frame_interval=0.0)
+                                 num_epochs=12, sync_every=6, log=lambda *_: None, frame_interval=0.0, model_name="none")
     out = res["output_dir"]
     assert out == str(tmp_path / "case")
     for name in ("albedoPred.exr", "normalPred.exr", "roughnessPred.png", "metallicPred.png", "depthPred.exr", "gt_image.exr", "gt_image.png",
@@ -573,11 +573,11 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     assert Image.open(os.path.join(out, "opt_env_img.png")).size == (96, 32)        # three panels side by side
     # resume path (--opt_src skip, :737-749) reads what was written
     res2 = pipeline.inverse_image(src, "case", opt_src="skip", opt_order=["skip"], save_path=str(tmp_path), size=32, spp=8, num_epochs=5,
-                                  sync_every=5, log=lambda *_: None)
+                                  sync_every=5, log=lambda *_: None, model_name="none")
     assert res2["trace"][-1].stop == "skip"
     # 'n' in --opt_order: shade with (and optimise) the normal map (inverse_img_w_mi.py:751-758,378-379)
     res3 = pipeline.inverse_image(src, "case_mn", opt_src="arm", opt_order=["arm", "n"], save_path=str(tmp_path), size=32, spp=8, num_epochs=6,
-                                  sync_every=6, log=lambda *_: None)
+                                  sync_every=6, log=lambda *_: None, model_name="none")
     assert [t.part for t in res3["trace"] if t.phase == "brdf" and t.loop == 1] == ["arm", "n"]
     assert res3["normal"] is not None and abs(float(res3["normal"].norm(dim=-1).mean()) - 1.0) < 1e-4
     assert json.load(open(os.path.join(res3["output_dir"], "config.json")))["use_mesh_normal"] is False

@@ -285,7 +285,7 @@ def test_cli_parses_the_reference_flags():
     cli = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cli)
     a = cli.parse_args(["--img_inverse_path", "x.png", "--save_name", "s", "--opt_src", "arm", "--opt_order", "rm", "a", "--opt_env_from", "2"])
-    assert a.opt_order == ["rm", "a"] and a.opt_env_from == 2 and a.model_name == "none" and not a.use_mask
+    assert a.opt_order == ["rm", "a"] and a.opt_env_from == 2 and a.model_name == "pos_mlp" and not a.use_mask   # the reference always runs pos_mlp (:782)
 
 
 def test_hsv_round_trip_and_material_edit_flags():
