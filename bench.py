@@ -224,14 +224,13 @@ def main(argv=None):
                 return ph
             if mode == "env":
                 from materialist_amd import posmlp
+                from materialist_amd.envhead import EnvMlpPhase
 
                 s_env = render.load_estimated_mesh(self.depth, use_mesh_normal=True)
                 pr = render.traverse(s_env)
                 pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = self.gt
                 enet = posmlp.envmap_net().to(dev)
-                ones = torch.ones(512, 3, device=dev)
-                return loop.FusedEnvPhase(s_env, self.gt_image, lambda: enet(ones).reshape(16, 32, 3), loop.capturable_adam(enet.parameters(), 1e-3),
-                                          spp=args.spp, use_graph=True, keep_pred=False)     # whole iteration replayed from a hipGraph after 3 eager ones
+                return EnvMlpPhase(s_env, self.gt_image, enet, torch.ones(512, 3, device=dev), spp=args.spp, lr=1e-3, use_graph=True)
             return loop.BrdfPhase(self.scene, self.gt_image, *self.init, None, optimize_part="rm", spp=args.spp)
 
     wl = Workload(args.images_per_gpu)
@@ -261,7 +260,8 @@ def main(argv=None):
     mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so: render+jac, loss statistics, streaming backward+Adam)",
                   "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
                   "pos_mlp": "hot loop B, --model_name pos_mlp (PosMLP sine layers, render, loss, backward in libmatpbr.so; autograd glue in torch)",
-                  "env": "hot loop A, envmap PosMLP head (torch, hipGraph) + matpbr_env_phase_step on the radiance transfer",
+                  "env": "hot loop A: envmap PosMLP (small-tile MFMA layers) + softplus / SH projection + one pass over the radiance transfer + "
+                         "backward + Adam, 27 launches of libmatpbr.so replayed from a hipGraph",
                   "torch": "hot loop B composed from torch ops"}
     modes = {k: dict(v, what=mode_names[k]) for k, v in modes.items()}
 
@@ -344,8 +344,8 @@ def main(argv=None):
             lib = _lib.load()
 
             def env_call():
-                lib.matpbr_env_phase_step(P_(ph_e.T), P_(lc), P_(ph_e.gt_srgb), None, P_(ph_e.d_light), P_(ph_e.stats), None, 0, 0, 0.0, P_(ph_e.ws),
-                                          ph_e.ws.numel() * 4, H, W, 1, __import__("ctypes").c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                lib.matpbr_env_phase_step(P_(ph_e.T), P_(lc), P_(ph_e.gt_srgb), None, P_(ph_e.d_light), P_(ph_e.stats), None, 0, 0, 0.0, P_(ph_e.ws_env),
+                                          ph_e.ws_env.numel() * 4, H, W, 1, __import__("ctypes").c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             ms_e = back_to_back(env_call)
             roof["env_prt"] = {"bound": "hbm", "kernel": "env_prt_kernel + env_final_kernel (render, loss, d_light in one pass over T)",
                                "achieved": BYTES_ENV * H * W / (ms_e * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "avg_launch_ms": ms_e,

@@ -170,6 +170,25 @@ int matpbr_env_phase_step(const float* T, const float* light, const float* gt_sr
                           float* history, int hist_len, int es_patience, float es_min_delta, void* workspace,
                           size_t workspace_bytes, int H, int W, int batch, void* stream);
 
+/* The envmap head of hot loop A without a framework in between (inverse_img_w_mi.py:117-124,238-254): the 16x32 envmap is
+ * softplus(envmap_net(start_envmap)) (mymodels/mlps.py:230-232) and the kernels integrate its SH projection.
+ *   matpbr_env_project      env[T,3] = softplus(y[T, ldy]), light[25,3] = proj[25,T] env      (T <= 1024 texels)
+ *   matpbr_env_project_bwd  d_y[T, ldg] = sigmoid(y) * (proj^T d_light) in columns 0..2, zero in the padding columns
+ *   matpbr_select_improved  dst = src (n floats) when stats[8] (improved) is set or `first`: SaveBest's envmap snapshot (:247)
+ *   matpbr_adam_step_dev    torch.optim.Adam on one flat buffer with hyper[0] = lr and hyper[1] = steps done so far in DEVICE memory
+ *                           (the count is advanced by the call): usable inside a captured hipGraph, lr changed by writing hyper[0]
+ *   matpbr_mlp_layer_bwd_input_w   matpbr_mlp_layer_bwd_input taking the layer's forward weight w[n_red, ldw] (no transposed copy);
+ *                           point sets of at most 1024 rows (MATPBR_ERR_UNSUPPORTED beyond) */
+int matpbr_env_project(const float* y, int ldy, const float* proj, float* env, float* light, int n_texels, void* stream);
+int matpbr_env_project_bwd(const float* y, int ldy, const float* proj, const float* d_light, float* d_y, int ldg, int n_texels,
+                           void* stream);
+int matpbr_select_improved(float* dst, const float* src, const float* stats, int first, long n, void* stream);
+int matpbr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
+                         void* stream);
+int matpbr_mlp_layer_bwd_input_w(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo,
+                                 float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
+                                 void* stream);
+
 /* Column sums of a row-major [M, N] fp32 matrix -> out[N]: the bias gradient of the PosMLP layers over M = H*W points
  * (mymodels/mlps.py:102-103 under autograd).  Deterministic two-pass; workspace of matpbr_column_sum_workspace_bytes(N). */
 int matpbr_sin_bwd(const float* d_y, long ld_d, const float* pre, long ld_p, float* out, long M, int n, void* stream);

@@ -220,6 +220,67 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float* __restrict__ p
     }
 }
 
+
+// ---- the envmap head of hot loop A (inverse_img_w_mi.py:238-239: envmap = envmap_net(start_envmap); PosMLP 'envmap' head:
+// softplus, mymodels/mlps.py:230-232) joined to the light the kernels integrate: texels e = softplus(y) [T,3] (y with row stride
+// ldy), light[k][c] = sum_t proj[k][t] e[t][c] (the fixed 25 x T SH projection of materialist_amd/sh.py).  T <= 1024 texels.
+__global__ __launch_bounds__(kBlock) void env_project_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ proj,
+                                                             float* __restrict__ env, float* __restrict__ light, int T) {
+    __shared__ float s_e[1024 * 3];
+    for (int i = threadIdx.x; i < T * 3; i += kBlock) {
+        const float v = y[(i / 3) * ldy + (i % 3)];
+        const float e = v > 20.0f ? v : log1pf(expf(v));          // torch.nn.functional.softplus (beta 1, threshold 20)
+        s_e[i] = e;
+        env[i] = e;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = wave; q < kNL; q += 4) {                          // one wave per light scalar, lanes along the texels
+        const int k = q / 3, c = q % 3;
+        float a = 0.0f;
+        for (int t = lane; t < T; t += 64) a = fmaf(proj[(long)k * T + t], s_e[t * 3 + c], a);
+        a = wave_sum_to_lane63(a);
+        if (lane == 63) light[q] = a;
+    }
+}
+// backward: d_y[t][c] = sigmoid(y[t][c]) * sum_k proj[k][t] d_light[k][c]  (columns 3.. of d_y are zeroed up to ldg)
+__global__ __launch_bounds__(kBlock) void env_project_bwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ proj,
+                                                                 const float* __restrict__ d_light, float* __restrict__ d_y, int ldg, int T) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T * ldg) return;
+    const int t = i / ldg, c = i % ldg;
+    float g = 0.0f;
+    if (c < 3) {
+        for (int k = 0; k < kNSH; ++k) g = fmaf(proj[(long)k * T + t], d_light[k * 3 + c], g);
+        const float v = y[t * ldy + c];
+        g *= v > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-v));
+    }
+    d_y[i] = g;
+}
+// dst = src where the image's statistics say the iteration improved (SaveBest's envmap snapshot, :247), n floats
+__global__ __launch_bounds__(kBlock) void select_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, const float* __restrict__ stats,
+                                                             int first, long n) {
+    if (!(first || stats[kStImproved] > 0.5f)) return;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) dst[i] = src[i];
+}
+// Adam with the step count and the learning rate in device memory (hyper[0] = lr, hyper[1] = step count so far): the update can
+// sit inside a captured hipGraph.  adam_dev_tick_kernel advances the count after the update.
+__global__ __launch_bounds__(kBlock) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, long n, const float* __restrict__ hyper, float b1, float b2,
+                                                          float eps) {
+    const float t = hyper[1] + 1.0f, lr = hyper[0];
+    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    const float lr_over_bc1 = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        float gi = g[i];
+        float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+        float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / fmaf(fsqrt(vi), inv_sqrt_bc2, eps);
+    }
+}
+__global__ void adam_dev_tick_kernel(float* __restrict__ hyper) { hyper[1] += 1.0f; }
+
 // Column sums of a row-major [M, N] matrix (N <= 1024): the bias gradient of a Linear layer over M = H*W points.
 // Pass 1: workgroup b sums rows [b*rows_per, ...) with thread t owning columns t, t+256, ... (coalesced row reads);
 // pass 2 adds the per-workgroup partials in fixed order.  PyTorch's reduce_kernel and rocBLAS gemv both take
@@ -253,6 +314,17 @@ __global__ __launch_bounds__(kBlock) void colsum_pass2_kernel(const float* __res
         for (int k = 0; k < 8; ++k) t += s_acc[k][cx];
         out[c] = t;
     }
+}
+
+// column sums of a small [M, N] matrix in one launch: a workgroup per 4 columns, 64 row slices per column (fixed-order folds)
+__global__ __launch_bounds__(kBlock) void colsum_small_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
+    const int slice = threadIdx.x & 63, cx = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + cx;
+    float a = 0.0f;
+    if (c < N)
+        for (int r = slice; r < M; r += 64) a += x[(long)r * N + c];
+    a = wave_sum_to_lane63(a);
+    if (slice == 63 && c < N) out[c] = a;
 }
 
 // Backward of y = sin(pre): out[i][j] = d_y[i*ld_d + j] * cos(pre[i*ld_p + j]), contiguous [M, n] result
@@ -806,6 +878,34 @@ int matpbr_relight(const float* T, const float* lights, float* out_rgb, int H, i
     return launch_status();
 }
 
+int matpbr_env_project(const float* y, int ldy, const float* proj, float* env, float* light, int n_texels, void* stream) {
+    if (!y || !proj || !env || !light || n_texels <= 0 || n_texels > 1024 || ldy < 3) return MATPBR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(env_project_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, y, ldy, proj, env, light, n_texels);
+    return launch_status();
+}
+
+int matpbr_env_project_bwd(const float* y, int ldy, const float* proj, const float* d_light, float* d_y, int ldg, int n_texels, void* stream) {
+    if (!y || !proj || !d_light || !d_y || n_texels <= 0 || ldy < 3 || ldg < 3) return MATPBR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(env_project_bwd_kernel, dim3((unsigned)((n_texels * ldg + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, ldy,
+                       proj, d_light, d_y, ldg, n_texels);
+    return launch_status();
+}
+
+int matpbr_select_improved(float* dst, const float* src, const float* stats, int first, long n, void* stream) {
+    if (!dst || !src || !stats || n <= 0) return MATPBR_ERR_INVALID_ARG;
+    unsigned blocks = (unsigned)std::min<long>((n + kBlock - 1) / kBlock, 1024);
+    hipLaunchKernelGGL(select_copy_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, dst, src, stats, first, n);
+    return launch_status();
+}
+
+int matpbr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps, void* stream) {
+    if (!p || !g || !m || !v || !hyper || n <= 0) return MATPBR_ERR_INVALID_ARG;
+    unsigned blocks = (unsigned)std::min<long>((n + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, (const float*)hyper, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_dev_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper);
+    return launch_status();
+}
+
 int matpbr_sin_bwd(const float* d_y, long ld_d, const float* pre, long ld_p, float* out, long M, int n, void* stream) {
     if (!d_y || !pre || !out || M <= 0 || n <= 0 || ld_d < n || ld_p < n) return MATPBR_ERR_INVALID_ARG;
     const long total = M * n;
@@ -819,6 +919,10 @@ size_t matpbr_column_sum_workspace_bytes(int N) { return N > 0 ? (size_t)kColsum
 
 int matpbr_column_sum(const float* x, float* out, long M, int N, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !out || M <= 0 || N <= 0) return MATPBR_ERR_INVALID_ARG;
+    if (M <= 1024) {   // the 512-point envmap MLP: one launch, 64 columns x 4 row slices per workgroup
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((unsigned)((N + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, out, (int)M, N);
+        return launch_status();
+    }
     if (!workspace || workspace_bytes < matpbr_column_sum_workspace_bytes(N)) return MATPBR_ERR_WORKSPACE;
     const long rows_per = (M + kColsumBlocks - 1) / kColsumBlocks;
     const int nblk = (int)((M + rows_per - 1) / rows_per);

@@ -845,6 +845,166 @@ __global__ __launch_bounds__(256) void mlp_mul_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Small point sets (M <= kSmallM rows): the 16x32 envmap MLP of hot loop A (mymodels/mlps.py PosMLP(output_type='envmap'), 512
+// points; inverse_img_w_mi.py:117-124,238-239).  A 128-row persistent tile would occupy 4-8 CUs; here every wave owns one 32x32
+// output tile over the whole reduction and feeds the MFMA straight from L2 (the operands of all layers together are < 3 MB):
+// 128 waves for a [512,256]x[256,256] product, ~130 MFMAs each.  Same entry points, same epilogues, same results contract.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr long kSmallM = 1024;
+
+__device__ __forceinline__ float4 ld4_masked(const float* p, int k, int K) {   // 4 consecutive k, zero beyond K (address clamped by the caller)
+  float4 v = *reinterpret_cast<const float4*>(p);
+  v.x = k < K ? v.x : 0.f;
+  v.y = k + 1 < K ? v.y : 0.f;
+  v.z = k + 2 < K ? v.z : 0.f;
+  v.w = k + 3 < K ? v.w : 0.f;
+  return v;
+}
+
+// C[m][n] = sum_k A[m][k] B[n][k] with the epilogues of mlp_gemm_nt: one workgroup per 32x32 tile of C.  Its four waves split the
+// reduction (k-quarters of <= 64), so every operand load of the tile is in flight at once (the data sits in another XCD's L2 or in
+// the Infinity Cache: ~2 us away) and 128 workgroups cover a [512,256] product; the partial tiles are folded through LDS in fixed
+// order and each wave finishes a quarter of the rows.  Lane l: row / column l & 31; lane half h = l >> 5 takes k = 8 j + 4 h .. + 3
+// of every 8-wide chunk j (A and B agree on the pairing, so the sum over k is unchanged).
+// EPI_MULC writes per-row-tile column sums to colsum[tile_m][256].
+// BKN: B is given as [K][ldb] (k-major: the forward weight of the layer, used as is by the backward product G W) instead of [N][ldb].
+template <int EPI, bool BKN = false>
+__global__ __launch_bounds__(256) void mlp_small_nt(const NtArgs p) {
+  __shared__ float s_part[4][16 * 64];
+  __shared__ float s_col[4][32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int tiles_n = (p.N + 31) >> 5;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int row = min(tm * 32 + li, p.M - 1), col = min(tn * 32 + li, p.N - 1);
+  const float* pa = p.A + (size_t)row * p.lda;
+  const float* pb = BKN ? p.B + col : p.B + (size_t)col * p.ldb;
+  const int kpad = (p.K + 3) & ~3;
+  const int kq = (((p.K + 3) / 4) + 7) & ~7;      // k per wave, a multiple of 8 (<= 64)
+  const int k_begin = wave * kq;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    float4 a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k_begin + 8 * j + 4 * lh;
+      const int kc = k < kpad ? k : kpad - 4;     // clamped address, masked value
+      const bool mine = 8 * j < kq;
+      a[j] = ld4_masked(pa + kc, k, mine ? p.K : 0);
+      if (BKN) {                                  // four rows of the k-major matrix: lanes run along n (coalesced)
+        const int K_ = mine ? p.K : 0;
+        b[j].x = k < K_ ? pb[(size_t)min(k, p.K - 1) * p.ldb] : 0.f;
+        b[j].y = k + 1 < K_ ? pb[(size_t)min(k + 1, p.K - 1) * p.ldb] : 0.f;
+        b[j].z = k + 2 < K_ ? pb[(size_t)min(k + 2, p.K - 1) * p.ldb] : 0.f;
+        b[j].w = k + 3 < K_ ? pb[(size_t)min(k + 3, p.K - 1) * p.ldb] : 0.f;
+      } else {
+        b[j] = ld4_masked(pb + kc, k, mine ? p.K : 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (8 * j < kq && k_begin + 8 * j < p.K) {  // wave-uniform
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b[j].w, acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_part[wave][r * 64 + lane] = acc[r];
+  __syncthreads();
+  const int n = tn * 32 + li;
+  const bool ncol = n < p.N;
+  const float bias = (EPI != EPI_MULC && ncol) ? p.bias[n] : 0.f;
+  float csum = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                   // wave w finishes accumulator rows 4 w .. 4 w + 3
+    const int r = 4 * wave + q;
+    const float v0 = ((s_part[0][r * 64 + lane] + s_part[1][r * 64 + lane]) + s_part[2][r * 64 + lane]) + s_part[3][r * 64 + lane];
+    const int m = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m < p.M && ncol) {
+      const size_t o = (size_t)m * p.ldo + n;
+      if (EPI == EPI_SINCOS) {
+        float sv, cv;
+        sincos_cw(v0 + bias, sv, cv);
+        p.out0[o] = sv;
+        p.out1[o] = cv;
+      } else if (EPI == EPI_BIAS) {
+        p.out0[o] = v0 + bias;
+      } else {
+        const float v = v0 * p.cmul[o];
+        p.out0[o] = v;
+        csum += v;
+      }
+    }
+  }
+  if (EPI == EPI_MULC && p.colsum != nullptr) {
+    csum += __shfl_xor(csum, 32);                 // the two lane halves hold different rows of the same column
+    if (lh == 0) s_col[wave][li] = csum;
+    __syncthreads();
+    if (wave == 0 && lh == 0 && ncol) p.colsum[(size_t)tm * 256 + n] = (s_col[0][li] + s_col[1][li]) + (s_col[2][li] + s_col[3][li]);
+  }
+}
+
+// dW[n][k] = sum_m G[m][n] X[m][k]: one workgroup per 32x32 tile of dW; its four waves split the reduction over m (<= kSmallM)
+// into quarters of <= 256 rows, issue every load of a 128-row half at once (64 + 64 dwords per lane), and fold their partial
+// tiles through LDS in fixed order.
+__global__ __launch_bounds__(256) void mlp_small_tn(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                    float* __restrict__ dW, int ldw, int M, int N, int K) {
+  __shared__ float s_part[3][16 * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int tiles_k = (K + 31) >> 5;
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+  const int n = tn * 32 + li, k = tk * 32 + li;
+  const bool nok = n < N, kok = k < K;
+  const float* pg = G + (nok ? n : N - 1);
+  const float* px = X + (kok ? k : K - 1);
+  const int quarter = ((M + 3) / 4 + 1) & ~1;     // rows per wave, even
+  const int m_begin = wave * quarter, m_end = min(M, m_begin + quarter);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int m0 = m_begin; m0 < m_end; m0 += 128) {
+    float a[64], b[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const int m = m0 + 2 * j + lh;
+      const int mc = m < M ? m : M - 1;
+      const float av = pg[(size_t)mc * ldg], bv = px[(size_t)mc * ldx];
+      a[j] = (m < m_end && nok) ? av : 0.f;
+      b[j] = (m < m_end && kok) ? bv : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 64; ++j)
+      if (m0 + 2 * j < m_end) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_part[wave - 1][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = ((acc[r] + s_part[0][r * 64 + lane]) + s_part[1][r * 64 + lane]) + s_part[2][r * 64 + lane];
+      const int nn = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (nn < N && kok) dW[(size_t)nn * ldw + k] = v;
+    }
+  }
+}
+
+template <int EPI, bool BKN = false>
+int launch_small_nt(NtArgs p, long M, hipStream_t stream) {
+  p.M = (int)M;
+  const int tiles = (int)((M + 31) / 32) * ((p.N + 31) / 32);
+  hipLaunchKernelGGL((mlp_small_nt<EPI, BKN>), dim3((unsigned)tiles), dim3(256), 0, stream, p);
+  return (int)((M + 31) / 32);   // column-sum groups
+}
+
 // (row tile, column half) work items; a workgroup must keep one column half across its persistent loop: grid multiple of 16
 inline unsigned nt_grid(long M, int N) {
   const long rt = (M + kBM - 1) / kBM;
@@ -903,7 +1063,10 @@ int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const
   if ((ldx & 3) || (ldw & 3) || ldx < ((K + 3) & ~3) || ldw < ((K + 3) & ~3) || ldo < N || !aligned16(x) || !aligned16(w))
     return MATPBR_ERR_INVALID_ARG;
   NtArgs p{x, w, bias, nullptr, s_out, c_out, nullptr, 0, N, K, ldx, ldw, ldo};
-  if (c_out)
+  if (M <= kSmallM) {
+    if (c_out) launch_small_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
+    else launch_small_nt<EPI_BIAS>(p, M, (hipStream_t)stream);
+  } else if (c_out)
     launch_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
   else
     launch_nt<EPI_BIAS>(p, M, (hipStream_t)stream);
@@ -920,7 +1083,20 @@ int matpbr_mlp_layer_bwd_input(const float* g, int ldg, const float* wt, int ldw
     return MATPBR_ERR_INVALID_ARG;
   if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
   NtArgs p{g, wt, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, 0, n_prev, n_red, ldg, ldwt, ldo};
-  const int groups = launch_nt<EPI_MULC>(p, M, (hipStream_t)stream);
+  const int groups = M <= kSmallM ? launch_small_nt<EPI_MULC>(p, M, (hipStream_t)stream) : launch_nt<EPI_MULC>(p, M, (hipStream_t)stream);
+  if (d_bias_prev)
+    hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_bwd_input_w(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo,
+                                 float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
+  if (!g || !w || !c_prev || !g_prev || M <= 0 || n_prev <= 0 || n_prev > 256 || n_red <= 0 || n_red > 256) return MATPBR_ERR_INVALID_ARG;
+  if (M > kSmallM) return MATPBR_ERR_UNSUPPORTED;   // large point sets use matpbr_mlp_layer_bwd_input with the transposed weight
+  if ((ldg & 3) || ldg < ((n_red + 3) & ~3) || ldw < n_prev || ldo < n_prev || !aligned16(g)) return MATPBR_ERR_INVALID_ARG;
+  if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
+  NtArgs p{g, w, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, 0, n_prev, n_red, ldg, ldw, ldo};
+  const int groups = launch_small_nt<EPI_MULC, true>(p, M, (hipStream_t)stream);
   if (d_bias_prev)
     hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
@@ -939,6 +1115,11 @@ int matpbr_mlp_layer_bwd_weight(const float* g, int ldg, const float* x, int ldx
                                 size_t workspace_bytes, long M, int N, int K, void* stream) {
   if (!g || !x || !d_w || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
   if ((ldg & 3) || (ldx & 3) || ldg < N || ldx < ((K + 3) & ~3) || ldw < K || !aligned16(g) || !aligned16(x)) return MATPBR_ERR_INVALID_ARG;
+  if (M <= kSmallM) {
+    const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
+    hipLaunchKernelGGL(mlp_small_tn, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, d_w, ldw, (int)M, N, K);
+    return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+  }
   if (!workspace || workspace_bytes < matpbr_mlp_bwd_weight_workspace_bytes(M)) return MATPBR_ERR_WORKSPACE;
   const int slabs = wgrad_slabs(M);
   long rows = (M + slabs - 1) / slabs;

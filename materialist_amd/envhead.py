@@ -1,0 +1,213 @@
+"""Hot loop A with the reference's light parameterisation, launch by launch on the C ABI (inverse_img_w_mi.py:117-124,225-254):
+
+    envmap = envmap_net(start_envmap)              PosMLP(output_type='envmap'): 13 -> 243 -> 256 -> 243 -> 256 -> 3, softplus
+    image  = render_envmap(scene, envmap, spp)     materials and normals fixed during the phase (:216-220)
+    loss   = MSE + L1 on x^(1/2.2); backward; Adam step; SaveBest; EarlyStopping
+
+The envmap MLP works on 512 points: composed from framework ops (autograd node, foreach Adam, SH projection matmul, selects)
+the iteration is ~60 launches of which the render is two.  Here the whole iteration is 27 launches of libmatpbr.so -- five
+sine / output layers on the small-tile MFMA kernels, softplus + SH projection, the pass over the radiance transfer, the
+snapshot of the best envmap, the backward chain (bias gradients in the GEMM epilogues, weights read as stored) and one Adam
+launch over a flat parameter buffer whose step count and learning rate live in device memory -- captured once into a hipGraph
+and replayed.  PyTorch holds the memory and the capture; the parameters stay `torch.nn.Parameter`s of the PosMLP module (views
+of the flat buffer), so `state_dict()` / `load_state_dict()` and the reference's checkpoint layout are untouched.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops
+from . import loss as _loss
+from . import render as _render
+
+_al4 = lambda n: (n + 3) // 4 * 4
+
+
+class EnvMlpPhase:
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_envmap: torch.Tensor, spp: int = 64,
+                 lr: float = 1e-3, patience: int = 0, min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None,
+                 history_len: int = 5000, use_graph: bool = True, env_size=(16, 32)):
+        if gt_image.ndim != 3:
+            raise NotImplementedError("the envmap MLP optimises one image per process (as the reference does)")
+        if getattr(net, "output_type", None) != "envmap":
+            raise ValueError("EnvMlpPhase needs a PosMLP with output_type='envmap'")
+        self.scene, self.net, self.spp = scene, net, int(spp)
+        self.gt = gt_image.contiguous()
+        dev = self.dev = self.gt.device
+        self.H, self.W = self.gt.shape[0], self.gt.shape[1]
+        self.env_size = tuple(env_size)
+        self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
+        self.lib = _lib.load()
+        self.use_graph, self._graph, self._warm, self.t = bool(use_graph), None, 0, 0
+        self.patience, self.min_delta = int(patience), float(min_delta)
+        # ---- network state: parameters as views of one flat buffer (weights with rows padded to 4 floats) ----------------------
+        x0 = net._points(start_envmap.detach().to(dev, torch.float32))
+        M, d0 = x0.shape
+        if M > 1024 or M != self.env_size[0] * self.env_size[1]:
+            raise ValueError("the envmap MLP runs on the small-tile kernels: at most 1024 texels")
+        self.M, self.d0, self.L = M, d0, net.n_layers
+        lins = [(getattr(net, f"lin{l}").linear if l < self.L - 1 else getattr(net, f"lin{l}")) for l in range(self.L)]
+        st = getattr(net, "_flat_state", None)
+        if st is None:
+            sizes = []
+            for lin in lins:
+                n, k = lin.weight.shape
+                sizes += [n * _al4(k), _al4(n)]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            off, views = 0, []
+            for lin in lins:
+                n, k = lin.weight.shape
+                wp = flat[off:off + n * _al4(k)].view(n, _al4(k))
+                wp[:, :k].copy_(lin.weight.detach())
+                lin.weight.data = wp[:, :k]                      # a strided view when k is not a multiple of 4 (the first layer)
+                off += n * _al4(k)
+                bp = flat[off:off + n]
+                bp.copy_(lin.bias.detach())
+                lin.bias.data = bp
+                off += _al4(n)
+                views.append((wp, bp))
+            st = net._flat_state = {"flat": flat, "views": views}
+        self.flat, self.views = st["flat"], st["views"]
+        self.gflat = torch.zeros_like(self.flat)
+        self.adam_m, self.adam_v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)    # a fresh Adam per phase (:225-229)
+        self.hyper = torch.tensor([float(lr), 0.0], dtype=torch.float32, device=dev)
+        gviews, off = [], 0
+        for wp, bp in self.views:
+            gw = self.gflat[off:off + wp.numel()].view_as(wp)
+            off += wp.numel()
+            gb = self.gflat[off:off + _al4(bp.numel())]
+            off += _al4(bp.numel())
+            gviews.append((gw, gb))
+        # ---- activations ---------------------------------------------------------------------------------------------------------
+        E = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.x0p = E(M, _al4(d0))
+        self.x0p[:, :d0] = x0
+        widths, Ks, ns = [], [], []
+        K = d0
+        for l in range(self.L - 1):
+            n = lins[l].weight.shape[0]
+            width = n + d0 if (l + 1) in net.skip else n
+            if width % 4:
+                raise ValueError("layer widths must be multiples of 4")
+            widths.append(width); Ks.append(K); ns.append(n)
+            K = width
+        self.n_last = lins[-1].weight.shape[0]
+        self.bufs = [E(M, w) for w in widths]
+        for l, w in enumerate(widths):
+            if w != ns[l]:
+                self.bufs[l][:, ns[l]:] = x0                     # cat(x, x0) of the skip layers: x0 is constant, written once
+        self.cbufs = [E(M, w) for w in widths]
+        self.gbufs = [E(M, w) for w in widths]
+        self.y = E(M, 4)
+        self.g_out = E(M, 4)
+        self.env = E(M, 3)
+        self.best_env_flat = E(M, 3)
+        self.light = E(25, 3)
+        self.d_light = E(25, 3)
+        self.proj = scene.projection(*self.env_size).contiguous()
+        self.stats = ops.new_loss_stats(1, dev)
+        if best_mse is not None:
+            self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
+        self.hist = E(history_len, 1)
+        self.ws_env = E(int(self.lib.matpbr_env_phase_workspace_bytes(self.H, self.W, 1)) // 4 + 1)
+        self.ws_in = E(int(self.lib.matpbr_mlp_bwd_input_workspace_bytes(M)) // 4 + 1)
+        shp = (self.H, self.W)
+        self.T = ops.shade_transfer(scene.a.contiguous(), scene.r.reshape(shp + (1,)).contiguous(), scene.m.reshape(shp + (1,)).contiguous(),
+                                    scene.shading_normal().contiguous(), self.spp, scene.fov)
+        # ---- the launch list of one iteration --------------------------------------------------------------------------------------
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        lib, calls = self.lib, []
+        inps = [self.x0p] + self.bufs
+        for l in range(self.L - 1):                              # sine layers: sin and cos from the GEMM epilogue
+            wp, bp = self.views[l]
+            calls.append((lib.matpbr_mlp_layer_fwd, (P(inps[l]), inps[l].stride(0), P(wp), wp.stride(0), P(bp), P(self.bufs[l]), P(self.cbufs[l]),
+                                                     self.bufs[l].stride(0), M, ns[l], Ks[l])))
+        wp, bp = self.views[-1]
+        calls.append((lib.matpbr_mlp_layer_fwd, (P(inps[-1]), inps[-1].stride(0), P(wp), wp.stride(0), P(bp), P(self.y), None, 4, M, self.n_last, K)))
+        calls.append((lib.matpbr_env_project, (P(self.y), 4, P(self.proj), P(self.env), P(self.light), M)))
+        calls.append((lib.matpbr_env_phase_step, (P(self.T), P(self.light), P(self.gt_srgb), None, P(self.d_light), P(self.stats), P(self.hist),
+                                                  history_len, self.patience, self.min_delta, P(self.ws_env), self.ws_env.numel() * 4, self.H,
+                                                  self.W, 1)))
+        self._select_at = len(calls)
+        calls.append((lib.matpbr_select_improved, (P(self.best_env_flat), P(self.env), P(self.stats), 0, M * 3)))
+        calls.append((lib.matpbr_env_project_bwd, (P(self.y), 4, P(self.proj), P(self.d_light), P(self.g_out), 4, M)))
+        gw, gb = gviews[-1]
+        calls.append((lib.matpbr_column_sum, (P(self.g_out), P(gb), M, 4, None, 0)))
+        calls.append((lib.matpbr_mlp_layer_bwd_weight, (P(self.g_out), 4, P(inps[-1]), inps[-1].stride(0), P(gw), gw.stride(0), None, 0, M,
+                                                        self.n_last, K)))
+        g, ldg, n_red = self.g_out, 4, self.n_last
+        for l in range(self.L - 1, 0, -1):                       # g = dL/d pre of layer l -> dL/d pre of layer l-1 and its bias gradient
+            wp, _ = self.views[l]
+            gw, gb = gviews[l - 1]
+            calls.append((lib.matpbr_mlp_layer_bwd_input_w, (P(g), ldg, P(wp), wp.stride(0), P(self.cbufs[l - 1]), P(self.gbufs[l - 1]),
+                                                             self.gbufs[l - 1].stride(0), P(gb), P(self.ws_in), self.ws_in.numel() * 4, M,
+                                                             ns[l - 1], n_red)))
+            g, ldg, n_red = self.gbufs[l - 1], self.gbufs[l - 1].stride(0), ns[l - 1]
+            calls.append((lib.matpbr_mlp_layer_bwd_weight, (P(g), ldg, P(inps[l - 1]), inps[l - 1].stride(0), P(gw), gw.stride(0), None, 0, M,
+                                                            ns[l - 1], Ks[l - 1])))
+        calls.append((lib.matpbr_adam_step_dev, (P(self.flat), P(self.gflat), P(self.adam_m), P(self.adam_v), self.flat.numel(), P(self.hyper),
+                                                 0.9, 0.999, 1e-8)))
+        self._calls = calls
+        self._first = True
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def set_lr(self, lr: float) -> None:
+        self.hyper[0:1].fill_(float(lr))
+
+    def _body(self) -> None:
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        for i, (fn, args) in enumerate(self._calls):
+            if i == self._select_at and self._first:
+                args = args[:3] + (1,) + args[4:]               # the first iteration always snapshots (best_env starts undefined)
+            code = fn(*args, stream)
+            if code != 0:
+                _lib.check(code, fn.__name__)
+        self._first = False
+
+    def step(self) -> None:
+        with torch.cuda.device(self.dev):
+            if not self.use_graph:
+                self._body()
+            elif self._graph is not None:
+                self._graph.replay()
+            elif self._warm < 3:                                 # eager iterations first (lazy initialisations, the forced first snapshot)
+                self._body()
+                self._warm += 1
+            else:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._body()
+                self._graph = graph                              # the capture itself does not execute: replay it for this iteration
+                graph.replay()
+        self.t += 1
+
+    def head(self) -> torch.Tensor:
+        """The envmap of the last executed iteration, [He, We, 3] (what `envmap_net(start_envmap)` returned in it)."""
+        return self.env.view(self.env_size + (3,))
+
+    @property
+    def best_env(self) -> torch.Tensor:
+        return self.best_env_flat.view(self.env_size + (3,))
+
+    @property
+    def best_img(self) -> torch.Tensor:
+        """Linear render under the best-so-far envmap (SaveBest.rendered_img of the env phase, :247)."""
+        light = self.scene.light_from_emitter(self.best_env).detach().reshape(1, 25, 3).contiguous()
+        return ops.relight(self.T, light, self.H, self.W)[0]
+
+    @property
+    def pred(self) -> torch.Tensor:
+        """Render under the current envmap (frames); not kept per iteration."""
+        return ops.relight(self.T, self.light.reshape(1, 25, 3), self.H, self.W)[0]
+
+    def poll(self) -> Dict[str, torch.Tensor]:
+        st, o = self.stats.cpu(), ops
+        return {"stopped": st[:, o.STAT_STOPPED] > 0.5, "iters": st[:, o.STAT_ITERS].to(torch.int64), "best_mse": st[:, o.STAT_BEST],
+                "mse": st[:, o.STAT_MSE], "loss": st[:, o.STAT_LOSS]}
+
+    def history(self) -> torch.Tensor:
+        return self.hist[: self.t]

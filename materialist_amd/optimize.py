@@ -127,19 +127,30 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         if background:
             return env_phase_runner_background(loop_num, lr_of, patience, min_delta, max_epochs)
         graph = max_epochs > 8 and gt.is_cuda
-        opt = _loop.capturable_adam(env_params, lr_of(0)) if graph else torch.optim.Adam(env_params, lr=lr_of(0))   # fresh Adam per loop (:225-229)
-        ph = _loop.FusedEnvPhase(scene, gt, env_head, opt, spp=spp, patience=patience,
-                                 min_delta=min_delta, best_mse=saver.best_loss, history_len=max_epochs, use_graph=graph)
-        done, stop = 0, "num_epochs"
+        if model_name == "pos_mlp":
+            # the reference's parameterisation (envmap_net, :117-124,238-239), every launch of the iteration on the C ABI
+            from .envhead import EnvMlpPhase
+
+            ph = EnvMlpPhase(scene, gt, env_net, start_envmap, spp=spp, lr=lr_of(0), patience=patience, min_delta=min_delta,
+                             best_mse=saver.best_loss, history_len=max_epochs, use_graph=graph, env_size=env_size)
+            set_lr, head_now = ph.set_lr, (lambda: ph.head())
+        else:
+            opt = _loop.capturable_adam(env_params, lr_of(0)) if graph else torch.optim.Adam(env_params, lr=lr_of(0))   # fresh Adam per loop (:225-229)
+            ph = _loop.FusedEnvPhase(scene, gt, env_head, opt, spp=spp, patience=patience,
+                                     min_delta=min_delta, best_mse=saver.best_loss, history_len=max_epochs, use_graph=graph)
+            set_lr, head_now = (lambda lr: _loop.set_lr(opt, lr)), (lambda: env_head().detach())
+        done, stop, lr_now = 0, "num_epochs", lr_of(0)
         while done < max_epochs:
             k = min(sync_every, max_epochs - done)
             for _ in range(k):
-                _loop.set_lr(opt, lr_of(done))
+                if lr_of(done) != lr_now:
+                    lr_now = lr_of(done)
+                    set_lr(lr_now)
                 ph.step()
                 done += 1
             info = ph.poll()
             if frames is not None and gt.ndim == 3 and frames.due("env"):
-                frames.env_frame(loop_num, done - 1, gt, ph.pred, env_head().detach())
+                frames.env_frame(loop_num, done - 1, gt, ph.pred, head_now())
             if bool(info["stopped"].all()):
                 stop = "early_stop"
                 break

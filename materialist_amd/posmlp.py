@@ -130,14 +130,15 @@ class _PosMlpHipFn(torch.autograd.Function):
     Same buffer trick as `_PosMlpFn` for the skip layers: the producer writes the first columns of a 256-wide buffer whose tail
     holds x0.  The input x0 gets no gradient here (it is the constant `start_arm` of the optimisation loop)."""
 
-    MIN_ROWS = 8192
+    MIN_ROWS = 8192         # persistent 128-row tiles from here up ...
+    SMALL_ROWS = 1024       # ... one 32x32 tile per wave straight from L2 up to here (the 16x32 envmap MLP); BLAS in between
 
     @staticmethod
     def supported(x0: torch.Tensor, skip, weights) -> bool:
         L = len(weights)
         if not (x0.is_cuda and x0.dtype == torch.float32 and not x0.requires_grad and L >= 2):
             return False
-        if x0.shape[0] < _PosMlpHipFn.MIN_ROWS:          # a 16x32 envmap is 4 row tiles: launch-latency territory, BLAS is fine
+        if _PosMlpHipFn.SMALL_ROWS < x0.shape[0] < _PosMlpHipFn.MIN_ROWS:
             return False
         d0, k = x0.shape[1], x0.shape[1]
         for l in range(L - 1):
@@ -171,9 +172,16 @@ class _PosMlpHipFn(torch.autograd.Function):
             coss.append(cbuf)
             inp, K = buf, width
         inps.append(inp)
-        out = torch.addmm(biases[L - 1], inp, weights[L - 1].t())
+        small = M <= _PosMlpHipFn.SMALL_ROWS
+        if small:                                      # the output layer on the small-tile kernel too: no BLAS call in the iteration
+            n_last = weights[L - 1].shape[0]
+            out = torch.empty((M, _ceil4(n_last)), dtype=torch.float32, device=x0.device)   # row stride: a multiple of 4 floats
+            ops.mlp_layer_fwd(inp, _pad_cols(weights[L - 1], _ceil4(K)), biases[L - 1], out, None, K)
+            out = out[:, :n_last]
+        else:
+            out = torch.addmm(biases[L - 1], inp, weights[L - 1].t())
         ctx.save_for_backward(x0, *weights, *inps, *coss)
-        ctx.L = L
+        ctx.L, ctx.small = L, small
         return out
 
     @staticmethod
@@ -188,9 +196,10 @@ class _PosMlpHipFn(torch.autograd.Function):
         grads = [None] * (2 * L)
         g = grad_out.contiguous()
         n_out = g.shape[1]
-        grads[2 * (L - 1)] = _split_k_tn(g, inps[L - 1])
         grads[2 * (L - 1) + 1] = _column_sum(g)
         g, n_red = _pad_cols(g, _ceil4(n_out)), n_out
+        grads[2 * (L - 1)] = (ops.mlp_layer_bwd_weight(g, inps[L - 1], n_out, weights[L - 1].shape[1]) if ctx.small
+                              else _split_k_tn(g[:, :n_out], inps[L - 1]))
         for l in range(L - 1, 0, -1):                  # g = dL/d pre of layer l  ->  dL/d pre of layer l-1, its bias gradient
             n_prev = weights[l - 1].shape[0]
             wt = _pad_cols(weights[l][:, :n_prev].t(), 256 if n_red > 224 else _ceil4(n_red))   # 256-wide rows: the fast kernels' precondition
@@ -201,7 +210,10 @@ class _PosMlpHipFn(torch.autograd.Function):
             g, n_red = g_prev, n_prev
             if l - 1 >= 1:
                 grads[2 * (l - 1)] = ops.mlp_layer_bwd_weight(g, inps[l - 1], n_prev, weights[l - 1].shape[1])
-        grads[0] = _split_k_tn(g[:, :n_red], x0)        # K = 15: a BLAS product
+        if ctx.small:
+            grads[0] = ops.mlp_layer_bwd_weight(g, inps[0], n_red, x0.shape[1])
+        else:
+            grads[0] = _split_k_tn(g[:, :n_red], x0)    # K = 15: a BLAS product
         return (None, None, *grads)
 
 

@@ -901,3 +901,61 @@ def test_outdoor_sample_with_mesh_mask(tmp_path):
     assert out["psnr_vs_photo"]["this_build_ground_only"] > 24.0      # 27 dB at this epoch cap, 42 dB with the default 5000
     assert out["psnr_vs_photo"]["this_build_sky_only"] > 28.0         # a 25-coefficient light has to carry the whole sky
     assert os.path.exists(os.path.join(str(tmp_path), "jinjya", "opt_env_img.png"))
+
+
+def test_env_mlp_phase_matches_the_autograd_composition():
+    """Hot loop A with the reference's envmap MLP (inverse_img_w_mi.py:117-124,238-254), every launch on the C ABI (EnvMlpPhase:
+    small-tile MFMA layers, softplus + SH projection, the pass over the radiance transfer, explicit backward chain, one Adam
+    launch with device-side step count) against the same iterations composed with torch autograd around `render_envmap`
+    (PosMLP module -> softplus -> projection -> autograd render -> env_loss -> torch.optim.Adam)."""
+    import copy
+
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+    from materialist_amd.envhead import EnvMlpPhase
+
+    dev = _cuda()
+    H = W = 48
+    spp = 16
+    sc = synthetic.make_scene(8, H, W)
+
+    def make_scene():
+        s = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+        p = render.traverse(s)
+        p["shape.bsdf.a"], p["shape.bsdf.r"], p["shape.bsdf.m"] = _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev)
+        return s
+
+    with torch.no_grad():
+        gt = render.render_envmap(make_scene(), _t(sc.light, dev), spp).clone()
+    torch.manual_seed(3)
+    net_a = posmlp.envmap_net().to(dev)
+    net_a.lin4.weight.data.normal_(0, 0.05)            # the reference zero-initialises the last layer: give the gradients something to do
+    net_b = copy.deepcopy(net_a)
+    ones = torch.ones(512, 3, device=dev)
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=1e-3)
+    sa = make_scene()
+    ph = EnvMlpPhase(make_scene(), gt, net_b, ones, spp=spp, lr=1e-3, use_graph=True)
+    for it in range(7):                                  # 3 eager iterations, the capture, 3 replays
+        if it == 5:
+            for gp in opt_a.param_groups:
+                gp["lr"] = 5e-4
+            ph.set_lr(5e-4)
+        env = net_a(ones).reshape(16, 32, 3)
+        pred = render.render_envmap(sa, env, spp)
+        total, mse, _ = loop._loss.env_loss(pred, gt)
+        total.backward()
+        opt_a.step()
+        opt_a.zero_grad()
+        ph.step()
+        st = ph.stats[0].cpu().numpy()
+        assert st[ops.STAT_MSE] == pytest.approx(float(mse.detach()), rel=5e-4), it
+        assert st[ops.STAT_LOSS] == pytest.approx(float(total.detach()), rel=5e-4), it
+    assert ph._graph is not None and ph.poll()["iters"].tolist() == [7]
+    for (ka, va), (kb, vb) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+        assert ka == kb and (va - vb).abs().max().item() < 2e-5, ka       # 7 Adam steps of <= 1e-3
+    assert_close(ph.head(), env.detach().cpu().numpy(), rtol=2e-3, what="envmap of the last iteration")
+    assert ph.best_env.shape == (16, 32, 3) and ph.best_img.shape == (H, W, 3)
+    # the module keeps working as a module (parameters are views of the flat buffer): state_dict round trip
+    before = net_b(ones).detach().clone()
+    sd = {k: v.clone() for k, v in net_b.state_dict().items()}
+    net_b.load_state_dict(sd)
+    assert torch.equal(net_b(ones).detach(), before)
