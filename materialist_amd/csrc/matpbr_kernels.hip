@@ -224,24 +224,18 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float* __restrict__ p
 // ---- the envmap head of hot loop A (inverse_img_w_mi.py:238-239: envmap = envmap_net(start_envmap); PosMLP 'envmap' head:
 // softplus, mymodels/mlps.py:230-232) joined to the light the kernels integrate: texels e = softplus(y) [T,3] (y with row stride
 // ldy), light[k][c] = sum_t proj[k][t] e[t][c] (the fixed 25 x T SH projection of materialist_amd/sh.py).  T <= 1024 texels.
-__global__ __launch_bounds__(kBlock) void env_project_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ proj,
-                                                             float* __restrict__ env, float* __restrict__ light, int T) {
-    __shared__ float s_e[1024 * 3];
-    for (int i = threadIdx.x; i < T * 3; i += kBlock) {
-        const float v = y[(i / 3) * ldy + (i % 3)];
+__global__ __launch_bounds__(64) void env_project_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ proj,
+                                                         float* __restrict__ env, float* __restrict__ light, int T) {
+    const int q = blockIdx.x, k = q / 3, c = q % 3;                // one wave per light scalar, lanes along the texels
+    float a = 0.0f;
+    for (int t = threadIdx.x; t < T; t += 64) {
+        const float v = y[t * ldy + c];
         const float e = v > 20.0f ? v : log1pf(expf(v));          // torch.nn.functional.softplus (beta 1, threshold 20)
-        s_e[i] = e;
-        env[i] = e;
+        if (k == 0) env[t * 3 + c] = e;
+        a = fmaf(proj[(long)k * T + t], e, a);
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int q = wave; q < kNL; q += 4) {                          // one wave per light scalar, lanes along the texels
-        const int k = q / 3, c = q % 3;
-        float a = 0.0f;
-        for (int t = lane; t < T; t += 64) a = fmaf(proj[(long)k * T + t], s_e[t * 3 + c], a);
-        a = wave_sum_to_lane63(a);
-        if (lane == 63) light[q] = a;
-    }
+    a = wave_sum_to_lane63(a);
+    if (threadIdx.x == 63) light[q] = a;
 }
 // backward: d_y[t][c] = sigmoid(y[t][c]) * sum_k proj[k][t] d_light[k][c]  (columns 3.. of d_y are zeroed up to ldg)
 __global__ __launch_bounds__(kBlock) void env_project_bwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ proj,
@@ -880,7 +874,7 @@ int matpbr_relight(const float* T, const float* lights, float* out_rgb, int H, i
 
 int matpbr_env_project(const float* y, int ldy, const float* proj, float* env, float* light, int n_texels, void* stream) {
     if (!y || !proj || !env || !light || n_texels <= 0 || n_texels > 1024 || ldy < 3) return MATPBR_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(env_project_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, y, ldy, proj, env, light, n_texels);
+    hipLaunchKernelGGL(env_project_kernel, dim3(kNL), dim3(64), 0, (hipStream_t)stream, y, ldy, proj, env, light, n_texels);
     return launch_status();
 }
 
