@@ -219,6 +219,23 @@ int matpbr_mlp_layer_bwd_weight(const float* g, int ldg, const float* x, int ldx
 int matpbr_mlp_sincos(const float* pre, long ldp, float* s_out, long lds, float* c_out, long ldc, long M, int n, void* stream);
 int matpbr_mlp_mul(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long M, int n, void* stream);
 
+/* The same sine-layer products on the bf16 matrix pipe with SPLIT OPERANDS (csrc/posmlp_kernels.hip, "bx" kernels): an f32 number is
+ * the exact sum of three bf16 numbers and a product of two bf16 numbers is exact in f32, so x w^T = sum_ij x_i w_j^T with f32
+ * accumulation; nprod = 9 keeps every partial product (the f32 product, exactly), nprod = 6 drops those below 2^-24 |x||w| (one f32
+ * rounding).  The layer then runs at its HBM traffic instead of the f32-MFMA rate.
+ *   matpbr_mlp_split_weights   w[N, K] (row stride ldw) -> wsplit (matpbr_mlp_wsplit_bytes(K); opaque), once per weight state; for the
+ *                              backward product pass the transposed weight wt[n_prev, n_red] of matpbr_mlp_layer_bwd_input
+ *   matpbr_mlp_layer_fwd_bx / _bwd_input_bx   as matpbr_mlp_layer_fwd / _bwd_input (sine layers: c_out required); M a multiple of 128,
+ *                              256-wide output buffers (ldo >= 256), x / g readable up to the next multiple of 32 columns
+ *                              (MATPBR_ERR_UNSUPPORTED otherwise: use the f32 entry points) */
+size_t matpbr_mlp_wsplit_bytes(int K);
+int matpbr_mlp_split_weights(const float* w, int ldw, int N, int K, void* wsplit, void* stream);
+int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo, long M,
+                            int N, int K, int nprod, void* stream);
+int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo,
+                                  float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
+                                  int nprod, void* stream);
+
 /* Forward-only relighting (render_final.py:148-203 `render_w_mi`, :290-418 `rotate_envmap` / `render_rolling_envmap`).
  * The render is linear in the light, R = sum_k light[k] * T[k]:
  *   matpbr_shade_transfer  per-pixel transfer (d render / d light, both lobes) of the current materials into T (matpbr_transfer_bytes(); 300 B/pixel, tiled

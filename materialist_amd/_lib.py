@@ -62,6 +62,12 @@ SIGNATURES = {
     "matpbr_adam_step_dev": (ctypes.c_int, [_c_f] * 4 + [ctypes.c_long, _c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "matpbr_mlp_layer_bwd_input_w": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_void_p,
                                                    ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_wsplit_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "matpbr_mlp_split_weights": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_void_p]),
+    "matpbr_mlp_layer_fwd_bx": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_bwd_input_bx": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_void_p, ctypes.c_size_t,
+                                                    ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_sin_bwd": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_layer_fwd": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_void_p]),

@@ -1005,6 +1005,244 @@ int launch_small_nt(NtArgs p, long M, hipStream_t stream) {
   return (int)((M + 31) / 32);   // column-sum groups
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-operand products on the bf16 matrix pipe ("bx" kernels).
+// An f32 number is the exact sum of three bf16 numbers, x = x1 + x2 + x3 (round-to-nearest pieces of the running residual: 8 + 8 + 8
+// significand bits), and a product of two bf16 numbers is exact in f32.  A x B = sum_{i,j} A_i B_j therefore runs on
+// v_mfma_f32_32x32x16_bf16 with f32 accumulation: all 9 products reproduce the f32 product exactly before accumulation; the 6
+// products with i + j <= 4 drop terms below 2^-24 |a||b| (the size of one f32 rounding).  The bf16 pipe is 16x the f32-input
+// MFMA (32 cycles per 32x32x16 step against 8 x 64), so 6 (9) products cost 0.375 (0.56) of the f32 kernel's matrix time, and
+// the layer becomes bound by its HBM traffic (read X, write sin and cos: 805 MB per 512x512 layer).
+//
+// No LDS in the k-loop, no barriers: every wave owns a 64 x 128 block of the output (2 x 4 accumulator tiles) and loads its
+// operands already in MFMA layout -- lane (l & 31, l >> 5) reads 16 consecutive k of its A row per 32-wide super-step (a full
+// 128-byte line per row) and splits them in registers; the weights are split once per call into `wsplit`, ordered so that a wave's
+// read of one operand is 1 KB contiguous, and come from L2.  One workgroup (2 x 2 waves, 128 x 256 outputs) per CU, persistent.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // round-to-nearest-even, lo -> bits 15:0
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// (x0, x1) -> three packed bf16 pairs with x = p1 + p2 + p3 exactly (up to the last piece's rounding, 2^-25 |x|)
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+  p2 = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+  p3 = cvt_pk_bf16(s0, s1);
+}
+
+// wsplit layout: [K/32 super-steps][2 steps][3 pieces][2 lane halves g][256 rows n] x uint4 (8 bf16: k = 32 ks + 16 g + 8 s + j).
+// One super-step (3072 uint4 = 48 KB) is also the LDS image of the weights for that super-step: a wave's read of one operand is
+// two contiguous 512-byte runs (conflict-free), the global -> LDS copy is a straight copy.
+constexpr int kBxStage = 2 * 3 * 2 * 256;   // uint4 per super-step
+__host__ __device__ inline size_t wsplit_index(int ks, int s, int piece, int n, int g) {
+  return ((((size_t)ks * 2 + s) * 3 + piece) * 2 + g) * 256 + n;
+}
+__global__ __launch_bounds__(256) void mlp_split_weights_kernel(const float* __restrict__ B, int ldb, int N, int K, uint4* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // over (ks, s, n, g)
+  const int nks = (K + 31) / 32;
+  if (idx >= nks * 2 * 256 * 2) return;
+  const int g = idx & 1, n = (idx >> 1) & 255, s = (idx >> 9) & 1, ks = idx >> 10;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * ks + 16 * g + 8 * s + j;
+    v[j] = (n < N && k < K) ? B[(size_t)n * ldb + k] : 0.f;
+  }
+  unsigned p[3][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split3(v[2 * q], v[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+  for (int piece = 0; piece < 3; ++piece) out[wsplit_index(ks, s, piece, n, g)] = make_uint4(p[piece][0], p[piece][1], p[piece][2], p[piece][3]);
+}
+
+// Eight waves per workgroup (4 row groups of 32 x 2 column halves of 128; 128 x 256 outputs per workgroup, one workgroup per
+// CU): two waves per SIMD, so that one wave's operand split / LDS traffic / epilogue runs under the other's products.
+constexpr int kBxThreads = 512;
+template <int EPI, int NPROD>
+__global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const uint4* __restrict__ wsplit) {
+  extern __shared__ __align__(16) unsigned char bx_smem[];
+  uint4* sB = reinterpret_cast<uint4*>(bx_smem);                         // [2 buffers][kBxStage]
+  float* sScr = reinterpret_cast<float*>(bx_smem + 2 * kBxStage * sizeof(uint4));   // [8 waves][32][kLd]
+  float* sRed = reinterpret_cast<float*>(bx_smem);                       // [32][256] after the last tile (aliases sB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int nks = (p.K + 31) / 32;
+  const int tiles = p.M / kBM;
+  constexpr int kCopy = kBxStage / kBxThreads;                           // uint4 per thread and super-step of the weight stream
+  float bn[4];
+  float4 csum4[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = wn * 128 + ni * 32 + li;
+    bn[ni] = (EPI != EPI_MULC) ? p.bias[n < p.N ? n : p.N - 1] : 0.f;
+    csum4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int b_lane = lh * 256 + wn * 128 + li;                           // + ((s * 3 + piece) * 2) * 256 + ni * 32
+  // the weights of super-step 0 are resident in buffer 0 at the start of every tile: the stream of super-steps runs across tiles
+  uint4 bnext[kCopy];
+#pragma unroll
+  for (int q = 0; q < kCopy; ++q) sB[tid + kBxThreads * q] = wsplit[tid + kBxThreads * q];
+  __syncthreads();
+  int buf = 0;
+
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int row0 = tile * kBM;
+    const float* pa0 = p.A + (size_t)(row0 + wm * 32 + li) * p.lda + 16 * lh;
+    f32x16 acc[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+
+    float4 raw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const float4*>(pa0 + 4 * q);
+    for (int ks = 0; ks < nks; ++ks) {
+      const int ksn = ks + 1 < nks ? ks + 1 : 0;                           // next super-step of the stream (wraps into the next tile)
+      float4 cur[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cur[q] = raw[q];
+      // in flight during this super-step's products: the next weights (global -> registers) and the next 16 k of the rows
+      const uint4* wsrc = wsplit + (size_t)ksn * kBxStage + tid;
+#pragma unroll
+      for (int q = 0; q < kCopy; ++q) bnext[q] = wsrc[kBxThreads * q];
+      if (ks + 1 < nks) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const float4*>(pa0 + 32 * (ks + 1) + 4 * q);
+      }
+      if (32 * (ks + 1) > p.K) {                            // ragged reduction (K = 241): columns at and beyond K are scratch, not zeros
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = 32 * ks + 16 * lh + 4 * q;
+          cur[q].x = k < p.K ? cur[q].x : 0.f;
+          cur[q].y = k + 1 < p.K ? cur[q].y : 0.f;
+          cur[q].z = k + 2 < p.K ? cur[q].z : 0.f;
+          cur[q].w = k + 3 < p.K ? cur[q].w : 0.f;
+        }
+      }
+      const uint4* sb = sB + buf * kBxStage + b_lane;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint4 bq[3][4];
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) bq[piece][ni] = sb[((s * 3 + piece) * 2) * 256 + ni * 32];
+        uint4 aq[3];
+        {
+          const float4 u = cur[2 * s], v = cur[2 * s + 1];
+          split3(u.x, u.y, aq[0].x, aq[1].x, aq[2].x);
+          split3(u.z, u.w, aq[0].y, aq[1].y, aq[2].y);
+          split3(v.x, v.y, aq[0].z, aq[1].z, aq[2].z);
+          split3(v.z, v.w, aq[0].w, aq[1].w, aq[2].w);
+        }
+        // products from the smallest terms up: (a3 b3, a2 b3, a3 b2 with NPROD = 9), a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          constexpr int ia[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, ib[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
+          if (NPROD == 6 && t < 3) continue;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[ia[t]]), __builtin_bit_cast(bf16x8, bq[ib[t]][ni]),
+                                                              acc[ni], 0, 0, 0);
+        }
+      }
+      // the other buffer was last read in the previous super-step, and every wave has passed that step's barrier
+      uint4* sdst = sB + (buf ^ 1) * kBxStage + tid;
+#pragma unroll
+      for (int q = 0; q < kCopy; ++q) sdst[kBxThreads * q] = bnext[q];
+      __syncthreads();
+      buf ^= 1;
+    }
+    // epilogue through a per-wave LDS transpose (16-byte stores / cos loads), as mlp_gemm_nt_wide
+    float* scr = sScr + wave * (32 * kLd);
+    const int t_row = lane >> 3, t_col = (lane & 7) * 4;
+    const size_t tile_row = (size_t)(row0 + wm * 32 + t_row) * p.ldo;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      float4 cv[2][4];
+      if (EPI == EPI_MULC) {
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps)
+            cv[n2][ps] = *reinterpret_cast<const float4*>(p.cmul + tile_row + (size_t)(8 * ps) * p.ldo + wn * 128 + (nh * 2 + n2) * 32 + t_col);
+      }
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) {
+        const int ni = nh * 2 + n2;
+        const size_t o0 = tile_row + wn * 128 + ni * 32 + t_col;
+        float second[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[ni][r];
+          if (EPI == EPI_SINCOS) {
+            sincos_cw(v + bn[ni], v, second[r]);
+          } else if (EPI == EPI_BIAS) {
+            v += bn[ni];
+          }
+          scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+          if (EPI == EPI_MULC) {
+            v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
+            csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
+          }
+          *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+        }
+        if (EPI == EPI_SINCOS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps)
+            *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+        }
+      }
+    }
+  }
+  if (EPI == EPI_MULC && p.colsum != nullptr) {
+    const int t_row = lane >> 3, t_col = (lane & 7) * 4;
+    __syncthreads();                                          // sRed aliases the weight buffers: every wave is done with them
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      *reinterpret_cast<float4*>(sRed + (wm * 8 + t_row) * 256 + wn * 128 + ni * 32 + t_col) = csum4[ni];
+    __syncthreads();
+    if (tid < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 32; ++sl) t += sRed[sl * 256 + tid];
+      p.colsum[(size_t)blockIdx.x * 256 + tid] = t;
+    }
+  }
+}
+
+constexpr size_t kBxSmem = 2 * kBxStage * sizeof(uint4) + 8 * 32 * kLd * sizeof(float);   // 96 KB of weights + 36 KB of epilogue scratch
+template <int EPI, int NPROD>
+void launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
+  static bool configured = false;                            // more than 64 KB of LDS needs the opt-in attribute, once per kernel
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_nt_bx<EPI, NPROD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBxSmem);
+    configured = true;
+  }
+  hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD>), dim3(grid), dim3(kBxThreads), kBxSmem, stream, p, wsplit);
+}
+template <int EPI>
+int launch_nt_bx(NtArgs p, const uint4* wsplit, int nprod, hipStream_t stream) {   // p.M a multiple of 128
+  const int tiles = p.M / kBM;
+  const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+  if (nprod == 9) launch_nt_bx_one<EPI, 9>(p, wsplit, grid, stream);
+  else launch_nt_bx_one<EPI, 6>(p, wsplit, grid, stream);
+  return (int)grid;
+}
+
 // (row tile, column half) work items; a workgroup must keep one column half across its persistent loop: grid multiple of 16
 inline unsigned nt_grid(long M, int N) {
   const long rt = (M + kBM - 1) / kBM;
@@ -1097,6 +1335,40 @@ int matpbr_mlp_layer_bwd_input_w(const float* g, int ldg, const float* w, int ld
   if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
   NtArgs p{g, w, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, 0, n_prev, n_red, ldg, ldw, ldo};
   const int groups = launch_small_nt<EPI_MULC, true>(p, M, (hipStream_t)stream);
+  if (d_bias_prev)
+    hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+size_t matpbr_mlp_wsplit_bytes(int K) { return K > 0 ? (size_t)((K + 31) / 32) * 2 * 3 * 256 * 2 * sizeof(uint4) : 0; }
+
+int matpbr_mlp_split_weights(const float* w, int ldw, int N, int K, void* wsplit, void* stream) {
+  if (!w || !wsplit || N <= 0 || N > 256 || K <= 0 || K > 256 || ldw < K) return MATPBR_ERR_INVALID_ARG;
+  const int n = ((K + 31) / 32) * 2 * 256 * 2;
+  hipLaunchKernelGGL(mlp_split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, (uint4*)wsplit);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo, long M, int N,
+                            int K, int nprod, void* stream) {
+  if (!x || !wsplit || !bias || !s_out || !c_out || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
+  if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
+      !aligned16(s_out) || !aligned16(c_out))
+    return MATPBR_ERR_UNSUPPORTED;
+  NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, N, K, ldx, 0, ldo};
+  launch_nt_bx<EPI_SINCOS>(p, (const uint4*)wsplit, nprod, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,
+                                  void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, void* stream) {
+  if (!g || !wtsplit || !c_prev || !g_prev || M <= 0 || n_prev <= 0 || n_prev > 256 || n_red <= 0 || n_red > 256) return MATPBR_ERR_INVALID_ARG;
+  if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || !aligned16(g) ||
+      !aligned16(g_prev) || !aligned16(c_prev))
+    return MATPBR_ERR_UNSUPPORTED;
+  if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
+  NtArgs p{g, nullptr, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, (int)M, n_prev, n_red, ldg, 0, ldo};
+  const int groups = launch_nt_bx<EPI_MULC>(p, (const uint4*)wtsplit, nprod, (hipStream_t)stream);
   if (d_bias_prev)
     hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;

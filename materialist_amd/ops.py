@@ -441,6 +441,48 @@ def mlp_layer_bwd_input(g: torch.Tensor, wt: torch.Tensor, c_prev: torch.Tensor,
     _lib.check(code, "matpbr_mlp_layer_bwd_input")
 
 
+def mlp_split_weights(w: torch.Tensor, N: int, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w[:N, :K] (row-major, unit column stride) split into three bf16 pieces in the operand order of the bx kernels (opaque bytes)."""
+    lib = _lib.load()
+    if not (w.is_cuda and w.dtype == torch.float32 and w.ndim == 2 and w.stride(1) == 1):
+        raise ValueError("mlp_split_weights: expected a [rows, cols] fp32 CUDA matrix with unit column stride")
+    need = int(lib.matpbr_mlp_wsplit_bytes(K))
+    if out is None or out.numel() < need:
+        out = torch.empty(need, dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        code = lib.matpbr_mlp_split_weights(_ptr(w), w.stride(0), N, K, _ptr(out), _stream(w))
+    _lib.check(code, "matpbr_mlp_split_weights")
+    return out
+
+
+def mlp_layer_fwd_bx(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: torch.Tensor, N: int, K: int,
+                     nprod: int = 6) -> None:
+    """mlp_layer_fwd on the bf16 matrix pipe with split operands (nprod 6 or 9 partial products per f32 product)."""
+    lib = _lib.load()
+    x, s_out, c_out = _mat2(x, "x"), _mat2(s_out, "s_out"), _mat2(c_out, "c_out")
+    if c_out.stride(0) != s_out.stride(0):
+        raise ValueError("c_out must share s_out's row stride")
+    with torch.cuda.device(x.device):
+        code = lib.matpbr_mlp_layer_fwd_bx(_ptr(x), x.stride(0), _ptr(wsplit), _ptr(bias.contiguous()), _ptr(s_out), _ptr(c_out), s_out.stride(0),
+                                           x.shape[0], N, K, int(nprod), _stream(x))
+    _lib.check(code, "matpbr_mlp_layer_fwd_bx")
+
+
+def mlp_layer_bwd_input_bx(g: torch.Tensor, wtsplit: torch.Tensor, c_prev: torch.Tensor, g_prev: torch.Tensor, n_prev: int, n_red: int,
+                           d_bias_prev: Optional[torch.Tensor], nprod: int = 6) -> None:
+    lib = _lib.load()
+    g = _mat2(g, "g")
+    M = g.shape[0]
+    if c_prev.stride(0) != g_prev.stride(0):
+        raise ValueError("c_prev and g_prev must share their row stride")
+    ws = _mlp_workspace("bwd_input", M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
+    with torch.cuda.device(g.device):
+        code = lib.matpbr_mlp_layer_bwd_input_bx(_ptr(g), g.stride(0), _ptr(wtsplit), _ptr(c_prev), _ptr(g_prev), g_prev.stride(0),
+                                                 _ptr(d_bias_prev) if d_bias_prev is not None else None, _ptr(ws), ws.numel() * 4, M, n_prev, n_red,
+                                                 int(nprod), _stream(g))
+    _lib.check(code, "matpbr_mlp_layer_bwd_input_bx")
+
+
 def mlp_layer_bwd_weight(g: torch.Tensor, x: torch.Tensor, N: int, K: int) -> torch.Tensor:
     """d_w [N, K] = g[:, :N]^T x[:, :K] over all rows (deterministic slab partials)."""
     lib = _lib.load()

@@ -130,6 +130,9 @@ class _PosMlpHipFn(torch.autograd.Function):
     Same buffer trick as `_PosMlpFn` for the skip layers: the producer writes the first columns of a 256-wide buffer whose tail
     holds x0.  The input x0 gets no gradient here (it is the constant `start_arm` of the optimisation loop)."""
 
+    # Partial products per f32 product of the 256-wide sine layers (large point sets): 0 = the exact-f32 MFMA kernels; 6 / 9 = the
+    # split-operand kernels on the bf16 matrix pipe (three bf16 pieces per operand, f32 accumulation; posmlp_kernels.hip "bx").
+    PRODUCTS = 6
     MIN_ROWS = 8192         # persistent 128-row tiles from here up ...
     SMALL_ROWS = 1024       # ... one 32x32 tile per wave straight from L2 up to here (the 16x32 envmap MLP); BLAS in between
 
@@ -166,7 +169,10 @@ class _PosMlpHipFn(torch.autograd.Function):
             buf = torch.empty((M, width), dtype=torch.float32, device=x0.device)
             cbuf = torch.empty((M, width), dtype=torch.float32, device=x0.device)
             inps.append(inp)
-            ops.mlp_layer_fwd(inp, _pad_cols(W, _ceil4(K)), b, buf, cbuf, K)
+            if _PosMlpHipFn.PRODUCTS and M % 128 == 0 and M >= _PosMlpHipFn.MIN_ROWS and width == 256 and inp.stride(0) >= (K + 31) // 32 * 32:
+                ops.mlp_layer_fwd_bx(inp, ops.mlp_split_weights(W, n, K), b, buf, cbuf, n, K, _PosMlpHipFn.PRODUCTS)
+            else:
+                ops.mlp_layer_fwd(inp, _pad_cols(W, _ceil4(K)), b, buf, cbuf, K)
             if width != n:
                 buf[:, n:] = x0
             coss.append(cbuf)
@@ -205,7 +211,12 @@ class _PosMlpHipFn(torch.autograd.Function):
             wt = _pad_cols(weights[l][:, :n_prev].t(), 256 if n_red > 224 else _ceil4(n_red))   # 256-wide rows: the fast kernels' precondition
             g_prev = torch.empty_like(coss[l - 1])
             d_b = torch.empty(n_prev, dtype=torch.float32, device=g.device)
-            ops.mlp_layer_bwd_input(g, wt, coss[l - 1], g_prev, n_prev, n_red, d_b)
+            M = g.shape[0]
+            if (_PosMlpHipFn.PRODUCTS and M % 128 == 0 and M >= _PosMlpHipFn.MIN_ROWS and g_prev.stride(0) == 256
+                    and g.stride(0) >= (n_red + 31) // 32 * 32 and wt.stride(0) >= n_red):
+                ops.mlp_layer_bwd_input_bx(g, ops.mlp_split_weights(wt, n_prev, n_red), coss[l - 1], g_prev, n_prev, n_red, d_b, _PosMlpHipFn.PRODUCTS)
+            else:
+                ops.mlp_layer_bwd_input(g, wt, coss[l - 1], g_prev, n_prev, n_red, d_b)
             grads[2 * (l - 1) + 1] = d_b
             g, n_red = g_prev, n_prev
             if l - 1 >= 1:

@@ -856,6 +856,89 @@ def test_posmlp_mfma_kernels_match_the_torch_composition(M, hidden, skip, d0, n_
         assert (a - b).abs().max().item() <= 3e-4 * scale, (i, (a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("N,K", [(256, 256), (241, 256), (256, 241)])
+@pytest.mark.parametrize("nprod", [6, 9])
+def test_split_operand_sine_layers_match_fp64_and_the_f32_kernels(N, K, nprod):
+    """f2: the split-operand kernels (each f32 operand = three bf16 pieces, 6 or 9 bf16 MFMA products, f32 accumulate) are an
+    f32-accurate product: against an fp64 product of the same rows their error equals that of the exact-f32 MFMA kernels (the
+    dominating term is the f32 accumulation over K <= 256), for the three operand shapes of the 8-layer network (full, skip-layer
+    outputs N = 241, skip-layer reduction K = 241 whose padding columns hold scratch), forward (sin/cos) and input gradient (cos
+    factor and bias-gradient column sums)."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    torch.manual_seed(3)
+    M = 128 * 300                                         # more tiles than CUs: every workgroup streams more than one tile
+    x = torch.randn(M, 256, device=dev)
+    x[:, 0] *= 50.0                                       # pre-activations of tens of radians, as with pixel coordinates
+    wp = torch.full((N, 256), 7.0, device=dev)            # columns >= K are scratch and must not be read as weights
+    wp[:, :K] = (torch.rand(N, K, device=dev) * 2 - 1) / 16
+    b = torch.randn(N, device=dev) * 0.1
+    rows = slice(M - 4096, M)
+    pre = x[rows, :K].double() @ wp[:, :K].double().t() + b.double()
+    ws = ops.mlp_split_weights(wp, N, K)
+    s0, c0 = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+    s1, c1 = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+    ops.mlp_layer_fwd(x, wp, b, s0, c0, K)
+    ops.mlp_layer_fwd_bx(x, ws, b, s1, c1, N, K, nprod)
+    torch.cuda.synchronize()
+    e_f32 = (s0[rows, :N].double() - torch.sin(pre)).abs().max().item()
+    e_bx = (s1[rows, :N].double() - torch.sin(pre)).abs().max().item()
+    assert e_bx <= max(2.0 * e_f32, 3e-5), (e_bx, e_f32)
+    assert (c1[rows, :N].double() - torch.cos(pre)).abs().max().item() <= 3e-5
+    assert (s1[:, :N] - s0[:, :N]).abs().max().item() <= 6e-5
+
+    g = torch.randn(M, 256, device=dev)
+    cprev = torch.rand(M, 256, device=dev)
+    ref = (g[rows, :K].double() @ wp[:, :K].double().t()) * cprev[rows, :N].double()
+    gp0, gp1 = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+    db0, db1 = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    ops.mlp_layer_bwd_input(g, wp, cprev, gp0, N, K, db0)
+    ops.mlp_layer_bwd_input_bx(g, ws, cprev, gp1, N, K, db1, nprod)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (gp1[rows, :N].double() - ref).abs().max().item() <= 2e-6 * scale
+    assert (gp1[:, :N] - gp0[:, :N]).abs().max().item() <= 4e-6 * scale
+    col = gp1[:, :N].double().sum(0)
+    assert (db1.double() - col).abs().max().item() <= 1e-5 * (col.abs().max().item() + 1.0)
+
+
+@pytest.mark.parametrize("products", [0, 6, 9])
+def test_posmlp_autograd_function_at_image_size_for_every_product_mode(products):
+    """f2: the whole 8-layer network through `_PosMlpHipFn` at 128 x 128 pixels (above MIN_ROWS, so the split-operand kernels are
+    the ones dispatched when PRODUCTS != 0) against the torch/BLAS composition: outputs and every parameter gradient."""
+    from materialist_amd import posmlp
+
+    dev = _cuda()
+    torch.manual_seed(5)
+    M, d0, n_out, skip = 128 * 128, 15, 5, (4,)
+    dims = [d0] + [256] * 8 + [n_out]
+    wb = []
+    for l in range(len(dims) - 1):
+        n = dims[l + 1] - d0 if (l + 1) in skip else dims[l + 1]
+        k = dims[l]
+        wb += [(torch.rand(n, k, device=dev) * 2 - 1) / k ** 0.5, (torch.rand(n, device=dev) * 2 - 1) / k ** 0.5]
+    x0 = torch.randn(M, d0, device=dev)
+    go = torch.randn(M, n_out, device=dev)
+    assert posmlp._PosMlpHipFn.supported(x0, skip, wb[0::2])
+    saved = posmlp._PosMlpHipFn.PRODUCTS
+    posmlp._PosMlpHipFn.PRODUCTS = products
+    try:
+        res = []
+        for fn in ("hip", "torch"):
+            ps = [t.clone().requires_grad_(True) for t in wb]
+            out = posmlp._PosMlpHipFn.apply(x0, skip, *ps) if fn == "hip" else posmlp._PosMlpFn.apply(x0, skip, len(dims) - 2, *ps)
+            out.backward(go)
+            res.append((out.detach(), [p.grad for p in ps]))
+    finally:
+        posmlp._PosMlpHipFn.PRODUCTS = saved
+    (o_h, g_h), (o_t, g_t) = res
+    assert (o_h - o_t).abs().max().item() <= 3e-5 * max(1.0, o_t.abs().max().item())
+    for i, (a, b) in enumerate(zip(g_h, g_t)):
+        scale = b.abs().max().item() + 1e-6
+        assert (a - b).abs().max().item() <= 5e-4 * scale, (i, (a - b).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("tag,kw", [("arm", dict(color_ch=5, out_dims=5, multires_view=2, output_type="arm")),
                                     ("armn", dict(color_ch=8, out_dims=8, multires_view=0, output_type="armn")),
                                     ("env", dict(color_ch=3, out_dims=3, multires_view=2, output_type="envmap"))])

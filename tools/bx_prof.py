@@ -1,0 +1,13 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from materialist_amd import ops
+dev = torch.device("cuda:0")
+M, N, K = 512 * 512, 256, 256
+x = torch.randn(M, 256, device=dev); w = torch.randn(N, 256, device=dev) / 16; b = torch.randn(N, device=dev)
+s, c = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+ws = ops.mlp_split_weights(w, N, K)
+for _ in range(5):
+    ops.mlp_layer_fwd(x, w, b, s, c, K)
+    ops.mlp_layer_fwd_bx(x, ws, b, s, c, N, K, 6)
+    ops.mlp_layer_fwd_bx(x, ws, b, s, c, N, K, 9)
+torch.cuda.synchronize()
