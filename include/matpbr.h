@@ -235,6 +235,10 @@ int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const f
 int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo,
                                   float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
                                   int nprod, void* stream);
+/* as matpbr_mlp_layer_bwd_weight with split operands (nprod 6 or 9): M a multiple of 16, ldg and ldx >= 256 (all 256 columns of
+ * both operands are read; those at or beyond N / K may hold anything finite or not and are dropped). */
+int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
+                                   size_t workspace_bytes, long M, int N, int K, int nprod, void* stream);
 
 /* Forward-only relighting (render_final.py:148-203 `render_w_mi`, :290-418 `rotate_envmap` / `render_rolling_envmap`).
  * The render is linear in the light, R = sum_k light[k] * T[k]:

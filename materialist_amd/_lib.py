@@ -77,6 +77,8 @@ SIGNATURES = {
     "matpbr_mlp_bwd_weight_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long]),
     "matpbr_mlp_layer_bwd_weight": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_bwd_weight_bx": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                     ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_sincos": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_mul": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_column_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),

@@ -1022,10 +1022,11 @@ int launch_small_nt(NtArgs p, long M, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // round-to-nearest-even, lo -> bits 15:0
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: round-to-nearest-even, lo -> bits 15:0
+  const f32x2v v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 // (x0, x1) -> three packed bf16 pairs with x = p1 + p2 + p3 exactly (up to the last piece's rounding, 2^-25 |x|)
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
@@ -1224,6 +1225,151 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
   }
 }
 
+// dW partials = G^T X over a slab of rows with split operands.  One workgroup owns the whole 256 x 256 output of its slab: eight
+// waves, wave (nq, kq) accumulates 64 x 128 of it (8 accumulator tiles), two waves per SIMD so that one wave's staging work (VALU
+// split, LDS traffic) runs in the shadow of the other's MFMAs.  Both operands are activations laid out [row m][column] with m the
+// reduction index, so the MFMA fragments (8 consecutive m of one column per lane) are built by the staging pass: a thread takes 2
+// adjacent columns x 8 rows (8 8-byte loads; a wave's load is a 512-byte run of a row), cuts the 16 values into three bf16 pieces
+// once -- every staged element is then read by 2 (G) or 4 (X) waves -- and writes one 16-byte LDS word per (piece, column).
+// Columns are stored permuted within their group of 16 (slot = 8 (c & 1) + (c >> 1 & 7)): the stores of 8 adjacent threads and the
+// fragment reads of 8 adjacent lanes both cover 8 distinct 16-byte bank groups; lane l of a fragment therefore holds column
+// wg_perm(l) of its tile, undone when the partials are stored.
+// Stage = 16 rows x 512 columns x 3 pieces = 48 KB, double-buffered; the rows of the next kWgDepth stages are in registers or in
+// flight (the loop runs at the latency of its loads unless enough bytes are in flight).
+// Columns at or beyond N (K) are computed and dropped by mlp_wgrad_reduce: dW[n][k] depends on column n of G and k of X only.
+constexpr int kWgStage = 2 * 3 * 2 * 256;                  // uint4 per buffer: [G|X][piece][row half][column slot]
+constexpr size_t kWgSmem = 2 * kWgStage * sizeof(uint4);
+constexpr int kWgDepth = 2;
+constexpr int kWgThreads = 512;
+__device__ __forceinline__ int wg_perm(int i) { return (i & 16) + 2 * (i & 7) + ((i >> 3) & 1); }   // fragment lane -> column within a tile of 32
+// EARLY: stage before the products of a step instead of after them.  The two waves of a SIMD (w and w + 4) meet at the barrier of
+// every step; with opposite orders one of them splits and stores while the other one multiplies.
+template <int NPROD, bool EARLY>
+__device__ __forceinline__ void wgrad_bx_body(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                              float* __restrict__ partial, long M, long rows_per_slab, uint4* sW) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nq = wave >> 1, kq = wave & 1, li = lane & 31, lh = lane >> 5;
+  const long m_begin = (long)blockIdx.x * rows_per_slab;
+  const long m_end = (m_begin + rows_per_slab < M) ? m_begin + rows_per_slab : M;
+  const int steps = m_begin < m_end ? (int)((m_end - m_begin) / 16) : 0;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][ki][r] = 0.f;
+
+  // staging: this thread's 2 columns (pair cp of the 256 pairs of G | X) and row half sh
+  const int cp = tid & 255, sh = tid >> 8;
+  const float* src = (cp >> 7) ? X + (m_begin + 8 * sh) * ldx + 2 * (cp & 127) : G + (m_begin + 8 * sh) * ldg + 2 * (cp & 127);
+  const long ld = (cp >> 7) ? ldx : ldg;
+  uint4* sdst = sW + (((cp >> 7) * 3) * 2 + sh) * 256 + ((cp & 127) >> 3) * 16 + (cp & 7);   // + buf * kWgStage + (piece * 2) * 256 + 8 * column
+  float2 raw[kWgDepth][8];
+  auto load_stage = [&](int slot, int step) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[slot][j] = *reinterpret_cast<const float2*>(src + (16L * step + j) * ld);
+  };
+  auto split_store = [&](int slot, int buf) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 pc[3];
+      const float2* r = raw[slot];
+#define MATPBR_COMP(v) (c == 0 ? (v).x : (v).y)
+      split3(MATPBR_COMP(r[0]), MATPBR_COMP(r[1]), pc[0].x, pc[1].x, pc[2].x);
+      split3(MATPBR_COMP(r[2]), MATPBR_COMP(r[3]), pc[0].y, pc[1].y, pc[2].y);
+      split3(MATPBR_COMP(r[4]), MATPBR_COMP(r[5]), pc[0].z, pc[1].z, pc[2].z);
+      split3(MATPBR_COMP(r[6]), MATPBR_COMP(r[7]), pc[0].w, pc[1].w, pc[2].w);
+#undef MATPBR_COMP
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) sdst[buf * kWgStage + (piece * 2) * 256 + 8 * c] = pc[piece];
+    }
+  };
+  // unconditional (the last steps re-stage the last rows, which nobody reads): loads under a branch could not be counted.
+  // The scheduling fences keep the loads in stage order: the count of loads in flight that the compiler derives for the waits in
+  // the loop is the minimum over the loop entry and the back edge.
+  auto stage = [&](int slot, int buf, int next_stage) {
+    __builtin_amdgcn_sched_barrier(0);
+    split_store(slot, buf);
+    __builtin_amdgcn_sched_barrier(0);
+    load_stage(slot, next_stage < steps ? next_stage : steps - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (steps > 0) {
+    load_stage(0, 0);
+    split_store(0, 0);
+#pragma unroll
+    for (int d = 0; d < kWgDepth; ++d) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_stage((1 + d) % kWgDepth, 1 + d < steps ? 1 + d : steps - 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // step st multiplies from buffer st & 1 and stages step st + 1 (registers (st + 1) % depth) into the other one
+    for (int st0 = 0; st0 < steps; st0 += kWgDepth) {
+#pragma unroll
+      for (int u = 0; u < kWgDepth; ++u) {
+        const int st = st0 + u;
+        if (st >= steps) break;
+        const int cur = st & 1;
+        if (EARLY) stage((u + 1) % kWgDepth, cur ^ 1, st + 1 + kWgDepth);
+        const uint4* sa = sW + cur * kWgStage + lh * 256 + nq * 64 + li;             // + (piece * 2) * 256 + ni * 32
+        const uint4* sb = sW + cur * kWgStage + (3 * 2 + lh) * 256 + kq * 128 + li;  // + (piece * 2) * 256 + ki * 32
+        uint4 a[3][2];
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) a[piece][ni] = sa[(piece * 2) * 256 + ni * 32];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          uint4 b[3][2];
+#pragma unroll
+          for (int piece = 0; piece < 3; ++piece)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) b[piece][k2] = sb[(piece * 2) * 256 + (kh * 2 + k2) * 32];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            constexpr int ia[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, ib[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
+            if (NPROD == 6 && t < 3) continue;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[ni][kh * 2 + k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ia[t]][ni]),
+                                                                              __builtin_bit_cast(bf16x8, b[ib[t]][k2]), acc[ni][kh * 2 + k2], 0, 0, 0);
+          }
+        }
+        if (!EARLY) stage((u + 1) % kWgDepth, cur ^ 1, st + 1 + kWgDepth);
+        __syncthreads();
+      }
+    }
+  }
+  float* out = partial + (long)blockIdx.x * 256 * 256;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nq * 64 + ni * 32 + wg_perm((r & 3) + 8 * (r >> 2) + 4 * lh);
+        const int k = kq * 128 + ki * 32 + wg_perm(li);
+        out[n * 256 + k] = acc[ni][ki][r];
+      }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_bx(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                              float* __restrict__ partial, long M, long rows_per_slab) {
+  extern __shared__ __align__(16) unsigned char wg_smem[];
+  uint4* sW = reinterpret_cast<uint4*>(wg_smem);
+  if (threadIdx.x >> 8)
+    wgrad_bx_body<NPROD, true>(G, ldg, X, ldx, partial, M, rows_per_slab, sW);
+  else
+    wgrad_bx_body<NPROD, false>(G, ldg, X, ldx, partial, M, rows_per_slab, sW);
+}
+
 constexpr size_t kBxSmem = 2 * kBxStage * sizeof(uint4) + 8 * 32 * kLd * sizeof(float);   // 96 KB of weights + 36 KB of epilogue scratch
 template <int EPI, int NPROD>
 void launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
@@ -1375,7 +1521,7 @@ int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, 
 }
 
 static int wgrad_slabs(long M) {
-  long s = (M + 1023) / 1024;   // >= 1024 rows per slab
+  long s = (M + 255) / 256;     // >= 256 rows per slab
   if (s > 256) s = 256;
   if (s < 1) s = 1;
   return (int)s;
@@ -1397,6 +1543,29 @@ int matpbr_mlp_layer_bwd_weight(const float* g, int ldg, const float* x, int ldx
   long rows = (M + slabs - 1) / slabs;
   rows = (rows + kWM - 1) / kWM * kWM;
   hipLaunchKernelGGL(mlp_wgrad_tn, dim3(slabs, (N + 127) / 128), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, K);
+  hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
+                                   size_t workspace_bytes, long M, int N, int K, int nprod, void* stream) {
+  if (!g || !x || !d_w || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
+  if ((nprod != 6 && nprod != 9) || (M & 15) || ldg < 256 || ldx < 256 || (ldg & 3) || (ldx & 3) || ldw < K || !aligned16(g) || !aligned16(x))
+    return MATPBR_ERR_UNSUPPORTED;   // all 256 columns of both are read
+  if (!workspace || workspace_bytes < matpbr_mlp_bwd_weight_workspace_bytes(M)) return MATPBR_ERR_WORKSPACE;
+  int slabs = wgrad_slabs(M);
+  long rows = ((M + slabs - 1) / slabs + 15) / 16 * 16;
+  slabs = (int)((M + rows - 1) / rows);
+  static bool configured[2] = {false, false};
+  if (nprod == 6) {
+    if (!configured[0]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_wgrad_bx<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgSmem);
+    configured[0] = true;
+    hipLaunchKernelGGL(mlp_wgrad_bx<6>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows);
+  } else {
+    if (!configured[1]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_wgrad_bx<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgSmem);
+    configured[1] = true;
+    hipLaunchKernelGGL(mlp_wgrad_bx<9>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows);
+  }
   hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }

@@ -497,6 +497,21 @@ def mlp_layer_bwd_weight(g: torch.Tensor, x: torch.Tensor, N: int, K: int) -> to
     return d_w
 
 
+def mlp_layer_bwd_weight_bx(g: torch.Tensor, x: torch.Tensor, N: int, K: int, nprod: int = 6) -> torch.Tensor:
+    """As mlp_layer_bwd_weight with split operands (three bf16 pieces per f32, `nprod` bf16 MFMA products, f32 accumulate): both
+    operands 256 columns wide in memory, rows a multiple of 16."""
+    lib = _lib.load()
+    g, x = _mat2(g, "g"), _mat2(x, "x")
+    M = g.shape[0]
+    ws = _mlp_workspace("bwd_weight", M, g.device, lib.matpbr_mlp_bwd_weight_workspace_bytes(M))
+    d_w = torch.empty((N, K), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        code = lib.matpbr_mlp_layer_bwd_weight_bx(_ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(d_w), K, _ptr(ws), ws.numel() * 4, M, N, K,
+                                                  nprod, _stream(g))
+    _lib.check(code, "matpbr_mlp_layer_bwd_weight_bx")
+    return d_w
+
+
 def brdf_terms(cos1, cos2, r, f0) -> torch.Tensor:
     """[N,4] = D_GGX(cos1, r), G1_GGX_Schlick(cos1, r), G_Smith(cos1, cos2, r), fresnelSchlick(cos1, f0) over N lanes."""
     lib = _lib.load()

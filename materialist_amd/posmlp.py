@@ -220,7 +220,11 @@ class _PosMlpHipFn(torch.autograd.Function):
             grads[2 * (l - 1) + 1] = d_b
             g, n_red = g_prev, n_prev
             if l - 1 >= 1:
-                grads[2 * (l - 1)] = ops.mlp_layer_bwd_weight(g, inps[l - 1], n_prev, weights[l - 1].shape[1])
+                x_in, k_in = inps[l - 1], weights[l - 1].shape[1]
+                if _PosMlpHipFn.PRODUCTS and M % 16 == 0 and M >= _PosMlpHipFn.MIN_ROWS and g.stride(0) >= 256 and x_in.stride(0) >= 256:
+                    grads[2 * (l - 1)] = ops.mlp_layer_bwd_weight_bx(g, x_in, n_prev, k_in, _PosMlpHipFn.PRODUCTS)
+                else:
+                    grads[2 * (l - 1)] = ops.mlp_layer_bwd_weight(g, x_in, n_prev, k_in)
         if ctx.small:
             grads[0] = ops.mlp_layer_bwd_weight(g, inps[0], n_red, x0.shape[1])
         else:

@@ -902,6 +902,39 @@ def test_split_operand_sine_layers_match_fp64_and_the_f32_kernels(N, K, nprod):
     col = gp1[:, :N].double().sum(0)
     assert (db1.double() - col).abs().max().item() <= 1e-5 * (col.abs().max().item() + 1.0)
 
+    # weight gradient g^T x over all rows; the columns beyond N / K hold non-finite scratch that must not leak
+    xin = torch.randn(M, 256, device=dev)
+    xin[:, K:] = float("nan")
+    gg = g.clone()
+    gg[:, N:] = float("inf")
+    ref_w = torch.zeros(N, K, dtype=torch.float64, device=dev)
+    for c in range(0, M, 12800):
+        ref_w += gg[c:c + 12800, :N].double().t() @ xin[c:c + 12800, :K].double()
+    dw0 = ops.mlp_layer_bwd_weight(gg, xin, N, K)
+    dw1 = ops.mlp_layer_bwd_weight_bx(gg, xin, N, K, nprod)
+    torch.cuda.synchronize()
+    scale_w = ref_w.abs().max().item()
+    e0 = (dw0.double() - ref_w).abs().max().item()
+    e1 = (dw1.double() - ref_w).abs().max().item()
+    assert torch.isfinite(dw1).all()
+    assert e1 <= max(2.0 * e0, 2e-6 * scale_w), (e1, e0, scale_w)
+
+
+@pytest.mark.parametrize("M", [16, 16 * 3, 16 * 1001, 16 * 4099])
+def test_split_operand_weight_gradient_ragged_slabs(M):
+    """The slab partition of the split-operand weight gradient for row counts that leave a short (odd number of 16-row steps)
+    last slab, a single step, and fewer steps than the prefetch depth."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    torch.manual_seed(M)
+    g = torch.randn(M, 256, device=dev)
+    x = torch.randn(M, 256, device=dev)
+    ref = g.double().t() @ x.double()
+    dw = ops.mlp_layer_bwd_weight_bx(g, x, 256, 256, 6)
+    torch.cuda.synchronize()
+    assert (dw.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() * max(1.0, (M / 4096) ** 0.5)
+
 
 @pytest.mark.parametrize("products", [0, 6, 9])
 def test_posmlp_autograd_function_at_image_size_for_every_product_mode(products):

@@ -66,6 +66,25 @@ def main():
             dbe = (db.double() - gp[:, :N].double().sum(0)).abs().max().item() / (gp[:, :N].double().sum(0).abs().max().item() + 1e-30)
             print(f"bwd  N={N} K={K} {name}: {us:7.1f} us  rel err {err:.2e}  bias-grad consistency {dbe:.2e}")
 
+        # weight gradient: g^T x over all rows, against fp64 on a slab-sized prefix and against the f32 kernel on everything
+        xin = torch.randn(M, 256, device=dev)
+        if K < 256:
+            xin[:, K:] = float("nan")                 # scratch columns must not leak
+        gg = g.clone()
+        if N < 256:
+            gg[:, N:] = float("inf")
+        ref_full = None
+        for name, nprod in (("f32", 0), ("bx6", 6), ("bx9", 9)):
+            fn = (lambda: ops.mlp_layer_bwd_weight(gg, xin, N, K)) if nprod == 0 else (lambda: ops.mlp_layer_bwd_weight_bx(gg, xin, N, K, nprod))
+            us = bench(fn)
+            dw = fn()
+            if ref_full is None:
+                ref_full = torch.zeros(N, K, dtype=torch.float64, device=dev)
+                for c in range(0, M, 32768):
+                    ref_full += gg[c:c + 32768, :N].double().t() @ xin[c:c + 32768, :K].double()
+            err = (dw.double() - ref_full).abs().max().item() / ref_full.abs().max().item()
+            print(f"wgrad N={N} K={K} {name}: {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s(f32-equivalent)  rel err {err:.2e}")
+
 
 if __name__ == "__main__":
     main()
