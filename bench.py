@@ -217,10 +217,11 @@ def main(argv=None):
                 net = posmlp.brdf_net("arm").to(dev)
                 init = self.init
                 start_arm = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1)], -1).clamp(0, 1)
-                ph = loop.PosMlpBrdfPhase(self.scene, self.gt_image, net, start_arm, {"albedo": init[0], "roughness": init[1], "metallic": init[2]},
-                                          optimize_part="rm", spp=args.spp)
-                ph.current_maps = lambda: (lambda m: {"albedo": m["albedo"].detach().clamp(0, 1), "roughness": m["roughness"].detach().clamp(0.07, 1),
-                                                      "metallic": m["metallic"].detach().clamp(0, 1)})(ph.maps_from_net()[0])
+                ph = loop.pos_mlp_brdf_phase(self.scene, self.gt_image, net, start_arm, {"albedo": init[0], "roughness": init[1], "metallic": init[2]},
+                                             optimize_part="rm", spp=args.spp)
+                if not hasattr(ph, "current_maps"):
+                    ph.current_maps = lambda: (lambda m: {"albedo": m["albedo"].detach().clamp(0, 1), "roughness": m["roughness"].detach().clamp(0.07, 1),
+                                                          "metallic": m["metallic"].detach().clamp(0, 1)})(ph.maps_from_net()[0])
                 return ph
             if mode == "env":
                 from materialist_amd import posmlp

@@ -240,6 +240,35 @@ int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, 
 int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
                                    size_t workspace_bytes, long M, int N, int K, int nprod, void* stream);
 
+/* The skinny ends of the coordinate MLP at image size, one streaming pass over the 256-wide matrix each (mymodels/mlps.py:219-236,
+ * inverse_img_w_mi.py:493-496):
+ *   matpbr_mlp_split_weights_t   matpbr_mlp_split_weights of the TRANSPOSE of w[K, ldw >= N] (element (n, k) = w[k * ldw + n]): the
+ *                                forward weight as the operand of matpbr_mlp_layer_bwd_input_bx, no transposed copy
+ *   matpbr_mlp_skinny_fwd        out[M, ldo][:, :J] = x[:, :K] w[J, :K]^T + bias, J in {3, 5, 8}, K a multiple of 32 (the zero-
+ *                                initialised output layer)
+ *   matpbr_mlp_arm_head_fwd      the same product for J = 5 followed by the 'arm' head: th[M,8] = tanh(.), u = 1.3 th + start[:, :5],
+ *                                y = (clamp(u, 0, 1) + u) - u as rounded in fp32 (the straight-through clamp); map_a[M,3] = y[:, 0:3], map_r[M] = 0.93 y[:, 3] + 0.07, map_m[M] = y[:, 4]
+ *                                (each map nullable: a map that the running part does not optimise keeps its fixed values)
+ *   matpbr_mlp_arm_head_bwd      d_x[M,8] = d maps chained through the head (straight-through clamp, tanh'), zero where a
+ *                                gradient pointer is null and in the padding columns 5..7
+ *   matpbr_mlp_skinny_bwd_weight d_w[j * ld_j + c * ld_c] = sum_m s[m][j] b[m][c]  (j < J <= 16 columns of the skinny s whose rows
+ *                                are padded to a multiple of 8 floats, c < C <= 256 columns of b[M, ldb >= 256]) and, when
+ *                                d_bias is not null, d_bias[j] = sum_m s[m][j].  With (s, b) = (d_x, last hidden layer) this is
+ *                                the output layer's gradient (ld_j = K, ld_c = 1); with (x0, d pre of the first layer) it is
+ *                                the first layer's, stored transposed (ld_j = 1, ld_c = row stride of d_w).
+ *   matpbr_adamw_step_dev        matpbr_adam_step_dev with torch.optim.AdamW's decoupled weight decay (:470) */
+int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wsplit, void* stream);
+int matpbr_mlp_skinny_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, long M, int J, int K,
+                          void* stream);
+int matpbr_mlp_arm_head_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* start, int lds, float* th,
+                            float* map_a, float* map_r, float* map_m, long M, int K, void* stream);
+int matpbr_mlp_arm_head_bwd(const float* g_a, const float* g_r, const float* g_m, const float* th, float* d_x, long M, void* stream);
+size_t matpbr_mlp_skinny_workspace_bytes(int J);
+int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ldb, float* d_w, long ld_j, long ld_c, float* d_bias,
+                                 void* workspace, size_t workspace_bytes, long M, int J, int C, void* stream);
+int matpbr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
+                          float weight_decay, void* stream);
+
 /* Forward-only relighting (render_final.py:148-203 `render_w_mi`, :290-418 `rotate_envmap` / `render_rolling_envmap`).
  * The render is linear in the light, R = sum_k light[k] * T[k]:
  *   matpbr_shade_transfer  per-pixel transfer (d render / d light, both lobes) of the current materials into T (matpbr_transfer_bytes(); 300 B/pixel, tiled

@@ -1,0 +1,259 @@
+"""Hot loop B in the reference's default `pos_mlp` mode, launch by launch on the C ABI (inverse_img_w_mi.py:159-172,470-590):
+
+    arm    = brdf_net(start_arm)                   PosMLP(output_type='arm'): 15 -> 241 -> 256 -> 241 -> 256 -> 5, residual tanh head
+    maps   = albedo | roughness * 0.93 + 0.07 | metallic                                   (:493-496)
+    image  = render_w_brdf(scene, maps, spp)       light and geometric normals fixed during the part
+    loss   = 3 (L1/MSE) MSE + L1 on x^(1/2.2) + scale_delta * L1 anchors; backward; AdamW + StepLR; SaveBest; EarlyStopping
+
+At 512 x 512 the network is eleven products over 262144 points.  Composed from framework ops (autograd node, three BLAS calls for
+the skinny ends, the head as elementwise kernels, a foreach AdamW) the iteration carried ~0.4 ms of glue around the sine layers;
+here every launch of the iteration is a kernel of libmatpbr.so: the first layer on the f32 MFMA kernel, the 256-wide layers on
+the split-operand bf16 MFMA kernels (forward with sin/cos epilogue, input gradient with cos and bias-gradient epilogue, weight
+gradient), the output layer with the tanh head, the head's backward, the two skinny weight gradients, one AdamW launch over a
+flat parameter buffer whose step count and learning rate live in device memory, and one select for the SaveBest snapshot of the
+weights.  No autograd graph, no allocation, no BLAS.  PyTorch holds the memory; the parameters stay `torch.nn.Parameter`s of the
+PosMLP module (views of the flat buffer), so `state_dict()` / `load_state_dict()` and the reference's checkpoint layout are
+untouched.
+"""
+from __future__ import annotations
+
+import types
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops
+from . import loss as _loss
+from . import render as _render
+from .posmlp import _PosMlpHipFn
+
+_al4 = lambda n: (n + 3) // 4 * 4
+
+
+def flat_state(net: torch.nn.Module, dev) -> dict:
+    """The module's parameters as views of one flat fp32 buffer: weights with rows padded to a multiple of 4 floats, biases padded
+    likewise (every view 16-byte aligned).  Created once per module; later phases find it on the module."""
+    L = net.n_layers
+    lins = [(getattr(net, f"lin{l}").linear if l < L - 1 else getattr(net, f"lin{l}")) for l in range(L)]
+    st = getattr(net, "_flat_state", None)
+    if (st is not None and "spans" in st and st["flat"].device == torch.device(dev)
+            and all(lin.weight.data_ptr() == wp.data_ptr() and lin.bias.data_ptr() == bp.data_ptr() for lin, (wp, bp) in zip(lins, st["views"]))):
+        return st                                             # still the module's storage (nothing re-pointed the parameters since)
+    total = sum(lin.weight.shape[0] * _al4(lin.weight.shape[1]) + _al4(lin.weight.shape[0]) for lin in lins)
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    off, views, spans = 0, [], {}
+    for l, lin in enumerate(lins):
+        n, k = lin.weight.shape
+        wp = flat[off:off + n * _al4(k)].view(n, _al4(k))
+        wp[:, :k].copy_(lin.weight.detach())
+        lin.weight.data = wp[:, :k]                          # a strided view when k is not a multiple of 4 (the first layer)
+        off += n * _al4(k)
+        bp = flat[off:off + n]
+        bp.copy_(lin.bias.detach())
+        lin.bias.data = bp
+        off += _al4(n)
+        views.append((wp, bp))
+    names = {id(p): name for name, p in net.named_parameters()}
+    for lin, (wp, bp) in zip(lins, views):
+        spans[names[id(lin.weight)]] = (wp, lin.weight.shape[1])
+        spans[names[id(lin.bias)]] = (bp, None)
+    st = net._flat_state = {"flat": flat, "views": views, "spans": spans}
+    return st
+
+
+class ArmMlpPhase:
+    """Same interface as `loop.PosMlpBrdfPhase` (step, step_and_check, stats, best, best_img, best_weights, pred, opt.param_groups)."""
+
+    @staticmethod
+    def supported(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> bool:
+        if mask is not None or gt_image.ndim != 3 or not gt_image.is_cuda or not scene.use_mesh_normal or "n" in optimize_part:
+            return False
+        if getattr(net, "output_type", None) != "arm" or not _PosMlpHipFn.PRODUCTS:
+            return False
+        M = gt_image.shape[0] * gt_image.shape[1]
+        if M % 128 or M < _PosMlpHipFn.MIN_ROWS:
+            return False
+        L = net.n_layers
+        d0 = getattr(net, "lin0").linear.weight.shape[1]
+        for l in range(L - 1):
+            n = getattr(net, f"lin{l}").linear.weight.shape[0]
+            if (n + d0 if (l + 1) in net.skip else n) != 256:
+                return False
+        return getattr(net, f"lin{L - 1}").weight.shape == (5, 256) and d0 <= 16
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_arm: torch.Tensor, fixed: Dict[str, torch.Tensor],
+                 optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000, weight_decay: float = 0.01):
+        from .loop import EarlyStopping, _lib_ws
+
+        if not ArmMlpPhase.supported(scene, gt_image, net, optimize_part, None):
+            raise NotImplementedError("ArmMlpPhase: 'arm' network with 256-wide layers on one image of at least 8192 pixels (a multiple of 128)")
+        self.ops, self.scene, self.net, self.part = ops, scene, net, optimize_part
+        self.spp, self.scale_delta = int(spp), float(scale_delta)
+        self.gt = gt_image.contiguous()
+        dev = self.dev = self.gt.device
+        H, W = self.H, self.W = self.gt.shape[0], self.gt.shape[1]
+        M = self.M = H * W
+        self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
+        self.start_arm = start_arm.detach().to(dev, torch.float32).contiguous()
+        self.fixed = {k: v.detach().contiguous() for k, v in fixed.items()}
+        self.orig = {"albedo": self.start_arm[:, 0:3].reshape(H, W, 3).contiguous(),             # regulariser anchors (:189-201)
+                     "roughness": self.start_arm[:, 3:4].reshape(H, W, 1).contiguous(),
+                     "metallic": self.start_arm[:, 4:5].reshape(H, W, 1).contiguous()}
+        self.products = int(_PosMlpHipFn.PRODUCTS)
+        # ---- network state --------------------------------------------------------------------------------------------------------
+        st = flat_state(net, dev)
+        self.flat, self.views, self._spans = st["flat"], st["views"], st["spans"]
+        self.L = net.n_layers
+        self.gflat = torch.zeros_like(self.flat)
+        self.adam_m, self.adam_v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)       # a fresh AdamW per part (:470)
+        self.hyper = torch.tensor([float(lr), 0.0], dtype=torch.float32, device=dev)
+        self.weight_decay = float(weight_decay)
+        self._lr, self._sched_epoch = float(lr), 0
+        self.opt = types.SimpleNamespace(param_groups=[{"lr": float(lr)}])                        # what the callers read back
+        self.gviews, off = [], 0
+        for wp, bp in self.views:
+            gw = self.gflat[off:off + wp.numel()].view_as(wp)
+            off += wp.numel()
+            gb = self.gflat[off:off + _al4(bp.numel())]
+            off += _al4(bp.numel())
+            self.gviews.append((gw, gb))
+        self._best_flat = self.flat.clone()
+        # ---- activations ----------------------------------------------------------------------------------------------------------
+        E = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        x0 = net._points(self.start_arm)
+        self.d0 = d0 = x0.shape[1]
+        self.x0p = E(M, 16)
+        self.x0p[:, :d0] = x0
+        self.ns = [self.views[l][0].shape[0] for l in range(self.L - 1)]
+        self.bufs = [E(M, 256) for _ in range(self.L - 1)]
+        for l, n in enumerate(self.ns):
+            if n != 256:
+                self.bufs[l][:, n:] = x0                        # cat(x, x0) of the skip layers: x0 is constant, written once
+        self.cbufs = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(self.L - 1)]
+        self.gbufs = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.th, self.d_x = E(M, 8), E(M, 8)
+        self.w_out_t = E(256, 8)                                 # the output weight transposed (operand of the input-gradient kernel)
+        nbytes = int(_lib.load().matpbr_mlp_wsplit_bytes(256))
+        self.wsplit = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.maps = {"albedo": E(H, W, 3), "roughness": E(H, W, 1), "metallic": E(H, W, 1)}
+        keys = {"a": "albedo", "r": "roughness", "m": "metallic"}
+        self.live = [keys[c] for c in self.part if c in keys]
+        # ---- render / loss state ----------------------------------------------------------------------------------------------------
+        self.stats = ops.new_loss_stats(1, dev)
+        if best_mse is not None:
+            self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
+        self.es = EarlyStopping(patience, min_delta) if patience > 0 else None
+        self.pred = torch.empty_like(self.gt)
+        self.g = {"albedo": E(H, W, 3), "roughness": E(H, W, 1), "metallic": E(H, W, 1)}
+        self.best = {k: v.clone() for k, v in self.fixed.items()}
+        self.best_img = torch.zeros_like(self.gt)
+        self.hist = E(history_len, 1)
+        self.ws = torch.empty(int(_lib_ws(1)) // 4, dtype=torch.float32, device=dev)
+        self._n = scene.shading_normal().contiguous()
+        self._light = scene.light.detach().contiguous()
+        self.dcache = ops.diffuse_cache(self._n, self._light, self.spp, scene.fov)
+        self.jac = ops.plane9(self.gt)
+        self.t = 0
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def set_lr(self, lr: float) -> None:
+        self._lr = float(lr)
+        self.hyper[0:1].fill_(self._lr)
+        self.opt.param_groups[0]["lr"] = self._lr
+
+    def forward(self) -> Dict[str, torch.Tensor]:
+        """brdf_net(start_arm) and the maps of :493-504 (maps that the part does not optimise keep their fixed values)."""
+        o, P = ops, self.products
+        wp, bp = self.views[0]
+        o.mlp_layer_fwd(self.x0p, wp, bp, self.bufs[0], self.cbufs[0], self.d0)
+        for l in range(1, self.L - 1):
+            wp, bp = self.views[l]
+            o.mlp_split_weights(wp, self.ns[l], 256, out=self.wsplit)
+            o.mlp_layer_fwd_bx(self.bufs[l - 1], self.wsplit, bp, self.bufs[l], self.cbufs[l], self.ns[l], 256, P)
+        wp, bp = self.views[-1]
+        live = self.live
+        o.mlp_arm_head_fwd(self.bufs[-1], wp, bp, self.start_arm, self.th, self.maps["albedo"] if "albedo" in live else None,
+                           self.maps["roughness"] if "roughness" in live else None, self.maps["metallic"] if "metallic" in live else None, 256)
+        return {k: (self.maps[k] if k in live else self.fixed[k]) for k in self.maps}
+
+    def backward(self) -> None:
+        """d loss / d maps (self.g) -> the gradient of every parameter, into the flat gradient buffer."""
+        o, P, live = ops, self.products, self.live
+        o.mlp_arm_head_bwd(self.g["albedo"] if "albedo" in live else None, self.g["roughness"] if "roughness" in live else None,
+                           self.g["metallic"] if "metallic" in live else None, self.th, self.d_x)
+        wp, _ = self.views[-1]
+        gw, gb = self.gviews[-1]
+        o.mlp_skinny_bwd_weight(self.d_x, self.bufs[-1], gw, 5, 256, d_bias=gb)
+        self.w_out_t[:, :5].copy_(wp.t())
+        g_prev = self.gbufs[0]
+        _, gb = self.gviews[self.L - 2]
+        o.mlp_layer_bwd_input(self.d_x, self.w_out_t, self.cbufs[-1], g_prev, self.ns[-1], 5, gb)
+        g, n_red = g_prev, self.ns[-1]
+        for l in range(self.L - 2, 0, -1):                       # g = dL/d pre of layer l: its weight gradient, then dL/d pre of layer l-1
+            wp, _ = self.views[l]
+            gw, _ = self.gviews[l]
+            o.mlp_layer_bwd_weight_bx(g, self.bufs[l - 1], n_red, 256, P, out=gw)
+            n_prev = self.ns[l - 1]
+            g_prev = self.gbufs[0] if g is self.gbufs[1] else self.gbufs[1]
+            _, gb = self.gviews[l - 1]
+            o.mlp_split_weights(wp, n_prev, n_red, out=self.wsplit, transposed=True)
+            o.mlp_layer_bwd_input_bx(g, self.wsplit, self.cbufs[l - 1], g_prev, n_prev, n_red, gb, P)
+            g, n_red = g_prev, n_prev
+        gw, _ = self.gviews[0]
+        o.mlp_skinny_bwd_weight(self.x0p, g, gw, self.d0, n_red, transposed_out=True)
+
+    def step(self) -> None:
+        o, sc = ops, self.scene
+        d = self.forward()
+        o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], self._n, self._light, self.spp, sc.fov, clamp_params=True, out=self.pred,
+                    dcache=self.dcache, jac=self.jac)
+        o.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
+                          self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part)
+        o.brdf_loss_bwd_jac(d["albedo"], d["roughness"], d["metallic"], self.jac, self.pred, self.gt_srgb, self.stats,
+                            self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta,
+                            self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
+                            self.best["metallic"], self.best_img, optimize_part=self.part)
+        self.backward()
+        lib = _lib.load()
+        with torch.cuda.device(self.dev):                        # SaveBest keeps the weights that produced the best render (:546-547)
+            _lib.check(lib.matpbr_select_improved(ops._ptr(self._best_flat), ops._ptr(self.flat), ops._ptr(self.stats), 0, self.flat.numel(),
+                                                  ops._stream(self.flat)), "matpbr_select_improved")
+        if self.t < self.hist.shape[0]:
+            self.hist[self.t].copy_(self.stats[:, o.STAT_MSE])
+        o.adamw_step_dev(self.flat, self.gflat, self.adam_m, self.adam_v, self.hyper, self.weight_decay)
+        if self._lr > 1.5e-4:                                     # StepLR(100, 0.8) stepped only while lr > 1.5e-4 (:471,553-554)
+            self._sched_epoch += 1
+            if self._sched_epoch % 100 == 0:
+                self.set_lr(self._lr * 0.8)
+        self.t += 1
+
+    @property
+    def best_weights(self) -> Dict[str, torch.Tensor]:
+        out, off = {}, 0
+        order = []
+        for wp, bp in self.views:
+            order += [(off, wp), (off + wp.numel(), bp)]
+            off += wp.numel() + _al4(bp.numel())
+        by_ptr = {t.data_ptr(): o_ for o_, t in order}
+        for name, (view, k) in self._spans.items():
+            o_ = by_ptr[view.data_ptr()]
+            best = self._best_flat[o_:o_ + view.numel()].view_as(view)
+            out[name] = (best[:, :k] if k is not None else best).clone()
+        return out
+
+    def current_maps(self) -> Dict[str, torch.Tensor]:
+        """The maps the network produces now, clamped as the render sees them (fresh tensors)."""
+        d = self.forward()
+        return {"albedo": d["albedo"].clamp(0, 1), "roughness": d["roughness"].clamp(0.07, 1), "metallic": d["metallic"].clamp(0, 1)}
+
+    def step_and_check(self) -> bool:
+        """One iteration followed by the host EarlyStopping check of the reference (:550); True when the part should stop."""
+        self.step()
+        if self.es is None:
+            return False
+        self.es(float(self.stats[0, ops.STAT_MSE]))
+        return self.es.early_stop
+
+    def history(self) -> torch.Tensor:
+        return self.hist[: self.t]

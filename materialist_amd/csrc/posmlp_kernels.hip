@@ -68,6 +68,22 @@ __device__ __forceinline__ void sincos_cw(float x, float& s_out, float& c_out) {
   c_out = __uint_as_float(__float_as_uint(cc) ^ (((q + 1u) & 2u) << 30));
 }
 
+// Columns at or beyond N of the 256-wide outputs are left alone: the buffer of a skip layer keeps x0 there (mymodels/mlps.py
+// :214-217 concatenates it every forward; a caller that owns the buffers writes it once).
+__device__ __forceinline__ void store4_upto(float* dst, float4 v, int valid, bool all) {   // all: uniform (N == 256), a scalar branch
+  if (all) {
+    *reinterpret_cast<float4*>(dst) = v;
+    return;
+  }
+  if (valid >= 4) {
+    *reinterpret_cast<float4*>(dst) = v;
+  } else {
+    if (valid > 0) dst[0] = v.x;
+    if (valid > 1) dst[1] = v.y;
+    if (valid > 2) dst[2] = v.z;
+  }
+}
+
 struct NtArgs {
   const float* A;      // [M, lda]   rows = points
   const float* B;      // [N, ldb]   rows = output features, k contiguous
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt(NtArgs p) {
       bn[ni] = (EPI != EPI_MULC) ? p.bias[ncol[ni]] : 0.f;
     }
     if (row0 + kBM <= p.M && p.ldo >= col0 + kBN) {
-      // interior tile whose 128 columns all exist (those past N are scratch): the per-wave LDS transpose of mlp_gemm_nt_wide, 16-byte
+      // interior tile whose 128 columns all exist (those past N are left alone): the per-wave LDS transpose of mlp_gemm_nt_wide, 16-byte
       // stores and 16-byte loads of the cos factors.  Both k-tile buffers are idle here (the next tile starts with a barrier).
       float* scr = sA[0] + wave * (32 * kLd);
       const int t_row = lane >> 3, t_col = (lane & 7) * 4;
@@ -273,14 +289,15 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt(NtArgs p) {
               v.x *= cv4[ni][ps].x; v.y *= cv4[ni][ps].y; v.z *= cv4[ni][ps].z; v.w *= cv4[ni][ps].w;
               cs4[ni].x += v.x; cs4[ni].y += v.y; cs4[ni].z += v.z; cs4[ni].w += v.w;
             }
-            *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+            store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (col0 + wn * 64 + ni * 32 + t_col), p.N >= 256);
           }
           if (EPI == EPI_SINCOS) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
-              *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+              store4_upto(p.out1 + o0 + (size_t)(8 * ps) * p.ldo, *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col),
+                          p.N - (col0 + wn * 64 + ni * 32 + t_col), p.N >= 256);
           }
         }
       }
@@ -671,14 +688,15 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt_wide(NtArgs p) {
               v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
               csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
             }
-            *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+            store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256);
           }
           if (EPI == EPI_SINCOS) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
-              *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+              store4_upto(p.out1 + o0 + (size_t)(8 * ps) * p.ldo, *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col),
+                          p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256);
           }
         }
       }
@@ -1044,6 +1062,8 @@ constexpr int kBxStage = 2 * 3 * 2 * 256;   // uint4 per super-step
 __host__ __device__ inline size_t wsplit_index(int ks, int s, int piece, int n, int g) {
   return ((((size_t)ks * 2 + s) * 3 + piece) * 2 + g) * 256 + n;
 }
+// TRANSPOSED: element (n, k) of the operand is B[k * ldb + n] (the forward weight serving as the backward product's operand)
+template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void mlp_split_weights_kernel(const float* __restrict__ B, int ldb, int N, int K, uint4* __restrict__ out) {
   const int idx = blockIdx.x * 256 + threadIdx.x;          // over (ks, s, n, g)
   const int nks = (K + 31) / 32;
@@ -1053,7 +1073,7 @@ __global__ __launch_bounds__(256) void mlp_split_weights_kernel(const float* __r
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int k = 32 * ks + 16 * g + 8 * s + j;
-    v[j] = (n < N && k < K) ? B[(size_t)n * ldb + k] : 0.f;
+    v[j] = (n < N && k < K) ? (TRANSPOSED ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k]) : 0.f;
   }
   unsigned p[3][4];
 #pragma unroll
@@ -1197,14 +1217,15 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
             v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
             csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
           }
-          *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+          store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256);
         }
         if (EPI == EPI_SINCOS) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps)
-            *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+            store4_upto(p.out1 + o0 + (size_t)(8 * ps) * p.ldo, *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col),
+                        p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256);
         }
       }
     }
@@ -1437,6 +1458,241 @@ int launch_nt(NtArgs p, long M, hipStream_t stream) {
   return groups;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The skinny ends of the network at image size (M = H*W rows): the output layer ([M,256] x [256,J], J <= 8) with the 'arm' head
+// of the residual coordinate MLP, the output layer's weight gradient and the first layer's (15 inputs).  One streaming pass over
+// the 256-wide matrix each (268 MB at 512 x 512): HBM-bound, VALU only.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_add_f(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {   // fixed-order tree; the total is in lane 63
+  v = dpp_add_f<0x111>(v);        // row_shr:1
+  v = dpp_add_f<0x112>(v);        // row_shr:2
+  v = dpp_add_f<0x114>(v);        // row_shr:4
+  v = dpp_add_f<0x118>(v);        // row_shr:8
+  v = dpp_add_f<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+  v = dpp_add_f<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+struct ArmHead {       // mymodels/mlps.py:233-236 ('arm') and inverse_img_w_mi.py:493-496
+  const float* start;  // [M, lds]: start_arm, the network's colour input (columns 0..4)
+  int lds;
+  float* th;           // [M, 8]: tanh(x), kept for the backward
+  float* map_a;        // [M, 3] | null: clamp(1.3 tanh(x) + start, 0, 1)[0:3]
+  float* map_r;        // [M]    | null: clamp(...)[3] * 0.93 + 0.07
+  float* map_m;        // [M]    | null: clamp(...)[4]
+};
+
+// out[m][j] = bias[j] + sum_k X[m][k] W[j][k].  A wave owns 64 rows: it stages 32 columns of them at a time into its own slice of
+// LDS (coalesced 128-byte row segments in, pitch 36 floats), then every lane walks ITS row -- 16-byte conflict-free LDS reads,
+// the weights as scalar operands (uniform across the wave, s_load) -- so the J sums need no cross-lane reduction and the head
+// runs with all 64 lanes busy.  The next chunk's loads are in flight during the FMAs.  Only this wave touches its LDS slice and a
+// wave's LDS operations execute in order: no barriers.
+constexpr int kSkPitch = 36;
+template <int J, bool HEAD>
+__global__ __launch_bounds__(256) void mlp_skinny_nt_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int ldo, long M, int K,
+                                                            const ArmHead h) {
+  __shared__ __align__(16) float stage[4][64 * kSkPitch];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* st = stage[wave];
+  const long tiles = (M + 63) / 64;
+  const int chunks = (K + 31) / 32;
+  const int lr = lane >> 3, lc = (lane & 7) * 4;              // staging: rows lr + 8 i, columns lc..lc+3 of the chunk
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+    const long row0 = tile * 64;
+    float4 pre[8];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        long m = row0 + lr + 8 * i;
+        m = m < M ? m : M - 1;
+        const int k = 32 * c + lc;
+        pre[i] = *reinterpret_cast<const float4*>(X + m * ldx + k);
+      }
+    };
+    float acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = 0.f;
+    load_chunk(0);
+    for (int c = 0; c < chunks; ++c) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(st + (lr + 8 * i) * kSkPitch + lc) = pre[i];
+      if (c + 1 < chunks) load_chunk(c + 1);
+      const float* wk = W + 32 * c;                           // uniform: the weights come through the scalar cache
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(st + lane * kSkPitch + 4 * q);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const float4 w = *reinterpret_cast<const float4*>(wk + (size_t)j * ldw + 4 * q);   // K is a multiple of 32
+          acc[j] = fmaf(x.x, w.x, fmaf(x.y, w.y, fmaf(x.z, w.z, fmaf(x.w, w.w, acc[j]))));
+        }
+      }
+    }
+    const long m = row0 + lane;
+    if (m < M) {
+      float v[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[j] = acc[j] + bias[j];
+      if (out != nullptr) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) out[m * ldo + j] = v[j];
+      }
+      if (HEAD) {
+        float y[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const float t = tanhf(v[j]);
+          h.th[m * 8 + j] = t;
+          // x = 1.3 tanh(x) + img; x = x.clamp(0,1).detach() + x - x.detach() (mlps.py:232-233): the value of the straight-through
+          // clamp is (clamp(x) + x) - x as rounded in fp32, not clamp(x) -- it can land one ulp outside [0,1], which the clamp
+          // of :494-496 then gates.  Separate roundings as torch's (no fma).
+          const float u = __fadd_rn(__fmul_rn(1.3f, t), h.start[m * h.lds + j]);
+          y[j] = __fsub_rn(__fadd_rn(fminf(fmaxf(u, 0.f), 1.f), u), u);
+        }
+        if (h.map_a) { h.map_a[m * 3 + 0] = y[0]; h.map_a[m * 3 + 1] = y[1]; h.map_a[m * 3 + 2] = y[2]; }
+        if (h.map_r) h.map_r[m] = __fadd_rn(__fmul_rn(y[3], 0.93f), 0.07f);
+        if (h.map_m) h.map_m[m] = y[4];
+      }
+    }
+  }
+}
+
+// d x[m][j] = g_y[j] * 1.3 * (1 - tanh(x)^2) for the live channels (g_y = d maps; the roughness map is 0.93 y + 0.07; the clamp
+// of :235 is a straight-through one), 0 for the others and for the padding columns 5..7.
+__global__ __launch_bounds__(256) void arm_head_bwd_kernel(const float* __restrict__ g_a, const float* __restrict__ g_r, const float* __restrict__ g_m,
+                                                           const float* __restrict__ th, float* __restrict__ d_x, long M) {
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+    const float4 t0 = *reinterpret_cast<const float4*>(th + m * 8);
+    const float t4 = th[m * 8 + 4];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float o4 = 0.f;
+    if (g_a) {
+      o.x = (g_a[m * 3 + 0] * 1.3f) * (1.f - t0.x * t0.x);
+      o.y = (g_a[m * 3 + 1] * 1.3f) * (1.f - t0.y * t0.y);
+      o.z = (g_a[m * 3 + 2] * 1.3f) * (1.f - t0.z * t0.z);
+    }
+    if (g_r) o.w = ((g_r[m] * 0.93f) * 1.3f) * (1.f - t0.w * t0.w);
+    if (g_m) o4 = (g_m[m] * 1.3f) * (1.f - t4 * t4);
+    *reinterpret_cast<float4*>(d_x + m * 8) = o;
+    *reinterpret_cast<float4*>(d_x + m * 8 + 4) = make_float4(o4, 0.f, 0.f, 0.f);
+  }
+}
+
+// partial[slab][j][c] = sum over the slab's rows of S[m][j] B[m][c] (J columns of the skinny S, 256 of the wide B), and
+// bpart[slab][j] = sum of S[m][j].  Thread (cq, rs): columns 4cq..4cq+3 of B, every 4th row of the slab; the S row is uniform
+// across a wave (scalar loads).  The four row slices are folded through LDS in fixed order.
+constexpr int kSkinnySlabs = 512;
+template <int J>
+__global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restrict__ S, int lds, const float* __restrict__ B, int ldb,
+                                                            float* __restrict__ partial, float* __restrict__ bpart, long M, long rows_per_slab) {
+  __shared__ float red[3][J][256];
+  __shared__ float bred[4][J];
+  const int cq = threadIdx.x & 63, rs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long m_begin = (long)blockIdx.x * rows_per_slab;
+  const long m_end = (m_begin + rows_per_slab < M) ? m_begin + rows_per_slab : M;
+  float4 acc[J];
+  float bs[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { acc[j] = make_float4(0.f, 0.f, 0.f, 0.f); bs[j] = 0.f; }
+  constexpr int U = 4;
+  for (long m0 = m_begin + rs; m0 < m_end; m0 += 4 * U) {
+    float4 b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + 4 * u;
+      b[u] = m < m_end ? *reinterpret_cast<const float4*>(B + m * ldb + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + 4 * u < m_end ? m0 + 4 * u : m_end - 1;   // past the end: b is zero, any finite row of S will do
+      const float* srow = S + m * lds;
+      const bool live = m0 + 4 * u < m_end;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const float sv = srow[j];
+        acc[j].x = fmaf(sv, b[u].x, acc[j].x);
+        acc[j].y = fmaf(sv, b[u].y, acc[j].y);
+        acc[j].z = fmaf(sv, b[u].z, acc[j].z);
+        acc[j].w = fmaf(sv, b[u].w, acc[j].w);
+        bs[j] += live ? sv : 0.f;
+      }
+    }
+  }
+  if (rs > 0) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) *reinterpret_cast<float4*>(&red[rs - 1][j][4 * cq]) = acc[j];
+  }
+  if (cq == 0) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) bred[rs][j] = bs[j];
+  }
+  __syncthreads();
+  if (rs == 0) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      float4 t = acc[j];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 o = *reinterpret_cast<const float4*>(&red[q][j][4 * cq]);
+        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * J + j) * 256 + 4 * cq) = t;
+    }
+    if (bpart != nullptr && threadIdx.x < J) bpart[(size_t)blockIdx.x * J + threadIdx.x] = (bred[0][threadIdx.x] + bred[1][threadIdx.x]) + (bred[2][threadIdx.x] + bred[3][threadIdx.x]);
+  }
+}
+
+// out[j * ld_j + c * ld_c] = sum over slabs of partial[slab][j][c] (j < Jv, c < C); d_b[j] = sum of bpart[slab][j].  One
+// workgroup per (j, 64 columns): 16 slab slices x 64 columns, fixed order.
+__global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __restrict__ partial, const float* __restrict__ bpart, int slabs, int J, int Jv,
+                                                             int C, float* __restrict__ out, long ld_j, long ld_c, float* __restrict__ d_b) {
+  __shared__ float red[16][64];
+  const int j = blockIdx.x >> 2, cl = threadIdx.x & 63, c = (blockIdx.x & 3) * 64 + cl, sl = threadIdx.x >> 6;
+  if (j >= Jv) return;                                       // uniform per workgroup
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int q = sl;
+  for (; q + 48 < slabs; q += 64) {
+    a0 += partial[((size_t)q * J + j) * 256 + c];
+    a1 += partial[((size_t)(q + 16) * J + j) * 256 + c];
+    a2 += partial[((size_t)(q + 32) * J + j) * 256 + c];
+    a3 += partial[((size_t)(q + 48) * J + j) * 256 + c];
+  }
+  for (; q < slabs; q += 16) a0 += partial[((size_t)q * J + j) * 256 + c];
+  red[sl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += red[u][cl];
+    out[j * ld_j + c * ld_c] = t;
+  }
+  if (d_b != nullptr && bpart != nullptr && (blockIdx.x & 3) == 0) {   // the bias gradient: 1024 threads over the slabs, LDS tree
+    __syncthreads();
+    float t = 0.f;
+    for (int q2 = threadIdx.x; q2 < slabs; q2 += 1024) t += bpart[(size_t)q2 * J + j];
+    red[sl][cl] = t;
+    __syncthreads();
+    if (sl == 0) {
+      float u = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u += red[r][cl];
+      red[0][cl] = u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float u = 0.f;
+      for (int r = 0; r < 64; ++r) u += red[0][r];
+      d_b[j] = u;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1491,7 +1747,14 @@ size_t matpbr_mlp_wsplit_bytes(int K) { return K > 0 ? (size_t)((K + 31) / 32) *
 int matpbr_mlp_split_weights(const float* w, int ldw, int N, int K, void* wsplit, void* stream) {
   if (!w || !wsplit || N <= 0 || N > 256 || K <= 0 || K > 256 || ldw < K) return MATPBR_ERR_INVALID_ARG;
   const int n = ((K + 31) / 32) * 2 * 256 * 2;
-  hipLaunchKernelGGL(mlp_split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, (uint4*)wsplit);
+  hipLaunchKernelGGL(mlp_split_weights_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, (uint4*)wsplit);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wsplit, void* stream) {
+  if (!w || !wsplit || N <= 0 || N > 256 || K <= 0 || K > 256 || ldw < N) return MATPBR_ERR_INVALID_ARG;
+  const int n = ((K + 31) / 32) * 2 * 256 * 2;
+  hipLaunchKernelGGL(mlp_split_weights_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, (uint4*)wsplit);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
@@ -1583,6 +1846,55 @@ int matpbr_mlp_mul(const float* a, long lda, const float* b, long ldb, float* ou
   long blocks = (M * n + 255) / 256;
   if (blocks > 256L * 32) blocks = 256L * 32;
   hipLaunchKernelGGL(mlp_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, M, n);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_skinny_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, long M, int J, int K,
+                          void* stream) {
+  if (!x || !w || !bias || !out || M <= 0 || (J != 3 && J != 5 && J != 8) || K <= 0 || K > 256 || (K & 31)) return MATPBR_ERR_INVALID_ARG;
+  if ((ldx & 3) || ldx < K || (ldw & 3) || ldw < K || ldo < J || !aligned16(x) || !aligned16(w)) return MATPBR_ERR_INVALID_ARG;
+  const unsigned grid = (unsigned)((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048);
+  const ArmHead none{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+  if (J == 3) hipLaunchKernelGGL((mlp_skinny_nt_kernel<3, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, out, ldo, M, K, none);
+  else if (J == 5) hipLaunchKernelGGL((mlp_skinny_nt_kernel<5, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, out, ldo, M, K, none);
+  else hipLaunchKernelGGL((mlp_skinny_nt_kernel<8, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, out, ldo, M, K, none);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_arm_head_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* start, int lds, float* th,
+                            float* map_a, float* map_r, float* map_m, long M, int K, void* stream) {
+  if (!x || !w || !bias || !start || !th || M <= 0 || K <= 0 || K > 256 || (K & 31) || lds < 5) return MATPBR_ERR_INVALID_ARG;
+  if ((ldx & 3) || ldx < K || (ldw & 3) || ldw < K || !aligned16(x) || !aligned16(w) || !aligned16(th)) return MATPBR_ERR_INVALID_ARG;
+  const unsigned grid = (unsigned)((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048);
+  const ArmHead h{start, lds, th, map_a, map_r, map_m};
+  hipLaunchKernelGGL((mlp_skinny_nt_kernel<5, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, (float*)nullptr, 0, M, K, h);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_arm_head_bwd(const float* g_a, const float* g_r, const float* g_m, const float* th, float* d_x, long M, void* stream) {
+  if (!th || !d_x || M <= 0 || !aligned16(th) || !aligned16(d_x)) return MATPBR_ERR_INVALID_ARG;
+  const unsigned grid = (unsigned)((M + 255) / 256 < 4096 ? (M + 255) / 256 : 4096);
+  hipLaunchKernelGGL(arm_head_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_a, g_r, g_m, th, d_x, M);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+size_t matpbr_mlp_skinny_workspace_bytes(int J) { return J > 0 && J <= 16 ? (size_t)kSkinnySlabs * ((J + 7) / 8 * 8) * 257 * sizeof(float) : 0; }
+
+int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ldb, float* d_w, long ld_j, long ld_c, float* d_bias, void* workspace,
+                                 size_t workspace_bytes, long M, int J, int C, void* stream) {
+  if (!s || !b || !d_w || M <= 0 || J <= 0 || J > 16 || C <= 0 || C > 256) return MATPBR_ERR_INVALID_ARG;
+  const int JP = (J + 7) / 8 * 8;                        // columns of S that are read: the caller pads S to a multiple of 8 columns
+  if (lds < JP || ldb < 256 || (ldb & 3) || !aligned16(b)) return MATPBR_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < matpbr_mlp_skinny_workspace_bytes(J)) return MATPBR_ERR_WORKSPACE;
+  long rows = (M + kSkinnySlabs - 1) / kSkinnySlabs;
+  rows = (rows + 3) / 4 * 4;
+  const int slabs = (int)((M + rows - 1) / rows);
+  float* partial = (float*)workspace;
+  float* bpart = partial + (size_t)kSkinnySlabs * JP * 256;
+  if (JP == 8) hipLaunchKernelGGL(mlp_skinny_tn_kernel<8>, dim3(slabs), dim3(256), 0, (hipStream_t)stream, s, lds, b, ldb, partial, bpart, M, rows);
+  else hipLaunchKernelGGL(mlp_skinny_tn_kernel<16>, dim3(slabs), dim3(256), 0, (hipStream_t)stream, s, lds, b, ldb, partial, bpart, M, rows);
+  hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(JP * 4), dim3(1024), 0, (hipStream_t)stream, (const float*)partial, (const float*)bpart, slabs, JP, J, C, d_w,
+                     ld_j, ld_c, d_bias);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 

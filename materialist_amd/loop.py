@@ -557,6 +557,16 @@ class PosMlpBrdfPhase:
         return self.es.early_stop
 
 
+def pos_mlp_brdf_phase(scene, gt_image, net, start_arm, fixed, optimize_part="arm", mask=None, **kw):
+    """The phase object of a `pos_mlp` part: the launch-by-launch `armhead.ArmMlpPhase` where it applies (one image of at least
+    8192 pixels, 'arm' network with 256-wide layers, no mask), the autograd composition `PosMlpBrdfPhase` otherwise."""
+    from .armhead import ArmMlpPhase
+
+    if ArmMlpPhase.supported(scene, gt_image, net, optimize_part, mask):
+        return ArmMlpPhase(scene, gt_image, net, start_arm, fixed, optimize_part=optimize_part, **kw)
+    return PosMlpBrdfPhase(scene, gt_image, net, start_arm, fixed, optimize_part=optimize_part, mask=mask, **kw)
+
+
 class PosMlpNormalPhase:
     """Hot loop B in `pos_mlp` mode with output_type 'armn' (inverse_img_w_mi.py:165-172,493-506,516-554): the coordinate MLP
     also predicts the shading normal (`'n'` in --opt_order, predicted normals instead of geometric ones).  Maps from the net

@@ -441,16 +441,18 @@ def mlp_layer_bwd_input(g: torch.Tensor, wt: torch.Tensor, c_prev: torch.Tensor,
     _lib.check(code, "matpbr_mlp_layer_bwd_input")
 
 
-def mlp_split_weights(w: torch.Tensor, N: int, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """w[:N, :K] (row-major, unit column stride) split into three bf16 pieces in the operand order of the bx kernels (opaque bytes)."""
+def mlp_split_weights(w: torch.Tensor, N: int, K: int, out: Optional[torch.Tensor] = None, transposed: bool = False) -> torch.Tensor:
+    """w[:N, :K] (row-major, unit column stride) split into three bf16 pieces in the operand order of the bx kernels (opaque bytes).
+    transposed: the operand is w[:K, :N]^T (the forward weight serving the backward product)."""
     lib = _lib.load()
     if not (w.is_cuda and w.dtype == torch.float32 and w.ndim == 2 and w.stride(1) == 1):
         raise ValueError("mlp_split_weights: expected a [rows, cols] fp32 CUDA matrix with unit column stride")
     need = int(lib.matpbr_mlp_wsplit_bytes(K))
     if out is None or out.numel() < need:
         out = torch.empty(need, dtype=torch.uint8, device=w.device)
+    fn = lib.matpbr_mlp_split_weights_t if transposed else lib.matpbr_mlp_split_weights
     with torch.cuda.device(w.device):
-        code = lib.matpbr_mlp_split_weights(_ptr(w), w.stride(0), N, K, _ptr(out), _stream(w))
+        code = fn(_ptr(w), w.stride(0), N, K, _ptr(out), _stream(w))
     _lib.check(code, "matpbr_mlp_split_weights")
     return out
 
@@ -497,19 +499,76 @@ def mlp_layer_bwd_weight(g: torch.Tensor, x: torch.Tensor, N: int, K: int) -> to
     return d_w
 
 
-def mlp_layer_bwd_weight_bx(g: torch.Tensor, x: torch.Tensor, N: int, K: int, nprod: int = 6) -> torch.Tensor:
+def mlp_layer_bwd_weight_bx(g: torch.Tensor, x: torch.Tensor, N: int, K: int, nprod: int = 6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """As mlp_layer_bwd_weight with split operands (three bf16 pieces per f32, `nprod` bf16 MFMA products, f32 accumulate): both
-    operands 256 columns wide in memory, rows a multiple of 16."""
+    operands 256 columns wide in memory, rows a multiple of 16.  out: a [N, >= K] matrix to receive the gradient."""
     lib = _lib.load()
     g, x = _mat2(g, "g"), _mat2(x, "x")
     M = g.shape[0]
     ws = _mlp_workspace("bwd_weight", M, g.device, lib.matpbr_mlp_bwd_weight_workspace_bytes(M))
-    d_w = torch.empty((N, K), dtype=torch.float32, device=g.device)
+    d_w = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
-        code = lib.matpbr_mlp_layer_bwd_weight_bx(_ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(d_w), K, _ptr(ws), ws.numel() * 4, M, N, K,
-                                                  nprod, _stream(g))
+        code = lib.matpbr_mlp_layer_bwd_weight_bx(_ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(d_w), d_w.stride(0), _ptr(ws), ws.numel() * 4,
+                                                  M, N, K, nprod, _stream(g))
     _lib.check(code, "matpbr_mlp_layer_bwd_weight_bx")
     return d_w
+
+
+def mlp_skinny_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, K: int) -> None:
+    """out[:, :J] = x[:, :K] w[:J, :K]^T + bias for the J in {3, 5, 8} outputs of the network at image size: one streaming pass."""
+    lib = _lib.load()
+    x, w = _mat2(x, "x"), _mat2(w, "w")
+    with torch.cuda.device(x.device):
+        code = lib.matpbr_mlp_skinny_fwd(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0), x.shape[0], w.shape[0], K,
+                                         _stream(x))
+    _lib.check(code, "matpbr_mlp_skinny_fwd")
+
+
+def mlp_arm_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, start: torch.Tensor, th: torch.Tensor, map_a: Optional[torch.Tensor],
+                     map_r: Optional[torch.Tensor], map_m: Optional[torch.Tensor], K: int) -> None:
+    """Output layer (5 channels) + the 'arm' head (mymodels/mlps.py:233-236, inverse_img_w_mi.py:493-496): th [M,8] = tanh(x w^T + b),
+    maps from the straight-through clamp of u = 1.3 th + start, (clamp(u, 0, 1) + u) - u; a map passed as None is not written."""
+    lib = _lib.load()
+    x, w = _mat2(x, "x"), _mat2(w, "w")
+    with torch.cuda.device(x.device):
+        code = lib.matpbr_mlp_arm_head_fwd(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(start), start.stride(0), _ptr(th),
+                                           _ptr(map_a) if map_a is not None else None, _ptr(map_r) if map_r is not None else None,
+                                           _ptr(map_m) if map_m is not None else None, x.shape[0], K, _stream(x))
+    _lib.check(code, "matpbr_mlp_arm_head_fwd")
+
+
+def mlp_arm_head_bwd(g_a: Optional[torch.Tensor], g_r: Optional[torch.Tensor], g_m: Optional[torch.Tensor], th: torch.Tensor, d_x: torch.Tensor) -> None:
+    """d_x [M,8] = the map gradients chained through the 'arm' head; None = that map is not being optimised (zero columns)."""
+    lib = _lib.load()
+    with torch.cuda.device(th.device):
+        code = lib.matpbr_mlp_arm_head_bwd(_ptr(g_a) if g_a is not None else None, _ptr(g_r) if g_r is not None else None,
+                                           _ptr(g_m) if g_m is not None else None, _ptr(th), _ptr(d_x), th.shape[0], _stream(th))
+    _lib.check(code, "matpbr_mlp_arm_head_bwd")
+
+
+def mlp_skinny_bwd_weight(s: torch.Tensor, b: torch.Tensor, d_w: torch.Tensor, J: int, C: int, d_bias: Optional[torch.Tensor] = None,
+                          transposed_out: bool = False) -> None:
+    """d_w[j, c] (transposed_out: d_w[c, j]) = sum_m s[m, j] b[m, c] for j < J <= 16, c < C <= 256; d_bias[j] = sum_m s[m, j].
+    s rows padded to a multiple of 8 floats, b 256 columns wide in memory."""
+    lib = _lib.load()
+    b = _mat2(b, "b")
+    M = b.shape[0]
+    ws = _mlp_workspace("skinny%d" % ((J + 7) // 8), 0, b.device, lib.matpbr_mlp_skinny_workspace_bytes(J))
+    ld_j, ld_c = (1, d_w.stride(0)) if transposed_out else (d_w.stride(0), 1)
+    with torch.cuda.device(b.device):
+        code = lib.matpbr_mlp_skinny_bwd_weight(_ptr(s), s.stride(0), _ptr(b), b.stride(0), _ptr(d_w), ld_j, ld_c,
+                                                _ptr(d_bias) if d_bias is not None else None, _ptr(ws), ws.numel() * 4, M, J, C, _stream(b))
+    _lib.check(code, "matpbr_mlp_skinny_bwd_weight")
+
+
+def adamw_step_dev(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hyper: torch.Tensor, weight_decay: float = 0.01,
+                   beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """torch.optim.AdamW on one flat buffer; hyper = [lr, steps done] in device memory (the count is advanced by the call)."""
+    lib = _lib.load()
+    with torch.cuda.device(p.device):
+        code = lib.matpbr_adamw_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper), float(beta1), float(beta2), float(eps),
+                                         float(weight_decay), _stream(p))
+    _lib.check(code, "matpbr_adamw_step_dev")
 
 
 def brdf_terms(cos1, cos2, r, f0) -> torch.Tensor:

@@ -194,9 +194,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
 
     # ------------------------------------------------------------------ hot loop B (:347-468), device-resident
     def brdf_part_runner_mlp(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
-        ph = _loop.PosMlpBrdfPhase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in ("albedo", "roughness", "metallic")},
-                                   optimize_part=part, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
-                                   best_mse=saver.best_loss, history_len=n_epochs, mask=mask)
+        ph = _loop.pos_mlp_brdf_phase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in ("albedo", "roughness", "metallic")},
+                                      optimize_part=part, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
+                                      best_mse=saver.best_loss, history_len=n_epochs, mask=mask)
         stop, it = "num_epochs", 0
         for it in range(n_epochs):
             if ph.step_and_check():                                                 # per-epoch host check, as the reference (:550)

@@ -735,6 +735,207 @@ def test_pos_mlp_phase_matches_torch_composition():
         assert (va - vb).abs().max().item() < 2e-5, ka
 
 
+@pytest.mark.parametrize("part", ["rm", "a", "arm"])
+def test_arm_mlp_phase_matches_the_torch_composition(part):
+    """f2 in the loop without a framework in between: ArmMlpPhase (every launch of the iteration a kernel of libmatpbr.so: sine
+    layers, output layer + tanh head, head backward, skinny weight gradients, AdamW on the flat buffer) against the same iterations
+    composed from torch ops around the autograd render with the reference network (inverse_img_w_mi.py:470-554): loss values and
+    every parameter after three AdamW steps, for the three parts of --opt_order."""
+    import copy
+
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+    from materialist_amd.armhead import ArmMlpPhase
+
+    dev = _cuda()
+    H = W = 128         # 16384 points: above MIN_ROWS, so the image-size kernels are the ones that run
+    spp = 8
+    sc = synthetic.make_scene(9, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp).clone()
+    # initial maps squeezed into [0.1, 0.9]: no map value sits on a clamp bound during these iterations (see the note at the end)
+    a0, r0, m0 = (0.1 + 0.8 * _t(v, dev).clamp(0, 1) for v in (sc.init_albedo, sc.init_roughness, sc.init_metallic))
+    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).clamp(0, 1)
+    torch.manual_seed(11)
+    net_a = posmlp.brdf_net("arm").to(dev)
+    net_a.lin4.weight.data.normal_(0, 0.02)
+    net_a.lin4.bias.data.normal_(0, 0.02)
+    net_b = copy.deepcopy(net_a)
+    fixed = {"albedo": a0, "roughness": r0, "metallic": m0}
+    assert ArmMlpPhase.supported(scene, gt, net_b, part, None)
+    ph = loop.pos_mlp_brdf_phase(scene, gt, net_b, start_arm, fixed, optimize_part=part, spp=spp)
+    assert isinstance(ph, ArmMlpPhase)
+    opt = torch.optim.AdamW(net_a.parameters(), lr=3e-4)
+    orig = {"albedo": start_arm[:, 0:3].reshape(H, W, 3), "roughness": start_arm[:, 3:4].reshape(H, W, 1),
+            "metallic": start_arm[:, 4:5].reshape(H, W, 1)}
+    posmlp._PosMlpHipFn.MIN_ROWS = 1 << 30             # the reference side on the torch/BLAS composition of the network
+    try:
+        for it in range(3):
+            arm = net_a(start_arm)
+            maps = {"albedo": arm[:, 0:3].clamp(0, 1).reshape(H, W, 3), "roughness": (arm[:, 3:4] * 0.93 + 0.07).clamp(0, 1).reshape(H, W, 1),
+                    "metallic": arm[:, 4:5].clamp(0, 1).reshape(H, W, 1)}
+            live = {k: maps[k] for k, c in (("albedo", "a"), ("roughness", "r"), ("metallic", "m")) if c in part}
+            use = {k: live.get(k, fixed[k]) for k in maps}
+            pred = render.render_w_brdf(scene, use["albedo"], use["roughness"], use["metallic"], None, spp)
+            total, mse, _, _ = loop._loss.brdf_loss(pred, gt, live, {k: orig[k] for k in live}, 0.1)
+            total.backward()
+            if it == 0:
+                g_ref = [p.grad.clone() for p in net_a.parameters()]
+            opt.step()
+            opt.zero_grad()
+            ph.step()
+            rel = 3e-4 if it == 0 else 2e-3                    # later iterations carry the AdamW-amplified last-bit noise (note at the end)
+            assert float(ph.stats[0, ops.STAT_MSE]) == pytest.approx(float(mse.detach()), rel=rel), it
+            assert float(ph.stats[0, ops.STAT_LOSS]) == pytest.approx(float(total.detach()), rel=rel), it
+            if it == 0:                                        # the gradient of every parameter, before AdamW normalises it
+                for l, (gw, gb) in enumerate(ph.gviews):
+                    rw, rb = g_ref[2 * l], g_ref[2 * l + 1]
+                    # (the L1 terms of the loss carry sign(pred - gt): a few pixels flip between two renders that differ in the last bits;
+                    # test_arm_mlp_phase_network_gradients_match_autograd pins the network half to 2e-5)
+                    assert (gw[:, :rw.shape[1]] - rw).norm().item() <= 1e-2 * rw.norm().item() + 1e-9, l
+                    assert (gb[:rb.shape[0]] - rb).norm().item() <= 1e-2 * rb.norm().item() + 1e-9, l
+    finally:
+        posmlp._PosMlpHipFn.MIN_ROWS = 8192
+    # (Where a map saturates, the value of the reference's straight-through clamp, (clamp(x) + x) - x in fp32, lands on 1 or on
+    # 1 + 2^-23 depending on the last bit of x, and the clamp of :494-496 gates the gradient on that: pixels contribute or not in
+    # either implementation, AdamW normalises, and parameters with gradients of the size of that noise move by up to lr per step in
+    # either direction.  That is a property of the reference's formulation, kept out of this comparison by the squeezed maps.)
+    sd_a, sd_b = net_a.state_dict(), net_b.state_dict()
+    assert list(sd_a) == list(sd_b)
+    for k in sd_a:
+        assert sd_a[k].shape == sd_b[k].shape
+        diff = (sd_a[k] - sd_b[k]).abs()
+        # AdamW normalises: the few parameters whose gradient is of the size of the render's last-bit noise may step the other way
+        # (a wrong gradient moves every parameter by ~lr per step: mean ~ 5e-4)
+        assert diff.mean().item() < 2e-5 and (diff < 3e-5).float().mean().item() > 0.95 and diff.max().item() <= 6.1 * 3e-4, (k, diff.max().item(), diff.mean().item())
+    bw = ph.best_weights
+    assert set(bw) == set(sd_b) and all(bw[k].shape == sd_b[k].shape for k in bw)
+
+
+def test_arm_mlp_phase_network_gradients_match_autograd():
+    """The network half of ArmMlpPhase on its own, where nothing is chaotic: forward() against the reference module's maps, and
+    backward() fed with given map gradients against torch autograd through the reference network (the straight-through clamp has
+    an identity gradient; the gating clamp of :494-496 lives in the loss kernels, not here)."""
+    import copy
+
+    from materialist_amd import loop, posmlp, render, synthetic
+    from materialist_amd.armhead import ArmMlpPhase
+
+    dev = _cuda()
+    H = W = 128
+    sc = synthetic.make_scene(5, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    gt = torch.rand(H, W, 3, device=dev)
+    a0, r0, m0 = _t(sc.init_albedo, dev), _t(sc.init_roughness, dev), _t(sc.init_metallic, dev)
+    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).clamp(0, 1)
+    torch.manual_seed(4)
+    net_a = posmlp.brdf_net("arm").to(dev)
+    net_a.lin4.weight.data.normal_(0, 0.05)
+    net_a.lin4.bias.data.normal_(0, 0.05)
+    net_b = copy.deepcopy(net_a)
+    ph = ArmMlpPhase(scene, gt, net_b, start_arm, {"albedo": a0, "roughness": r0, "metallic": m0}, optimize_part="arm", spp=8)
+    maps = ph.forward()
+    posmlp._PosMlpHipFn.MIN_ROWS = 1 << 30             # the reference side on the torch/BLAS composition of the network
+    try:
+        arm = net_a(start_arm)
+        ref = {"albedo": arm[:, 0:3].reshape(H, W, 3), "roughness": (arm[:, 3:4] * 0.93 + 0.07).reshape(H, W, 1), "metallic": arm[:, 4:5].reshape(H, W, 1)}
+        for k in ref:                                      # one ulp of the straight-through clamp's (c + x) - x on top of the network's rounding
+            assert (maps[k] - ref[k].detach()).abs().max().item() <= 3e-6, k
+        g = {k: torch.randn_like(v) for k, v in ref.items()}
+        torch.autograd.backward([ref[k] for k in ref], [g[k] for k in ref])
+    finally:
+        posmlp._PosMlpHipFn.MIN_ROWS = 8192
+    for k in g:
+        ph.g[k].copy_(g[k])
+    ph.backward()
+    g_ref = [p.grad for p in net_a.parameters()]
+    for l, (gw, gb) in enumerate(ph.gviews):
+        rw, rb = g_ref[2 * l], g_ref[2 * l + 1]
+        assert (gw[:, :rw.shape[1]] - rw).abs().max().item() <= 3e-4 * rw.abs().max().item(), l
+        assert (gw[:, :rw.shape[1]] - rw).norm().item() <= 2e-5 * rw.norm().item(), l
+        assert (gw[:, rw.shape[1]:] == 0).all()            # the padding column of the first layer never receives a gradient
+        assert (gb[:rb.shape[0]] - rb).norm().item() <= 2e-5 * rb.norm().item(), l
+
+
+def test_skinny_layers_and_arm_head_match_torch():
+    """The skinny ends of the network at image size: output layer (J = 3, 5, 8) against an fp64 product, the 'arm' head against
+    torch's (tanh, residual, clamp, 0.93 r + 0.07) bit for bit on the same pre-activations, its backward against autograd, the two
+    skinny weight gradients (+ bias gradient) against fp64, and AdamW on a flat buffer against torch.optim.AdamW."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    torch.manual_seed(2)
+    M = 128 * 77 + 5
+    x = torch.randn(M, 256, device=dev)
+    for J in (3, 5, 8):
+        w = torch.randn(J, 256, device=dev) / 16
+        b = torch.randn(J, device=dev)
+        out = torch.full((M, 8), float("nan"), device=dev)
+        ops.mlp_skinny_fwd(x, w, b, out, 256)
+        ref = x.double() @ w.double().t() + b.double()
+        assert (out[:, :J].double() - ref).abs().max().item() < 2e-5
+        assert torch.isnan(out[:, J:]).all()
+    w = torch.randn(5, 256, device=dev) / 8
+    b = torch.randn(5, device=dev) * 0.1
+    start = torch.rand(M, 5, device=dev)
+    pre = torch.empty(M, 8, device=dev)
+    ops.mlp_skinny_fwd(x, w, b, pre, 256)
+    th = torch.empty(M, 8, device=dev)
+    ma, mr, mm = torch.empty(M, 3, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.mlp_arm_head_fwd(x, w, b, start, th, ma, mr, mm, 256)
+    xs = pre[:, :5].clone().requires_grad_(True)
+    y = 1.3 * torch.tanh(xs) + start
+    y = y.clamp(0, 1).detach() + y - y.detach()
+    a_t, r_t, m_t = y[:, 0:3], y[:, 3] * 0.93 + 0.07, y[:, 4]
+    assert (th[:, :5] - torch.tanh(xs.detach())).abs().max().item() <= 2e-7
+    assert (ma - a_t.detach()).abs().max().item() <= 3e-7 and (mr - r_t.detach()).abs().max().item() <= 3e-7
+    assert (mm - m_t.detach()).abs().max().item() <= 3e-7
+    mr_only = torch.full((M,), -1.0, device=dev)
+    ops.mlp_arm_head_fwd(x, w, b, start, th, None, mr_only, None, 256)      # maps that are not optimised are not written
+    assert torch.equal(mr_only, mr)
+    ga, gr, gm = torch.randn(M, 3, device=dev), torch.randn(M, device=dev), torch.randn(M, device=dev)
+    ((a_t * ga).sum() + (r_t * gr).sum() + (m_t * gm).sum()).backward()
+    d_x = torch.full((M, 8), float("nan"), device=dev)
+    ops.mlp_arm_head_bwd(ga, gr, gm, th, d_x)
+    assert (d_x[:, :5] - xs.grad).abs().max().item() <= 2e-6 * xs.grad.abs().max().item()
+    assert (d_x[:, 5:] == 0).all()
+    ops.mlp_arm_head_bwd(None, gr, gm, th, d_x)
+    assert (d_x[:, 0:3] == 0).all() and (d_x[:, 3:5] - xs.grad[:, 3:5]).abs().max().item() <= 2e-6 * xs.grad.abs().max().item()
+    # skinny weight gradients
+    ops.mlp_arm_head_bwd(ga, gr, gm, th, d_x)
+    gw, gb = torch.full((5, 256), float("nan"), device=dev), torch.full((8,), float("nan"), device=dev)
+    ops.mlp_skinny_bwd_weight(d_x, x, gw, 5, 256, d_bias=gb)
+    ref = d_x[:, :5].double().t() @ x.double()
+    assert (gw.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() * (M / 4096) ** 0.5
+    refb = d_x[:, :5].double().sum(0)
+    assert (gb[:5].double() - refb).abs().max().item() <= 2e-6 * (refb.abs().max().item() + d_x.abs().max().item() * M ** 0.5)
+    x0p = torch.zeros(M, 16, device=dev)
+    x0p[:, :15] = torch.randn(M, 15, device=dev)
+    x0p[:, 0] = torch.arange(M, device=dev) % 512
+    g1 = torch.randn(M, 256, device=dev)
+    g1[:, 241:] = float("nan")                         # columns beyond the layer's width hold scratch
+    gw0 = torch.zeros(241, 16, device=dev)
+    ops.mlp_skinny_bwd_weight(x0p, g1, gw0, 15, 241, transposed_out=True)
+    ref = g1[:, :241].double().t() @ x0p[:, :15].double()
+    assert (gw0[:, :15].double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() * (M / 4096) ** 0.5
+    assert (gw0[:, 15] == 0).all()
+    # AdamW on the flat buffer
+    p0 = torch.randn(5000, device=dev)
+    p_t = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p_t], lr=3e-4)
+    p_h, m_h, v_h = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    hyper = torch.tensor([3e-4, 0.0], device=dev)
+    for it in range(4):
+        g = torch.randn(5000, device=dev)
+        p_t.grad = g.clone()
+        opt.step()
+        ops.adamw_step_dev(p_h, g, m_h, v_h, hyper, 0.01)
+    assert float(hyper[1]) == 4.0
+    assert (p_h - p_t.detach()).abs().max().item() <= 5e-7          # p * (1 - lr wd) - update in one fma against torch's two roundings
+
+
 def test_column_sum():
     from materialist_amd import ops
 
