@@ -244,7 +244,7 @@ int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int 
  * inverse_img_w_mi.py:493-496):
  *   matpbr_mlp_split_weights_t   matpbr_mlp_split_weights of the TRANSPOSE of w[K, ldw >= N] (element (n, k) = w[k * ldw + n]): the
  *                                forward weight as the operand of matpbr_mlp_layer_bwd_input_bx, no transposed copy
- *   matpbr_mlp_skinny_fwd        out[M, ldo][:, :J] = x[:, :K] w[J, :K]^T + bias, J in {3, 5, 8}, K a multiple of 32 (the zero-
+ *   matpbr_mlp_skinny_fwd        out[M, ldo][:, :J] = x[:, :K] w[J, :K]^T + bias, J in {3, 5, 8}, K a multiple of 4 (the zero-
  *                                initialised output layer)
  *   matpbr_mlp_arm_head_fwd      the same product for J = 5 followed by the 'arm' head: th[M,8] = tanh(.), u = 1.3 th + start[:, :5],
  *                                y = (clamp(u, 0, 1) + u) - u as rounded in fp32 (the straight-through clamp); map_a[M,3] = y[:, 0:3], map_r[M] = 0.93 y[:, 3] + 0.07, map_m[M] = y[:, 4]

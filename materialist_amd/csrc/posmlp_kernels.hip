@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(256) void mlp_split_weights_kernel(const float* __r
 // Eight waves per workgroup (4 row groups of 32 x 2 column halves of 128; 128 x 256 outputs per workgroup, one workgroup per
 // CU): two waves per SIMD, so that one wave's operand split / LDS traffic / epilogue runs under the other's products.
 constexpr int kBxThreads = 512;
-template <int EPI, int NPROD>
+template <int EPI, int NPROD, bool FULL>   // FULL: all 256 output columns exist (N == 256): unguarded 16-byte stores
 __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const uint4* __restrict__ wsplit) {
   extern __shared__ __align__(16) unsigned char bx_smem[];
   uint4* sB = reinterpret_cast<uint4*>(bx_smem);                         // [2 buffers][kBxStage]
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
             v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
             csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
           }
-          store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256);
+          store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);   // uniform per wave and column tile
         }
         if (EPI == EPI_SINCOS) {
 #pragma unroll
@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps)
             store4_upto(p.out1 + o0 + (size_t)(8 * ps) * p.ldo, *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col),
-                        p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256);
+                        p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);   // uniform per wave and column tile
         }
       }
     }
@@ -1392,14 +1392,20 @@ __global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_bx(const float* __res
 }
 
 constexpr size_t kBxSmem = 2 * kBxStage * sizeof(uint4) + 8 * 32 * kLd * sizeof(float);   // 96 KB of weights + 36 KB of epilogue scratch
-template <int EPI, int NPROD>
-void launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
+template <int EPI, int NPROD, bool FULL>
+void launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
   static bool configured = false;                            // more than 64 KB of LDS needs the opt-in attribute, once per kernel
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_nt_bx<EPI, NPROD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBxSmem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_nt_bx<EPI, NPROD, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBxSmem);
     configured = true;
   }
-  hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD>), dim3(grid), dim3(kBxThreads), kBxSmem, stream, p, wsplit);
+  hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD, FULL>), dim3(grid), dim3(kBxThreads), kBxSmem, stream, p, wsplit);
+}
+template <int EPI, int NPROD>
+void launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
+  // the input-gradient buffers have no tail to protect: columns at or beyond N of G' are scratch for every consumer
+  if (p.N >= 256 || EPI == EPI_MULC) launch_nt_bx_full<EPI, NPROD, true>(p, wsplit, grid, stream);
+  else launch_nt_bx_full<EPI, NPROD, false>(p, wsplit, grid, stream);
 }
 template <int EPI>
 int launch_nt_bx(NtArgs p, const uint4* wsplit, int nprod, hipStream_t stream) {   // p.M a multiple of 128
@@ -1487,50 +1493,51 @@ struct ArmHead {       // mymodels/mlps.py:233-236 ('arm') and inverse_img_w_mi.
   float* map_m;        // [M]    | null: clamp(...)[4]
 };
 
-// out[m][j] = bias[j] + sum_k X[m][k] W[j][k].  A wave owns 64 rows: it stages 32 columns of them at a time into its own slice of
-// LDS (coalesced 128-byte row segments in, pitch 36 floats), then every lane walks ITS row -- 16-byte conflict-free LDS reads,
-// the weights as scalar operands (uniform across the wave, s_load) -- so the J sums need no cross-lane reduction and the head
-// runs with all 64 lanes busy.  The next chunk's loads are in flight during the FMAs.  Only this wave touches its LDS slice and a
-// wave's LDS operations execute in order: no barriers.
-constexpr int kSkPitch = 36;
+// out[m][j] = bias[j] + sum_k X[m][k] W[j][k].  A wave owns 64 consecutive rows: lane l holds columns 4l..4l+3 of the weights
+// and of the row being multiplied (one whole 1 KB row per wave load -- 128-byte segments of many rows run at half the bandwidth),
+// J DPP tree sums per row leave the totals in lane 63, from where they are handed to lane (row & 63): after 64 rows every lane
+// holds the J sums of ITS row and the head runs once with all lanes busy.  Four rows in flight per wave.
 template <int J, bool HEAD>
 __global__ __launch_bounds__(256) void mlp_skinny_nt_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, float* __restrict__ out, int ldo, long M, int K,
                                                             const ArmHead h) {
-  __shared__ __align__(16) float stage[4][64 * kSkPitch];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* st = stage[wave];
-  const long tiles = (M + 63) / 64;
-  const int chunks = (K + 31) / 32;
-  const int lr = lane >> 3, lc = (lane & 7) * 4;              // staging: rows lr + 8 i, columns lc..lc+3 of the chunk
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
-    const long row0 = tile * 64;
-    float4 pre[8];
-    auto load_chunk = [&](int c) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (long)gridDim.x * 4;
+  const int k0 = 4 * lane;
+  const bool in = k0 < K;                                     // K is a multiple of 4
+  float4 w[J];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        long m = row0 + lr + 8 * i;
+  for (int j = 0; j < J; ++j) w[j] = in ? *reinterpret_cast<const float4*>(W + (size_t)j * ldw + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const long tiles = (M + 63) / 64;
+  constexpr int R = 4;
+  for (long tile = wave; tile < tiles; tile += waves) {
+    const long row0 = tile * 64;
+    float mine[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) mine[j] = 0.f;
+    float4 x[R];
+    auto load_rows = [&](int g) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        long m = row0 + g * R + r;
         m = m < M ? m : M - 1;
-        const int k = 32 * c + lc;
-        pre[i] = *reinterpret_cast<const float4*>(X + m * ldx + k);
+        x[r] = in ? *reinterpret_cast<const float4*>(X + m * ldx + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
-    float acc[J];
+    load_rows(0);
+    for (int g = 0; g < 64 / R; ++g) {
+      float4 cur[R];
 #pragma unroll
-    for (int j = 0; j < J; ++j) acc[j] = 0.f;
-    load_chunk(0);
-    for (int c = 0; c < chunks; ++c) {
+      for (int r = 0; r < R; ++r) cur[r] = x[r];
+      if (g + 1 < 64 / R) load_rows(g + 1);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(st + (lr + 8 * i) * kSkPitch + lc) = pre[i];
-      if (c + 1 < chunks) load_chunk(c + 1);
-      const float* wk = W + 32 * c;                           // uniform: the weights come through the scalar cache
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 x = *reinterpret_cast<const float4*>(st + lane * kSkPitch + 4 * q);
+      for (int r = 0; r < R; ++r) {
+        const int row = g * R + r;                            // uniform
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-          const float4 w = *reinterpret_cast<const float4*>(wk + (size_t)j * ldw + 4 * q);   // K is a multiple of 32
-          acc[j] = fmaf(x.x, w.x, fmaf(x.y, w.y, fmaf(x.z, w.z, fmaf(x.w, w.w, acc[j]))));
+          const float t = wave_sum_lane63(fmaf(cur[r].x, w[j].x, fmaf(cur[r].y, w[j].y, fmaf(cur[r].z, w[j].z, cur[r].w * w[j].w))));
+          const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+          mine[j] = lane == row ? total : mine[j];
         }
       }
     }
@@ -1538,7 +1545,7 @@ __global__ __launch_bounds__(256) void mlp_skinny_nt_kernel(const float* __restr
     if (m < M) {
       float v[J];
 #pragma unroll
-      for (int j = 0; j < J; ++j) v[j] = acc[j] + bias[j];
+      for (int j = 0; j < J; ++j) v[j] = mine[j] + bias[j];
       if (out != nullptr) {
 #pragma unroll
         for (int j = 0; j < J; ++j) out[m * ldo + j] = v[j];
@@ -1561,6 +1568,14 @@ __global__ __launch_bounds__(256) void mlp_skinny_nt_kernel(const float* __restr
       }
     }
   }
+}
+
+template <int J, bool HEAD>
+void launch_skinny_nt(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, long M, int K, const ArmHead& h,
+                      hipStream_t stream) {
+  const long tiles = (M + 63) / 64;
+  const unsigned grid = (unsigned)((tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048);
+  hipLaunchKernelGGL((mlp_skinny_nt_kernel<J, HEAD>), dim3(grid), dim3(256), 0, stream, x, ldx, w, ldw, bias, out, ldo, M, K, h);
 }
 
 // d x[m][j] = g_y[j] * 1.3 * (1 - tanh(x)^2) for the live channels (g_y = d maps; the roughness map is 0.93 y + 0.07; the clamp
@@ -1851,23 +1866,21 @@ int matpbr_mlp_mul(const float* a, long lda, const float* b, long ldb, float* ou
 
 int matpbr_mlp_skinny_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, long M, int J, int K,
                           void* stream) {
-  if (!x || !w || !bias || !out || M <= 0 || (J != 3 && J != 5 && J != 8) || K <= 0 || K > 256 || (K & 31)) return MATPBR_ERR_INVALID_ARG;
+  if (!x || !w || !bias || !out || M <= 0 || (J != 3 && J != 5 && J != 8) || K <= 0 || K > 256 || (K & 3)) return MATPBR_ERR_INVALID_ARG;
   if ((ldx & 3) || ldx < K || (ldw & 3) || ldw < K || ldo < J || !aligned16(x) || !aligned16(w)) return MATPBR_ERR_INVALID_ARG;
-  const unsigned grid = (unsigned)((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048);
   const ArmHead none{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
-  if (J == 3) hipLaunchKernelGGL((mlp_skinny_nt_kernel<3, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, out, ldo, M, K, none);
-  else if (J == 5) hipLaunchKernelGGL((mlp_skinny_nt_kernel<5, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, out, ldo, M, K, none);
-  else hipLaunchKernelGGL((mlp_skinny_nt_kernel<8, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, out, ldo, M, K, none);
+  if (J == 3) launch_skinny_nt<3, false>(x, ldx, w, ldw, bias, out, ldo, M, K, none, (hipStream_t)stream);
+  else if (J == 5) launch_skinny_nt<5, false>(x, ldx, w, ldw, bias, out, ldo, M, K, none, (hipStream_t)stream);
+  else launch_skinny_nt<8, false>(x, ldx, w, ldw, bias, out, ldo, M, K, none, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
 int matpbr_mlp_arm_head_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* start, int lds, float* th,
                             float* map_a, float* map_r, float* map_m, long M, int K, void* stream) {
-  if (!x || !w || !bias || !start || !th || M <= 0 || K <= 0 || K > 256 || (K & 31) || lds < 5) return MATPBR_ERR_INVALID_ARG;
+  if (!x || !w || !bias || !start || !th || M <= 0 || K <= 0 || K > 256 || (K & 3) || lds < 5) return MATPBR_ERR_INVALID_ARG;
   if ((ldx & 3) || ldx < K || (ldw & 3) || ldw < K || !aligned16(x) || !aligned16(w) || !aligned16(th)) return MATPBR_ERR_INVALID_ARG;
-  const unsigned grid = (unsigned)((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048);
   const ArmHead h{start, lds, th, map_a, map_r, map_m};
-  hipLaunchKernelGGL((mlp_skinny_nt_kernel<5, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, (float*)nullptr, 0, M, K, h);
+  launch_skinny_nt<5, true>(x, ldx, w, ldw, bias, nullptr, 0, M, K, h, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
