@@ -260,7 +260,7 @@ def main(argv=None):
             modes["fused_b8"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
     mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so: render+jac, loss statistics, streaming backward+Adam)",
                   "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
-                  "pos_mlp": "hot loop B, --model_name pos_mlp (PosMLP sine layers, render, loss, backward in libmatpbr.so; autograd glue in torch)",
+                  "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
                   "env": "hot loop A: envmap PosMLP (small-tile MFMA layers) + softplus / SH projection + one pass over the radiance transfer + "
                          "backward + Adam, 27 launches of libmatpbr.so replayed from a hipGraph",
                   "torch": "hot loop B composed from torch ops"}
@@ -354,29 +354,51 @@ def main(argv=None):
             roof["env_prt"]["frac"] = roof["env_prt"]["achieved"] / roof["env_prt"]["peak"]
             del ph_e
 
-    # the PosMLP side of the pos_mlp iteration: nine [H*W,256]x[256,256] products per iteration on the exact-f32 MFMA, in the
-    # hand-written kernels of libmatpbr.so (epilogues included); the BLAS product of the same shape is timed beside them
+    # the PosMLP side of the pos_mlp iteration: nine [H*W,256]x[256,256] products per iteration, f32-accurate, in the hand-written
+    # kernels of libmatpbr.so (epilogues included): the split-operand kernels on the bf16 matrix pipe (what the iteration runs),
+    # the exact-f32 MFMA kernels and the BLAS product of the same shape beside them
     gemm = None
     if B == 1 and not args.no_extras:
+        from materialist_amd import posmlp as _pm
+
         Mg = H * W
         xg, gg = torch.randn(Mg, 256, device=dev), torch.randn(Mg, 256, device=dev)
         wg, bg = torch.randn(256, 256, device=dev) / 16, torch.randn(256, device=dev)
         sg, cg, gp = (torch.empty(Mg, 256, device=dev) for _ in range(3))
         dbg = torch.empty(256, device=dev)
+        dwg = torch.empty(256, 256, device=dev)
         flop = 2.0 * Mg * 256 * 256
+        tf = lambda ms: flop / (ms * 1e-3) / 1e12
+        P = int(_pm._PosMlpHipFn.PRODUCTS) or 6
+        wsp = ops.mlp_split_weights(wg, 256, 256)
+        bx = None
+        if Mg % 128 == 0:
+            ms_f = back_to_back(lambda: ops.mlp_layer_fwd_bx(xg, wsp, bg, sg, cg, 256, 256, P), 20)
+            ms_i = back_to_back(lambda: ops.mlp_layer_bwd_input_bx(gg, wsp, cg, gp, 256, 256, dbg, P), 20)
+            ms_w = back_to_back(lambda: ops.mlp_layer_bwd_weight_bx(gg, xg, 256, 256, P, out=dwg), 20)
+            bx = {"products": P, "forward_sincos": {"avg_launch_ms": ms_f, "achieved": tf(ms_f)},
+                  "bwd_input_mulcos_colsum": {"avg_launch_ms": ms_i, "achieved": tf(ms_i)},
+                  "bwd_weight": {"avg_launch_ms": ms_w, "achieved": tf(ms_w)}, "achieved": 3 * flop / ((ms_f + ms_i + ms_w) * 1e-3) / 1e12}
         ms_fwd = back_to_back(lambda: ops.mlp_layer_fwd(xg, wg, bg, sg, cg, 256), 20)
         ms_din = back_to_back(lambda: ops.mlp_layer_bwd_input(gg, wg, cg, gp, 256, 256, dbg), 20)
         ms_dw = back_to_back(lambda: ops.mlp_layer_bwd_weight(gg, xg, 256, 256), 20)
         ms_g = back_to_back(lambda: torch.mm(xg, wg), 20)
-        tf = lambda ms: flop / (ms * 1e-3) / 1e12
-        gemm = {"bound": "mfma", "kernel": "mlp_gemm_nt_pipe<sincos> / <mul cos> / mlp_wgrad_tn: [H*W,256]x[256,256] on v_mfma_f32_32x32x2_f32",
-                "achieved": 3 * flop / ((ms_fwd + ms_din + ms_dw) * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+        f32k = {"kernel": "mlp_gemm_nt_wide<sincos> / <mul cos> / mlp_wgrad_tn on v_mfma_f32_32x32x2_f32",
+                "achieved": 3 * flop / ((ms_fwd + ms_din + ms_dw) * 1e-3) / 1e12,
                 "forward_sincos": {"avg_launch_ms": ms_fwd, "achieved": tf(ms_fwd)},
                 "bwd_input_mulcos_colsum": {"avg_launch_ms": ms_din, "achieved": tf(ms_din)},
-                "bwd_weight": {"avg_launch_ms": ms_dw, "achieved": tf(ms_dw)},
+                "bwd_weight": {"avg_launch_ms": ms_dw, "achieved": tf(ms_dw)}}
+        gemm = {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
+                "peak_note": "dense f32 MFMA peak; 'achieved' counts f32-equivalent flop (2 M N K per product).  The split-operand kernels "
+                             "issue 6 bf16 MFMA products per f32 product (bf16 dense peak 2500): their own matrix-pipe fraction is 6 x achieved / 2500",
+                "kernel": "mlp_nt_bx<sincos> / <mul cos> / mlp_wgrad_bx: [H*W,256]x[256,256], operands split into three bf16 pieces, f32 accumulate"
+                          if bx else f32k["kernel"],
+                "achieved": (bx or f32k)["achieved"], "split_operand": bx, "exact_f32": f32k,
                 "blas_product_same_shape": {"avg_launch_ms": ms_g, "achieved": tf(ms_g), "kernel": "hipBLASLt f32 (PyTorch-ROCm), no epilogue"}}
         gemm["frac"] = gemm["achieved"] / gemm["peak"]
-        del xg, gg, wg, sg, cg, gp
+        if bx:
+            gemm["bf16_pipe_frac"] = P * bx["achieved"] / 2500.0
+        del xg, gg, wg, sg, cg, gp, dwg
 
     # BASELINE configs[4]: forward-only relighting, 2048x2048, 360 lights, through the precomputed transfer (HBM-bound kernel)
     relight = None

@@ -1,5 +1,11 @@
-// Sine-layer GEMMs of the PosMLP (mymodels/mlps.py:102-103 `SineLayer.forward = sin(linear(x))`, :216-229 the layer loop,
-// and their autograd backward), hand-written for gfx950 on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+// Sine-layer GEMMs of the PosMLP (mymodels/mlps.py:102-103 `SineLayer.forward = sin(linear(x))`, :216-236 the layer loop and
+// the output heads, and their autograd backward), hand-written for gfx950.  Three families, one C ABI section at the end:
+//   * exact-f32 MFMA (v_mfma_f32_32x32x2_f32): mlp_gemm_nt_wide / _pipe / mlp_gemm_nt, mlp_wgrad_tn -- any shape (round 1; notes below)
+//   * split-operand products on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 = three bf16 pieces, 6 of 9 partial products,
+//     f32 accumulate; as accurate as the exact-f32 kernels): mlp_nt_bx, mlp_wgrad_bx -- the 256-wide layers at image size, which
+//     is where the iteration's time is (258 / 243 / 180 us per layer at 512x512 against 357 / 318 / 283)
+//   * small point sets (<= 1024 rows, the envmap MLP): mlp_small_nt / mlp_small_tn; and the skinny ends at image size: output
+//     layer + 'arm' head, its backward, the 5-row and 15-column weight gradients (mlp_skinny_*), HBM-bound streaming kernels
 //
 // The coordinate MLP of hot loop B runs over M = H*W points (262 144 at 512x512) with layers of width <= 256: nine
 // [M,256]x[256,256] products per iteration (311 GFLOP) plus, in a stock composition, one full pass over an [M,256] matrix for
