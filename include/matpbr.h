@@ -43,7 +43,7 @@ enum {
     MATPBR_ERR_WORKSPACE = -4,
 };
 
-enum { MATPBR_LIGHT_SH25 = 0 };
+enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 };
 
 /* flags */
 #define MATPBR_FLAG_CLAMP_PARAMS 1u /* maps are raw optimiser parameters: render clamp(a,0,1), clamp(r,.07,1), clamp(m,0,1)
@@ -182,6 +182,12 @@ int matpbr_env_phase_step(const float* T, const float* light, const float* gt_sr
 int matpbr_env_project(const float* y, int ldy, const float* proj, float* env, float* light, int n_texels, void* stream);
 int matpbr_env_project_bwd(const float* y, int ldy, const float* proj, const float* d_light, float* d_y, int ldg, int n_texels,
                            void* stream);
+/* Other light parameterisations -> the [B,25,3] SH coefficients that the shading entry points take (MATPBR_LIGHT_SH25), and the
+ * gradient back.  MATPBR_LIGHT_SH9: light [B,9,3], bands 0..2.  MATPBR_LIGHT_ENV_TEXELS: light [B, He*2He, 3], the equirectangular
+ * texel map that is `emitter.data` of the reference scene (inverse_img_w_mi.py:63,217-219; 16 x 32), projected by midpoint quadrature
+ * with the direction <-> texel mapping of myutils/envmap_utils.py:29-36 (= materialist_amd.sh.envmap_to_sh_matrix). */
+int matpbr_light_to_sh25(const float* light, int light_kind, int n_light, float* sh25, int batch, void* stream);
+int matpbr_light_to_sh25_bwd(const float* d_sh25, int light_kind, int n_light, float* d_light, int batch, void* stream);
 int matpbr_select_improved(float* dst, const float* src, const float* stats, int first, long n, void* stream);
 int matpbr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
                          void* stream);

@@ -251,6 +251,75 @@ __global__ __launch_bounds__(kBlock) void env_project_bwd_kernel(const float* __
     }
     d_y[i] = g;
 }
+// Other light parameterisations -> the 25 x 3 SH coefficients the shading kernels take (and the gradient back).
+//   SH9: bands 0..2, the higher bands are zero.
+//   ENV_TEXELS: an equirectangular He x 2He texel map (the reference scene's `emitter.data`, inverse_img_w_mi.py:63,217-219), projected
+//   by midpoint quadrature: coef[k][c] = sum_t Y_k(dir_t) dOmega_t env[t][c], texel centres mapped to directions as
+//   myutils/envmap_utils.py:29-36 maps directions to texels (theta = acos(y), phi = atan2(x, -z)); = materialist_amd.sh.envmap_to_sh_matrix.
+__device__ __forceinline__ void texel_basis(int t, int He, float Yw[kNSH]) {        // Y_k(dir_t) * dOmega_t
+    const int We = 2 * He, row = t / We, col = t % We;
+    const float pi = 3.14159265358979323846f;
+    const float th = (row + 0.5f) / He * pi, ph = (col + 0.5f) / We * 2.0f * pi;
+    const float st = sinf(th), w[3] = {st * sinf(ph), cosf(th), -st * cosf(ph)};
+    const float domega = (cosf((float)row / He * pi) - cosf((float)(row + 1) / He * pi)) * (2.0f * pi / We);
+    sh_poly(w, Yw);
+#pragma unroll
+    for (int k = 0; k < kNSH; ++k) Yw[k] *= kShNorm[k] * domega;
+}
+__global__ __launch_bounds__(64) void light_to_sh25_kernel(const float* __restrict__ light, int kind, int n_light, float* __restrict__ sh25) {
+    const int b = blockIdx.x;
+    const float* src = light + (long)b * n_light * 3;
+    float* dst = sh25 + (long)b * kNL;
+    if (kind == MATPBR_LIGHT_SH9) {
+        for (int q = threadIdx.x; q < kNL; q += 64) dst[q] = q < 27 ? src[q] : 0.0f;
+        return;
+    }
+    const int He = (int)(sqrtf((float)(n_light / 2)) + 0.5f);
+    float acc[kNSH][3];
+#pragma unroll
+    for (int k = 0; k < kNSH; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+    for (int t = threadIdx.x; t < n_light; t += 64) {
+        float Yw[kNSH];
+        texel_basis(t, He, Yw);
+        const float e0 = src[t * 3], e1 = src[t * 3 + 1], e2 = src[t * 3 + 2];
+#pragma unroll
+        for (int k = 0; k < kNSH; ++k) {
+            acc[k][0] = fmaf(Yw[k], e0, acc[k][0]);
+            acc[k][1] = fmaf(Yw[k], e1, acc[k][1]);
+            acc[k][2] = fmaf(Yw[k], e2, acc[k][2]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kNSH; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = wave_sum_to_lane63(acc[k][c]);
+            if (threadIdx.x == 63) dst[k * 3 + c] = v;
+        }
+}
+__global__ __launch_bounds__(kBlock) void light_to_sh25_bwd_kernel(const float* __restrict__ d_sh25, int kind, int n_light, float* __restrict__ d_light,
+                                                                   int batch) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (long)batch * n_light) return;
+    const int b = (int)(i / n_light), t = (int)(i % n_light);
+    const float* g = d_sh25 + (long)b * kNL;
+    float* dst = d_light + i * 3;
+    if (kind == MATPBR_LIGHT_SH9) {
+        dst[0] = g[t * 3]; dst[1] = g[t * 3 + 1]; dst[2] = g[t * 3 + 2];
+        return;
+    }
+    const int He = (int)(sqrtf((float)(n_light / 2)) + 0.5f);
+    float Yw[kNSH];
+    texel_basis(t, He, Yw);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kNSH; ++k) {
+        a0 = fmaf(Yw[k], g[k * 3], a0);
+        a1 = fmaf(Yw[k], g[k * 3 + 1], a1);
+        a2 = fmaf(Yw[k], g[k * 3 + 2], a2);
+    }
+    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+}
 // dst = src where the image's statistics say the iteration improved (SaveBest's envmap snapshot, :247), n floats
 __global__ __launch_bounds__(kBlock) void select_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, const float* __restrict__ stats,
                                                              int first, long n) {
@@ -883,6 +952,27 @@ int matpbr_env_project_bwd(const float* y, int ldy, const float* proj, const flo
     if (!y || !proj || !d_light || !d_y || n_texels <= 0 || ldy < 3 || ldg < 3) return MATPBR_ERR_INVALID_ARG;
     hipLaunchKernelGGL(env_project_bwd_kernel, dim3((unsigned)((n_texels * ldg + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, ldy,
                        proj, d_light, d_y, ldg, n_texels);
+    return launch_status();
+}
+
+static bool light_shape_ok(int kind, int n_light) {
+    if (kind == MATPBR_LIGHT_SH9) return n_light == 9;
+    if (kind != MATPBR_LIGHT_ENV_TEXELS || n_light < 2 || (n_light & 1)) return false;
+    const int He = (int)(std::sqrt((double)(n_light / 2)) + 0.5);
+    return 2 * He * He == n_light;
+}
+
+int matpbr_light_to_sh25(const float* light, int light_kind, int n_light, float* sh25, int batch, void* stream) {
+    if (!light || !sh25 || batch <= 0 || !light_shape_ok(light_kind, n_light)) return MATPBR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(light_to_sh25_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, light, light_kind, n_light, sh25);
+    return launch_status();
+}
+
+int matpbr_light_to_sh25_bwd(const float* d_sh25, int light_kind, int n_light, float* d_light, int batch, void* stream) {
+    if (!d_sh25 || !d_light || batch <= 0 || !light_shape_ok(light_kind, n_light)) return MATPBR_ERR_INVALID_ARG;
+    const long total = (long)batch * n_light;
+    hipLaunchKernelGGL(light_to_sh25_bwd_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, d_sh25, light_kind,
+                       n_light, d_light, batch);
     return launch_status();
 }
 

@@ -561,6 +561,42 @@ def mlp_skinny_bwd_weight(s: torch.Tensor, b: torch.Tensor, d_w: torch.Tensor, J
     _lib.check(code, "matpbr_mlp_skinny_bwd_weight")
 
 
+LIGHT_SH9, LIGHT_ENV_TEXELS = 1, 2
+
+
+class _LightToSh25(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, light, kind):
+        lib = _lib.load()
+        light = _dev(light, "light")
+        B, n = light.shape[0], light.shape[1]
+        out = torch.empty((B, NSH, 3), dtype=torch.float32, device=light.device)
+        with torch.cuda.device(light.device):
+            code = lib.matpbr_light_to_sh25(_ptr(light), int(kind), n, _ptr(out), B, _stream(light))
+        _lib.check(code, "matpbr_light_to_sh25")
+        ctx.kind, ctx.n = int(kind), n
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        d_out = d_out.contiguous()
+        B = d_out.shape[0]
+        d_light = torch.empty((B, ctx.n, 3), dtype=torch.float32, device=d_out.device)
+        with torch.cuda.device(d_out.device):
+            code = lib.matpbr_light_to_sh25_bwd(_ptr(d_out), ctx.kind, ctx.n, _ptr(d_light), B, _stream(d_out))
+        _lib.check(code, "matpbr_light_to_sh25_bwd")
+        return d_light, None
+
+
+def light_to_sh25(light: torch.Tensor, kind: int) -> torch.Tensor:
+    """[B, n, 3] light of kind LIGHT_SH9 (n = 9) or LIGHT_ENV_TEXELS (n = He * 2He equirectangular texels, the reference scene's
+    `emitter.data`) -> the [B, 25, 3] SH coefficients the shading kernels take; differentiable."""
+    squeeze = light.ndim == 2
+    out = _LightToSh25.apply(light.reshape((1,) + tuple(light.shape)) if squeeze else light, kind)
+    return out[0] if squeeze else out
+
+
 def adamw_step_dev(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hyper: torch.Tensor, weight_decay: float = 0.01,
                    beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
     """torch.optim.AdamW on one flat buffer; hyper = [lr, steps done] in device memory (the count is advanced by the call)."""

@@ -936,6 +936,32 @@ def test_skinny_layers_and_arm_head_match_torch():
     assert (p_h - p_t.detach()).abs().max().item() <= 5e-7          # p * (1 - lr wd) - update in one fma against torch's two roundings
 
 
+def test_light_kinds_sh9_and_env_texels():
+    """SURVEY 8b's other light parameterisations: SH9 (bands 0..2) and the equirectangular texel map that is `emitter.data` of the
+    reference scene -> the SH25 light of the kernels, against the host-side projection matrix (fp64), with the gradient back."""
+    from materialist_amd import ops, sh
+
+    dev = _cuda()
+    torch.manual_seed(0)
+    for He in (16, 8):
+        env = torch.rand(2, He * 2 * He, 3, device=dev, requires_grad=True)
+        coef = ops.light_to_sh25(env, ops.LIGHT_ENV_TEXELS)
+        P = torch.from_numpy(sh.envmap_to_sh_matrix(He, 2 * He)).to(dev)                     # [25, T] float64
+        ref = P @ env.detach().double()
+        assert (coef.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+        g = torch.randn_like(coef)
+        coef.backward(g)
+        gref = P.t() @ g.double()
+        assert (env.grad.double() - gref).abs().max().item() < 2e-5 * gref.abs().max().item()
+    sh9 = torch.randn(3, 9, 3, device=dev, requires_grad=True)
+    c9 = ops.light_to_sh25(sh9, ops.LIGHT_SH9)
+    assert torch.equal(c9[:, :9], sh9.detach()) and (c9[:, 9:] == 0).all()
+    c9.backward(torch.ones_like(c9))
+    assert torch.equal(sh9.grad, torch.ones_like(sh9))
+    with pytest.raises(Exception):
+        ops.light_to_sh25(torch.rand(1, 100, 3, device=dev), ops.LIGHT_ENV_TEXELS)            # not He x 2He
+
+
 def test_column_sum():
     from materialist_amd import ops
 
