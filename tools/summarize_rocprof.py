@@ -1,5 +1,6 @@
 """Condense rocprofv3 CSV output into the small summaries committed under profiles/.
-usage: summarize_rocprof.py <dir with *kernel_stats.csv | *counter_collection.csv> [--filter substr]"""
+usage: summarize_rocprof.py <dir with *kernel_stats.csv | *counter_collection.csv> [--filter substr] [--all]
+(--all: every kernel of the trace, not only the top of the list plus libmatpbr.so's own)"""
 import collections
 import csv
 import glob
@@ -8,6 +9,7 @@ import sys
 
 d = sys.argv[1]
 flt = sys.argv[sys.argv.index("--filter") + 1] if "--filter" in sys.argv else None
+everything = "--all" in sys.argv
 
 
 def short(name):
@@ -22,7 +24,7 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=
     print("name,calls,avg_us,min_us,max_us,pct")
     OWN = ("shade_", "relight", "loss_", "adam", "light_grad", "colsum", "normals_from", "eval_brdf", "sample_brdf", "sh_eval", "jac_bwd", "env_", "diffuse_cache", "mlp_")
     for i, r in enumerate(rows):
-        if i < 14 or any(k in r["Name"] for k in OWN):       # the top of the list plus every kernel of libmatpbr.so
+        if everything or i < 14 or any(k in r["Name"] for k in OWN):       # the top of the list plus every kernel of libmatpbr.so
             print(f"{short(r['Name'])},{r['Calls']},{float(r['AverageNs']) / 1e3:.2f},{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f},{r['Percentage']}")
 for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
