@@ -125,8 +125,9 @@ def _pad_cols(t: torch.Tensor, cols: int) -> torch.Tensor:
 class _PosMlpHipFn(torch.autograd.Function):
     """The coordinate MLP on the hand-written exact-f32 MFMA kernels of libmatpbr.so (csrc/posmlp_kernels.hip): one launch per sine
     layer forward (`sin`/`cos` in the GEMM epilogue; the pre-activation is never stored), one per layer for dL/d input (the `* cos`
-    and the bias-gradient column sums in the epilogue) and one slab-split launch per weight gradient.  The zero-initialised
-    output layer ([M,256] x [256,5]) stays a BLAS call; its backward into the last sine layer goes through the fused kernel.
+    and the bias-gradient column sums in the epilogue) and one slab-split launch per weight gradient.  The skinny ends (the
+    zero-initialised output layer [M,256] x [256,5], its weight gradient and the first layer's) run on the streaming kernels of the
+    same library when the hidden layers are 256 wide; other widths fall back to BLAS calls for those three.
     Same buffer trick as `_PosMlpFn` for the skip layers: the producer writes the first columns of a 256-wide buffer whose tail
     holds x0.  The input x0 gets no gradient here (it is the constant `start_arm` of the optimisation loop)."""
 
@@ -184,6 +185,11 @@ class _PosMlpHipFn(torch.autograd.Function):
             out = torch.empty((M, _ceil4(n_last)), dtype=torch.float32, device=x0.device)   # row stride: a multiple of 4 floats
             ops.mlp_layer_fwd(inp, _pad_cols(weights[L - 1], _ceil4(K)), biases[L - 1], out, None, K)
             out = out[:, :n_last]
+        elif weights[L - 1].shape[0] in (3, 5, 8) and K % 4 == 0 and inp.stride(0) % 4 == 0:
+            n_last = weights[L - 1].shape[0]                  # one streaming pass of libmatpbr.so (no BLAS call in the iteration)
+            out = torch.empty((M, 8), dtype=torch.float32, device=x0.device)
+            ops.mlp_skinny_fwd(inp, _pad_cols(weights[L - 1], _ceil4(K)), biases[L - 1].contiguous(), out, K)
+            out = out[:, :n_last]
         else:
             out = torch.addmm(biases[L - 1], inp, weights[L - 1].t())
         ctx.save_for_backward(x0, *weights, *inps, *coss)
@@ -202,10 +208,20 @@ class _PosMlpHipFn(torch.autograd.Function):
         grads = [None] * (2 * L)
         g = grad_out.contiguous()
         n_out = g.shape[1]
-        grads[2 * (L - 1) + 1] = _column_sum(g)
-        g, n_red = _pad_cols(g, _ceil4(n_out)), n_out
-        grads[2 * (L - 1)] = (ops.mlp_layer_bwd_weight(g, inps[L - 1], n_out, weights[L - 1].shape[1]) if ctx.small
-                              else _split_k_tn(g[:, :n_out], inps[L - 1]))
+        k_last = weights[L - 1].shape[1]
+        skinny = (not ctx.small) and n_out <= 8 and inps[L - 1].stride(0) >= 256 and k_last <= 256       # the 256-wide operand of the skinny kernels
+        if skinny:
+            g = _pad_cols(g, 8)
+            d_w = torch.empty((n_out, k_last), dtype=torch.float32, device=g.device)
+            d_b = torch.empty(8, dtype=torch.float32, device=g.device)
+            ops.mlp_skinny_bwd_weight(g, inps[L - 1], d_w, n_out, k_last, d_bias=d_b)
+            grads[2 * (L - 1)], grads[2 * (L - 1) + 1] = d_w, d_b[:n_out]
+            n_red = n_out
+        else:
+            grads[2 * (L - 1) + 1] = _column_sum(g)
+            g, n_red = _pad_cols(g, _ceil4(n_out)), n_out
+            grads[2 * (L - 1)] = (ops.mlp_layer_bwd_weight(g, inps[L - 1], n_out, k_last) if ctx.small
+                                  else _split_k_tn(g[:, :n_out], inps[L - 1]))
         for l in range(L - 1, 0, -1):                  # g = dL/d pre of layer l  ->  dL/d pre of layer l-1, its bias gradient
             n_prev = weights[l - 1].shape[0]
             wt = _pad_cols(weights[l][:, :n_prev].t(), 256 if n_red > 224 else _ceil4(n_red))   # 256-wide rows: the fast kernels' precondition
@@ -228,7 +244,13 @@ class _PosMlpHipFn(torch.autograd.Function):
         if ctx.small:
             grads[0] = ops.mlp_layer_bwd_weight(g, inps[0], n_red, x0.shape[1])
         else:
-            grads[0] = _split_k_tn(g[:, :n_red], x0)    # K = 15: a BLAS product
+            d0 = x0.shape[1]
+            if d0 <= 16 and g.stride(0) >= 256:           # K = 15: the skinny kernel (x0 by scalar loads, one pass over g)
+                d_w0 = torch.zeros((n_red, _ceil4(d0)), dtype=torch.float32, device=g.device)
+                ops.mlp_skinny_bwd_weight(_pad_cols(x0, 8 if d0 <= 8 else 16), g, d_w0, d0, n_red, transposed_out=True)
+                grads[0] = d_w0[:, :d0]
+            else:
+                grads[0] = _split_k_tn(g[:, :n_red], x0)
         return (None, None, *grads)
 
 
