@@ -44,6 +44,9 @@ def parse(argv=None):
     ap.add_argument("--mode", choices=["fused", "torch", "pos_mlp"], default=None,
                     help="default: pos_mlp (the reference's default mode: maps from the residual PosMLP) for one image per GPU, fused "
                          "(--model_name none, whole iteration in libmatpbr.so) for a batch; torch: the none-mode step composed from torch ops")
+    ap.add_argument("--mlp-products", type=int, choices=[0, 6, 9], default=None,
+                    help="partial products per f32 product of the 256-wide PosMLP layers: 6 (default) / 9 = split-operand kernels on the bf16 "
+                         "matrix pipe (f32-accurate: three bf16 pieces per operand, f32 accumulate), 0 = the exact-f32 MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-relight", action="store_true", help="skip the 2048x2048 relighting measurement (1.3 GB transfer buffer)")
     ap.add_argument("--no-extras", action="store_true", help="headline mode only (no other loops, no kernel roofline legs)")
@@ -184,6 +187,10 @@ def main(argv=None):
     from materialist_amd import loop, ops, render, synthetic
     from materialist_amd.dist import shard_range
 
+    from materialist_amd import posmlp as _posmlp
+
+    if args.mlp_products is not None:
+        _posmlp._PosMlpHipFn.PRODUCTS = args.mlp_products
     H = W = args.size
     proto = _Protocol(dist, world, dev, torch.cuda.synchronize)
     mode = args.mode or ("pos_mlp" if args.images_per_gpu == 1 else "fused")
@@ -254,6 +261,15 @@ def main(argv=None):
                 continue
             e_el, _ = proto.timed(wl.phase(extra).step, 10, steps)
             modes[extra] = {"it_per_s": steps * B * world / e_el, "ms_per_step": e_el / steps * 1e3, "images_per_gpu": B}
+        if mode == "pos_mlp" and _posmlp._PosMlpHipFn.PRODUCTS:
+            # the same loop with the 256-wide layers on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), for the record
+            keep = _posmlp._PosMlpHipFn.PRODUCTS
+            _posmlp._PosMlpHipFn.PRODUCTS = 0
+            try:
+                e_el, _ = proto.timed(wl.phase("pos_mlp").step, 10, 100)
+            finally:
+                _posmlp._PosMlpHipFn.PRODUCTS = keep
+            modes["pos_mlp_exact_f32"] = {"it_per_s": 100 * B * world / e_el, "ms_per_step": e_el / 100 * 1e3, "images_per_gpu": B}
         if B != 8 and H * W <= 512 * 512:
             wl8 = Workload(8)                 # BASELINE configs[2]: 64 images, 8 per GPU; this is one GPU's shard (every rank runs its own)
             e_el, _ = proto.timed(wl8.phase("fused").step, 10, 300)
@@ -261,6 +277,8 @@ def main(argv=None):
     mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so: render+jac, loss statistics, streaming backward+Adam)",
                   "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
                   "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
+                  "pos_mlp_exact_f32": "the pos_mlp loop with --mlp-products 0: 256-wide layers on the exact-f32 MFMA kernels, autograd composition "
+                                       "(loop.PosMlpBrdfPhase); the default differs from it only in how the f32 products are formed (same error vs fp64)",
                   "env": "hot loop A: envmap PosMLP (small-tile MFMA layers) + softplus / SH projection + one pass over the radiance transfer + "
                          "backward + Adam, 27 launches of libmatpbr.so replayed from a hipGraph",
                   "torch": "hot loop B composed from torch ops"}
@@ -435,7 +453,13 @@ def main(argv=None):
             "config": {"workload": f"C2-synthetic (BASELINE configs[1]): {H}x{W}, one epoch of hot loop B, part 'rm' of --opt_order 'rm a', "
                                    f"{'--model_name pos_mlp' if mode == 'pos_mlp' else '--model_name none'} "
                                    f"(maps -> render -> gamma-2.2 MSE/L1 loss -> backward -> Adam(W)), spp={args.spp}, geometric normals, SH25 light",
-                       "mode": mode, "mode_requested": args.mode, "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25"},
+                       "mode": mode, "mode_requested": args.mode, "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25",
+                       "mlp_products": int(_posmlp._PosMlpHipFn.PRODUCTS),
+                       "mlp_arithmetic": ("f32 results: each f32 operand of the 256-wide layers is the exact sum of three bf16 pieces; 6 of the 9 partial "
+                                          "products (the dropped ones are below 2^-24 relative) on v_mfma_f32_32x32x16_bf16 with f32 accumulation; error "
+                                          "against an fp64 product equals that of the exact-f32 MFMA kernels (tests/test_gpu_parity.py::"
+                                          "test_split_operand_sine_layers_match_fp64_and_the_f32_kernels); --mlp-products 0 runs the exact-f32 kernels"
+                                          if _posmlp._PosMlpHipFn.PRODUCTS else "exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32)")},
             "ranks": [{"rank": r, "it_per_s": args.steps * B / t} for r, t in enumerate(per_rank)],
             "modes": modes,
             "psnr_db": {"initial_guess": psnr0, "after_timed_steps": psnr1, "vs": "own HIP render of the synthetic ground truth (Mitsuba cannot run, SURVEY F3)"},
