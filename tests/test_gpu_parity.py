@@ -859,6 +859,62 @@ def test_arm_mlp_phase_network_gradients_match_autograd():
         assert (gb[:rb.shape[0]] - rb).norm().item() <= 2e-5 * rb.norm().item(), l
 
 
+def test_arm_mlp_phase_schedule_snapshot_and_early_stopping():
+    """The host-visible behaviour of ArmMlpPhase around the kernels: StepLR(100, 0.8) stepped only while lr > 1.5e-4
+    (inverse_img_w_mi.py:471,553-554) against torch's scheduler, SaveBest's weight snapshot = the weights that PRODUCED the best
+    render (:546-547; taken before the optimiser step), `load_state_dict` of that snapshot into the live module, and the host
+    EarlyStopping of `step_and_check` (:550)."""
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+    from materialist_amd.armhead import ArmMlpPhase
+
+    dev = _cuda()
+    H = W = 96
+    sc = synthetic.make_scene(2, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, 8).clone()
+    a0, r0, m0 = _t(sc.init_albedo, dev), _t(sc.init_roughness, dev), _t(sc.init_metallic, dev)
+    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).clamp(0, 1)
+    torch.manual_seed(1)
+    net = posmlp.brdf_net("arm").to(dev)
+    ph = ArmMlpPhase(scene, gt, net, start_arm, {"albedo": a0, "roughness": r0, "metallic": m0}, optimize_part="rm", spp=8, patience=0)
+    # the learning-rate trajectory against torch's StepLR driven by the reference's rule
+    probe = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([probe], lr=3e-4)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=100, gamma=0.8)
+    first_mse, flat_before_best, best_seen = None, None, float("inf")
+    for it in range(520):
+        flat_now = ph.flat.clone() if it < 40 else None
+        ph.step()
+        opt.step()
+        if opt.param_groups[0]["lr"] > 1.5e-4:
+            sched.step()
+        assert ph.opt.param_groups[0]["lr"] == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12), it
+        if it % 100 == 99 or it < 3:
+            assert float(ph.hyper[0]) == pytest.approx(opt.param_groups[0]["lr"], rel=1e-6), it
+        if it < 40:                                        # snapshot semantics on the first iterations (one host sync each)
+            mse = float(ph.stats[0, ops.STAT_MSE])
+            first_mse = mse if first_mse is None else first_mse
+            if mse < best_seen:
+                best_seen, flat_before_best = mse, flat_now
+            assert torch.equal(ph._best_flat, flat_before_best), it
+    assert opt.param_groups[0]["lr"] == pytest.approx(3e-4 * 0.8 ** 4)       # 1.2288e-4: the schedule has stopped
+    assert float(ph.hyper[1]) == 520.0
+    assert float(ph.stats[0, ops.STAT_BEST]) < first_mse
+    bw = ph.best_weights
+    net.load_state_dict(bw)                                # what optimize_envmap_ARMN does after every part (:586-587)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, bw[k]), k
+    assert torch.equal(ph.flat, ph._best_flat)             # the parameters are still views of the flat buffer
+    # host EarlyStopping: with a huge min_delta nothing counts as an improvement after the first iteration
+    ph2 = loop.pos_mlp_brdf_phase(scene, gt, net, start_arm, {"albedo": a0, "roughness": r0, "metallic": m0}, optimize_part="rm", spp=8,
+                                  patience=3, min_delta=1.0)
+    assert isinstance(ph2, ArmMlpPhase)
+    stops = [ph2.step_and_check() for _ in range(4)]
+    assert stops == [False, False, False, True]
+
+
 def test_skinny_layers_and_arm_head_match_torch():
     """The skinny ends of the network at image size: output layer (J = 3, 5, 8) against an fp64 product, the 'arm' head against
     torch's (tanh, residual, clamp, 0.93 r + 0.07) bit for bit on the same pre-activations, its backward against autograd, the two
