@@ -264,6 +264,10 @@ int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int 
  *                                the first layer's, stored transposed (ld_j = 1, ld_c = row stride of d_w).
  *   matpbr_adamw_step_dev        matpbr_adam_step_dev with torch.optim.AdamW's decoupled weight decay (:470) */
 int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wsplit, void* stream);
+/* up to 8 splits in one launch (host arrays of n_jobs entries; transposed[j] != 0 selects the _t variant for job j): the weights of
+ * every layer change together, once per optimiser step */
+int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const int* N, const int* K, const int* transposed,
+                                   void* const* wsplit, int n_jobs, void* stream);
 int matpbr_mlp_skinny_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, long M, int J, int K,
                           void* stream);
 int matpbr_mlp_arm_head_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* start, int lds, float* th,
@@ -274,6 +278,10 @@ int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ld
                                  void* workspace, size_t workspace_bytes, long M, int J, int C, void* stream);
 int matpbr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
                           float weight_decay, void* stream);
+/* the same with SaveBest's weight snapshot in the same pass: best[i] = p[i] (the weights that produced this iteration's render)
+ * when stats[8] (improved) is set, before p is updated; best / stats nullable together */
+int matpbr_adamw_step_snapshot_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2,
+                                   float eps, float weight_decay, float* best, const float* stats, void* stream);
 
 /* Forward-only relighting (render_final.py:148-203 `render_w_mi`, :290-418 `rotate_envmap` / `render_rolling_envmap`).
  * The render is linear in the light, R = sum_k light[k] * T[k]:

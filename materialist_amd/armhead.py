@@ -7,7 +7,7 @@
 
 At 512 x 512 the network is eleven products over 262144 points.  Composed from framework ops (autograd node, three BLAS calls for
 the skinny ends, the head as elementwise kernels, a foreach AdamW) the iteration carried ~0.4 ms of glue around the sine layers;
-here every launch of the iteration is a kernel of libmatpbr.so: the first layer on the f32 MFMA kernel, the 256-wide layers on
+here every launch of the iteration is a kernel of libmatpbr.so: one launch that cuts all weights into their bf16 pieces, the first layer on the f32 MFMA kernel, the 256-wide layers on
 the split-operand bf16 MFMA kernels (forward with sin/cos epilogue, input gradient with cos and bias-gradient epilogue, weight
 gradient), the output layer with the tanh head, the head's backward, the two skinny weight gradients, one AdamW launch over a
 flat parameter buffer whose step count and learning rate live in device memory, and one select for the SaveBest snapshot of the
@@ -134,8 +134,23 @@ class ArmMlpPhase:
         self.gbufs = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(2)]
         self.th, self.d_x = E(M, 8), E(M, 8)
         self.w_out_t = E(256, 8)                                 # the output weight transposed (operand of the input-gradient kernel)
+        # split-operand images of the 256-wide layers' weights, forward and (transposed) backward operand: written by ONE launch
+        # at the start of every iteration (the weights change once per optimiser step)
         nbytes = int(_lib.load().matpbr_mlp_wsplit_bytes(256))
-        self.wsplit = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.wsplit_f = {l: torch.empty(nbytes, dtype=torch.uint8, device=dev) for l in range(1, self.L - 1)}
+        self.wsplit_b = {l: torch.empty(nbytes, dtype=torch.uint8, device=dev) for l in range(1, self.L - 1)}
+        jobs = []
+        for l in range(1, self.L - 1):
+            wp, _ = self.views[l]
+            jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l], 256, 0, self.wsplit_f[l].data_ptr()))              # W_l [n_l, 256]
+            jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l - 1], self.ns[l], 1, self.wsplit_b[l].data_ptr()))    # (W_l[:, :n_{l-1}])^T
+        if len(jobs) > 8:
+            raise NotImplementedError("ArmMlpPhase: at most four 256-wide layers after the first")
+        import ctypes as _ct
+
+        nj = len(jobs)
+        self._split_args = ((_ct.c_void_p * nj)(*[j[0] for j in jobs]), (_ct.c_int * nj)(*[j[1] for j in jobs]), (_ct.c_int * nj)(*[j[2] for j in jobs]),
+                            (_ct.c_int * nj)(*[j[3] for j in jobs]), (_ct.c_int * nj)(*[j[4] for j in jobs]), (_ct.c_void_p * nj)(*[j[5] for j in jobs]), nj)
         self.maps = {"albedo": E(H, W, 3), "roughness": E(H, W, 1), "metallic": E(H, W, 1)}
         keys = {"a": "albedo", "r": "roughness", "m": "metallic"}
         self.live = [keys[c] for c in self.part if c in keys]
@@ -165,12 +180,13 @@ class ArmMlpPhase:
     def forward(self) -> Dict[str, torch.Tensor]:
         """brdf_net(start_arm) and the maps of :493-504 (maps that the part does not optimise keep their fixed values)."""
         o, P = ops, self.products
+        with torch.cuda.device(self.dev):
+            _lib.check(_lib.load().matpbr_mlp_split_weights_multi(*self._split_args, o._stream(self.flat)), "matpbr_mlp_split_weights_multi")
         wp, bp = self.views[0]
         o.mlp_layer_fwd(self.x0p, wp, bp, self.bufs[0], self.cbufs[0], self.d0)
         for l in range(1, self.L - 1):
             wp, bp = self.views[l]
-            o.mlp_split_weights(wp, self.ns[l], 256, out=self.wsplit)
-            o.mlp_layer_fwd_bx(self.bufs[l - 1], self.wsplit, bp, self.bufs[l], self.cbufs[l], self.ns[l], 256, P)
+            o.mlp_layer_fwd_bx(self.bufs[l - 1], self.wsplit_f[l], bp, self.bufs[l], self.cbufs[l], self.ns[l], 256, P)
         wp, bp = self.views[-1]
         live = self.live
         o.mlp_arm_head_fwd(self.bufs[-1], wp, bp, self.start_arm, self.th, self.maps["albedo"] if "albedo" in live else None,
@@ -197,8 +213,7 @@ class ArmMlpPhase:
             n_prev = self.ns[l - 1]
             g_prev = self.gbufs[0] if g is self.gbufs[1] else self.gbufs[1]
             _, gb = self.gviews[l - 1]
-            o.mlp_split_weights(wp, n_prev, n_red, out=self.wsplit, transposed=True)
-            o.mlp_layer_bwd_input_bx(g, self.wsplit, self.cbufs[l - 1], g_prev, n_prev, n_red, gb, P)
+            o.mlp_layer_bwd_input_bx(g, self.wsplit_b[l], self.cbufs[l - 1], g_prev, n_prev, n_red, gb, P)
             g, n_red = g_prev, n_prev
         gw, _ = self.gviews[0]
         o.mlp_skinny_bwd_weight(self.x0p, g, gw, self.d0, n_red, transposed_out=True)
@@ -215,13 +230,14 @@ class ArmMlpPhase:
                             self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
                             self.best["metallic"], self.best_img, optimize_part=self.part)
         self.backward()
-        lib = _lib.load()
-        with torch.cuda.device(self.dev):                        # SaveBest keeps the weights that produced the best render (:546-547)
-            _lib.check(lib.matpbr_select_improved(ops._ptr(self._best_flat), ops._ptr(self.flat), ops._ptr(self.stats), 0, self.flat.numel(),
-                                                  ops._stream(self.flat)), "matpbr_select_improved")
         if self.t < self.hist.shape[0]:
             self.hist[self.t].copy_(self.stats[:, o.STAT_MSE])
-        o.adamw_step_dev(self.flat, self.gflat, self.adam_m, self.adam_v, self.hyper, self.weight_decay)
+        lib = _lib.load()
+        with torch.cuda.device(self.dev):       # AdamW; SaveBest keeps the weights that produced the best render (:546-547) in the same pass
+            _lib.check(lib.matpbr_adamw_step_snapshot_dev(o._ptr(self.flat), o._ptr(self.gflat), o._ptr(self.adam_m), o._ptr(self.adam_v),
+                                                          self.flat.numel(), o._ptr(self.hyper), 0.9, 0.999, 1e-8, self.weight_decay,
+                                                          o._ptr(self._best_flat), o._ptr(self.stats), o._stream(self.flat)),
+                       "matpbr_adamw_step_snapshot_dev")
         if self._lr > 1.5e-4:                                     # StepLR(100, 0.8) stepped only while lr > 1.5e-4 (:471,553-554)
             self._sched_epoch += 1
             if self._sched_epoch % 100 == 0:

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(kBlock) void select_copy_kernel(float* __restrict__
 // sit inside a captured hipGraph.  adam_dev_tick_kernel advances the count after the update.
 __global__ __launch_bounds__(kBlock) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, long n, const float* __restrict__ hyper, float b1, float b2,
-                                                          float eps, float wd) {
+                                                          float eps, float wd, float* __restrict__ best, const float* __restrict__ stats) {
+    const bool snap = best != nullptr && stats[kStImproved] > 0.5f;   // SaveBest keeps the weights that produced this iteration's render
     const float t = hyper[1] + 1.0f, lr = hyper[0];
     const float keep = 1.0f - lr * wd;        // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) before the Adam update
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
@@ -340,7 +341,9 @@ __global__ __launch_bounds__(kBlock) void adam_dev_kernel(float* __restrict__ p,
         float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
         float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
         m[i] = mi; v[i] = vi;
-        p[i] = p[i] * keep - lr_over_bc1 * mi / fmaf(fsqrt(vi), inv_sqrt_bc2, eps);
+        const float pi = p[i];
+        if (snap) best[i] = pi;
+        p[i] = pi * keep - lr_over_bc1 * mi / fmaf(fsqrt(vi), inv_sqrt_bc2, eps);
     }
 }
 __global__ void adam_dev_tick_kernel(float* __restrict__ hyper) { hyper[1] += 1.0f; }
@@ -983,14 +986,19 @@ int matpbr_select_improved(float* dst, const float* src, const float* stats, int
     return launch_status();
 }
 
-int matpbr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
-                          float weight_decay, void* stream) {
-    if (!p || !g || !m || !v || !hyper || n <= 0 || weight_decay < 0.0f) return MATPBR_ERR_INVALID_ARG;
+int matpbr_adamw_step_snapshot_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
+                                   float weight_decay, float* best, const float* stats, void* stream) {
+    if (!p || !g || !m || !v || !hyper || n <= 0 || weight_decay < 0.0f || ((best == nullptr) != (stats == nullptr))) return MATPBR_ERR_INVALID_ARG;
     unsigned blocks = (unsigned)std::min<long>((n + kBlock - 1) / kBlock, 2048);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, (const float*)hyper, beta1, beta2, eps,
-                       weight_decay);
+                       weight_decay, best, stats);
     hipLaunchKernelGGL(adam_dev_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper);
     return launch_status();
+}
+
+int matpbr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
+                          float weight_decay, void* stream) {
+    return matpbr_adamw_step_snapshot_dev(p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay, nullptr, nullptr, stream);
 }
 
 int matpbr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps, void* stream) {

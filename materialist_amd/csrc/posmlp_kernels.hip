@@ -1088,6 +1088,35 @@ __global__ __launch_bounds__(256) void mlp_split_weights_kernel(const float* __r
   for (int piece = 0; piece < 3; ++piece) out[wsplit_index(ks, s, piece, n, g)] = make_uint4(p[piece][0], p[piece][1], p[piece][2], p[piece][3]);
 }
 
+// Several operands in one launch (the weights of every layer change together, once per optimiser step): blockIdx.y = job
+struct SplitJobs {
+  const float* w[8];
+  uint4* out[8];
+  int ldw[8], N[8], K[8], transposed[8];
+};
+__global__ __launch_bounds__(256) void mlp_split_weights_multi_kernel(const SplitJobs jobs) {
+  const int j = blockIdx.y;
+  const float* __restrict__ B = jobs.w[j];
+  uint4* __restrict__ out = jobs.out[j];
+  const int ldb = jobs.ldw[j], N = jobs.N[j], K = jobs.K[j];
+  const bool tr = jobs.transposed[j] != 0;
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // over (ks, s, n, g)
+  const int nks = (K + 31) / 32;
+  if (idx >= nks * 2 * 256 * 2) return;
+  const int g = idx & 1, n = (idx >> 1) & 255, s = (idx >> 9) & 1, ks = idx >> 10;
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = 32 * ks + 16 * g + 8 * s + q;
+    v[q] = (n < N && k < K) ? (tr ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k]) : 0.f;
+  }
+  unsigned p[3][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split3(v[2 * q], v[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+  for (int piece = 0; piece < 3; ++piece) out[wsplit_index(ks, s, piece, n, g)] = make_uint4(p[piece][0], p[piece][1], p[piece][2], p[piece][3]);
+}
+
 // Eight waves per workgroup (4 row groups of 32 x 2 column halves of 128; 128 x 256 outputs per workgroup, one workgroup per
 // CU): two waves per SIMD, so that one wave's operand split / LDS traffic / epilogue runs under the other's products.
 constexpr int kBxThreads = 512;
@@ -1769,6 +1798,21 @@ int matpbr_mlp_split_weights(const float* w, int ldw, int N, int K, void* wsplit
   if (!w || !wsplit || N <= 0 || N > 256 || K <= 0 || K > 256 || ldw < K) return MATPBR_ERR_INVALID_ARG;
   const int n = ((K + 31) / 32) * 2 * 256 * 2;
   hipLaunchKernelGGL(mlp_split_weights_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, (uint4*)wsplit);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const int* N, const int* K, const int* transposed, void* const* wsplit,
+                                   int n_jobs, void* stream) {
+  if (!w || !ldw || !N || !K || !transposed || !wsplit || n_jobs <= 0 || n_jobs > 8) return MATPBR_ERR_INVALID_ARG;
+  SplitJobs jobs{};
+  int kmax = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    if (!w[j] || !wsplit[j] || N[j] <= 0 || N[j] > 256 || K[j] <= 0 || K[j] > 256 || ldw[j] < (transposed[j] ? N[j] : K[j])) return MATPBR_ERR_INVALID_ARG;
+    jobs.w[j] = w[j]; jobs.out[j] = (uint4*)wsplit[j]; jobs.ldw[j] = ldw[j]; jobs.N[j] = N[j]; jobs.K[j] = K[j]; jobs.transposed[j] = transposed[j];
+    kmax = K[j] > kmax ? K[j] : kmax;
+  }
+  const int n = ((kmax + 31) / 32) * 2 * 256 * 2;
+  hipLaunchKernelGGL(mlp_split_weights_multi_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
