@@ -218,6 +218,8 @@ def main(argv=None):
         def phase(self, mode):
             if mode == "fused":
                 return loop.FusedBrdfPhase(self.scene, self.gt_image, *self.init, optimize_part="rm", spp=args.spp)
+            if mode == "fused_a":                           # the second part of --opt_order 'rm a': roughness fixed, specular sums reused
+                return loop.FusedBrdfPhase(self.scene, self.gt_image, *self.init, optimize_part="a", spp=args.spp)
             if mode == "pos_mlp":
                 from materialist_amd import posmlp
 
@@ -256,8 +258,8 @@ def main(argv=None):
     modes = {mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3, "images_per_gpu": B}}
     wl8 = None
     if not args.no_extras and mode != "torch":
-        for extra, steps in (("fused", 2000), ("pos_mlp", 100), ("env", 500)):
-            if extra == mode or (extra != "fused" and B > 1):
+        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("pos_mlp", 100), ("env", 500)):
+            if extra == mode or (not extra.startswith("fused") and B > 1):
                 continue
             e_el, _ = proto.timed(wl.phase(extra).step, 10, steps)
             modes[extra] = {"it_per_s": steps * B * world / e_el, "ms_per_step": e_el / steps * 1e3, "images_per_gpu": B}
@@ -274,8 +276,13 @@ def main(argv=None):
             wl8 = Workload(8)                 # BASELINE configs[2]: 64 images, 8 per GPU; this is one GPU's shard (every rank runs its own)
             e_el, _ = proto.timed(wl8.phase("fused").step, 10, 300)
             modes["fused_b8"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
+            e_el, _ = proto.timed(wl8.phase("fused_a").step, 10, 300)
+            modes["fused_b8_a"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
     mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so: render+jac, loss statistics, streaming backward+Adam)",
                   "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
+                  "fused_a": "the same loop in part 'a' of --opt_order 'rm a' (roughness fixed): after the part's first render the specular sums of "
+                             "every pixel are reused (bit-identical to walking the samples), so the forward is a streaming kernel too",
+                  "fused_b8_a": "part 'a' on the 8-image shard (image-iterations/s)",
                   "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
                   "pos_mlp_exact_f32": "the pos_mlp loop with --mlp-products 0: 256-wide layers on the exact-f32 MFMA kernels, autograd composition "
                                        "(loop.PosMlpBrdfPhase); the default differs from it only in how the f32 products are formed (same error vs fp64)",

@@ -154,6 +154,10 @@ typedef struct MatpbrBrdfPhase {
     int es_patience;                      /* 200 // loop_num (:361); <= 0 disables early stopping */
     float es_min_delta;                   /* 0.005 if 'a' in part else 0.001 (:360-363) */
     int hist_len;
+    float* s1cache;                       /* nullable, 3 planes (a third of matpbr_plane9_bytes()): when part_mask has no MATPBR_PART_R the
+                                             roughness, normals and light are constants of the part (:317-342): the step with t == 1 walks
+                                             the samples and keeps the specular sums here and in `jac`; later steps combine them
+                                             (bit-identical render, no samples).  The caller must not touch pr / jac / s1cache in between. */
 } MatpbrBrdfPhase;
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);

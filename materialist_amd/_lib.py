@@ -23,7 +23,7 @@ class MatpbrBrdfPhase(ctypes.Structure):
                 [(k, ctypes.c_void_p) for k in ("best_a", "best_r", "best_m", "best_img", "stats", "history", "workspace")] +
                 [("workspace_bytes", ctypes.c_size_t), ("H", ctypes.c_int), ("W", ctypes.c_int), ("batch", ctypes.c_int), ("spp", ctypes.c_int),
                  ("fov_x_deg", ctypes.c_float), ("scale_delta", ctypes.c_float), ("part_mask", ctypes.c_uint32), ("es_patience", ctypes.c_int),
-                 ("es_min_delta", ctypes.c_float), ("hist_len", ctypes.c_int)])
+                 ("es_min_delta", ctypes.c_float), ("hist_len", ctypes.c_int), ("s1cache", ctypes.c_void_p)])
 
 
 class MatpbrError(RuntimeError):

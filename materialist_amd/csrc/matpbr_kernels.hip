@@ -862,7 +862,14 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     ShadeArgs sa{};
     sa.a = q.pa; sa.r = q.pr; sa.m = q.pm; sa.n = q.n; sa.dcache = q.dcache; sa.out = q.pred; sa.jac = q.jac;
     sa.stats = q.stats; sa.block_sums = fwd_sums; sa.clamp = 1;
-    hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, sa, q.light, g, tab);
+    // a part that leaves the roughness alone: the specular sums of every pixel are constants of the part; its first iteration
+    // (t == 1) walks the samples and keeps them (jac planes + s1cache), the others combine them (bit-identical, no samples)
+    const bool r_fixed = !(q.part_mask & MATPBR_PART_R) && q.s1cache != nullptr;
+    sa.s1 = r_fixed ? q.s1cache : nullptr;
+    if (r_fixed && t > 1)
+        hipLaunchKernelGGL(shade_cached_kernel, grid, dim3(kBlock), 0, st, sa, g);
+    else
+        hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, sa, q.light, g, tab);
     // 2. loss statistics, SaveBest / EarlyStopping decisions (:388-418, misc.py:37-97)
     hipLaunchKernelGGL(loss_sums2_kernel<1>, dim3(kRedBlocks, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                        (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,

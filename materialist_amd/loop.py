@@ -295,6 +295,9 @@ class FusedBrdfPhase:
         ph.fov_x_deg, ph.scale_delta = scene.fov, self.scale_delta
         ph.part_mask = sum(self.PARTS[ch] for ch in optimize_part)
         ph.es_patience, ph.es_min_delta, ph.hist_len = int(patience), float(min_delta), int(history_len)
+        # parts that leave the roughness alone: the specular sums of every pixel are constants of the part (kept from its first render)
+        self.s1cache = None if "r" in optimize_part else torch.empty((3,) + tuple(self.jac.shape[1:]), dtype=torch.float32, device=self.jac.device)
+        ph.s1cache = P(self.s1cache) if self.s1cache is not None else None
         self._ph, self._lib = ph, lib
 
     def lr_at(self, t0: int) -> float:
