@@ -325,6 +325,10 @@ def main(argv=None):
                  "fwd_op": back_to_back(lambda: ops.shade_fwd(*mm, nrm, lgt, args.spp, out=pred), 20),
                  "bwd_op": back_to_back(lambda: ops.shade_bwd(*mm, nrm, lgt, d_probe, args.spp, want_mat=True), 20),
                  "diffuse_cache": back_to_back(lambda: ops.diffuse_cache(nrm, lgt, args.spp, out=dcache), 20)}
+            s1 = torch.empty((3,) + tuple(jac.shape[1:]), dtype=torch.float32, device=dev)
+            ops.shade_fwd(*mm, nrm, lgt, args.spp, clamp_params=True, out=pred, dcache=dcache, jac=jac, s1=s1)
+            t["fwd_cached"] = back_to_back(lambda: ops.shade_fwd_cached(mm[0], mm[2], jac, s1, clamp_params=True, out=pred))
+            t["bwd_loop_a"] = back_to_back(lambda: ops.brdf_loss_bwd_jac(*mm, jac, pred, gt_srgb, stats, *mm, 0.1, *g, optimize_part="a"))
             return t
 
         def entry(px, t_f, t_b, note):
@@ -357,6 +361,10 @@ def main(argv=None):
                      "traffic": traffic, "traffic_source": tsrc,
                      "operator_face": entry(px, tk["fwd_op"], tk["bwd_op"],
                                             "stand-alone matpbr_shade_fwd / matpbr_shade_bwd<mat>: both lobes sampled in-kernel (18 + 20 directions)"),
+                     "fixed_roughness_parts": entry(px, tk["fwd_cached"], tk["bwd_loop_a"],
+                                                    "the same pair in the parts of --opt_order that leave the roughness alone ('a' of 'rm a', about half of "
+                                                    "the reference schedule's BRDF iterations): shade_cached_kernel combines the specular sums kept from the "
+                                                    "part's first render (bit-identical to walking the samples) + jac_bwd_kernel<fused>; both streaming"),
                      "diffuse_cache_ms": tk["diffuse_cache"]})
         if wr is not wl:
             tk1 = kernel_times(wl)

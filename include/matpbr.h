@@ -91,6 +91,16 @@ int matpbr_shade_fwd_ex(const float* a, const float* r, const float* m, const fl
                         const MatpbrCamera* cam, uint32_t flags, void* stream);
 int matpbr_diffuse_cache(const float* n, const float* light, int light_kind, int n_light, float* dcache, int H, int W, int batch,
                          int spp, const MatpbrCamera* cam, void* stream);
+/* While r, the shading normals and the light stay as they are (the parts of --opt_order without 'r', inverse_img_w_mi.py:317-342,
+ * 497-504), the specular sums of every pixel are constants:
+ *   matpbr_shade_fwd_keep     matpbr_shade_fwd_ex that also writes S1 into `s1` ([3][B*H*W] floats; jac required)
+ *   matpbr_shade_fwd_cached   the render for new a, m from the planes `jac` (0-5) and `s1` of that call: the same fused operations in
+ *                             the same order, bit-identical to walking the samples again; 44 + 36 B/pixel, no samples */
+int matpbr_shade_fwd_keep(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind,
+                          int n_light, const float* dcache, float* out_rgb, float* jac, float* s1, int H, int W, int batch, int spp,
+                          const MatpbrCamera* cam, uint32_t flags, void* stream);
+int matpbr_shade_fwd_cached(const float* a, const float* m, const float* jac, const float* s1, float* out_rgb, int H, int W, int batch,
+                            uint32_t flags, void* stream);
 
 /* Backward render.  Replaces the AD pass that `loss.backward()` drives through dr.wrap_ad / mi.render
  * (inverse_img_w_mi.py:59,69,248,420,544).  Any of d_a/d_r/d_m (all three or none), d_n, d_light may be

@@ -43,6 +43,9 @@ SIGNATURES = {
     "matpbr_plane9_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "matpbr_shade_fwd_ex": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.POINTER(MatpbrCamera), ctypes.c_uint32, ctypes.c_void_p]),
+    "matpbr_shade_fwd_keep": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, _c_f, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.POINTER(MatpbrCamera), ctypes.c_uint32, ctypes.c_void_p]),
+    "matpbr_shade_fwd_cached": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]),
     "matpbr_diffuse_cache": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(MatpbrCamera), ctypes.c_void_p]),
     "matpbr_shade_bwd_jac": (ctypes.c_int, [_c_f] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -169,6 +169,8 @@ class ArmMlpPhase:
         self._light = scene.light.detach().contiguous()
         self.dcache = ops.diffuse_cache(self._n, self._light, self.spp, scene.fov)
         self.jac = ops.plane9(self.gt)
+        # a part that leaves the roughness alone ('a' of --opt_order 'rm a'): the specular sums are constants of the part (:497-504)
+        self.s1 = None if "roughness" in self.live else torch.empty((3, 1, H, W), dtype=torch.float32, device=dev)
         self.t = 0
 
     # ------------------------------------------------------------------------------------------------------------------------------
@@ -221,8 +223,11 @@ class ArmMlpPhase:
     def step(self) -> None:
         o, sc = ops, self.scene
         d = self.forward()
-        o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], self._n, self._light, self.spp, sc.fov, clamp_params=True, out=self.pred,
-                    dcache=self.dcache, jac=self.jac)
+        if self.s1 is not None and self.t > 0:                  # bit-identical to walking the samples again
+            o.shade_fwd_cached(d["albedo"], d["metallic"], self.jac, self.s1, clamp_params=True, out=self.pred)
+        else:
+            o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], self._n, self._light, self.spp, sc.fov, clamp_params=True, out=self.pred,
+                        dcache=self.dcache, jac=self.jac, s1=self.s1)
         o.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
                           self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part)
         o.brdf_loss_bwd_jac(d["albedo"], d["roughness"], d["metallic"], self.jac, self.pred, self.gt_srgb, self.stats,

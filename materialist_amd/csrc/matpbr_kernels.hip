@@ -657,6 +657,35 @@ int matpbr_shade_fwd_ex(const float* a, const float* r, const float* m, const fl
     return launch_status();
 }
 
+int matpbr_shade_fwd_keep(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind, int n_light,
+                          const float* dcache, float* out_rgb, float* jac, float* s1, int H, int W, int batch, int spp, const MatpbrCamera* cam,
+                          uint32_t flags, void* stream) {
+    if (!a || !r || !m || !n || !light || !out_rgb || !jac || !s1 || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+    if (!sh25(light_kind, n_light)) return MATPBR_ERR_INVALID_ARG;
+    if (!valid_spp(spp)) return MATPBR_ERR_UNSUPPORTED;
+    Geom g;
+    RuleTable tab;
+    if (!make_geom(H, W, cam, g)) return MATPBR_ERR_INVALID_ARG;
+    if (!fill_rule_table(spp, tab)) return MATPBR_ERR_UNSUPPORTED;
+    ShadeArgs q{};
+    q.a = a; q.r = r; q.m = m; q.n = n; q.dcache = dcache; q.out = out_rgb; q.jac = jac; q.s1 = s1;
+    q.clamp = (flags & MATPBR_FLAG_CLAMP_PARAMS) ? 1 : 0;
+    hipLaunchKernelGGL(shade_kernel<true>, dim3((unsigned)grid_blocks(H, W), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, q, light, g, tab);
+    return launch_status();
+}
+
+int matpbr_shade_fwd_cached(const float* a, const float* m, const float* jac, const float* s1, float* out_rgb, int H, int W, int batch,
+                            uint32_t flags, void* stream) {
+    if (!a || !m || !jac || !s1 || !out_rgb || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+    Geom g;
+    if (!make_geom(H, W, nullptr, g)) return MATPBR_ERR_INVALID_ARG;
+    ShadeArgs q{};
+    q.a = a; q.m = m; q.out = out_rgb; q.jac = const_cast<float*>(jac); q.s1 = const_cast<float*>(s1);
+    q.clamp = (flags & MATPBR_FLAG_CLAMP_PARAMS) ? 1 : 0;
+    hipLaunchKernelGGL(shade_cached_kernel, dim3((unsigned)grid_blocks(H, W), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, q, g);
+    return launch_status();
+}
+
 int matpbr_shade_fwd(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind,
                      int n_light, float* out_rgb, int H, int W, int batch, int spp, const MatpbrCamera* cam, uint32_t flags,
                      void* stream) {

@@ -112,10 +112,30 @@ def plane9(a: torch.Tensor) -> torch.Tensor:
     return torch.empty((9, B, H, W), dtype=torch.float32, device=a.device)
 
 
+def shade_fwd_cached(a, m, jac: torch.Tensor, s1: torch.Tensor, clamp_params: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The render for new albedo / metallic maps from the planes a previous `shade_fwd(..., jac=jac, s1=s1)` kept, valid while the
+    roughness, the normals and the light of that call are unchanged: bit-identical to rendering again, no samples."""
+    lib = _lib.load()
+    a = _dev(a, "albedo", (3,))
+    B, H, W = _bhw(a)
+    m = _dev(m, "metallic").reshape(B, H, W, 1)
+    if jac.numel() != 3 * a.numel() or s1.numel() != a.numel() or not (jac.is_contiguous() and s1.is_contiguous()):
+        raise ValueError("shade_fwd_cached: jac / s1 must be the contiguous plane buffers of the kept render")
+    if out is None:
+        out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        code = lib.matpbr_shade_fwd_cached(_ptr(a), _ptr(m), _ptr(jac), _ptr(s1), _ptr(out), H, W, B, FLAG_CLAMP_PARAMS if clamp_params else 0,
+                                           _stream(a))
+    _lib.check(code, "matpbr_shade_fwd_cached")
+    return out
+
+
 def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0, clamp_params: bool = False,
-              out: Optional[torch.Tensor] = None, dcache: Optional[torch.Tensor] = None, jac: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, dcache: Optional[torch.Tensor] = None, jac: Optional[torch.Tensor] = None,
+              s1: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Render.  `dcache` = diffuse_cache(n, light, spp) skips the diffuse-lobe samples (valid while n and light are unchanged);
-    `jac` ([9,B,H,W], filled) lets shade_bwd_jac / brdf_loss_bwd_jac form the material gradients of this pass."""
+    `jac` ([9,B,H,W], filled) lets shade_bwd_jac / brdf_loss_bwd_jac form the material gradients of this pass; `s1` ([3,B,H,W],
+    filled, needs jac) keeps what `shade_fwd_cached` needs besides jac."""
     lib = _lib.load()
     a = _dev(a, "albedo", (3,))
     B, H, W = _bhw(a)
@@ -132,8 +152,15 @@ def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0, clamp_params
         out = torch.empty_like(a)
     cam = MatpbrCamera(float(fov_x_deg))
     with torch.cuda.device(a.device), _timed("shade_fwd"):
-        code = lib.matpbr_shade_fwd_ex(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(dcache), _ptr(out), _ptr(jac),
-                                       H, W, B, check_spp(spp), ctypes.byref(cam), FLAG_CLAMP_PARAMS if clamp_params else 0, _stream(a))
+        if s1 is not None:
+            if jac is None or s1.numel() != a.numel() or not s1.is_contiguous():
+                raise ValueError("shade_fwd: s1 needs jac and must be a contiguous fp32 CUDA tensor of 3*B*H*W floats")
+            code = lib.matpbr_shade_fwd_keep(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(dcache), _ptr(out), _ptr(jac),
+                                             _ptr(s1), H, W, B, check_spp(spp), ctypes.byref(cam), FLAG_CLAMP_PARAMS if clamp_params else 0,
+                                             _stream(a))
+        else:
+            code = lib.matpbr_shade_fwd_ex(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(dcache), _ptr(out), _ptr(jac),
+                                           H, W, B, check_spp(spp), ctypes.byref(cam), FLAG_CLAMP_PARAMS if clamp_params else 0, _stream(a))
     _lib.check(code, "matpbr_shade_fwd_ex")
     return out
 

@@ -471,6 +471,29 @@ def test_fused_phase_with_fixed_roughness_reuses_the_specular_sums_bit_exactly(p
     assert torch.equal(cached.best_img, walked.best_img)
 
 
+def test_cached_forward_is_bit_identical_to_the_render():
+    """matpbr_shade_fwd_keep / matpbr_shade_fwd_cached on the piecewise face: new albedo and metallic maps under the planes kept from
+    a render with the same roughness, normals and light give the render's bits (with and without clamping, a batch of two, an odd
+    pixel count)."""
+    from materialist_amd import ops, synthetic
+
+    dev = _cuda()
+    H, W, spp = 33, 37, 32
+    sc = [synthetic.make_scene(i, H, W) for i in (1, 2)]
+    a, r, m, light = (_t(np.stack([getattr(s, k) for s in sc]), dev) for k in ("albedo", "roughness", "metallic", "light"))
+    n = ops.normals_from_depth(_t(np.stack([s.depth for s in sc]), dev))
+    dcache = ops.diffuse_cache(n, light, spp)
+    jac, s1 = ops.plane9(a), torch.empty(3, 2, H, W, device=dev)
+    for clamp in (False, True):
+        ops.shade_fwd(a, r, m, n, light, spp, clamp_params=clamp, dcache=dcache, jac=jac, s1=s1)
+        torch.manual_seed(int(clamp))
+        a2 = (a + 0.3 * torch.randn_like(a)) if clamp else (a * torch.rand_like(a))
+        m2 = (m + 0.3 * torch.randn_like(m)) if clamp else torch.rand_like(m)
+        full = ops.shade_fwd(a2, r, m2, n, light, spp, clamp_params=clamp, dcache=dcache, jac=ops.plane9(a))
+        fast = ops.shade_fwd_cached(a2, m2, jac, s1, clamp_params=clamp)
+        assert torch.equal(full, fast), clamp
+
+
 def test_adam_step_matches_torch():
     from materialist_amd import ops
 
