@@ -1275,6 +1275,50 @@ def test_split_operand_weight_gradient_ragged_slabs(M):
     assert (dw.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() * max(1.0, (M / 4096) ** 0.5)
 
 
+def test_split_operand_layers_full_size_properties():
+    """BASELINE configs[1] size (512 x 512 = 262144 rows), through size-independent properties: sin^2 + cos^2 = 1 at every output,
+    the x0 tail of a skip layer's buffer survives the forward untouched, the input gradient and the weight gradient are linear in g
+    (within f32 rounding), the bias gradient is the column sum of the input gradient, and a repeated launch gives the same bits."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    torch.manual_seed(9)
+    M, N, K = 512 * 512, 241, 256
+    x = torch.randn(M, 256, device=dev)
+    x[:, 0] = torch.arange(M, device=dev) % 512                       # pixel coordinates: arguments of hundreds of radians
+    w = torch.zeros(N, 256, device=dev)
+    w[:, :K] = (torch.rand(N, K, device=dev) * 2 - 1) / 16
+    w[:, 0] *= 0.05
+    b = torch.randn(N, device=dev) * 0.1
+    tail = torch.randn(M, 256 - N, device=dev)
+    s_out, c_out = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+    s_out[:, N:] = tail
+    ws = ops.mlp_split_weights(w, N, K)
+    ops.mlp_layer_fwd_bx(x, ws, b, s_out, c_out, N, K, 6)
+    assert torch.equal(s_out[:, N:], tail)
+    one = s_out[:, :N] ** 2 + c_out[:, :N] ** 2
+    assert (one - 1).abs().max().item() < 5e-6
+    s2, c2 = torch.empty_like(s_out), torch.empty_like(c_out)
+    ops.mlp_layer_fwd_bx(x, ws, b, s2, c2, N, K, 6)
+    assert torch.equal(s2[:, :N], s_out[:, :N]) and torch.equal(c2[:, :N], c_out[:, :N])
+    # backward operands: g [M, 256] with n_red = 256 columns, n_prev = N
+    g1, g2 = torch.randn(M, 256, device=dev), torch.randn(M, 256, device=dev)
+    wt = (torch.rand(N, 256, device=dev) * 2 - 1) / 16
+    wts = ops.mlp_split_weights(wt, N, 256)
+    outs, dbs, dws = [], [], []
+    for g in (g1, g2, g1 + g2):
+        gp, db = torch.empty(M, 256, device=dev), torch.empty(N, device=dev)
+        ops.mlp_layer_bwd_input_bx(g, wts, c_out, gp, N, 256, db, 6)
+        outs.append(gp[:, :N].clone()); dbs.append(db)
+        dws.append(ops.mlp_layer_bwd_weight_bx(g, x, 256, 256, 6))
+    scale = outs[2].abs().max().item()
+    assert (outs[0] + outs[1] - outs[2]).abs().max().item() < 4e-6 * scale
+    col = outs[2].double().sum(0)
+    assert (dbs[2].double() - col).abs().max().item() < 1e-5 * (col.abs().max().item() + 1.0)
+    assert (dws[0] + dws[1] - dws[2]).abs().max().item() < 2e-5 * dws[2].abs().max().item()
+    assert torch.equal(ops.mlp_layer_bwd_weight_bx(g1, x, 256, 256, 6), dws[0])
+
+
 @pytest.mark.parametrize("products", [0, 6, 9])
 def test_posmlp_autograd_function_at_image_size_for_every_product_mode(products):
     """f2: the whole 8-layer network through `_PosMlpHipFn` at 128 x 128 pixels (above MIN_ROWS, so the split-operand kernels are
