@@ -257,6 +257,14 @@ int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, 
                                   int nprod, void* stream);
 /* as matpbr_mlp_layer_bwd_weight with split operands (nprod 6 or 9): M a multiple of 16, ldg and ldx >= 256 (all 256 columns of
  * both operands are read; those at or beyond N / K may hold anything finite or not and are dropped). */
+/* matpbr_mlp_layer_fwd / _fwd_bx for a skip layer (N < 256 outputs in a 256-wide buffer whose columns N.. hold x0, mymodels/mlps.py
+ * :214-217): `tail` [M, ldt >= 256 - N] = those x0 values.  The layer kernel then stores whole 16-byte words (also over the tail) and
+ * a second small launch rewrites the tail: guarding the one straddling word of every row inside the epilogue costs ~30 us per
+ * layer at 512 x 512, the rewrite ~8.  The cosine buffer's tail is scratch.  tail == NULL: the columns N.. are left untouched. */
+int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo,
+                              const float* tail, int ldt, long M, int N, int K, void* stream);
+int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
+                                 const float* tail, int ldt, long M, int N, int K, int nprod, void* stream);
 int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
                                    size_t workspace_bytes, long M, int N, int K, int nprod, void* stream);
 

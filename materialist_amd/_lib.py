@@ -98,6 +98,10 @@ SIGNATURES = {
     "matpbr_mlp_split_weights_multi": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p]),
     "matpbr_adamw_step_snapshot_dev": (ctypes.c_int, [_c_f] * 4 + [ctypes.c_long, _c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                                   _c_f, _c_f, ctypes.c_void_p]),
+    "matpbr_mlp_layer_fwd_tail": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_long,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_fwd_bx_tail": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_long,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_sincos": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_mul": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_column_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),

@@ -185,10 +185,13 @@ class ArmMlpPhase:
         with torch.cuda.device(self.dev):
             _lib.check(_lib.load().matpbr_mlp_split_weights_multi(*self._split_args, o._stream(self.flat)), "matpbr_mlp_split_weights_multi")
         wp, bp = self.views[0]
+        # skip layers on the split-operand kernel: whole 16-byte stores over the x0 tail, rewritten by a small launch (-20 us per layer
+        # against guarding the straddling word of every row in the epilogue); the first layer's kernel keeps its guard (no gain there)
+        tail = lambda l: self.x0p if self.ns[l] != 256 else None
         o.mlp_layer_fwd(self.x0p, wp, bp, self.bufs[0], self.cbufs[0], self.d0)
         for l in range(1, self.L - 1):
             wp, bp = self.views[l]
-            o.mlp_layer_fwd_bx(self.bufs[l - 1], self.wsplit_f[l], bp, self.bufs[l], self.cbufs[l], self.ns[l], 256, P)
+            o.mlp_layer_fwd_bx(self.bufs[l - 1], self.wsplit_f[l], bp, self.bufs[l], self.cbufs[l], self.ns[l], 256, P, tail=tail(l))
         wp, bp = self.views[-1]
         live = self.live
         o.mlp_arm_head_fwd(self.bufs[-1], wp, bp, self.start_arm, self.th, self.maps["albedo"] if "albedo" in live else None,

@@ -76,6 +76,17 @@ __device__ __forceinline__ void sincos_cw(float x, float& s_out, float& c_out) {
 
 // Columns at or beyond N of the 256-wide outputs are left alone: the buffer of a skip layer keeps x0 there (mymodels/mlps.py
 // :214-217 concatenates it every forward; a caller that owns the buffers writes it once).
+// out[m][N + j] = tail[m][j], j < 256 - N: the x0 columns of a skip layer's buffer, rewritten after a forward that stored whole
+// 16-byte words over them (guarding the one straddling word of every row in the epilogue costs ~30 us per layer, this pass ~8)
+__global__ __launch_bounds__(256) void mlp_tail_copy_kernel(float* __restrict__ out, int ldo, const float* __restrict__ tail, int ldt, long M, int N) {
+  const int w = 256 - N;
+  const long total = M * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / w;
+    const int j = (int)(i - m * w);
+    out[m * ldo + N + j] = tail[m * ldt + j];
+  }
+}
 __device__ __forceinline__ void store4_upto(float* dst, float4 v, int valid, bool all) {   // all: uniform (N == 256), a scalar branch
   if (all) {
     *reinterpret_cast<float4*>(dst) = v;
@@ -100,6 +111,8 @@ struct NtArgs {
   float* colsum;       // [gridDim.x, 256] per-workgroup column sums of out0 (EPI_MULC), may be null
   int M;
   int N, K, lda, ldb, ldo;
+  const float* tail;   // nullable [M, ldt]: the values that belong in columns N.. of out0 (x0 of a skip layer).  Given: the epilogue
+  int ldt;             // stores whole 16-byte words over them and the caller rewrites them (mlp_tail_copy_kernel); null: they are guarded
 };
 
 // LDS image of a k-tile: [row][k] with a pitch of 36 floats: 16-byte writes and 16-byte reads are both conflict-free (8 lanes x
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt(NtArgs p) {
               v.x *= cv4[ni][ps].x; v.y *= cv4[ni][ps].y; v.z *= cv4[ni][ps].z; v.w *= cv4[ni][ps].w;
               cs4[ni].x += v.x; cs4[ni].y += v.y; cs4[ni].z += v.z; cs4[ni].w += v.w;
             }
-            store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (col0 + wn * 64 + ni * 32 + t_col), p.N >= 256);
+            store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (col0 + wn * 64 + ni * 32 + t_col), p.N >= 256 || p.tail != nullptr);
           }
           if (EPI == EPI_SINCOS) {
 #pragma unroll
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt(NtArgs p) {
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
               store4_upto(p.out1 + o0 + (size_t)(8 * ps) * p.ldo, *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col),
-                          p.N - (col0 + wn * 64 + ni * 32 + t_col), p.N >= 256);
+                          p.N - (col0 + wn * 64 + ni * 32 + t_col), p.N >= 256 || p.tail != nullptr);   // the cos tail is scratch
           }
         }
       }
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt_wide(NtArgs p) {
               v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
               csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
             }
-            store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256);
+            store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256 || p.tail != nullptr);
           }
           if (EPI == EPI_SINCOS) {
 #pragma unroll
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_nt_wide(NtArgs p) {
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
               store4_upto(p.out1 + o0 + (size_t)(8 * ps) * p.ldo, *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col),
-                          p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256);
+                          p.N - (wn * 128 + ni * 32 + t_col), p.N >= 256 || p.tail != nullptr);
           }
         }
       }
@@ -1252,7 +1265,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
             v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
             csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
           }
-          store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);   // uniform per wave and column tile
+          store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);
         }
         if (EPI == EPI_SINCOS) {
 #pragma unroll
@@ -1260,7 +1273,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps)
             store4_upto(p.out1 + o0 + (size_t)(8 * ps) * p.ldo, *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col),
-                        p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);   // uniform per wave and column tile
+                        p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);
         }
       }
     }
@@ -1439,7 +1452,7 @@ void launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipS
 template <int EPI, int NPROD>
 void launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
   // the input-gradient buffers have no tail to protect: columns at or beyond N of G' are scratch for every consumer
-  if (p.N >= 256 || EPI == EPI_MULC) launch_nt_bx_full<EPI, NPROD, true>(p, wsplit, grid, stream);
+  if (p.N >= 256 || EPI == EPI_MULC || p.tail != nullptr) launch_nt_bx_full<EPI, NPROD, true>(p, wsplit, grid, stream);
   else launch_nt_bx_full<EPI, NPROD, false>(p, wsplit, grid, stream);
 }
 template <int EPI>
@@ -1490,6 +1503,7 @@ int launch_nt(NtArgs p, long M, hipStream_t stream) {
     q.out0 = p.out0 + (size_t)done * p.ldo;
     if (p.out1) q.out1 = p.out1 + (size_t)done * p.ldo;
     if (p.cmul) q.cmul = p.cmul + (size_t)done * p.ldo;
+    if (p.tail) q.tail = p.tail + (size_t)done * p.ldt;
     if (p.colsum) q.colsum = p.colsum + (size_t)groups * 256;
     q.M = (int)(M - done);
     const unsigned grid = nt_grid(M - done, p.N);
@@ -1747,12 +1761,14 @@ __global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __rest
 
 extern "C" {
 
-int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo, long M,
-                         int N, int K, void* stream) {
+int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo,
+                              const float* tail, int ldt, long M, int N, int K, void* stream) {
   if (!x || !w || !bias || !s_out || M <= 0 || M > 0x7fffff00L || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
   if ((ldx & 3) || (ldw & 3) || ldx < ((K + 3) & ~3) || ldw < ((K + 3) & ~3) || ldo < N || !aligned16(x) || !aligned16(w))
     return MATPBR_ERR_INVALID_ARG;
+  if (tail && (ldo < 256 || ldt < 256 - N || !c_out)) return MATPBR_ERR_INVALID_ARG;   // the tail fills columns N..255 of a 256-wide sine layer
   NtArgs p{x, w, bias, nullptr, s_out, c_out, nullptr, 0, N, K, ldx, ldw, ldo};
+  p.tail = tail; p.ldt = ldt;
   if (M <= kSmallM) {
     if (c_out) launch_small_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
     else launch_small_nt<EPI_BIAS>(p, M, (hipStream_t)stream);
@@ -1760,7 +1776,15 @@ int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const
     launch_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
   else
     launch_nt<EPI_BIAS>(p, M, (hipStream_t)stream);
+  if (tail && N < 256)
+    hipLaunchKernelGGL(mlp_tail_copy_kernel, dim3((unsigned)((M * (256 - N) + 255) / 256 < 2048 ? (M * (256 - N) + 255) / 256 : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, s_out, ldo, tail, ldt, M, N);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo, long M,
+                         int N, int K, void* stream) {
+  return matpbr_mlp_layer_fwd_tail(x, ldx, w, ldw, bias, s_out, c_out, ldo, nullptr, 0, M, N, K, stream);
 }
 
 size_t matpbr_mlp_bwd_input_workspace_bytes(long M) { (void)M; return (size_t)(kPersistent + 16) * 256 * sizeof(float); }
@@ -1823,15 +1847,25 @@ int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wspl
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
-int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo, long M, int N,
-                            int K, int nprod, void* stream) {
+int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
+                                 const float* tail, int ldt, long M, int N, int K, int nprod, void* stream) {
   if (!x || !wsplit || !bias || !s_out || !c_out || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
   if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
       !aligned16(s_out) || !aligned16(c_out))
     return MATPBR_ERR_UNSUPPORTED;
+  if (tail && ldt < 256 - N) return MATPBR_ERR_INVALID_ARG;
   NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, N, K, ldx, 0, ldo};
+  p.tail = tail; p.ldt = ldt;
   launch_nt_bx<EPI_SINCOS>(p, (const uint4*)wsplit, nprod, (hipStream_t)stream);
+  if (tail && N < 256)
+    hipLaunchKernelGGL(mlp_tail_copy_kernel, dim3((unsigned)((M * (256 - N) + 255) / 256 < 2048 ? (M * (256 - N) + 255) / 256 : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, s_out, ldo, tail, ldt, M, N);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo, long M, int N,
+                            int K, int nprod, void* stream) {
+  return matpbr_mlp_layer_fwd_bx_tail(x, ldx, wsplit, bias, s_out, c_out, ldo, nullptr, 0, M, N, K, nprod, stream);
 }
 
 int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,

@@ -438,7 +438,8 @@ def _mlp_workspace(kind: str, M: int, device, nbytes: int) -> torch.Tensor:
     return _mlp_ws[key]
 
 
-def mlp_layer_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: Optional[torch.Tensor], K: int) -> None:
+def mlp_layer_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: Optional[torch.Tensor], K: int,
+                  tail: Optional[torch.Tensor] = None) -> None:
     """s_out[:, :N] = sin(x[:, :K] w[:, :K]^T + bias), c_out[:, :N] = cos(same) (c_out None: no activation).  x [M, >=K], w [N, >=K];
     s_out / c_out are [M, >=N] with the same row stride.  One MFMA kernel (posmlp_kernels.hip)."""
     lib = _lib.load()
@@ -446,9 +447,10 @@ def mlp_layer_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, s_out: t
     M, N = x.shape[0], w.shape[0]
     if c_out is not None and (c_out.stride(0) != s_out.stride(0) or not c_out.is_cuda):
         raise ValueError("c_out must share s_out's row stride")
-    with torch.cuda.device(x.device):
-        code = lib.matpbr_mlp_layer_fwd(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(bias.contiguous()), _ptr(s_out),
-                                        _ptr(c_out) if c_out is not None else None, s_out.stride(0), M, N, K, _stream(x))
+    with torch.cuda.device(x.device):                          # tail: x0 of a skip layer, stored into columns N.. with the outputs
+        code = lib.matpbr_mlp_layer_fwd_tail(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(bias.contiguous()), _ptr(s_out),
+                                             _ptr(c_out) if c_out is not None else None, s_out.stride(0),
+                                             _ptr(tail) if tail is not None else None, tail.stride(0) if tail is not None else 0, M, N, K, _stream(x))
     _lib.check(code, "matpbr_mlp_layer_fwd")
 
 
@@ -485,15 +487,16 @@ def mlp_split_weights(w: torch.Tensor, N: int, K: int, out: Optional[torch.Tenso
 
 
 def mlp_layer_fwd_bx(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: torch.Tensor, N: int, K: int,
-                     nprod: int = 6) -> None:
+                     nprod: int = 6, tail: Optional[torch.Tensor] = None) -> None:
     """mlp_layer_fwd on the bf16 matrix pipe with split operands (nprod 6 or 9 partial products per f32 product)."""
     lib = _lib.load()
     x, s_out, c_out = _mat2(x, "x"), _mat2(s_out, "s_out"), _mat2(c_out, "c_out")
     if c_out.stride(0) != s_out.stride(0):
         raise ValueError("c_out must share s_out's row stride")
     with torch.cuda.device(x.device):
-        code = lib.matpbr_mlp_layer_fwd_bx(_ptr(x), x.stride(0), _ptr(wsplit), _ptr(bias.contiguous()), _ptr(s_out), _ptr(c_out), s_out.stride(0),
-                                           x.shape[0], N, K, int(nprod), _stream(x))
+        code = lib.matpbr_mlp_layer_fwd_bx_tail(_ptr(x), x.stride(0), _ptr(wsplit), _ptr(bias.contiguous()), _ptr(s_out), _ptr(c_out), s_out.stride(0),
+                                                _ptr(tail) if tail is not None else None, tail.stride(0) if tail is not None else 0,
+                                                x.shape[0], N, K, int(nprod), _stream(x))
     _lib.check(code, "matpbr_mlp_layer_fwd_bx")
 
 

@@ -1301,6 +1301,25 @@ def test_split_operand_layers_full_size_properties():
     s2, c2 = torch.empty_like(s_out), torch.empty_like(c_out)
     ops.mlp_layer_fwd_bx(x, ws, b, s2, c2, N, K, 6)
     assert torch.equal(s2[:, :N], s_out[:, :N]) and torch.equal(c2[:, :N], c_out[:, :N])
+    # the tail handed to the kernel instead (whole 16-byte stores): same outputs, the tail columns hold the given values
+    x0p = torch.zeros(M, 16, device=dev)
+    x0p[:, :256 - N] = tail
+    s3, c3 = torch.full((M, 256), float("nan"), device=dev), torch.empty(M, 256, device=dev)
+    ops.mlp_layer_fwd_bx(x, ws, b, s3, c3, N, K, 6, tail=x0p)
+    assert torch.equal(s3[:, :N], s_out[:, :N]) and torch.equal(s3[:, N:], tail) and torch.equal(c3[:, :N], c_out[:, :N])
+    # the first layer's kernel (K = 15, exact-f32 MFMA) with and without the tail
+    xk = torch.zeros(M, 16, device=dev)
+    xk[:, :15] = torch.randn(M, 15, device=dev)
+    wk = torch.zeros(N, 16, device=dev)
+    wk[:, :15] = torch.randn(N, 15, device=dev) / 4
+    sa, ca = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+    sb, cb = torch.full((M, 256), float("nan"), device=dev), torch.empty(M, 256, device=dev)
+    sa[:, N:] = tail
+    ops.mlp_layer_fwd(xk, wk, b, sa, ca, 15)
+    ops.mlp_layer_fwd(xk, wk, b, sb, cb, 15, tail=x0p)
+    assert torch.equal(sa, sb) and torch.equal(ca[:, :N], cb[:, :N])
+    ref = torch.sin(xk[:4096, :15].double() @ wk[:, :15].double().t() + b.double())
+    assert (sa[:4096, :N].double() - ref).abs().max().item() < 5e-6
     # backward operands: g [M, 256] with n_red = 256 columns, n_prev = N
     g1, g2 = torch.randn(M, 256, device=dev), torch.randn(M, 256, device=dev)
     wt = (torch.rand(N, 256, device=dev) * 2 - 1) / 16
