@@ -426,7 +426,16 @@ __device__ __forceinline__ void lane_setup(Lane& ln, const float wi[3], const fl
     ln.VoH = fmaxf(dot3(wo, ln.h), 0.0f);
     ln.nh_raw = dot3(n, ln.h);
     ln.NoH = fmaxf(ln.nh_raw, 0.0f);
-    ln.den = ggx_den_literal(ln.pc, ln.NoH);
+    // den = NoH^2 (alpha2 - 1) + 1 of D_GGX (:95) is ill-conditioned on the GGX peak not only in fp32 arithmetic but in the fp32
+    // INPUTS (|n|^2 = 1 +- 6e-8 against den ~ alpha2 ~ 2e-5): for a unit normal 1 - NoH^2 is |n x h|^2, which is well conditioned
+    // in both; a normal that is not unit keeps the literal form (the two differ by 1 - |n|^2 there)
+    const float nn = dot3(n, n);
+    if (fabsf(nn - 1.0f) < 1e-5f && ln.nh_raw > 0.0f) {
+        const float cx = n[1] * ln.h[2] - n[2] * ln.h[1], cy = n[2] * ln.h[0] - n[0] * ln.h[2], cz = n[0] * ln.h[1] - n[1] * ln.h[0];
+        ln.den = ggx_den_stable(ln.pc, fmaf(cx, cx, fmaf(cy, cy, cz * cz)));
+    } else {
+        ln.den = ggx_den_literal(ln.pc, ln.NoH);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void eval_brdf_kernel(const float* __restrict__ wi, const float* __restrict__ wo,

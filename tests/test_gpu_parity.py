@@ -62,16 +62,14 @@ def test_eval_brdf_matches_reference_golden(golden_dir, name):
     d_a, d_r, d_m, d_n = ops.eval_brdf_bwd(wi, wo, n, a, r, m, ones)
     assert_close(d_a, g["d_a"].T, what="d_a")
     assert_close(d_m, g["d_m"], what="d_m")
-    # d_r / d_n carry the GGX peak (D ~ 1e4 at r = 0.07): fp32 loses digits in NoH^2(alpha2-1)+1, so the
-    # literal N-lane form is held to 1e-2 on the peak lanes and 1e-3 elsewhere
-    peak = (g["r"] < 0.15)
+    # d_r / d_n carry the GGX peak (D ~ 1e4 at r = 0.07).  NoH^2(alpha2-1)+1 is ill-conditioned there in fp32 arithmetic AND in
+    # the fp32 inputs; the N-lane kernels form 1 - NoH^2 as |n x h|^2 for unit normals, which is neither: 1e-3 on every lane
     for got, ref, nm in ((d_r, g["d_r"], "d_r"), (d_n, g["d_n"].T, "d_n")):
         got = got.cpu().numpy()
         scale = np.abs(ref).mean()
         err = np.abs(got - ref) / np.maximum(np.abs(ref), scale)
         err_rows = err if err.ndim == 1 else err.max(1)
-        assert err_rows[~peak].max() <= RTOL, f"{nm}: {err_rows[~peak].max():.3e}"
-        assert err_rows[peak].max() <= 2e-2, f"{nm} (GGX peak lanes): {err_rows[peak].max():.3e}"
+        assert err_rows.max() <= RTOL, f"{nm}: {err_rows.max():.3e} (r of the worst lane {g['r'][err_rows.argmax()]:.3f})"
     for ch in range(3):
         e = torch.zeros_like(f)
         e[:, ch] = 1.0
