@@ -330,6 +330,12 @@ int matpbr_eval_brdf_bwd(const float* wi, const float* wo, const float* n, const
 int matpbr_brdf_terms(const float* cos1, const float* cos2, const float* r, const float* f0, float* out, long N, void* stream);
 int matpbr_sample_brdf(const float* sample1, const float* sample2, const float* wo, const float* n, const float* a,
                        const float* r, const float* m, float* wi, float* pdf, float* weight, long N, void* stream);
+/* Attached sampling (a5): d/dr of what matpbr_sample_brdf returns, THROUGH the sampled direction and the pdf it divides by, as the
+ * live reference differentiates it (myutils/mi_plugin.py:227-230 `mi_specular_sampler` is differentiable in the roughness, :1335-1341
+ * the weight divides by an attached pdf).  d_wi[N,3], d_pdf[N], d_weight[N,3]; forward-mode derivatives lane by lane, pinned to the
+ * reference's own autograd (tests/golden/sample_brdf_grad.npz).  The image kernels use the detached convention. */
+int matpbr_sample_brdf_dr(const float* sample1, const float* sample2, const float* wo, const float* n, const float* a, const float* r,
+                          const float* m, float* d_wi, float* d_pdf, float* d_weight, long N, void* stream);
 
 /* Radiance of the SH light in N directions: L[N,3] = sum_k coef[k,:] Y_k(w)
  * (myutils/computeSH.py:165-224 `projection`). */

@@ -551,6 +551,106 @@ __global__ __launch_bounds__(kBlock) void sample_brdf_kernel(const float* __rest
     pdf[k] = p > 0.0f ? p : 0.0f;
 }
 
+// ---- attached sampling: d/dr of sample_brdf THROUGH the sampled direction and the pdf -------------------------------------
+// The live reference differentiates mi_specular_sampler and the pdf it divides by (myutils/mi_plugin.py:227-230,1335-1341).
+// Forward-mode duals (value, d/dr) through the same formulas as sample_brdf_kernel, lane by lane.
+struct Du { float v, d; };
+__device__ __forceinline__ Du du(float v, float d = 0.0f) { return Du{v, d}; }
+__device__ __forceinline__ Du operator+(Du a, Du b) { return Du{a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Du operator-(Du a, Du b) { return Du{a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Du operator*(Du a, Du b) { return Du{a.v * b.v, fmaf(a.v, b.d, a.d * b.v)}; }
+__device__ __forceinline__ Du operator*(float a, Du b) { return Du{a * b.v, a * b.d}; }
+__device__ __forceinline__ Du operator+(Du a, float b) { return Du{a.v + b, a.d}; }
+__device__ __forceinline__ Du operator-(float a, Du b) { return Du{a - b.v, -b.d}; }
+__device__ __forceinline__ Du du_rcp(Du a) { const float i = 1.0f / a.v; return Du{i, -a.d * i * i}; }
+__device__ __forceinline__ Du du_sqrt(Du a) { const float s = sqrtf(a.v); return Du{s, a.v > 0.0f ? 0.5f * a.d / s : 0.0f}; }
+__device__ __forceinline__ Du du_max(Du a, float lo) { return a.v > lo ? a : Du{lo, 0.0f}; }   // torch.clamp / dr.maximum: gradient where a > lo
+__device__ __forceinline__ Du du_pow5(Du a) { const float a2 = a.v * a.v, a4 = a2 * a2; return Du{a4 * a.v, 5.0f * a4 * a.d}; }
+__device__ __forceinline__ Du du_dot(const Du a[3], const float b[3]) { return b[0] * a[0] + b[1] * a[1] + b[2] * a[2]; }
+__device__ __forceinline__ Du du_dot(const Du a[3], const Du b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__global__ __launch_bounds__(kBlock) void sample_brdf_dr_kernel(const float* __restrict__ sample1, const float* __restrict__ sample2,
+                                                                const float* __restrict__ wo, const float* __restrict__ n, const float* __restrict__ a,
+                                                                const float* __restrict__ r, const float* __restrict__ m, float* __restrict__ d_wi,
+                                                                float* __restrict__ d_pdf, float* __restrict__ d_weight, long N) {
+    long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= N) return;
+    const float wov[3] = {wo[3 * k], wo[3 * k + 1], wo[3 * k + 2]}, nv[3] = {n[3 * k], n[3 * k + 1], n[3 * k + 2]};
+    const float av[3] = {a[3 * k], a[3 * k + 1], a[3 * k + 2]}, mv = m[k];
+    const float u0 = sample2[2 * k], u1 = sample2[2 * k + 1];
+    const Du rr = du(r[k], 1.0f);
+    const Du r2 = rr * rr, alpha2 = r2 * r2;
+    float s[3], t[3];
+    frame(nv, s, t);
+    float sp, cp;
+    sincosf(2.0f * kPi * u1, &sp, &cp);
+    Du wi[3];
+    Du sin2_h = du(-1.0f), cos_h = du(0.0f);
+    bool ggx = false;
+    if (sample1[k] > 0.5f) {                                   // cosine lobe: the direction does not move with r
+        const float st_ = fsqrt(fmaxf(u0, 0.0f)), ct = fsqrt(fmaxf(1.0f - u0, 0.0f));
+        float w[3];
+        to_world(s, t, nv, st_ * cp, st_ * sp, ct, w);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wi[c] = du(w[c]);
+    } else {                                                   // GGX half vector, theta_h(u0; r)  (mi_plugin.py:217-253)
+        const Du q = du_rcp(u0 * (alpha2 + (-1.0f)) + 1.0f);
+        const Du ct2 = (1.0f - u0) * q, st2 = (u0 * alpha2) * q;
+        const Du ct = du_sqrt(du_max(ct2, 0.0f)), st_ = du_sqrt(du_max(st2, 0.0f));
+        Du wh[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wh[c] = (s[c] * cp) * st_ + (t[c] * sp) * st_ + nv[c] * ct;
+        const Du d = 2.0f * du_dot(wh, wov);
+        Du raw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) raw[c] = d * wh[c] + (-wov[c]);
+        const Du il = du_rcp(du_sqrt(du_dot(raw, raw)));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wi[c] = raw[c] * il;
+        if (d.v > 0.0f) { sin2_h = st2; cos_h = ct; ggx = true; }
+    }
+    // eval_brdf at (wi, wo) with everything a dual (:1372-1427)
+    Du h[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) h[c] = wi[c] + wov[c];
+    const Du ihl = du_rcp(du_sqrt(du_dot(h, h)));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) h[c] = h[c] * ihl;
+    const Du NoL = du_max(du_dot(wi, nv), 0.0f);
+    const float NoV = fmaxf(dot3(nv, wov), 0.0f);
+    Du NoH = du_max(du_dot(h, nv), 0.0f);
+    const Du VoH = du_max(du_dot(h, wov), 0.0f);
+    Du one_m;                                                  // 1 - NoH^2 without cancellation (unit n)
+    if (ggx) {
+        one_m = sin2_h;
+        NoH = cos_h;
+    } else {
+        const Du cx = nv[1] * h[2] - nv[2] * h[1], cy = nv[2] * h[0] - nv[0] * h[2], cz = nv[0] * h[1] - nv[1] * h[0];
+        one_m = cx * cx + cy * cy + cz * cz;
+    }
+    const Du den = one_m * (1.0f - alpha2) + alpha2 + 1e-6f;   // = NoH^2 (alpha2 - 1) + 1 + 1e-6  (:95)
+    const Du iden = du_rcp(den);
+    const Du D = (kInvPi * alpha2) * (iden * iden);
+    const Du pdf = (0.125f * (D * NoH)) * du_rcp(du_max(VoH, 1e-6f)) + (0.5f * kInvPi) * NoL;
+    const Du rp1 = rr + 1.0f, kk = 0.125f * (rp1 * rp1);
+    const Du g1l = du_rcp(NoL * (1.0f - kk) + kk + 1e-6f), g1v = du_rcp(NoV * (1.0f - kk) + kk + 1e-6f);
+    const Du G = g1l * g1v;
+    const Du FDm1 = (2.0f * (VoH * VoH)) * rr + (-0.5f);
+    const Du Fo = FDm1 * du(pow5(1.0f - NoV)) + 1.0f, Fi = FDm1 * du_pow5(1.0f - NoL) + 1.0f;
+    const Du x5 = du_pow5(1.0f - VoH);
+    const Du dsc = (Fo * Fi) * NoL, ssc = (0.25f * (D * G)) * NoL;
+    const bool live = pdf.v > 1e-6f;
+    const Du ip = du_rcp(pdf + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float kd = av[c] * (1.0f - mv) * kInvPi, C0 = fmaf(mv, av[c], (1.0f - mv) * 0.04f);
+        const Du f = kd * dsc + ssc * ((1.0f - C0) * x5 + C0);
+        d_weight[3 * k + c] = live ? (f * ip).d : 0.0f;
+        d_wi[3 * k + c] = wi[c].d;
+    }
+    d_pdf[k] = pdf.v > 0.0f ? pdf.d : 0.0f;
+}
+
 __global__ __launch_bounds__(kBlock) void sh_eval_kernel(const float* __restrict__ w, const float* __restrict__ coef,
                                                          float* __restrict__ L, long N) {
     __shared__ float s_c[kNL + 1];
@@ -802,6 +902,15 @@ int matpbr_sample_brdf(const float* sample1, const float* sample2, const float* 
     if (N == 0) return MATPBR_OK;
     hipLaunchKernelGGL(sample_brdf_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, sample1,
                        sample2, wo, n, a, r, m, wi, pdf, weight, N);
+    return launch_status();
+}
+
+int matpbr_sample_brdf_dr(const float* sample1, const float* sample2, const float* wo, const float* n, const float* a, const float* r,
+                          const float* m, float* d_wi, float* d_pdf, float* d_weight, long N, void* stream) {
+    if (!sample1 || !sample2 || !wo || !n || !a || !r || !m || !d_wi || !d_pdf || !d_weight || N < 0) return MATPBR_ERR_INVALID_ARG;
+    if (N == 0) return MATPBR_OK;
+    hipLaunchKernelGGL(sample_brdf_dr_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, sample1, sample2, wo, n,
+                       a, r, m, d_wi, d_pdf, d_weight, N);
     return launch_status();
 }
 

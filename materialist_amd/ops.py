@@ -276,6 +276,24 @@ def sample_brdf(sample1, sample2, wo, n, a, r, m):
     return wi, pdf, w
 
 
+def sample_brdf_dr(sample1, sample2, wo, n, a, r, m):
+    """d/dr of `sample_brdf` through the sampled direction and the pdf (the reference's attached convention, mi_plugin.py:227-230,
+    1335-1341): returns (d_wi [N,3], d_pdf [N], d_weight [N,3])."""
+    lib = _lib.load()
+    wo, n, a = (_dev(t, k, (3,)) for t, k in ((wo, "wo"), (n, "n"), (a, "a")))
+    sample2 = _dev(sample2, "sample2", (2,))
+    sample1, r, m = _dev(sample1, "sample1").reshape(-1), _dev(r, "r").reshape(-1), _dev(m, "m").reshape(-1)
+    N = r.numel()
+    d_wi = torch.empty((N, 3), dtype=torch.float32, device=r.device)
+    d_w = torch.empty((N, 3), dtype=torch.float32, device=r.device)
+    d_pdf = torch.empty(N, dtype=torch.float32, device=r.device)
+    with torch.cuda.device(r.device):
+        code = lib.matpbr_sample_brdf_dr(_ptr(sample1), _ptr(sample2), _ptr(wo), _ptr(n), _ptr(a), _ptr(r), _ptr(m), _ptr(d_wi), _ptr(d_pdf),
+                                         _ptr(d_w), N, _stream(r))
+    _lib.check(code, "matpbr_sample_brdf_dr")
+    return d_wi, d_pdf, d_w
+
+
 def sh_eval(w, coef):
     lib = _lib.load()
     w = _dev(w, "w", (3,))

@@ -110,6 +110,32 @@ def test_sample_brdf_matches_reference_golden(golden_dir):
     assert_close(pdf, g["pdf"], rtol=5e-3, what="pdf")
 
 
+def test_attached_sampling_derivative_matches_the_reference_autograd(golden_dir):
+    """a5, the live reference's gradient convention at the plugin face: d/dr of sample_brdf THROUGH the sampled direction and the
+    pdf (myutils/mi_plugin.py:227-230,1335-1341).  matpbr_sample_brdf_dr (forward-mode derivatives, fp32) against the reference's
+    own torch autograd, recorded lane by lane in tests/golden/sample_brdf_grad.npz (1024 lanes, half cosine lobe, half GGX)."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    g = np.load(os.path.join(golden_dir, "sample_brdf.npz"))
+    gg = np.load(os.path.join(golden_dir, "sample_brdf_grad.npz"))
+    d_wi, d_pdf, d_w = ops.sample_brdf_dr(_t(g["sample1"], dev), _t(g["sample2"].T, dev), _t(g["wo"].T, dev), _t(g["n"].T, dev),
+                                          _t(g["a"].T, dev), _t(g["r"], dev), _t(g["m"], dev))
+    d_wi, d_pdf, d_w = d_wi.cpu().numpy().astype(np.float64), d_pdf.cpu().numpy().astype(np.float64), d_w.cpu().numpy().astype(np.float64)
+    ref_wi, ref_pdf, ref_w = gg["dwi_dr"].T, gg["dpdf_dr"], gg["dweight_dr"].T
+    ok = (g["pdf"] > 2e-6) & (g["r"] > 0.0701) & (g["r"] < 0.9999)        # away from the pdf > 1e-6 mask (:1338) and the clamp ends of r
+    assert ok.mean() > 0.9
+    diffuse = g["sample1"] > 0.5
+    assert np.abs(d_wi[diffuse]).max() == 0.0                              # only GGX-sampled directions move with r
+    assert np.abs(d_wi[ok] - ref_wi[ok]).max() <= 1e-3 * max(np.abs(ref_wi[ok]).max(), 1.0)
+    for got, ref, nm in ((d_pdf, ref_pdf, "d pdf / d r"), (d_w, ref_w, "d weight / d r")):
+        scale = np.abs(ref[ok]).mean()
+        err = np.abs(got[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), scale)
+        assert err.max() <= 2e-3, f"{nm}: {err.max():.3e}"
+    # and it is not the detached derivative: on GGX lanes the two differ visibly
+    assert np.abs(ref_wi[ok & ~diffuse]).max() > 0.1
+
+
 def test_samplers_match_reference_golden(golden_dir):
     from materialist_amd import ops
 
