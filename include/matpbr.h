@@ -48,6 +48,10 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
 /* flags */
 #define MATPBR_FLAG_CLAMP_PARAMS 1u /* maps are raw optimiser parameters: render clamp(a,0,1), clamp(r,.07,1), clamp(m,0,1)
                                        (inverse_img_w_mi.py:371-377) */
+#define MATPBR_FLAG_ATTACHED_SAMPLING 2u /* matpbr_shade_bwd only: d_r is the derivative of the rendered value THROUGH the GGX quadrature
+                                           nodes (their half-vector angles move with r, and with them wi, the weights and the radiance),
+                                           the convention of the live reference (myutils/mi_plugin.py:227-230,1335-1341), instead of the
+                                           stop-gradient convention of the default.  d_a, d_m, d_n, d_light do not change. */
 #define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
 #define MATPBR_PART_R 4u
 #define MATPBR_PART_M 8u

@@ -651,6 +651,92 @@ __global__ __launch_bounds__(kBlock) void sample_brdf_dr_kernel(const float* __r
     d_pdf[k] = pdf.v > 0.0f ? pdf.d : 0.0f;
 }
 
+// Image level (MATPBR_FLAG_ATTACHED_SAMPLING of matpbr_shade_bwd): the material backward treats the quadrature nodes of the GGX
+// lobe as constants; with the flag, d_r becomes the exact derivative of the rendered value -- the half-vector angles theta_h(u0; r)
+// move with r, and with them wi, the weights G1(NoL) G1(NoV) NoL VoH / NoH and the radiance L(wi).  This kernel walks the specular
+// samples of a pixel once with forward-mode duals and ADDS (attached - detached) of the specular lobe's r-derivative to d_r; the
+// diffuse lobe's nodes do not depend on r.  One pixel per lane, scalar code: an option of the operator face, not a hot path.
+__device__ __forceinline__ void sh_poly_du(const Du w[3], Du B[kNSH]) {      // sh_poly (matpbr_device.hpp) on duals
+    const Du X = du(0.0f) - w[2], Y = w[0], Z = w[1];
+    const Du z2 = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z, y2 = Y * Y, x2 = X * X;
+    const Du d = x2 - y2;
+    const Du t5 = 5.0f * z2 + (-1.0f), t7 = 7.0f * z2 + (-1.0f), t73 = t7 + (-2.0f);
+    const Du s3 = Y * (3.0f * x2 - y2), c3 = X * (x2 - 3.0f * y2);
+    B[0] = du(1.0f);
+    B[1] = Y; B[2] = Z; B[3] = X;
+    B[4] = xy; B[5] = yz; B[6] = 3.0f * z2 + (-1.0f); B[7] = xz; B[8] = d;
+    B[9] = s3; B[10] = xy * Z; B[11] = Y * t5; B[12] = Z * (t5 + (-2.0f)); B[13] = X * t5; B[14] = d * Z; B[15] = c3;
+    B[16] = xy * d; B[17] = s3 * Z; B[18] = xy * t7; B[19] = yz * t73; B[20] = (35.0f * z2 + (-30.0f)) * z2 + 3.0f;
+    B[21] = xz * t73; B[22] = d * t7; B[23] = c3 * Z; B[24] = d * d - 4.0f * (xy * xy);
+}
+__global__ __launch_bounds__(kBlock) void shade_dr_attached_kernel(const float* __restrict__ a, const float* __restrict__ r, const float* __restrict__ m,
+                                                                   const float* __restrict__ n, const float* __restrict__ light,
+                                                                   const float* __restrict__ d_out, float* __restrict__ d_r, const Geom g,
+                                                                   const RuleTable tab) {
+    __shared__ float s_c[kNL];
+    const int b = blockIdx.y;
+    if (threadIdx.x < kNL) s_c[threadIdx.x] = light[(long)b * kNL + threadIdx.x] * kShNorm[threadIdx.x / 3];
+    __syncthreads();
+    const int P = g.H * g.W;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    const long i = (long)b * P + p;
+    const float av[3] = {a[3 * i], a[3 * i + 1], a[3 * i + 2]}, rv = r[i], mv = m[i];
+    float nv[3] = {n[3 * i], n[3 * i + 1], n[3 * i + 2]};
+    const float inl = rsq(fmaxf(dot3(nv, nv), 1e-30f));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nv[c] *= inl;
+    const float x = (g.cx - (float)(p % g.W)) * g.inv_f, y = ((float)(p / g.W) - g.cy) * g.inv_f, il = rsq(fmaf(x, x, fmaf(y, y, 1.0f)));
+    const float wo[3] = {x * il, y * il, il};
+    float s[3], t[3];
+    frame(nv, s, t);
+    const float NoV = fmaxf(dot3(nv, wo), 0.0f);
+    const Du rr = du(rv, 1.0f), r2 = rr * rr, alpha2 = r2 * r2;
+    const Du rp1 = rr + 1.0f, kk = 0.125f * (rp1 * rp1);
+    const Du g1v = du_rcp(NoV * (1.0f - kk) + kk + 1e-6f);
+    float att[3] = {0.0f, 0.0f, 0.0f}, att5[3] = {0.0f, 0.0f, 0.0f}, det[3] = {0.0f, 0.0f, 0.0f}, det5[3] = {0.0f, 0.0f, 0.0f};
+    for (int ring = 0; ring < tab.nu_s; ++ring) {
+        const float u0 = tab.sring[ring].x, wq = tab.sring[ring].z;
+        const Du q = du_rcp(u0 * (alpha2 + (-1.0f)) + 1.0f);
+        const Du ct = du_sqrt(du_max((1.0f - u0) * q, 0.0f)), st_ = du_sqrt(du_max((u0 * alpha2) * q, 0.0f));   // :232-233
+        // d ln D / dr at a fixed direction, D_GGX of :89-97 with its 1e-6: den = ct^2 (alpha2 - 1) + 1 + 1e-6 = alpha2 q + 1e-6 here
+        const float lamD = 4.0f / rv - 8.0f * rv * rv * rv * ((1.0f - u0) * q.v) / fmaf(alpha2.v, q.v, 1e-6f);
+        for (int j = 0; j < tab.nphi_s; ++j) {
+            const float cp = tab.saz[ring][j].x, sp = tab.saz[ring][j].y;
+            Du wh[3], wi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wh[c] = (s[c] * cp) * st_ + (t[c] * sp) * st_ + nv[c] * ct;
+            const Du d = du_dot(wh, wo);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wi[c] = (2.0f * d) * wh[c] + (-wo[c]);                                    // reflect, :245
+            const Du nl = du_dot(wi, nv);
+            if (!(d.v > 0.0f) || !(nl.v > 0.0f)) continue;
+            const Du g1l = du_rcp(nl * (1.0f - kk) + kk + 1e-6f);
+            const Du wgt = (wq * (g1l * g1v)) * ((nl * d) * du_rcp(ct));
+            const Du x5 = du_pow5(1.0f - d);
+            const float lam = lamD - 0.25f * (rv + 1.0f) * (g1l.v * (1.0f - nl.v) + g1v.v * (1.0f - NoV));
+            Du B[kNSH];
+            sh_poly_du(wi, B);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Du L = du(0.0f);
+#pragma unroll
+                for (int k = 0; k < kNSH; ++k) L = L + s_c[k * 3 + c] * B[k];
+                const Du xs = wgt * L, xs5 = xs * x5;
+                att[c] += xs.d; att5[c] += xs5.d;
+                det[c] = fmaf(xs.v, lam, det[c]); det5[c] = fmaf(xs5.v, lam, det5[c]);
+            }
+        }
+    }
+    float delta = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float C0 = fmaf(mv, av[c], (1.0f - mv) * 0.04f);
+        delta = fmaf(d_out[3 * i + c], fmaf(C0, att[c] - det[c], (1.0f - C0) * (att5[c] - det5[c])), delta);
+    }
+    d_r[i] += delta;
+}
+
 __global__ __launch_bounds__(kBlock) void sh_eval_kernel(const float* __restrict__ w, const float* __restrict__ coef,
                                                          float* __restrict__ L, long N) {
     __shared__ float s_c[kNL + 1];
@@ -824,7 +910,6 @@ int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float
                      int n_light, const float* d_out_rgb, float* d_a, float* d_r, float* d_m, float* d_n, float* d_light,
                      void* workspace, size_t workspace_bytes, int H, int W, int batch, int spp, const MatpbrCamera* cam,
                      uint32_t flags, void* stream) {
-    (void)flags;
     if (!a || !r || !m || !n || !light || !d_out_rgb || batch <= 0) return MATPBR_ERR_INVALID_ARG;
     if (!sh25(light_kind, n_light)) return MATPBR_ERR_INVALID_ARG;
     if (!valid_spp(spp)) return MATPBR_ERR_UNSUPPORTED;
@@ -847,6 +932,9 @@ int matpbr_shade_bwd(const float* a, const float* r, const float* m, const float
         ShadeArgs q{};
         q.a = a; q.r = r; q.m = m; q.n = n; q.d_out = d_out_rgb; q.d_a = d_a; q.d_r = d_r; q.d_m = d_m;
         hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, q, light, g, tab);
+        if (flags & MATPBR_FLAG_ATTACHED_SAMPLING)   // d_r += (attached - detached) derivative of the specular lobe
+            hipLaunchKernelGGL(shade_dr_attached_kernel, dim3((unsigned)((H * W + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0, st, a, r, m,
+                               n, light, d_out_rgb, d_r, g, tab);
     }
     if (want_n)
         hipLaunchKernelGGL((shade_bwd_nl_kernel<true, false>), grid, dim3(kBlock), 0, st, a, r, m, n, light, d_out_rgb, d_n, (float*)nullptr, g, tab);

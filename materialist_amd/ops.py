@@ -14,6 +14,7 @@ LIGHT_SH25 = 0
 NSH = 25
 MAX_SPP = 128
 FLAG_CLAMP_PARAMS = 1
+FLAG_ATTACHED_SAMPLING = 2
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
  STAT_ES_HAS, STAT_STOPPED, STAT_ITERS, STAT_GT_SUM) = range(16)
@@ -199,8 +200,9 @@ def shade_bwd_jac(a, r, m, jac, d_out):
 
 
 def shade_bwd(a, r, m, n, light, d_out, spp: int, fov_x_deg: float = 35.0, want_mat=True, want_n=False, want_light=False,
-              workspace: Optional[torch.Tensor] = None):
-    """Returns (d_a, d_r, d_m, d_n, d_light); entries not requested are None."""
+              workspace: Optional[torch.Tensor] = None, attached: bool = False):
+    """Returns (d_a, d_r, d_m, d_n, d_light); entries not requested are None.  attached: d_r through the GGX quadrature nodes (the
+    live reference's convention, mi_plugin.py:227-230,1335-1341) instead of the stop-gradient default."""
     lib = _lib.load()
     a = _dev(a, "albedo", (3,))
     B, H, W = _bhw(a)
@@ -224,7 +226,7 @@ def shade_bwd(a, r, m, n, light, d_out, spp: int, fov_x_deg: float = 35.0, want_
     with torch.cuda.device(a.device), _timed("shade_bwd"):
         code = lib.matpbr_shade_bwd(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(d_out), _ptr(d_a),
                                     _ptr(d_r), _ptr(d_m), _ptr(d_n), _ptr(d_l), _ptr(workspace), ws_bytes, H, W, B,
-                                    check_spp(spp), ctypes.byref(cam), 0, _stream(a))
+                                    check_spp(spp), ctypes.byref(cam), FLAG_ATTACHED_SAMPLING if attached else 0, _stream(a))
     _lib.check(code, "matpbr_shade_bwd")
     return d_a, d_r, d_m, d_n, d_l
 

@@ -24,6 +24,13 @@ from . import sh as _sh
 DEFAULT_FOV = 35.0  # inverse_img_w_mi.py:32, myutils/default_cam.json
 
 
+# Gradient convention of the operator face w.r.t. the roughness.  False (default): the sampled directions and their pdfs are
+# constants of the backward pass (stop-gradient), which is what the fused loops use.  True: d_r is the exact derivative of the
+# rendered value through the GGX quadrature nodes -- the convention of the live reference, whose sampler is differentiable in the
+# roughness and whose weight divides by an attached pdf (myutils/mi_plugin.py:227-230,1335-1341).  MATPBR_FLAG_ATTACHED_SAMPLING.
+ATTACHED_SAMPLING = False
+
+
 class _ShadeFn(torch.autograd.Function):
     """Differentiable R(a, r, m, n, light) -> rgb; stands in for dr.wrap_ad + mi.render (inverse_img_w_mi.py:59-80)."""
 
@@ -46,7 +53,9 @@ class _ShadeFn(torch.autograd.Function):
         want_n, want_light = need[3], need[4]
         d_out = d_out.contiguous()
         d_a = d_r = d_m = d_n = d_l = None
-        if want_mat:
+        if want_mat and ATTACHED_SAMPLING:       # d_r through the GGX quadrature nodes (the live reference's convention)
+            d_a, d_r, d_m, _, _ = ops.shade_bwd(a, r, m, n, light, d_out, ctx.spp, ctx.fov, want_mat=True, attached=True)
+        elif want_mat:
             d_a, d_r, d_m = ops.shade_bwd_jac(a, r, m, ctx.jac, d_out)
         if want_n or want_light:
             ws = None

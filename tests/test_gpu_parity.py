@@ -225,6 +225,51 @@ def test_shade_bwd_matches_oracle(oracle64, spp):
                 assert g_ is None
 
 
+@pytest.mark.parametrize("spp", [64, 16])
+def test_attached_sampling_flag_gives_the_exact_r_derivative_of_the_render(oracle64, spp):
+    """a5 at image level, MATPBR_FLAG_ATTACHED_SAMPLING of matpbr_shade_bwd: d_r becomes the derivative of the rendered value
+    through the GGX quadrature nodes (the live reference's convention, mi_plugin.py:227-230,1335-1341).  Checked against central
+    differences of the fp64 oracle render in r (every pixel perturbed at once: pixels are independent); d_a and d_m are untouched
+    by the flag; and the attached and the default (stop-gradient) d_r are two estimates of the same dI/dr: cosine similarity
+    reported and bounded."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    H, W = 40, 56
+    sc, n = _scene_arrays(H, W, image_id=2)
+    rng = np.random.default_rng(11)
+    d_out = rng.normal(size=(H, W, 3)).astype(np.float32)
+    rgh = np.clip(sc.roughness, 0.08, 0.98)
+    h = 1e-5
+    up = oracle64.shade_fwd(sc.albedo, rgh + h, sc.metallic, n, sc.light, spp)
+    dn = oracle64.shade_fwd(sc.albedo, rgh - h, sc.metallic, n, sc.light, spp)
+    ref = (((up - dn) / (2 * h)) * d_out).sum(-1, keepdims=True)
+    args = [_t(x, dev) for x in (sc.albedo, rgh, sc.metallic, n, sc.light, d_out)]
+    d_a0, d_r0, d_m0, _, _ = ops.shade_bwd(*args, spp)
+    d_a1, d_r1, d_m1, _, _ = ops.shade_bwd(*args, spp, attached=True)
+    assert torch.equal(d_a0, d_a1) and torch.equal(d_m0, d_m1)
+    assert_close(d_r1, ref, rtol=3e-3, what=f"attached d_r spp{spp}")
+    a_, d_ = d_r1.double().flatten(), d_r0.double().flatten()
+    cos = float((a_ * d_).sum() / (a_.norm() * d_.norm()))
+    print(f"attached vs detached d_r at spp {spp}: cosine {cos:.4f}, norm ratio {float(a_.norm() / d_.norm()):.4f}")
+    assert 0.5 < cos < 0.99999                              # related, and not the same thing
+    err_detached = np.abs(d_r0.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err_detached > 1e-2                              # the default is NOT the derivative of the rendered value
+    # the operator face: render.ATTACHED_SAMPLING switches the autograd backward of render_w_brdf
+    from materialist_amd import render
+
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=False)
+    scene._set("emitter.data", _t(sc.light, dev))
+    r_t = _t(rgh, dev).requires_grad_(True)
+    render.ATTACHED_SAMPLING = True
+    try:
+        out = render.render_w_brdf(scene, _t(sc.albedo, dev), r_t, _t(sc.metallic, dev), _t(n, dev), spp)
+        out.backward(_t(d_out, dev))
+    finally:
+        render.ATTACHED_SAMPLING = False
+    assert_close(r_t.grad, ref, rtol=3e-3, what="attached d_r through render_w_brdf")
+
+
 def test_extreme_materials_and_back_facing_normals(oracle64):
     """Edge cases the reference's known-answer vectors hold at lane level (App. C: back-facing / zero cases), here at image level:
     parameter maps on their clamp boundaries (roughness 0.07 / 1, metallic 0 / 1, albedo 0 / 1) and normals over the whole
