@@ -5,8 +5,9 @@ The initial maps come from MaterialNet (`matnet_weights` = the reference's `matn
 downloads from the HF hub, :648-654; there is no network here), or from `pred_dir` (files in the layout the reference
 writes: albedoPred.exr, normalPred.exr, roughnessPred.png, metallicPred.png, depthPred.exr), or, failing both, from a
 flat prior (albedo = the linearised image, roughness 0.5, metallic 0, fronto-parallel plane).  The reference turns the
-collected frames into env_optimization.mp4 / mat_optimization.mp4 (`create_video_from_frames`, :593-599) through OpenCV; no video
-encoder exists in this image, so the same frames become env_optimization.gif / mat_optimization.gif (Pillow), the PNGs are kept.
+collected frames into env_optimization.mp4 / mat_optimization.mp4 (`create_video_from_frames`, :593-612) through imageio's ffmpeg
+plugin; no video encoder exists in this image, so the same frames are JPEG-coded and muxed by `video_mp4.write_mp4` (Motion-JPEG
+in MP4) under the same file names; the PNGs are kept.
 """
 from __future__ import annotations
 
@@ -226,6 +227,22 @@ class FrameWriter:
         self.mat_frames.append(path)
 
 
+def create_video_from_frames(frame_paths: Sequence[str], out_path: str, fps: int = 10) -> Optional[str]:
+    """create_video_from_frames (inverse_img_w_mi.py:602-612): every collected frame, in order, at `fps`, as an mp4.  No ffmpeg in
+    this image: the frames are JPEG-coded and muxed by `video_mp4.write_mp4` (Motion-JPEG in MP4)."""
+    from PIL import Image
+
+    from .video_mp4 import write_mp4
+
+    paths = [p for p in frame_paths if os.path.exists(p)]
+    if not paths:
+        return None
+    ims = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
+    h, w = ims[0].shape[:2]
+    ims = [im if im.shape[:2] == (h, w) else np.asarray(Image.fromarray(im).resize((w, h), Image.BILINEAR)) for im in ims]
+    return write_mp4(out_path, ims, fps=fps)
+
+
 def create_animation_from_frames(frame_paths: Sequence[str], out_path: str, fps: int = 10, max_frames: int = 40, max_side: int = 480) -> Optional[str]:
     """Stand-in for create_video_from_frames (inverse_img_w_mi.py:593-599; mp4 through OpenCV there): an animated GIF of at most
     `max_frames` evenly spaced frames, the long side reduced to `max_side` pixels (GIF encoding is slow: 80 frames at 768 pixels cost
@@ -370,8 +387,8 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
                                         shading_normal=scene.geo_normal if use_mesh_normal else None,
                                         model_name=model_name, use_mask=use_mask and "mask" in mat)
     frames.close()
-    create_animation_from_frames(frames.env_frames, os.path.join(output_dir, "env_optimization.gif"))   # :593-599
-    create_animation_from_frames(frames.mat_frames, os.path.join(output_dir, "mat_optimization.gif"))
+    create_video_from_frames(frames.env_frames, os.path.join(output_dir, "env_optimization.mp4"))        # :593-599
+    create_video_from_frames(frames.mat_frames, os.path.join(output_dir, "mat_optimization.mp4"))
     write_hdr(os.path.join(output_dir, "final_envmap.hdr"), res["envmap"].detach().cpu().numpy())   # :297
     res["output_dir"] = output_dir
     return res

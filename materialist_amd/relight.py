@@ -210,7 +210,10 @@ def render_rolling_envmap(save_name: str, env_path: Optional[str], frames: int =
     if imgs:
         from PIL import Image
 
-        gif_path = os.path.join(out_dir, f"rolling_envmap_{save_name}_{env_id}.gif")
+        from .video_mp4 import write_mp4
+
+        gif_path = os.path.join(out_dir, f"rolling_envmap_{save_name}_{env_id}.gif")     # render_final.py:405-414 writes both
         pil = [Image.fromarray(i) for i in imgs]
         pil[0].save(gif_path, save_all=True, append_images=pil[1:], duration=100, loop=0)
-    return {"animation_dir": anim_dir, "frames": paths, "gif": gif_path}
+        mp4_path = write_mp4(os.path.join(out_dir, f"rolling_envmap_{save_name}_{env_id}.mp4"), imgs, fps=10)
+    return {"animation_dir": anim_dir, "frames": paths, "gif": gif_path, "mp4": mp4_path if imgs else None}

@@ -685,7 +685,7 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     out = res["output_dir"]
     assert out == str(tmp_path / "case")
     for name in ("albedoPred.exr", "normalPred.exr", "roughnessPred.png", "metallicPred.png", "depthPred.exr", "gt_image.exr", "gt_image.png",
-                 "config.json", "env.png", "final_envmap.hdr", "opt_env_img.png", "env_optimization.gif", "mat_optimization.gif", "case.ply"):
+                 "config.json", "env.png", "final_envmap.hdr", "opt_env_img.png", "env_optimization.mp4", "mat_optimization.mp4", "case.ply"):
         assert os.path.exists(os.path.join(out, name)), name
     assert sorted(os.listdir(os.path.join(out, "best_results"))) == ["albedo.exr", "envmap.hdr", "metallic.exr", "normal.exr",
                                                                      "rendered_img.exr", "roughness.exr"]
@@ -714,6 +714,7 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     roll = relight.render_rolling_envmap("case", None, frames=10, rotation_step=36.0, input_path=str(tmp_path), save_path=str(tmp_path), spp=8)
     assert len(roll["frames"]) == 10 and os.path.basename(roll["frames"][3]) == "frame_0003.png"
     assert os.path.exists(roll["gif"]) and os.path.basename(roll["gif"]) == "rolling_envmap_case_envmap.gif"
+    assert os.path.exists(roll["mp4"]) and os.path.basename(roll["mp4"]) == "rolling_envmap_case_envmap.mp4"      # render_final.py:405-409
 
 
 @pytest.mark.parametrize("model_name", ["none", "pos_mlp"])
