@@ -10,7 +10,6 @@ from __future__ import annotations
 from typing import Dict, Optional
 
 import torch
-import torch.nn.functional as NF
 
 _EPS = 1e-8  # the deterministic render can return exact zeros (back-facing pixels); x^(1/2.2) has no gradient there
 

@@ -13,7 +13,6 @@ depth edges the area-weighted vertex normals of the two meshes agree to 0.14 deg
 from __future__ import annotations
 
 import math
-import struct
 from typing import Tuple
 
 import numpy as np
