@@ -1651,11 +1651,11 @@ __global__ __launch_bounds__(256) void arm_head_bwd_kernel(const float* __restri
 // partial[slab][j][c] = sum over the slab's rows of S[m][j] B[m][c] (J columns of the skinny S, 256 of the wide B), and
 // bpart[slab][j] = sum of S[m][j].  Thread (cq, rs): columns 4cq..4cq+3 of B, every 4th row of the slab; the S row is uniform
 // across a wave (scalar loads).  The four row slices are folded through LDS in fixed order.
-constexpr int kSkinnySlabs = 512;
+constexpr int kSkinnySlabs = 1024;
 template <int J>
 __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restrict__ S, int lds, const float* __restrict__ B, int ldb,
                                                             float* __restrict__ partial, float* __restrict__ bpart, long M, long rows_per_slab) {
-  __shared__ float red[3][J][256];
+  __shared__ float red[3][8][256];                         // the fold runs 8 columns of S at a time (24 KB: four workgroups per CU)
   __shared__ float bred[4][J];
   const int cq = threadIdx.x & 63, rs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long m_begin = (long)blockIdx.x * rows_per_slab;
@@ -1688,28 +1688,33 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
       }
     }
   }
-  if (rs > 0) {
-#pragma unroll
-    for (int j = 0; j < J; ++j) *reinterpret_cast<float4*>(&red[rs - 1][j][4 * cq]) = acc[j];
-  }
   if (cq == 0) {
 #pragma unroll
     for (int j = 0; j < J; ++j) bred[rs][j] = bs[j];
   }
-  __syncthreads();
-  if (rs == 0) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      float4 t = acc[j];
+  for (int j0 = 0; j0 < J; j0 += 8) {
+    if (j0 > 0) __syncthreads();                          // the previous eight have been folded
+    if (rs > 0) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const float4 o = *reinterpret_cast<const float4*>(&red[q][j][4 * cq]);
-        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-      }
-      *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * J + j) * 256 + 4 * cq) = t;
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(&red[rs - 1][j][4 * cq]) = acc[j0 + j];
     }
-    if (bpart != nullptr && threadIdx.x < J) bpart[(size_t)blockIdx.x * J + threadIdx.x] = (bred[0][threadIdx.x] + bred[1][threadIdx.x]) + (bred[2][threadIdx.x] + bred[3][threadIdx.x]);
+    __syncthreads();
+    if (rs == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float4 t = acc[j0 + j];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const float4 o = *reinterpret_cast<const float4*>(&red[q][j][4 * cq]);
+          t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * J + j0 + j) * 256 + 4 * cq) = t;
+      }
+    }
   }
+  if (rs == 0 && bpart != nullptr && threadIdx.x < J)
+    bpart[(size_t)blockIdx.x * J + threadIdx.x] = (bred[0][threadIdx.x] + bred[1][threadIdx.x]) + (bred[2][threadIdx.x] + bred[3][threadIdx.x]);
 }
 
 // out[j * ld_j + c * ld_c] = sum over slabs of partial[slab][j][c] (j < Jv, c < C); d_b[j] = sum of bpart[slab][j].  One
