@@ -1514,6 +1514,123 @@ int launch_nt(NtArgs p, long M, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Thin reductions (K <= 16) into a 256-wide layer at image size: the first layer's forward (x0 [M,15] -> sin, cos [M,241]) and the
+// input gradient of the last sine layer (d x [M,5] -> G' [M,256] * cos).  There is no k-loop to speak of (8 or 4 MFMA steps per
+// 32 x 32 tile): these are store-bound passes (537 MB), and what the general kernel loses on them is the shape of its launch --
+// 128 x 128 tiles in 2 column halves, k-tiles staged through LDS with barriers.  Here a wave owns 32 whole rows: the weights of
+// all 8 column tiles sit in registers, A comes straight from the rows (64 bytes each), the tile goes through the wave's own LDS
+// slice for 16-byte stores, no barrier anywhere; many independent waves per CU keep the stores flowing.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int EPI, int KP>   // KP: K padded to 8 or 16 (the row stride of A and B covers it; padding columns hold zeros)
+__global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int tiles) {
+  __shared__ __align__(16) float scr_all[4][32 * kLd];
+  __shared__ __align__(16) float sWt[256 * KP];                // the weights [n][k], zero beyond N / K: 16 KB, read per column tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  float* scr = scr_all[wave];
+  constexpr int KS = KP / 2;                                   // MFMA steps (32x32x2)
+  for (int i = threadIdx.x; i < 256 * KP; i += 256) {
+    const int nn = i / KP, k = i - nn * KP;
+    sWt[i] = (nn < p.N && k < p.K) ? p.B[(size_t)nn * p.ldb + k] : 0.f;
+  }
+  float bn[8];
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) bn[ni] = (EPI != EPI_MULC && ni * 32 + li < p.N) ? p.bias[ni * 32 + li] : 0.f;
+  __syncthreads();
+  const int t_row = lane >> 3, t_col = (lane & 7) * 4;
+  float4 csum[8];
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) csum[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 32;
+    // A: row li, k = 2 s + lh (both halves read the same 4 * KP bytes of the row)
+    float av[KS];
+    {
+      const int m = row0 + li < p.M ? row0 + li : p.M - 1;
+      const float4* ap = reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda);
+#pragma unroll
+      for (int q = 0; q < KP / 4; ++q) {
+        const float4 v = ap[q];
+        av[2 * q] = lh ? v.y : v.x;
+        av[2 * q + 1] = lh ? v.w : v.z;
+      }
+    }
+    const bool full_rows = row0 + 32 <= p.M;
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      if (ni * 32 >= p.N) break;                               // uniform
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      float wb[KS];
+#pragma unroll
+      for (int q = 0; q < KP / 4; ++q) {                       // row (ni * 32 + li) of the weights, k = 2 s + lh
+        const float4 v = *reinterpret_cast<const float4*>(sWt + (ni * 32 + li) * KP + 4 * q);
+        wb[2 * q] = lh ? v.y : v.x;
+        wb[2 * q + 1] = lh ? v.w : v.z;
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < KS; ++sidx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sidx], wb[sidx], acc, 0, 0, 0);
+      float4 cv[4];
+      const size_t o0 = (size_t)(row0 + t_row) * p.ldo + ni * 32 + t_col;
+      if (EPI == EPI_MULC) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+          cv[ps] = (full_rows || row0 + t_row + 8 * ps < p.M) ? *reinterpret_cast<const float4*>(p.cmul + o0 + (size_t)(8 * ps) * p.ldo)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float second[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        if (EPI == EPI_SINCOS) sincos_cw(v + bn[ni], v, second[r]);
+        else if (EPI == EPI_BIAS) v += bn[ni];
+        scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
+      }
+      const bool all_cols = ni * 32 + 32 <= p.N || p.tail != nullptr;    // uniform; with a tail the caller rewrites columns N..
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+        if (EPI == EPI_MULC) {
+          v.x *= cv[ps].x; v.y *= cv[ps].y; v.z *= cv[ps].z; v.w *= cv[ps].w;
+          csum[ni].x += v.x; csum[ni].y += v.y; csum[ni].z += v.z; csum[ni].w += v.w;
+        }
+        if (full_rows || row0 + t_row + 8 * ps < p.M)
+          store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (ni * 32 + t_col), all_cols);
+      }
+      if (EPI == EPI_SINCOS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+          if (full_rows || row0 + t_row + 8 * ps < p.M)
+            store4_upto(p.out1 + o0 + (size_t)(8 * ps) * p.ldo, *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col),
+                        p.N - (ni * 32 + t_col), all_cols);
+      }
+    }
+  }
+  if (EPI == EPI_MULC && p.colsum != nullptr) {                // per-workgroup column sums of G' (the bias gradient of the layer below)
+    __shared__ float red[32][256];
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) *reinterpret_cast<float4*>(&red[wave * 8 + t_row][ni * 32 + t_col]) = csum[ni];
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 32; ++sl) t += red[sl][threadIdx.x];
+    p.colsum[(size_t)blockIdx.x * 256 + threadIdx.x] = t;
+  }
+}
+constexpr int kThinBlocks = 1024;                            // workgroups of the thin-K kernels (4 per CU)
+template <int EPI>
+int launch_thin_k(const NtArgs& p, hipStream_t stream) {     // returns the number of workgroups (rows of the colsum partials)
+  const int tiles = (p.M + 31) / 32;
+  const int grid = (tiles + 3) / 4 < kThinBlocks ? (tiles + 3) / 4 : kThinBlocks;
+  if (p.K <= 8) hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 8>), dim3(grid), dim3(256), 0, stream, p, tiles);
+  else hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 16>), dim3(grid), dim3(256), 0, stream, p, tiles);
+  return grid;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // The skinny ends of the network at image size (M = H*W rows): the output layer ([M,256] x [256,J], J <= 8) with the 'arm' head
 // of the residual coordinate MLP, the output layer's weight gradient and the first layer's (15 inputs).  One streaming pass over
 // the 256-wide matrix each (268 MB at 512 x 512): HBM-bound, VALU only.
@@ -1774,9 +1891,15 @@ int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, 
   if (tail && (ldo < 256 || ldt < 256 - N || !c_out)) return MATPBR_ERR_INVALID_ARG;   // the tail fills columns N..255 of a 256-wide sine layer
   NtArgs p{x, w, bias, nullptr, s_out, c_out, nullptr, 0, N, K, ldx, ldw, ldo};
   p.tail = tail; p.ldt = ldt;
+  const bool thin = M > kSmallM && K <= 16 && ldx >= (K <= 8 ? 8 : 16) && ldw >= (K <= 8 ? 8 : 16) && ldo >= 256 && !(ldo & 3) && aligned16(s_out) &&
+                    (!c_out || aligned16(c_out));
   if (M <= kSmallM) {
     if (c_out) launch_small_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
     else launch_small_nt<EPI_BIAS>(p, M, (hipStream_t)stream);
+  } else if (thin) {
+    p.M = (int)M;
+    if (c_out) launch_thin_k<EPI_SINCOS>(p, (hipStream_t)stream);
+    else launch_thin_k<EPI_BIAS>(p, (hipStream_t)stream);
   } else if (c_out)
     launch_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
   else
@@ -1792,7 +1915,10 @@ int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const
   return matpbr_mlp_layer_fwd_tail(x, ldx, w, ldw, bias, s_out, c_out, ldo, nullptr, 0, M, N, K, stream);
 }
 
-size_t matpbr_mlp_bwd_input_workspace_bytes(long M) { (void)M; return (size_t)(kPersistent + 16) * 256 * sizeof(float); }
+size_t matpbr_mlp_bwd_input_workspace_bytes(long M) {
+  (void)M;
+  return (size_t)((kPersistent + 16) > kThinBlocks ? (kPersistent + 16) : kThinBlocks) * 256 * sizeof(float);
+}
 
 int matpbr_mlp_layer_bwd_input(const float* g, int ldg, const float* wt, int ldwt, const float* c_prev, float* g_prev, int ldo,
                                float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
@@ -1802,7 +1928,14 @@ int matpbr_mlp_layer_bwd_input(const float* g, int ldg, const float* wt, int ldw
     return MATPBR_ERR_INVALID_ARG;
   if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
   NtArgs p{g, wt, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, 0, n_prev, n_red, ldg, ldwt, ldo};
-  const int groups = M <= kSmallM ? launch_small_nt<EPI_MULC>(p, M, (hipStream_t)stream) : launch_nt<EPI_MULC>(p, M, (hipStream_t)stream);
+  const bool thin = M > kSmallM && n_red <= 16 && ldg >= (n_red <= 8 ? 8 : 16) && ldo >= 256 && !(ldo & 3) && aligned16(c_prev) && aligned16(g_prev);
+  int groups;
+  if (thin) {
+    p.M = (int)M;
+    groups = launch_thin_k<EPI_MULC>(p, (hipStream_t)stream);
+  } else {
+    groups = M <= kSmallM ? launch_small_nt<EPI_MULC>(p, M, (hipStream_t)stream) : launch_nt<EPI_MULC>(p, M, (hipStream_t)stream);
+  }
   if (d_bias_prev)
     hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
