@@ -824,21 +824,26 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad_tn(const float* __restrict__
       }
 }
 
-__global__ __launch_bounds__(256) void mlp_wgrad_reduce(const float* __restrict__ partial, int slabs, float* __restrict__ dW, int N, int K,
-                                                        int ldw) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;   // over 256 x 256
-  const int n = idx >> 8, k = idx & 255;
-  if (n >= N || k >= K) return;   // rows n >= 128 exist only when the launch had a second n-half, i.e. N > 128
+__global__ __launch_bounds__(1024) void mlp_wgrad_reduce(const float* __restrict__ partial, int slabs, float* __restrict__ dW, int N, int K,
+                                                         int ldw) {
+  // 256 outputs per workgroup x 4 slices of the slabs (a chain of slabs / 16 dependent rounds instead of slabs / 4), LDS fold
+  __shared__ float red[4][256];
+  const int t = threadIdx.x & 255, sl = threadIdx.x >> 8;
+  const int idx = blockIdx.x * 256 + t;   // over 256 x 256
+  const int per = (slabs + 3) / 4, c0 = sl * per, c1 = c0 + per < slabs ? c0 + per : slabs;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int c = 0;
-  for (; c + 3 < slabs; c += 4) {
+  int c = c0;
+  for (; c + 3 < c1; c += 4) {
     s0 += partial[(long)(c + 0) * 65536 + idx];
     s1 += partial[(long)(c + 1) * 65536 + idx];
     s2 += partial[(long)(c + 2) * 65536 + idx];
     s3 += partial[(long)(c + 3) * 65536 + idx];
   }
-  for (; c < slabs; ++c) s0 += partial[(long)c * 65536 + idx];
-  dW[(long)n * ldw + k] = (s0 + s1) + (s2 + s3);
+  for (; c < c1; ++c) s0 += partial[(long)c * 65536 + idx];
+  red[sl][t] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  const int n = idx >> 8, k = idx & 255;
+  if (sl == 0 && n < N && k < K) dW[(long)n * ldw + k] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
 // column sums of the per-workgroup partials [groups, 256] -> out[n]: one workgroup per column, fixed-order tree
@@ -2043,7 +2048,7 @@ int matpbr_mlp_layer_bwd_weight(const float* g, int ldg, const float* x, int ldx
   long rows = (M + slabs - 1) / slabs;
   rows = (rows + kWM - 1) / kWM * kWM;
   hipLaunchKernelGGL(mlp_wgrad_tn, dim3(slabs, (N + 127) / 128), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, K);
-  hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
+  hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
@@ -2066,7 +2071,7 @@ int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int 
     configured[1] = true;
     hipLaunchKernelGGL(mlp_wgrad_bx<9>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows);
   }
-  hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
+  hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
