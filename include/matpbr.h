@@ -269,6 +269,12 @@ int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, 
                               const float* tail, int ldt, long M, int N, int K, void* stream);
 int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
                                  const float* tail, int ldt, long M, int N, int K, int nprod, void* stream);
+/* matpbr_mlp_layer_fwd_bx of the LAST sine layer (N = 256 outputs) that also finishes the network: its epilogue forms the five
+ * outputs of the output layer w_out[5, ldw_out >= 256], bias_out[5] for the rows it holds and runs the 'arm' head on them
+ * (= matpbr_mlp_arm_head_fwd on s_out, without the pass over s_out). */
+int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
+                                 const float* w_out, int ldw_out, const float* bias_out, const float* start, int lds, float* th,
+                                 float* map_a, float* map_r, float* map_m, long M, int K, int nprod, void* stream);
 int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
                                    size_t workspace_bytes, long M, int N, int K, int nprod, void* stream);
 

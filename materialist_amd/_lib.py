@@ -103,6 +103,8 @@ SIGNATURES = {
     "matpbr_mlp_layer_fwd_bx_tail": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_long,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_sample_brdf_dr": (ctypes.c_int, [_c_f] * 10 + [ctypes.c_long, ctypes.c_void_p]),
+    "matpbr_mlp_layer_fwd_bx_head": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int,
+                                                   _c_f, _c_f, _c_f, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_sincos": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_mul": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_column_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),

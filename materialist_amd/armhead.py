@@ -189,13 +189,18 @@ class ArmMlpPhase:
         # against guarding the straddling word of every row in the epilogue); the first layer's kernel keeps its guard (no gain there)
         tail = lambda l: self.x0p if self.ns[l] != 256 else None
         o.mlp_layer_fwd(self.x0p, wp, bp, self.bufs[0], self.cbufs[0], self.d0)
+        live = self.live
+        maps = [self.maps[k] if k in live else None for k in ("albedo", "roughness", "metallic")]
+        wo, bo = self.views[-1]
         for l in range(1, self.L - 1):
             wp, bp = self.views[l]
-            o.mlp_layer_fwd_bx(self.bufs[l - 1], self.wsplit_f[l], bp, self.bufs[l], self.cbufs[l], self.ns[l], 256, P, tail=tail(l))
-        wp, bp = self.views[-1]
-        live = self.live
-        o.mlp_arm_head_fwd(self.bufs[-1], wp, bp, self.start_arm, self.th, self.maps["albedo"] if "albedo" in live else None,
-                           self.maps["roughness"] if "roughness" in live else None, self.maps["metallic"] if "metallic" in live else None, 256)
+            if l == self.L - 2 and self.ns[l] == 256:           # the last sine layer finishes the network in its epilogue
+                o.mlp_layer_fwd_bx_head(self.bufs[l - 1], self.wsplit_f[l], bp, self.bufs[l], self.cbufs[l], 256, P, wo, bo, self.start_arm, self.th,
+                                        *maps)
+            else:
+                o.mlp_layer_fwd_bx(self.bufs[l - 1], self.wsplit_f[l], bp, self.bufs[l], self.cbufs[l], self.ns[l], 256, P, tail=tail(l))
+        if self.ns[-1] != 256:
+            o.mlp_arm_head_fwd(self.bufs[-1], wo, bo, self.start_arm, self.th, *maps, 256)
         return {k: (self.maps[k] if k in live else self.fixed[k]) for k in self.maps}
 
     def backward(self) -> None:

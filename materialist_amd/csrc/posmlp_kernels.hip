@@ -74,6 +74,55 @@ __device__ __forceinline__ void sincos_cw(float x, float& s_out, float& c_out) {
   c_out = __uint_as_float(__float_as_uint(cc) ^ (((q + 1u) & 2u) << 30));
 }
 
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_add_f(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {   // fixed-order tree; the total is in lane 63
+  v = dpp_add_f<0x111>(v);        // row_shr:1
+  v = dpp_add_f<0x112>(v);        // row_shr:2
+  v = dpp_add_f<0x114>(v);        // row_shr:4
+  v = dpp_add_f<0x118>(v);        // row_shr:8
+  v = dpp_add_f<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+  v = dpp_add_f<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+struct ArmHead {       // mymodels/mlps.py:233-236 ('arm') and inverse_img_w_mi.py:493-496
+  const float* start;  // [M, lds]: start_arm, the network's colour input (columns 0..4)
+  int lds;
+  float* th;           // [M, 8]: tanh(x), kept for the backward
+  float* map_a;        // [M, 3] | null: clamp(1.3 tanh(x) + start, 0, 1)[0:3]
+  float* map_r;        // [M]    | null: clamp(...)[3] * 0.93 + 0.07
+  float* map_m;        // [M]    | null: clamp(...)[4]
+};
+
+// the 'arm' head on the five outputs v of row m (mymodels/mlps.py:231-233, inverse_img_w_mi.py:493-496)
+__device__ __forceinline__ void arm_head_store(const ArmHead& h, long m, const float v[5]) {
+  float y[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float t = tanhf(v[j]);
+    h.th[m * 8 + j] = t;
+    // x = 1.3 tanh(x) + img; x = x.clamp(0,1).detach() + x - x.detach() (mlps.py:232-233): the value of the straight-through
+    // clamp is (clamp(x) + x) - x as rounded in fp32, not clamp(x) -- it can land one ulp outside [0,1], which the clamp
+    // of :494-496 then gates.  Separate roundings as torch's (no fma).
+    const float u = __fadd_rn(__fmul_rn(1.3f, t), h.start[m * h.lds + j]);
+    y[j] = __fsub_rn(__fadd_rn(fminf(fmaxf(u, 0.f), 1.f), u), u);
+  }
+  if (h.map_a) { h.map_a[m * 3 + 0] = y[0]; h.map_a[m * 3 + 1] = y[1]; h.map_a[m * 3 + 2] = y[2]; }
+  if (h.map_r) h.map_r[m] = __fadd_rn(__fmul_rn(y[3], 0.93f), 0.07f);
+  if (h.map_m) h.map_m[m] = y[4];
+}
+// the output layer handed to the forward kernel of the last sine layer, which then finishes the network in its epilogue
+struct HeadArgs {
+  const float* w;      // [5, ldw >= 256]
+  int ldw;
+  const float* bias;   // [5]
+  ArmHead h;
+};
+
 // Columns at or beyond N of the 256-wide outputs are left alone: the buffer of a skip layer keeps x0 there (mymodels/mlps.py
 // :214-217 concatenates it every forward; a caller that owns the buffers writes it once).
 // out[m][N + j] = tail[m][j], j < 256 - N: the x0 columns of a skip layer's buffer, rewritten after a forward that stored whole
@@ -1138,12 +1187,18 @@ __global__ __launch_bounds__(256) void mlp_split_weights_multi_kernel(const Spli
 // Eight waves per workgroup (4 row groups of 32 x 2 column halves of 128; 128 x 256 outputs per workgroup, one workgroup per
 // CU): two waves per SIMD, so that one wave's operand split / LDS traffic / epilogue runs under the other's products.
 constexpr int kBxThreads = 512;
-template <int EPI, int NPROD, bool FULL>   // FULL: all 256 output columns exist (N == 256): unguarded 16-byte stores
-__global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const uint4* __restrict__ wsplit) {
+// HEAD (forward of the LAST sine layer, N == 256): the epilogue also forms the five outputs of the network's output layer for its
+// 128 rows -- each lane dots the 16-byte words of sines it is about to store with the matching weights (from a 5 KB LDS image), an
+// 8-lane DPP fold and one LDS exchange between the two column halves complete the rows -- and runs the 'arm' head on them: the
+// separate pass over the 268 MB of sines (76 us at 512 x 512) disappears.
+template <int EPI, int NPROD, bool FULL, bool HEAD = false>   // FULL: all 256 output columns exist (N == 256): unguarded 16-byte stores
+__global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const uint4* __restrict__ wsplit, const HeadArgs hd) {
   extern __shared__ __align__(16) unsigned char bx_smem[];
   uint4* sB = reinterpret_cast<uint4*>(bx_smem);                         // [2 buffers][kBxStage]
   float* sScr = reinterpret_cast<float*>(bx_smem + 2 * kBxStage * sizeof(uint4));   // [8 waves][32][kLd]
   float* sRed = reinterpret_cast<float*>(bx_smem);                       // [32][256] after the last tile (aliases sB)
+  float* sW4 = sScr + 8 * 32 * kLd;                                      // HEAD: [5][256] output-layer weights
+  float* sComb = sW4 + 5 * 256;                                          // HEAD: [128 rows][2 column halves][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int nks = (p.K + 31) / 32;
@@ -1162,6 +1217,9 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
   uint4 bnext[kCopy];
 #pragma unroll
   for (int q = 0; q < kCopy; ++q) sB[tid + kBxThreads * q] = wsplit[tid + kBxThreads * q];
+  if (HEAD) {
+    for (int i = tid; i < 5 * 256; i += kBxThreads) sW4[i] = hd.w[(size_t)(i >> 8) * hd.ldw + (i & 255)];
+  }
   __syncthreads();
   int buf = 0;
 
@@ -1238,6 +1296,13 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
     float* scr = sScr + wave * (32 * kLd);
     const int t_row = lane >> 3, t_col = (lane & 7) * 4;
     const size_t tile_row = (size_t)(row0 + wm * 32 + t_row) * p.ldo;
+    float hacc[4][5];
+    if (HEAD) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) hacc[ps][j] = 0.f;
+    }
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
       float4 cv[2][4];
@@ -1270,6 +1335,13 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
             v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
             csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
           }
+          if (HEAD) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              const float4 w4 = *reinterpret_cast<const float4*>(sW4 + j * 256 + wn * 128 + ni * 32 + t_col);
+              hacc[ps][j] = __builtin_fmaf(v.x, w4.x, __builtin_fmaf(v.y, w4.y, __builtin_fmaf(v.z, w4.z, __builtin_fmaf(v.w, w4.w, hacc[ps][j]))));
+            }
+          }
           store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);
         }
         if (EPI == EPI_SINCOS) {
@@ -1281,6 +1353,27 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
                         p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);
         }
       }
+    }
+    if (HEAD) {
+      // the 8 lanes of a row (lane & 7) hold its partial dot products over this wave's 128 columns: fold (total in lane 8 g + 7)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          float v = hacc[ps][j];
+          v = dpp_add_f<0x111>(v);    // row_shr:1
+          v = dpp_add_f<0x112>(v);    // row_shr:2
+          v = dpp_add_f<0x114>(v);    // row_shr:4
+          if ((lane & 7) == 7) sComb[((wm * 32 + t_row + 8 * ps) * 2 + wn) * 8 + j] = v;
+        }
+      __syncthreads();
+      if (tid < kBM) {                                        // one thread per row of the tile: both column halves + bias, then the head
+        float v5[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v5[j] = (sComb[(tid * 2) * 8 + j] + sComb[(tid * 2 + 1) * 8 + j]) + hd.bias[j];
+        arm_head_store(hd.h, (long)row0 + tid, v5);
+      }
+      // sComb is written again at the end of the next tile, eight barriers from here
     }
   }
   if (EPI == EPI_MULC && p.colsum != nullptr) {
@@ -1445,6 +1538,7 @@ __global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_bx(const float* __res
 }
 
 constexpr size_t kBxSmem = 2 * kBxStage * sizeof(uint4) + 8 * 32 * kLd * sizeof(float);   // 96 KB of weights + 36 KB of epilogue scratch
+constexpr size_t kBxSmemHead = kBxSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float);           // + output-layer weights and the row exchange
 template <int EPI, int NPROD, bool FULL>
 void launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
   static bool configured = false;                            // more than 64 KB of LDS needs the opt-in attribute, once per kernel
@@ -1452,7 +1546,17 @@ void launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipS
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_nt_bx<EPI, NPROD, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBxSmem);
     configured = true;
   }
-  hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD, FULL>), dim3(grid), dim3(kBxThreads), kBxSmem, stream, p, wsplit);
+  hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD, FULL>), dim3(grid), dim3(kBxThreads), kBxSmem, stream, p, wsplit, HeadArgs{});
+}
+template <int NPROD>
+void launch_nt_bx_head(const NtArgs& p, const uint4* wsplit, const HeadArgs& hd, unsigned grid, hipStream_t stream) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_nt_bx<EPI_SINCOS, NPROD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kBxSmemHead);
+    configured = true;
+  }
+  hipLaunchKernelGGL((mlp_nt_bx<EPI_SINCOS, NPROD, true, true>), dim3(grid), dim3(kBxThreads), kBxSmemHead, stream, p, wsplit, hd);
 }
 template <int EPI, int NPROD>
 void launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
@@ -1640,30 +1744,6 @@ int launch_thin_k(const NtArgs& p, hipStream_t stream) {     // returns the numb
 // of the residual coordinate MLP, the output layer's weight gradient and the first layer's (15 inputs).  One streaming pass over
 // the 256-wide matrix each (268 MB at 512 x 512): HBM-bound, VALU only.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
-__device__ __forceinline__ float dpp_add_f(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true);
-  return v + __builtin_bit_cast(float, moved);
-}
-__device__ __forceinline__ float wave_sum_lane63(float v) {   // fixed-order tree; the total is in lane 63
-  v = dpp_add_f<0x111>(v);        // row_shr:1
-  v = dpp_add_f<0x112>(v);        // row_shr:2
-  v = dpp_add_f<0x114>(v);        // row_shr:4
-  v = dpp_add_f<0x118>(v);        // row_shr:8
-  v = dpp_add_f<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
-  v = dpp_add_f<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
-  return v;
-}
-
-struct ArmHead {       // mymodels/mlps.py:233-236 ('arm') and inverse_img_w_mi.py:493-496
-  const float* start;  // [M, lds]: start_arm, the network's colour input (columns 0..4)
-  int lds;
-  float* th;           // [M, 8]: tanh(x), kept for the backward
-  float* map_a;        // [M, 3] | null: clamp(1.3 tanh(x) + start, 0, 1)[0:3]
-  float* map_r;        // [M]    | null: clamp(...)[3] * 0.93 + 0.07
-  float* map_m;        // [M]    | null: clamp(...)[4]
-};
-
 // out[m][j] = bias[j] + sum_k X[m][k] W[j][k].  A wave owns 64 consecutive rows: lane l holds columns 4l..4l+3 of the weights
 // and of the row being multiplied (one whole 1 KB row per wave load -- 128-byte segments of many rows run at half the bandwidth),
 // J DPP tree sums per row leave the totals in lane 63, from where they are handed to lane (row & 63): after 64 rows every lane
@@ -1721,22 +1801,7 @@ __global__ __launch_bounds__(256) void mlp_skinny_nt_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < J; ++j) out[m * ldo + j] = v[j];
       }
-      if (HEAD) {
-        float y[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const float t = tanhf(v[j]);
-          h.th[m * 8 + j] = t;
-          // x = 1.3 tanh(x) + img; x = x.clamp(0,1).detach() + x - x.detach() (mlps.py:232-233): the value of the straight-through
-          // clamp is (clamp(x) + x) - x as rounded in fp32, not clamp(x) -- it can land one ulp outside [0,1], which the clamp
-          // of :494-496 then gates.  Separate roundings as torch's (no fma).
-          const float u = __fadd_rn(__fmul_rn(1.3f, t), h.start[m * h.lds + j]);
-          y[j] = __fsub_rn(__fadd_rn(fminf(fmaxf(u, 0.f), 1.f), u), u);
-        }
-        if (h.map_a) { h.map_a[m * 3 + 0] = y[0]; h.map_a[m * 3 + 1] = y[1]; h.map_a[m * 3 + 2] = y[2]; }
-        if (h.map_r) h.map_r[m] = __fadd_rn(__fmul_rn(y[3], 0.93f), 0.07f);
-        if (h.map_m) h.map_m[m] = y[4];
-      }
+      if (HEAD) arm_head_store(h, m, v);
     }
   }
 }
@@ -2003,6 +2068,23 @@ int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, co
   if (tail && N < 256)
     hipLaunchKernelGGL(mlp_tail_copy_kernel, dim3((unsigned)((M * (256 - N) + 255) / 256 < 2048 ? (M * (256 - N) + 255) / 256 : 2048)), dim3(256), 0,
                        (hipStream_t)stream, s_out, ldo, tail, ldt, M, N);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
+                                 const float* w_out, int ldw_out, const float* bias_out, const float* start, int lds, float* th, float* map_a,
+                                 float* map_r, float* map_m, long M, int K, int nprod, void* stream) {
+  if (!x || !wsplit || !bias || !s_out || !c_out || !w_out || !bias_out || !start || !th || M <= 0 || K <= 0 || K > 256 || lds < 5 || ldw_out < 256)
+    return MATPBR_ERR_INVALID_ARG;
+  if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
+      !aligned16(s_out) || !aligned16(c_out))
+    return MATPBR_ERR_UNSUPPORTED;
+  NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, 256, K, ldx, 0, ldo};
+  const HeadArgs hd{w_out, ldw_out, bias_out, ArmHead{start, lds, th, map_a, map_r, map_m}};
+  const int tiles = (int)(M / kBM);
+  const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+  if (nprod == 9) launch_nt_bx_head<9>(p, (const uint4*)wsplit, hd, grid, (hipStream_t)stream);
+  else launch_nt_bx_head<6>(p, (const uint4*)wsplit, hd, grid, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 

@@ -520,6 +520,21 @@ def mlp_layer_fwd_bx(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, 
     _lib.check(code, "matpbr_mlp_layer_fwd_bx")
 
 
+def mlp_layer_fwd_bx_head(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: torch.Tensor, K: int, nprod: int,
+                          w_out: torch.Tensor, bias_out: torch.Tensor, start: torch.Tensor, th: torch.Tensor, map_a: Optional[torch.Tensor],
+                          map_r: Optional[torch.Tensor], map_m: Optional[torch.Tensor]) -> None:
+    """mlp_layer_fwd_bx of the last sine layer (256 outputs) whose epilogue also forms the output layer and the 'arm' head for the
+    rows it holds (= mlp_arm_head_fwd on s_out without reading s_out back)."""
+    lib = _lib.load()
+    x, s_out, c_out, w_out = _mat2(x, "x"), _mat2(s_out, "s_out"), _mat2(c_out, "c_out"), _mat2(w_out, "w_out")
+    P = lambda t: _ptr(t) if t is not None else None
+    with torch.cuda.device(x.device):
+        code = lib.matpbr_mlp_layer_fwd_bx_head(_ptr(x), x.stride(0), _ptr(wsplit), _ptr(bias.contiguous()), _ptr(s_out), _ptr(c_out), s_out.stride(0),
+                                                _ptr(w_out), w_out.stride(0), _ptr(bias_out), _ptr(start), start.stride(0), _ptr(th), P(map_a),
+                                                P(map_r), P(map_m), x.shape[0], K, int(nprod), _stream(x))
+    _lib.check(code, "matpbr_mlp_layer_fwd_bx_head")
+
+
 def mlp_layer_bwd_input_bx(g: torch.Tensor, wtsplit: torch.Tensor, c_prev: torch.Tensor, g_prev: torch.Tensor, n_prev: int, n_red: int,
                            d_bias_prev: Optional[torch.Tensor], nprod: int = 6) -> None:
     lib = _lib.load()
