@@ -837,6 +837,200 @@ void oracle_shade_fwd_frozen(const real* a, const real* r, const real* m, const 
         split_pixel_frozen(wo, nh, a + idx * 3, r[idx], m[idx], nsh, r_s[idx], light + b * MATPBR_NSH * 3, &q, out + idx * 3);
     }
 }
+/* ------------------------------------------------------------------------------------------------
+ * Lazy re-sampling of the specular sums in hot loop B (the parts of --opt_order that move the roughness,
+ * inverse_img_w_mi.py:493-515 / 371-386).  This is the SPECIFICATION of materialist_amd/csrc/matpbr_lazy.hpp.
+ *
+ * With light and shading normals fixed during a BRDF phase (:317-342) the specular sums S0, S1 of a pixel are
+ * functions of its roughness alone, and Adam moves r by at most lr ~ 3e-4 per step.  A pixel therefore keeps
+ *     r_ref,  SD = S0 - S1 and S1 at r_ref,  their slopes gSD, gS1 (one-sided difference over LAZY_H in the direction
+ *     the pixel is travelling),  the detached r-derivatives dSD, dS1 of the backward convention,
+ * and renders  out = a (1-m) P(r) + C0 (SD + gSD dr) + (S1 + gS1 dr),  dr = r - r_ref,  with P(r) exact from the cached
+ * diffuse coefficients, as long as r stays inside the pixel's validity interval [r_ref - lo, r_ref + hi].  Outside of it
+ * the 20 GGX samples are walked again (refresh).  The interval is built so that the extrapolation stays well inside the
+ * parity bar |lazy - exact| <= 1e-3 max(|exact|, mean|exact|):
+ *   * smooth part: a radius rho, controlled like an ODE step size -- at a refresh the prediction of the old state is
+ *     compared with the exact sums (relative error e at distance D), rho' = 0.9 D sqrt(tol_s / e), within [rho/2, 2 rho];
+ *   * kinks: S0, S1 are C0 but not C1 in r where a sample's reflected direction crosses the horizon (NoL = max(n.wi, 0))
+ *     or its half vector turns away from the view (VoH = max(wo.h, 0)).  Both crossings are predicted to first order
+ *     from d(theta_h)/dr of the GGX sampler (:232-233); beyond a crossing the linear model is off by J |r - r_k| with
+ *     J = the sample's weight per unit of the clamped variable times its r-derivative, so the interval ends
+ *     tol_k / J behind the crossing (crossings too weak to matter inside rho_max are ignored).
+ * Layout of a state: LAZY_NSTATE reals per pixel, indices LZ_*.
+ * ---------------------------------------------------------------------------------------------- */
+#define LAZY_NSTATE 22
+enum { LZ_RREF = 0, LZ_LO, LZ_HI, LZ_RHO, LZ_SD = 4, LZ_S1 = 7, LZ_GSD = 10, LZ_GS1 = 13, LZ_DSD = 16, LZ_DS1 = 19 };
+#define LAZY_H R(1e-3)
+#define LAZY_RHO_INIT R(2e-3)
+#define LAZY_RHO_MIN R(2.5e-4)
+#define LAZY_RHO_MAX R(3e-2)
+#define LAZY_TOL_S R(2.5e-4)
+#define LAZY_TOL_K R(1.5e-4)
+#define LAZY_KINK_SAFETY R(0.8)
+#define LAZY_MOVED R(1e-4)
+int oracle_lazy_nstate(void) { return LAZY_NSTATE; }
+
+typedef struct LazySums { real S0[3], S1[3], dS0[3], dS1[3]; } LazySums;
+typedef struct LazyKinks { real lo, hi; } LazyKinks;
+static void lazy_kink(real x, real xp, real J, real tol_k, LazyKinks* k) {
+    if (!(J * LAZY_RHO_MAX > tol_k)) return;               /* cannot cost tol_k anywhere within reach */
+    if (!(fabs(xp) > R(1e-12))) return;
+    real dk = -x / xp * LAZY_KINK_SAFETY, om = tol_k / J;
+    if (fabs(dk) < R(2) * LAZY_H) {                        /* inside the slope stencil: the model mixes both branches */
+        if (fabs(dk) + om < k->hi) k->hi = fabs(dk) + om;
+        if (fabs(dk) + om < k->lo) k->lo = fabs(dk) + om;
+    } else if (dk > R(0)) { if (dk + om < k->hi) k->hi = dk + om; }
+    else { if (-dk + om < k->lo) k->lo = -dk + om; }
+}
+/* the specular sums at roughness r (all 20 samples); with `kinks` also the crossing scan, for which C0 / scale (per channel)
+ * weigh a sample's contribution to the rendered value relative to the parity scale */
+static void lazy_sums(const real wo[3], const real n[3], real r, const real* coef, const Rules* q, LazySums* S, LazyKinks* kinks,
+                      const real C0[3], const real scale[3], real tol_k) {
+    const real *u0 = q->su0, *u1 = q->su1, *w = q->sw;
+    real s[3], t[3];
+    oracle_frame(n, s, t);
+    const real vx = dot3(s, wo), vy = dot3(t, wo), vz = dot3(n, wo);
+    const real NoV = rmax(vz, R(0)), g1v = oracle_G1_GGX_Schlick(NoV, r);
+    const real alpha2 = pow4r(r), kk = (r + R(1)) * (r + R(1)) / R(8);
+    for (int c = 0; c < 3; ++c) S->S0[c] = S->S1[c] = S->dS0[c] = S->dS1[c] = R(0);
+    for (int j = 0; j < q->ns; ++j) {
+        SpecSample sp;
+        real L[3];
+        if (spec_sample(u0[j], u1[j], w[j], wo, n, s, t, r, g1v, NoV, &sp)) {
+            oracle_sh_eval(sp.wi, coef, L);
+            for (int c = 0; c < 3; ++c) {
+                real x = sp.wgt * L[c];
+                S->S0[c] += x; S->S1[c] += x * sp.x5;
+                S->dS0[c] += x * sp.lam; S->dS1[c] += x * sp.lam * sp.x5;
+            }
+        }
+        if (!kinks) continue;
+        /* the sample's two clamped variables and their r-derivatives through theta_h(u0; r)  (:232-233) */
+        const real qq = R(1) / (u0[j] * (alpha2 - R(1)) + R(1));
+        const real c2 = (R(1) - u0[j]) * qq, s2 = alpha2 * u0[j] * qq;
+        const real ct = sqrt(rmax(c2, R(0))), st = sqrt(rmax(s2, R(0)));
+        const real g = R(4) * r * r * r * u0[j] * qq * c2;                 /* d sin^2/dr = -d cos^2/dr */
+        const real stp = st > R(0) ? g / (R(2) * st) : R(0), ctp = ct > R(0) ? -g / (R(2) * ct) : R(0);
+        const real phi = R(2) * O_PI * u1[j], T = cos(phi) * vx + sin(phi) * vy;
+        const real d = st * T + ct * vz, dp = stp * T + ctp * vz;
+        const real wlz = R(2) * d * ct - vz, wlzp = R(2) * (dp * ct + d * ctp);
+        real l[3] = {st * cos(phi), st * sin(phi), ct}, wh[3], wi[3];
+        to_world(s, t, n, l, wh);
+        for (int i = 0; i < 3; ++i) wi[i] = R(2) * d * wh[i] - wo[i];
+        oracle_sh_eval(wi, coef, L);
+        const real dpos = rmax(d, R(0)), nlpos = rmax(wlz, R(0));
+        const real g1l0 = R(1) / (kk + R(1e-6)), g1l = R(1) / (nlpos * (R(1) - kk) + kk + R(1e-6));
+        const real x5 = pow5(R(1) - dpos);
+        real J1 = R(0), J2 = R(0);
+        for (int c = 0; c < 3; ++c) {
+            const real F = C0[c] + (R(1) - C0[c]) * x5, aL = fabs(L[c]);
+            const real K1 = w[j] * g1v * g1l0 * dpos / ct * F * aL, K2 = w[j] * g1v * g1l * nlpos / ct * aL;
+            J1 = rmax(J1, K1 / scale[c]);
+            J2 = rmax(J2, K2 / scale[c]);
+        }
+        lazy_kink(wlz, wlzp, J1 * fabs(wlzp), tol_k, kinks);
+        lazy_kink(d, dp, J2 * fabs(dp), tol_k, kinks);
+    }
+}
+static real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* refresh of one pixel at (clamped) roughness r: new state `st`, the exact render `out`.  The parity scale that weighs kinks and
+ * the measured extrapolation error is taken from what is known BEFORE the samples are walked (so that one walk suffices): the old
+ * state's prediction of the render at r, or the floor alone on a forced (first) refresh, whose intervals are <= rho_init anyway. */
+static void lazy_refresh_pixel(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef, const Rules* q,
+                               const real A[9], real floor_, real tol, const real* old, real* st, real out[3]) {
+    real C0[3], P[3], scale[3], pSD[3], pS1[3];
+    LazySums S, Sh;
+    const real dr = old ? r - old[LZ_RREF] : R(0);
+    for (int c = 0; c < 3; ++c) {
+        C0[c] = (R(1) - m) * R(0.04) + m * a[c];
+        P[c] = A[c] + r * A[3 + c] + r * r * A[6 + c];
+        scale[c] = floor_;
+        if (old) {
+            pSD[c] = old[LZ_SD + c] + old[LZ_GSD + c] * dr;
+            pS1[c] = old[LZ_S1 + c] + old[LZ_GS1 + c] * dr;
+            scale[c] = rmax(fabs(a[c] * (R(1) - m) * P[c] + C0[c] * pSD[c] + pS1[c]), floor_);
+        }
+    }
+    real dir = (old && dr < R(0)) ? R(-1) : R(1);
+    if (r + dir * LAZY_H > R(1) || r + dir * LAZY_H < R(0.07)) dir = -dir;
+    LazyKinks k = {R(1e30), R(1e30)};
+    lazy_sums(wo, n, r, coef, q, &S, &k, C0, scale, tol * LAZY_TOL_K);
+    lazy_sums(wo, n, r + dir * LAZY_H, coef, q, &Sh, NULL, NULL, NULL, R(0));
+    for (int c = 0; c < 3; ++c) {
+        st[LZ_SD + c] = S.S0[c] - S.S1[c];
+        st[LZ_S1 + c] = S.S1[c];
+        st[LZ_GSD + c] = ((Sh.S0[c] - Sh.S1[c]) - st[LZ_SD + c]) / (dir * LAZY_H);
+        st[LZ_GS1 + c] = (Sh.S1[c] - S.S1[c]) / (dir * LAZY_H);
+        st[LZ_DSD + c] = S.dS0[c] - S.dS1[c];
+        st[LZ_DS1 + c] = S.dS1[c];
+        out[c] = a[c] * (R(1) - m) * P[c] + C0[c] * st[LZ_SD + c] + st[LZ_S1 + c];
+    }
+    real rho = LAZY_RHO_INIT;
+    if (old) {
+        rho = old[LZ_RHO];
+        if (fabs(dr) > LAZY_MOVED) {
+            real e = R(0);
+            for (int c = 0; c < 3; ++c)
+                e = rmax(e, fabs(C0[c] * (pSD[c] - st[LZ_SD + c]) + (pS1[c] - st[LZ_S1 + c])) / scale[c]);
+            const real want = R(0.9) * fabs(dr) * sqrt(tol * LAZY_TOL_S / rmax(e, R(1e-12)));
+            rho = clampr(want, R(0.5) * rho, R(2) * rho);
+        }
+    }
+    rho = clampr(rho, LAZY_RHO_MIN, LAZY_RHO_MAX);
+    st[LZ_RREF] = r; st[LZ_LO] = k.lo < rho ? k.lo : rho; st[LZ_HI] = k.hi < rho ? k.hi : rho; st[LZ_RHO] = rho;
+}
+/* the streaming evaluation from a state: render, jac (P, SD, d out/d r as the backward pass uses them), need = 1 when r has left the
+ * validity interval (then out / jac are NOT to be used: the pixel must be refreshed) */
+static int lazy_eval_pixel(const real a[3], real r, real m, const real A[9], const real* st, real out[3], real jac[9]) {
+    const real dr = r - st[LZ_RREF];
+    for (int c = 0; c < 3; ++c) {
+        const real C0 = (R(1) - m) * R(0.04) + m * a[c];
+        const real P = A[c] + r * A[3 + c] + r * r * A[6 + c], dP = A[3 + c] + R(2) * r * A[6 + c];
+        const real SD = st[LZ_SD + c] + st[LZ_GSD + c] * dr, S1 = st[LZ_S1 + c] + st[LZ_GS1 + c] * dr;
+        out[c] = a[c] * (R(1) - m) * P + C0 * SD + S1;
+        jac[c] = P; jac[3 + c] = SD;
+        jac[6 + c] = a[c] * (R(1) - m) * dP + C0 * st[LZ_DSD + c] + st[LZ_DS1 + c];
+    }
+    return (dr < -st[LZ_LO] || dr > st[LZ_HI]) ? 1 : 0;
+}
+/* One lazy forward over N lanes / an image: evaluate from `state` (in/out, [.., LAZY_NSTATE]); lanes that left their interval --
+ * or all of them when `force` is set (first iteration of a part: `state` is not read) -- are refreshed in place.  out[..,3],
+ * jac[..,9] (nullable), refreshed[..] (nullable, int32 flags).  floor_[batch] = the mean-radiance floor of the parity scale. */
+static void lazy_driver(const real* a, const real* r, const real* m, const real* n, const real* light, real* state, real* out, real* jac,
+                        int32_t* refreshed, long P, int batch, int spp, const View* v, const real* floor_, real tol, int force) {
+    Rules q;
+    rules_init(&q, spp);
+#pragma omp parallel for schedule(static)
+    for (long idx = 0; idx < P * batch; ++idx) {
+        long b = idx / P, p = idx % P;
+        real wo[3], nh[3], A[9], jj[9], st_new[LAZY_NSTATE];
+        view_of(v, v->wo ? idx : p, wo);
+        unit_normal(n + idx * 3, nh);
+        const real* coef = light + b * MATPBR_NSH * 3;
+        diffuse_coef(wo, nh, coef, &q, A);
+        real* st = state + idx * LAZY_NSTATE;
+        const real rc = clampr(r[idx], R(0.07), R(1));
+        int need = force ? 1 : lazy_eval_pixel(a + idx * 3, rc, m[idx], A, st, out + idx * 3, jj);
+        if (need) {
+            lazy_refresh_pixel(wo, nh, a + idx * 3, rc, m[idx], coef, &q, A, floor_[b], tol, force ? NULL : st, st_new, out + idx * 3);
+            memcpy(st, st_new, sizeof(st_new));
+            lazy_eval_pixel(a + idx * 3, rc, m[idx], A, st, out + idx * 3, jj);
+        }
+        if (jac) memcpy(jac + idx * 9, jj, sizeof(jj));
+        if (refreshed) refreshed[idx] = need;
+    }
+}
+void oracle_lazy_fwd(const real* a, const real* r, const real* m, const real* n, const real* light, real* state, real* out, real* jac,
+                     int32_t* refreshed, int H, int W, int batch, int spp, real fov_x_deg, const real* floor_, real tol, int force) {
+    View v = {H, W, 0, 0, W, fov_x_deg, NULL};
+    lazy_driver(a, r, m, n, light, state, out, jac, refreshed, (long)H * W, batch, spp, &v, floor_, tol, force);
+}
+void oracle_lazy_fwd_lanes(const real* a, const real* r, const real* m, const real* n, const real* wo, const real* light, real* state,
+                           real* out, real* jac, int32_t* refreshed, long N, int spp, real floor_, real tol, int force) {
+    View v = {0, 0, 0, 0, 1, R(0), wo};
+    lazy_driver(a, r, m, n, light, state, out, jac, refreshed, N, 1, spp, &v, &floor_, tol, force);
+}
+
 /* Per-pixel radiance transfer of the production estimator: R[c] = sum_k light[k][c] T[k][c]; T[B,H,W,25,3]. */
 void oracle_shade_transfer(const real* a, const real* r, const real* m, const real* n, real* T, int H, int W, int batch, int spp,
                            real fov_x_deg) {

@@ -226,6 +226,35 @@ class Oracle:
                                          ctypes.c_int(spp), self._r(fov_deg))
         return out
 
+    # -- lazy re-sampling (specification of csrc/matpbr_lazy.hpp) ---------------------------------
+    def lazy_nstate(self):
+        return int(self.lib.oracle_lazy_nstate())
+
+    def lazy_fwd(self, a, r, m, n, light, state, spp, floor, tol=1.0, force=False, fov_deg=35.0):
+        """One lazy forward of an image batch.  `state` [..., NSTATE] is updated IN PLACE (must be a contiguous array of this
+        oracle's dtype); returns (out [...,3], jac [...,9], refreshed [...] int32)."""
+        a, r, m, n, light = map(self._a, (a, r, m, n, light))
+        B, H, W = self._bhw(a)
+        assert state.dtype == self.dtype and state.flags.c_contiguous and state.shape == a.shape[:-1] + (self.lazy_nstate(),)
+        out = np.empty_like(a)
+        jac = np.empty(a.shape[:-1] + (9,), self.dtype)
+        ref = np.empty(a.shape[:-1], np.int32)
+        fl = self._a(np.broadcast_to(np.asarray(floor, dtype=self.dtype), (B,)))
+        self.lib.oracle_lazy_fwd(*map(self._p, (a, r, m, n, light, state, out, jac, ref)), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(B),
+                                 ctypes.c_int(spp), self._r(fov_deg), self._p(fl), self._r(tol), ctypes.c_int(1 if force else 0))
+        return out, jac, ref
+
+    def lazy_fwd_lanes(self, a, r, m, n, wo, light, state, spp, floor, tol=1.0, force=False):
+        a, r, m, n, wo, light = map(self._a, (a, r, m, n, wo, light))
+        N = a.shape[0]
+        assert state.dtype == self.dtype and state.flags.c_contiguous and state.shape == (N, self.lazy_nstate())
+        out = np.empty_like(a)
+        jac = np.empty((N, 9), self.dtype)
+        ref = np.empty(N, np.int32)
+        self.lib.oracle_lazy_fwd_lanes(*map(self._p, (a, r, m, n, wo, light, state, out, jac, ref)), ctypes.c_long(N), ctypes.c_int(spp),
+                                       self._r(floor), self._r(tol), ctypes.c_int(1 if force else 0))
+        return out, jac, ref
+
     def shade_transfer(self, a, r, m, n, spp, fov_deg=35.0):
         """Per-pixel radiance transfer T[..., 25, 3]: render = sum_k light[k] * T[k]."""
         a, r, m, n = map(self._a, (a, r, m, n))
