@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MATPBR_VERSION 200 /* 0.2.0 */
+#define MATPBR_VERSION 300 /* 0.3.0 */
 #define MATPBR_MAX_SPP 128
 #define MATPBR_NSH 25
 
@@ -52,6 +52,8 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
                                            nodes (their half-vector angles move with r, and with them wi, the weights and the radiance),
                                            the convention of the live reference (myutils/mi_plugin.py:227-230,1335-1341), instead of the
                                            stop-gradient convention of the default.  d_a, d_m, d_n, d_light do not change. */
+#define MATPBR_FLAG_LAZY_FORCE 16u /* matpbr_shade_fwd_lazy: rebuild the model of every pixel (first render of a part; `lazy_state` is not read) */
+#define MATPBR_FLAG_JAC16 32u      /* matpbr_brdf_loss_bwd_jac: `jac` holds the half-precision planes written by matpbr_shade_fwd_lazy */
 #define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
 #define MATPBR_PART_R 4u
 #define MATPBR_PART_M 8u
@@ -105,6 +107,32 @@ int matpbr_shade_fwd_keep(const float* a, const float* r, const float* m, const 
                           const MatpbrCamera* cam, uint32_t flags, void* stream);
 int matpbr_shade_fwd_cached(const float* a, const float* m, const float* jac, const float* s1, float* out_rgb, int H, int W, int batch,
                             uint32_t flags, void* stream);
+
+/* The same render WITHOUT walking the GGX samples of every pixel in every iteration, for the parts of --opt_order that move the roughness
+ * (inverse_img_w_mi.py:371-386, 493-515).  Light and shading normals are fixed during a BRDF phase (:317-342), so the specular sums of a
+ * pixel are functions of its roughness alone, and Adam moves the roughness by 1e-4 .. 3e-4 per step.  `lazy_state`
+ * (matpbr_lazy_state_bytes(); opaque, owned by the caller, must persist between calls) holds a local model per pixel: the sums at the
+ * roughness r_ref they were last sampled at, their slopes in r, the r-derivatives of the backward convention, and a validity
+ * interval around r_ref.  A call renders every pixel whose roughness is still inside its interval from the model (a streaming pass),
+ * walks the samples of the others again (1-2 % of the pixels per iteration on recorded runs), rebuilds their models, and writes
+ *   out_rgb  the render; differs from matpbr_shade_fwd_ex by < 1e-3 max(|exact|, mean|exact|) on every pixel (the intervals are built
+ *            for a quarter of that; oracle/matpbr_oracle.c `lazy_refresh_pixel` is the specification, tests/test_gpu_lazy.py the gate)
+ *   jac16    5 planes of B*H*W 32-bit words: half2 (P_c, S0_c - S1_c) x rgb, half2 (JR_0, JR_1), half2 (JR_2, 0), what
+ *            matpbr_brdf_loss_bwd_jac(..., MATPBR_FLAG_JAC16) reads (matpbr_plane9_bytes() is room enough)
+ *   sums     (nullable) [B][matpbr_lazy_sums_count()] partial sums of out_rgb, for mean(pred) (:388)
+ * `dcache` = matpbr_diffuse_cache(n, light); flags: MATPBR_FLAG_CLAMP_PARAMS, MATPBR_FLAG_LAZY_FORCE (first call with this state, or after
+ * light / normals / dcache changed).  The parity scale needs the mean radiance of the image: with `stats` (layout above, nullable) it is
+ * 0.5 (stats[15] / stats[0]) / (3 H W) per image, else `floor` (> 0).  `tol` scales the interval tolerances (1 = as specified).
+ *   matpbr_lazy_state_unpack  test / inspection: the models in the oracle's layout [B*H*W][22] (r_ref, lo, hi, rho, SD, S1, gSD, gS1,
+ *                             dSD, dS1) and / or refreshed[B*H*W] = 1 for the pixels whose samples the last call walked
+ *   matpbr_jac16_unpack       jac16 -> the nine fp32 planes of matpbr_shade_fwd_ex's `jac` */
+size_t matpbr_lazy_state_bytes(int H, int W, int batch);
+int matpbr_lazy_sums_count(int H, int W);
+int matpbr_shade_fwd_lazy(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind, int n_light,
+                          const float* dcache, void* lazy_state, float* out_rgb, void* jac16, const float* stats, float* sums, int H, int W,
+                          int batch, int spp, const MatpbrCamera* cam, uint32_t flags, float floor, float tol, void* stream);
+int matpbr_lazy_state_unpack(const void* lazy_state, float* state22, int* refreshed, int H, int W, int batch, void* stream);
+int matpbr_jac16_unpack(const void* jac16, float* jac, int H, int W, int batch, void* stream);
 
 /* Backward render.  Replaces the AD pass that `loss.backward()` drives through dr.wrap_ad / mi.render
  * (inverse_img_w_mi.py:59,69,248,420,544).  Any of d_a/d_r/d_m (all three or none), d_n, d_light may be
@@ -172,6 +200,16 @@ typedef struct MatpbrBrdfPhase {
                                              roughness, normals and light are constants of the part (:317-342): the step with t == 1 walks
                                              the samples and keeps the specular sums here and in `jac`; later steps combine them
                                              (bit-identical render, no samples).  The caller must not touch pr / jac / s1cache in between. */
+    void* lazy_state;                     /* nullable, matpbr_lazy_state_bytes(): when part_mask has MATPBR_PART_R (and dcache is given) the
+                                             render of every step is matpbr_shade_fwd_lazy (the step with t == 1 builds the models) and `jac`
+                                             holds its half-precision planes.  NULL: every step walks the samples of every pixel. */
+    float lazy_tol;                       /* scales the interval tolerances of the lazy render; <= 0: 1 */
+    float* pred_next;                     /* nullable [B,H,W,3], with lazy_state: the step's last launch is the backward pass + Adam of this iteration AND
+                                             the render of the next one from the updated parameters (maps, models and Adam state are read once per
+                                             iteration; no jac planes).  On return `pred` holds this iteration's render as always and `pred_next` the
+                                             next one (pixels that left their model's interval pending); the caller SWAPS pred and pred_next before the
+                                             next step, calls the steps with t = 1, 2, 3, ... and leaves workspace / lazy_state / pr / pm alone in between.
+                                             The SaveBest snapshot of a map that the part does not optimise is not rewritten. */
 } MatpbrBrdfPhase;
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);

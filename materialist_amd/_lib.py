@@ -23,7 +23,8 @@ class MatpbrBrdfPhase(ctypes.Structure):
                 [(k, ctypes.c_void_p) for k in ("best_a", "best_r", "best_m", "best_img", "stats", "history", "workspace")] +
                 [("workspace_bytes", ctypes.c_size_t), ("H", ctypes.c_int), ("W", ctypes.c_int), ("batch", ctypes.c_int), ("spp", ctypes.c_int),
                  ("fov_x_deg", ctypes.c_float), ("scale_delta", ctypes.c_float), ("part_mask", ctypes.c_uint32), ("es_patience", ctypes.c_int),
-                 ("es_min_delta", ctypes.c_float), ("hist_len", ctypes.c_int), ("s1cache", ctypes.c_void_p)])
+                 ("es_min_delta", ctypes.c_float), ("hist_len", ctypes.c_int), ("s1cache", ctypes.c_void_p), ("lazy_state", ctypes.c_void_p),
+                 ("lazy_tol", ctypes.c_float), ("pred_next", ctypes.c_void_p)])
 
 
 class MatpbrError(RuntimeError):
@@ -48,6 +49,12 @@ SIGNATURES = {
     "matpbr_shade_fwd_cached": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]),
     "matpbr_diffuse_cache": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(MatpbrCamera), ctypes.c_void_p]),
+    "matpbr_lazy_state_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "matpbr_lazy_sums_count": (ctypes.c_int, [ctypes.c_int] * 2),
+    "matpbr_shade_fwd_lazy": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(MatpbrCamera), ctypes.c_uint32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
+    "matpbr_lazy_state_unpack": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_jac16_unpack": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_shade_bwd_jac": (ctypes.c_int, [_c_f] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_brdf_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_brdf_loss_stats": (ctypes.c_int, [_c_f] * 9 + [ctypes.c_float, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,

@@ -19,6 +19,7 @@
 #include "../../include/matpbr.h"
 #include "matpbr_device.hpp"
 #include "matpbr_shade.hpp"
+#include "matpbr_lazy.hpp"
 
 using namespace matpbr;
 
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
                                                             const float* __restrict__ a0, const float* __restrict__ pr,
                                                             const float* __restrict__ r0, const float* __restrict__ pm,
                                                             const float* __restrict__ m0, float* __restrict__ part, long n3, long n1,
-                                                            const float* __restrict__ fwd_sums, int n_fwd) {
+                                                            const float* __restrict__ fwd_sums, int n_fwd, unsigned part_mask) {
     __shared__ float s_buf[4];
     const int b = blockIdx.y;
     float ratio = 1.0f;
@@ -78,12 +79,13 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
         float d = xs - gt_srgb[b * n3 + i];
         s[0] = fmaf(d, d, s[0]);
         s[1] += fabsf(d);
-        s[2] += fabsf(fminf(fmaxf(pa[b * n3 + i], 0.0f), 1.0f) - a0[b * n3 + i]);
+        if (part_mask & MATPBR_PART_A) s[2] += fabsf(fminf(fmaxf(pa[b * n3 + i], 0.0f), 1.0f) - a0[b * n3 + i]);   // a regulariser counts only in its part (:398-409)
     }
-    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n1; i += (long)gridDim.x * kBlock) {
-        s[3] += fabsf(fminf(fmaxf(pr[b * n1 + i], 0.07f), 1.0f) - r0[b * n1 + i]);
-        s[4] += fabsf(fminf(fmaxf(pm[b * n1 + i], 0.0f), 1.0f) - m0[b * n1 + i]);
-    }
+    if (part_mask & (MATPBR_PART_R | MATPBR_PART_M))
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n1; i += (long)gridDim.x * kBlock) {
+            if (part_mask & MATPBR_PART_R) s[3] += fabsf(fminf(fmaxf(pr[b * n1 + i], 0.07f), 1.0f) - r0[b * n1 + i]);
+            if (part_mask & MATPBR_PART_M) s[4] += fabsf(fminf(fmaxf(pm[b * n1 + i], 0.0f), 1.0f) - m0[b * n1 + i]);
+        }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         float v = block_sum(s[k], s_buf);
@@ -1018,6 +1020,95 @@ int matpbr_normals_from_depth(const float* depth, float* out_n, int H, int W, in
     return launch_status();
 }
 
+// ---- lazy re-sampling (matpbr_lazy.hpp) ---------------------------------------------------------
+size_t matpbr_lazy_state_bytes(int H, int W, int batch) {
+    if (H <= 0 || W <= 0 || batch <= 0) return 0;
+    const long P = (long)H * W;
+    return lazy_planes_bytes(P, batch) + lazy_counts_bytes(P, batch) + lazy_lists_bytes(P, batch);
+}
+int matpbr_lazy_sums_count(int H, int W) {
+    if (H <= 0 || W <= 0) return 0;
+    return lazy_fwd_blocks((long)H * W) + lazy_groups((long)H * W);
+}
+
+static long long* g_lazy_dbg = nullptr;
+extern "C" void matpbr_dbg_set(long long* p) { g_lazy_dbg = p; }
+struct LazyBuffers { uint32_t* planes; uint32_t* counts; uint16_t* lists; int nblk, ngrp; };
+static LazyBuffers lazy_buffers(void* lazy_state, long P, int batch) {
+    LazyBuffers lb;
+    lb.planes = (uint32_t*)lazy_state;
+    lb.counts = (uint32_t*)((char*)lazy_state + lazy_planes_bytes(P, batch));
+    lb.lists = (uint16_t*)((char*)lb.counts + lazy_counts_bytes(P, batch));
+    lb.nblk = lazy_fwd_blocks(P);
+    lb.ngrp = lazy_groups(P);
+    return lb;
+}
+// re-sample the pixels of the current work lists, rebuild their models, patch out / jac16 / sums
+static int lazy_refresh(const float* a, const float* r, const float* m, const float* n, const float* light, const float* dcache, void* lazy_state,
+                        float* out_rgb, void* jac16, const float* stats, float* sums, const Geom& g, const RuleTable& tab, int batch, int clamp,
+                        int force, float floor_, float tol, hipStream_t st) {
+    const long P = (long)g.H * g.W;
+    const LazyBuffers lb = lazy_buffers(lazy_state, P, batch);
+    LazyRefreshArgs ra{};
+    ra.a = a; ra.r = r; ra.m = m; ra.n = n; ra.dcache = dcache; ra.state = lb.planes; ra.out = out_rgb; ra.jac16 = (uint32_t*)jac16; ra.stats = stats;
+    ra.block_sums = sums; ra.counts = lb.counts; ra.lists = lb.lists; ra.clamp = clamp; ra.force = force; ra.n_sums = lb.nblk + lb.ngrp;
+    ra.n_fwd = lb.nblk; ra.nblk = lb.nblk; ra.floor = floor_; ra.tol = tol > 0.0f ? tol : 1.0f;
+    ra.dbg = g_lazy_dbg;
+    if (tab.nphi_s <= 4)
+        hipLaunchKernelGGL(lazy_refresh_kernel<4>, dim3((unsigned)lb.ngrp, (unsigned)batch), dim3(kBlock), 0, st, ra, light, g, tab);
+    else
+        hipLaunchKernelGGL(lazy_refresh_kernel<8>, dim3((unsigned)lb.ngrp, (unsigned)batch), dim3(kBlock), 0, st, ra, light, g, tab);
+    return launch_status();
+}
+static int lazy_forward(const float* a, const float* r, const float* m, const float* n, const float* light, const float* dcache, void* lazy_state,
+                        float* out_rgb, void* jac16, const float* stats, float* sums, const Geom& g, const RuleTable& tab, int batch, int clamp,
+                        int force, float floor_, float tol, hipStream_t st) {
+    const long P = (long)g.H * g.W;
+    const LazyBuffers lb = lazy_buffers(lazy_state, P, batch);
+    if (lb.nblk > kLazyMaxBlocks) return MATPBR_ERR_UNSUPPORTED;
+    LazyFwdArgs fa{};
+    fa.a = a; fa.r = r; fa.m = m; fa.state = lb.planes; fa.out = out_rgb; fa.jac16 = (uint32_t*)jac16; fa.stats = stats; fa.block_sums = sums;
+    fa.counts = lb.counts; fa.lists = lb.lists; fa.clamp = clamp; fa.force = force; fa.n_sums = lb.nblk + lb.ngrp;
+    hipLaunchKernelGGL(lazy_fwd_kernel, dim3((unsigned)lb.nblk, (unsigned)batch), dim3(kBlock), 0, st, fa, (int)P);
+    return lazy_refresh(a, r, m, n, light, dcache, lazy_state, out_rgb, jac16, stats, sums, g, tab, batch, clamp, force, floor_, tol, st);
+}
+
+int matpbr_shade_fwd_lazy(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind, int n_light,
+                          const float* dcache, void* lazy_state, float* out_rgb, void* jac16, const float* stats, float* sums, int H, int W,
+                          int batch, int spp, const MatpbrCamera* cam, uint32_t flags, float floor_, float tol, void* stream) {
+    if (!a || !r || !m || !n || !light || !dcache || !lazy_state || !out_rgb || !jac16 || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+    if (!sh25(light_kind, n_light)) return MATPBR_ERR_INVALID_ARG;
+    if (!valid_spp(spp)) return MATPBR_ERR_UNSUPPORTED;
+    if (!stats && !(floor_ > 0.0f)) return MATPBR_ERR_INVALID_ARG;
+    Geom g;
+    RuleTable tab;
+    if (!make_geom(H, W, cam, g)) return MATPBR_ERR_INVALID_ARG;
+    if (!fill_rule_table(spp, tab)) return MATPBR_ERR_UNSUPPORTED;
+    return lazy_forward(a, r, m, n, light, dcache, lazy_state, out_rgb, jac16, stats, sums, g, tab, batch, (flags & MATPBR_FLAG_CLAMP_PARAMS) ? 1 : 0,
+                        (flags & MATPBR_FLAG_LAZY_FORCE) ? 1 : 0, floor_, tol, (hipStream_t)stream);
+}
+
+int matpbr_lazy_state_unpack(const void* lazy_state, float* state22, int* refreshed, int H, int W, int batch, void* stream) {
+    if (!lazy_state || (!state22 && !refreshed) || H <= 0 || W <= 0 || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+    const long P = (long)H * W, BP = P * batch;
+    const uint32_t* counts = (const uint32_t*)((const char*)lazy_state + lazy_planes_bytes(P, batch));
+    const uint16_t* lists = (const uint16_t*)((const char*)counts + lazy_counts_bytes(P, batch));
+    if (state22)
+        hipLaunchKernelGGL(lazy_unpack_kernel, dim3((unsigned)((BP + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const uint32_t*)lazy_state, state22, BP);
+    if (refreshed)
+        hipLaunchKernelGGL(lazy_refreshed_kernel, dim3((unsigned)lazy_fwd_blocks(P), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, counts, lists,
+                           refreshed, (int)P, lazy_fwd_blocks(P));
+    return launch_status();
+}
+
+int matpbr_jac16_unpack(const void* jac16, float* jac, int H, int W, int batch, void* stream) {
+    if (!jac16 || !jac || H <= 0 || W <= 0 || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+    const long BP = (long)H * W * batch;
+    hipLaunchKernelGGL(jac16_unpack_kernel, dim3((unsigned)((BP + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, (const uint32_t*)jac16, jac, BP);
+    return launch_status();
+}
+
 size_t matpbr_brdf_loss_workspace_bytes(int batch) { return batch > 0 ? (size_t)batch * kRedBlocks * 5 * sizeof(float) : 0; }
 
 static unsigned part_mask_of(uint32_t flags) {
@@ -1038,7 +1129,7 @@ int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_s
     hipLaunchKernelGGL(loss_sums1_kernel, grid, dim3(kBlock), 0, st, pred, gt, part, n3);
     hipLaunchKernelGGL(loss_final1_kernel, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks);
     hipLaunchKernelGGL(loss_sums2_kernel<0>, grid, dim3(kBlock), 0, st, pred, gt_srgb, stats, pa, a0, pr, r0, pm, m0, part, n3, n1,
-                       (const float*)nullptr, 0);
+                       (const float*)nullptr, 0, part_mask_of(flags));
     hipLaunchKernelGGL(loss_final2_kernel<0>, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks, 1.0f / (float)n3,
                        1.0f / (float)n1, scale_delta, part_mask_of(flags), 0, 0.0f,
                        (const float*)nullptr, 0, (float*)nullptr, 0, batch);
@@ -1062,14 +1153,16 @@ int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, 
     q.inv_n1 = 1.0f / ((float)H * (float)W);
     q.part_mask = part_mask_of(flags);
     const long P = (long)H * W;
-    hipLaunchKernelGGL(jac_bwd_kernel<true>, dim3((unsigned)((P + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, q,
-                       P);
+    if (flags & MATPBR_FLAG_JAC16)
+        hipLaunchKernelGGL((jac_bwd_kernel<true, true>), dim3((unsigned)((P + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, q, P);
+    else
+        hipLaunchKernelGGL((jac_bwd_kernel<true, false>), dim3((unsigned)((P + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, q, P);
     return launch_status();
 }
 
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
     if (H <= 0 || W <= 0 || batch <= 0) return 0;
-    return ((size_t)batch * grid_blocks(H, W) + (size_t)batch * kRedBlocks * 5) * sizeof(float);
+    return ((size_t)batch * (grid_blocks(H, W) + lazy_groups((long)H * W)) + (size_t)batch * kRedBlocks * 5) * sizeof(float);
 }
 
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* stream) {
@@ -1087,11 +1180,15 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     if (!make_geom(q.H, q.W, &cam, g)) return MATPBR_ERR_INVALID_ARG;
     if (!fill_rule_table(q.spp, tab)) return MATPBR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int nfwd = grid_blocks(q.H, q.W);
+    // the parts that move the roughness render from per-pixel local models when the caller provides their storage (matpbr_lazy.hpp)
+    const bool lazy = q.lazy_state != nullptr && (q.part_mask & MATPBR_PART_R) && q.dcache != nullptr &&
+                      lazy_fwd_blocks((long)q.H * q.W) <= kLazyMaxBlocks;
+    const bool lazy_fused = lazy && q.pred_next != nullptr;   // backward of this iteration and forward of the next one in one launch
+    const int nfwd = grid_blocks(q.H, q.W) + (lazy ? lazy_groups((long)q.H * q.W) : 0);
     float* fwd_sums = (float*)q.workspace;
     float* part = fwd_sums + (size_t)q.batch * nfwd;
     const long n1 = (long)q.H * q.W, n3 = n1 * 3;
-    dim3 grid((unsigned)nfwd, (unsigned)q.batch);
+    dim3 grid((unsigned)grid_blocks(q.H, q.W), (unsigned)q.batch);
     // 1. render with the clamped parameters (:371-386): specular samples only when the diffuse coefficients are cached;
     //    writes the jac planes and per-workgroup sums for mean(pred)
     ShadeArgs sa{};
@@ -1101,14 +1198,24 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     // (t == 1) walks the samples and keeps them (jac planes + s1cache), the others combine them (bit-identical, no samples)
     const bool r_fixed = !(q.part_mask & MATPBR_PART_R) && q.s1cache != nullptr;
     sa.s1 = r_fixed ? q.s1cache : nullptr;
-    if (r_fixed && t > 1)
+    if (lazy_fused && t > 1) {
+        // pred already holds this iteration's render (written by the previous step's launch as pred_next; the caller swapped the two): only
+        // the pixels that left their model's interval are pending
+        const int rc = lazy_refresh(q.pa, q.pr, q.pm, q.n, q.light, q.dcache, q.lazy_state, q.pred, nullptr, q.stats, fwd_sums, g, tab, q.batch, 1, 0,
+                                    0.0f, q.lazy_tol, st);
+        if (rc != MATPBR_OK) return rc;
+    } else if (lazy) {
+        const int rc = lazy_forward(q.pa, q.pr, q.pm, q.n, q.light, q.dcache, q.lazy_state, q.pred, q.jac, q.stats, fwd_sums, g, tab, q.batch, 1,
+                                    t == 1 ? 1 : 0, 0.0f, q.lazy_tol, st);
+        if (rc != MATPBR_OK) return rc;
+    } else if (r_fixed && t > 1)
         hipLaunchKernelGGL(shade_cached_kernel, grid, dim3(kBlock), 0, st, sa, g);
     else
         hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, sa, q.light, g, tab);
     // 2. loss statistics, SaveBest / EarlyStopping decisions (:388-418, misc.py:37-97)
     hipLaunchKernelGGL(loss_sums2_kernel<1>, dim3(kRedBlocks, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                        (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
-                       (const float*)fwd_sums, nfwd);
+                       (const float*)fwd_sums, nfwd, q.part_mask);
     hipLaunchKernelGGL(loss_final2_kernel<1>, dim3((unsigned)q.batch), dim3(kBlock), 0, st, (const float*)part, q.stats, kRedBlocks,
                        1.0f / (float)n3, 1.0f / (float)n1, q.scale_delta, q.part_mask, q.es_patience, q.es_min_delta, (const float*)fwd_sums, nfwd,
                        q.history, q.hist_len, q.batch);
@@ -1125,7 +1232,18 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     jb.scale_delta = q.scale_delta; jb.inv_n3 = 1.0f / (float)n3; jb.inv_n1 = 1.0f / (float)n1; jb.part_mask = q.part_mask;
     jb.lr_over_bc1 = (float)(lr / bc1); jb.b1 = b1; jb.b2 = b2; jb.eps = eps; jb.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
     jb.check_stop = 1;
-    hipLaunchKernelGGL(jac_bwd_kernel<true>, dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);
+    if (lazy_fused) {
+        const LazyBuffers lb = lazy_buffers(q.lazy_state, n1, q.batch);
+        LazyStepArgs ls{};
+        ls.j = jb;
+        for (int k = 0; k < kLzPlanes; ++k) ls.plane[k] = lb.planes + (size_t)k * (size_t)q.batch * (size_t)n1;
+        ls.pred_next = q.pred_next; ls.block_sums = fwd_sums; ls.counts = lb.counts; ls.lists = lb.lists;
+        ls.n_sums = lb.nblk + lb.ngrp;
+        hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, (int)n1);
+    } else if (lazy)
+        hipLaunchKernelGGL((jac_bwd_kernel<true, true>), dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);
+    else
+        hipLaunchKernelGGL((jac_bwd_kernel<true, false>), dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);
     return launch_status();
 }
 

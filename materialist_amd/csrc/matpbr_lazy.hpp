@@ -1,0 +1,587 @@
+// matpbr_lazy.hpp -- hot loop B without walking the GGX samples of every pixel in every iteration (gfx950, wave64, fp32).
+//
+// In the parts of --opt_order that move the roughness (inverse_img_w_mi.py:371-386 / 493-515) light and shading normals are fixed
+// (:317-342), so the specular sums S0, S1 of a pixel are functions of its roughness alone -- and Adam moves r by 1e-4 .. 3e-4 per
+// step.  Each pixel keeps a LOCAL MODEL around the roughness r_ref its 20 samples were last walked at:
+//     P, SD = S0 - S1, S1 at r_ref (fp32);  their slopes P', gSD, gS1 and A2 (P is a quadratic in r), and the detached r-derivatives
+//     dSD, dS1 of the backward convention (fp16: they only multiply dr = r - r_ref <= 0.03);  a validity interval [r_ref - lo, r_ref + hi].
+// lazy_fwd_kernel renders out = a (1-m) P(r) + C0 SD(r) + S1(r) from the model -- a streaming kernel -- writes the half-precision
+// jac planes of the backward pass, and lists the pixels that have left their interval; lazy_refresh_kernel walks the samples of the
+// listed pixels only (1-2 % of the image per iteration on recorded runs), rebuilds their models and patches their render.
+// oracle/matpbr_oracle.c (lazy_refresh_pixel / lazy_eval_pixel) is the specification: interval construction (step-size control for
+// the smooth part, first-order prediction of the horizon / back-facing crossings of every sample for the kinks) is explained there.
+// Gate (tests/test_gpu_lazy.py): |lazy - exact| <= 1e-3 max(|exact|, mean|exact|) on every pixel in every iteration.
+#pragma once
+#include "matpbr_shade.hpp"
+
+namespace matpbr {
+
+// ---- constants of the specification (oracle/matpbr_oracle.c LAZY_*) --------------------------------------------------------
+constexpr float kLzH = 1e-3f, kLzRhoInit = 2e-3f, kLzRhoMin = 2.5e-4f, kLzRhoMax = 3e-2f, kLzTolS = 2.5e-4f, kLzTolK = 1.5e-4f;
+constexpr float kLzKinkSafety = 0.8f, kLzMoved = 1e-4f;
+
+// ---- state: 32-bit planes of B*P entries (a lane's two pixels are an 8-byte access, a wave's access is 512 contiguous bytes) ----
+enum { kLzRref = 0, kLzLoHi = 1 /* half2 (lo, hi) */, kLzRho = 2, kLzP = 3, kLzSD = 6, kLzS1 = 9,
+       kLzPk = 12 /* half2 (P', A2) */, kLzSk = 15 /* half2 (gSD, gS1) */, kLzDk = 18 /* half2 (dSD, dS1) */, kLzPlanes = 21 };
+// jac16: 5 planes, half2 (P_c, SD_c) for c = 0..2, half2 (JR_0, JR_1), half2 (JR_2, 0)
+constexpr int kJac16Planes = 5;
+constexpr int kLazyBlockPixels = 2 * kBlock;
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) { return __builtin_bit_cast(uint32_t, h2{(_Float16)lo, (_Float16)hi}); }
+__device__ __forceinline__ float h2_lo(uint32_t u) { return (float)__builtin_bit_cast(h2, u).x; }
+__device__ __forceinline__ float h2_hi(uint32_t u) { return (float)__builtin_bit_cast(h2, u).y; }
+__device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__host__ __device__ inline int lazy_fwd_blocks(long P) { return (int)((P + kLazyBlockPixels - 1) / kLazyBlockPixels); }
+// workgroups of the refresh kernel per image (each takes every lazy_groups()-th chunk of the image's work list; also the number of
+// partial sums it contributes): enough to fill the GPU when a few per cent of a 512 x 512 image are listed, few enough to be cheap when none is
+__host__ __device__ inline int lazy_groups(long P) { const int n = lazy_fwd_blocks(P) / 4; return n < 16 ? 16 : (n > 256 ? 256 : n); }
+// [planes][counts: B * nblk u32][lists: B * nblk * 512 u16]
+inline size_t lazy_planes_bytes(long P, int batch) { return (size_t)kLzPlanes * (size_t)batch * (size_t)P * 4; }
+inline size_t lazy_counts_bytes(long P, int batch) { return (size_t)batch * (size_t)lazy_fwd_blocks(P) * 4; }
+inline size_t lazy_lists_bytes(long P, int batch) { return (size_t)batch * (size_t)lazy_fwd_blocks(P) * kLazyBlockPixels * 2; }
+
+// =================================================================================================
+// streaming forward from the per-pixel models
+// =================================================================================================
+struct LazyFwdArgs {
+    const float *a, *r, *m;
+    const uint32_t* state;
+    float* out;
+    uint32_t* jac16;
+    const float* stats;       // nullable: skip images whose EarlyStopping has fired
+    float* block_sums;        // nullable [B][n_sums]: slot blockIdx.x = sum of the rgb this workgroup rendered (listed pixels excluded)
+    uint32_t* counts;
+    uint16_t* lists;
+    int clamp, force, n_sums;
+};
+
+__global__ __launch_bounds__(kBlock) void lazy_fwd_kernel(const LazyFwdArgs q, int P) {
+    __shared__ float s_sum[4];
+    __shared__ int s_cnt[4];
+    const int b = blockIdx.y;
+    if (q.stats && img_stopped(q.stats, b)) return;
+    const long BP = (long)gridDim.y * P;
+    const int q0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
+    const bool act0 = q0 < P, two = q0 + 1 < P;
+    const int p0 = act0 ? q0 : P - 1, p1 = two ? q0 + 1 : p0;
+    const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
+    bool need0 = act0, need1 = two;
+    float tot = 0.0f;
+    if (!q.force) {
+        f2 a[3], r = f2{q.r[i0], q.r[i1]}, m = f2{q.m[i0], q.m[i1]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[c] = f2{q.a[i0 * 3 + c], q.a[i1 * 3 + c]};
+        if (q.clamp) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[c] = clamp2(a[c], 0.0f, 1.0f);
+            r = clamp2(r, 0.07f, 1.0f);
+            m = clamp2(m, 0.0f, 1.0f);
+        }
+        const uint32_t* __restrict__ S = q.state;
+        const f2 dr = r - f2{as_f(S[kLzRref * BP + i0]), as_f(S[kLzRref * BP + i1])};
+        const uint32_t lh0 = S[kLzLoHi * BP + i0], lh1 = S[kLzLoHi * BP + i1];
+        need0 = act0 && !(dr.x >= -h2_lo(lh0) && dr.x <= h2_hi(lh0));
+        need1 = two && !(dr.y >= -h2_lo(lh1) && dr.y <= h2_hi(lh1));
+        const f2 omm = 1.0f - m;
+        f2 JR[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f2 Pv = f2{as_f(S[(kLzP + c) * BP + i0]), as_f(S[(kLzP + c) * BP + i1])};
+            const f2 SDv = f2{as_f(S[(kLzSD + c) * BP + i0]), as_f(S[(kLzSD + c) * BP + i1])};
+            const f2 S1v = f2{as_f(S[(kLzS1 + c) * BP + i0]), as_f(S[(kLzS1 + c) * BP + i1])};
+            const uint32_t pk0 = S[(kLzPk + c) * BP + i0], pk1 = S[(kLzPk + c) * BP + i1];
+            const uint32_t sk0 = S[(kLzSk + c) * BP + i0], sk1 = S[(kLzSk + c) * BP + i1];
+            const uint32_t dk0 = S[(kLzDk + c) * BP + i0], dk1 = S[(kLzDk + c) * BP + i1];
+            const f2 dP0 = f2{h2_lo(pk0), h2_lo(pk1)}, A2 = f2{h2_hi(pk0), h2_hi(pk1)};
+            const f2 Pc = vfma(vfma(A2, dr, dP0), dr, Pv);                        // P(r) = P + P' dr + A2 dr^2 (exact quadratic)
+            const f2 dP = vfma(2.0f * A2, dr, dP0);
+            const f2 SD = vfma(f2{h2_lo(sk0), h2_lo(sk1)}, dr, SDv);
+            const f2 S1 = vfma(f2{h2_hi(sk0), h2_hi(sk1)}, dr, S1v);
+            const f2 C0 = vfma(m, a[c], omm * 0.04f);                                // :1412
+            const f2 rgb = vfma(a[c] * omm, Pc, vfma(C0, SD, S1));
+            JR[c] = vfma(a[c] * omm, dP, vfma(C0, f2{h2_lo(dk0), h2_lo(dk1)}, f2{h2_hi(dk0), h2_hi(dk1)}));
+            if (act0 && !need0) { q.out[i0 * 3 + c] = rgb.x; q.jac16[c * BP + i0] = pack_h2(Pc.x, SD.x); tot += rgb.x; }
+            if (two && !need1) { q.out[i1 * 3 + c] = rgb.y; q.jac16[c * BP + i1] = pack_h2(Pc.y, SD.y); tot += rgb.y; }
+        }
+        if (act0 && !need0) { q.jac16[3 * BP + i0] = pack_h2(JR[0].x, JR[1].x); q.jac16[4 * BP + i0] = pack_h2(JR[2].x, 0.0f); }
+        if (two && !need1) { q.jac16[3 * BP + i1] = pack_h2(JR[0].y, JR[1].y); q.jac16[4 * BP + i1] = pack_h2(JR[2].y, 0.0f); }
+    }
+    // the pixels that left their interval, compacted in a fixed order (wave, then first / second pixel of the lanes): the list's
+    // order never enters a result, and it is reproducible all the same
+    const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n0 = __popcll(b0), nw = n0 + __popcll(b1);
+    if (q.block_sums) tot = wave_sum_to_lane63(tot);
+    if (lane == 63) { s_cnt[wave] = nw; s_sum[wave] = tot; }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) base += w < wave ? s_cnt[w] : 0;
+    uint16_t* list = q.lists + ((long)b * gridDim.x + blockIdx.x) * kLazyBlockPixels;
+    if (need0) list[base + __popcll(b0 & below)] = (uint16_t)(2 * threadIdx.x);
+    if (need1) list[base + n0 + __popcll(b1 & below)] = (uint16_t)(2 * threadIdx.x + 1);
+    if (threadIdx.x == 0) {
+        q.counts[(long)b * gridDim.x + blockIdx.x] = (uint32_t)((s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]));
+        if (q.block_sums) q.block_sums[(long)b * q.n_sums + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    }
+}
+
+// =================================================================================================
+// one launch per iteration of hot loop B: backward of iteration t + Adam + forward of iteration t+1
+// =================================================================================================
+// With the models in HBM the render is a function of (a, r, m, model) that costs a few FMAs, so the streaming backward pass of
+// iteration t (jac_bwd_kernel<FUSED>: d loss / d pred from pred_t, the target and the statistics; material gradients; regularisers;
+// clamp gating; SaveBest snapshot; Adam) renders iteration t+1 from the parameters it has just updated while the pixel's model is
+// still in registers: the maps, the models and the Adam state are read once per iteration, and the jac planes disappear (P, SD and
+// d out / d r at r_t are re-formed from the model, which is what the forward of iteration t rendered from).  Pixels whose new
+// roughness has left their interval are listed for lazy_refresh_kernel, which patches pred_{t+1} at the head of the next step.
+// In parts that do not optimise the albedo the SaveBest snapshot of the albedo is not rewritten (it cannot have changed).
+struct LazyStepArgs {
+    JacBwdArgs j;             // as for jac_bwd_kernel<FUSED> (jac unused; pred = pred_t, complete)
+    const uint32_t* plane[kLzPlanes];   // the model planes, one base pointer each (scalar operands of the loads)
+    float* pred_next;         // [B,H,W,3] render of the updated parameters (listed pixels pending)
+    float* block_sums;        // [B][n_sums]: slot blockIdx.x
+    uint32_t* counts;
+    uint16_t* lists;
+    int n_sums;
+};
+
+// Loads / stores at (wave-uniform base pointer) + (32-bit per-lane byte offset): the form the hardware addresses directly
+// (global_load ... v_off, s[base]); indexing 21 planes through 64-bit per-lane arithmetic costs more VALU issue slots than the
+// arithmetic of the step itself.  Byte offsets stay below 2^32 (12 B x B*H*W: 357 M pixels).
+__device__ __forceinline__ uint32_t ldu(const void* base, unsigned off) { return *(const uint32_t*)((const char*)base + off); }
+__device__ __forceinline__ float ldf(const void* base, unsigned off) { return *(const float*)((const char*)base + off); }
+__device__ __forceinline__ void stf(void* base, unsigned off, float v) { *(float*)((char*)base + off) = v; }
+
+// one pixel of lazy_step_kernel; returns whether the pixel's new roughness has left its model's interval, adds its render to `tot`
+__device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned i, float ratio, float sr, bool improved, float& tot) {
+    const JacBwdArgs& q = qs.j;
+    const unsigned o1 = i * 4u, o3 = i * 12u;
+    const float ra[3] = {ldf(q.a, o3), ldf(q.a, o3 + 4), ldf(q.a, o3 + 8)}, rr = ldf(q.r, o1), rm = ldf(q.m, o1);
+    const float pr[3] = {ldf(q.pred, o3), ldf(q.pred, o3 + 4), ldf(q.pred, o3 + 8)};
+    const float gt[3] = {ldf(q.gt_srgb, o3), ldf(q.gt_srgb, o3 + 4), ldf(q.gt_srgb, o3 + 8)};
+    // the pixel's model
+    const float rref = as_f(ldu(qs.plane[kLzRref], o1));
+    const uint32_t lohi = ldu(qs.plane[kLzLoHi], o1);
+    float Pv[3], SDv[3], S1v[3];
+    uint32_t pk[3], sk[3], dk[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Pv[c] = as_f(ldu(qs.plane[kLzP + c], o1)); SDv[c] = as_f(ldu(qs.plane[kLzSD + c], o1)); S1v[c] = as_f(ldu(qs.plane[kLzS1 + c], o1));
+        pk[c] = ldu(qs.plane[kLzPk + c], o1); sk[c] = ldu(qs.plane[kLzSk + c], o1); dk[c] = ldu(qs.plane[kLzDk + c], o1);
+    }
+    float a[3];
+    const float r = fminf(fmaxf(rr, 0.07f), 1.0f), m = fminf(fmaxf(rm, 0.0f), 1.0f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = fminf(fmaxf(ra[c], 0.0f), 1.0f);
+    // ---- backward of iteration t at (a, r, m): d loss / d pred of 3 (l1/mse) mse + l1 on xs = max(pred ratio, eps)^(1/2.2)  (:388-418)
+    const float dr = r - rref, omm = 1.0f - m;
+    float da[3], drr = 0.0f, dm = 0.0f, xs_keep[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float x = pr[c] * ratio;
+        const float xc = fmaxf(x, kLossEps);
+        const float xs = pow_inv_gamma(xc);
+        const float d = xs - gt[c];
+        const float dxs = x > kLossEps ? xs * rcp(xc) * (1.0f / 2.2f) : 0.0f;
+        const float go = ratio * dxs * fmaf(6.0f * sr, d, fsign(d)) * q.inv_n3;
+        xs_keep[c] = xs;
+        const float dP0 = h2_lo(pk[c]), A2 = h2_hi(pk[c]);
+        const float Pc = fmaf(fmaf(A2, dr, dP0), dr, Pv[c]), dPc = fmaf(2.0f * A2, dr, dP0);
+        const float SD = fmaf(h2_lo(sk[c]), dr, SDv[c]);
+        const float C0 = fmaf(m, a[c], omm * 0.04f);
+        const float JR = fmaf(a[c] * omm, dPc, fmaf(C0, h2_lo(dk[c]), h2_hi(dk[c])));
+        da[c] = go * fmaf(m, SD, omm * Pc);
+        dm = fmaf(go, fmaf(a[c] - 0.04f, SD, -(a[c] * Pc)), dm);
+        drr = fmaf(go, JR, drr);
+    }
+    float na[3] = {ra[0], ra[1], ra[2]}, nr = rr, nm = rm;     // the raw parameters after the step
+    if (q.part_mask & MATPBR_PART_A) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float gsum = da[c] + q.scale_delta * q.inv_n3 * fsign(a[c] - ldf(q.a0, o3 + 4 * c));                                 // :398,418
+            gsum = (ra[c] >= 0.0f && ra[c] <= 1.0f) ? gsum : 0.0f;                                                               // clamp backward
+            if (q.d_a) stf(q.d_a, o3 + 4 * c, gsum);
+            if (improved && q.best_a) stf(q.best_a, o3 + 4 * c, a[c]);
+            if (q.am[0]) { na[c] = adam_update(ra[c], gsum, q.am[0], q.av[0], (long)i * 3 + c, q); stf(q.pa, o3 + 4 * c, na[c]); }
+        }
+    } else if (q.d_a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) stf(q.d_a, o3 + 4 * c, (ra[c] >= 0.0f && ra[c] <= 1.0f) ? da[c] : 0.0f);
+    }
+    if (improved && q.best_img) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) stf(q.best_img, o3 + 4 * c, xs_keep[c]);
+    }
+    float gr = drr + ((q.part_mask & MATPBR_PART_R) ? q.scale_delta * q.inv_n1 * fsign(r - ldf(q.r0, o1)) : 0.0f);
+    float gm = dm + ((q.part_mask & MATPBR_PART_M) ? q.scale_delta * q.inv_n1 * fsign(m - ldf(q.m0, o1)) : 0.0f);
+    gr = (rr >= 0.07f && rr <= 1.0f) ? gr : 0.0f;
+    gm = (rm >= 0.0f && rm <= 1.0f) ? gm : 0.0f;
+    if (q.d_r) stf(q.d_r, o1, gr);
+    if (q.d_m) stf(q.d_m, o1, gm);
+    if (improved && q.best_r) stf(q.best_r, o1, r);
+    if (improved && q.best_m) stf(q.best_m, o1, m);
+    if ((q.part_mask & MATPBR_PART_R) && q.am[1]) { nr = adam_update(rr, gr, q.am[1], q.av[1], (long)i, q); stf(q.pr, o1, nr); }
+    if ((q.part_mask & MATPBR_PART_M) && q.am[2]) { nm = adam_update(rm, gm, q.am[2], q.av[2], (long)i, q); stf(q.pm, o1, nm); }
+    // ---- forward of iteration t+1 from the same model
+    const float r1 = fminf(fmaxf(nr, 0.07f), 1.0f), m1 = fminf(fmaxf(nm, 0.0f), 1.0f), dr1 = r1 - rref, omm1 = 1.0f - m1;
+    const bool need = !(dr1 >= -h2_lo(lohi) && dr1 <= h2_hi(lohi));
+    if (!need) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a1 = fminf(fmaxf(na[c], 0.0f), 1.0f);
+            const float Pc = fmaf(fmaf(h2_hi(pk[c]), dr1, h2_lo(pk[c])), dr1, Pv[c]);
+            const float SD = fmaf(h2_lo(sk[c]), dr1, SDv[c]), S1 = fmaf(h2_hi(sk[c]), dr1, S1v[c]);
+            const float C0 = fmaf(m1, a1, omm1 * 0.04f);
+            const float rgb = fmaf(a1 * omm1, Pc, fmaf(C0, SD, S1));
+            stf(qs.pred_next, o3 + 4 * c, rgb);
+            tot += rgb;
+        }
+    }
+    return need;
+}
+
+// a workgroup takes 512 consecutive pixels, thread t the pixels t and t + 256 of them: every load instruction of a wave covers 64
+// consecutive pixels, and the two pixels' independent chains interleave
+__global__ __launch_bounds__(kBlock) void lazy_step_kernel(const LazyStepArgs qs, int P) {
+    __shared__ float s_sum[4];
+    __shared__ int s_cnt[4];
+    const JacBwdArgs& q = qs.j;
+    const int b = blockIdx.y;
+    if (q.check_stop && img_stopped_before(q.stats, b)) return;
+    const int q0 = blockIdx.x * kLazyBlockPixels + threadIdx.x, q1 = q0 + kBlock;
+    const float ratio = q.stats[b * kStatsStride + kStRatio], sr = q.stats[b * kStatsStride + kStSr];
+    const bool improved = q.stats[b * kStatsStride + kStImproved] > 0.5f;
+    float tot = 0.0f;
+    bool need0 = false, need1 = false;
+    if (q0 < P) need0 = lazy_step_pixel(qs, (unsigned)(b * P + q0), ratio, sr, improved, tot);
+    if (q1 < P) need1 = lazy_step_pixel(qs, (unsigned)(b * P + q1), ratio, sr, improved, tot);
+    const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n0 = __popcll(b0), nw = n0 + __popcll(b1);
+    tot = wave_sum_to_lane63(tot);
+    if (lane == 63) { s_cnt[wave] = nw; s_sum[wave] = tot; }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) base += w < wave ? s_cnt[w] : 0;
+    uint16_t* list = qs.lists + ((long)b * gridDim.x + blockIdx.x) * kLazyBlockPixels;
+    if (need0) list[base + __popcll(b0 & below)] = (uint16_t)threadIdx.x;
+    if (need1) list[base + n0 + __popcll(b1 & below)] = (uint16_t)(kBlock + threadIdx.x);
+    if (threadIdx.x == 0) {
+        qs.counts[(long)b * gridDim.x + blockIdx.x] = (uint32_t)((s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]));
+        qs.block_sums[(long)b * qs.n_sums + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    }
+}
+
+// =================================================================================================
+// refresh: walk the samples of the listed pixels, rebuild their models, patch their render
+// =================================================================================================
+// Mapping: LPI lanes per listed pixel, lane `sub` takes the azimuths sub, sub + LPI, ... of every ring, and the two halves of every
+// packed register hold the SAME pixel at r and at r + dir h (the one-sided difference that gives the slopes): the serial chain of a
+// refresh is nu_s samples instead of 2 x nu_s x nphi_s, which matters because this kernel runs at a few waves per CU.
+struct LazyRefreshArgs {
+    const float *a, *r, *m, *n, *dcache;
+    uint32_t* state;
+    float* out;
+    uint32_t* jac16;
+    const float* stats;       // nullable; with it the parity floor is half the image's mean radiance, 0.5 (sum gt / ratio) / (3 P)
+    float* block_sums;        // nullable [B][n_sums]: slot n_fwd + blockIdx.x
+    const uint32_t* counts;
+    const uint16_t* lists;
+    int clamp, force, n_sums, n_fwd, nblk;
+    float floor, tol;
+    long long* dbg;
+};
+
+__device__ __forceinline__ void pixel_set_r(Pixel& px, f2 r) {
+    px.r = r;
+    px.alpha2 = pow4(r);
+    px.am1 = px.alpha2 - 1.0f;
+    const f2 rp1 = r + 1.0f, k = (rp1 * rp1) * 0.125f;
+    px.omk = 1.0f - k;
+    px.kpe = k + 1e-6f;
+    px.dk_dr = rp1 * 0.25f;
+    px.g1v = rcp(vfma(px.NoV, px.omk, px.kpe));
+}
+// (selects, not branches on which bound to update: a reference picked by a branch sends lo / hi to scratch memory)
+__device__ __forceinline__ void lazy_kink(float x, float xp, float J, float tol_k, float& lo, float& hi) {
+    const bool valid = (J * kLzRhoMax > tol_k) && (fabsf(xp) > 1e-12f);
+    const float dk = -x * rcp(xp) * kLzKinkSafety, ad = fabsf(dk) + tol_k * rcp(J);
+    const bool both = fabsf(dk) < 2.0f * kLzH, up = dk > 0.0f;
+    hi = (valid && (both || up)) ? fminf(hi, ad) : hi;
+    lo = (valid && (both || !up)) ? fminf(lo, ad) : lo;
+}
+template <int LPI>
+__device__ __forceinline__ float lane_group_sum(float v) {
+#pragma unroll
+    for (int msk = 1; msk < LPI; msk <<= 1) v += __shfl_xor(v, msk);
+    return v;
+}
+template <int LPI>
+__device__ __forceinline__ float lane_group_min(float v) {
+#pragma unroll
+    for (int msk = 1; msk < LPI; msk <<= 1) v = fminf(v, __shfl_xor(v, msk));
+    return v;
+}
+
+constexpr int kLazyMaxBlocks = 8192;   // forward workgroups per image whose counts fit the LDS prefix (512 x 8192 pixels = 2048 x 2048)
+template <int LPI>
+__global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefreshArgs q, const float* __restrict__ light, const Geom g,
+                                                                 const RuleTable tab) {
+    __shared__ float2 s_saz[kMaxRings * kMaxAz];
+    __shared__ int s_pref[kLazyMaxBlocks + 1];      // exclusive prefix of the image's per-workgroup counts: the work list is their concatenation
+    __shared__ int s_wave[4];
+    __shared__ float s_sum[4];
+    long long ts[10];
+    int nts = 0;
+#define LZ_STAMP() do { if (q.dbg) ts[nts++] = wall_clock64(); } while (0)
+    LZ_STAMP();
+    if (threadIdx.x < kMaxRings * kMaxAz) s_saz[threadIdx.x] = (&tab.saz[0][0])[threadIdx.x];
+    const int b = blockIdx.y;
+    const int P = g.H * g.W;
+    const long BP = (long)gridDim.y * P;
+    const bool stopped = q.stats && img_stopped(q.stats, b);
+    // every workgroup scans all counts of its image (2 KB at 512 x 512): no second launch, no global prefix array to chase
+    const int per = (q.nblk + kBlock - 1) / kBlock, first = threadIdx.x * per;
+    int mine = 0;
+    for (int j = 0; j < per; ++j) {
+        const int blk = first + j;
+        const int c = (blk < q.nblk && !stopped) ? (int)q.counts[(long)b * q.nblk + blk] : 0;
+        if (blk < q.nblk) s_pref[blk] = mine;       // exclusive within the thread's run; the thread offset is added below
+        mine += c;
+    }
+    int incl = mine;                                 // inclusive scan of the per-thread totals: wave (DPP-free, shuffles), then the 4 waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if ((threadIdx.x & 63) >= d) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) woff += w < (int)(threadIdx.x >> 6) ? s_wave[w] : 0;
+    const int excl = woff + incl - mine;
+    for (int j = 0; j < per; ++j)
+        if (first + j < q.nblk) s_pref[first + j] += excl;
+    const int T = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
+    if (threadIdx.x == 0) s_pref[q.nblk] = T;
+    __syncthreads();
+    LZ_STAMP();
+    float tot = 0.0f;
+    constexpr int kItems = kBlock / LPI;
+    if ((long)blockIdx.x * kItems < T) {
+        float floor_ = q.floor;
+        if (q.stats) {
+            const float ratio = q.stats[b * kStatsStride + kStRatio];
+            floor_ = 0.5f * q.stats[b * kStatsStride + kStGtSum] / (3.0f * (float)P) / (ratio > 0.0f ? ratio : 1.0f);
+        }
+        const float tol_k = q.tol * kLzTolK, tol_s = q.tol * kLzTolS;
+        LightRegs lr;
+        load_light_regs(lr, light + (long)b * kNL);
+        LZ_STAMP();
+        const int sub = threadIdx.x % LPI, slot = threadIdx.x / LPI;
+        for (int base = blockIdx.x * kItems; base < T; base += gridDim.x * kItems) {   // chunks of kItems items, strided over the workgroups
+            const bool active = base + slot < T;
+            const int it = active ? base + slot : T - 1;
+            int lo_b = 0, hi_b = q.nblk;            // largest blk with s_pref[blk] <= it
+            while (hi_b - lo_b > 1) {
+                const int mid = (lo_b + hi_b) >> 1;
+                if (s_pref[mid] <= it) lo_b = mid; else hi_b = mid;
+            }
+            const int blk = lo_b;
+            const int p = blk * kLazyBlockPixels + (int)q.lists[((long)b * q.nblk + blk) * kLazyBlockPixels + (it - s_pref[blk])];
+            const long i = (long)b * P + p;
+            if (base == (int)(blockIdx.x * kItems)) LZ_STAMP();
+            Pixel px;
+            load_pixel(px, q.a, q.r, q.m, q.n, i, i, p, p, g, q.clamp != 0);
+            const float rc = px.r.x, mv = px.m.x;
+            if (base == (int)(blockIdx.x * kItems)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); LZ_STAMP(); }
+            // what the old model predicts at the new roughness: the parity scale of this refresh, and the measured extrapolation error
+            const bool has_old = !q.force;
+            float rho = kLzRhoInit, dr = 0.0f, pSD[3] = {0, 0, 0}, pS1[3] = {0, 0, 0};
+            if (has_old) {
+                dr = rc - as_f(q.state[kLzRref * BP + i]);
+                rho = as_f(q.state[kLzRho * BP + i]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t sk = q.state[(kLzSk + c) * BP + i];
+                    pSD[c] = fmaf(h2_lo(sk), dr, as_f(q.state[(kLzSD + c) * BP + i]));
+                    pS1[c] = fmaf(h2_hi(sk), dr, as_f(q.state[(kLzS1 + c) * BP + i]));
+                }
+            }
+            float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float A0 = q.dcache[c * BP + i], A1 = q.dcache[(3 + c) * BP + i];
+                A2[c] = q.dcache[(6 + c) * BP + i];
+                Pc[c] = fmaf(fmaf(A2[c], rc, A1), rc, A0);
+                dP[c] = fmaf(2.0f * rc, A2[c], A1);
+                kd[c] = px.a[c].x * (1.0f - mv);
+                C0[c] = fmaf(mv, px.a[c].x, (1.0f - mv) * 0.04f);
+                const float pred = has_old ? fabsf(fmaf(kd[c], Pc[c], fmaf(C0[c], pSD[c], pS1[c]))) : 0.0f;
+                iscale[c] = 1.0f / fmaxf(pred, floor_);
+            }
+            float dir = (has_old && dr < 0.0f) ? -1.0f : 1.0f;
+            if (rc + dir * kLzH > 1.0f || rc + dir * kLzH < 0.07f) dir = -dir;
+            pixel_set_r(px, f2{rc, rc + dir * kLzH});
+
+            f2 S0[3], S1[3], dS0[3], dS1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S0[c] = S1[c] = dS0[c] = dS1[c] = f2{0.0f, 0.0f};
+            float klo = 1e30f, khi = 1e30f;
+            const f2 four_over_r = 4.0f * rcp(px.r);
+            const f2 cv = px.dk_dr * px.g1v * (1.0f - px.NoV);
+            const float g1l0 = rcp(px.kpe.x), r3x4 = 4.0f * rc * rc * rc;
+            for (int k = 0; k < tab.nu_s; ++k) {
+                const float4 rg = tab.sring[k];
+                SpecRing R;
+                spec_ring<true>(px, rg, R);
+                const f2 lam0 = vfma(four_over_r, vfma(R.q * R.idq, -2.0f * rg.y, 1.0f), -cv);
+                // d sin^2 theta_h / dr = -d cos^2 theta_h / dr = 4 r^3 u0 q cos^2 theta_h   (mi_specular_sampler :232-233)
+                const float gq = r3x4 * rg.x * R.q.x * (R.q.x * rg.y);
+                const float stp = 0.5f * gq * rcp(R.st.x), ctp = -0.5f * gq * rcp(R.ct.x);
+                for (int j = sub; j < tab.nphi_s; j += LPI) {
+                    const float2 az = s_saz[k * kMaxAz + j];
+                    SpecSample sm;
+                    spec_sample(px, R, az, sm);
+                    const f2 wgt = (R.ringw * sm.g1l) * (sm.NoL * sm.dpos);
+                    f2 L[3];
+                    sh_radiance(lr, sm.wi, L);
+                    const f2 wx = wgt * sm.x5;
+                    const f2 lam = vfma(px.dk_dr * sm.g1l, sm.NoL - 1.0f, lam0);
+                    const f2 wl = wgt * lam, wlx = wl * sm.x5;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        S0[c] = vfma(wgt, L[c], S0[c]);
+                        S1[c] = vfma(wx, L[c], S1[c]);
+                        dS0[c] = vfma(wl, L[c], dS0[c]);
+                        dS1[c] = vfma(wlx, L[c], dS1[c]);
+                    }
+                    // where this sample's clamped variables n.wi and wo.h cross zero, to first order in r
+                    const float dp = fmaf(stp, fmaf(az.x, px.vx.x, az.y * px.vy.x), ctp * px.vz.x);
+                    const float wlzp = 2.0f * fmaf(dp, R.ct.x, sm.d.x * ctp);
+                    float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float aL = fabsf(L[c].x) * iscale[c];
+                        m1 = fmaxf(m1, fmaf(1.0f - C0[c], sm.x5.x, C0[c]) * aL);
+                        m2 = fmaxf(m2, aL);
+                    }
+                    lazy_kink(sm.wlz.x, wlzp, R.ringw.x * g1l0 * sm.dpos.x * m1 * fabsf(wlzp), tol_k, klo, khi);
+                    lazy_kink(sm.d.x, dp, R.ringw.x * sm.g1l.x * sm.NoL.x * m2 * fabsf(dp), tol_k, klo, khi);
+                }
+            }
+            if (base == (int)(blockIdx.x * kItems)) LZ_STAMP();
+            klo = lane_group_min<LPI>(klo);
+            khi = lane_group_min<LPI>(khi);
+            float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3];
+            const float ih = dir * (1.0f / kLzH);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float s0x = lane_group_sum<LPI>(S0[c].x), s0y = lane_group_sum<LPI>(S0[c].y);
+                const float s1x = lane_group_sum<LPI>(S1[c].x), s1y = lane_group_sum<LPI>(S1[c].y);
+                const float d0 = lane_group_sum<LPI>(dS0[c].x), d1 = lane_group_sum<LPI>(dS1[c].x);
+                vSD[c] = s0x - s1x;
+                vS1[c] = s1x;
+                gSD[c] = ((s0y - s1y) - vSD[c]) * ih;
+                gS1[c] = (s1y - s1x) * ih;
+                dSD[c] = d0 - d1;
+                dS1v[c] = d1;
+            }
+            if (base == (int)(blockIdx.x * kItems)) LZ_STAMP();
+            if (active && sub == 0) {
+                if (has_old && fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
+                    float e = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) e = fmaxf(e, fabsf(fmaf(C0[c], pSD[c] - vSD[c], pS1[c] - vS1[c])) * iscale[c]);
+                    const float want = 0.9f * fabsf(dr) * fsqrt(tol_s / fmaxf(e, 1e-12f));
+                    rho = fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
+                }
+                rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
+                uint32_t* S = q.state;
+                S[kLzRref * BP + i] = as_u(rc);
+                S[kLzLoHi * BP + i] = pack_h2(0.998f * fminf(klo, rho), 0.998f * fminf(khi, rho));   // fp16 rounding must not widen the interval
+                S[kLzRho * BP + i] = as_u(rho);
+                float jr[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    S[(kLzP + c) * BP + i] = as_u(Pc[c]);
+                    S[(kLzSD + c) * BP + i] = as_u(vSD[c]);
+                    S[(kLzS1 + c) * BP + i] = as_u(vS1[c]);
+                    S[(kLzPk + c) * BP + i] = pack_h2(dP[c], A2[c]);
+                    S[(kLzSk + c) * BP + i] = pack_h2(gSD[c], gS1[c]);
+                    S[(kLzDk + c) * BP + i] = pack_h2(dSD[c], dS1v[c]);
+                    const float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
+                    q.out[i * 3 + c] = rgb;
+                    tot += rgb;
+                    if (q.jac16) q.jac16[c * BP + i] = pack_h2(Pc[c], vSD[c]);
+                    jr[c] = fmaf(kd[c], dP[c], fmaf(C0[c], dSD[c], dS1v[c]));
+                }
+                if (q.jac16) {
+                    q.jac16[3 * BP + i] = pack_h2(jr[0], jr[1]);
+                    q.jac16[4 * BP + i] = pack_h2(jr[2], 0.0f);
+                }
+            }
+        }
+    }
+    LZ_STAMP();
+    if (q.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int k = 0; k < nts; ++k) q.dbg[k] = ts[k];
+        q.dbg[15] = nts; q.dbg[14] = T;
+    }
+    if (q.block_sums) {
+        tot = wave_sum_to_lane63(tot);
+        if ((threadIdx.x & 63) == 63) s_sum[threadIdx.x >> 6] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) q.block_sums[(long)b * q.n_sums + q.n_fwd + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    }
+}
+
+// ---- test / inspection helpers -------------------------------------------------------------------
+// state -> the oracle's layout [B*P][22]: r_ref, lo, hi, rho, SD, S1, gSD, gS1, dSD, dS1; refreshed[B*P] (nullable) = 1 for the pixels
+// of the last call's work lists
+__global__ __launch_bounds__(kBlock) void lazy_unpack_kernel(const uint32_t* __restrict__ S, float* __restrict__ st, long BP) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= BP) return;
+    float* o = st + i * 22;
+    const uint32_t lh = S[kLzLoHi * BP + i];
+    o[0] = as_f(S[kLzRref * BP + i]); o[1] = h2_lo(lh); o[2] = h2_hi(lh); o[3] = as_f(S[kLzRho * BP + i]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t sk = S[(kLzSk + c) * BP + i], dk = S[(kLzDk + c) * BP + i];
+        o[4 + c] = as_f(S[(kLzSD + c) * BP + i]); o[7 + c] = as_f(S[(kLzS1 + c) * BP + i]);
+        o[10 + c] = h2_lo(sk); o[13 + c] = h2_hi(sk); o[16 + c] = h2_lo(dk); o[19 + c] = h2_hi(dk);
+    }
+}
+__global__ __launch_bounds__(kBlock) void lazy_refreshed_kernel(const uint32_t* __restrict__ counts, const uint16_t* __restrict__ lists,
+                                                                int* __restrict__ refreshed, int P, int nblk) {
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int n = (int)counts[(long)b * nblk + blk];
+    for (int k = threadIdx.x; k < kLazyBlockPixels; k += kBlock) {
+        const int p = blk * kLazyBlockPixels + k;
+        if (p < P) refreshed[(long)b * P + p] = 0;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += kBlock) refreshed[(long)b * P + blk * kLazyBlockPixels + lists[((long)b * nblk + blk) * kLazyBlockPixels + k]] = 1;
+}
+__global__ __launch_bounds__(kBlock) void jac16_unpack_kernel(const uint32_t* __restrict__ j16, float* __restrict__ jac, long BP) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= BP) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t u = j16[c * BP + i];
+        jac[c * BP + i] = h2_lo(u);
+        jac[(3 + c) * BP + i] = h2_hi(u);
+    }
+    const uint32_t u3 = j16[3 * BP + i], u4 = j16[4 * BP + i];
+    jac[6 * BP + i] = h2_lo(u3); jac[7 * BP + i] = h2_hi(u3); jac[8 * BP + i] = h2_lo(u4);
+}
+
+}  // namespace matpbr

@@ -649,13 +649,18 @@ constexpr float kLossEps = 1e-8f;  // materialist_amd/loss.py _EPS: x^(1/2.2) ha
 __device__ __forceinline__ float fsign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 __device__ __forceinline__ float pow_inv_gamma(float x) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.2f)); }
 __device__ __forceinline__ float adam_update(float p, float gi, float* m, float* v, long i, const JacBwdArgs& q) {
-    const float mi = fmaf(q.b1, m[i], (1.0f - q.b1) * gi);
-    const float vi = fmaf(q.b2, v[i], (1.0f - q.b2) * gi * gi);
-    m[i] = mi; v[i] = vi;
+    const unsigned off = (unsigned)i * 4u;     // uniform base + 32-bit lane offset (byte offsets below 2^32)
+    float* mp = (float*)((char*)m + off);
+    float* vp = (float*)((char*)v + off);
+    const float mi = fmaf(q.b1, *mp, (1.0f - q.b1) * gi);
+    const float vi = fmaf(q.b2, *vp, (1.0f - q.b2) * gi * gi);
+    *mp = mi; *vp = vi;
     return p - q.lr_over_bc1 * mi / fmaf(fsqrt(vi), q.inv_sqrt_bc2, q.eps);
 }
 
-template <bool FUSED>
+// J16: `jac` holds the five half-precision planes of the lazy forward (matpbr_lazy.hpp): half2 (P_c, SD_c) x 3, half2 (JR_0, JR_1), half2 (JR_2, 0)
+typedef _Float16 jac_h2 __attribute__((ext_vector_type(2)));
+template <bool FUSED, bool J16 = false>
 __global__ __launch_bounds__(kBlock) void jac_bwd_kernel(const JacBwdArgs q, long P) {
     const int b = blockIdx.y;
     if (FUSED && q.check_stop && img_stopped_before(q.stats, b)) return;
@@ -690,9 +695,20 @@ __global__ __launch_bounds__(kBlock) void jac_bwd_kernel(const JacBwdArgs q, lon
     }
     float da[3], dr = 0.0f, dm = 0.0f;
     const float omm = 1.0f - m;
+    float jrv[3] = {0.0f, 0.0f, 0.0f};
+    if (J16) {
+        const jac_h2 u3 = __builtin_bit_cast(jac_h2, q.jac[3 * BP + i]), u4 = __builtin_bit_cast(jac_h2, q.jac[4 * BP + i]);
+        jrv[0] = (float)u3.x; jrv[1] = (float)u3.y; jrv[2] = (float)u4.x;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float Pc = q.jac[c * BP + i], SD = q.jac[(3 + c) * BP + i], JR = q.jac[(6 + c) * BP + i];
+        float Pc, SD, JR;
+        if (J16) {
+            const jac_h2 u = __builtin_bit_cast(jac_h2, q.jac[c * BP + i]);
+            Pc = (float)u.x; SD = (float)u.y; JR = jrv[c];
+        } else {
+            Pc = q.jac[c * BP + i]; SD = q.jac[(3 + c) * BP + i]; JR = q.jac[(6 + c) * BP + i];
+        }
         da[c] = go[c] * fmaf(m, SD, omm * Pc);
         dm = fmaf(go[c], fmaf(a[c] - 0.04f, SD, -(a[c] * Pc)), dm);
         dr = fmaf(go[c], JR, dr);

@@ -237,11 +237,15 @@ class FusedBrdfPhase:
     `run(k)` may enqueue k iterations blindly and `poll()` (one host sync) tells how far each image really got."""
 
     PARTS = {"a": 2, "r": 4, "m": 8}
+    LAZY = True
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
                  min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
-                 originals: Optional[Dict[str, torch.Tensor]] = None, keep_grads: bool = False):
+                 originals: Optional[Dict[str, torch.Tensor]] = None, keep_grads: bool = False, lazy: Optional[bool] = None,
+                 lazy_tol: float = 1.0):
+        """`lazy` (default `FusedBrdfPhase.LAZY`): in parts that move the roughness, render from per-pixel local models in r and walk
+        the GGX samples only of the pixels that left their model's validity interval (include/matpbr.h `matpbr_shade_fwd_lazy`)."""
         import ctypes
 
         from . import _lib, ops
@@ -267,7 +271,8 @@ class FusedBrdfPhase:
         self.stats = ops.new_loss_stats(B, dev)
         if best_mse is not None:   # SaveBest.best_loss is global across phases and never reset (F11)
             self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
-        self.stats[:, ops.STAT_GT_SUM] = self.gt.reshape(B, -1).sum(dim=1)
+        # summed in double: the fp32 result then does not depend on how torch tiles the reduction (a batch row vs the image alone)
+        self.stats[:, ops.STAT_GT_SUM] = self.gt.reshape(B, -1).double().sum(dim=1).float()
         lib = _lib.load()
         self.ws = torch.empty(int(lib.matpbr_brdf_phase_workspace_bytes(self.H, self.W, B)) // 4 + 1, dtype=torch.float32, device=dev)
         self.hist = torch.zeros((history_len, B), dtype=torch.float32, device=dev)
@@ -298,6 +303,14 @@ class FusedBrdfPhase:
         # parts that leave the roughness alone: the specular sums of every pixel are constants of the part (kept from its first render)
         self.s1cache = None if "r" in optimize_part else torch.empty((3,) + tuple(self.jac.shape[1:]), dtype=torch.float32, device=self.jac.device)
         ph.s1cache = P(self.s1cache) if self.s1cache is not None else None
+        self.lazy = bool(self.LAZY if lazy is None else lazy) and "r" in optimize_part
+        self.lazy_state = ops.lazy_state(self.p["albedo"]) if self.lazy else None
+        ph.lazy_state = P(self.lazy_state) if self.lazy else None
+        ph.lazy_tol = float(lazy_tol)
+        # lazy: the step's last launch also renders the next iterate (into pred_next); the two render buffers swap roles every step
+        self._pred_bufs = [self.pred, torch.empty_like(self.gt)] if self.lazy else None
+        self._pred_cur = 0
+        ph.pred_next = P(self._pred_bufs[1]) if self.lazy else None
         self._ph, self._lib = ph, lib
 
     def lr_at(self, t0: int) -> float:
@@ -315,6 +328,12 @@ class FusedBrdfPhase:
                                                     ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
         self._libmod.check(code, "matpbr_brdf_phase_step")
         self.t += 1
+        if self._pred_bufs is not None:
+            # self.pred = the render this step evaluated; the buffer its last launch rendered the next iterate into becomes `pred` of the next step
+            self.pred = self._pred_bufs[self._pred_cur]
+            self._pred_cur ^= 1
+            self._ph.pred = ct.c_void_p(self._pred_bufs[self._pred_cur].data_ptr())
+            self._ph.pred_next = ct.c_void_p(self._pred_bufs[self._pred_cur ^ 1].data_ptr())
 
     def run(self, n: int) -> None:
         for _ in range(n):

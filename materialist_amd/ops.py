@@ -15,6 +15,9 @@ NSH = 25
 MAX_SPP = 128
 FLAG_CLAMP_PARAMS = 1
 FLAG_ATTACHED_SAMPLING = 2
+FLAG_LAZY_FORCE = 16
+FLAG_JAC16 = 32
+LAZY_NSTATE = 22
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
  STAT_ES_HAS, STAT_STOPPED, STAT_ITERS, STAT_GT_SUM) = range(16)
@@ -164,6 +167,70 @@ def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0, clamp_params
                                            H, W, B, check_spp(spp), ctypes.byref(cam), FLAG_CLAMP_PARAMS if clamp_params else 0, _stream(a))
     _lib.check(code, "matpbr_shade_fwd_ex")
     return out
+
+
+def lazy_state(a: torch.Tensor) -> torch.Tensor:
+    """Storage of the per-pixel local models of `shade_fwd_lazy` for maps shaped like `a` (opaque bytes; zero-filled)."""
+    B, H, W = _bhw(a)
+    return torch.zeros(int(_lib.load().matpbr_lazy_state_bytes(H, W, B)), dtype=torch.uint8, device=a.device)
+
+
+def shade_fwd_lazy(a, r, m, n, light, spp: int, dcache: torch.Tensor, state: torch.Tensor, out: Optional[torch.Tensor] = None,
+                   jac16: Optional[torch.Tensor] = None, force: bool = False, clamp_params: bool = False, floor: Optional[float] = None,
+                   stats: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None, tol: float = 1.0, fov_x_deg: float = 35.0):
+    """The render from per-pixel local models in the roughness (include/matpbr.h `matpbr_shade_fwd_lazy`): pixels whose roughness is
+    still inside the validity interval of their model are a streaming evaluation, the others are re-sampled and their models rebuilt
+    in `state` (from `lazy_state`).  `force=True` on the first call (and whenever light / normals / dcache changed).  Returns
+    (out, jac16); jac16 feeds `brdf_loss_bwd_jac(..., jac16=True)` or `jac16_unpack`."""
+    lib = _lib.load()
+    a = _dev(a, "albedo", (3,))
+    B, H, W = _bhw(a)
+    r = _dev(r, "roughness").reshape(B, H, W, 1)
+    m = _dev(m, "metallic").reshape(B, H, W, 1)
+    n = _dev(n, "normal", (3,))
+    light = _dev(light, "light", (NSH, 3))
+    if n.numel() != a.numel() or r.numel() * 3 != a.numel() or light.numel() != B * NSH * 3:
+        raise ValueError("shade_fwd_lazy: inconsistent map / light shapes")
+    if dcache is None or not dcache.is_cuda or dcache.dtype != torch.float32 or not dcache.is_contiguous() or dcache.numel() != 3 * a.numel():
+        raise ValueError("shade_fwd_lazy: dcache must be diffuse_cache(n, light, spp)")
+    if not state.is_cuda or state.dtype != torch.uint8 or state.numel() < int(lib.matpbr_lazy_state_bytes(H, W, B)):
+        raise ValueError("shade_fwd_lazy: state must come from lazy_state()")
+    if stats is None and not (floor is not None and floor > 0):
+        raise ValueError("shade_fwd_lazy: give the mean-radiance floor of the parity scale (or the statistics buffer)")
+    if out is None:
+        out = torch.empty_like(a)
+    if jac16 is None:
+        jac16 = torch.empty((5, B, H, W), dtype=torch.int32, device=a.device)
+    if sums is not None and sums.numel() < B * int(lib.matpbr_lazy_sums_count(H, W)):
+        raise ValueError("shade_fwd_lazy: sums too small")
+    cam = MatpbrCamera(float(fov_x_deg))
+    flags = (FLAG_CLAMP_PARAMS if clamp_params else 0) | (FLAG_LAZY_FORCE if force else 0)
+    with torch.cuda.device(a.device), _timed("shade_fwd"):
+        code = lib.matpbr_shade_fwd_lazy(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(dcache), _ptr(state), _ptr(out),
+                                         _ptr(jac16), _ptr(stats), _ptr(sums), H, W, B, check_spp(spp), ctypes.byref(cam), flags,
+                                         float(floor or 0.0), float(tol), _stream(a))
+    _lib.check(code, "matpbr_shade_fwd_lazy")
+    return out, jac16
+
+
+def lazy_state_unpack(state: torch.Tensor, a: torch.Tensor):
+    """(models [B,H,W,22] in the oracle's layout, refreshed [B,H,W] int32: the pixels the last `shade_fwd_lazy` re-sampled)."""
+    B, H, W = _bhw(a)
+    st = torch.empty((B, H, W, LAZY_NSTATE), dtype=torch.float32, device=a.device)
+    ref = torch.empty((B, H, W), dtype=torch.int32, device=a.device)
+    with torch.cuda.device(a.device):
+        code = _lib.load().matpbr_lazy_state_unpack(_ptr(state), _ptr(st), _ptr(ref), H, W, B, _stream(a))
+    _lib.check(code, "matpbr_lazy_state_unpack")
+    return st, ref
+
+
+def jac16_unpack(jac16: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    B, H, W = _bhw(a)
+    jac = plane9(a)
+    with torch.cuda.device(a.device):
+        code = _lib.load().matpbr_jac16_unpack(_ptr(jac16), _ptr(jac), H, W, B, _stream(a))
+    _lib.check(code, "matpbr_jac16_unpack")
+    return jac
 
 
 def diffuse_cache(n, light, spp: int, fov_x_deg: float = 35.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -354,7 +421,7 @@ def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: floa
 
 
 def brdf_loss_bwd_jac(pa, pr, pm, jac, pred, gt_srgb, stats, a0, r0, m0, scale_delta: float, d_a, d_r, d_m,
-                      best_a=None, best_r=None, best_m=None, best_img=None, optimize_part: str = "arm") -> None:
+                      best_a=None, best_r=None, best_m=None, best_img=None, optimize_part: str = "arm", jac16: bool = False) -> None:
     """Backward of the fused BRDF-phase loss into preallocated d_a/d_r/d_m from the jac planes of the forward pass that rendered
     pa/pr/pm with clamp_params=True (see include/matpbr.h)."""
     lib = _lib.load()
@@ -363,7 +430,7 @@ def brdf_loss_bwd_jac(pa, pr, pm, jac, pred, gt_srgb, stats, a0, r0, m0, scale_d
     with torch.cuda.device(pa.device), _timed("shade_bwd"):
         code = lib.matpbr_brdf_loss_bwd_jac(_ptr(pa), _ptr(pr), _ptr(pm), _ptr(jac), _ptr(pred), _ptr(gt_srgb), _ptr(stats), _ptr(a0), _ptr(r0),
                                             _ptr(m0), float(scale_delta), _ptr(d_a), _ptr(d_r), _ptr(d_m), _ptr(best_a), _ptr(best_r),
-                                            _ptr(best_m), _ptr(best_img), H, W, B, part_mask(optimize_part), _stream(pa))
+                                            _ptr(best_m), _ptr(best_img), H, W, B, part_mask(optimize_part) | (FLAG_JAC16 if jac16 else 0), _stream(pa))
     _lib.check(code, "matpbr_brdf_loss_bwd_jac")
 
 

@@ -74,11 +74,11 @@ def test_batch_of_8_at_512_matches_stand_alone_renders_and_the_oracle_on_a_crop(
     scene_b._set("emitter.data", light)
     init = [st(k) for k in ("init_albedo", "init_roughness", "init_metallic")]
     gt = out
-    fb = loop.FusedBrdfPhase(scene_b, gt, *init, optimize_part="rm", spp=spp)
+    fb = loop.FusedBrdfPhase(scene_b, gt, *init, optimize_part="rm", spp=spp, lazy=False)
     fb.run(2)
     scene_1 = render.load_estimated_mesh(depth[2], use_mesh_normal=True)
     scene_1._set("emitter.data", light[2])
-    f1 = loop.FusedBrdfPhase(scene_1, gt[2], *[x[2] for x in init], optimize_part="rm", spp=spp)
+    f1 = loop.FusedBrdfPhase(scene_1, gt[2], *[x[2] for x in init], optimize_part="rm", spp=spp, lazy=False)
     f1.run(2)
     for k in ("roughness", "metallic"):
         assert torch.equal(fb.p[k][2], f1.p[k]), k

@@ -1,0 +1,241 @@
+"""GPU tests of the lazy re-sampling path of hot loop B (include/matpbr.h `matpbr_shade_fwd_lazy`, csrc/matpbr_lazy.hpp).
+
+The gate: at EVERY iteration of a 2 000-iteration 512 x 512 'rm' run,
+    |lazy - exact| <= 1e-3 max(|exact|, mean|exact|)   on every pixel,
+where `exact` walks the 20 GGX samples of every pixel (matpbr_shade_fwd_ex) at the same parameters; d out / d r within 2e-3 of the
+exact (detached) derivative at the pixels that were just re-sampled.  The models are checked against the oracle's specification
+(oracle/matpbr_oracle.c `lazy_refresh_pixel`), the fused phase against the phase that walks every sample."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    torch.manual_seed(20250629)
+    return torch.device("cuda:0")
+
+
+def _t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+
+
+def _rel(lazy, exact):
+    """max over pixels of |lazy - exact| / max(|exact|, mean|exact|) (device scalar)"""
+    scale = torch.maximum(exact.abs(), exact.abs().mean())
+    return ((lazy - exact).abs() / scale).max()
+
+
+def test_lazy_models_match_the_oracle_specification(oracle64):
+    """A forced call builds the model of every pixel; a second call after a random move of the roughness re-samples exactly the pixels
+    the specification says have left their interval (up to fp32 / fp16 rounding at the interval ends) and renders the others from
+    their model.  Values, slopes, derivatives, intervals and renders against oracle.lazy_fwd."""
+    from materialist_amd import ops, synthetic
+
+    dev = _cuda()
+    H, W, spp = 48, 64, 64
+    sc = synthetic.make_scene(2, H, W)
+    o = oracle64
+    n64 = o.normals_from_depth(sc.depth.astype(np.float64))
+    rng = np.random.default_rng(5)
+    n64 = n64 + 0.25 * rng.normal(size=n64.shape)           # tilt: grazing views, samples near the horizon
+    n64 /= np.linalg.norm(n64, axis=-1, keepdims=True)
+    a, r, m, n, light = (_t(x, dev) for x in (sc.albedo, sc.roughness, sc.metallic, n64, sc.light))
+    a64, r64, m64 = (x.cpu().numpy().astype(np.float64) for x in (a, r, m))
+    n64 = n.cpu().numpy().astype(np.float64)
+    l64 = light.cpu().numpy().astype(np.float64)
+    dcache = ops.diffuse_cache(n, light, spp)
+    exact = ops.shade_fwd(a, r, m, n, light, spp, dcache=dcache)
+    floor = 0.5 * float(exact.mean())
+    state = ops.lazy_state(a)
+    out, j16 = ops.shade_fwd_lazy(a, r, m, n, light, spp, dcache, state, force=True, floor=floor)
+    st, ref = ops.lazy_state_unpack(state, a)
+    assert int(ref.sum()) == H * W
+    assert float(_rel(out, exact)) < 2e-5                    # a forced call IS the exact render (fp32 summation order aside)
+    st_o = np.zeros((H, W, o.lazy_nstate()))
+    out_o, jac_o, ref_o = o.lazy_fwd(a64, r64, m64, n64, l64, st_o, spp, floor, force=True)
+    st = st[0].cpu().numpy().astype(np.float64)
+    S = np.abs(st_o[..., 4:10]).mean()
+    assert np.abs(st[..., 0] - st_o[..., 0]).max() < 1e-6
+    assert np.abs(st[..., 4:10] - st_o[..., 4:10]).max() < 2e-5 * S, "SD / S1 at the reference point"
+    # slopes: one-sided differences over h = 1e-3 in fp32 (noise ~ 1e-6 S / h) stored as fp16
+    tol_g = 3e-3 * (np.abs(st_o[..., 10:16]) + S)
+    assert (np.abs(st[..., 10:16] - st_o[..., 10:16]) <= tol_g).all(), "gSD / gS1"
+    assert (np.abs(st[..., 16:22] - st_o[..., 16:22]) <= 1e-3 * (np.abs(st_o[..., 16:22]) + np.abs(st_o[..., 16:22]).mean())).all(), "dSD / dS1"
+    assert np.allclose(st[..., 3], st_o[..., 3], rtol=1e-5), "rho"
+    # intervals: never wider than specified (rounded down), and the same up to 3 % on all but a handful of pixels (the crossing
+    # prediction divides two small fp32 numbers when a sample sits on the horizon)
+    for k in (1, 2):
+        assert (st[..., k] <= st_o[..., k] * 1.02 + 1e-6).mean() > 0.995
+        assert (np.abs(st[..., k] - st_o[..., k]) <= 0.03 * st_o[..., k] + 2e-5).mean() > 0.99
+    jac = ops.jac16_unpack(j16, a)[:, 0].permute(1, 2, 0).cpu().numpy().astype(np.float64)   # [H,W,9] planes P, SD, JR
+    assert (np.abs(jac - jac_o) <= 1.5e-3 * (np.abs(jac_o) + np.abs(jac_o).mean())).all(), "jac16 vs the specification"
+
+    # second call: move r by up to +-0.01
+    r2 = (r + _t(rng.uniform(-0.01, 0.01, (H, W, 1)), dev)).clamp(0.07, 1.0)
+    exact2 = ops.shade_fwd(a, r2, m, n, light, spp, dcache=dcache)
+    out2, _ = ops.shade_fwd_lazy(a, r2, m, n, light, spp, dcache, state, floor=floor)
+    st2, ref2 = ops.lazy_state_unpack(state, a)
+    out2_o, _, ref2_o = o.lazy_fwd(a64, r2.cpu().numpy().astype(np.float64), m64, n64, l64, st_o, spp, floor)
+    ref2 = ref2[0].cpu().numpy()
+    frac = ref2.mean()
+    assert 0.02 < frac < 0.98, frac
+    dr = np.abs(r2.cpu().numpy()[..., 0] - st[..., 0])
+    edge = np.minimum(np.abs(dr - st[..., 1]), np.abs(dr - st[..., 2])) < 0.04 * np.maximum(st[..., 1], st[..., 2]) + 3e-5
+    assert ((ref2 == ref2_o) | edge).all(), "a pixel well inside / outside its interval was (not) re-sampled"
+    assert float(_rel(out2, exact2)) < 1e-3
+    same = ref2 == ref2_o
+    o2 = out2[0].cpu().numpy() if out2.ndim == 4 else out2.cpu().numpy()
+    assert (np.abs(o2 - out2_o)[same] <= 3e-5 * (np.abs(out2_o)[same] + np.abs(out2_o).mean())).all(), "lazy render vs the specification"
+    # the re-sampled pixels now sit at their new roughness
+    st2 = st2[0].cpu().numpy()
+    assert np.abs(st2[..., 0] - r2.cpu().numpy()[..., 0])[ref2 == 1].max() < 1e-6
+
+
+def test_lazy_batch_equals_stand_alone_and_is_reproducible():
+    from materialist_amd import ops, synthetic
+
+    dev = _cuda()
+    H, W, spp, B = 96, 80, 64, 3
+    scs = [synthetic.make_scene(i, H, W) for i in range(B)]
+    st = lambda k: _t(np.stack([getattr(s, k) for s in scs]), dev)
+    a, r, m, light = st("albedo"), st("roughness"), st("metallic"), st("light")
+    n = ops.normals_from_depth(st("depth"))
+    dcache = ops.diffuse_cache(n, light, spp)
+    floor = 0.3
+    s_b = ops.lazy_state(a)
+    ops.shade_fwd_lazy(a, r, m, n, light, spp, dcache, s_b, force=True, floor=floor)
+    r2 = (r + 0.004 * torch.randn_like(r)).clamp(0.07, 1)
+    nsum = ops._lib.load().matpbr_lazy_sums_count(H, W)
+    sums = torch.zeros((B, nsum), device=dev)
+    out_b, j_b = ops.shade_fwd_lazy(a, r2, m, n, light, spp, dcache, s_b, floor=floor, sums=sums)
+    # the partial sums add up to the sum of the render
+    assert torch.allclose(sums.sum(1), out_b.reshape(B, -1).sum(1), rtol=1e-5)
+    for b in range(B):
+        s1 = ops.lazy_state(a[b])
+        dc1 = ops.diffuse_cache(n[b], light[b], spp)
+        ops.shade_fwd_lazy(a[b], r[b], m[b], n[b], light[b], spp, dc1, s1, force=True, floor=floor)
+        out1, j1 = ops.shade_fwd_lazy(a[b], r2[b], m[b], n[b], light[b], spp, dc1, s1, floor=floor)
+        assert torch.equal(out_b[b], out1.reshape(out_b[b].shape)), b
+        assert torch.equal(j_b[:, b], j1[:, 0]), b
+    # same call sequence again: bit-identical
+    s_c = ops.lazy_state(a)
+    ops.shade_fwd_lazy(a, r, m, n, light, spp, dcache, s_c, force=True, floor=floor)
+    out_c, _ = ops.shade_fwd_lazy(a, r2, m, n, light, spp, dcache, s_c, floor=floor)
+    assert torch.equal(out_b, out_c) and torch.equal(s_b, s_c)
+
+
+def _phase_setup(dev, H, W, spp, image_id=0):
+    from materialist_amd import render, synthetic
+
+    sc = synthetic.make_scene(image_id, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    return scene, gt, init
+
+
+def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_iteration():
+    """THE GATE: 2 000 iterations of part 'rm' at 512 x 512 (lr schedule of inverse_img_w_mi.py:363-365,431-432).  Every iteration's
+    lazy render against the exact render of the same parameters; d out / d r of the just re-sampled pixels against the exact jac."""
+    from materialist_amd import loop, ops
+
+    dev = _cuda()
+    H = W = 512
+    spp, iters = 64, 2000
+    scene, gt, init = _phase_setup(dev, H, W, spp)
+    ph = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp, lazy=True, history_len=iters)
+    assert ph.lazy and ph.lazy_state is not None
+    worst = torch.zeros((), device=dev)
+    worst_dr = torch.zeros((), device=dev)
+    nref = torch.zeros(iters, device=dev)
+    exact, jac = torch.empty_like(gt), ops.plane9(gt)
+    for it in range(iters):
+        pa, pr, pm = ph.p["albedo"].clone(), ph.p["roughness"].clone(), ph.p["metallic"].clone()
+        ph.step()
+        ops.shade_fwd(pa, pr, pm, ph.n, ph.light, spp, clamp_params=True, out=exact, dcache=ph.dcache, jac=jac)
+        worst = torch.maximum(worst, _rel(ph.pred, exact))
+        # the pixels listed for re-sampling by this step's last launch (their new roughness left the model's interval)
+        _, ref = ops.lazy_state_unpack(ph.lazy_state, pa)
+        nref[it] = ref.float().mean() if it else 1.0
+        if it % 100 == 1:
+            # d out / d r right after a re-sampling: the same models, stand-alone, at the parameters as they are now
+            pn = [ph.p[k].clone() for k in ("albedo", "roughness", "metallic")]
+            st2 = ph.lazy_state.clone()
+            _, j16 = ops.shade_fwd_lazy(*pn, ph.n, ph.light, spp, ph.dcache, st2, clamp_params=True, floor=0.5 * float(gt.mean()))
+            _, ref2 = ops.lazy_state_unpack(st2, pa)
+            ops.shade_fwd(*pn, ph.n, ph.light, spp, clamp_params=True, out=exact, dcache=ph.dcache, jac=jac)
+            jl = ops.jac16_unpack(j16, pa)
+            sel = ref2.reshape(-1) > 0
+            if bool(sel.any()):
+                e = (jl[6:9].reshape(3, -1) - jac[6:9].reshape(3, -1)).abs() / torch.maximum(jac[6:9].reshape(3, -1).abs(), jac[6:9].abs().mean())
+                worst_dr = torch.maximum(worst_dr, e[:, sel].max())
+    nref = nref.cpu().numpy()
+    print(f"lazy gate: worst |lazy - exact| / scale over {iters} iterations = {float(worst):.3e}; d_r at refresh points {float(worst_dr):.3e}; "
+          f"re-sampled fraction: first 100 its {nref[1:100].mean():.4f}, 100-500 {nref[100:500].mean():.4f}, 500-2000 {nref[500:].mean():.4f}")
+    assert float(worst) <= 1e-3
+    assert float(worst_dr) <= 2e-3
+    assert nref[0] == 1.0 and nref[1:].mean() < 0.1
+
+
+def test_lazy_phase_lands_where_the_phase_that_walks_every_sample_lands():
+    """400 iterations of 'rm' then 'arm' style steps, lazy against exact sampling: the loss curves agree to 1 % and the maps end
+    within a fraction of the distance travelled."""
+    from materialist_amd import loop, ops
+
+    dev = _cuda()
+    H = W = 256
+    spp, iters = 64, 400
+    scene, gt, init = _phase_setup(dev, H, W, spp, image_id=1)
+    for part in ("rm", "arm"):
+        lz = loop.FusedBrdfPhase(scene, gt, *init, optimize_part=part, spp=spp, lazy=True, history_len=iters)
+        ex = loop.FusedBrdfPhase(scene, gt, *init, optimize_part=part, spp=spp, lazy=False, history_len=iters)
+        lz.run(iters)
+        ex.run(iters)
+        h_l, h_e = lz.history()[:, 0].cpu().numpy(), ex.history()[:, 0].cpu().numpy()
+        assert h_e[-1] < 0.8 * h_e[0]
+        assert np.abs(h_l - h_e).max() <= 0.01 * h_e.max(), part
+        assert abs(h_l[-1] - h_e[-1]) <= 0.01 * h_e[-1], part
+        for k in ("roughness", "metallic") + (("albedo",) if "a" in part else ()):
+            moved = (ex.p[k] - init[{"albedo": 0, "roughness": 1, "metallic": 2}[k]]).abs().mean().item()
+            diff = (lz.p[k] - ex.p[k]).abs().mean().item()
+            assert diff < 0.05 * moved + 1e-5, (part, k, diff, moved)
+        assert float(lz.stats[0, ops.STAT_BEST]) == pytest.approx(float(ex.stats[0, ops.STAT_BEST]), rel=0.01)
+
+
+def test_lazy_phase_early_stopping_and_batch():
+    """The device-side EarlyStopping and the per-image skip work the same on the lazy path; a batched lazy phase equals its images
+    run alone, bit for bit."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    H, W, spp, B = 64, 96, 16, 2
+    scs = [synthetic.make_scene(10 + i, H, W) for i in range(B)]
+    st = lambda k: _t(np.stack([getattr(s, k) for s in scs]), dev)
+    scene_b = render.load_estimated_mesh(st("depth"), use_mesh_normal=True)
+    scene_b._set("emitter.data", st("light"))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene_b, st("albedo"), st("roughness"), st("metallic"), None, spp)
+    init = [st(k) for k in ("init_albedo", "init_roughness", "init_metallic")]
+    fb = loop.FusedBrdfPhase(scene_b, gt, *init, optimize_part="rm", spp=spp, lazy=True)
+    fb.run(30)
+    for b in range(B):
+        s1 = render.load_estimated_mesh(st("depth")[b], use_mesh_normal=True)
+        s1._set("emitter.data", st("light")[b])
+        f1 = loop.FusedBrdfPhase(s1, gt[b], *[x[b] for x in init], optimize_part="rm", spp=spp, lazy=True)
+        f1.run(30)
+        for k in ("roughness", "metallic"):
+            assert torch.equal(fb.p[k][b], f1.p[k]), (b, k)
+        assert float(fb.stats[b, ops.STAT_MSE]) == float(f1.stats[0, ops.STAT_MSE])
+    es = loop.FusedBrdfPhase(scene_b, gt, *init, optimize_part="arm", spp=spp, patience=4, min_delta=0.5, lazy=True)
+    es.run(12)
+    info = es.poll()
+    assert info["stopped"].tolist() == [True] * B and info["iters"].tolist() == [5] * B
+    frozen = {k: v.clone() for k, v in es.p.items()}
+    es.run(3)
+    assert all(torch.equal(frozen[k], es.p[k]) for k in frozen)

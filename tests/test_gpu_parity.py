@@ -434,7 +434,7 @@ def test_fused_brdf_phase_matches_torch_composition():
     with torch.no_grad():
         gt = render.render_w_brdf(make_scene(), _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
     ref = loop.BrdfPhase(make_scene(), gt, *init, None, optimize_part="arm", spp=spp)
-    fused = loop.FusedBrdfPhase(make_scene(), gt, *init, spp=spp)
+    fused = loop.FusedBrdfPhase(make_scene(), gt, *init, spp=spp, lazy=False)   # the kernels that walk every sample; lazy path: test_gpu_lazy.py
     for it in range(5):
         mse_ref = ref.step()
         fused.step()
@@ -468,7 +468,7 @@ def test_fused_phase_parts_and_device_early_stopping():
     init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
     # part 'rm': albedo must not move; reference composition with the same part
     ref = loop.BrdfPhase(scene, gt, *init, None, optimize_part="rm", spp=spp)
-    fused = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp)
+    fused = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp, lazy=False)
     for _ in range(3):
         mse_ref = ref.step()
         fused.step()
@@ -477,7 +477,7 @@ def test_fused_phase_parts_and_device_early_stopping():
     assert (fused.p["roughness"] - ref.params["roughness"].detach()).abs().max().item() < 3e-5
     assert float(fused.stats[0, ops.STAT_LA]) == 0.0 and float(fused.stats[0, ops.STAT_LR]) > 0.0
     # early stopping: huge min_delta -> every iteration after the first is a miss -> stops after 1 + patience iterations
-    es = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="arm", spp=spp, patience=4, min_delta=0.5)
+    es = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="arm", spp=spp, patience=4, min_delta=0.5, lazy=False)
     es.run(12)
     info = es.poll()
     assert info["stopped"].tolist() == [True] and info["iters"].tolist() == [5]
@@ -501,7 +501,7 @@ def test_fused_phase_parts_and_device_early_stopping():
     with torch.no_grad():
         pred0 = render.render_w_brdf(scb, initb[0].clamp(0, 1), initb[1].clamp(0.07, 1), initb[2].clamp(0, 1), None, spp)
     gtb = torch.stack([gt, pred0[1]]).contiguous()
-    fb = loop.FusedBrdfPhase(scb, gtb, *initb, optimize_part="arm", spp=spp, patience=3, min_delta=0.3)
+    fb = loop.FusedBrdfPhase(scb, gtb, *initb, optimize_part="arm", spp=spp, patience=3, min_delta=0.3, lazy=False)
     fb.run(10)
     ib = fb.poll()
     assert ib["iters"][0].item() >= ib["iters"][1].item() and ib["stopped"][1].item()

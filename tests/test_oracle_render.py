@@ -89,3 +89,45 @@ def test_normals_from_depth_plane(oracle64):
     n = oracle64.normals_from_depth(2.0 + 0.002 * jj)
     assert (n[8:-8, 8:-8, 0] > 0).all() and (n[..., 2] > 0).all()
     np.testing.assert_allclose(np.linalg.norm(n, axis=-1), 1.0, atol=1e-12)
+
+
+def test_lazy_specification_stays_within_the_parity_bar_on_a_drifting_roughness(oracle64):
+    """The specification of the lazy re-sampling path (oracle lazy_refresh_pixel / lazy_eval_pixel, mirrored by csrc/matpbr_lazy.hpp):
+    a forced call is the exact render; while every pixel's roughness drifts by up to 3e-4 per step (Adam's bound at the reference's
+    learning rate, inverse_img_w_mi.py:359) the lazy render stays within 1e-3 max(|exact|, mean|exact|) of walking every sample, the
+    models are rebuilt for a small fraction of the pixels, and the jac it hands to the backward pass is the exact one at refresh."""
+    from materialist_amd import synthetic
+
+    H, W, spp, T = 24, 32, 64, 120
+    sc = synthetic.make_scene(3, H, W)
+    o = oracle64
+    f64 = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    a, m, light = f64(sc.albedo), f64(sc.metallic), f64(sc.light)
+    n = o.normals_from_depth(f64(sc.depth))
+    rng = np.random.default_rng(0)
+    n = n + 0.3 * rng.normal(size=n.shape)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    r = np.clip(f64(sc.roughness), 0.07, 1.0)
+    state = np.zeros((H, W, o.lazy_nstate()))
+    vel = rng.uniform(-1, 1, r.shape)
+    worst, frac = 0.0, []
+    for t in range(T):
+        exact = o.shade_fwd(a, r, m, n, light, spp)
+        floor = 0.5 * np.abs(exact).mean()
+        lazy, jac, ref = o.lazy_fwd(a, r, m, n, light, state, spp, floor, force=(t == 0))
+        err = np.abs(lazy - exact) / np.maximum(np.abs(exact), np.abs(exact).mean())
+        if t == 0:
+            assert err.max() < 1e-13 and ref.all()
+            d_r = o.shade_bwd(a, r, m, n, light, np.ones_like(exact), spp, want_n=False, want_light=False)[1]
+            np.testing.assert_allclose(jac[..., 6:9].sum(-1), d_r[..., 0], rtol=1e-10, atol=1e-12)
+        else:
+            frac.append(ref.mean())
+        worst = max(worst, err.max())
+        vel = 0.9 * vel + 0.1 * rng.normal(size=r.shape)
+        r = np.clip(r + 3e-4 * np.tanh(3 * vel), 0.07, 1.0)
+    assert worst < 1e-3, worst
+    assert 0.0 < np.mean(frac) < 0.15, np.mean(frac)
+    # every interval is positive, no wider than the radius, and the radius inside its bounds
+    assert (state[..., 1] > 0).all() and (state[..., 2] > 0).all()
+    assert (state[..., 1] <= state[..., 3] + 1e-15).all() and (state[..., 2] <= state[..., 3] + 1e-15).all()
+    assert (state[..., 3] >= 2.5e-4).all() and (state[..., 3] <= 3e-2).all()

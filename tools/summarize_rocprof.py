@@ -22,7 +22,7 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"# kernel stats ({os.path.relpath(f, d)}): total {tot / 1e6:.3f} ms over {sum(int(r['Calls']) for r in rows)} dispatches")
     print("name,calls,avg_us,min_us,max_us,pct")
-    OWN = ("shade_", "relight", "loss_", "adam", "light_grad", "colsum", "normals_from", "eval_brdf", "sample_brdf", "sh_eval", "jac_bwd", "env_", "diffuse_cache", "mlp_")
+    OWN = ("lazy_", "shade_", "relight", "loss_", "adam", "light_grad", "colsum", "normals_from", "eval_brdf", "sample_brdf", "sh_eval", "jac_bwd", "env_", "diffuse_cache", "mlp_")
     for i, r in enumerate(rows):
         if everything or i < 14 or any(k in r["Name"] for k in OWN):       # the top of the list plus every kernel of libmatpbr.so
             print(f"{short(r['Name'])},{r['Calls']},{float(r['AverageNs']) / 1e3:.2f},{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f},{r['Percentage']}")
