@@ -1031,8 +1031,6 @@ int matpbr_lazy_sums_count(int H, int W) {
     return lazy_fwd_blocks((long)H * W) + lazy_groups((long)H * W);
 }
 
-static long long* g_lazy_dbg = nullptr;
-extern "C" void matpbr_dbg_set(long long* p) { g_lazy_dbg = p; }
 struct LazyBuffers { uint32_t* planes; uint32_t* counts; uint16_t* lists; int nblk, ngrp; };
 static LazyBuffers lazy_buffers(void* lazy_state, long P, int batch) {
     LazyBuffers lb;
@@ -1053,7 +1051,6 @@ static int lazy_refresh(const float* a, const float* r, const float* m, const fl
     ra.a = a; ra.r = r; ra.m = m; ra.n = n; ra.dcache = dcache; ra.state = lb.planes; ra.out = out_rgb; ra.jac16 = (uint32_t*)jac16; ra.stats = stats;
     ra.block_sums = sums; ra.counts = lb.counts; ra.lists = lb.lists; ra.clamp = clamp; ra.force = force; ra.n_sums = lb.nblk + lb.ngrp;
     ra.n_fwd = lb.nblk; ra.nblk = lb.nblk; ra.floor = floor_; ra.tol = tol > 0.0f ? tol : 1.0f;
-    ra.dbg = g_lazy_dbg;
     if (tab.nphi_s <= 4)
         hipLaunchKernelGGL(lazy_refresh_kernel<4>, dim3((unsigned)lb.ngrp, (unsigned)batch), dim3(kBlock), 0, st, ra, light, g, tab);
     else
@@ -1184,7 +1181,7 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     const bool lazy = q.lazy_state != nullptr && (q.part_mask & MATPBR_PART_R) && q.dcache != nullptr &&
                       lazy_fwd_blocks((long)q.H * q.W) <= kLazyMaxBlocks;
     const bool lazy_fused = lazy && q.pred_next != nullptr;   // backward of this iteration and forward of the next one in one launch
-    const int nfwd = grid_blocks(q.H, q.W) + (lazy ? lazy_groups((long)q.H * q.W) : 0);
+    const int nfwd = grid_blocks(q.H, q.W) + ((lazy && !(lazy_fused && t > 1)) ? lazy_groups((long)q.H * q.W) : 0);
     float* fwd_sums = (float*)q.workspace;
     float* part = fwd_sums + (size_t)q.batch * nfwd;
     const long n1 = (long)q.H * q.W, n3 = n1 * 3;
@@ -1199,11 +1196,8 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     const bool r_fixed = !(q.part_mask & MATPBR_PART_R) && q.s1cache != nullptr;
     sa.s1 = r_fixed ? q.s1cache : nullptr;
     if (lazy_fused && t > 1) {
-        // pred already holds this iteration's render (written by the previous step's launch as pred_next; the caller swapped the two): only
-        // the pixels that left their model's interval are pending
-        const int rc = lazy_refresh(q.pa, q.pr, q.pm, q.n, q.light, q.dcache, q.lazy_state, q.pred, nullptr, q.stats, fwd_sums, g, tab, q.batch, 1, 0,
-                                    0.0f, q.lazy_tol, st);
-        if (rc != MATPBR_OK) return rc;
+        // pred already holds this iteration's render, complete, and fwd_sums its partial sums: written by the previous step's last launch
+        // (as pred_next; the caller swapped the two)
     } else if (lazy) {
         const int rc = lazy_forward(q.pa, q.pr, q.pm, q.n, q.light, q.dcache, q.lazy_state, q.pred, q.jac, q.stats, fwd_sums, g, tab, q.batch, 1,
                                     t == 1 ? 1 : 0, 0.0f, q.lazy_tol, st);
@@ -1237,9 +1231,9 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
         LazyStepArgs ls{};
         ls.j = jb;
         for (int k = 0; k < kLzPlanes; ++k) ls.plane[k] = lb.planes + (size_t)k * (size_t)q.batch * (size_t)n1;
-        ls.pred_next = q.pred_next; ls.block_sums = fwd_sums; ls.counts = lb.counts; ls.lists = lb.lists;
-        ls.n_sums = lb.nblk + lb.ngrp;
-        hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, (int)n1);
+        ls.pred_next = q.pred_next; ls.block_sums = fwd_sums; ls.n = q.n; ls.dcache = q.dcache; ls.counts = lb.counts; ls.lists = lb.lists; ls.n_sums = lb.nblk;
+        ls.tol = q.lazy_tol > 0.0f ? q.lazy_tol : 1.0f;
+        hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);
     } else if (lazy)
         hipLaunchKernelGGL((jac_bwd_kernel<true, true>), dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);
     else

@@ -130,6 +130,38 @@ __global__ __launch_bounds__(kBlock) void lazy_fwd_kernel(const LazyFwdArgs q, i
     }
 }
 
+// ---- shared by the re-sampling code of both kernels below -------------------------------------------------------------------
+__device__ __forceinline__ void pixel_set_r(Pixel& px, f2 r) {
+    px.r = r;
+    px.alpha2 = pow4(r);
+    px.am1 = px.alpha2 - 1.0f;
+    const f2 rp1 = r + 1.0f, k = (rp1 * rp1) * 0.125f;
+    px.omk = 1.0f - k;
+    px.kpe = k + 1e-6f;
+    px.dk_dr = rp1 * 0.25f;
+    px.g1v = rcp(vfma(px.NoV, px.omk, px.kpe));
+}
+// (selects, not branches on which bound to update: a reference picked by a branch sends lo / hi to scratch memory)
+__device__ __forceinline__ void lazy_kink(float x, float xp, float J, float tol_k, float& lo, float& hi) {
+    const bool valid = (J * kLzRhoMax > tol_k) && (fabsf(xp) > 1e-12f);
+    const float dk = -x * rcp(xp) * kLzKinkSafety, ad = fabsf(dk) + tol_k * rcp(J);
+    const bool both = fabsf(dk) < 2.0f * kLzH, up = dk > 0.0f;
+    hi = (valid && (both || up)) ? fminf(hi, ad) : hi;
+    lo = (valid && (both || !up)) ? fminf(lo, ad) : lo;
+}
+template <int LPI>
+__device__ __forceinline__ float lane_group_sum(float v) {
+#pragma unroll
+    for (int msk = 1; msk < LPI; msk <<= 1) v += __shfl_xor(v, msk);
+    return v;
+}
+template <int LPI>
+__device__ __forceinline__ float lane_group_min(float v) {
+#pragma unroll
+    for (int msk = 1; msk < LPI; msk <<= 1) v = fminf(v, __shfl_xor(v, msk));
+    return v;
+}
+
 // =================================================================================================
 // one launch per iteration of hot loop B: backward of iteration t + Adam + forward of iteration t+1
 // =================================================================================================
@@ -141,14 +173,26 @@ __global__ __launch_bounds__(kBlock) void lazy_fwd_kernel(const LazyFwdArgs q, i
 // roughness has left their interval are listed for lazy_refresh_kernel, which patches pred_{t+1} at the head of the next step.
 // In parts that do not optimise the albedo the SaveBest snapshot of the albedo is not rewritten (it cannot have changed).
 struct LazyStepArgs {
-    JacBwdArgs j;             // as for jac_bwd_kernel<FUSED> (jac unused; pred = pred_t, complete)
-    const uint32_t* plane[kLzPlanes];   // the model planes, one base pointer each (scalar operands of the loads)
-    float* pred_next;         // [B,H,W,3] render of the updated parameters (listed pixels pending)
+    JacBwdArgs j;             // as for jac_bwd_kernel<FUSED> (jac unused; pred = pred_t)
+    uint32_t* plane[kLzPlanes];   // the model planes, one base pointer each (scalar operands of the loads)
+    float* pred_next;         // [B,H,W,3] render of the updated parameters
     float* block_sums;        // [B][n_sums]: slot blockIdx.x
-    uint32_t* counts;
+    const float *n, *dcache;  // shading normals, diffuse coefficients (re-sampling only)
+    uint32_t* counts;         // per workgroup: how many of its pixels were re-sampled, and which (inspection: matpbr_lazy_state_unpack)
     uint16_t* lists;
     int n_sums;
+    float tol;
 };
+// LDS exchange between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be held back
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// what the lane that owns a pixel hands to the lanes that walk its samples
+struct LazyRecord { float a[3], r, m, dr; };
+constexpr int kRecStride = 7;         // floats per record: pixel, a (clamped, updated), r, m, r - r_ref (odd stride: conflict-free)
+constexpr int kWalkVals = 20;         // per-sample contributions: S0, S1, dS0, dS1 at r (12), S0, S1 at r + dir h (6), interval lo / hi
 
 // Loads / stores at (wave-uniform base pointer) + (32-bit per-lane byte offset): the form the hardware addresses directly
 // (global_load ... v_off, s[base]); indexing 21 planes through 64-bit per-lane arithmetic costs more VALU issue slots than the
@@ -158,7 +202,7 @@ __device__ __forceinline__ float ldf(const void* base, unsigned off) { return *(
 __device__ __forceinline__ void stf(void* base, unsigned off, float v) { *(float*)((char*)base + off) = v; }
 
 // one pixel of lazy_step_kernel; returns whether the pixel's new roughness has left its model's interval, adds its render to `tot`
-__device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned i, float ratio, float sr, bool improved, float& tot) {
+__device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned i, float ratio, float sr, bool improved, float& tot, LazyRecord& rec) {
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
     const float ra[3] = {ldf(q.a, o3), ldf(q.a, o3 + 4), ldf(q.a, o3 + 8)}, rr = ldf(q.r, o1), rm = ldf(q.m, o1);
@@ -230,14 +274,16 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
     // ---- forward of iteration t+1 from the same model
     const float r1 = fminf(fmaxf(nr, 0.07f), 1.0f), m1 = fminf(fmaxf(nm, 0.0f), 1.0f), dr1 = r1 - rref, omm1 = 1.0f - m1;
     const bool need = !(dr1 >= -h2_lo(lohi) && dr1 <= h2_hi(lohi));
-    if (!need) {
+    rec.r = r1; rec.m = m1; rec.dr = dr1;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float a1 = fminf(fmaxf(na[c], 0.0f), 1.0f);
-            const float Pc = fmaf(fmaf(h2_hi(pk[c]), dr1, h2_lo(pk[c])), dr1, Pv[c]);
-            const float SD = fmaf(h2_lo(sk[c]), dr1, SDv[c]), S1 = fmaf(h2_hi(sk[c]), dr1, S1v[c]);
-            const float C0 = fmaf(m1, a1, omm1 * 0.04f);
-            const float rgb = fmaf(a1 * omm1, Pc, fmaf(C0, SD, S1));
+    for (int c = 0; c < 3; ++c) {
+        const float a1 = fminf(fmaxf(na[c], 0.0f), 1.0f);
+        const float Pc = fmaf(fmaf(h2_hi(pk[c]), dr1, h2_lo(pk[c])), dr1, Pv[c]);
+        const float SD = fmaf(h2_lo(sk[c]), dr1, SDv[c]), S1 = fmaf(h2_hi(sk[c]), dr1, S1v[c]);
+        const float C0 = fmaf(m1, a1, omm1 * 0.04f);
+        const float rgb = fmaf(a1 * omm1, Pc, fmaf(C0, SD, S1));
+        rec.a[c] = a1;
+        if (!need) {
             stf(qs.pred_next, o3 + 4 * c, rgb);
             tot += rgb;
         }
@@ -245,38 +291,229 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
     return need;
 }
 
-// a workgroup takes 512 consecutive pixels, thread t the pixels t and t + 256 of them: every load instruction of a wave covers 64
-// consecutive pixels, and the two pixels' independent chains interleave
-__global__ __launch_bounds__(kBlock) void lazy_step_kernel(const LazyStepArgs qs, int P) {
+// SH radiance with the (pre-normalised) coefficients in LDS: the walk below runs one sample per lane inside a streaming kernel and
+// cannot afford the 76 VGPRs that hold the coefficients in shade_kernel
+struct RadianceLdsUse {
+    const float* c;
+    f2* L;
+    template <int K> __device__ __forceinline__ void operator()(f2 Bk) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) L[ch] = K == 0 ? f2{c[ch], c[ch]} : vfma(Bk, c[3 * K + ch], L[ch]);
+    }
+};
+
+// A workgroup takes 512 consecutive pixels, thread t the pixels t and t + 256 of them (every load instruction of a wave covers 64
+// consecutive pixels, the two pixels' independent chains interleave).  Pixels whose new roughness has left their model's interval
+// -- a few of the 512 per iteration -- are re-sampled before the workgroup ends: eight lanes per pixel, four azimuths x (r, r + dir h:
+// the one-sided difference that gives the slopes), each lane walking the rings of its azimuth, contributions folded by a fixed
+// butterfly; waves without listed pixels leave at once.  The render this launch leaves behind is complete.
+__global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
     __shared__ float s_sum[4];
     __shared__ int s_cnt[4];
+    __shared__ float s_light[kNL + 1];
+    __shared__ float4 s_ring[kMaxRings];
+    __shared__ float2 s_saz[kMaxRings * kMaxAz];
+    __shared__ float s_rec[kLazyBlockPixels * kRecStride];
     const JacBwdArgs& q = qs.j;
     const int b = blockIdx.y;
     if (q.check_stop && img_stopped_before(q.stats, b)) return;
+    const int P = g.H * g.W;
     const int q0 = blockIdx.x * kLazyBlockPixels + threadIdx.x, q1 = q0 + kBlock;
     const float ratio = q.stats[b * kStatsStride + kStRatio], sr = q.stats[b * kStatsStride + kStSr];
     const bool improved = q.stats[b * kStatsStride + kStImproved] > 0.5f;
+    if (threadIdx.x < kNL) s_light[threadIdx.x] = light[(long)b * kNL + threadIdx.x] * kShNorm[threadIdx.x / 3];
+    if (threadIdx.x < kMaxRings * kMaxAz) s_saz[threadIdx.x] = (&tab.saz[0][0])[threadIdx.x];
+    if (threadIdx.x < kMaxRings) s_ring[threadIdx.x] = tab.sring[threadIdx.x];
     float tot = 0.0f;
     bool need0 = false, need1 = false;
-    if (q0 < P) need0 = lazy_step_pixel(qs, (unsigned)(b * P + q0), ratio, sr, improved, tot);
-    if (q1 < P) need1 = lazy_step_pixel(qs, (unsigned)(b * P + q1), ratio, sr, improved, tot);
+    LazyRecord rec0, rec1;
+    if (q0 < P) need0 = lazy_step_pixel(qs, (unsigned)(b * P + q0), ratio, sr, improved, tot, rec0);
+    if (q1 < P) need1 = lazy_step_pixel(qs, (unsigned)(b * P + q1), ratio, sr, improved, tot, rec1);
     const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int n0 = __popcll(b0), nw = n0 + __popcll(b1);
-    tot = wave_sum_to_lane63(tot);
-    if (lane == 63) { s_cnt[wave] = nw; s_sum[wave] = tot; }
+    const int n0 = __popcll(b0);
+    if (lane == 63) s_cnt[wave] = n0 + __popcll(b1);
     __syncthreads();
     int base = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) base += w < wave ? s_cnt[w] : 0;
-    uint16_t* list = qs.lists + ((long)b * gridDim.x + blockIdx.x) * kLazyBlockPixels;
-    if (need0) list[base + __popcll(b0 & below)] = (uint16_t)threadIdx.x;
-    if (need1) list[base + n0 + __popcll(b1 & below)] = (uint16_t)(kBlock + threadIdx.x);
-    if (threadIdx.x == 0) {
-        qs.counts[(long)b * gridDim.x + blockIdx.x] = (uint32_t)((s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]));
-        qs.block_sums[(long)b * qs.n_sums + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    const int count = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+    const int idx0 = base + __popcll(b0 & below), idx1 = base + n0 + __popcll(b1 & below);   // fixed order: wave, first / second pixel, lane
+    if (count > 0) {
+        // the owners hand their pixels over (records in list order) and are done with them
+        auto deposit = [&](bool need, int idx, int local, const LazyRecord& rc) {
+            if (need) {
+                float* o = s_rec + idx * kRecStride;
+                o[0] = __builtin_bit_cast(float, local);
+                o[1] = rc.a[0]; o[2] = rc.a[1]; o[3] = rc.a[2]; o[4] = rc.r; o[5] = rc.m; o[6] = rc.dr;
+            }
+        };
+        deposit(need0, idx0, (int)threadIdx.x, rec0);
+        deposit(need1, idx1, (int)(kBlock + threadIdx.x), rec1);
+        __syncthreads();
+        float floor_;
+        {
+            const float rt = q.stats[b * kStatsStride + kStRatio];
+            floor_ = 0.5f * q.stats[b * kStatsStride + kStGtSum] / (3.0f * (float)P) / (rt > 0.0f ? rt : 1.0f);
+        }
+        const float tol_k = qs.tol * kLzTolK, tol_s = qs.tol * kLzTolS;
+        const int sub = lane & 7, half = sub >> 2, azi = sub & 3;
+        const long BPl = (long)gridDim.y * P;
+        // a wave walks the items of its own lane groups and exchanges through its own slice of s_red: no workgroup barrier, and a
+        // wave without items is done
+        // eight lanes per pixel: 32 pixels per pass of the workgroup, a wave whose lanes have no pixel left is done
+        for (int ib = wave * 8; ib < count; ib += 32) {
+            const int item = ib + (lane >> 3);
+            const bool item_ok = item < count;
+            const float* rc = s_rec + (item_ok ? item : ib) * kRecStride;
+            const int p = blockIdx.x * kLazyBlockPixels + __builtin_bit_cast(int, rc[0]);
+            const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
+            const float rc_r = rc[4], mv = rc[5], dr = rc[6];
+            // geometry of the pixel (the same at r and at r + dir h: plain floats), as load_pixel forms it
+            float nn[3], ss[3], tt[3], vx, vy, vz, NoV;
+            {
+                float nv[3] = {ldf(qs.n, o3), ldf(qs.n, o3 + 4), ldf(qs.n, o3 + 8)};
+                const float inl = rsq(fmaxf(dot3(nv, nv), 1e-30f));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) nn[c] = nv[c] * inl;
+                const float fi = (float)(p / g.W), fj = (float)(p % g.W);
+                const float x = (g.cx - fj) * g.inv_f, y = (fi - g.cy) * g.inv_f, il = rsq(fmaf(x, x, fmaf(y, y, 1.0f)));
+                const float wo[3] = {x * il, y * il, il};
+                frame(nn, ss, tt);
+                vx = dot3(ss, wo); vy = dot3(tt, wo); vz = dot3(nn, wo);
+                NoV = fmaxf(vz, 0.0f);
+            }
+            float dir = dr < 0.0f ? -1.0f : 1.0f;
+            if (rc_r + dir * kLzH > 1.0f || rc_r + dir * kLzH < 0.07f) dir = -dir;
+            float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3], pSD[3], pS1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float A0 = ldf(qs.dcache + c * BPl, o1), A1 = ldf(qs.dcache + (3 + c) * BPl, o1);
+                A2[c] = ldf(qs.dcache + (6 + c) * BPl, o1);
+                const uint32_t sk = ldu(qs.plane[kLzSk + c], o1);      // what the old model predicts at the new roughness
+                pSD[c] = fmaf(h2_lo(sk), dr, as_f(ldu(qs.plane[kLzSD + c], o1)));
+                pS1[c] = fmaf(h2_hi(sk), dr, as_f(ldu(qs.plane[kLzS1 + c], o1)));
+                Pc[c] = fmaf(fmaf(A2[c], rc_r, A1), rc_r, A0);
+                dP[c] = fmaf(2.0f * rc_r, A2[c], A1);
+                kd[c] = rc[1 + c] * (1.0f - mv);
+                C0[c] = fmaf(mv, rc[1 + c], (1.0f - mv) * 0.04f);
+                iscale[c] = 1.0f / fmaxf(fabsf(fmaf(kd[c], Pc[c], fmaf(C0[c], pSD[c], pS1[c]))), floor_);
+            }
+            // ---- this lane's samples: one azimuth of every ring, at r (sub 0-3) or at r + dir h (sub 4-7)  (spec_ring / spec_sample /
+            // spec_accumulate of matpbr_shade.hpp, one value per lane)
+            float S0[3] = {0, 0, 0}, S1[3] = {0, 0, 0}, dS0[3] = {0, 0, 0}, dS1[3] = {0, 0, 0}, klo = 1e30f, khi = 1e30f;
+            {
+                const float rr = rc_r + (half ? dir * kLzH : 0.0f);
+                const float alpha2 = pow4(rr), am1 = alpha2 - 1.0f, rp1 = rr + 1.0f, kk = (rp1 * rp1) * 0.125f;
+                const float omk = 1.0f - kk, kpe = kk + 1e-6f, dk_dr = rp1 * 0.25f, g1v = rcp(fmaf(NoV, omk, kpe));
+                const float four_over_r = 4.0f * rcp(rr), cv = dk_dr * g1v * (1.0f - NoV), r3x4 = 4.0f * rr * rr * rr, g1l0 = rcp(kpe);
+                for (int ring = 0; ring < tab.nu_s; ++ring) {
+                    const float4 rg = s_ring[ring];
+                    const float rq = rcp(fmaf(am1, rg.x, 1.0f));
+                    const float cos2 = rq * rg.y, sin2 = (alpha2 * rg.x) * rq, ict = rsq(cos2);
+                    const float ct = cos2 * ict, st = sin2 * rsq(sin2), ringw = (g1v * rg.z) * ict, idq = rcp(rq + 1e-6f * rcp(alpha2));
+                    const float lam0 = fmaf(four_over_r, fmaf(rq * idq, -2.0f * rg.y, 1.0f), -cv);
+                    const float gq = r3x4 * rg.x * rq * cos2;      // d sin^2 theta_h / dr  (mi_specular_sampler :232-233)
+                    const float stp = 0.5f * gq * rcp(st), ctp = -0.5f * gq * rcp(ct);
+                    for (int j = azi; j < tab.nphi_s; j += 4) {
+                        asm volatile("" ::: "memory");   // keeps the 75 coefficient reads below inside the loop (hoisted, they pin 75 VGPRs)
+                        const float2 az = s_saz[ring * kMaxAz + j];
+                        const float whx = st * az.x, why = st * az.y;
+                        const float d = fmaf(ct, vz, fmaf(why, vy, whx * vx)), d2 = d + d;
+                        const float wlx = fmaf(d2, whx, -vx), wly = fmaf(d2, why, -vy), wlz = fmaf(d2, ct, -vz);      // 2 (wo.wh) wh - wo  (:245)
+                        float wi[3], B[kNSH], L[3] = {0, 0, 0};
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) wi[c] = fmaf(wlz, nn[c], fmaf(wly, tt[c], wlx * ss[c]));
+                        const float NoL = fmaxf(wlz, 0.0f), dpos = fmaxf(d, 0.0f), g1l = rcp(fmaf(NoL, omk, kpe)), x5 = pow5(1.0f - dpos);
+                        const float wgt = (ringw * g1l) * (NoL * dpos);
+                        sh_poly(wi, B);
+#pragma unroll
+                        for (int k = 0; k < kNSH; ++k) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) L[c] = fmaf(B[k], s_light[3 * k + c], L[c]);
+                        }
+                        const float wx = wgt * x5, wl = wgt * fmaf(dk_dr * g1l, NoL - 1.0f, lam0), wlx5 = wl * x5;
+                        float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            S0[c] = fmaf(wgt, L[c], S0[c]); S1[c] = fmaf(wx, L[c], S1[c]);
+                            dS0[c] = fmaf(wl, L[c], dS0[c]); dS1[c] = fmaf(wlx5, L[c], dS1[c]);
+                            const float aL = fabsf(L[c]) * iscale[c];
+                            m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL);
+                            m2 = fmaxf(m2, aL);
+                        }
+                        // where this sample's clamped variables n.wi and wo.h cross zero, to first order in r
+                        const float dp = fmaf(stp, fmaf(az.x, vx, az.y * vy), ctp * vz);
+                        const float wlzp = 2.0f * fmaf(dp, ct, d * ctp);
+                        lazy_kink(wlz, wlzp, ringw * g1l0 * dpos * m1 * fabsf(wlzp), tol_k, klo, khi);
+                        lazy_kink(d, dp, ringw * g1l * NoL * m2 * fabsf(dp), tol_k, klo, khi);
+                    }
+                }
+            }
+            // fold over the four azimuth lanes with a fixed butterfly (the same tree for every pixel: reproducible)
+            float fv[kWalkVals];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                fv[c] = lane_group_sum<4>(S0[c]); fv[3 + c] = lane_group_sum<4>(S1[c]);
+                fv[6 + c] = lane_group_sum<4>(dS0[c]); fv[9 + c] = lane_group_sum<4>(dS1[c]);
+            }
+            fv[18] = lane_group_min<4>(klo);
+            fv[19] = lane_group_min<4>(khi);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {   // the sums at r + dir h, from the lanes four further up
+                fv[12 + c] = __shfl_down(fv[c], 4);
+                fv[15 + c] = __shfl_down(fv[3 + c], 4);
+            }
+            if (item_ok && sub == 0) {
+                const float ih = dir * (1.0f / kLzH);
+                float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    vSD[c] = fv[c] - fv[3 + c];
+                    vS1[c] = fv[3 + c];
+                    gSD[c] = ((fv[12 + c] - fv[15 + c]) - vSD[c]) * ih;
+                    gS1[c] = (fv[15 + c] - fv[3 + c]) * ih;
+                    dSD[c] = fv[6 + c] - fv[9 + c];
+                    dS1v[c] = fv[9 + c];
+                }
+                float rho = as_f(ldu(qs.plane[kLzRho], o1));
+                if (fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
+                    float e = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) e = fmaxf(e, fabsf(fmaf(C0[c], pSD[c] - vSD[c], pS1[c] - vS1[c])) * iscale[c]);
+                    const float want = 0.9f * fabsf(dr) * fsqrt(tol_s / fmaxf(e, 1e-12f));
+                    rho = fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
+                }
+                rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
+                *(uint32_t*)((char*)qs.plane[kLzRref] + o1) = as_u(rc_r);
+                *(uint32_t*)((char*)qs.plane[kLzLoHi] + o1) = pack_h2(0.998f * fminf(fv[18], rho), 0.998f * fminf(fv[19], rho));
+                *(uint32_t*)((char*)qs.plane[kLzRho] + o1) = as_u(rho);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    *(uint32_t*)((char*)qs.plane[kLzP + c] + o1) = as_u(Pc[c]);
+                    *(uint32_t*)((char*)qs.plane[kLzSD + c] + o1) = as_u(vSD[c]);
+                    *(uint32_t*)((char*)qs.plane[kLzS1 + c] + o1) = as_u(vS1[c]);
+                    *(uint32_t*)((char*)qs.plane[kLzPk + c] + o1) = pack_h2(dP[c], A2[c]);
+                    *(uint32_t*)((char*)qs.plane[kLzSk + c] + o1) = pack_h2(gSD[c], gS1[c]);
+                    *(uint32_t*)((char*)qs.plane[kLzDk + c] + o1) = pack_h2(dSD[c], dS1v[c]);
+                    const float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
+                    stf(qs.pred_next, o3 + 4 * c, rgb);
+                    tot += rgb;
+                }
+            }
+        }
     }
+    if (qs.lists) {
+        uint16_t* list = qs.lists + ((long)b * gridDim.x + blockIdx.x) * kLazyBlockPixels;
+        if (need0) list[idx0] = (uint16_t)threadIdx.x;
+        if (need1) list[idx1] = (uint16_t)(kBlock + threadIdx.x);
+        if (threadIdx.x == 0) qs.counts[(long)b * gridDim.x + blockIdx.x] = (uint32_t)count;
+    }
+    tot = wave_sum_to_lane63(tot);
+    if (lane == 63) s_sum[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) qs.block_sums[(long)b * qs.n_sums + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
 }
 
 // =================================================================================================
@@ -296,39 +533,7 @@ struct LazyRefreshArgs {
     const uint16_t* lists;
     int clamp, force, n_sums, n_fwd, nblk;
     float floor, tol;
-    long long* dbg;
 };
-
-__device__ __forceinline__ void pixel_set_r(Pixel& px, f2 r) {
-    px.r = r;
-    px.alpha2 = pow4(r);
-    px.am1 = px.alpha2 - 1.0f;
-    const f2 rp1 = r + 1.0f, k = (rp1 * rp1) * 0.125f;
-    px.omk = 1.0f - k;
-    px.kpe = k + 1e-6f;
-    px.dk_dr = rp1 * 0.25f;
-    px.g1v = rcp(vfma(px.NoV, px.omk, px.kpe));
-}
-// (selects, not branches on which bound to update: a reference picked by a branch sends lo / hi to scratch memory)
-__device__ __forceinline__ void lazy_kink(float x, float xp, float J, float tol_k, float& lo, float& hi) {
-    const bool valid = (J * kLzRhoMax > tol_k) && (fabsf(xp) > 1e-12f);
-    const float dk = -x * rcp(xp) * kLzKinkSafety, ad = fabsf(dk) + tol_k * rcp(J);
-    const bool both = fabsf(dk) < 2.0f * kLzH, up = dk > 0.0f;
-    hi = (valid && (both || up)) ? fminf(hi, ad) : hi;
-    lo = (valid && (both || !up)) ? fminf(lo, ad) : lo;
-}
-template <int LPI>
-__device__ __forceinline__ float lane_group_sum(float v) {
-#pragma unroll
-    for (int msk = 1; msk < LPI; msk <<= 1) v += __shfl_xor(v, msk);
-    return v;
-}
-template <int LPI>
-__device__ __forceinline__ float lane_group_min(float v) {
-#pragma unroll
-    for (int msk = 1; msk < LPI; msk <<= 1) v = fminf(v, __shfl_xor(v, msk));
-    return v;
-}
 
 constexpr int kLazyMaxBlocks = 8192;   // forward workgroups per image whose counts fit the LDS prefix (512 x 8192 pixels = 2048 x 2048)
 template <int LPI>
@@ -338,10 +543,6 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
     __shared__ int s_pref[kLazyMaxBlocks + 1];      // exclusive prefix of the image's per-workgroup counts: the work list is their concatenation
     __shared__ int s_wave[4];
     __shared__ float s_sum[4];
-    long long ts[10];
-    int nts = 0;
-#define LZ_STAMP() do { if (q.dbg) ts[nts++] = wall_clock64(); } while (0)
-    LZ_STAMP();
     if (threadIdx.x < kMaxRings * kMaxAz) s_saz[threadIdx.x] = (&tab.saz[0][0])[threadIdx.x];
     const int b = blockIdx.y;
     const int P = g.H * g.W;
@@ -373,7 +574,6 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
     const int T = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
     if (threadIdx.x == 0) s_pref[q.nblk] = T;
     __syncthreads();
-    LZ_STAMP();
     float tot = 0.0f;
     constexpr int kItems = kBlock / LPI;
     if ((long)blockIdx.x * kItems < T) {
@@ -385,7 +585,6 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
         const float tol_k = q.tol * kLzTolK, tol_s = q.tol * kLzTolS;
         LightRegs lr;
         load_light_regs(lr, light + (long)b * kNL);
-        LZ_STAMP();
         const int sub = threadIdx.x % LPI, slot = threadIdx.x / LPI;
         for (int base = blockIdx.x * kItems; base < T; base += gridDim.x * kItems) {   // chunks of kItems items, strided over the workgroups
             const bool active = base + slot < T;
@@ -398,11 +597,9 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
             const int blk = lo_b;
             const int p = blk * kLazyBlockPixels + (int)q.lists[((long)b * q.nblk + blk) * kLazyBlockPixels + (it - s_pref[blk])];
             const long i = (long)b * P + p;
-            if (base == (int)(blockIdx.x * kItems)) LZ_STAMP();
             Pixel px;
             load_pixel(px, q.a, q.r, q.m, q.n, i, i, p, p, g, q.clamp != 0);
             const float rc = px.r.x, mv = px.m.x;
-            if (base == (int)(blockIdx.x * kItems)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); LZ_STAMP(); }
             // what the old model predicts at the new roughness: the parity scale of this refresh, and the measured extrapolation error
             const bool has_old = !q.force;
             float rho = kLzRhoInit, dr = 0.0f, pSD[3] = {0, 0, 0}, pS1[3] = {0, 0, 0};
@@ -478,7 +675,6 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     lazy_kink(sm.d.x, dp, R.ringw.x * sm.g1l.x * sm.NoL.x * m2 * fabsf(dp), tol_k, klo, khi);
                 }
             }
-            if (base == (int)(blockIdx.x * kItems)) LZ_STAMP();
             klo = lane_group_min<LPI>(klo);
             khi = lane_group_min<LPI>(khi);
             float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3];
@@ -495,7 +691,6 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                 dSD[c] = d0 - d1;
                 dS1v[c] = d1;
             }
-            if (base == (int)(blockIdx.x * kItems)) LZ_STAMP();
             if (active && sub == 0) {
                 if (has_old && fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
                     float e = 0.0f;
@@ -530,11 +725,6 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                 }
             }
         }
-    }
-    LZ_STAMP();
-    if (q.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
-        for (int k = 0; k < nts; ++k) q.dbg[k] = ts[k];
-        q.dbg[15] = nts; q.dbg[14] = T;
     }
     if (q.block_sums) {
         tot = wave_sum_to_lane63(tot);
