@@ -214,7 +214,7 @@ def shade_fwd_lazy(a, r, m, n, light, spp: int, dcache: torch.Tensor, state: tor
 
 
 def lazy_state_unpack(state: torch.Tensor, a: torch.Tensor):
-    """(models [B,H,W,22] in the oracle's layout, refreshed [B,H,W] int32: the pixels the last `shade_fwd_lazy` re-sampled)."""
+    """(models [B,H,W,22]: r_ref, lo, hi, rho, SD, S1, gSD, gS1, dSD, dS1 (rgb each), refreshed [B,H,W] int32: the pixels the last `shade_fwd_lazy` re-sampled)."""
     B, H, W = _bhw(a)
     st = torch.empty((B, H, W, LAZY_NSTATE), dtype=torch.float32, device=a.device)
     ref = torch.empty((B, H, W), dtype=torch.int32, device=a.device)
