@@ -71,11 +71,17 @@ def launch_ranks(n: int, argv) -> int:
 
 
 def cpu_baseline(size, spp, target_s):
-    """Time the fp32 OpenMP build of the CPU oracle (a port of the reference BRDF path, not Mitsuba) on a bounded
-    crop of the same synthetic workload: shade fwd + bwd (materials) of an n x n crop; it/s scaled by pixel count."""
+    """The CPU side of the comparison, on a bounded crop of the same synthetic workload, scaled by pixel count.
+      value        the SAME iteration as the headline (--model_name pos_mlp, part 'rm'): residual PosMLP forward + backward (torch CPU,
+                   fp32, the module of materialist_amd/posmlp.py = the reference's mymodels/mlps.py network) + the reference-literal
+                   spp-sample estimator (sample_brdf's 50/50 lobe choice with the mixture pdf, mi_plugin.py:1296-1341, oracle kind=1)
+                   forward + material backward, fp32 + OpenMP;
+      shade_only   round 2's leg: shade forward + backward alone with the production estimator (what the HIP kernels compute).
+    Neither is Mitsuba (it cannot run here): kind = "port"."""
     import numpy as np
+    import torch
 
-    from materialist_amd import synthetic
+    from materialist_amd import posmlp, synthetic
     from oracle.oracle import Oracle
 
     o = Oracle(np.float32)
@@ -83,26 +89,49 @@ def cpu_baseline(size, spp, target_s):
     sc = synthetic.make_scene(0, size, size)
     n_full = Oracle(np.float64).normals_from_depth(sc.depth.astype(np.float64)).astype(np.float32)
 
-    def run(n):
+    def shade(n, kind):
         sl = (slice(0, n), slice(0, n))
         a, r, m, nn = sc.albedo[sl], sc.roughness[sl], sc.metallic[sl], n_full[sl]
         t0 = time.perf_counter()
-        out = o.shade_fwd(a, r, m, nn, sc.light, spp)
-        o.shade_bwd(a, r, m, nn, sc.light, np.ones_like(out), spp, want_n=False, want_light=False)
+        out = o.shade_fwd(a, r, m, nn, sc.light, spp, kind=kind)
+        o.shade_bwd(a, r, m, nn, sc.light, np.ones_like(out), spp, want_n=False, want_light=False, kind=kind)
         return time.perf_counter() - t0
 
-    t_probe = run(32)
-    per_px = t_probe / (32 * 32)
-    n = int(min(size, max(32, (target_s / per_px) ** 0.5)))
-    n -= n % 8
-    reps, t = 0, 0.0
-    while t < target_s and reps < 64:      # small crops finish early on many-core hosts: repeat up to the time budget
-        t += run(n)
-        reps += 1
-    its = reps * (n * n) / (size * size) / t
+    def timed(fn, budget):
+        t_probe = fn(32)
+        n = int(min(size, max(32, (budget / (t_probe / 1024.0)) ** 0.5)))
+        n -= n % 8
+        reps, t = 0, 0.0
+        while t < budget and reps < 64:      # small crops finish early on many-core hosts: repeat up to the time budget
+            t += fn(n)
+            reps += 1
+        return reps * (n * n) / (size * size) / t, n, reps, t
+
+    its_shade, n_s, reps_s, t_s = timed(lambda n: shade(n, 0), 0.3 * target_s)
+    its_lit, n_l, reps_l, t_l = timed(lambda n: shade(n, 1), 0.3 * target_s)
+    threads = min(cores, 32)                 # torch's CPU GEMMs stop scaling (and start thrashing) far below 256 threads on these shapes
+    torch.set_num_threads(threads)
+    net = posmlp.brdf_net("arm")
+
+    def mlp(n):
+        start = torch.rand(n * n, 5)
+        t0 = time.perf_counter()
+        net.zero_grad(set_to_none=True)
+        y = net(start)
+        y.sum().backward()
+        return time.perf_counter() - t0
+
+    mlp(64)                                  # first call: thread pool / oneDNN set-up
+    its_mlp, n_m, reps_m, t_m = timed(mlp, 0.4 * target_s)
+    its = 1.0 / (1.0 / its_mlp + 1.0 / its_lit)
     return {"value": its, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"oracle f32+OpenMP shade fwd+bwd(arm), {reps} x ({n}x{n} crop of the {size}x{size} spp={spp} image), {t:.1f}s, scaled by pixels; "
-                      "CPU restatement of the reference BRDF path (same estimator as the kernels; not Mitsuba)"}
+            "sample": f"the headline's iteration on the CPU, scaled by pixels from crops of the {size}x{size} image: PosMLP 'arm' forward + backward "
+                      f"(torch CPU fp32, {threads} threads; {reps_m} x {n_m}x{n_m} points, {t_m:.1f}s -> {its_mlp:.3g} it/s) + reference-literal spp={spp} "
+                      f"estimator (oracle kind=1, f32 + OpenMP on {cores} cores) forward + material backward ({reps_l} x {n_l}x{n_l}, {t_l:.1f}s -> "
+                      f"{its_lit:.3g} it/s); not Mitsuba",
+            "shade_only": {"value": its_shade, "unit": "it/s",
+                           "sample": f"oracle f32+OpenMP shade fwd+bwd(arm) with the production estimator, {reps_s} x ({n_s}x{n_s} crop), {t_s:.1f}s, "
+                                     "scaled by pixels (round 2's cpu_baseline)"}}
 
 
 class _Protocol:
@@ -218,6 +247,8 @@ def main(argv=None):
         def phase(self, mode):
             if mode == "fused":
                 return loop.FusedBrdfPhase(self.scene, self.gt_image, *self.init, optimize_part="rm", spp=args.spp)
+            if mode == "fused_exact":                       # every pixel's 20 GGX samples walked in every iteration (round 2's loop)
+                return loop.FusedBrdfPhase(self.scene, self.gt_image, *self.init, optimize_part="rm", spp=args.spp, lazy=False)
             if mode == "fused_a":                           # the second part of --opt_order 'rm a': roughness fixed, specular sums reused
                 return loop.FusedBrdfPhase(self.scene, self.gt_image, *self.init, optimize_part="a", spp=args.spp)
             if mode == "pos_mlp":
@@ -258,7 +289,7 @@ def main(argv=None):
     modes = {mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3, "images_per_gpu": B}}
     wl8 = None
     if not args.no_extras and mode != "torch":
-        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("pos_mlp", 100), ("env", 500)):
+        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("pos_mlp", 100), ("env", 500)):
             if extra == mode or (not extra.startswith("fused") and B > 1):
                 continue
             e_el, _ = proto.timed(wl.phase(extra).step, 10, steps)
@@ -278,7 +309,13 @@ def main(argv=None):
             modes["fused_b8"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
             e_el, _ = proto.timed(wl8.phase("fused_a").step, 10, 300)
             modes["fused_b8_a"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
-    mode_names = {"fused": "hot loop B, --model_name none (whole iteration in libmatpbr.so: render+jac, loss statistics, streaming backward+Adam)",
+            e_el, _ = proto.timed(wl8.phase("fused_exact").step, 10, 100)
+            modes["fused_b8_exact"] = {"it_per_s": 100 * 8 * world / e_el, "ms_per_step": e_el / 100 * 1e3, "images_per_gpu": 8}
+    mode_names = {"fused": "hot loop B, --model_name none, whole iteration in libmatpbr.so: loss statistics (2 launches) + ONE launch for the backward pass, "
+                           "Adam and the next iteration's render from per-pixel local models in the roughness (pixels that left their model's interval "
+                           "are re-sampled in the same launch; |render - exact sampling| <= 1e-3 on every pixel of every iteration, tests/test_gpu_lazy.py)",
+                  "fused_exact": "the same loop walking the 20 GGX samples of every pixel in every iteration (round 2: render+jac, statistics, streaming backward+Adam)",
+                  "fused_b8_exact": "the 8-image shard with exact sampling in every iteration (round 2's fused_b8)",
                   "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
                   "fused_a": "the same loop in part 'a' of --opt_order 'rm a' (roughness fixed): after the part's first render the specular sums of "
                              "every pixel are reused (bit-identical to walking the samples), so the forward is a streaming kernel too",
@@ -340,35 +377,69 @@ def main(argv=None):
             e["frac"] = e["achieved"] / (HBM_PEAK / 1e9)
             return e
 
+        def lazy_step_times(w):
+            """The ONE launch that is the BRDF fwd+bwd pair of the lazy loop (backward of iteration t + Adam + render of iteration t+1), timed
+            IN the loop (iterations 301-500 of a phase, so that the share of pixels re-sampled per launch is the loop's, not the start-up's)
+            with HIP events around it, and the two statistics launches back to back."""
+            ph = w.phase("fused")
+            ph.run(300)
+            ev = []
+            for _ in range(200):
+                ph.step_timed(ev)             # the real loop, HIP events around the launch in question (on the launch stream)
+            torch.cuda.synchronize()
+            t_step = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            _, ref = ops.lazy_state_unpack(ph.lazy_state, ph.p["albedo"])
+            t_stats = back_to_back(lambda: ph.launch_stage(2))
+            return t_step, t_stats, float(ref.float().mean())
+
         wr = wl8 if wl8 is not None else wl
         tk = kernel_times(wr)
         px = H * W * wr.B
-        traffic, tsrc = None, None
+        pmc = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f"brdf_fwd+bwd_{H}x{W}_b{wr.B}_spp{args.spp}")
-                tsrc = tj.get("source")
+                pmc = json.load(open(tpath))
             except Exception:
-                traffic = None
-        roof = entry(px, tk["fwd_loop"], tk["bwd_loop"],
-                     "the in-loop pair of hot loop B: shade_kernel<jac> with the phase's cached diffuse-lobe coefficients (20 GGX samples per pixel) "
-                     "and jac_bwd_kernel<fused> (streaming; no samples); algorithmic bytes = SURVEY 8d's 44 + 64 B/pixel, the kernels also move "
-                     "the 9-float dcache / jac planes (traffic).  The forward is VALU-issue-bound (DESIGN.md section 4)")
-        roof.update({"bound": "hbm", "kernel": "shade_kernel<jac> + jac_bwd_kernel<fused>", "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
-                     "traffic": traffic, "traffic_source": tsrc,
+                pmc = {}
+        key = f"{H}x{W}_b{wr.B}_spp{args.spp}"
+        t_step, t_stats, resampled = lazy_step_times(wr)
+        ach = (BYTES_FWD + BYTES_BWD_ARM) * px / (t_step * 1e-3) / 1e9
+        traffic = pmc.get(f"lazy_step_{key}")
+        roof = {"bound": "hbm", "kernel": "lazy_step_kernel: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, SaveBest "
+                                          "snapshot, Adam) + render of iteration t+1 from per-pixel local models in the roughness, pixels that left their "
+                                          "model's interval re-sampled (20 GGX samples) in the same launch",
+                "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / (HBM_PEAK / 1e9), "avg_launch_ms": t_step,
+                "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM,
+                "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
+                "resampled_fraction": resampled, "stats_launches_ms": t_stats,
+                "traffic": traffic, "traffic_source": pmc.get("source_r03") if traffic else None,
+                "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
+                "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "
+                        "really moves per launch (PMC: maps, the 80 B/pixel models, target, pred in and out, anchors, Adam moments, snapshots), "
+                        "own_traffic_frac = traffic / duration / peak: how close the launch is to the HBM limit on its OWN bytes"}
+        ex = entry(px, tk["fwd_loop"], tk["bwd_loop"],
+                   "round 2's pair (FusedBrdfPhase(lazy=False)): shade_kernel<jac> walks the 20 GGX samples of every pixel (cached diffuse lobe) + "
+                   "jac_bwd_kernel<fused> (streaming)")
+        valu = pmc.get("shade_kernel_jac_valu_active_frac")
+        ex["fwd"].update({"bound": "valu", "valu_frac": valu,
+                          "valu_note": "SQ_ACTIVE_INST_VALU x 4 / (SIMDs x GRBM_GUI_ACTIVE / 8), profiles/r02_pmc_b8_{sq,grbm}.csv: the share of the launch the "
+                                       "vector ALUs are issuing; the canonical HBM fraction beside it is reported for continuity only"})
+        tb = pmc.get("detail_b8", {}).get("matpbr::jac_bwd_kernel<true>") if wr.B == 8 else pmc.get("detail_b1", {}).get("matpbr::jac_bwd_kernel<true>")
+        ex["bwd"].update({"bound": "hbm", "own_traffic_frac": (tb / (tk["bwd_loop"] * 1e-3) / HBM_PEAK) if tb else None})
+        roof.update({"exact_sampling_pair": ex,
                      "operator_face": entry(px, tk["fwd_op"], tk["bwd_op"],
                                             "stand-alone matpbr_shade_fwd / matpbr_shade_bwd<mat>: both lobes sampled in-kernel (18 + 20 directions)"),
                      "fixed_roughness_parts": entry(px, tk["fwd_cached"], tk["bwd_loop_a"],
-                                                    "the same pair in the parts of --opt_order that leave the roughness alone ('a' of 'rm a', about half of "
+                                                    "the pair in the parts of --opt_order that leave the roughness alone ('a' of 'rm a', about half of "
                                                     "the reference schedule's BRDF iterations): shade_cached_kernel combines the specular sums kept from the "
                                                     "part's first render (bit-identical to walking the samples) + jac_bwd_kernel<fused>; both streaming"),
                      "diffuse_cache_ms": tk["diffuse_cache"]})
         if wr is not wl:
-            tk1 = kernel_times(wl)
-            roof["single_image"] = entry(H * W * wl.B, tk1["fwd_loop"], tk1["bwd_loop"], f"the same in-loop pair on {wl.B} x {H}x{W}")
+            t1, ts1, rs1 = lazy_step_times(wl)
+            a1 = (BYTES_FWD + BYTES_BWD_ARM) * H * W * wl.B / (t1 * 1e-3) / 1e9
+            roof["single_image"] = {"achieved": a1, "frac": a1 / (HBM_PEAK / 1e9), "avg_launch_ms": t1, "stats_launches_ms": ts1, "resampled_fraction": rs1,
+                                    "note": f"lazy_step_kernel on {wl.B} x {H}x{W} (working set inside the 256 MB Infinity Cache: launch-latency territory)"}
         # hot loop A: one pass over the radiance transfer per iteration (HBM-bound by construction)
         ph_e = wl.phase("env") if B == 1 else None
         if ph_e is not None:

@@ -213,6 +213,11 @@ typedef struct MatpbrBrdfPhase {
 } MatpbrBrdfPhase;
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);
+/* The same iteration stage by stage (profiling, and callers that interleave their own work): matpbr_brdf_phase_step enqueues all three. */
+#define MATPBR_STAGE_RENDER 1u   /* the render of the iteration (nothing to launch in the pred_next mode after t = 1) */
+#define MATPBR_STAGE_STATS 2u    /* loss statistics, SaveBest / EarlyStopping decisions */
+#define MATPBR_STAGE_BACKWARD 4u /* loss backward + Adam (+ the next iteration's render in the pred_next mode) */
+int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* phase, int t, float lr, uint32_t stages, void* stream);
 
 /* One evaluation of hot loop A (inverse_img_w_mi.py:238-250) for a candidate light.  Materials and normals are fixed during the
  * phase (:216-220) and the render is linear in the light, so the phase works on the radiance transfer T of

@@ -1163,6 +1163,10 @@ size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
 }
 
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* stream) {
+    return matpbr_brdf_phase_stages(ph, t, lr, MATPBR_STAGE_RENDER | MATPBR_STAGE_STATS | MATPBR_STAGE_BACKWARD, stream);
+}
+
+int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_t stages, void* stream) {
     if (!ph || t < 1) return MATPBR_ERR_INVALID_ARG;
     const MatpbrBrdfPhase& q = *ph;
     if (!q.pa || !q.pr || !q.pm || !q.n || !q.light || !q.gt_srgb || !q.a0 || !q.r0 || !q.m0 || !q.pred || !q.jac || !q.stats || q.batch <= 0)
@@ -1195,7 +1199,8 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     // (t == 1) walks the samples and keeps them (jac planes + s1cache), the others combine them (bit-identical, no samples)
     const bool r_fixed = !(q.part_mask & MATPBR_PART_R) && q.s1cache != nullptr;
     sa.s1 = r_fixed ? q.s1cache : nullptr;
-    if (lazy_fused && t > 1) {
+    if (!(stages & MATPBR_STAGE_RENDER)) {
+    } else if (lazy_fused && t > 1) {
         // pred already holds this iteration's render, complete, and fwd_sums its partial sums: written by the previous step's last launch
         // (as pred_next; the caller swapped the two)
     } else if (lazy) {
@@ -1207,12 +1212,15 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     else
         hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, sa, q.light, g, tab);
     // 2. loss statistics, SaveBest / EarlyStopping decisions (:388-418, misc.py:37-97)
+    if (stages & MATPBR_STAGE_STATS) {
     hipLaunchKernelGGL(loss_sums2_kernel<1>, dim3(kRedBlocks, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                        (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
                        (const float*)fwd_sums, nfwd, q.part_mask);
     hipLaunchKernelGGL(loss_final2_kernel<1>, dim3((unsigned)q.batch), dim3(kBlock), 0, st, (const float*)part, q.stats, kRedBlocks,
                        1.0f / (float)n3, 1.0f / (float)n1, q.scale_delta, q.part_mask, q.es_patience, q.es_min_delta, (const float*)fwd_sums, nfwd,
                        q.history, q.hist_len, q.batch);
+    }
+    if (!(stages & MATPBR_STAGE_BACKWARD)) return launch_status();
     // 3. backward of the loss through the render (:420) from the jac planes, regularisers, clamp gating, best-so-far snapshot,
     //    and the Adam update of the maps of this part (:359,429) in the same pass
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;

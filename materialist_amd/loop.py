@@ -327,6 +327,9 @@ class FusedBrdfPhase:
             code = self._lib.matpbr_brdf_phase_step(ct.byref(self._ph), self.t + 1, self.lr_at(self.t),
                                                     ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
         self._libmod.check(code, "matpbr_brdf_phase_step")
+        self._advance()
+
+    def _advance(self) -> None:
         self.t += 1
         if self._pred_bufs is not None:
             # self.pred = the render this step evaluated; the buffer its last launch rendered the next iterate into becomes `pred` of the next step
@@ -334,6 +337,25 @@ class FusedBrdfPhase:
             self._pred_cur ^= 1
             self._ph.pred = ct.c_void_p(self._pred_bufs[self._pred_cur].data_ptr())
             self._ph.pred_next = ct.c_void_p(self._pred_bufs[self._pred_cur ^ 1].data_ptr())
+
+    def launch_stage(self, stages: int) -> None:
+        """Enqueue some stages of the NEXT iteration without advancing the phase (1 render, 2 statistics, 4 backward + Adam; kernel timing)."""
+        ct = self._ct
+        with torch.cuda.device(self.gt.device):
+            code = self._lib.matpbr_brdf_phase_stages(ct.byref(self._ph), self.t + 1, self.lr_at(self.t), int(stages),
+                                                      ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
+        self._libmod.check(code, "matpbr_brdf_phase_stages")
+
+    def step_timed(self, events: list) -> None:
+        """`step()` with a pair of HIP events around its last launch (the backward pass + Adam, in the lazy mode also the next render),
+        appended to `events`: the in-loop duration of that launch for bench.py's roofline."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.launch_stage(1 | 2)
+        e0.record()
+        self.launch_stage(4)
+        e1.record()
+        events.append((e0, e1))
+        self._advance()
 
     def run(self, n: int) -> None:
         for _ in range(n):

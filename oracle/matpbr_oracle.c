@@ -797,6 +797,21 @@ void oracle_shade_bwd(const real* a, const real* r, const real* m, const real* n
                       real fov_x_deg) {
     oracle_shade_bwd_kind(a, r, m, n, light, d_out, d_a, d_r, d_m, d_n, d_light, H, W, batch, spp, fov_x_deg, 0);
 }
+/* SURVEY.md 8b names the CPU twin of the C ABI matpbr_shade_{fwd,bwd}_cpu: host pointers, the argument meaning of
+ * matpbr_shade_fwd / matpbr_shade_bwd for an SH25 light (include/matpbr.h).  They live in the ORACLE library, not in libmatpbr.so:
+ * the product path has no CPU fallback. */
+int matpbr_shade_fwd_cpu(const real* a, const real* r, const real* m, const real* n, const real* light, real* out_rgb, int H, int W,
+                         int batch, int spp, real fov_x_deg) {
+    if (!a || !r || !m || !n || !light || !out_rgb || H <= 0 || W <= 0 || batch <= 0 || spp < 2 || (spp & 1)) return -1;
+    oracle_shade_fwd(a, r, m, n, light, out_rgb, H, W, batch, spp, fov_x_deg);
+    return 0;
+}
+int matpbr_shade_bwd_cpu(const real* a, const real* r, const real* m, const real* n, const real* light, const real* d_out_rgb, real* d_a,
+                         real* d_r, real* d_m, real* d_n, real* d_light, int H, int W, int batch, int spp, real fov_x_deg) {
+    if (!a || !r || !m || !n || !light || !d_out_rgb || !d_a || !d_r || !d_m || H <= 0 || W <= 0 || batch <= 0 || spp < 2 || (spp & 1)) return -1;
+    oracle_shade_bwd(a, r, m, n, light, d_out_rgb, d_a, d_r, d_m, d_n, d_light, H, W, batch, spp, fov_x_deg);
+    return 0;
+}
 void oracle_shade_bwd_lanes(const real* a, const real* r, const real* m, const real* n, const real* wo, const real* light,
                             const real* d_out, real* d_a, real* d_r, real* d_m, real* d_n, real* d_light, long N, int spp, int kind) {
     View v = {0, 0, 0, 0, 1, R(0), wo};

@@ -34,7 +34,8 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recu
             continue
         agg[(k, r["Grid_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"# counters ({os.path.relpath(f, d)})")
-    print("kernel,grid,vgpr,sgpr,scratch,counter,dispatches,mean,min,max")
+    print("kernel,grid,vgpr,sgpr,scratch,counter,dispatches,mean,min,max,mean_of_last_40")
     for key, cs in agg.items():
         for c, v in cs.items():
-            print(",".join(key) + f",{c},{len(v)},{sum(v) / len(v):.4f},{min(v):.4f},{max(v):.4f}")
+            tail = v[-40:]      # rows are in dispatch order: the timed steps of a `--steps 40` run (after its warm-up)
+            print(",".join(key) + f",{c},{len(v)},{sum(v) / len(v):.4f},{min(v):.4f},{max(v):.4f},{sum(tail) / len(tail):.4f}")
