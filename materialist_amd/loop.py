@@ -20,60 +20,60 @@ from . import render as _render
 
 
 class EarlyStopping:
-    """myutils/misc.py:37-60: relative-improvement patience; `min_delta` is a fraction of the best loss."""
+    """Patience on the relative improvement of a loss, with the behaviour of the reference's helper (myutils/misc.py:37-60, pinned by
+    tests/golden/misc.npz): a call counts as a miss when the loss is above `(1 - min_delta)` times the loss of the last call that was
+    not a miss; `patience` misses since that call raise `early_stop`, which then stays up; the first call only sets the level."""
 
     def __init__(self, patience: int = 10, min_delta: float = 0.0):
-        self.patience = patience
-        self.min_delta = min_delta
-        self.counter = 0
-        self.best_loss = None
-        self.early_stop = False
+        self.patience, self.min_delta = patience, min_delta
+        self._level, self._misses, self._fired = None, 0, False
+
+    counter = property(lambda self: self._misses)
+    best_loss = property(lambda self: self._level)
+    early_stop = property(lambda self: self._fired)
 
     def __call__(self, val_loss: float) -> None:
-        if self.best_loss is None:
-            self.best_loss = val_loss
-        elif val_loss > self.best_loss * (1 - self.min_delta):
-            self.counter += 1
-            if self.counter >= self.patience:
-                self.early_stop = True
+        miss = self._level is not None and val_loss > self._level * (1 - self.min_delta)
+        if miss:
+            self._misses += 1
+            self._fired = self._fired or self._misses >= self.patience
         else:
-            self.best_loss = val_loss
-            self.counter = 0
+            if self._level is not None:
+                self._misses = 0
+            self._level = val_loss
 
 
 class SaveBest:
-    """myutils/misc.py:62-97: keep a detached clone of every map whenever `loss` is strictly below the best
-    seen so far; the best loss is global across phases and never reset (F11)."""
+    """The best-so-far snapshot of the reference's helper (myutils/misc.py:62-97) as one table: `update` replaces every slot with a
+    detached copy when the loss is STRICTLY below the best one seen, which is global across phases and never reset.
+    Slots are read as `best_<slot>` (`rendered_img` without the prefix, as the reference names it) or through `get_best()`."""
 
-    FIELDS = ("albedo", "roughness", "metallic", "normal", "envmap", "rendered_img")
+    SLOTS = ("albedo", "roughness", "metallic", "normal", "envmap", "rendered_img")
 
     def __init__(self):
         self.best_loss = float("inf")
-        self.best_albedo = self.best_roughness = self.best_metallic = None
-        self.best_envmap = self.rendered_img = self.best_normal = None
+        self._kept = dict.fromkeys(self.SLOTS)
         self.best_brdfnet_weight = None
 
-    @staticmethod
-    def _detach_and_clone(t):
-        return t.detach().clone() if isinstance(t, torch.Tensor) else copy.deepcopy(t)
-
     def update(self, loss, albedo, roughness, metallic, normal, envmap, rendered_img, brdfnet_weights=None) -> bool:
-        if loss < self.best_loss:
-            self.best_loss = loss
-            self.best_albedo = self._detach_and_clone(albedo)
-            self.best_roughness = self._detach_and_clone(roughness)
-            self.best_metallic = self._detach_and_clone(metallic)
-            self.best_envmap = self._detach_and_clone(envmap)
-            self.rendered_img = self._detach_and_clone(rendered_img)
-            self.best_normal = self._detach_and_clone(normal)
-            if brdfnet_weights is not None:
-                self.best_brdfnet_weight = copy.deepcopy(brdfnet_weights)
-            return True
-        return False
+        if not loss < self.best_loss:
+            return False
+        self.best_loss = loss
+        given = dict(zip(self.SLOTS, (albedo, roughness, metallic, normal, envmap, rendered_img)))
+        self._kept = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else copy.deepcopy(v)) for k, v in given.items()}
+        if brdfnet_weights is not None:
+            self.best_brdfnet_weight = copy.deepcopy(brdfnet_weights)
+        return True
+
+    def __getattr__(self, name):
+        slot = name[5:] if name.startswith("best_") else name
+        kept = self.__dict__.get("_kept")
+        if kept is not None and slot in kept:
+            return kept[slot]
+        raise AttributeError(name)
 
     def get_best(self):
-        return {"envmap": self.best_envmap, "albedo": self.best_albedo, "roughness": self.best_roughness,
-                "metallic": self.best_metallic, "normal": self.best_normal, "rendered_img": self.rendered_img}
+        return dict(self._kept)
 
 
 class DeviceSaveBest:
