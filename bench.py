@@ -257,8 +257,10 @@ def main(argv=None):
                 net = posmlp.brdf_net("arm").to(dev)
                 init = self.init
                 start_arm = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1)], -1).clamp(0, 1)
+                # EarlyStopping armed as in the pipeline (it never fires here: the point is to time the loop WITH its polling of the device flag)
                 ph = loop.pos_mlp_brdf_phase(self.scene, self.gt_image, net, start_arm, {"albedo": init[0], "roughness": init[1], "metallic": init[2]},
-                                             optimize_part="rm", spp=args.spp)
+                                             optimize_part="rm", spp=args.spp, patience=10 ** 6, min_delta=0.001)
+                ph.bench_step = ph.step_and_check    # what optimize.brdf_part_runner_mlp calls per epoch (:550)
                 if not hasattr(ph, "current_maps"):
                     ph.current_maps = lambda: (lambda m: {"albedo": m["albedo"].detach().clamp(0, 1), "roughness": m["roughness"].detach().clamp(0.07, 1),
                                                           "metallic": m["metallic"].detach().clamp(0, 1)})(ph.maps_from_net()[0])
@@ -278,7 +280,8 @@ def main(argv=None):
     B = wl.B
     phase = wl.phase(mode)
     psnr0 = float(loop._loss.psnr(render.render_w_brdf(wl.scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), wl.gt_image).mean())
-    elapsed, per_rank = proto.timed(phase.step, args.warmup, args.steps)
+    stepper = lambda p: getattr(p, "bench_step", p.step)
+    elapsed, per_rank = proto.timed(stepper(phase), args.warmup, args.steps)
     value = args.steps * B * world / elapsed
     m = phase.current_maps()
     with torch.no_grad():
@@ -292,14 +295,14 @@ def main(argv=None):
         for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("pos_mlp", 100), ("env", 500)):
             if extra == mode or (not extra.startswith("fused") and B > 1):
                 continue
-            e_el, _ = proto.timed(wl.phase(extra).step, 10, steps)
+            e_el, _ = proto.timed(stepper(wl.phase(extra)), 10, steps)
             modes[extra] = {"it_per_s": steps * B * world / e_el, "ms_per_step": e_el / steps * 1e3, "images_per_gpu": B}
         if mode == "pos_mlp" and _posmlp._PosMlpHipFn.PRODUCTS:
             # the same loop with the 256-wide layers on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), for the record
             keep = _posmlp._PosMlpHipFn.PRODUCTS
             _posmlp._PosMlpHipFn.PRODUCTS = 0
             try:
-                e_el, _ = proto.timed(wl.phase("pos_mlp").step, 10, 100)
+                e_el, _ = proto.timed(stepper(wl.phase("pos_mlp")), 10, 100)
             finally:
                 _posmlp._PosMlpHipFn.PRODUCTS = keep
             modes["pos_mlp_exact_f32"] = {"it_per_s": 100 * B * world / e_el, "ms_per_step": e_el / 100 * 1e3, "images_per_gpu": B}

@@ -163,6 +163,15 @@ int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_s
                            const float* pm, const float* a0, const float* r0, const float* m0, float scale_delta,
                            float* stats, void* workspace, size_t workspace_bytes, int H, int W, int batch, uint32_t flags,
                            void* stream);   /* flags: MATPBR_PART_* of the maps being optimised (none set = all three) */
+/* matpbr_brdf_loss_stats with the EarlyStopping state machine of matpbr_brdf_phase_step kept in `stats` (es_patience >= 0; myutils/misc.py:37-60)
+ * and the per-iteration loss_mse in history[hist_len, B] (nullable): once stats[b][13] is set the image's statistics rest, its `improved` flag stays
+ * down (no snapshot in matpbr_brdf_loss_bwd_jac) and matpbr_adamw_step_snapshot_dev(..., stats) rests too, so a caller whose iteration contains
+ * kernels of its own (the PosMLP of --model_name pos_mlp, inverse_img_w_mi.py:471-566) may poll the flag every few iterations: the iterations
+ * enqueued past the stop change nothing.  es_patience == 0 disables stopping (the state machine still counts iterations). */
+int matpbr_brdf_loss_stats_es(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr, const float* pm,
+                              const float* a0, const float* r0, const float* m0, float scale_delta, float* stats, void* workspace,
+                              size_t workspace_bytes, int H, int W, int batch, uint32_t flags, int es_patience, float es_min_delta, float* history,
+                              int hist_len, void* stream);
 int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, const float* jac, const float* pred,
                              const float* gt_srgb, const float* stats, const float* a0, const float* r0, const float* m0,
                              float scale_delta, float* d_a, float* d_r, float* d_m, float* best_a, float* best_r, float* best_m,
@@ -210,6 +219,9 @@ typedef struct MatpbrBrdfPhase {
                                              next one (pixels that left their model's interval pending); the caller SWAPS pred and pred_next before the
                                              next step, calls the steps with t = 1, 2, 3, ... and leaves workspace / lazy_state / pr / pm alone in between.
                                              The SaveBest snapshot of a map that the part does not optimise is not rewritten. */
+    uint32_t flags;                       /* MATPBR_FLAG_ATTACHED_SAMPLING (pred_next mode only): d loss / d r through the GGX quadrature nodes -- the models'
+                                             slopes are that derivative -- i.e. the live reference's gradient convention (myutils/mi_plugin.py:227-230,
+                                             1335-1341) instead of the stop-gradient default */
 } MatpbrBrdfPhase;
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);
@@ -354,7 +366,8 @@ int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ld
 int matpbr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
                           float weight_decay, void* stream);
 /* the same with SaveBest's weight snapshot in the same pass: best[i] = p[i] (the weights that produced this iteration's render)
- * when stats[8] (improved) is set, before p is updated; best / stats nullable together */
+ * when stats[8] (improved) is set, before p is updated (best nullable; best needs stats).  With `stats`, an image whose EarlyStopping
+ * fired in an earlier iteration (stats[13] >= 2) rests: no update, no step count (the reference's loop has left by then, :250-254,548-555) */
 int matpbr_adamw_step_snapshot_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2,
                                    float eps, float weight_decay, float* best, const float* stats, void* stream);
 

@@ -24,7 +24,7 @@ class MatpbrBrdfPhase(ctypes.Structure):
                 [("workspace_bytes", ctypes.c_size_t), ("H", ctypes.c_int), ("W", ctypes.c_int), ("batch", ctypes.c_int), ("spp", ctypes.c_int),
                  ("fov_x_deg", ctypes.c_float), ("scale_delta", ctypes.c_float), ("part_mask", ctypes.c_uint32), ("es_patience", ctypes.c_int),
                  ("es_min_delta", ctypes.c_float), ("hist_len", ctypes.c_int), ("s1cache", ctypes.c_void_p), ("lazy_state", ctypes.c_void_p),
-                 ("lazy_tol", ctypes.c_float), ("pred_next", ctypes.c_void_p)])
+                 ("lazy_tol", ctypes.c_float), ("pred_next", ctypes.c_void_p), ("flags", ctypes.c_uint32)])
 
 
 class MatpbrError(RuntimeError):
@@ -59,6 +59,8 @@ SIGNATURES = {
     "matpbr_brdf_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_brdf_loss_stats": (ctypes.c_int, [_c_f] * 9 + [ctypes.c_float, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]),
+    "matpbr_brdf_loss_stats_es": (ctypes.c_int, [_c_f] * 9 + [ctypes.c_float, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_float, _c_f, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_brdf_loss_bwd_jac": (ctypes.c_int, [_c_f] * 10 + [ctypes.c_float] + [_c_f] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                                                               ctypes.c_uint32, ctypes.c_void_p]),
     "matpbr_brdf_phase_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),

@@ -84,7 +84,7 @@ class ArmMlpPhase:
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_arm: torch.Tensor, fixed: Dict[str, torch.Tensor],
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
                  min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000, weight_decay: float = 0.01):
-        from .loop import EarlyStopping, _lib_ws
+        from .loop import _lib_ws
 
         if not ArmMlpPhase.supported(scene, gt_image, net, optimize_part, None):
             raise NotImplementedError("ArmMlpPhase: 'arm' network with 256-wide layers on one image of at least 8192 pixels (a multiple of 128)")
@@ -158,7 +158,9 @@ class ArmMlpPhase:
         self.stats = ops.new_loss_stats(1, dev)
         if best_mse is not None:
             self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
-        self.es = EarlyStopping(patience, min_delta) if patience > 0 else None
+        # EarlyStopping lives in the statistics buffer on the device (matpbr_brdf_loss_stats_es): the host polls it every `sync_every`
+        # iterations; iterations enqueued past the stop change nothing (statistics, snapshot and AdamW rest)
+        self.patience, self.min_delta, self.sync_every = int(patience), float(min_delta), 8
         self.pred = torch.empty_like(self.gt)
         self.g = {"albedo": E(H, W, 3), "roughness": E(H, W, 1), "metallic": E(H, W, 1)}
         self.best = {k: v.clone() for k, v in self.fixed.items()}
@@ -237,14 +239,13 @@ class ArmMlpPhase:
             o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], self._n, self._light, self.spp, sc.fov, clamp_params=True, out=self.pred,
                         dcache=self.dcache, jac=self.jac, s1=self.s1)
         o.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
-                          self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part)
+                          self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part,
+                          es_patience=self.patience, es_min_delta=self.min_delta, history=self.hist)
         o.brdf_loss_bwd_jac(d["albedo"], d["roughness"], d["metallic"], self.jac, self.pred, self.gt_srgb, self.stats,
                             self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta,
                             self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
                             self.best["metallic"], self.best_img, optimize_part=self.part)
         self.backward()
-        if self.t < self.hist.shape[0]:
-            self.hist[self.t].copy_(self.stats[:, o.STAT_MSE])
         lib = _lib.load()
         with torch.cuda.device(self.dev):       # AdamW; SaveBest keeps the weights that produced the best render (:546-547) in the same pass
             _lib.check(lib.matpbr_adamw_step_snapshot_dev(o._ptr(self.flat), o._ptr(self.gflat), o._ptr(self.adam_m), o._ptr(self.adam_v),
@@ -277,12 +278,16 @@ class ArmMlpPhase:
         return {"albedo": d["albedo"].clamp(0, 1), "roughness": d["roughness"].clamp(0.07, 1), "metallic": d["metallic"].clamp(0, 1)}
 
     def step_and_check(self) -> bool:
-        """One iteration followed by the host EarlyStopping check of the reference (:550); True when the part should stop."""
+        """One iteration; every `sync_every` iterations the host reads the device's EarlyStopping flag (:550) and returns True when the
+        part has stopped.  The iterations enqueued between the stop and the poll were no-ops (`iterations_run` tells how many really ran)."""
         self.step()
-        if self.es is None:
+        if self.patience <= 0 or self.t % self.sync_every:
             return False
-        self.es(float(self.stats[0, ops.STAT_MSE]))
-        return self.es.early_stop
+        return bool(self.stats[0, ops.STAT_STOPPED] > 0.5)
+
+    @property
+    def iterations_run(self) -> int:
+        return int(self.stats[0, ops.STAT_ITERS])
 
     def history(self) -> torch.Tensor:
         return self.hist[: self.t]

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void loss_final2_kernel(const float* __rest
     __shared__ int s_skip;
     const int b = blockIdx.x;
     float* st = stats + b * kStatsStride;
-    if (MODE >= 1) {
+    if (MODE == 1 || (MODE == 2 && es_patience >= 0)) {
         if (threadIdx.x == 0) s_skip = stats_enter(st) ? 1 : 0;
         __syncthreads();
         if (s_skip) return;
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(kBlock) void select_copy_kernel(float* __restrict__
 __global__ __launch_bounds__(kBlock) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, long n, const float* __restrict__ hyper, float b1, float b2,
                                                           float eps, float wd, float* __restrict__ best, const float* __restrict__ stats) {
+    if (stats != nullptr && stats[kStStopped] > 1.5f) return;          // EarlyStopping fired in an earlier iteration: the optimiser rests
     const bool snap = best != nullptr && stats[kStImproved] > 0.5f;   // SaveBest keeps the weights that produced this iteration's render
     const float t = hyper[1] + 1.0f, lr = hyper[0];
     const float keep = 1.0f - lr * wd;        // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) before the Adam update
@@ -348,7 +349,10 @@ __global__ __launch_bounds__(kBlock) void adam_dev_kernel(float* __restrict__ p,
         p[i] = pi * keep - lr_over_bc1 * mi / fmaf(fsqrt(vi), inv_sqrt_bc2, eps);
     }
 }
-__global__ void adam_dev_tick_kernel(float* __restrict__ hyper) { hyper[1] += 1.0f; }
+__global__ void adam_dev_tick_kernel(float* __restrict__ hyper, const float* __restrict__ stats) {
+    if (stats != nullptr && stats[kStStopped] > 1.5f) return;
+    hyper[1] += 1.0f;
+}
 
 // Column sums of a row-major [M, N] matrix (N <= 1024): the bias gradient of a Linear layer over M = H*W points.
 // Pass 1: workgroup b sums rows [b*rows_per, ...) with thread t owning columns t, t+256, ... (coalesced row reads);
@@ -1113,9 +1117,10 @@ static unsigned part_mask_of(uint32_t flags) {
     return (flags & all) ? (flags & all) : all;   // no part bit = all three maps (optimize_part 'arm')
 }
 
-int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr, const float* pm,
-                           const float* a0, const float* r0, const float* m0, float scale_delta, float* stats, void* workspace,
-                           size_t workspace_bytes, int H, int W, int batch, uint32_t flags, void* stream) {
+int matpbr_brdf_loss_stats_es(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr, const float* pm,
+                              const float* a0, const float* r0, const float* m0, float scale_delta, float* stats, void* workspace,
+                              size_t workspace_bytes, int H, int W, int batch, uint32_t flags, int es_patience, float es_min_delta, float* history,
+                              int hist_len, void* stream) {
     if (!pred || !gt || !gt_srgb || !pa || !pr || !pm || !a0 || !r0 || !m0 || !stats || H <= 0 || W <= 0 || batch <= 0)
         return MATPBR_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < matpbr_brdf_loss_workspace_bytes(batch)) return MATPBR_ERR_WORKSPACE;
@@ -1127,10 +1132,17 @@ int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_s
     hipLaunchKernelGGL(loss_final1_kernel, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks);
     hipLaunchKernelGGL(loss_sums2_kernel<0>, grid, dim3(kBlock), 0, st, pred, gt_srgb, stats, pa, a0, pr, r0, pm, m0, part, n3, n1,
                        (const float*)nullptr, 0, part_mask_of(flags));
-    hipLaunchKernelGGL(loss_final2_kernel<0>, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks, 1.0f / (float)n3,
-                       1.0f / (float)n1, scale_delta, part_mask_of(flags), 0, 0.0f,
-                       (const float*)nullptr, 0, (float*)nullptr, 0, batch);
+    hipLaunchKernelGGL(loss_final2_kernel<2>, dim3((unsigned)batch), dim3(kBlock), 0, st, part, stats, kRedBlocks, 1.0f / (float)n3,
+                       1.0f / (float)n1, scale_delta, part_mask_of(flags), es_patience, es_min_delta,
+                       (const float*)nullptr, 0, history, hist_len, batch);
     return launch_status();
+}
+
+int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr, const float* pm,
+                           const float* a0, const float* r0, const float* m0, float scale_delta, float* stats, void* workspace,
+                           size_t workspace_bytes, int H, int W, int batch, uint32_t flags, void* stream) {
+    return matpbr_brdf_loss_stats_es(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta, stats, workspace, workspace_bytes, H, W, batch, flags, -1,
+                                     0.0f, nullptr, 0, stream);
 }
 
 
@@ -1241,6 +1253,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         for (int k = 0; k < kLzPlanes; ++k) ls.plane[k] = lb.planes + (size_t)k * (size_t)q.batch * (size_t)n1;
         ls.pred_next = q.pred_next; ls.block_sums = fwd_sums; ls.n = q.n; ls.dcache = q.dcache; ls.counts = lb.counts; ls.lists = lb.lists; ls.n_sums = lb.nblk;
         ls.tol = q.lazy_tol > 0.0f ? q.lazy_tol : 1.0f;
+        ls.attached = (q.flags & MATPBR_FLAG_ATTACHED_SAMPLING) ? 1 : 0;
         hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);
     } else if (lazy)
         hipLaunchKernelGGL((jac_bwd_kernel<true, true>), dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);
@@ -1350,11 +1363,11 @@ int matpbr_select_improved(float* dst, const float* src, const float* stats, int
 
 int matpbr_adamw_step_snapshot_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
                                    float weight_decay, float* best, const float* stats, void* stream) {
-    if (!p || !g || !m || !v || !hyper || n <= 0 || weight_decay < 0.0f || ((best == nullptr) != (stats == nullptr))) return MATPBR_ERR_INVALID_ARG;
+    if (!p || !g || !m || !v || !hyper || n <= 0 || weight_decay < 0.0f || (best != nullptr && stats == nullptr)) return MATPBR_ERR_INVALID_ARG;
     unsigned blocks = (unsigned)std::min<long>((n + kBlock - 1) / kBlock, 2048);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, (const float*)hyper, beta1, beta2, eps,
                        weight_decay, best, stats);
-    hipLaunchKernelGGL(adam_dev_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper);
+    hipLaunchKernelGGL(adam_dev_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper, stats);
     return launch_status();
 }
 

@@ -182,6 +182,7 @@ struct LazyStepArgs {
     uint16_t* lists;
     int n_sums;
     float tol;
+    int attached;             // d out / d r through the GGX quadrature nodes: the models' slopes (MATPBR_FLAG_ATTACHED_SAMPLING) instead of dSD, dS1
 };
 // LDS exchange between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be held back
 __device__ __forceinline__ void wave_lds_sync() {
@@ -238,7 +239,9 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
         const float Pc = fmaf(fmaf(A2, dr, dP0), dr, Pv[c]), dPc = fmaf(2.0f * A2, dr, dP0);
         const float SD = fmaf(h2_lo(sk[c]), dr, SDv[c]);
         const float C0 = fmaf(m, a[c], omm * 0.04f);
-        const float JR = fmaf(a[c] * omm, dPc, fmaf(C0, h2_lo(dk[c]), h2_hi(dk[c])));
+        // d out / d r: the stop-gradient convention (dSD, dS1) by default; with `attached` the derivative of the rendered value through
+        // the sample directions, which is what the models' slopes are (the live reference's convention, mi_plugin.py:227-230,1335-1341)
+        const float JR = fmaf(a[c] * omm, dPc, qs.attached ? fmaf(C0, h2_lo(sk[c]), h2_hi(sk[c])) : fmaf(C0, h2_lo(dk[c]), h2_hi(dk[c])));
         da[c] = go * fmaf(m, SD, omm * Pc);
         dm = fmaf(go, fmaf(a[c] - 0.04f, SD, -(a[c] * Pc)), dm);
         drr = fmaf(go, JR, drr);

@@ -42,6 +42,7 @@
 // sin/cos epilogue adds 35 us although it rides inside the next tile's MFMA stream.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <type_traits>
 
 #include "../../include/matpbr.h"
@@ -1539,38 +1540,44 @@ __global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_bx(const float* __res
 
 constexpr size_t kBxSmem = 2 * kBxStage * sizeof(uint4) + 8 * 32 * kLd * sizeof(float);   // 96 KB of weights + 36 KB of epilogue scratch
 constexpr size_t kBxSmemHead = kBxSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float);           // + output-layer weights and the row exchange
+// More than 64 KB of dynamic LDS needs an opt-in attribute, which HIP keeps per device: one bit per (kernel, device), set under the
+// device that is current at the launch (a process may drive several GPUs through the C ABI, from several threads).  A failure is
+// reported to the caller and retried at the next launch.
+template <auto Kernel>
+bool lds_opt_in(size_t bytes) {
+  static std::atomic<unsigned long long> done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return true;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  done.fetch_or(bit, std::memory_order_release);
+  return true;
+}
 template <int EPI, int NPROD, bool FULL>
-void launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
-  static bool configured = false;                            // more than 64 KB of LDS needs the opt-in attribute, once per kernel
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_nt_bx<EPI, NPROD, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBxSmem);
-    configured = true;
-  }
+bool launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
+  if (!lds_opt_in<&mlp_nt_bx<EPI, NPROD, FULL>>(kBxSmem)) return false;
   hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD, FULL>), dim3(grid), dim3(kBxThreads), kBxSmem, stream, p, wsplit, HeadArgs{});
+  return true;
 }
 template <int NPROD>
-void launch_nt_bx_head(const NtArgs& p, const uint4* wsplit, const HeadArgs& hd, unsigned grid, hipStream_t stream) {
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_nt_bx<EPI_SINCOS, NPROD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kBxSmemHead);
-    configured = true;
-  }
+bool launch_nt_bx_head(const NtArgs& p, const uint4* wsplit, const HeadArgs& hd, unsigned grid, hipStream_t stream) {
+  if (!lds_opt_in<&mlp_nt_bx<EPI_SINCOS, NPROD, true, true>>(kBxSmemHead)) return false;
   hipLaunchKernelGGL((mlp_nt_bx<EPI_SINCOS, NPROD, true, true>), dim3(grid), dim3(kBxThreads), kBxSmemHead, stream, p, wsplit, hd);
+  return true;
 }
 template <int EPI, int NPROD>
-void launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
+bool launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
   // the input-gradient buffers have no tail to protect: columns at or beyond N of G' are scratch for every consumer
-  if (p.N >= 256 || EPI == EPI_MULC || p.tail != nullptr) launch_nt_bx_full<EPI, NPROD, true>(p, wsplit, grid, stream);
-  else launch_nt_bx_full<EPI, NPROD, false>(p, wsplit, grid, stream);
+  if (p.N >= 256 || EPI == EPI_MULC || p.tail != nullptr) return launch_nt_bx_full<EPI, NPROD, true>(p, wsplit, grid, stream);
+  return launch_nt_bx_full<EPI, NPROD, false>(p, wsplit, grid, stream);
 }
 template <int EPI>
-int launch_nt_bx(NtArgs p, const uint4* wsplit, int nprod, hipStream_t stream) {   // p.M a multiple of 128
+int launch_nt_bx(NtArgs p, const uint4* wsplit, int nprod, hipStream_t stream) {   // p.M a multiple of 128; returns the grid, -1 when the launch could not be set up
   const int tiles = p.M / kBM;
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-  if (nprod == 9) launch_nt_bx_one<EPI, 9>(p, wsplit, grid, stream);
-  else launch_nt_bx_one<EPI, 6>(p, wsplit, grid, stream);
-  return (int)grid;
+  const bool ok = nprod == 9 ? launch_nt_bx_one<EPI, 9>(p, wsplit, grid, stream) : launch_nt_bx_one<EPI, 6>(p, wsplit, grid, stream);
+  return ok ? (int)grid : -1;
 }
 
 // (row tile, column half) work items; a workgroup must keep one column half across its persistent loop: grid multiple of 16
@@ -2064,7 +2071,7 @@ int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, co
   if (tail && ldt < 256 - N) return MATPBR_ERR_INVALID_ARG;
   NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, N, K, ldx, 0, ldo};
   p.tail = tail; p.ldt = ldt;
-  launch_nt_bx<EPI_SINCOS>(p, (const uint4*)wsplit, nprod, (hipStream_t)stream);
+  if (launch_nt_bx<EPI_SINCOS>(p, (const uint4*)wsplit, nprod, (hipStream_t)stream) < 0) return MATPBR_ERR_LAUNCH;
   if (tail && N < 256)
     hipLaunchKernelGGL(mlp_tail_copy_kernel, dim3((unsigned)((M * (256 - N) + 255) / 256 < 2048 ? (M * (256 - N) + 255) / 256 : 2048)), dim3(256), 0,
                        (hipStream_t)stream, s_out, ldo, tail, ldt, M, N);
@@ -2083,9 +2090,9 @@ int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, co
   const HeadArgs hd{w_out, ldw_out, bias_out, ArmHead{start, lds, th, map_a, map_r, map_m}};
   const int tiles = (int)(M / kBM);
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-  if (nprod == 9) launch_nt_bx_head<9>(p, (const uint4*)wsplit, hd, grid, (hipStream_t)stream);
-  else launch_nt_bx_head<6>(p, (const uint4*)wsplit, hd, grid, (hipStream_t)stream);
-  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+  const bool ok = nprod == 9 ? launch_nt_bx_head<9>(p, (const uint4*)wsplit, hd, grid, (hipStream_t)stream)
+                             : launch_nt_bx_head<6>(p, (const uint4*)wsplit, hd, grid, (hipStream_t)stream);
+  return ok && hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
 int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo, long M, int N,
@@ -2102,6 +2109,7 @@ int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, 
   if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
   NtArgs p{g, nullptr, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, (int)M, n_prev, n_red, ldg, 0, ldo};
   const int groups = launch_nt_bx<EPI_MULC>(p, (const uint4*)wtsplit, nprod, (hipStream_t)stream);
+  if (groups < 0) return MATPBR_ERR_LAUNCH;
   if (d_bias_prev)
     hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
@@ -2143,14 +2151,11 @@ int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int 
   int slabs = wgrad_slabs(M);
   long rows = ((M + slabs - 1) / slabs + 15) / 16 * 16;
   slabs = (int)((M + rows - 1) / rows);
-  static bool configured[2] = {false, false};
   if (nprod == 6) {
-    if (!configured[0]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_wgrad_bx<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgSmem);
-    configured[0] = true;
+    if (!lds_opt_in<&mlp_wgrad_bx<6>>(kWgSmem)) return MATPBR_ERR_LAUNCH;
     hipLaunchKernelGGL(mlp_wgrad_bx<6>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows);
   } else {
-    if (!configured[1]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_wgrad_bx<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgSmem);
-    configured[1] = true;
+    if (!lds_opt_in<&mlp_wgrad_bx<9>>(kWgSmem)) return MATPBR_ERR_LAUNCH;
     hipLaunchKernelGGL(mlp_wgrad_bx<9>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows);
   }
   hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);

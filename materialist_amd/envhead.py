@@ -50,26 +50,9 @@ class EnvMlpPhase:
             raise ValueError("the envmap MLP runs on the small-tile kernels: at most 1024 texels")
         self.M, self.d0, self.L = M, d0, net.n_layers
         lins = [(getattr(net, f"lin{l}").linear if l < self.L - 1 else getattr(net, f"lin{l}")) for l in range(self.L)]
-        st = getattr(net, "_flat_state", None)
-        if st is None:
-            sizes = []
-            for lin in lins:
-                n, k = lin.weight.shape
-                sizes += [n * _al4(k), _al4(n)]
-            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-            off, views = 0, []
-            for lin in lins:
-                n, k = lin.weight.shape
-                wp = flat[off:off + n * _al4(k)].view(n, _al4(k))
-                wp[:, :k].copy_(lin.weight.detach())
-                lin.weight.data = wp[:, :k]                      # a strided view when k is not a multiple of 4 (the first layer)
-                off += n * _al4(k)
-                bp = flat[off:off + n]
-                bp.copy_(lin.bias.detach())
-                lin.bias.data = bp
-                off += _al4(n)
-                views.append((wp, bp))
-            st = net._flat_state = {"flat": flat, "views": views}
+        from .armhead import flat_state
+
+        st = flat_state(net, dev)   # validates that the module's parameters still alias the flat buffer on this device, rebuilds otherwise
         self.flat, self.views = st["flat"], st["views"]
         self.gflat = torch.zeros_like(self.flat)
         self.adam_m, self.adam_v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)    # a fresh Adam per phase (:225-229)
@@ -148,8 +131,9 @@ class EnvMlpPhase:
             g, ldg, n_red = self.gbufs[l - 1], self.gbufs[l - 1].stride(0), ns[l - 1]
             calls.append((lib.matpbr_mlp_layer_bwd_weight, (P(g), ldg, P(inps[l - 1]), inps[l - 1].stride(0), P(gw), gw.stride(0), None, 0, M,
                                                             ns[l - 1], Ks[l - 1])))
-        calls.append((lib.matpbr_adam_step_dev, (P(self.flat), P(self.gflat), P(self.adam_m), P(self.adam_v), self.flat.numel(), P(self.hyper),
-                                                 0.9, 0.999, 1e-8)))
+        # the update and the step count stop with the image (stats[13] >= 2): the reference breaks right after the stopping iteration (:250-254)
+        calls.append((lib.matpbr_adamw_step_snapshot_dev, (P(self.flat), P(self.gflat), P(self.adam_m), P(self.adam_v), self.flat.numel(), P(self.hyper),
+                                                           0.9, 0.999, 1e-8, 0.0, None, P(self.stats))))
         self._calls = calls
         self._first = True
 

@@ -243,9 +243,11 @@ class FusedBrdfPhase:
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
                  min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
                  originals: Optional[Dict[str, torch.Tensor]] = None, keep_grads: bool = False, lazy: Optional[bool] = None,
-                 lazy_tol: float = 1.0):
+                 lazy_tol: float = 1.0, attached_sampling: bool = False):
         """`lazy` (default `FusedBrdfPhase.LAZY`): in parts that move the roughness, render from per-pixel local models in r and walk
-        the GGX samples only of the pixels that left their model's validity interval (include/matpbr.h `matpbr_shade_fwd_lazy`)."""
+        the GGX samples only of the pixels that left their model's validity interval (include/matpbr.h `matpbr_shade_fwd_lazy`).
+        `attached_sampling` (lazy parts only): the roughness gradient through the GGX sample directions, the live reference's convention
+        (mi_plugin.py:227-230,1335-1341), instead of the stop-gradient default."""
         import ctypes
 
         from . import _lib, ops
@@ -307,6 +309,9 @@ class FusedBrdfPhase:
         self.lazy_state = ops.lazy_state(self.p["albedo"]) if self.lazy else None
         ph.lazy_state = P(self.lazy_state) if self.lazy else None
         ph.lazy_tol = float(lazy_tol)
+        if attached_sampling and not self.lazy:
+            raise ValueError("attached_sampling needs the lazy path (a part that optimises the roughness)")
+        ph.flags = ops.FLAG_ATTACHED_SAMPLING if attached_sampling else 0
         # lazy: the step's last launch also renders the next iterate (into pred_next); the two render buffers swap roles every step
         self._pred_bufs = [self.pred, torch.empty_like(self.gt)] if self.lazy else None
         self._pred_cur = 0

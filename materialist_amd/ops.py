@@ -404,8 +404,10 @@ def part_mask(optimize_part: str) -> int:
 
 
 def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: float, stats: torch.Tensor,
-                    workspace: Optional[torch.Tensor] = None, optimize_part: str = "arm") -> torch.Tensor:
-    """Fills `stats` [B, STATS_STRIDE] in place (ratio, mse, l1, l1/mse, regulariser L1s, loss, improved, best_mse)."""
+                    workspace: Optional[torch.Tensor] = None, optimize_part: str = "arm", es_patience: int = -1, es_min_delta: float = 0.0,
+                    history: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fills `stats` [B, STATS_STRIDE] in place (ratio, mse, l1, l1/mse, regulariser L1s, loss, improved, best_mse).  es_patience >= 0: the
+    EarlyStopping state machine runs in `stats` on the device (include/matpbr.h `matpbr_brdf_loss_stats_es`), loss_mse goes to `history`."""
     lib = _lib.load()
     pred = _dev(pred, "pred", (3,))
     B, H, W = _bhw(pred)
@@ -414,8 +416,9 @@ def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: floa
     if workspace is None or workspace.numel() * 4 < need:
         workspace = torch.empty(need // 4, dtype=torch.float32, device=pred.device)
     with torch.cuda.device(pred.device):
-        code = lib.matpbr_brdf_loss_stats(_ptr(pred), *[_ptr(t) for t in ts], float(scale_delta), _ptr(stats), _ptr(workspace),
-                                          workspace.numel() * 4, H, W, B, part_mask(optimize_part), _stream(pred))
+        code = lib.matpbr_brdf_loss_stats_es(_ptr(pred), *[_ptr(t) for t in ts], float(scale_delta), _ptr(stats), _ptr(workspace),
+                                             workspace.numel() * 4, H, W, B, part_mask(optimize_part), int(es_patience), float(es_min_delta),
+                                             _ptr(history), 0 if history is None else int(history.shape[0]), _stream(pred))
     _lib.check(code, "matpbr_brdf_loss_stats")
     return stats
 

@@ -239,3 +239,35 @@ def test_lazy_phase_early_stopping_and_batch():
     frozen = {k: v.clone() for k, v in es.p.items()}
     es.run(3)
     assert all(torch.equal(frozen[k], es.p[k]) for k in frozen)
+
+
+def test_lazy_phase_offers_the_attached_roughness_gradient():
+    """`attached_sampling=True`: d loss / d r of the fused loop follows the derivative of the rendered value THROUGH the GGX sample
+    directions (the live reference's convention; the models' slopes are that derivative), = matpbr_shade_bwd(MATPBR_FLAG_ATTACHED_SAMPLING)
+    chained with the same loss gradient; the default stays the stop-gradient convention."""
+    from materialist_amd import loop, ops
+
+    dev = _cuda()
+    H = W = 128
+    spp = 64
+    scene, gt, init = _phase_setup(dev, H, W, spp, image_id=4)
+    got = {}
+    for att in (False, True):
+        ph = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp, lazy=True, keep_grads=True, attached_sampling=att)
+        pa, pr, pm = (ph.p[k].clone() for k in ("albedo", "roughness", "metallic"))
+        ph.step()
+        got[att] = ph.g["roughness"].clone()
+        if att:
+            # the loss gradient w.r.t. the render at these parameters, from the torch composition, pushed through the operator face
+            pred = ops.shade_fwd(pa, pr, pm, ph.n, ph.light, spp, clamp_params=True).requires_grad_(True)
+            lo, _, _, _ = loop._loss.brdf_loss(pred, gt, {}, {}, 0.1, ph.gt_srgb)
+            (d_pred,) = torch.autograd.grad(lo, pred)
+            ref = {a: ops.shade_bwd(pa.clamp(0, 1), pr.clamp(0.07, 1), pm.clamp(0, 1), ph.n, ph.light, d_pred.contiguous(), spp, attached=a)[1] for a in (False, True)}
+    reg = 0.1 / (H * W)      # the L1 anchor's share of d loss / d r (:418): sign(r - r0) scale_delta / n
+    for att in (False, True):
+        err = (got[att] - ref[att]).abs()
+        scale = ref[att].abs().mean()
+        assert float(((err - reg).clamp_min(0) / torch.maximum(ref[att].abs(), scale)).max()) < (2e-2 if att else 3e-3), att
+    # the two conventions differ measurably, and each run follows its own
+    assert float((ref[True] - ref[False]).norm() / ref[False].norm()) > 0.02
+    assert float((got[True] - ref[True]).norm()) < 0.3 * float((got[True] - ref[False]).norm())

@@ -1033,12 +1033,23 @@ def test_arm_mlp_phase_schedule_snapshot_and_early_stopping():
     for k, v in net.state_dict().items():
         assert torch.equal(v, bw[k]), k
     assert torch.equal(ph.flat, ph._best_flat)             # the parameters are still views of the flat buffer
-    # host EarlyStopping: with a huge min_delta nothing counts as an improvement after the first iteration
+    # EarlyStopping on the device: with a huge min_delta nothing counts as an improvement after the first iteration, so the state machine
+    # fires in iteration 4 (which still completes, as the reference's loop does); the host polls every `sync_every` iterations and the
+    # iterations enqueued in between are no-ops: statistics, snapshot and AdamW rest
     ph2 = loop.pos_mlp_brdf_phase(scene, gt, net, start_arm, {"albedo": a0, "roughness": r0, "metallic": m0}, optimize_part="rm", spp=8,
                                   patience=3, min_delta=1.0)
-    assert isinstance(ph2, ArmMlpPhase)
+    assert isinstance(ph2, ArmMlpPhase) and ph2.sync_every == 8
     stops = [ph2.step_and_check() for _ in range(4)]
-    assert stops == [False, False, False, True]
+    flat4, best4, stats4 = ph2.flat.clone(), ph2._best_flat.clone(), ph2.stats.clone()
+    stops += [ph2.step_and_check() for _ in range(4)]
+    assert stops == [False] * 7 + [True]
+    assert ph2.iterations_run == 4
+    assert torch.equal(ph2.flat, flat4) and torch.equal(ph2._best_flat, best4)
+    assert float(ph2.stats[0, ops.STAT_MSE]) == float(stats4[0, ops.STAT_MSE]) and float(ph2.stats[0, ops.STAT_STOPPED]) == 2.0
+    host = loop.EarlyStopping(patience=3, min_delta=1.0)
+    for v in ph2.history()[:4, 0].cpu().tolist():
+        host(v)
+    assert host.early_stop and (ph2.history()[4:8] == 0).all()
 
 
 def test_last_sine_layer_with_the_head_in_its_epilogue():
