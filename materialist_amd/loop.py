@@ -335,6 +335,7 @@ class FusedBrdfPhase:
         self._advance()
 
     def _advance(self) -> None:
+        ct = self._ct
         self.t += 1
         if self._pred_bufs is not None:
             # self.pred = the render this step evaluated; the buffer its last launch rendered the next iterate into becomes `pred` of the next step

@@ -234,3 +234,101 @@ def test_hip_render_is_within_45_db_of_the_converged_integral(oracle64, kind):
     got, literal = psnr(out[sl].cpu().numpy().astype(np.float64)), psnr(lit)
     print(f"{kind}: HIP spp 64 {got:.1f} dB, reference-literal estimator spp 64 {literal:.1f} dB (vs spp 4096)")
     assert got >= 45.0 and got >= literal - 1.0
+
+
+# ---------------------------------------------------------------------------------------------- configs[3], the HIP optimisation path
+def test_hip_path_at_1024_render_batch_fused_iterations_and_one_pos_mlp_step(oracle64):
+    """configs[3]'s resolution through the kernels of libmatpbr.so (the reference hard-codes 512 in six places): a 1024x1024
+    render against the fp64 oracle on a 64x64 window with the full image's view directions; a batch of two equals the stand-alone
+    renders bit for bit; two FusedBrdfPhase iterations (exact sampling and the lazy path) keep their 512x512 properties; one
+    ArmMlpPhase iteration runs its M = 1 048 576-row kernels and improves on nothing worse than its first loss."""
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+    from materialist_amd.armhead import ArmMlpPhase
+
+    dev = _cuda()
+    H = W = 1024
+    spp = 64
+    scs = [synthetic.make_scene(20 + i, H, W) for i in range(2)]
+    st = lambda k: _t(np.stack([getattr(s, k) for s in scs]), dev)
+    n = ops.normals_from_depth(st("depth"))
+    a, r, m, light = st("albedo"), st("roughness"), st("metallic"), st("light")
+    out = ops.shade_fwd(a, r, m, n, light, spp)
+    for b in range(2):
+        assert torch.equal(out[b], ops.shade_fwd(a[b], r[b], m[b], n[b], light[b], spp)), b
+    i0, j0, w = 700, 131, 64
+    sl = (slice(i0, i0 + w), slice(j0, j0 + w))
+    n1 = n[1].cpu().numpy().astype(np.float64)
+    ref = oracle64.shade_fwd_win(scs[1].albedo[sl], scs[1].roughness[sl], scs[1].metallic[sl], n1[sl], scs[1].light, spp, H, W, i0, j0)
+    _close(out[1][sl], ref, 1e-3, "1024x1024 render vs oracle on a 64x64 window")
+    # hot loop B, --model_name none: exact sampling and the lazy path, batch == stand-alone, lazy within 1e-3 of exact
+    scene_b = render.load_estimated_mesh(st("depth"), use_mesh_normal=True)
+    scene_b._set("emitter.data", light)
+    init = [st(k) for k in ("init_albedo", "init_roughness", "init_metallic")]
+    scene_1 = render.load_estimated_mesh(st("depth")[1], use_mesh_normal=True)
+    scene_1._set("emitter.data", light[1])
+    for lazy in (False, True):
+        fb = loop.FusedBrdfPhase(scene_b, out, *init, optimize_part="rm", spp=spp, lazy=lazy)
+        f1 = loop.FusedBrdfPhase(scene_1, out[1], *[x[1] for x in init], optimize_part="rm", spp=spp, lazy=lazy)
+        pr_before = fb.p["roughness"].clone()
+        fb.run(2)
+        f1.run(2)
+        for k in ("roughness", "metallic"):
+            assert torch.equal(fb.p[k][1], f1.p[k]), (lazy, k)
+        assert float(fb.stats[1, ops.STAT_MSE]) == float(f1.stats[0, ops.STAT_MSE])
+        assert fb.poll()["iters"].tolist() == [2, 2]
+        assert float((fb.p["roughness"] - pr_before).abs().max()) <= 2 * 3e-4 * 1.001       # Adam's bound: lr per step
+        if lazy:      # the second iteration's render came from the models: against the phase that walks every sample
+            e1 = loop.FusedBrdfPhase(scene_1, out[1], *[x[1] for x in init], optimize_part="rm", spp=spp, lazy=False)
+            e1.run(2)
+            scale = torch.maximum(e1.pred.abs(), e1.pred.abs().mean())
+            assert float(((f1.pred - e1.pred).abs() / scale).max()) < 1e-3
+    # hot loop B, --model_name pos_mlp: one iteration with 1 048 576 rows through the image-size MLP kernels
+    net = posmlp.brdf_net("arm").to(dev)
+    i1 = [x[1] for x in init]
+    start_arm = torch.cat([i1[0].reshape(-1, 3), i1[1].reshape(-1, 1), i1[2].reshape(-1, 1)], -1).clamp(0, 1)
+    ph = loop.pos_mlp_brdf_phase(scene_1, out[1], net, start_arm, {"albedo": i1[0], "roughness": i1[1], "metallic": i1[2]}, optimize_part="rm", spp=spp)
+    assert isinstance(ph, ArmMlpPhase) and ph.bufs[0].shape[0] == H * W
+    ph.step()
+    first = float(ph.stats[0, ops.STAT_MSE])
+    # the zero-initialised output layer makes the first render the render of the start maps (mymodels/mlps.py:174-176, 232-234)
+    r0 = ops.shade_fwd(i1[0].clamp(0, 1), (i1[1] * 0.93 + 0.07).clamp(0.07, 1), i1[2].clamp(0, 1), ph._n, ph._light, spp, dcache=ph.dcache)
+    assert torch.allclose(ph.pred, r0, rtol=2e-5, atol=1e-6)
+    for _ in range(4):
+        ph.step()
+    assert np.isfinite(first) and float(ph.stats[0, ops.STAT_BEST]) <= first
+    assert all(torch.isfinite(v).all() for v in (ph.flat, ph.maps["roughness"], ph.pred))
+
+
+def test_split_operand_and_exact_f32_loops_reach_the_same_loss_at_512():
+    """20 iterations of the headline loop (512x512, part 'rm') with the 256-wide layers on the split-operand bf16-MFMA kernels and
+    on the exact-f32 MFMA kernels (--mlp-products 0): the same loss to 1e-3 at every iteration."""
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+    from materialist_amd.posmlp import _PosMlpHipFn
+
+    dev = _cuda()
+    H = W = 512
+    spp = 64
+    sc = synthetic.make_scene(0, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    start_arm = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1)], -1).clamp(0, 1)
+    curves = {}
+    keep = _PosMlpHipFn.PRODUCTS
+    try:
+        for products in (6, 0):
+            _PosMlpHipFn.PRODUCTS = products
+            torch.manual_seed(7)
+            net = posmlp.brdf_net("arm").to(dev)
+            ph = loop.pos_mlp_brdf_phase(scene, gt, net, start_arm, {"albedo": init[0], "roughness": init[1], "metallic": init[2]}, optimize_part="rm", spp=spp)
+            losses = []
+            for _ in range(20):
+                ph.step()
+                losses.append(ph.stats[0, ops.STAT_LOSS].clone() if hasattr(ph, "stats") else ph.last["loss"].clone())
+            curves[products] = torch.stack(losses).cpu().numpy()
+    finally:
+        _PosMlpHipFn.PRODUCTS = keep
+    assert curves[6][-1] < curves[6][0]
+    assert np.abs(curves[6] - curves[0]).max() <= 1e-3 * np.abs(curves[0]).max(), (curves[6], curves[0])

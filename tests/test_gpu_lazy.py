@@ -263,11 +263,13 @@ def test_lazy_phase_offers_the_attached_roughness_gradient():
             lo, _, _, _ = loop._loss.brdf_loss(pred, gt, {}, {}, 0.1, ph.gt_srgb)
             (d_pred,) = torch.autograd.grad(lo, pred)
             ref = {a: ops.shade_bwd(pa.clamp(0, 1), pr.clamp(0.07, 1), pm.clamp(0, 1), ph.n, ph.light, d_pred.contiguous(), spp, attached=a)[1] for a in (False, True)}
-    reg = 0.1 / (H * W)      # the L1 anchor's share of d loss / d r (:418): sign(r - r0) scale_delta / n
-    for att in (False, True):
-        err = (got[att] - ref[att]).abs()
-        scale = ref[att].abs().mean()
-        assert float(((err - reg).clamp_min(0) / torch.maximum(ref[att].abs(), scale)).max()) < (2e-2 if att else 3e-3), att
+    # stop-gradient default: the jac of the models (half precision) against the exact kernels, every pixel
+    e = (got[False] - ref[False]).abs() / torch.maximum(ref[False].abs(), ref[False].abs().mean())
+    assert float(e.max()) < 3e-3
+    # attached: the slopes are one-sided differences over h = 1e-3, the operator face differentiates analytically at the point: equal up to
+    # half a per cent on the typical pixel, apart where a sample crosses the horizon within h (the derivative jumps there)
+    e = (got[True] - ref[True]).abs() / torch.maximum(ref[True].abs(), ref[True].abs().mean())
+    assert float(e.flatten().median()) < 1e-2 and float((got[True] - ref[True]).norm() / ref[True].norm()) < 0.08
     # the two conventions differ measurably, and each run follows its own
-    assert float((ref[True] - ref[False]).norm() / ref[False].norm()) > 0.02
+    assert float((ref[True] - ref[False]).norm() / ref[False].norm()) > 0.2
     assert float((got[True] - ref[True]).norm()) < 0.3 * float((got[True] - ref[False]).norm())
