@@ -51,6 +51,9 @@ def parse(argv=None):
     ap.add_argument("--no-relight", action="store_true", help="skip the 2048x2048 relighting measurement (1.3 GB transfer buffer)")
     ap.add_argument("--no-extras", action="store_true", help="headline mode only (no other loops, no kernel roofline legs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even at world size 1 and run the barrier / all_gather of the timing protocol: "
+                         "what the N-rank runs do, provable on one GPU (tests/test_gpu_configs.py)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise the launcher and the timing protocol with a CPU stand-in step over gloo (tests/test_bench_launcher.py)")
     return ap.parse_args(argv)
@@ -137,12 +140,13 @@ def cpu_baseline(size, spp, target_s):
 class _Protocol:
     """The timing contract: W untimed steps, then EXACTLY K steps between barrier + synchronize fences, MAX over ranks."""
 
-    def __init__(self, dist, world, device, sync):
+    def __init__(self, dist, world, device, sync, collectives=None):
         self.dist, self.world, self.device, self.sync = dist, world, device, sync
+        self.collectives = world > 1 if collectives is None else bool(collectives)     # --force-dist: also at world size 1
 
     def fence(self):
         self.sync()
-        if self.world > 1:
+        if self.collectives:
             self.dist.barrier()
         self.sync()
 
@@ -159,7 +163,7 @@ class _Protocol:
         mine = time.perf_counter() - t0
         el = torch.tensor([mine], dtype=torch.float64, device=self.device)
         per_rank = [mine]
-        if self.world > 1:
+        if self.collectives:
             bufs = [torch.zeros_like(el) for _ in range(self.world)]
             self.dist.all_gather(bufs, el)
             per_rank = [float(b.item()) for b in bufs]
@@ -206,8 +210,10 @@ def main(argv=None):
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(args.size, args.spp, args.cpu_seconds)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local_rank)
@@ -221,7 +227,7 @@ def main(argv=None):
     if args.mlp_products is not None:
         _posmlp._PosMlpHipFn.PRODUCTS = args.mlp_products
     H = W = args.size
-    proto = _Protocol(dist, world, dev, torch.cuda.synchronize)
+    proto = _Protocol(dist, world, dev, torch.cuda.synchronize, collectives=use_dist)
     mode = args.mode or ("pos_mlp" if args.images_per_gpu == 1 else "fused")
     if mode == "pos_mlp" and args.images_per_gpu > 1:
         raise SystemExit("--mode pos_mlp optimises one image per process (use --mode fused for --images-per-gpu > 1)")
@@ -536,8 +542,8 @@ def main(argv=None):
     if rank == 0:
         out = {
             "metric": "opt_iterations_per_sec_512x512", "value": value, "unit": "it/s", "n_gpus": world,
-            "world_size": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "world_size": dist.get_world_size() if use_dist else 1, "collective_backend": dist.get_backend() if use_dist else None,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2-synthetic (BASELINE configs[1]): {H}x{W}, one epoch of hot loop B, part 'rm' of --opt_order 'rm a', "
                                    f"{'--model_name pos_mlp' if mode == 'pos_mlp' else '--model_name none'} "
@@ -559,7 +565,7 @@ def main(argv=None):
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

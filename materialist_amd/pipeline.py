@@ -280,11 +280,87 @@ def save_results(path: str, best: Dict[str, torch.Tensor], normal: torch.Tensor)
     write_exr(os.path.join(path, "normal.exr"), np_(normal))
 
 
+def initial_prediction(img: np.ndarray, size: int, device, matnet=None, matnet_weights: Optional[str] = None, pred_dir: Optional[str] = None):
+    """MaterialNet's initial guess of the maps (inverse_img_w_mi.py:648-661): from a loaded network, a weights file, a directory of
+    predictions in the reference's file layout, or -- with a warning -- the flat prior."""
+    if matnet is None and matnet_weights:
+        from .materialnet import MaterialNet
+
+        matnet = MaterialNet()
+        matnet.load_state_dict(torch.load(matnet_weights, map_location="cpu", weights_only=True))
+    if matnet is not None:
+        return matnet.to(device).eval().infer_image(img)
+    if pred_dir:
+        return load_predictions(pred_dir, (size, size))
+    warnings.warn("neither --matnet_weights nor --pred_dir given: starting from a FLAT prior (albedo = image, roughness 0.5, "
+                  "metallic 0, planar depth) instead of MaterialNet's prediction (inverse_img_w_mi.py:648-661)", UserWarning)
+    return flat_prior(img)
+
+
+def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], opt_src: str = "arm", opt_order: Sequence[str] = ("arm",),
+                           opt_env_from: int = 0, save_path: Optional[str] = None, size: int = 512, spp: int = 64, num_epochs: int = 5000,
+                           pred_dirs: Optional[Sequence[Optional[str]]] = None, device: str = "cuda", matnet=None, log=print) -> Dict[str, object]:
+    """`--model_name none` on several photographs at once: the images of a rank's shard as ONE batch in the kernels' batch dimension
+    (per-image light, SaveBest and EarlyStopping on the device), each with the reference's output directory (inverse_img_w_mi.py:623-770
+    per image; the reference runs them one after another, run_inverse_pipeline.sh:16-28).  Scenes with a `mesh_mask.png`, `--use_mask`
+    and parts with 'n' stay with `inverse_image` (they need per-image operator calls)."""
+    from . import optimize, render
+    from . import mesh as _mesh
+
+    if "n" in str(list(opt_order)):
+        raise ValueError("inverse_images_batched optimises a / r / m under the geometric normal")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+    mats, depths, out_dirs = [], [], []
+    for k, (path, name) in enumerate(zip(img_paths, save_names)):
+        output_dir = get_output_dir(name, save_path)
+        os.makedirs(os.path.join(output_dir, "best_results"), exist_ok=True)
+        if os.path.exists(os.path.join(output_dir, "mesh_mask.png")):
+            raise ValueError(f"{output_dir}: has a mesh_mask.png; run it through inverse_image")
+        img = center_crop_and_resize(load_image(path), (size, size))
+        if not path.endswith(".exr"):
+            img = np.asarray(_loss.srgb_to_linear(torch.from_numpy(img)).numpy(), dtype=np.float32)
+        pred = initial_prediction(img, size, device, matnet=matnet, pred_dir=pred_dirs[k] if pred_dirs else None)
+        mats.append({"gt_image": t(img), "albedo": t(pred["albedo"]).clamp(0, 1), "roughness": t(pred["roughness"]).unsqueeze(-1).clamp(0.07, 1),
+                     "metallic": t(pred["metallic"]).unsqueeze(-1).clamp(0, 1)})
+        write_exr(os.path.join(output_dir, "albedoPred.exr"), pred["albedo"])
+        write_exr(os.path.join(output_dir, "normalPred.exr"), pred["normal"])
+        write_png(os.path.join(output_dir, "roughnessPred.png"), pred["roughness"], linear=True)
+        write_png(os.path.join(output_dir, "metallicPred.png"), pred["metallic"], linear=True)
+        write_exr(os.path.join(output_dir, "depthPred.exr"), pred["depth"])
+        write_exr(os.path.join(output_dir, "gt_image.exr"), img)
+        write_png(os.path.join(output_dir, "gt_image.png"), img, linear=True)
+        with open(os.path.join(output_dir, "config.json"), "w") as f:
+            json.dump({"img_path": path, "save_name": name, "opt_src": opt_src, "opt_order": list(opt_order), "use_mask": False,
+                       "opt_env_from": opt_env_from, "model_name": "none", "timestamp": time.strftime("%Y-%m-%d %H:%M:%S"),
+                       "image_size": list(img.shape[:2]), "spp": spp, "output_type": "arm", "use_mesh_normal": True}, f, indent=4)
+        depth = 2 * pred["depth"].max() - pred["depth"]
+        mesh_path = os.path.join(output_dir, f"{name}.ply")
+        if not os.path.exists(mesh_path):
+            _mesh.write_ply(mesh_path, *_mesh.depth_to_mesh(np.array(depth, dtype=np.float64), render.DEFAULT_FOV))
+        depths.append(t(depth))
+        out_dirs.append(output_dir)
+    B = len(mats)
+    mat = {k: torch.stack([m[k] for m in mats]) for k in mats[0]}
+    scene = render.load_estimated_mesh(torch.stack(depths), use_mesh_normal=True, device=device)
+    res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
+                                        num_epochs=num_epochs, log=log, model_name="none")
+    nrm = scene.geo_normal
+    for b, output_dir in enumerate(out_dirs):
+        best = {k: res[k][b] for k in ("albedo", "roughness", "metallic", "rendered_img")}
+        env = res["envmap"][b] if res["envmap"].ndim == 4 else res["envmap"]
+        best["envmap"] = env
+        save_results(os.path.join(output_dir, "best_results"), best, nrm[b])
+        write_hdr(os.path.join(output_dir, "final_envmap.hdr"), env.detach().cpu().numpy())
+    res["output_dirs"] = out_dirs
+    return res
+
+
 def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", opt_order: Sequence[str] = ("arm",), use_mask: bool = False,
                   opt_env_from: int = 0, save_path: Optional[str] = None, model_name: str = "pos_mlp", size: int = 512, spp: int = 64,
                   num_epochs: int = 5000, pred_dir: Optional[str] = None, device: str = "cuda", sync_every: int = 10,
-                  log=print, matnet_weights: Optional[str] = None, frame_interval: float = 0.2) -> Dict[str, object]:
-    """inverse_img_w_mi.py:623-770 (resolution-generic: `size`; `model_name` is honoured, F4)."""
+                  log=print, matnet_weights: Optional[str] = None, frame_interval: float = 0.2, matnet=None) -> Dict[str, object]:
+    """inverse_img_w_mi.py:623-770 (resolution-generic: `size`; `model_name` is honoured, F4).  `matnet`: an already loaded MaterialNet
+    (run_batch.py loads the weights once on rank 0 and broadcasts them)."""
     from . import optimize, render
 
     if model_name not in ("none", "pos_mlp"):
@@ -301,19 +377,7 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
     mat: Dict[str, torch.Tensor] = {}
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
     if opt_src != "skip" or list(opt_order) != ["skip"]:
-        if matnet_weights:                                                                       # :648-661
-            from .materialnet import MaterialNet
-
-            matnet = MaterialNet()
-            matnet.load_state_dict(torch.load(matnet_weights, map_location="cpu", weights_only=True))
-            pred = matnet.to(device).eval().infer_image(img)
-            del matnet
-        elif pred_dir:
-            pred = load_predictions(pred_dir, (size, size))
-        else:
-            warnings.warn("neither --matnet_weights nor --pred_dir given: starting from a FLAT prior (albedo = image, roughness 0.5, "
-                          "metallic 0, planar depth) instead of MaterialNet's prediction (inverse_img_w_mi.py:648-661)", UserWarning)
-            pred = flat_prior(img)
+        pred = initial_prediction(img, size, device, matnet=matnet, matnet_weights=matnet_weights, pred_dir=pred_dir)
         mat["gt_image"] = t(img)                                                                 # :663-670
         mat["albedo"] = t(pred["albedo"]).clamp(0, 1)
         mat["normal"] = t(pred["normal"])

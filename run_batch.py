@@ -26,6 +26,11 @@ def main(argv=None):
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--num_epochs", type=int, default=5000)
+    ap.add_argument("--matnet_weights", type=str, default=None,
+                    help="MaterialNet weights (the reference downloads Lez/MatNet matnet_weights.pth, inverse_img_w_mi.py:648-654): read by rank 0 "
+                         "only and broadcast to the other ranks as one flat buffer")
+    ap.add_argument("--pred_dir", type=str, default=None,
+                    help="MaterialNet predictions in the reference's file layout (albedoPred.exr ...): <pred_dir>/<image name>/ or <pred_dir> itself")
     a = ap.parse_args(argv)
     import numpy as np
     import torch
@@ -33,8 +38,23 @@ def main(argv=None):
     from materialist_amd import batch, optimize, pipeline, render, synthetic
 
     rank, world, local = batch.init_distributed()
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
     paths = list(a.images) if a.images else [f"synthetic:{i}" for i in range(a.synthetic)]
+    matnet = None
+    if a.matnet_weights and a.images:            # weights: one reader, one broadcast
+        from materialist_amd.dist import broadcast_state_dict
+        from materialist_amd.materialnet import MaterialNet
+
+        sd = torch.load(a.matnet_weights, map_location="cpu", weights_only=True) if rank == 0 else None
+        matnet = MaterialNet()
+        matnet.load_state_dict(broadcast_state_dict(sd, dev))
+        matnet = matnet.to(dev).eval()
+
+    def pred_dir_of(path):
+        if not a.pred_dir:
+            return None
+        sub = os.path.join(a.pred_dir, os.path.splitext(os.path.basename(path))[0])
+        return sub if os.path.isdir(sub) else a.pred_dir
 
     def process(i, path, cfg):
         if path.startswith("synthetic:"):
@@ -51,12 +71,20 @@ def main(argv=None):
         else:
             name = os.path.splitext(os.path.basename(path))[0]
             res = pipeline.inverse_image(path, name, cfg["opt_src"], cfg["opt_order"], False, cfg["opt_env_from"], cfg["save_path"], cfg["model_name"],
-                                         size=cfg["size"], spp=cfg["spp"], num_epochs=cfg["num_epochs"], device=str(dev), log=lambda *_: None)
+                                         size=cfg["size"], spp=cfg["spp"], num_epochs=cfg["num_epochs"], device=str(dev), log=lambda *_: None,
+                                         matnet=matnet, pred_dir=pred_dir_of(path))
         return [res["best_loss"], res["psnr"], float(sum(max(t.epoch, 0) + 1 for t in res["trace"] if t.phase != "end"))]
 
     def process_shard(ids, shard_paths, cfg):
-        """`--model_name none` on synthetic scenes: the rank's whole shard as one batch (B images in the kernels' batch dimension,
-        per-image lights, SaveBest and EarlyStopping per image on the device)."""
+        """`--model_name none`: the rank's whole shard as one batch (B images in the kernels' batch dimension, per-image lights, SaveBest
+        and EarlyStopping per image on the device) -- synthetic scenes, or photographs with their MaterialNet predictions."""
+        if not shard_paths[0].startswith("synthetic:"):
+            names = [os.path.splitext(os.path.basename(p))[0] for p in shard_paths]
+            res = pipeline.inverse_images_batched(shard_paths, names, cfg["opt_src"], cfg["opt_order"], cfg["opt_env_from"], cfg["save_path"],
+                                                  size=cfg["size"], spp=cfg["spp"], num_epochs=cfg["num_epochs"],
+                                                  pred_dirs=[pred_dir_of(p) for p in shard_paths], device=str(dev), matnet=matnet, log=lambda *_: None)
+            its = float(sum(max(t.epoch, 0) + 1 for t in res["trace"] if t.phase != "end"))
+            return [[bl, ps, its] for bl, ps in zip(res["best_loss_per_image"], res["psnr_per_image"])]
         scs = [synthetic.make_scene(int(p.split(":")[1]), cfg["size"], cfg["size"]) for p in shard_paths]
         st = lambda k: torch.from_numpy(np.stack([getattr(s, k) for s in scs])).to(dev)
         depth = st("depth")
@@ -73,7 +101,13 @@ def main(argv=None):
 
     cfg = {"save_path": a.save_path, "opt_src": a.opt_src, "opt_order": a.opt_order, "opt_env_from": a.opt_env_from, "model_name": a.model_name,
            "size": a.size, "spp": a.spp, "num_epochs": a.num_epochs}
-    batched = a.model_name == "none" and paths and all(p.startswith("synthetic:") for p in paths)
+    # a rank's shard runs as one batch in --model_name none mode (file images: unless one of them has a mesh_mask.png, which needs the
+    # per-image operator path)
+    def has_mesh_mask(p):
+        return os.path.exists(os.path.join(pipeline.get_output_dir(os.path.splitext(os.path.basename(p))[0], a.save_path), "mesh_mask.png"))
+
+    batched = a.model_name == "none" and bool(paths) and "n" not in str(a.opt_order) and (
+        all(p.startswith("synthetic:") for p in paths) or not any(p.startswith("synthetic:") or has_mesh_mask(p) for p in paths))
     rows = batch.run_batch(paths, cfg, process, process_shard=process_shard if batched else None)
     if rank == 0:
         for r in rows:

@@ -148,3 +148,39 @@ def test_run_batch_hands_a_rank_its_whole_shard_and_survives_a_failing_rank(fail
             assert r["error"] == "RuntimeError: boom" and all(np.isnan(v) for v in r["values"])
         else:
             assert r["error"] is None and r["values"] == [2.0 * r["image_id"], float(len(r["path"]))]
+
+
+def _weights_worker(rank, world, port, path, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from materialist_amd.dist import broadcast_state_dict
+
+        # only rank 0 reads the file (the other ranks are handed a path that does not exist)
+        sd = torch.load(path, map_location="cpu", weights_only=True) if rank == 0 else None
+        got = broadcast_state_dict(sd, torch.device("cpu"))
+        out_q.put((rank, {k: (tuple(v.shape), str(v.dtype), float(v.double().sum())) for k, v in got.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_network_weights_leave_rank_0_once_as_a_flat_buffer(tmp_path):
+    """rank 0 loads MaterialNet / PosMLP weights and broadcasts ONE flat buffer; every rank ends with the same state_dict."""
+    torch.manual_seed(3)
+    sd = {"pretrained.blocks.0.attn.qkv.weight": torch.randn(12, 4), "pretrained.blocks.0.attn.qkv.bias": torch.randn(12),
+          "depth_head.scratch.output_conv2.0.weight": torch.randn(2, 3, 3, 3), "empty": torch.zeros(0)}
+    path = str(tmp_path / "w.pth")
+    torch.save(sd, path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_weights_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = {k: (tuple(v.shape), str(v.dtype), float(v.double().sum())) for k, v in sd.items()}
+    assert res[0] == want and res[1] == want

@@ -332,3 +332,85 @@ def test_split_operand_and_exact_f32_loops_reach_the_same_loss_at_512():
         _PosMlpHipFn.PRODUCTS = keep
     assert curves[6][-1] < curves[6][0]
     assert np.abs(curves[6] - curves[0]).max() <= 1e-3 * np.abs(curves[0]).max(), (curves[6], curves[0])
+
+
+# ---------------------------------------------------------------------------------------------- configs[2], what N ranks do, on one GPU
+def test_rccl_path_of_the_bench_at_world_size_one():
+    """`bench.py` launched exactly as the driver launches its N-rank runs (`python -m torch.distributed.run --nproc-per-node ...`), with one
+    rank and --force-dist: RCCL `init_process_group("nccl", device_id=...)`, the barrier and the all_gather of the timing protocol
+    execute on the GPU, and `world_size` in the JSON line comes from `dist.get_world_size()`.  The C3 command itself: --mode fused
+    --images-per-gpu 8, whose headline is image-iterations/s over all ranks."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    _cuda()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--force-dist", "--gpus", "1", "--mode", "fused", "--images-per-gpu", "8", "--no-extras", "--no-cpu-baseline",
+           "--steps", "30", "--warmup", "5"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)      # a child process: never an exec from a GPU-initialised one
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["world_size"] == 1 and out["n_gpus"] == 1 and out["collective_backend"] == "nccl"
+    assert out["config"]["images_per_gpu"] == 8 and out["config"]["mode"] == "fused"
+    assert out["value"] == pytest.approx(30 * 8 / (out["ms_per_step"] * 30 * 1e-3), rel=1e-6)       # image-iterations/s over all ranks
+    assert len(out["ranks"]) == 1 and out["value"] > 1000
+
+
+def test_run_batch_takes_predictions_and_runs_a_shard_of_photographs_as_one_batch(golden_dir, tmp_path):
+    """run_batch.py on two photographs with MaterialNet predictions given as files (--pred_dir): no flat-prior warning, and in
+    --model_name none mode the rank's shard is ONE batch in the kernels' batch dimension; every image gets the reference's output
+    directory (best_results/*.exr, envmap.hdr, final_envmap.hdr, config.json, .ply)."""
+    import json
+    import subprocess
+    import sys
+    import warnings
+
+    from PIL import Image
+
+    from materialist_amd.imageio_exr import write_exr
+
+    _cuda()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(golden_dir, "jinjya256.npz"))
+    imgs, preds = tmp_path / "imgs", tmp_path / "preds"
+    imgs.mkdir()
+    for k, name in enumerate(("shrine_a", "shrine_b")):
+        gt = z["gt_linear_f16"].astype(np.float32)
+        if k:
+            gt = gt[:, ::-1].copy()                        # a second, different photograph: the mirror image
+        write_exr(str(imgs / f"{name}.exr"), gt)
+        d = preds / name
+        d.mkdir(parents=True)
+        flip = (lambda x: x[:, ::-1].copy()) if k else (lambda x: x)
+        write_exr(str(d / "albedoPred.exr"), flip(z["albedo_pred_f16"].astype(np.float32)))
+        H, W = z["depth_pred_f32"].shape
+        up = np.zeros((H, W, 3), np.float32)
+        up[..., 2] = 1
+        write_exr(str(d / "normalPred.exr"), up)
+        Image.fromarray(flip(z["roughness_pred_u8"])).save(str(d / "roughnessPred.png"))
+        Image.fromarray(flip(z["metallic_pred_u8"])).save(str(d / "metallicPred.png"))
+        write_exr(str(d / "depthPred.exr"), flip(z["depth_pred_f32"]))
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(root, "run_batch.py"), "--images", str(imgs / "shrine_a.exr"), str(imgs / "shrine_b.exr"),
+           "--pred_dir", str(preds), "--save_path", str(out), "--model_name", "none", "--opt_src", "a", "--opt_order", "rm", "a", "--opt_env_from", "2",
+           "--size", "256", "--num_epochs", "60"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert "FLAT prior" not in res.stderr
+    rows = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert [os.path.basename(r["image"]) for r in rows] == ["shrine_a.exr", "shrine_b.exr"] and all(r["error"] is None for r in rows)
+    assert rows[0]["iterations"] == rows[1]["iterations"]          # one batch: the shard's images share the enqueued iterations
+    assert all(np.isfinite(r["psnr_db"]) and r["psnr_db"] > 15 for r in rows)
+    for name in ("shrine_a", "shrine_b"):
+        d = out / name
+        for f in ("config.json", f"{name}.ply", "final_envmap.hdr", "albedoPred.exr", "gt_image.png", "best_results/albedo.exr", "best_results/roughness.exr",
+                  "best_results/metallic.exr", "best_results/rendered_img.exr", "best_results/normal.exr", "best_results/envmap.hdr"):
+            assert (d / f).exists(), (name, f)
