@@ -53,6 +53,9 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
                                            the convention of the live reference (myutils/mi_plugin.py:227-230,1335-1341), instead of the
                                            stop-gradient convention of the default.  d_a, d_m, d_n, d_light do not change. */
 #define MATPBR_FLAG_LAZY_FORCE 16u /* matpbr_shade_fwd_lazy: rebuild the model of every pixel (first render of a part; `lazy_state` is not read) */
+#define MATPBR_FLAG_MODELS_READY 64u /* MatpbrBrdfPhase.flags: the caller has already built (and possibly edited) what the step with t == 1 would
+                                        build -- the models in lazy_state (matpbr_shade_fwd_lazy with MATPBR_FLAG_LAZY_FORCE), or jac + s1cache of a
+                                        part without MATPBR_PART_R (matpbr_shade_fwd_keep): pixels without geometry are given constant models */
 #define MATPBR_FLAG_JAC16 32u      /* matpbr_brdf_loss_bwd_jac: `jac` holds the half-precision planes written by matpbr_shade_fwd_lazy */
 #define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
 #define MATPBR_PART_R 4u
@@ -219,7 +222,7 @@ typedef struct MatpbrBrdfPhase {
                                              next one (pixels that left their model's interval pending); the caller SWAPS pred and pred_next before the
                                              next step, calls the steps with t = 1, 2, 3, ... and leaves workspace / lazy_state / pr / pm alone in between.
                                              The SaveBest snapshot of a map that the part does not optimise is not rewritten. */
-    uint32_t flags;                       /* MATPBR_FLAG_ATTACHED_SAMPLING (pred_next mode only): d loss / d r through the GGX quadrature nodes -- the models'
+    uint32_t flags;                       /* MATPBR_FLAG_MODELS_READY; MATPBR_FLAG_ATTACHED_SAMPLING (pred_next mode only): d loss / d r through the GGX quadrature nodes -- the models'
                                              slopes are that derivative -- i.e. the live reference's gradient convention (myutils/mi_plugin.py:227-230,
                                              1335-1341) instead of the stop-gradient default */
 } MatpbrBrdfPhase;

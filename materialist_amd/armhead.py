@@ -173,6 +173,10 @@ class ArmMlpPhase:
         self.jac = ops.plane9(self.gt)
         # a part that leaves the roughness alone ('a' of --opt_order 'rm a'): the specular sums are constants of the part (:497-504)
         self.s1 = None if "roughness" in self.live else torch.empty((3, 1, H, W), dtype=torch.float32, device=dev)
+        self._bg_mask = scene.bg_mask
+        if self._bg_mask is not None:
+            self._bg_flat = self._bg_mask.reshape(-1)
+            self._bg_rgb = (scene.bg_basis @ self._light.reshape(25, 3)).contiguous()
         self.t = 0
 
     # ------------------------------------------------------------------------------------------------------------------------------
@@ -238,6 +242,10 @@ class ArmMlpPhase:
         else:
             o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], self._n, self._light, self.spp, sc.fov, clamp_params=True, out=self.pred,
                         dcache=self.dcache, jac=self.jac, s1=self.s1)
+        if self._bg_mask is not None and not (self.s1 is not None and self.t > 0):
+            # pixels without geometry: the environment along the camera ray, no material gradient (after the kernels have written these buffers)
+            self.pred.view(-1, 3)[self._bg_flat] = self._bg_rgb[self._bg_flat]
+            o.background_into_jac(self.jac, self.s1, self._bg_mask, self._bg_rgb)
         o.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
                           self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part,
                           es_patience=self.patience, es_min_delta=self.min_delta, history=self.hist)

@@ -1217,9 +1217,9 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         // (as pred_next; the caller swapped the two)
     } else if (lazy) {
         const int rc = lazy_forward(q.pa, q.pr, q.pm, q.n, q.light, q.dcache, q.lazy_state, q.pred, q.jac, q.stats, fwd_sums, g, tab, q.batch, 1,
-                                    t == 1 ? 1 : 0, 0.0f, q.lazy_tol, st);
+                                    (t == 1 && !(q.flags & MATPBR_FLAG_MODELS_READY)) ? 1 : 0, 0.0f, q.lazy_tol, st);
         if (rc != MATPBR_OK) return rc;
-    } else if (r_fixed && t > 1)
+    } else if (r_fixed && (t > 1 || (q.flags & MATPBR_FLAG_MODELS_READY)))
         hipLaunchKernelGGL(shade_cached_kernel, grid, dim3(kBlock), 0, st, sa, g);
     else
         hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, sa, q.light, g, tab);

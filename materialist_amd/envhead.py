@@ -100,6 +100,8 @@ class EnvMlpPhase:
         shp = (self.H, self.W)
         self.T = ops.shade_transfer(scene.a.contiguous(), scene.r.reshape(shp + (1,)).contiguous(), scene.m.reshape(shp + (1,)).contiguous(),
                                     scene.shading_normal().contiguous(), self.spp, scene.fov)
+        if scene.bg_mask is not None:    # pixels without geometry see the environment along their camera ray: their transfer is the SH basis there
+            ops.background_into_transfer(self.T, self.H, self.W, scene.bg_basis)
         # ---- the launch list of one iteration --------------------------------------------------------------------------------------
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         lib, calls = self.lib, []

@@ -312,6 +312,24 @@ class FusedBrdfPhase:
         if attached_sampling and not self.lazy:
             raise ValueError("attached_sampling needs the lazy path (a part that optimises the roughness)")
         ph.flags = ops.FLAG_ATTACHED_SAMPLING if attached_sampling else 0
+        # pixels without geometry (Scene.set_mesh_mask): build what the first step would build, give those pixels constant models
+        # (they render the environment along their camera ray and receive no material gradient), and tell the steps so
+        self.bg_mask = scene.bg_mask
+        if self.bg_mask is not None:
+            if B != 1:
+                raise NotImplementedError("pixels without geometry: single-image scenes")
+            bg_rgb = (scene.bg_basis @ self.light.reshape(25, 3)).reshape(self.H, self.W, 3)
+            pc = (self.p["albedo"], self.p["roughness"], self.p["metallic"])
+            if self.lazy:
+                ops.shade_fwd_lazy(*pc, self.n, self.light, self.spp, self.dcache, self.lazy_state, out=self.pred, jac16=self.jac.view(torch.int32)[:5],
+                                   force=True, clamp_params=True, floor=0.5 * float(self.gt.mean()), fov_x_deg=scene.fov)
+                ops.background_into_lazy_state(self.lazy_state, self.p["albedo"], self.bg_mask, bg_rgb, self.p["roughness"])
+            elif self.s1cache is not None:
+                ops.shade_fwd(*pc, self.n, self.light, self.spp, scene.fov, clamp_params=True, out=self.pred, dcache=self.dcache, jac=self.jac, s1=self.s1cache)
+                ops.background_into_jac(self.jac, self.s1cache, self.bg_mask, bg_rgb)
+            else:
+                raise NotImplementedError("pixels without geometry need the lazy path in parts that optimise the roughness")
+            ph.flags |= ops.FLAG_MODELS_READY
         # lazy: the step's last launch also renders the next iterate (into pred_next); the two render buffers swap roles every step
         self._pred_bufs = [self.pred, torch.empty_like(self.gt)] if self.lazy else None
         self._pred_cur = 0
@@ -423,6 +441,8 @@ class FusedEnvPhase:
         sc = scene
         self.T = ops.shade_transfer(sc.a.contiguous(), sc.r.reshape(shp + (1,)).contiguous(), sc.m.reshape(shp + (1,)).contiguous(),
                                     sc.shading_normal().contiguous(), self.spp, sc.fov)
+        if sc.bg_mask is not None:       # pixels without geometry see the environment along their camera ray: their transfer is the SH basis there
+            ops.background_into_transfer(self.T, self.H, self.W, sc.bg_basis)
 
     def step(self) -> None:
         if not self.use_graph:

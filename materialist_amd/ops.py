@@ -17,6 +17,7 @@ FLAG_CLAMP_PARAMS = 1
 FLAG_ATTACHED_SAMPLING = 2
 FLAG_LAZY_FORCE = 16
 FLAG_JAC16 = 32
+FLAG_MODELS_READY = 64
 LAZY_NSTATE = 22
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
@@ -231,6 +232,55 @@ def jac16_unpack(jac16: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
         code = _lib.load().matpbr_jac16_unpack(_ptr(jac16), _ptr(jac), H, W, B, _stream(a))
     _lib.check(code, "matpbr_jac16_unpack")
     return jac
+
+
+# ---- pixels without geometry (mesh_mask.png, inverse_img_w_mi.py:713-724): their camera ray sees the environment, out = sum_k light[k] Y_k(ray).
+# In the terms the fused loops work with (out = a (1-m) P + C0 (S0-S1) + S1, material gradients from P, S0-S1 and d out/d r) that is P = 0,
+# S0-S1 = 0, S1 = background, d out/d r = 0: such a pixel renders the background whatever its materials are and hands them no gradient.  The
+# helpers below write exactly that into the per-pixel buffers of a single image after the kernels have filled them.
+def _half_bits(x: float) -> int:
+    import numpy as np
+
+    return int(np.array([x], dtype=np.float16).view(np.uint16)[0])
+
+
+def background_into_lazy_state(state: torch.Tensor, a: torch.Tensor, bg_mask: torch.Tensor, bg_rgb: torch.Tensor, r: torch.Tensor) -> None:
+    """Constant models for the masked pixels of ONE image: P = SD = 0, S1 = bg_rgb, no slopes, an interval no roughness can leave."""
+    B, H, W = _bhw(a)
+    if B != 1:
+        raise NotImplementedError("pixels without geometry: single-image scenes")
+    P = H * W
+    planes = state[: 21 * 4 * P].view(torch.int32).view(21, P)
+    idx = bg_mask.reshape(-1).nonzero().reshape(-1)
+    bits = lambda t: t.contiguous().view(torch.int32)
+    planes[0, idx] = bits(r.reshape(-1)[idx].clamp(0.07, 1.0).float())
+    big = _half_bits(60000.0)
+    planes[1, idx] = (big << 16) | big
+    planes[2, idx] = bits(torch.full((idx.numel(),), 0.03, device=a.device))
+    planes[3:9, idx] = 0
+    for c in range(3):
+        planes[9 + c, idx] = bits(bg_rgb.reshape(-1, 3)[idx, c].float())
+    planes[12:21, idx] = 0
+
+
+def background_into_jac(jac: torch.Tensor, s1: Optional[torch.Tensor], bg_mask: torch.Tensor, bg_rgb: torch.Tensor) -> None:
+    """The same for the fp32 jac planes ([9, 1, H, W]: P, SD, d out/d r) and, if kept, the S1 planes ([3, 1, H, W])."""
+    m = bg_mask.reshape(-1)
+    jac.view(9, -1)[:, m] = 0.0
+    if s1 is not None:
+        s1.view(3, -1)[:, m] = bg_rgb.reshape(-1, 3)[m].t()
+
+
+def background_into_transfer(T: torch.Tensor, H: int, W: int, bg_basis: torch.Tensor) -> None:
+    """Radiance transfer of ONE image (tiled [ceil(P/256)][75][256]): a masked pixel's transfer is the SH basis along its camera ray, per channel."""
+    P = H * W
+    tiles = (P + 255) // 256
+    Tv = T[: tiles * 75 * 256].view(tiles, 25, 3, 256)
+    Y = torch.zeros((tiles * 256, 25), dtype=torch.float32, device=T.device)
+    Y[:P] = bg_basis
+    sel = (Y.abs().sum(1) > 0).view(tiles, 1, 1, 256)
+    Yv = Y.view(tiles, 256, 25).permute(0, 2, 1).unsqueeze(2)          # [tiles, 25, 1, 256]
+    Tv.copy_(torch.where(sel, Yv.expand(-1, -1, 3, -1), Tv))
 
 
 def diffuse_cache(n, light, spp: int, fov_x_deg: float = 35.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -90,7 +90,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
     say = (lambda msg: log(f"[{time.perf_counter() - t_start:7.2f} s] {msg}")) if log is not None else (lambda *_: None)
 
     # ------------------------------------------------------------------ hot loop A (:236-254), device-resident
-    background = scene.bg_mask is not None                                          # mesh_mask.png: operator-face phases only
+    background = scene.bg_mask is not None                                          # mesh_mask.png: pixels that see the environment directly
 
     def env_phase_runner_background(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
         """Hot loop A on the operator face (scenes with pixels that see the environment directly)."""
@@ -124,7 +124,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         return done - 1, stop, mse
 
     def env_phase_runner(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
-        if background:
+        if background and gt.ndim != 3:
             return env_phase_runner_background(loop_num, lr_of, patience, min_delta, max_epochs)
         graph = max_epochs > 8 and gt.is_cuda
         if model_name == "pos_mlp":
@@ -279,11 +279,15 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         return it, ph.opt.param_groups[0]["lr"], stop
 
     def brdf_part_runner(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
-        if model_name == "pos_mlp" and (not scene.use_mesh_normal or background):
-            return brdf_part_runner_mlp_normal(loop_num, part, patience, min_delta, n_epochs)
+        if model_name == "pos_mlp":
+            from .armhead import ArmMlpPhase
+
+            # predicted normals, or pixels without geometry on an image the launch-by-launch phase does not take: the operator face
+            if not scene.use_mesh_normal or (background and not ArmMlpPhase.supported(scene, gt, brdf_net, part, mask)):
+                return brdf_part_runner_mlp_normal(loop_num, part, patience, min_delta, n_epochs)
         if model_name == "pos_mlp":
             return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
-        if "n" in part or not scene.use_mesh_normal or mask is not None or background:
+        if "n" in part or not scene.use_mesh_normal or mask is not None:
             return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
         ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], optimize_part=part, spp=spp,
                                   scale_delta=scale_delta, patience=patience, min_delta=min_delta,
