@@ -416,6 +416,18 @@ int matpbr_sh_eval(const float* w, const float* coef /*[25,3]*/, float* L, long 
 int matpbr_normals_from_depth(const float* depth, float* out_n, int H, int W, int batch, const MatpbrCamera* cam,
                               void* stream);
 
+/* HOST function (no GPU involved; host pointers): the reference's depth -> mesh conversion `depth_file_to_mesh` -> `detect_boundary_points`
+ * (myutils/mesh_recon.py:41-74,86-331, called with minAngle 6 at inverse_img_w_mi.py:726) with its gap closing at depth discontinuities, and
+ * the rotation into the renderer's frame (inverse_img_w_mi.py:727): the same sequential algorithm, vertex for vertex and triangle for
+ * triangle (tests/golden/mesh_normals.npz).  depth[H,W] is the array handed to the mesher (2 max - prediction, 0 = no geometry).
+ *   new_depth[H,W]          depth after the boundary pixels were pushed back (pass 2)
+ *   vertices[2 H W x 3]     doubles: the H W grid vertices (row-major), then the duplicates; *n_vertices of them are valid
+ *   triangles[2 (H-1)(W-1) x 3], *n_triangles
+ *   normals[H W x 3]        (nullable) area-weighted normal of every grid vertex, towards the camera: the per-pixel geometric normal the
+ *                           kernels shade with; zero where the vertex has no triangle (the camera ray sees the environment) */
+int matpbr_depth_to_mesh_host(const float* depth, int H, int W, float fov_x_deg, float min_angle_deg, float* new_depth, double* vertices,
+                              int* n_vertices, int* triangles, int* n_triangles, float* normals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,7 @@ SIGNATURES = {
     "matpbr_brdf_terms": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_sample_brdf": (ctypes.c_int, [_c_f] * 10 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_sh_eval": (ctypes.c_int, [_c_f] * 3 + [ctypes.c_long, ctypes.c_void_p]),
+    "matpbr_depth_to_mesh_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 6),
     "matpbr_normals_from_depth": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),
                                                  ctypes.c_void_p]),
 }

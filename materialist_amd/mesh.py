@@ -1,14 +1,14 @@
 """`<save_name>.ply` of the output layout: the depth heightfield as a triangle mesh in the renderer's frame.
 
 The reference builds it with Python loops over every pixel (`depth_file_to_mesh`, myutils/mesh_recon.py:41-74,86-331; minutes at
-512x512) and shades with its face normals.  The kernels here need only the per-pixel geometric normal (`matpbr_normals_from_depth`);
-the mesh is written for tools that expect the file.  Vectorised restatement of the regular part of the reference's triangulation:
+512x512) and shades with its face normals.  `reference_mesh` is that algorithm, gap closing at depth discontinuities included, as a
+host function of libmatpbr.so (`matpbr_depth_to_mesh_host`: the same sequential passes in C++, milliseconds; vertex for vertex and
+triangle for triangle, tests/golden/mesh_normals.npz); the pipeline writes its mesh and shades with its per-pixel normals.
+`depth_to_mesh` is the regular part of the triangulation alone, vectorised (no gap closing; synthetic scenes have no depth edges):
   * vertex (i, j) = K^-1 [j, i, 1] depth[i, j], rotated 180 degrees about x (inverse_img_w_mi.py:727): ((j-cx)/f d, -(i-cy)/f d, -d);
   * two triangles per 2x2 cell with the reference's vertex order (:190-193,250-254): (i,j),(i+1,j),(i,j+1) and (i,j+1),(i+1,j),(i+1,j+1);
   * cells touching a zero depth (mesh_mask.png, inverse_img_w_mi.py:723) carry no triangle (:187-188).
-NOT restated: the reference's gap closing at depth discontinuities (it overwrites the depth of foreground boundary pixels with the
-farther neighbour's and duplicates vertices, :86-170,196-246); at such edges this mesh keeps the stretched triangles.  Away from
-depth edges the area-weighted vertex normals of the two meshes agree to 0.14 degrees (tests: mesh_normals.npz golden).
+Away from depth edges the area-weighted vertex normals of the two meshes agree to 0.14 degrees.
 """
 from __future__ import annotations
 
@@ -32,6 +32,30 @@ def depth_to_mesh(depth: np.ndarray, fov_x_deg: float = 35.0) -> Tuple[np.ndarra
     # the reference emits the two triangles of a cell together, row by row (:176-254): keep that order
     T = np.stack([np.stack([a, b, c], -1), np.stack([c, b, d], -1)], axis=2).reshape(-1, 3)
     return V, T[valid[T].all(1)].astype(np.int32)
+
+
+def reference_mesh(depth: np.ndarray, fov_x_deg: float = 35.0, min_angle_deg: float = 6.0) -> dict:
+    """The reference's mesh of a depth map (inverse_img_w_mi.py:721-727: `depth_file_to_mesh(depth, K, minAngle=6)` + rotation about x).
+    depth [H,W] = the array handed to the mesher (2 max - prediction, 0 where `mesh_mask.png` removes geometry).  Returns
+    {"vertices" [N,3] float64 (grid vertices first, duplicates after), "triangles" [T,3] int32, "depth" [H,W] float32 after the boundary
+    pixels were pushed back, "normals" [H,W,3] float32 per-pixel geometric normal (zero where a pixel has no triangle), "has_faces" [H,W]}."""
+    import ctypes
+
+    from . import _lib
+
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    H, W = depth.shape
+    new_depth = np.empty_like(depth)
+    V = np.empty((2 * H * W, 3), dtype=np.float64)
+    T = np.empty((2 * (H - 1) * (W - 1), 3), dtype=np.int32)
+    nrm = np.empty((H, W, 3), dtype=np.float32)
+    nv, nt = ctypes.c_int(0), ctypes.c_int(0)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    code = _lib.load().matpbr_depth_to_mesh_host(P(depth), H, W, float(fov_x_deg), float(min_angle_deg), P(new_depth), P(V),
+                                                  ctypes.cast(ctypes.byref(nv), ctypes.c_void_p), P(T), ctypes.cast(ctypes.byref(nt), ctypes.c_void_p), P(nrm))
+    _lib.check(code, "matpbr_depth_to_mesh_host")
+    return {"vertices": V[: nv.value].copy(), "triangles": T[: nt.value].copy(), "depth": new_depth, "normals": nrm,
+            "has_faces": np.abs(nrm).sum(-1) > 0}
 
 
 def write_ply(path: str, vertices: np.ndarray, triangles: np.ndarray) -> None:

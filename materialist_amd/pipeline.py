@@ -310,7 +310,7 @@ def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], 
     if "n" in str(list(opt_order)):
         raise ValueError("inverse_images_batched optimises a / r / m under the geometric normal")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
-    mats, depths, out_dirs = [], [], []
+    mats, depths, normals, out_dirs = [], [], [], []
     for k, (path, name) in enumerate(zip(img_paths, save_names)):
         output_dir = get_output_dir(name, save_path)
         os.makedirs(os.path.join(output_dir, "best_results"), exist_ok=True)
@@ -334,14 +334,19 @@ def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], 
                        "opt_env_from": opt_env_from, "model_name": "none", "timestamp": time.strftime("%Y-%m-%d %H:%M:%S"),
                        "image_size": list(img.shape[:2]), "spp": spp, "output_type": "arm", "use_mesh_normal": True}, f, indent=4)
         depth = 2 * pred["depth"].max() - pred["depth"]
+        rm = _mesh.reference_mesh(np.array(depth, dtype=np.float32), render.DEFAULT_FOV)
+        if not bool(rm["has_faces"].all()):
+            raise ValueError(f"{output_dir}: pixels without geometry; run it through inverse_image")
         mesh_path = os.path.join(output_dir, f"{name}.ply")
         if not os.path.exists(mesh_path):
-            _mesh.write_ply(mesh_path, *_mesh.depth_to_mesh(np.array(depth, dtype=np.float64), render.DEFAULT_FOV))
+            _mesh.write_ply(mesh_path, rm["vertices"], rm["triangles"])
+        normals.append(t(rm["normals"]))
         depths.append(t(depth))
         out_dirs.append(output_dir)
     B = len(mats)
     mat = {k: torch.stack([m[k] for m in mats]) for k in mats[0]}
     scene = render.load_estimated_mesh(torch.stack(depths), use_mesh_normal=True, device=device)
+    scene.geo_normal = torch.stack(normals).contiguous()                   # the reference mesher's per-pixel normals (gap closing included)
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
                                         num_epochs=num_epochs, log=log, model_name="none")
     nrm = scene.geo_normal
@@ -439,11 +444,12 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
     if not os.path.exists(mesh_path):
         from . import mesh as _mesh
 
-        d_mesh = np.array(depth, dtype=np.float64)
+        d_mesh = np.array(depth, dtype=np.float32)
         if mesh_mask is not None:
             d_mesh[mesh_mask.numpy()] = 0.0                                                      # :723
-        _mesh.write_ply(mesh_path, *_mesh.depth_to_mesh(d_mesh, render.DEFAULT_FOV))
-    scene = render.load_estimated_mesh(t(depth), use_mesh_normal=use_mesh_normal, device=device, mesh_mask=mesh_mask)
+        rm = _mesh.reference_mesh(d_mesh, render.DEFAULT_FOV)                                    # :726-727, minAngle 6, gap closing included
+        _mesh.write_ply(mesh_path, rm["vertices"], rm["triangles"])
+    scene = render.load_estimated_mesh(t(depth), use_mesh_normal=use_mesh_normal, device=device, mesh_mask=mesh_mask, geometry="mesh")
     frames = FrameWriter(output_dir, min_interval=frame_interval)
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
                                         num_epochs=num_epochs, sync_every=sync_every, log=log, frames=frames,

@@ -194,7 +194,8 @@ def traverse(scene: Scene) -> SceneParameters:
 
 
 def load_estimated_mesh(depth: Optional[torch.Tensor], use_mesh_normal: bool, max_path: int = 4, height: int = 512, width: int = 512,
-                        device="cuda", fov_x_deg: float = DEFAULT_FOV, batch: int = 1, mesh_mask: Optional[torch.Tensor] = None) -> Scene:
+                        device="cuda", fov_x_deg: float = DEFAULT_FOV, batch: int = 1, mesh_mask: Optional[torch.Tensor] = None,
+                        geometry: str = "depth") -> Scene:
     """Counterpart of load_estimated_mesh(mesh_path, use_mesh_normal, max_path) (inverse_img_w_mi.py:30-56).
     The reference loads a .ply triangulated from depth; the per-pixel build needs only the geometric normal
     of the heightfield, computed on the GPU from `depth` [H,W] (or [B,H,W]).  `max_path` is accepted for
@@ -205,7 +206,25 @@ def load_estimated_mesh(depth: Optional[torch.Tensor], use_mesh_normal: bool, ma
         depth = depth.to(device, torch.float32)
         height, width = depth.shape[-2], depth.shape[-1]
         batch = depth.shape[0] if depth.ndim == 3 else 1
-        geo = ops.normals_from_depth(depth.contiguous(), fov_x_deg)
+        if geometry == "mesh":
+            # the reference's own mesh of this depth map (gap closing at depth edges included): per-pixel normal = area-weighted normal of
+            # the pixel's grid vertex; a pixel whose vertex carries no triangle has no geometry (its camera ray sees the environment)
+            if batch != 1:
+                raise NotImplementedError("geometry='mesh' takes one depth map")
+            from . import mesh as _mesh
+
+            d_host = depth.detach().cpu().numpy().astype(np.float32).copy()
+            if mesh_mask is not None:
+                d_host[mesh_mask.cpu().numpy().astype(bool)] = 0.0                              # inverse_img_w_mi.py:723
+            rm = _mesh.reference_mesh(d_host, fov_x_deg)
+            geo = torch.from_numpy(rm["normals"]).to(device)
+            holes = torch.from_numpy(~rm["has_faces"])
+            mesh_mask = holes if mesh_mask is None else (mesh_mask.cpu().bool() | holes)
+            geo[holes.to(device)] = torch.tensor([0.0, 0.0, 1.0], device=device)               # any unit vector: these pixels are never shaded
+        elif geometry == "depth":
+            geo = ops.normals_from_depth(depth.contiguous(), fov_x_deg)
+        else:
+            raise ValueError("geometry: 'depth' (central differences of the depth map, on the GPU) or 'mesh' (the reference's mesher, on the host)")
     scene = Scene(height, width, device, geo, use_mesh_normal, fov_x_deg, batch)
     if mesh_mask is not None:
         scene.set_mesh_mask(mesh_mask)

@@ -109,7 +109,8 @@ def main():
     nrm = np.where(ln > 0, sign * acc / np.maximum(ln, 1e-30), 0.0)
     np.savez_compressed(os.path.join(HERE, "mesh_normals.npz"), depth_pred=pred, depth_mesh_input=depth, fov_x_deg=fov,
                         n_vertices=V.shape[0], n_triangles=T.shape[0], grid_positions=P.astype(np.float32),
-                        vertex_normal_area_weighted=nrm.astype(np.float32), has_faces=(ln[..., 0] > 0))
+                        vertex_normal_area_weighted=nrm.astype(np.float32), has_faces=(ln[..., 0] > 0),
+                        vertices=V.astype(np.float64), triangles=T.astype(np.int32))
     print("vertices", V.shape[0], "(grid", H * W, ") triangles", T.shape[0], "of", 2 * (H - 1) * (W - 1), "pixels with faces", int((ln > 0).sum()))
 
 

@@ -187,6 +187,33 @@ def test_geometric_normal_against_the_reference_mesh(golden_dir, oracle64):
     print(f"depth-edge pixels {moved.sum()} of {H * W}: median angular difference {np.median(ang[moved]):.1f} deg")
 
 
+def test_reference_mesher_is_reproduced_vertex_for_vertex_and_triangle_for_triangle(golden_dir):
+    """a9, gap closing included: `mesh.reference_mesh` (the host function `matpbr_depth_to_mesh_host` of libmatpbr.so: the three sequential
+    passes of myutils/mesh_recon.py:86-331 in C++) against the mesh the reference's own `depth_file_to_mesh(minAngle=6)` +
+    `rotate_mesh_around_x` produced for a depth map with a raised foreground block (depth edges on four sides): the same triangles in the
+    same order, the same vertices (grid + duplicates), and the per-pixel geometric normal on EVERY pixel."""
+    from materialist_amd import mesh
+
+    g = np.load(os.path.join(golden_dir, "mesh_normals.npz"))
+    H, W = g["depth_mesh_input"].shape
+    m = mesh.reference_mesh(g["depth_mesh_input"], float(g["fov_x_deg"]), 6.0)
+    assert m["vertices"].shape[0] == int(g["n_vertices"]) > H * W                      # duplicates were made
+    assert np.array_equal(m["triangles"], g["triangles"])
+    np.testing.assert_allclose(m["vertices"], g["vertices"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m["vertices"][: H * W].reshape(H, W, 3), g["grid_positions"], rtol=0, atol=2e-7)
+    moved = np.abs(g["depth_mesh_input"] - m["depth"]) > 0
+    assert 0.01 < moved.mean() < 0.08                                                 # the boundary pixels that were pushed back
+    assert np.array_equal(m["has_faces"], g["has_faces"])
+    ref = g["vertex_normal_area_weighted"].astype(np.float64)
+    ang = np.degrees(np.arccos(np.clip((m["normals"].astype(np.float64) * ref).sum(-1), -1, 1)))
+    assert ang.max() < 0.05, ang.max()                                                # float32 storage of both
+    # a pixel without depth carries no triangle, and neither does a cell that touches it (:187-188)
+    d = g["depth_mesh_input"].copy()
+    d[5:9, 30:34] = 0.0
+    h = mesh.reference_mesh(d, float(g["fov_x_deg"]), 6.0)
+    assert not h["has_faces"][6:8, 31:33].any() and h["has_faces"][20, 5] and h["triangles"].shape[0] < m["triangles"].shape[0]
+
+
 def test_ply_round_trip(tmp_path):
     from materialist_amd import mesh
 
