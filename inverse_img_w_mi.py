@@ -24,6 +24,9 @@ def parse_args(argv=None):
     ap.add_argument("--num_epochs", type=int, default=5000)
     ap.add_argument("--pred_dir", type=str, default=None, help="directory with *Pred.exr/png initial maps (MaterialNet output layout)")
     ap.add_argument("--matnet_weights", type=str, default=None, help="matnet_weights.pth (Lez/MatNet on the HF hub) for the MaterialNet initial guess")
+    ap.add_argument("--geometry", type=str, default="mesh", choices=["mesh", "depth"],
+                    help="per-pixel geometric normals: from the reference's mesh of the depth map, gap closing at depth edges included (mesh_recon.py, "
+                         "default), or central differences of the depth map itself")
     return ap.parse_args(argv)
 
 
@@ -33,7 +36,7 @@ def main(argv=None):
 
     res = inverse_image(args.img_inverse_path, args.save_name, args.opt_src, args.opt_order, args.use_mask, args.opt_env_from,
                         args.save_path, args.model_name, size=args.size, spp=args.spp, num_epochs=args.num_epochs, pred_dir=args.pred_dir,
-                        matnet_weights=args.matnet_weights)
+                        matnet_weights=args.matnet_weights, geometry=args.geometry)
     print(f"done: PSNR {res['psnr']:.2f} dB, best loss_mse {res['best_loss']:.6f}, outputs in {res['output_dir']}")
 
 
