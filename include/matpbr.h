@@ -333,6 +333,21 @@ int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, co
 int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
                                  const float* w_out, int ldw_out, const float* bias_out, const float* start, int lds, float* th,
                                  float* map_a, float* map_r, float* map_m, long M, int K, int nprod, void* stream);
+/* ONE float per sine activation.  sin and cos of a pre-activation lie on the unit circle: the forward pass can store the sine with the SIGN of
+ * the cosine in its last mantissa bit (the stored value moves by at most one ulp) and no cosines at all (a third of a 256-wide layer's
+ * traffic); the backward pass rebuilds cos = sign * sqrt(1 - sin^2) where it multiplies by it.  The products stay f32-accurate; the cosine
+ * factor of the backward pass carries |error| ~ 1.2e-7 / |cos| (rms relative error of a layer ~ 1e-5).
+ *   matpbr_mlp_layer_fwd_bx / _bx_tail / _bx_head with c_out == NULL   write such sines
+ *   matpbr_mlp_layer_fwd_sgn          the same for the thin first layer (K <= 16, image size), as matpbr_mlp_layer_fwd_tail
+ *   matpbr_mlp_layer_bwd_input_bx_sgn / matpbr_mlp_layer_bwd_input_sgn   as matpbr_mlp_layer_bwd_input_bx / _bwd_input (n_red <= 16, image size) with
+ *                                     `s_prev` = those sines of the layer below in place of its cosines */
+int matpbr_mlp_layer_fwd_sgn(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, int ldo, const float* tail, int ldt,
+                             long M, int N, int K, void* stream);
+int matpbr_mlp_layer_bwd_input_sgn(const float* g, int ldg, const float* wt, int ldwt, const float* s_prev, float* g_prev, int ldo,
+                                   float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream);
+int matpbr_mlp_layer_bwd_input_bx_sgn(const float* g, int ldg, const void* wtsplit, const float* s_prev, float* g_prev, int ldo,
+                                      float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
+                                      int nprod, void* stream);
 int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
                                    size_t workspace_bytes, long M, int N, int K, int nprod, void* stream);
 

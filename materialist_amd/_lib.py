@@ -90,6 +90,12 @@ SIGNATURES = {
     "matpbr_mlp_bwd_weight_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long]),
     "matpbr_mlp_layer_bwd_weight": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_fwd_sgn": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_long,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_bwd_input_sgn": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_void_p,
+                                                     ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_bwd_input_bx_sgn": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_void_p, ctypes.c_size_t,
+                                                        ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_layer_bwd_weight_bx": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                      ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_split_weights_t": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),

@@ -64,6 +64,8 @@ def flat_state(net: torch.nn.Module, dev) -> dict:
 class ArmMlpPhase:
     """Same interface as `loop.PosMlpBrdfPhase` (step, step_and_check, stats, best, best_img, best_weights, pred, opt.param_groups)."""
 
+    PACKED = True     # one float per sine activation (class switch: the tests run both)
+
     @staticmethod
     def supported(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> bool:
         if mask is not None or gt_image.ndim != 3 or not gt_image.is_cuda or not scene.use_mesh_normal or "n" in optimize_part:
@@ -130,7 +132,10 @@ class ArmMlpPhase:
         for l, n in enumerate(self.ns):
             if n != 256:
                 self.bufs[l][:, n:] = x0                        # cat(x, x0) of the skip layers: x0 is constant, written once
-        self.cbufs = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(self.L - 1)]
+        # PACKED: the sines carry the sign of their cosine in the last mantissa bit and the backward pass rebuilds cos = +-sqrt(1 - sin^2)
+        # (include/matpbr.h `matpbr_mlp_layer_fwd_sgn`): no cosine matrices, a third less traffic per forward layer
+        self.packed = bool(self.PACKED)
+        self.cbufs = [None if self.packed else torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(self.L - 1)]
         self.gbufs = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(2)]
         self.th, self.d_x = E(M, 8), E(M, 8)
         self.w_out_t = E(256, 8)                                 # the output weight transposed (operand of the input-gradient kernel)
@@ -194,7 +199,10 @@ class ArmMlpPhase:
         # skip layers on the split-operand kernel: whole 16-byte stores over the x0 tail, rewritten by a small launch (-20 us per layer
         # against guarding the straddling word of every row in the epilogue); the first layer's kernel keeps its guard (no gain there)
         tail = lambda l: self.x0p if self.ns[l] != 256 else None
-        o.mlp_layer_fwd(self.x0p, wp, bp, self.bufs[0], self.cbufs[0], self.d0)
+        if self.packed:
+            o.mlp_layer_fwd(self.x0p, wp, bp, self.bufs[0], None, self.d0, packed=True)
+        else:
+            o.mlp_layer_fwd(self.x0p, wp, bp, self.bufs[0], self.cbufs[0], self.d0)
         live = self.live
         maps = [self.maps[k] if k in live else None for k in ("albedo", "roughness", "metallic")]
         wo, bo = self.views[-1]
@@ -220,7 +228,7 @@ class ArmMlpPhase:
         self.w_out_t[:, :5].copy_(wp.t())
         g_prev = self.gbufs[0]
         _, gb = self.gviews[self.L - 2]
-        o.mlp_layer_bwd_input(self.d_x, self.w_out_t, self.cbufs[-1], g_prev, self.ns[-1], 5, gb)
+        o.mlp_layer_bwd_input(self.d_x, self.w_out_t, self.bufs[-1] if self.packed else self.cbufs[-1], g_prev, self.ns[-1], 5, gb, packed=self.packed)
         g, n_red = g_prev, self.ns[-1]
         for l in range(self.L - 2, 0, -1):                       # g = dL/d pre of layer l: its weight gradient, then dL/d pre of layer l-1
             wp, _ = self.views[l]
@@ -229,7 +237,8 @@ class ArmMlpPhase:
             n_prev = self.ns[l - 1]
             g_prev = self.gbufs[0] if g is self.gbufs[1] else self.gbufs[1]
             _, gb = self.gviews[l - 1]
-            o.mlp_layer_bwd_input_bx(g, self.wsplit_b[l], self.cbufs[l - 1], g_prev, n_prev, n_red, gb, P)
+            o.mlp_layer_bwd_input_bx(g, self.wsplit_b[l], self.bufs[l - 1] if self.packed else self.cbufs[l - 1], g_prev, n_prev, n_red, gb, P,
+                                     packed=self.packed)
             g, n_red = g_prev, n_prev
         gw, _ = self.gviews[0]
         o.mlp_skinny_bwd_weight(self.x0p, g, gw, self.d0, n_red, transposed_out=True)

@@ -163,7 +163,26 @@ struct NtArgs {
   int N, K, lda, ldb, ldo;
   const float* tail;   // nullable [M, ldt]: the values that belong in columns N.. of out0 (x0 of a skip layer).  Given: the epilogue
   int ldt;             // stores whole 16-byte words over them and the caller rewrites them (mlp_tail_copy_kernel); null: they are guarded
+  int cmul_sin;        // EPI_MULC: `cmul` holds the SINES of the layer below with the sign of their cosine in the last mantissa bit
 };
+
+// One float per sine activation instead of two.  The backward pass needs cos(pre) of every hidden unit; sin and cos lie on the unit circle,
+// so |cos| = sqrt(1 - sin^2) and only its sign is missing: the forward epilogue writes it into the LAST MANTISSA BIT of the sine it
+// stores (the stored sine moves by at most one ulp, the size of the rounding it already carries) and stops writing the cosines
+// (268 MB per 256-wide layer at 512 x 512, a third of the layer's traffic).  The backward epilogue rebuilds the cosine from the stored
+// sine.  Cost: where |cos| is small the square root amplifies the sine's rounding, |error| ~ 1.2e-7 / |cos| (1e-5 at |cos| = 0.01, 1.3 %
+// of the units; rms relative error of a layer's cosines ~ 1e-5): the PRODUCTS stay f32-accurate, the cos factor of the backward pass is
+// good to five digits (tests/test_gpu_parity.py::test_sines_that_carry_the_sign_of_their_cosine).
+__device__ __forceinline__ float pack_cos_sign(float s, float c) {
+  return __uint_as_float((__float_as_uint(s) & ~1u) | (__float_as_uint(c) >> 31));
+}
+__device__ __forceinline__ float cos_from_packed_sin(float sp) {
+  const float c = __builtin_amdgcn_sqrtf(__builtin_fmaxf(__builtin_fmaf(-sp, sp, 1.0f), 0.0f));
+  return __uint_as_float(__float_as_uint(c) | (__float_as_uint(sp) << 31));
+}
+__device__ __forceinline__ float4 cos_from_packed_sin(float4 v) {
+  return make_float4(cos_from_packed_sin(v.x), cos_from_packed_sin(v.y), cos_from_packed_sin(v.z), cos_from_packed_sin(v.w));
+}
 
 // LDS image of a k-tile: [row][k] with a pitch of 36 floats: 16-byte writes and 16-byte reads are both conflict-free (8 lanes x
 // 4 banks cover the 32 banks; SQ_LDS_BANK_CONFLICT = 0).  Lane half h of an MFMA takes k = 16 h + step inside the tile (A and
@@ -1324,6 +1343,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
           float v = acc[ni][r];
           if (EPI == EPI_SINCOS) {
             sincos_cw(v + bn[ni], v, second[r]);
+            if (p.out1 == nullptr) v = pack_cos_sign(v, second[r]);      // uniform: the sines carry the sign of their cosine
           } else if (EPI == EPI_BIAS) {
             v += bn[ni];
           }
@@ -1333,6 +1353,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
         for (int ps = 0; ps < 4; ++ps) {
           float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
           if (EPI == EPI_MULC) {
+            if (p.cmul_sin) cv[n2][ps] = cos_from_packed_sin(cv[n2][ps]);
             v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
             csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
           }
@@ -1345,7 +1366,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
           }
           store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);
         }
-        if (EPI == EPI_SINCOS) {
+        if (EPI == EPI_SINCOS && p.out1 != nullptr) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
 #pragma unroll
@@ -1698,8 +1719,10 @@ __global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int til
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[r];
-        if (EPI == EPI_SINCOS) sincos_cw(v + bn[ni], v, second[r]);
-        else if (EPI == EPI_BIAS) v += bn[ni];
+        if (EPI == EPI_SINCOS) {
+          sincos_cw(v + bn[ni], v, second[r]);
+          if (p.out1 == nullptr) v = pack_cos_sign(v, second[r]);
+        } else if (EPI == EPI_BIAS) v += bn[ni];
         scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
       }
       const bool all_cols = ni * 32 + 32 <= p.N || p.tail != nullptr;    // uniform; with a tail the caller rewrites columns N..
@@ -1707,13 +1730,14 @@ __global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int til
       for (int ps = 0; ps < 4; ++ps) {
         float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
         if (EPI == EPI_MULC) {
+          if (p.cmul_sin) cv[ps] = cos_from_packed_sin(cv[ps]);
           v.x *= cv[ps].x; v.y *= cv[ps].y; v.z *= cv[ps].z; v.w *= cv[ps].w;
           csum[ni].x += v.x; csum[ni].y += v.y; csum[ni].z += v.z; csum[ni].w += v.w;
         }
         if (full_rows || row0 + t_row + 8 * ps < p.M)
           store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (ni * 32 + t_col), all_cols);
       }
-      if (EPI == EPI_SINCOS) {
+      if (EPI == EPI_SINCOS && p.out1 != nullptr) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
 #pragma unroll
@@ -1987,6 +2011,23 @@ int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, 
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
+int matpbr_mlp_layer_fwd_sgn(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, int ldo, const float* tail, int ldt,
+                             long M, int N, int K, void* stream) {
+  if (!x || !w || !bias || !s_out || M <= 0 || M > 0x7fffff00L || N <= 0 || N > 256 || K <= 0 || K > 16) return MATPBR_ERR_INVALID_ARG;
+  // the thin-K kernel only (the first layer of the coordinate MLP at image size): every other shape keeps its cosines
+  if (M <= kSmallM || (ldx & 3) || (ldw & 3) || ldx < (K <= 8 ? 8 : 16) || ldw < (K <= 8 ? 8 : 16) || ldo < 256 || (ldo & 3) || !aligned16(x) || !aligned16(w) ||
+      !aligned16(s_out))
+    return MATPBR_ERR_UNSUPPORTED;
+  if (tail && ldt < 256 - N) return MATPBR_ERR_INVALID_ARG;
+  NtArgs p{x, w, bias, nullptr, s_out, nullptr, nullptr, (int)M, N, K, ldx, ldw, ldo};
+  p.tail = tail; p.ldt = ldt;
+  launch_thin_k<EPI_SINCOS>(p, (hipStream_t)stream);
+  if (tail && N < 256)
+    hipLaunchKernelGGL(mlp_tail_copy_kernel, dim3((unsigned)((M * (256 - N) + 255) / 256 < 2048 ? (M * (256 - N) + 255) / 256 : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, s_out, ldo, tail, ldt, M, N);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
 int matpbr_mlp_layer_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo, long M,
                          int N, int K, void* stream) {
   return matpbr_mlp_layer_fwd_tail(x, ldx, w, ldw, bias, s_out, c_out, ldo, nullptr, 0, M, N, K, stream);
@@ -1997,15 +2038,17 @@ size_t matpbr_mlp_bwd_input_workspace_bytes(long M) {
   return (size_t)((kPersistent + 16) > kThinBlocks ? (kPersistent + 16) : kThinBlocks) * 256 * sizeof(float);
 }
 
-int matpbr_mlp_layer_bwd_input(const float* g, int ldg, const float* wt, int ldwt, const float* c_prev, float* g_prev, int ldo,
-                               float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
+static int mlp_layer_bwd_input_impl(const float* g, int ldg, const float* wt, int ldwt, const float* c_prev, float* g_prev, int ldo,
+                                    float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int sgn, void* stream) {
   if (!g || !wt || !c_prev || !g_prev || M <= 0 || M > 0x7fffff00L || n_prev <= 0 || n_prev > 256 || n_red <= 0 || n_red > 256)
     return MATPBR_ERR_INVALID_ARG;
   if ((ldg & 3) || (ldwt & 3) || ldg < ((n_red + 3) & ~3) || ldwt < ((n_red + 3) & ~3) || ldo < n_prev || !aligned16(g) || !aligned16(wt))
     return MATPBR_ERR_INVALID_ARG;
   if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
   NtArgs p{g, wt, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, 0, n_prev, n_red, ldg, ldwt, ldo};
+  p.cmul_sin = sgn;
   const bool thin = M > kSmallM && n_red <= 16 && ldg >= (n_red <= 8 ? 8 : 16) && ldo >= 256 && !(ldo & 3) && aligned16(c_prev) && aligned16(g_prev);
+  if (sgn && !thin) return MATPBR_ERR_UNSUPPORTED;
   int groups;
   if (thin) {
     p.M = (int)M;
@@ -2016,6 +2059,15 @@ int matpbr_mlp_layer_bwd_input(const float* g, int ldg, const float* wt, int ldw
   if (d_bias_prev)
     hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_bwd_input(const float* g, int ldg, const float* wt, int ldwt, const float* c_prev, float* g_prev, int ldo,
+                               float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
+  return mlp_layer_bwd_input_impl(g, ldg, wt, ldwt, c_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, 0, stream);
+}
+int matpbr_mlp_layer_bwd_input_sgn(const float* g, int ldg, const float* wt, int ldwt, const float* s_prev, float* g_prev, int ldo,
+                                   float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
+  return mlp_layer_bwd_input_impl(g, ldg, wt, ldwt, s_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, 1, stream);
 }
 
 int matpbr_mlp_layer_bwd_input_w(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo,
@@ -2064,9 +2116,10 @@ int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wspl
 
 int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
                                  const float* tail, int ldt, long M, int N, int K, int nprod, void* stream) {
-  if (!x || !wsplit || !bias || !s_out || !c_out || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
+  // c_out == NULL: the sines carry the sign of their cosine in their last mantissa bit and no cosines are written (matpbr_mlp_layer_fwd_bx_sgn)
+  if (!x || !wsplit || !bias || !s_out || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
   if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
-      !aligned16(s_out) || !aligned16(c_out))
+      !aligned16(s_out) || (c_out && !aligned16(c_out)))
     return MATPBR_ERR_UNSUPPORTED;
   if (tail && ldt < 256 - N) return MATPBR_ERR_INVALID_ARG;
   NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, N, K, ldx, 0, ldo};
@@ -2081,10 +2134,10 @@ int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, co
 int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
                                  const float* w_out, int ldw_out, const float* bias_out, const float* start, int lds, float* th, float* map_a,
                                  float* map_r, float* map_m, long M, int K, int nprod, void* stream) {
-  if (!x || !wsplit || !bias || !s_out || !c_out || !w_out || !bias_out || !start || !th || M <= 0 || K <= 0 || K > 256 || lds < 5 || ldw_out < 256)
+  if (!x || !wsplit || !bias || !s_out || !w_out || !bias_out || !start || !th || M <= 0 || K <= 0 || K > 256 || lds < 5 || ldw_out < 256)
     return MATPBR_ERR_INVALID_ARG;
   if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
-      !aligned16(s_out) || !aligned16(c_out))
+      !aligned16(s_out) || (c_out && !aligned16(c_out)))
     return MATPBR_ERR_UNSUPPORTED;
   NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, 256, K, ldx, 0, ldo};
   const HeadArgs hd{w_out, ldw_out, bias_out, ArmHead{start, lds, th, map_a, map_r, map_m}};
@@ -2100,19 +2153,29 @@ int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const f
   return matpbr_mlp_layer_fwd_bx_tail(x, ldx, wsplit, bias, s_out, c_out, ldo, nullptr, 0, M, N, K, nprod, stream);
 }
 
-int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,
-                                  void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, void* stream) {
+static int mlp_layer_bwd_input_bx_impl(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,
+                                       void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, int sgn, void* stream) {
   if (!g || !wtsplit || !c_prev || !g_prev || M <= 0 || n_prev <= 0 || n_prev > 256 || n_red <= 0 || n_red > 256) return MATPBR_ERR_INVALID_ARG;
   if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || !aligned16(g) ||
       !aligned16(g_prev) || !aligned16(c_prev))
     return MATPBR_ERR_UNSUPPORTED;
   if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
   NtArgs p{g, nullptr, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, (int)M, n_prev, n_red, ldg, 0, ldo};
+  p.cmul_sin = sgn;
   const int groups = launch_nt_bx<EPI_MULC>(p, (const uint4*)wtsplit, nprod, (hipStream_t)stream);
   if (groups < 0) return MATPBR_ERR_LAUNCH;
   if (d_bias_prev)
     hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,
+                                  void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, void* stream) {
+  return mlp_layer_bwd_input_bx_impl(g, ldg, wtsplit, c_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, nprod, 0, stream);
+}
+int matpbr_mlp_layer_bwd_input_bx_sgn(const float* g, int ldg, const void* wtsplit, const float* s_prev, float* g_prev, int ldo, float* d_bias_prev,
+                                      void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, void* stream) {
+  return mlp_layer_bwd_input_bx_impl(g, ldg, wtsplit, s_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, nprod, 1, stream);
 }
 
 static int wgrad_slabs(long M) {

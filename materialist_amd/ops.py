@@ -579,12 +579,19 @@ def _mlp_workspace(kind: str, M: int, device, nbytes: int) -> torch.Tensor:
 
 
 def mlp_layer_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: Optional[torch.Tensor], K: int,
-                  tail: Optional[torch.Tensor] = None) -> None:
+                  tail: Optional[torch.Tensor] = None, packed: bool = False) -> None:
     """s_out[:, :N] = sin(x[:, :K] w[:, :K]^T + bias), c_out[:, :N] = cos(same) (c_out None: no activation).  x [M, >=K], w [N, >=K];
-    s_out / c_out are [M, >=N] with the same row stride.  One MFMA kernel (posmlp_kernels.hip)."""
+    s_out / c_out are [M, >=N] with the same row stride.  One MFMA kernel (posmlp_kernels.hip).  packed: sines that carry the sign of
+    their cosine in the last mantissa bit, no cosines (include/matpbr.h `matpbr_mlp_layer_fwd_sgn`; thin first layer at image size)."""
     lib = _lib.load()
     x, w, s_out = _mat2(x, "x"), _mat2(w, "w"), _mat2(s_out, "s_out")
     M, N = x.shape[0], w.shape[0]
+    if packed:
+        with torch.cuda.device(x.device):
+            code = lib.matpbr_mlp_layer_fwd_sgn(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(bias.contiguous()), _ptr(s_out), s_out.stride(0),
+                                                _ptr(tail) if tail is not None else None, tail.stride(0) if tail is not None else 0, M, N, K, _stream(x))
+        _lib.check(code, "matpbr_mlp_layer_fwd_sgn")
+        return
     if c_out is not None and (c_out.stride(0) != s_out.stride(0) or not c_out.is_cuda):
         raise ValueError("c_out must share s_out's row stride")
     with torch.cuda.device(x.device):                          # tail: x0 of a skip layer, stored into columns N.. with the outputs
@@ -595,8 +602,9 @@ def mlp_layer_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, s_out: t
 
 
 def mlp_layer_bwd_input(g: torch.Tensor, wt: torch.Tensor, c_prev: torch.Tensor, g_prev: torch.Tensor, n_prev: int, n_red: int,
-                        d_bias_prev: Optional[torch.Tensor]) -> None:
-    """g_prev[:, :n_prev] = (g[:, :n_red] wt[:n_prev, :n_red]^T) * c_prev[:, :n_prev]; d_bias_prev = column sums of g_prev."""
+                        d_bias_prev: Optional[torch.Tensor], packed: bool = False) -> None:
+    """g_prev[:, :n_prev] = (g[:, :n_red] wt[:n_prev, :n_red]^T) * c_prev[:, :n_prev]; d_bias_prev = column sums of g_prev.
+    packed: `c_prev` holds the sign-carrying SINES of the layer below (the cosine is rebuilt in the epilogue)."""
     lib = _lib.load()
     g, wt = _mat2(g, "g"), _mat2(wt, "wt")
     M = g.shape[0]
@@ -604,7 +612,7 @@ def mlp_layer_bwd_input(g: torch.Tensor, wt: torch.Tensor, c_prev: torch.Tensor,
         raise ValueError("c_prev and g_prev must share their row stride")
     ws = _mlp_workspace("bwd_input", M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
     with torch.cuda.device(g.device):
-        code = lib.matpbr_mlp_layer_bwd_input(_ptr(g), g.stride(0), _ptr(wt), wt.stride(0), _ptr(c_prev), _ptr(g_prev), g_prev.stride(0),
+        code = (lib.matpbr_mlp_layer_bwd_input_sgn if packed else lib.matpbr_mlp_layer_bwd_input)(_ptr(g), g.stride(0), _ptr(wt), wt.stride(0), _ptr(c_prev), _ptr(g_prev), g_prev.stride(0),
                                               _ptr(d_bias_prev) if d_bias_prev is not None else None, _ptr(ws), ws.numel() * 4, M, n_prev,
                                               n_red, _stream(g))
     _lib.check(code, "matpbr_mlp_layer_bwd_input")
@@ -626,37 +634,40 @@ def mlp_split_weights(w: torch.Tensor, N: int, K: int, out: Optional[torch.Tenso
     return out
 
 
-def mlp_layer_fwd_bx(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: torch.Tensor, N: int, K: int,
+def mlp_layer_fwd_bx(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: Optional[torch.Tensor], N: int, K: int,
                      nprod: int = 6, tail: Optional[torch.Tensor] = None) -> None:
-    """mlp_layer_fwd on the bf16 matrix pipe with split operands (nprod 6 or 9 partial products per f32 product)."""
+    """mlp_layer_fwd on the bf16 matrix pipe with split operands (nprod 6 or 9 partial products per f32 product).  c_out None: the sines
+    carry the sign of their cosine in the last mantissa bit and no cosines are written."""
     lib = _lib.load()
-    x, s_out, c_out = _mat2(x, "x"), _mat2(s_out, "s_out"), _mat2(c_out, "c_out")
-    if c_out.stride(0) != s_out.stride(0):
+    x, s_out = _mat2(x, "x"), _mat2(s_out, "s_out")
+    if c_out is not None and _mat2(c_out, "c_out").stride(0) != s_out.stride(0):
         raise ValueError("c_out must share s_out's row stride")
     with torch.cuda.device(x.device):
-        code = lib.matpbr_mlp_layer_fwd_bx_tail(_ptr(x), x.stride(0), _ptr(wsplit), _ptr(bias.contiguous()), _ptr(s_out), _ptr(c_out), s_out.stride(0),
+        code = lib.matpbr_mlp_layer_fwd_bx_tail(_ptr(x), x.stride(0), _ptr(wsplit), _ptr(bias.contiguous()), _ptr(s_out),
+                                                _ptr(c_out) if c_out is not None else None, s_out.stride(0),
                                                 _ptr(tail) if tail is not None else None, tail.stride(0) if tail is not None else 0,
                                                 x.shape[0], N, K, int(nprod), _stream(x))
     _lib.check(code, "matpbr_mlp_layer_fwd_bx")
 
 
-def mlp_layer_fwd_bx_head(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: torch.Tensor, K: int, nprod: int,
+def mlp_layer_fwd_bx_head(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: Optional[torch.Tensor], K: int, nprod: int,
                           w_out: torch.Tensor, bias_out: torch.Tensor, start: torch.Tensor, th: torch.Tensor, map_a: Optional[torch.Tensor],
                           map_r: Optional[torch.Tensor], map_m: Optional[torch.Tensor]) -> None:
     """mlp_layer_fwd_bx of the last sine layer (256 outputs) whose epilogue also forms the output layer and the 'arm' head for the
     rows it holds (= mlp_arm_head_fwd on s_out without reading s_out back)."""
     lib = _lib.load()
-    x, s_out, c_out, w_out = _mat2(x, "x"), _mat2(s_out, "s_out"), _mat2(c_out, "c_out"), _mat2(w_out, "w_out")
+    x, s_out, w_out = _mat2(x, "x"), _mat2(s_out, "s_out"), _mat2(w_out, "w_out")
     P = lambda t: _ptr(t) if t is not None else None
     with torch.cuda.device(x.device):
-        code = lib.matpbr_mlp_layer_fwd_bx_head(_ptr(x), x.stride(0), _ptr(wsplit), _ptr(bias.contiguous()), _ptr(s_out), _ptr(c_out), s_out.stride(0),
+        code = lib.matpbr_mlp_layer_fwd_bx_head(_ptr(x), x.stride(0), _ptr(wsplit), _ptr(bias.contiguous()), _ptr(s_out), P(c_out), s_out.stride(0),
                                                 _ptr(w_out), w_out.stride(0), _ptr(bias_out), _ptr(start), start.stride(0), _ptr(th), P(map_a),
                                                 P(map_r), P(map_m), x.shape[0], K, int(nprod), _stream(x))
     _lib.check(code, "matpbr_mlp_layer_fwd_bx_head")
 
 
 def mlp_layer_bwd_input_bx(g: torch.Tensor, wtsplit: torch.Tensor, c_prev: torch.Tensor, g_prev: torch.Tensor, n_prev: int, n_red: int,
-                           d_bias_prev: Optional[torch.Tensor], nprod: int = 6) -> None:
+                           d_bias_prev: Optional[torch.Tensor], nprod: int = 6, packed: bool = False) -> None:
+    """packed: `c_prev` holds the sign-carrying sines of the layer below."""
     lib = _lib.load()
     g = _mat2(g, "g")
     M = g.shape[0]
@@ -664,7 +675,7 @@ def mlp_layer_bwd_input_bx(g: torch.Tensor, wtsplit: torch.Tensor, c_prev: torch
         raise ValueError("c_prev and g_prev must share their row stride")
     ws = _mlp_workspace("bwd_input", M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
     with torch.cuda.device(g.device):
-        code = lib.matpbr_mlp_layer_bwd_input_bx(_ptr(g), g.stride(0), _ptr(wtsplit), _ptr(c_prev), _ptr(g_prev), g_prev.stride(0),
+        code = (lib.matpbr_mlp_layer_bwd_input_bx_sgn if packed else lib.matpbr_mlp_layer_bwd_input_bx)(_ptr(g), g.stride(0), _ptr(wtsplit), _ptr(c_prev), _ptr(g_prev), g_prev.stride(0),
                                                  _ptr(d_bias_prev) if d_bias_prev is not None else None, _ptr(ws), ws.numel() * 4, M, n_prev, n_red,
                                                  int(nprod), _stream(g))
     _lib.check(code, "matpbr_mlp_layer_bwd_input_bx")

@@ -1590,3 +1590,71 @@ def test_env_mlp_phase_matches_the_autograd_composition():
     sd = {k: v.clone() for k, v in net_b.state_dict().items()}
     net_b.load_state_dict(sd)
     assert torch.equal(net_b(ones).detach(), before)
+
+
+def test_sines_that_carry_the_sign_of_their_cosine():
+    """One float per sine activation (include/matpbr.h `matpbr_mlp_layer_fwd_sgn` / `_bx` with c_out NULL): the stored sine is the exact
+    kernel's sine up to its last mantissa bit, which holds the sign of the cosine; the backward epilogue rebuilds cos = +-sqrt(1 - sin^2):
+    never the wrong sign, |error| <= 3e-7 / |cos| + 3e-6, and an input gradient whose rms error against fp64 is 1e-5 of its scale.
+    Both kernels that write such sines (thin first layer, 256-wide split-operand layer) and both that read them."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    torch.manual_seed(11)
+    M = 128 * 200
+    # 256-wide layer
+    x = torch.randn(M, 256, device=dev)
+    x[:, 0] *= 50.0
+    w = (torch.rand(256, 256, device=dev) * 2 - 1) / 16
+    b = torch.randn(256, device=dev) * 0.1
+    ws = ops.mlp_split_weights(w, 256, 256)
+    s_ref, c_ref = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+    s_pk = torch.empty(M, 256, device=dev)
+    ops.mlp_layer_fwd_bx(x, ws, b, s_ref, c_ref, 256, 256, 6)
+    ops.mlp_layer_fwd_bx(x, ws, b, s_pk, None, 256, 256, 6)
+    bits_ref, bits_pk = s_ref.view(torch.int32), s_pk.view(torch.int32)
+    assert torch.equal(bits_pk & ~1, bits_ref & ~1)                                   # the same sine but for the last bit ...
+    assert torch.equal((bits_pk & 1).bool(), c_ref < 0)                                # ... which is the sign of the cosine
+    g = torch.randn(M, 256, device=dev)
+    wt = (torch.rand(256, 256, device=dev) * 2 - 1) / 16
+    wts = ops.mlp_split_weights(wt, 256, 256)
+    gp_c, gp_s = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+    db_c, db_s = torch.empty(256, device=dev), torch.empty(256, device=dev)
+    ops.mlp_layer_bwd_input_bx(g, wts, c_ref, gp_c, 256, 256, db_c, 6)
+    ops.mlp_layer_bwd_input_bx(g, wts, s_pk, gp_s, 256, 256, db_s, 6, packed=True)
+    prod = g.double() @ wt.double().t()
+    pre = x.double() @ w.double().t() + b.double()
+    ref = prod * torch.cos(pre)
+    scale = ref.abs().max().item()
+    # the rebuilt cosine against the exact kernel's, seen through the two gradients: |error| <= 1.5e-7 / |cos|, at most 3e-4 (measured:
+    # tools/dbg/sgn.py), never the opposite sign
+    ct = c_ref.double()
+    bound = prod.abs() * torch.minimum(3e-7 / ct.abs().clamp_min(1e-9), torch.full_like(ct, 3e-4)) + 2e-6 * scale
+    assert ((gp_s.double() - gp_c.double()).abs() <= bound).all()
+    big = prod.abs() > 1e-2 * prod.abs().max()
+    assert ((gp_s.double() * gp_c.double())[big & (ct.abs() > 1e-3)] > 0).all()
+    rms = lambda t: float(t.pow(2).mean().sqrt())
+    assert rms(gp_s.double() - ref) <= 2e-5 * rms(ref) and rms(gp_c.double() - ref) <= 2e-6 * rms(ref)
+    assert (db_s.double() - gp_s.double().sum(0)).abs().max().item() <= 1e-5 * (gp_s.double().sum(0).abs().max().item() + 1.0)
+    assert (gp_s - gp_c).abs().max().item() <= 2e-3 * scale                           # the worst unit: cos within 1e-3 of zero
+    # thin first layer (K = 15) and the thin input gradient (5 columns) at image size
+    x0 = torch.zeros(M, 16, device=dev)
+    x0[:, :15] = torch.randn(M, 15, device=dev) * 3
+    w0 = torch.zeros(241, 16, device=dev)
+    w0[:, :15] = torch.randn(241, 15, device=dev) * 0.3
+    b0 = torch.randn(241, device=dev) * 0.1
+    t_ref, tc_ref, t_pk = torch.zeros(M, 256, device=dev), torch.zeros(M, 256, device=dev), torch.zeros(M, 256, device=dev)
+    ops.mlp_layer_fwd(x0, w0, b0, t_ref, tc_ref, 15)
+    ops.mlp_layer_fwd(x0, w0, b0, t_pk, None, 15, packed=True)
+    assert torch.equal(t_pk.view(torch.int32)[:, :241] & ~1, t_ref.view(torch.int32)[:, :241] & ~1)
+    assert torch.equal((t_pk.view(torch.int32)[:, :241] & 1).bool(), tc_ref[:, :241] < 0)
+    assert float(t_pk[:, 241:].abs().max()) == 0.0                                    # the skip layer's tail columns are not touched
+    d5 = torch.zeros(M, 8, device=dev)
+    d5[:, :5] = torch.randn(M, 5, device=dev)
+    wo_t = torch.zeros(256, 8, device=dev)
+    wo_t[:, :5] = torch.randn(256, 5, device=dev) * 0.1
+    o_c, o_s = torch.empty(M, 256, device=dev), torch.empty(M, 256, device=dev)
+    bb_c, bb_s = torch.empty(256, device=dev), torch.empty(256, device=dev)
+    ops.mlp_layer_bwd_input(d5, wo_t, c_ref, o_c, 256, 5, bb_c)
+    ops.mlp_layer_bwd_input(d5, wo_t, s_pk, o_s, 256, 5, bb_s, packed=True)
+    assert rms((o_s - o_c).double()) <= 2e-5 * rms(o_c.double())
