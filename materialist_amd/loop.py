@@ -316,13 +316,11 @@ class FusedBrdfPhase:
         # (they render the environment along their camera ray and receive no material gradient), and tell the steps so
         self.bg_mask = scene.bg_mask
         if self.bg_mask is not None:
-            if B != 1:
-                raise NotImplementedError("pixels without geometry: single-image scenes")
-            bg_rgb = (scene.bg_basis @ self.light.reshape(25, 3)).reshape(self.H, self.W, 3)
+            bg_rgb = scene.background_radiance(self.light)
             pc = (self.p["albedo"], self.p["roughness"], self.p["metallic"])
             if self.lazy:
                 ops.shade_fwd_lazy(*pc, self.n, self.light, self.spp, self.dcache, self.lazy_state, out=self.pred, jac16=self.jac.view(torch.int32)[:5],
-                                   force=True, clamp_params=True, floor=0.5 * float(self.gt.mean()), fov_x_deg=scene.fov)
+                                   force=True, clamp_params=True, stats=self.stats, fov_x_deg=scene.fov)      # per-image parity floor from the statistics row
                 ops.background_into_lazy_state(self.lazy_state, self.p["albedo"], self.bg_mask, bg_rgb, self.p["roughness"])
             elif self.s1cache is not None:
                 ops.shade_fwd(*pc, self.n, self.light, self.spp, scene.fov, clamp_params=True, out=self.pred, dcache=self.dcache, jac=self.jac, s1=self.s1cache)

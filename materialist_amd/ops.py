@@ -245,11 +245,9 @@ def _half_bits(x: float) -> int:
 
 
 def background_into_lazy_state(state: torch.Tensor, a: torch.Tensor, bg_mask: torch.Tensor, bg_rgb: torch.Tensor, r: torch.Tensor) -> None:
-    """Constant models for the masked pixels of ONE image: P = SD = 0, S1 = bg_rgb, no slopes, an interval no roughness can leave."""
+    """Constant models for the masked pixels ([(B,)H,W] mask): P = SD = 0, S1 = bg_rgb, no slopes, an interval no roughness can leave."""
     B, H, W = _bhw(a)
-    if B != 1:
-        raise NotImplementedError("pixels without geometry: single-image scenes")
-    P = H * W
+    P = B * H * W
     planes = state[: 21 * 4 * P].view(torch.int32).view(21, P)
     idx = bg_mask.reshape(-1).nonzero().reshape(-1)
     bits = lambda t: t.contiguous().view(torch.int32)
@@ -272,15 +270,18 @@ def background_into_jac(jac: torch.Tensor, s1: Optional[torch.Tensor], bg_mask: 
 
 
 def background_into_transfer(T: torch.Tensor, H: int, W: int, bg_basis: torch.Tensor) -> None:
-    """Radiance transfer of ONE image (tiled [ceil(P/256)][75][256]): a masked pixel's transfer is the SH basis along its camera ray, per channel."""
+    """Radiance transfer (per image tiled [ceil(P/256)][75][256]; bg_basis [P,25] or [B,P,25]): a masked pixel's transfer is the SH
+    basis along its camera ray, per channel."""
     P = H * W
     tiles = (P + 255) // 256
-    Tv = T[: tiles * 75 * 256].view(tiles, 25, 3, 256)
-    Y = torch.zeros((tiles * 256, 25), dtype=torch.float32, device=T.device)
-    Y[:P] = bg_basis
-    sel = (Y.abs().sum(1) > 0).view(tiles, 1, 1, 256)
-    Yv = Y.view(tiles, 256, 25).permute(0, 2, 1).unsqueeze(2)          # [tiles, 25, 1, 256]
-    Tv.copy_(torch.where(sel, Yv.expand(-1, -1, 3, -1), Tv))
+    basis = bg_basis.reshape(-1, P, 25)
+    B = basis.shape[0]
+    Tv = T[: B * tiles * 75 * 256].view(B, tiles, 25, 3, 256)
+    Y = torch.zeros((B, tiles * 256, 25), dtype=torch.float32, device=T.device)
+    Y[:, :P] = basis
+    sel = (Y.abs().sum(2) > 0).view(B, tiles, 1, 1, 256)
+    Yv = Y.view(B, tiles, 256, 25).permute(0, 1, 3, 2).unsqueeze(3)     # [B, tiles, 25, 1, 256]
+    Tv.copy_(torch.where(sel, Yv.expand(-1, -1, -1, 3, -1), Tv))
 
 
 def diffuse_cache(n, light, spp: int, fov_x_deg: float = 35.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -124,7 +124,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         return done - 1, stop, mse
 
     def env_phase_runner(loop_num: int, lr_of, patience: int, min_delta: float, max_epochs: int):
-        if background and gt.ndim != 3:
+        if background and gt.ndim != 3 and model_name == "pos_mlp":
             return env_phase_runner_background(loop_num, lr_of, patience, min_delta, max_epochs)
         graph = max_epochs > 8 and gt.is_cuda
         if model_name == "pos_mlp":

@@ -302,20 +302,27 @@ def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], 
                            pred_dirs: Optional[Sequence[Optional[str]]] = None, device: str = "cuda", matnet=None, log=print) -> Dict[str, object]:
     """`--model_name none` on several photographs at once: the images of a rank's shard as ONE batch in the kernels' batch dimension
     (per-image light, SaveBest and EarlyStopping on the device), each with the reference's output directory (inverse_img_w_mi.py:623-770
-    per image; the reference runs them one after another, run_inverse_pipeline.sh:16-28).  Scenes with a `mesh_mask.png`, `--use_mask`
-    and parts with 'n' stay with `inverse_image` (they need per-image operator calls)."""
+    per image; the reference runs them one after another, run_inverse_pipeline.sh:16-28).  `mesh_mask.png` and pixels the mesher
+    leaves without a triangle are per-image background masks of the batch; `--use_mask` and parts with 'n' stay with `inverse_image`
+    (they need per-image operator calls)."""
     from . import optimize, render
     from . import mesh as _mesh
 
     if "n" in str(list(opt_order)):
         raise ValueError("inverse_images_batched optimises a / r / m under the geometric normal")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
-    mats, depths, normals, out_dirs = [], [], [], []
+    mats, depths, normals, out_dirs, holes = [], [], [], [], []
     for k, (path, name) in enumerate(zip(img_paths, save_names)):
         output_dir = get_output_dir(name, save_path)
         os.makedirs(os.path.join(output_dir, "best_results"), exist_ok=True)
-        if os.path.exists(os.path.join(output_dir, "mesh_mask.png")):
-            raise ValueError(f"{output_dir}: has a mesh_mask.png; run it through inverse_image")
+        mm_path, mesh_mask = os.path.join(output_dir, "mesh_mask.png"), np.zeros((size, size), dtype=bool)
+        if os.path.exists(mm_path):                          # :713-724: pixels without geometry
+            from PIL import Image
+
+            mk = np.asarray(Image.open(mm_path))
+            mesh_mask = np.ascontiguousarray((mk[..., 0] if mk.ndim == 3 else mk) > 0)
+            if mesh_mask.shape != (size, size):
+                raise ValueError(f"{mm_path}: mask is {mesh_mask.shape}, the run is {size}x{size}")
         img = center_crop_and_resize(load_image(path), (size, size))
         if not path.endswith(".exr"):
             img = np.asarray(_loss.srgb_to_linear(torch.from_numpy(img)).numpy(), dtype=np.float32)
@@ -333,20 +340,23 @@ def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], 
             json.dump({"img_path": path, "save_name": name, "opt_src": opt_src, "opt_order": list(opt_order), "use_mask": False,
                        "opt_env_from": opt_env_from, "model_name": "none", "timestamp": time.strftime("%Y-%m-%d %H:%M:%S"),
                        "image_size": list(img.shape[:2]), "spp": spp, "output_type": "arm", "use_mesh_normal": True}, f, indent=4)
-        depth = 2 * pred["depth"].max() - pred["depth"]
-        rm = _mesh.reference_mesh(np.array(depth, dtype=np.float32), render.DEFAULT_FOV)
-        if not bool(rm["has_faces"].all()):
-            raise ValueError(f"{output_dir}: pixels without geometry; run it through inverse_image")
+        depth = np.array(2 * pred["depth"].max() - pred["depth"], dtype=np.float32)
+        depth[mesh_mask] = 0.0                                                                   # :723
+        rm = _mesh.reference_mesh(depth, render.DEFAULT_FOV)
         mesh_path = os.path.join(output_dir, f"{name}.ply")
         if not os.path.exists(mesh_path):
             _mesh.write_ply(mesh_path, rm["vertices"], rm["triangles"])
-        normals.append(t(rm["normals"]))
+        holes.append(torch.from_numpy(~rm["has_faces"]))
+        nrm_k = t(rm["normals"])
+        nrm_k[holes[-1].to(device)] = torch.tensor([0.0, 0.0, 1.0], device=device)                # never shaded: these pixels show the environment
+        normals.append(nrm_k)
         depths.append(t(depth))
         out_dirs.append(output_dir)
     B = len(mats)
     mat = {k: torch.stack([m[k] for m in mats]) for k in mats[0]}
     scene = render.load_estimated_mesh(torch.stack(depths), use_mesh_normal=True, device=device)
     scene.geo_normal = torch.stack(normals).contiguous()                   # the reference mesher's per-pixel normals (gap closing included)
+    scene.set_mesh_mask(torch.stack(holes))                                # vertices without a triangle: no geometry along that camera ray
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
                                         num_epochs=num_epochs, log=log, model_name="none")
     nrm = scene.geo_normal

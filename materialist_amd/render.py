@@ -122,22 +122,27 @@ class Scene:
         """`mesh_mask.png` (inverse_img_w_mi.py:713-724: `depth[mesh_mask] = 0`, no triangles there): the camera ray of such a
         pixel leaves the scene and sees the environment emitter.  With SH lighting that radiance is sum_k light[k] Y_k(ray), linear
         in the light: the render composes it over the shaded image with `torch.where`, so the light receives its gradient from
-        these pixels and the materials none.  Supported for single images on the operator face (`render_envmap`/`render_w_brdf`);
-        the fused C-ABI loops do not know about it and the drivers route such scenes through the operator face."""
+        these pixels and the materials none.  One [H,W] mask, or [B,H,W] for a batch; the fused loops take the same pixels as
+        constant models (loop.FusedBrdfPhase) and as SH-basis rows of the radiance transfer (loop.FusedEnvPhase)."""
         if mask is None or not bool(mask.any()):
             self.bg_mask = self.bg_basis = None
             return
-        if self.B > 1:
-            raise NotImplementedError("mesh masks are supported for single-image scenes")
-        mask = mask.to(self.device).bool().reshape(self.H, self.W)
+        shp = (self.B, self.H, self.W) if self.B > 1 else (self.H, self.W)
+        mask = mask.to(self.device).bool().reshape(shp)
         f = (self.W / 2.0) / np.tan(np.radians(self.fov) / 2.0)       # pinhole of the kernels (SURVEY App. E)
         cx, cy = (self.W - 1) / 2.0, (self.H - 1) / 2.0
         i, j = np.meshgrid(np.arange(self.H, dtype=np.float64), np.arange(self.W, dtype=np.float64), indexing="ij")
         ray = np.stack([(j - cx) / f, -(i - cy) / f, -np.ones_like(i)], -1)
         ray /= np.linalg.norm(ray, axis=-1, keepdims=True)
-        Y = _sh.sh_basis(ray).reshape(self.H * self.W, _sh.NSH) * mask.cpu().numpy().reshape(-1, 1)
+        Y = torch.from_numpy(_sh.sh_basis(ray).reshape(self.H * self.W, _sh.NSH)).to(self.device, torch.float32)
         self.bg_mask = mask
-        self.bg_basis = torch.from_numpy(Y).to(self.device, torch.float32)
+        self.bg_basis = (Y * mask.reshape(shp[:-2] + (self.H * self.W, 1))).contiguous()        # [H*W,25] or [B,H*W,25]
+
+    def background_radiance(self, light: torch.Tensor) -> torch.Tensor:
+        """Radiance the masked pixels see along their camera rays, [(B,)H,W,3]; linear in the [25,3] light(s)."""
+        if self.B > 1 and light.ndim == 2:
+            light = light.unsqueeze(0).expand(self.B, -1, -1)
+        return (self.bg_basis @ light).reshape(self.bg_mask.shape + (3,))
 
     # -- mi.traverse face ----------------------------------------------------------------------------
     def _get(self, key):
@@ -184,8 +189,7 @@ class Scene:
         m = self.m.reshape(shp + (1,))
         img = _ShadeFn.apply(self.a, r, m, self.shading_normal(), light, int(spp), self.fov, self._ws)
         if self.bg_mask is not None:
-            bg = (self.bg_basis @ light).reshape(self.H, self.W, 3)
-            img = torch.where(self.bg_mask.unsqueeze(-1), bg, img)
+            img = torch.where(self.bg_mask.unsqueeze(-1), self.background_radiance(light), img)
         return img
 
 
@@ -209,18 +213,18 @@ def load_estimated_mesh(depth: Optional[torch.Tensor], use_mesh_normal: bool, ma
         if geometry == "mesh":
             # the reference's own mesh of this depth map (gap closing at depth edges included): per-pixel normal = area-weighted normal of
             # the pixel's grid vertex; a pixel whose vertex carries no triangle has no geometry (its camera ray sees the environment)
-            if batch != 1:
-                raise NotImplementedError("geometry='mesh' takes one depth map")
             from . import mesh as _mesh
 
-            d_host = depth.detach().cpu().numpy().astype(np.float32).copy()
+            d_host = depth.detach().cpu().numpy().astype(np.float32).reshape(batch, height, width).copy()
             if mesh_mask is not None:
-                d_host[mesh_mask.cpu().numpy().astype(bool)] = 0.0                              # inverse_img_w_mi.py:723
-            rm = _mesh.reference_mesh(d_host, fov_x_deg)
-            geo = torch.from_numpy(rm["normals"]).to(device)
-            holes = torch.from_numpy(~rm["has_faces"])
-            mesh_mask = holes if mesh_mask is None else (mesh_mask.cpu().bool() | holes)
+                d_host[mesh_mask.cpu().numpy().astype(bool).reshape(d_host.shape)] = 0.0       # inverse_img_w_mi.py:723
+            rms = [_mesh.reference_mesh(d, fov_x_deg) for d in d_host]                          # host pass, milliseconds per image
+            geo = torch.from_numpy(np.stack([rm["normals"] for rm in rms])).to(device)
+            holes = torch.from_numpy(np.stack([~rm["has_faces"] for rm in rms]))
+            mesh_mask = holes if mesh_mask is None else (mesh_mask.cpu().bool().reshape(holes.shape) | holes)
             geo[holes.to(device)] = torch.tensor([0.0, 0.0, 1.0], device=device)               # any unit vector: these pixels are never shaded
+            if depth.ndim == 2:
+                geo, mesh_mask = geo[0], mesh_mask[0]
         elif geometry == "depth":
             geo = ops.normals_from_depth(depth.contiguous(), fov_x_deg)
         else:

@@ -101,13 +101,10 @@ def main(argv=None):
 
     cfg = {"save_path": a.save_path, "opt_src": a.opt_src, "opt_order": a.opt_order, "opt_env_from": a.opt_env_from, "model_name": a.model_name,
            "size": a.size, "spp": a.spp, "num_epochs": a.num_epochs}
-    # a rank's shard runs as one batch in --model_name none mode (file images: unless one of them has a mesh_mask.png, which needs the
-    # per-image operator path)
-    def has_mesh_mask(p):
-        return os.path.exists(os.path.join(pipeline.get_output_dir(os.path.splitext(os.path.basename(p))[0], a.save_path), "mesh_mask.png"))
-
+    # a rank's shard runs as one batch in --model_name none mode (synthetic scenes, or photographs; a photograph's mesh_mask.png and
+    # the pixels its mesh leaves uncovered are per-image masks of the batch)
     batched = a.model_name == "none" and bool(paths) and "n" not in str(a.opt_order) and (
-        all(p.startswith("synthetic:") for p in paths) or not any(p.startswith("synthetic:") or has_mesh_mask(p) for p in paths))
+        all(p.startswith("synthetic:") for p in paths) or not any(p.startswith("synthetic:") for p in paths))
     rows = batch.run_batch(paths, cfg, process, process_shard=process_shard if batched else None)
     if rank == 0:
         for r in rows:

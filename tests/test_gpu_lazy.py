@@ -343,3 +343,68 @@ def test_pixels_without_geometry_run_in_the_fused_loops():
     assert float(fe.stats[0, ops.STAT_MSE]) == pytest.approx(float(mse), rel=2e-4)
     assert torch.allclose(fe.pred, pred.detach(), rtol=2e-4, atol=1e-6)
     assert (fe.d_light.reshape(25, 3) - l0.grad).abs().max().item() <= 2e-4 * float(l0.grad.abs().max())
+
+
+def test_a_batch_with_per_image_background_masks_equals_the_images_alone():
+    """A shard of photographs whose meshes leave different pixels uncovered (run_batch.py, pipeline.inverse_images_batched): the masks ride
+    in the batch dimension; every image of the batch goes through the fused BRDF and env phases exactly as it does alone."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    H, W, spp = 64, 96, 16
+    scs = [synthetic.make_scene(20 + k, H, W) for k in range(2)]
+    masks = torch.zeros(2, H, W, dtype=torch.bool)
+    masks[0, :11] = True
+    masks[1, 40:, 70:] = True
+    masks[1, 5:9, 5:30] = True
+
+    def scene_(ks):
+        depth = torch.stack([_t(scs[k].depth, dev) for k in ks])
+        mk = masks[list(ks)]
+        s = render.load_estimated_mesh(depth if len(ks) > 1 else depth[0], use_mesh_normal=True, mesh_mask=mk if len(ks) > 1 else mk[0])
+        light = torch.stack([_t(scs[k].light, dev) for k in ks])
+        s._set("emitter.data", light if len(ks) > 1 else light[0])
+        return s
+
+    def maps(ks, names):
+        out = [torch.stack([_t(getattr(scs[k], nm), dev) for k in ks]) for nm in names]
+        return out if len(ks) > 1 else [x[0] for x in out]
+
+    true_names, init_names = ("albedo", "roughness", "metallic"), ("init_albedo", "init_roughness", "init_metallic")
+    with torch.no_grad():
+        gt_b = render.render_w_brdf(scene_((0, 1)), *maps((0, 1), true_names), None, spp)
+        for k in range(2):
+            gt_k = render.render_w_brdf(scene_((k,)), *maps((k,), true_names), None, spp)
+            assert torch.equal(gt_b[k], gt_k)
+            bg = scene_((k,)).background_radiance(_t(scs[k].light, dev))
+            assert torch.equal(gt_k[masks[k].to(dev)], bg[masks[k].to(dev)])
+    for part in ("rm", "a"):
+        batch = loop.FusedBrdfPhase(scene_((0, 1)), gt_b, *maps((0, 1), init_names), optimize_part=part, spp=spp)
+        alone = [loop.FusedBrdfPhase(scene_((k,)), gt_b[k].contiguous(), *maps((k,), init_names), optimize_part=part, spp=spp) for k in range(2)]
+        for it in range(8):
+            batch.step()
+            for ph in alone:
+                ph.step()
+        for k in range(2):
+            for name in ("albedo", "roughness", "metallic"):
+                assert torch.equal(batch.p[name][k], alone[k].p[name]), (part, k, name)
+            assert torch.equal(batch.pred[k], alone[k].pred), (part, k)
+            assert torch.equal(batch.stats[k, : ops.STAT_BEST + 1], alone[k].stats[0, : ops.STAT_BEST + 1]), (part, k)
+    # hot loop A: one light per image, the masked pixels' transfer rows are the SH basis along their rays
+    lights = torch.nn.Parameter(torch.stack([_t(s.light, dev) for s in scs]) * 0.7)
+    s_b = scene_((0, 1))
+    pr = render.traverse(s_b)
+    pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = maps((0, 1), true_names)
+    fe = loop.FusedEnvPhase(s_b, gt_b, lambda: lights, torch.optim.Adam([lights], lr=1e-2), spp=spp)
+    fe.step()
+    for k in range(2):
+        s_k = scene_((k,))
+        pr = render.traverse(s_k)
+        pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = maps((k,), true_names)
+        l0 = (_t(scs[k].light, dev) * 0.7).requires_grad_(True)
+        pred = render.render_envmap(s_k, l0, spp)
+        lo, mse, _ = loop._loss.env_loss(pred, gt_b[k])
+        lo.backward()
+        assert float(fe.stats[k, ops.STAT_MSE]) == pytest.approx(float(mse), rel=2e-4)
+        assert torch.allclose(fe.pred[k], pred.detach(), rtol=2e-4, atol=1e-6)
+        assert (fe.d_light[k] - l0.grad).abs().max().item() <= 2e-4 * float(l0.grad.abs().max())
