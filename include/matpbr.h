@@ -265,6 +265,15 @@ int matpbr_env_project_bwd(const float* y, int ldy, const float* proj, const flo
 int matpbr_light_to_sh25(const float* light, int light_kind, int n_light, float* sh25, int batch, void* stream);
 int matpbr_light_to_sh25_bwd(const float* d_sh25, int light_kind, int n_light, float* d_light, int batch, void* stream);
 int matpbr_select_improved(float* dst, const float* src, const float* stats, int first, long n, void* stream);
+/* `--use_mask` (inverse_img_w_mi.py:379-381,509-511: `mat['roughness'][mask] = mat['roughness'][mask].mean()`, same for metallic) on one
+ * [n] map per image (batch images, n = H*W), deterministic (fixed-order sums, one workgroup per image).
+ *   forward  (gate == NULL): out[i] = mask[i] ? mean over the mask of clamp(in[j], lo, hi) : in[i]   (out may alias in);
+ *   backward (gate != NULL): out[i] = mask[i] ? (lo <= gate[i] <= hi ? mean over the mask of in[j] : 0) : in[i], with in = d loss / d out of
+ *                            the forward and gate = the forward's input: the gradient of every masked entry is the mean of the masked
+ *                            gradients, through the clamp of its own input.
+ * mask: one byte per pixel (0 / non-zero).  A mask without pixels leaves the map as it is. */
+int matpbr_masked_mean_fill(const float* in, const unsigned char* mask, const float* gate, float lo, float hi, float* out, long n, int batch,
+                            void* stream);
 int matpbr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
                          void* stream);
 int matpbr_mlp_layer_bwd_input_w(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo,

@@ -68,7 +68,7 @@ class ArmMlpPhase:
 
     @staticmethod
     def supported(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> bool:
-        if mask is not None or gt_image.ndim != 3 or not gt_image.is_cuda or not scene.use_mesh_normal or "n" in optimize_part:
+        if gt_image.ndim != 3 or not gt_image.is_cuda or not scene.use_mesh_normal or "n" in optimize_part:
             return False
         if getattr(net, "output_type", None) != "arm" or not _PosMlpHipFn.PRODUCTS:
             return False
@@ -85,7 +85,8 @@ class ArmMlpPhase:
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_arm: torch.Tensor, fixed: Dict[str, torch.Tensor],
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
-                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000, weight_decay: float = 0.01):
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000, weight_decay: float = 0.01,
+                 mask: Optional[torch.Tensor] = None):
         from .loop import _lib_ws
 
         if not ArmMlpPhase.supported(scene, gt_image, net, optimize_part, None):
@@ -182,6 +183,10 @@ class ArmMlpPhase:
         if self._bg_mask is not None:
             self._bg_flat = self._bg_mask.reshape(-1)
             self._bg_rgb = (scene.bg_basis @ self._light.reshape(25, 3)).contiguous()
+        # --use_mask (:509-511): inside the mask roughness and metallic are their masked means (of the clamped maps); the render, the loss and
+        # the snapshots see the filled maps, the network receives the mean of the masked gradients through each entry's own clamp
+        self._mask_u8 = None if mask is None else mask.to(dev).reshape(H, W).to(torch.uint8).contiguous()
+        self._fed = {k: E(H, W, 1) for k in ("roughness", "metallic")} if mask is not None else None
         self.t = 0
 
     # ------------------------------------------------------------------------------------------------------------------------------
@@ -246,6 +251,10 @@ class ArmMlpPhase:
     def step(self) -> None:
         o, sc = ops, self.scene
         d = self.forward()
+        if self._mask_u8 is not None:
+            d = dict(d)
+            for k in ("roughness", "metallic"):
+                d[k] = o.masked_mean_fill(d[k], self._mask_u8, out=self._fed[k])
         if self.s1 is not None and self.t > 0:                  # bit-identical to walking the samples again
             o.shade_fwd_cached(d["albedo"], d["metallic"], self.jac, self.s1, clamp_params=True, out=self.pred)
         else:
@@ -262,6 +271,10 @@ class ArmMlpPhase:
                             self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta,
                             self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
                             self.best["metallic"], self.best_img, optimize_part=self.part)
+        if self._mask_u8 is not None:
+            for k in ("roughness", "metallic"):
+                if k in self.live:
+                    o.masked_mean_fill(self.g[k], self._mask_u8, out=self.g[k], gate=self.maps[k])
         self.backward()
         lib = _lib.load()
         with torch.cuda.device(self.dev):       # AdamW; SaveBest keeps the weights that produced the best render (:546-547) in the same pass
@@ -292,6 +305,10 @@ class ArmMlpPhase:
     def current_maps(self) -> Dict[str, torch.Tensor]:
         """The maps the network produces now, clamped as the render sees them (fresh tensors)."""
         d = self.forward()
+        if self._mask_u8 is not None:
+            d = dict(d)
+            for k in ("roughness", "metallic"):
+                d[k] = self.ops.masked_mean_fill(d[k], self._mask_u8)
         return {"albedo": d["albedo"].clamp(0, 1), "roughness": d["roughness"].clamp(0.07, 1), "metallic": d["metallic"].clamp(0, 1)}
 
     def step_and_check(self) -> bool:

@@ -1389,6 +1389,49 @@ int matpbr_sin_bwd(const float* d_y, long ld_d, const float* pre, long ld_p, flo
 }
 
 constexpr int kColsumBlocks = 512;
+// ---- --use_mask: masked entries of a map become their mean (include/matpbr.h matpbr_masked_mean_fill) -------------------------------
+constexpr int kMaskThreads = 1024;
+__global__ __launch_bounds__(kMaskThreads) void masked_mean_fill_kernel(const float* __restrict__ in, const unsigned char* __restrict__ mask,
+                                                                        const float* __restrict__ gate, float lo, float hi, float* out, long n) {
+    __shared__ float s_sum[kMaskThreads / 64];
+    __shared__ float s_cnt[kMaskThreads / 64];
+    __shared__ float s_mean;
+    const long base = (long)blockIdx.x * n;
+    const float* x = in + base;
+    const unsigned char* mk = mask + base;
+    float sum = 0.0f, cnt = 0.0f;
+    for (long i = threadIdx.x; i < n; i += kMaskThreads)
+        if (mk[i]) {
+            const float v = x[i];
+            sum += gate ? v : fminf(fmaxf(v, lo), hi);
+            cnt += 1.0f;
+        }
+    sum = wave_sum_to_lane63(sum);
+    cnt = wave_sum_to_lane63(cnt);
+    if ((threadIdx.x & 63) == 63) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.0f, tc = 0.0f;
+        for (int w = 0; w < kMaskThreads / 64; ++w) { ts += s_sum[w]; tc += s_cnt[w]; }
+        s_mean = tc > 0.0f ? ts / tc : 0.0f;
+    }
+    __syncthreads();
+    const float mean = s_mean;
+    const float* gt = gate ? gate + base : nullptr;
+    float* o = out + base;
+    for (long i = threadIdx.x; i < n; i += kMaskThreads) {
+        float v = x[i];
+        if (mk[i]) v = gt ? ((gt[i] >= lo && gt[i] <= hi) ? mean : 0.0f) : mean;
+        o[i] = v;
+    }
+}
+int matpbr_masked_mean_fill(const float* in, const unsigned char* mask, const float* gate, float lo, float hi, float* out, long n, int batch,
+                            void* stream) {
+    if (!in || !mask || !out || n <= 0 || batch <= 0 || !(lo <= hi)) return MATPBR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(masked_mean_fill_kernel, dim3((unsigned)batch), dim3(kMaskThreads), 0, (hipStream_t)stream, in, mask, gate, lo, hi, out, n);
+    return launch_status();
+}
+
 size_t matpbr_column_sum_workspace_bytes(int N) { return N > 0 ? (size_t)kColsumBlocks * N * sizeof(float) : 0; }
 
 int matpbr_column_sum(const float* x, float* out, long M, int N, void* workspace, size_t workspace_bytes, void* stream) {

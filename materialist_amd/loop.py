@@ -627,11 +627,11 @@ class PosMlpBrdfPhase:
 
 def pos_mlp_brdf_phase(scene, gt_image, net, start_arm, fixed, optimize_part="arm", mask=None, **kw):
     """The phase object of a `pos_mlp` part: the launch-by-launch `armhead.ArmMlpPhase` where it applies (one image of at least
-    8192 pixels, 'arm' network with 256-wide layers, no mask), the autograd composition `PosMlpBrdfPhase` otherwise."""
+    8192 pixels, 'arm' network with 256-wide layers; `--use_mask` included), the autograd composition `PosMlpBrdfPhase` otherwise."""
     from .armhead import ArmMlpPhase
 
     if ArmMlpPhase.supported(scene, gt_image, net, optimize_part, mask):
-        return ArmMlpPhase(scene, gt_image, net, start_arm, fixed, optimize_part=optimize_part, **kw)
+        return ArmMlpPhase(scene, gt_image, net, start_arm, fixed, optimize_part=optimize_part, mask=mask, **kw)
     return PosMlpBrdfPhase(scene, gt_image, net, start_arm, fixed, optimize_part=optimize_part, mask=mask, **kw)
 
 

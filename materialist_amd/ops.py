@@ -284,6 +284,27 @@ def background_into_transfer(T: torch.Tensor, H: int, W: int, bg_basis: torch.Te
     Tv.copy_(torch.where(sel, Yv.expand(-1, -1, -1, 3, -1), Tv))
 
 
+def masked_mean_fill(x: torch.Tensor, mask_u8: torch.Tensor, out: Optional[torch.Tensor] = None, lo: float = 0.0, hi: float = 1.0,
+                     gate: Optional[torch.Tensor] = None, batch: int = 1) -> torch.Tensor:
+    """`--use_mask` on `batch` maps of x.numel() / batch entries each (include/matpbr.h `matpbr_masked_mean_fill`): masked entries become the masked mean of the clamped
+    map; with `gate` (the forward's input) the backward form: masked gradients become their mean, through the clamp of the entry's own input.
+    mask_u8: uint8, one byte per pixel."""
+    lib = _lib.load()
+    x = _dev(x, "map")
+    if mask_u8.dtype != torch.uint8 or not mask_u8.is_cuda or not mask_u8.is_contiguous() or mask_u8.numel() != x.numel():
+        raise ValueError("masked_mean_fill: mask must be a contiguous uint8 CUDA tensor with one byte per map entry")
+    if gate is not None and (_dev(gate, "gate").numel() != x.numel()):
+        raise ValueError("masked_mean_fill: gate must have the map's shape")
+    B = int(batch)
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        code = lib.matpbr_masked_mean_fill(_ptr(x), ctypes.c_void_p(mask_u8.data_ptr()), _ptr(gate), float(lo), float(hi), _ptr(out), x.numel() // B, B,
+                                           _stream(x))
+    _lib.check(code, "matpbr_masked_mean_fill")
+    return out
+
+
 def diffuse_cache(n, light, spp: int, fov_x_deg: float = 35.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per-pixel coefficients of the diffuse lobe, a(1-m)(A0 + r A1 + r^2 A2): [9, B, H, W] planes, constants while the shading
     normals and the light stay fixed (a whole BRDF phase, inverse_img_w_mi.py:317-342)."""

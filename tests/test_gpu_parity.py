@@ -939,6 +939,68 @@ def test_arm_mlp_phase_matches_the_torch_composition(part):
     assert set(bw) == set(sd_b) and all(bw[k].shape == sd_b[k].shape for k in bw)
 
 
+def test_use_mask_in_the_launch_by_launch_pos_mlp_phase():
+    """`--use_mask` (inverse_img_w_mi.py:509-511) in ArmMlpPhase: `matpbr_masked_mean_fill` forward and backward against torch autograd
+    through `x.clamp(0, 1)`, `x[mask] = x[mask].mean()`, then three iterations of the phase against the autograd composition
+    (`loop.PosMlpBrdfPhase` with the same mask): losses, and maps that are uniform inside the mask."""
+    import copy
+
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+    from materialist_amd.armhead import ArmMlpPhase
+
+    dev = _cuda()
+    H = W = 128
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    mask = torch.zeros(H, W, dtype=torch.bool)
+    mask[20:90, 30:100] = True
+    mask[5:9, 5:9] = True
+    mk = mask.to(dev)
+    x = (torch.rand(H, W, 1, generator=gen) * 1.6 - 0.3).to(dev).requires_grad_(True)       # some entries outside [0, 1]
+    y_ref = loop.masked_mean_fill(x.clamp(0, 1), mk)
+    gy = torch.randn(H, W, 1, generator=gen).to(dev)
+    y_ref.backward(gy)
+    u8 = mk.to(torch.uint8).contiguous()
+    y = ops.masked_mean_fill(x.detach(), u8)
+    assert torch.equal(y[~mk], x.detach()[~mk])                                           # unmasked entries pass through (the kernels clamp them)
+    assert (y[mk] - y_ref.detach()[mk]).abs().max().item() < 1e-6
+    gx = ops.masked_mean_fill(gy, u8, gate=x.detach())
+    inside = ((x.detach() >= 0) & (x.detach() <= 1)).reshape(H, W)
+    assert (gx[mk] - x.grad[mk]).abs().max().item() < 1e-6 * float(gy.abs().max())
+    assert torch.equal(gx[~mk], gy[~mk]) and float(gx[mk & ~inside].abs().max()) == 0.0
+    # ---- the phase
+    spp = 8
+    sc = synthetic.make_scene(9, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp).clone()
+    a0, r0, m0 = (0.1 + 0.8 * _t(v, dev).clamp(0, 1) for v in (sc.init_albedo, sc.init_roughness, sc.init_metallic))
+    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).clamp(0, 1)
+    torch.manual_seed(11)
+    net_a = posmlp.brdf_net("arm").to(dev)
+    net_a.lin4.weight.data.normal_(0, 0.02)
+    net_a.lin4.bias.data.normal_(0, 0.02)
+    net_b = copy.deepcopy(net_a)
+    fixed = {"albedo": a0, "roughness": r0, "metallic": m0}
+    for part in ("rm", "a"):
+        assert ArmMlpPhase.supported(scene, gt, net_b, part, mk)
+        ph = loop.pos_mlp_brdf_phase(scene, gt, net_b, start_arm, fixed, optimize_part=part, spp=spp, mask=mk)
+        assert isinstance(ph, ArmMlpPhase)
+        ref = loop.PosMlpBrdfPhase(scene, gt, net_a, start_arm, fixed, optimize_part=part, spp=spp, mask=mk)
+        for it in range(3):
+            ref.step()
+            ph.step()
+            rel = 3e-4 if it == 0 else 2e-3
+            assert float(ph.stats[0, ops.STAT_MSE]) == pytest.approx(float(ref.stats[0, ops.STAT_MSE]), rel=rel), (part, it)
+            assert float(ph.stats[0, ops.STAT_LOSS]) == pytest.approx(float(ref.stats[0, ops.STAT_LOSS]), rel=rel), (part, it)
+        for k in ("roughness", "metallic"):
+            inside_vals = ph.best[k].reshape(H, W)[mk]
+            assert float(inside_vals.max() - inside_vals.min()) == 0.0, (part, k)         # one value inside the mask
+            assert (ph.best[k] - ref.best[k]).abs().max().item() < 2e-4, (part, k)
+        cm = ph.current_maps()
+        assert float(cm["roughness"].reshape(H, W)[mk].std()) == 0.0
+
+
 def test_arm_mlp_phase_network_gradients_match_autograd():
     """The network half of ArmMlpPhase on its own, where nothing is chaotic: forward() against the reference module's maps, and
     backward() fed with given map gradients against torch autograd through the reference network (the straight-through clamp has
