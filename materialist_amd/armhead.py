@@ -253,8 +253,9 @@ class ArmMlpPhase:
         d = self.forward()
         if self._mask_u8 is not None:
             d = dict(d)
-            for k in ("roughness", "metallic"):
-                d[k] = o.masked_mean_fill(d[k], self._mask_u8, out=self._fed[k])
+            for k in ("roughness", "metallic"):                 # a map the part does not optimise is taken as it is (no clamp)
+                lo, hi = (0.0, 1.0) if k in self.live else (-3.0e38, 3.0e38)
+                d[k] = o.masked_mean_fill(d[k], self._mask_u8, out=self._fed[k], lo=lo, hi=hi)
         if self.s1 is not None and self.t > 0:                  # bit-identical to walking the samples again
             o.shade_fwd_cached(d["albedo"], d["metallic"], self.jac, self.s1, clamp_params=True, out=self.pred)
         else:
@@ -308,7 +309,8 @@ class ArmMlpPhase:
         if self._mask_u8 is not None:
             d = dict(d)
             for k in ("roughness", "metallic"):
-                d[k] = self.ops.masked_mean_fill(d[k], self._mask_u8)
+                lo, hi = (0.0, 1.0) if k in self.live else (-3.0e38, 3.0e38)
+                d[k] = self.ops.masked_mean_fill(d[k], self._mask_u8, lo=lo, hi=hi)
         return {"albedo": d["albedo"].clamp(0, 1), "roughness": d["roughness"].clamp(0.07, 1), "metallic": d["metallic"].clamp(0, 1)}
 
     def step_and_check(self) -> bool:

@@ -398,6 +398,131 @@ class FusedBrdfPhase:
         return {"albedo": self.p["albedo"].clamp(0, 1), "roughness": self.p["roughness"].clamp(0.07, 1), "metallic": self.p["metallic"].clamp(0, 1)}
 
 
+class MaskedBrdfPhase:
+    """Hot loop B, `--model_name none` under `--use_mask` (inverse_img_w_mi.py:347-468 with :379-381), launch by launch on the C ABI.
+    Inside the mask the roughness and the metallic the render sees are the masked means of the clamped maps: two image-wide reductions per
+    iteration sit between the optimiser step and the next render (the mean of the new parameters) and between the render's backward pass and
+    the optimiser step (the mean of the masked gradients), so the one-launch step of `FusedBrdfPhase` does not apply; the iteration is
+    fill x2, render (+ jac planes), statistics with the SaveBest / EarlyStopping commit on the device, streaming backward from the jac
+    planes (+ snapshots), masked gradient means, one Adam launch over the flat parameter buffer.  One image, geometric normals.
+    Same interface as `FusedBrdfPhase` (run, poll, lr_at, current_maps, stats, best, best_img, pred, history)."""
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
+                 mask: torch.Tensor, optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
+                 originals: Optional[Dict[str, torch.Tensor]] = None):
+        from . import _lib, ops
+
+        if gt_image.ndim != 3 or not scene.use_mesh_normal or "n" in optimize_part:
+            raise NotImplementedError("MaskedBrdfPhase: one image, geometric normals, parts of a / r / m")
+        self.ops, self._libmod, self.scene, self.part = ops, _lib, scene, optimize_part
+        self.spp, self.scale_delta, self.base_lr = int(spp), float(scale_delta), float(lr)
+        self.gt = gt_image.contiguous()
+        dev = self.gt.device
+        H, W = self.H, self.W = self.gt.shape[0], self.gt.shape[1]
+        n = H * W
+        self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
+        keys = {"a": "albedo", "r": "roughness", "m": "metallic"}
+        self.live = [keys[c] for c in "arm" if c in optimize_part]
+        start = {"albedo": albedo.reshape(H, W, 3), "roughness": roughness.reshape(H, W, 1), "metallic": metallic.reshape(H, W, 1)}
+        sizes = {"albedo": 3 * n, "roughness": n, "metallic": n}
+        total = sum(sizes[k] for k in self.live)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)               # the optimised maps, one buffer: one Adam launch
+        self.gflat = torch.zeros_like(self.flat)
+        self.adam_m, self.adam_v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.p, self.g, off = {}, {}, 0
+        for k in ("albedo", "roughness", "metallic"):
+            if k in self.live:
+                self.p[k] = self.flat[off:off + sizes[k]].view(start[k].shape)
+                self.p[k].copy_(start[k])
+                self.g[k] = self.gflat[off:off + sizes[k]].view(start[k].shape)
+                off += sizes[k]
+            else:
+                self.p[k] = start[k].detach().clone().contiguous()
+                self.g[k] = torch.zeros_like(self.p[k])
+        self.orig = {k: (originals[k] if originals is not None and k in originals else start[k]).detach().reshape(start[k].shape).clone().contiguous()
+                     for k in start}
+        self.mask_u8 = mask.to(dev).reshape(H, W).to(torch.uint8).contiguous()
+        self.fed = {k: torch.empty(H, W, 1, dtype=torch.float32, device=dev) for k in ("roughness", "metallic")}
+        self.bounds = {"roughness": (0.07, 1.0), "metallic": (0.0, 1.0)}                  # the clamps of :375,377, taken before the mean
+        self.hyper = torch.tensor([self.base_lr, 0.0], dtype=torch.float32, device=dev)   # lr, Adam's step count (advanced on the device)
+        self._lr = self.base_lr
+        self.stats = ops.new_loss_stats(1, dev)
+        if best_mse is not None:
+            self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
+        self.patience, self.min_delta = int(patience), float(min_delta)
+        self.hist = torch.zeros((history_len, 1), dtype=torch.float32, device=dev)
+        self.ws = torch.empty(int(_lib_ws(1)) // 4, dtype=torch.float32, device=dev)
+        self.pred = torch.empty_like(self.gt)
+        self.best = {k: v.detach().clone() for k, v in self.p.items()}
+        self.best_img = torch.zeros_like(self.gt)
+        self._n = scene.shading_normal().contiguous()
+        self._light = scene.light.detach().contiguous()
+        self.dcache = ops.diffuse_cache(self._n, self._light, self.spp, scene.fov)
+        self.jac = ops.plane9(self.gt)
+        self.s1 = None if "roughness" in self.live else torch.empty((3, 1, H, W), dtype=torch.float32, device=dev)
+        self._bg_mask = scene.bg_mask
+        if self._bg_mask is not None:
+            self._bg_flat = self._bg_mask.reshape(-1)
+            self._bg_rgb = scene.background_radiance(self._light).reshape(-1, 3).contiguous()
+        self.t = 0
+
+    lr_at = FusedBrdfPhase.lr_at
+
+    def _fed_maps(self) -> Dict[str, torch.Tensor]:
+        d = dict(self.p)
+        for k in ("roughness", "metallic"):                     # a map the part does not optimise is taken as it is (no clamp, :372-381)
+            lo, hi = self.bounds[k] if k in self.live else (-3.0e38, 3.0e38)
+            d[k] = self.ops.masked_mean_fill(self.p[k], self.mask_u8, out=self.fed[k], lo=lo, hi=hi)
+        return d
+
+    def step(self) -> None:
+        o, sc = self.ops, self.scene
+        lr = self.lr_at(self.t)
+        if lr != self._lr:
+            self._lr = lr
+            self.hyper[0:1].fill_(lr)
+        d = self._fed_maps()
+        if self.s1 is not None and self.t > 0:                  # the roughness is fixed: the specular sums are constants of the part
+            o.shade_fwd_cached(d["albedo"], d["metallic"], self.jac, self.s1, clamp_params=True, out=self.pred)
+        else:
+            o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], self._n, self._light, self.spp, sc.fov, clamp_params=True, out=self.pred,
+                        dcache=self.dcache, jac=self.jac, s1=self.s1)
+        if self._bg_mask is not None and not (self.s1 is not None and self.t > 0):
+            self.pred.view(-1, 3)[self._bg_flat] = self._bg_rgb[self._bg_flat]
+            o.background_into_jac(self.jac, self.s1, self._bg_mask, self._bg_rgb)
+        o.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
+                          self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part,
+                          es_patience=self.patience, es_min_delta=self.min_delta, history=self.hist)
+        o.brdf_loss_bwd_jac(d["albedo"], d["roughness"], d["metallic"], self.jac, self.pred, self.gt_srgb, self.stats,
+                            self.orig["albedo"], self.orig["roughness"], self.orig["metallic"], self.scale_delta,
+                            self.g["albedo"], self.g["roughness"], self.g["metallic"], self.best["albedo"], self.best["roughness"],
+                            self.best["metallic"], self.best_img, optimize_part=self.part)
+        for k in ("roughness", "metallic"):
+            if k in self.live:                                  # the mean of the masked gradients, through each entry's own clamp (:375-381)
+                lo, hi = self.bounds[k]
+                o.masked_mean_fill(self.g[k], self.mask_u8, out=self.g[k], lo=lo, hi=hi, gate=self.p[k])
+        lib = self._libmod.load()
+        with torch.cuda.device(self.gt.device):                 # torch.optim.Adam (:359): decoupled decay 0; rests once EarlyStopping has fired
+            self._libmod.check(lib.matpbr_adamw_step_snapshot_dev(o._ptr(self.flat), o._ptr(self.gflat), o._ptr(self.adam_m), o._ptr(self.adam_v),
+                                                                  self.flat.numel(), o._ptr(self.hyper), 0.9, 0.999, 1e-8, 0.0, None,
+                                                                  o._ptr(self.stats), o._stream(self.flat)), "matpbr_adamw_step_snapshot_dev")
+        self.t += 1
+
+    def run(self, n: int) -> None:
+        for _ in range(n):
+            self.step()
+
+    poll = FusedBrdfPhase.poll
+
+    def history(self) -> torch.Tensor:
+        return self.hist[: self.t]
+
+    def current_maps(self) -> Dict[str, torch.Tensor]:
+        d = self._fed_maps()
+        return {"albedo": d["albedo"].clamp(0, 1), "roughness": d["roughness"].clamp(0.07, 1), "metallic": d["metallic"].clamp(0, 1)}
+
+
 class FusedEnvPhase:
     """Hot loop A (inverse_img_w_mi.py:236-254).  Materials and normals are fixed while the light is optimised (:216-220) and the
     render is linear in the light, so the phase computes the per-pixel radiance transfer once (`matpbr_shade_transfer`) and
@@ -582,8 +707,8 @@ class PosMlpBrdfPhase:
         live = [keys[c] for c in self.part if c in keys]
         maps = {k: (raw[k].contiguous() if k in live else self.fixed[k]) for k in raw}
         if self.mask is not None:                                                        # :509-511, after the clamps of :493-495
-            for k in ("roughness", "metallic"):
-                maps[k] = masked_mean_fill(maps[k].clamp(0, 1), self.mask).contiguous()
+            for k in ("roughness", "metallic"):                                          # (a map the part does not optimise: as it is)
+                maps[k] = masked_mean_fill(maps[k].clamp(0, 1) if k in live else maps[k], self.mask).contiguous()
             live = [k for k in live]                                                     # gradients reach the net through the fill
         return maps, live
 

@@ -221,8 +221,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         return it, ph.opt.param_groups[0]["lr"], stop
 
     def brdf_part_runner_normal(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
-        """Parts that optimise the normal map (output_type 'armn', use_mesh_normal False; :335-340,378-379,406-409) or run under
-        `--use_mask`: the autograd render with the torch-composed loss (BrdfPhase) and the reference's per-epoch host EarlyStopping."""
+        """Parts that optimise the normal map (output_type 'armn', use_mesh_normal False; :335-340,378-379,406-409), and `--use_mask` on
+        a batch: the autograd render with the torch-composed loss (BrdfPhase) and the reference's per-epoch host EarlyStopping."""
         ph = _loop.BrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], None if scene.use_mesh_normal else mat["normal"],
                              optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask,
                              originals=originals)
@@ -287,12 +287,14 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 return brdf_part_runner_mlp_normal(loop_num, part, patience, min_delta, n_epochs)
         if model_name == "pos_mlp":
             return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
-        if "n" in part or not scene.use_mesh_normal or mask is not None:
+        if "n" in part or not scene.use_mesh_normal or (mask is not None and gt.ndim != 3):
             return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
-        ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], optimize_part=part, spp=spp,
-                                  scale_delta=scale_delta, patience=patience, min_delta=min_delta,
-                                  best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs,
-                                  originals=originals)
+        phase_kw = dict(optimize_part=part, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
+                        best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs, originals=originals)
+        if mask is not None:      # --use_mask: launch by launch (two image-wide means per iteration), same device-side SaveBest / EarlyStopping
+            ph = _loop.MaskedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mask, **phase_kw)
+        else:
+            ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], **phase_kw)
         done, stop = 0, "num_epochs"
         while done < n_epochs:
             k = min(sync_every, n_epochs - done)

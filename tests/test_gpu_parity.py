@@ -1001,6 +1001,49 @@ def test_use_mask_in_the_launch_by_launch_pos_mlp_phase():
         assert float(cm["roughness"].reshape(H, W)[mk].std()) == 0.0
 
 
+@pytest.mark.parametrize("part", ["rm", "a", "arm"])
+def test_use_mask_none_mode_phase_matches_the_torch_composition(part):
+    """`--model_name none --use_mask` launch by launch on the C ABI (`loop.MaskedBrdfPhase`) against the autograd composition
+    (`loop.BrdfPhase` with the same mask: torch clamps, masked means, torch losses, torch.optim.Adam): per-iteration statistics, the maps
+    after the iterations, one value inside the mask."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    H, W, spp = 96, 128, 16
+    sc = synthetic.make_scene(14, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp).clone()
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    yy, xx = torch.meshgrid(torch.linspace(0, 6.0, H, device=dev), torch.linspace(0, 9.0, W, device=dev), indexing="ij")
+    # a roughness that varies inside the mask (with a constant one the regulariser |mean - r0| sits on its kink in the first iteration and
+    # its sign is rounding noise), some values beyond the clamp bounds: their gates must close
+    init[1] = (init[1] * 1.3 - 0.1 + 0.35 * (torch.sin(yy) * torch.cos(xx)).unsqueeze(-1)).contiguous()
+    if "r" not in part:
+        init[1] = init[1].clamp(0.07, 1)                  # a map that is not optimised comes from the stage before, inside its bounds
+    mask = torch.zeros(H, W, dtype=torch.bool, device=dev)
+    mask[10:70, 20:100] = True
+    ref = loop.BrdfPhase(scene, gt, *init, None, optimize_part=part, spp=spp, mask=mask)
+    ph = loop.MaskedBrdfPhase(scene, gt, *init, mask, optimize_part=part, spp=spp)
+    for it in range(6):
+        mse_ref = ref.step()
+        ph.step()
+        assert float(ph.stats[0, ops.STAT_MSE]) == pytest.approx(float(mse_ref), rel=5e-4), (part, it)
+        assert float(ph.stats[0, ops.STAT_LOSS]) == pytest.approx(float(ref.last["loss"]), rel=5e-4), (part, it)
+    cur, cur_ref = ph.current_maps(), ref.current_maps()
+    for k in ("albedo", "roughness", "metallic"):
+        d = (cur[k] - cur_ref[k].detach().reshape(cur[k].shape)).abs()
+        free = d if k == "albedo" else d.reshape(H, W)[~mask]
+        # Adam normalises: where a gradient is all but zero its sign may differ between the two renders' last bits
+        assert float((free < 5e-5).float().mean()) > 0.99 and float(free.mean()) < 1e-5, (part, k, float(free.max()))
+    for k in ("roughness", "metallic"):
+        inside = cur[k].reshape(H, W)[mask]
+        assert float(inside.max() - inside.min()) == 0.0
+        assert abs(float(inside[0]) - float(cur_ref[k].detach().reshape(H, W)[mask][0])) < 5e-5, (part, k)
+    assert int(ph.poll()["iters"][0]) == 6
+
+
 def test_arm_mlp_phase_network_gradients_match_autograd():
     """The network half of ArmMlpPhase on its own, where nothing is chaotic: forward() against the reference module's maps, and
     backward() fed with given map gradients against torch autograd through the reference network (the straight-through clamp has
