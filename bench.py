@@ -320,7 +320,8 @@ def main(argv=None):
             modes["fused_b8_a"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
             e_el, _ = proto.timed(wl8.phase("fused_exact").step, 10, 100)
             modes["fused_b8_exact"] = {"it_per_s": 100 * 8 * world / e_el, "ms_per_step": e_el / 100 * 1e3, "images_per_gpu": 8}
-    mode_names = {"fused": "hot loop B, --model_name none, whole iteration in libmatpbr.so: loss statistics (2 launches) + ONE launch for the backward pass, "
+    mode_names = {"fused": "hot loop B, --model_name none, whole iteration in libmatpbr.so, TWO launches: the partial sums of the loss statistics, "
+                           "then ONE launch that folds them (every workgroup, fixed order), commits SaveBest / EarlyStopping and runs the backward pass, "
                            "Adam and the next iteration's render from per-pixel local models in the roughness (pixels that left their model's interval "
                            "are re-sampled in the same launch; |render - exact sampling| <= 1e-3 on every pixel of every iteration, tests/test_gpu_lazy.py)",
                   "fused_exact": "the same loop walking the 20 GGX samples of every pixel in every iteration (round 2: render+jac, statistics, streaming backward+Adam)",
@@ -389,7 +390,7 @@ def main(argv=None):
         def lazy_step_times(w):
             """The ONE launch that is the BRDF fwd+bwd pair of the lazy loop (backward of iteration t + Adam + render of iteration t+1), timed
             IN the loop (iterations 301-500 of a phase, so that the share of pixels re-sampled per launch is the loop's, not the start-up's)
-            with HIP events around it, and the two statistics launches back to back."""
+            with HIP events around it, and the statistics launch back to back."""
             ph = w.phase("fused")
             ph.run(300)
             ev = []

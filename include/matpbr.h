@@ -221,7 +221,11 @@ typedef struct MatpbrBrdfPhase {
                                              iteration; no jac planes).  On return `pred` holds this iteration's render as always and `pred_next` the
                                              next one (pixels that left their model's interval pending); the caller SWAPS pred and pred_next before the
                                              next step, calls the steps with t = 1, 2, 3, ... and leaves workspace / lazy_state / pr / pm alone in between.
-                                             The SaveBest snapshot of a map that the part does not optimise is not rewritten. */
+                                             The SaveBest snapshot of a map that the part does not optimise is not rewritten.
+                                             An iteration is then TWO launches: the partial sums of the loss statistics, and this launch, at whose head
+                                             every workgroup folds them (fixed order) and forms the iteration's scalars from the SaveBest / EarlyStopping
+                                             state of the iteration before, which lives in `workspace` in two alternating copies (read t-1, written t:
+                                             the step with t = 1 copies `stats` in); `stats` is rewritten by one workgroup per image at every step. */
     uint32_t flags;                       /* MATPBR_FLAG_MODELS_READY; MATPBR_FLAG_ATTACHED_SAMPLING (pred_next mode only): d loss / d r through the GGX quadrature nodes -- the models'
                                              slopes are that derivative -- i.e. the live reference's gradient convention (myutils/mi_plugin.py:227-230,
                                              1335-1341) instead of the stop-gradient default */

@@ -10,6 +10,7 @@
 //     (scalar loads, no VGPRs);
 //   * every reduction (light gradient, loss statistics) is two-pass with fixed-order partials: no atomics, bit-reproducible.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void loss_final1_kernel(const float* __rest
 }
 // pass 2: sum (xs-gs)^2, sum |xs-gs| over [H,W,3]; sum |a-a0| over [H,W,3]; sum |r-r0|, |m-m0| over [H,W]
 // FROM_FWD: ratio is formed here from the forward kernel's per-workgroup sums and the stored sum(gt) (no pass 1).
-template <int MODE>   // 0: ratio from stats (piecewise API); 1: BRDF phase step (ratio from the forward sums)
+template <int MODE>   // 0: ratio from stats (piecewise API); 1: BRDF phase step (ratio from the forward sums); 3: the same, folded by the step kernel
 __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restrict__ pred, const float* __restrict__ gt_srgb,
                                                             const float* __restrict__ stats, const float* __restrict__ pa,
                                                             const float* __restrict__ a0, const float* __restrict__ pr,
@@ -66,10 +67,12 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
     const int b = blockIdx.y;
     float ratio = 1.0f;
     if (MODE >= 1 && img_stopped(stats, b)) return;
-    if (MODE == 1) {
+    float sp_total = 0.0f;
+    if (MODE == 1 || MODE == 3) {
         float sp = 0.0f;
         for (int i = threadIdx.x; i < n_fwd; i += kBlock) sp += fwd_sums[(long)b * n_fwd + i];
-        ratio = stats[b * kStatsStride + kStGtSum] / block_sum(sp, s_buf);
+        sp_total = block_sum(sp, s_buf);
+        ratio = stats[b * kStatsStride + kStGtSum] / sp_total;
     } else if (MODE == 0) {
         ratio = stats[b * kStatsStride + kStRatio];
     }
@@ -86,44 +89,14 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
             if (part_mask & MATPBR_PART_R) s[3] += fabsf(fminf(fmaxf(pr[b * n1 + i], 0.07f), 1.0f) - r0[b * n1 + i]);
             if (part_mask & MATPBR_PART_M) s[4] += fabsf(fminf(fmaxf(pm[b * n1 + i], 0.0f), 1.0f) - m0[b * n1 + i]);
         }
+    // MODE 3: one image's rows are followed by the folded sum of the render (the step kernel forms the ratio from it)
+    float* rows = part + (long)b * (MODE == 3 ? step_part_stride((int)gridDim.x) : (long)gridDim.x * 5);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         float v = block_sum(s[k], s_buf);
-        if (threadIdx.x == 0) part[((long)b * gridDim.x + blockIdx.x) * 5 + k] = v;
+        if (threadIdx.x == 0) rows[(long)blockIdx.x * 5 + k] = v;
     }
-}
-// Per-image scalars of the iteration, SaveBest's decision, and (es_patience > 0) the EarlyStopping state machine of
-// myutils/misc.py:37-60 kept on the device: once an image has stopped, every later kernel of the fused step skips it, so
-// the host may enqueue iterations ahead and read the flag occasionally without changing any decision.
-// The iteration in which EarlyStopping fires still finishes (snapshot of a new best, optimiser step), as in the reference's
-// loop, which tests early_stop after optimizer.step(): kStStopped goes 0 -> 1 here and 1 -> 2 on the next entry.
-__device__ __forceinline__ bool stats_enter(float* st) {   // true: the image stopped earlier, nothing to do
-    if (st[kStStopped] > 0.5f) {
-        st[kStStopped] = 2.0f;
-        st[kStImproved] = 0.0f;
-        return true;
-    }
-    return false;
-}
-__device__ __forceinline__ void stats_commit(float* st, float mse, float l1, float sr, float la, float lr, float lm, float scale_delta,
-                                             int es_patience, float es_min_delta, float* history, int hist_len, int batch, int b) {
-    st[kStMse] = mse; st[kStL1] = l1; st[kStSr] = sr; st[kStLa] = la; st[kStLr] = lr; st[kStLm] = lm;
-    st[kStLoss] = 3.0f * sr * mse + l1 + scale_delta * (la + lr + lm);   // :412-414
-    float best = st[kStBest];
-    bool improved = mse < best;                            // SaveBest.update: strict < (myutils/misc.py:75)
-    st[kStImproved] = improved ? 1.0f : 0.0f;
-    st[kStBest] = improved ? mse : best;
-    const int it = (int)st[kStIters];
-    if (history && it < hist_len) history[(long)it * batch + b] = mse;
-    st[kStIters] = (float)(it + 1);
-    if (es_patience > 0) {                                 // EarlyStopping.__call__ (myutils/misc.py:51-60)
-        if (st[kStEsHas] < 0.5f) { st[kStEsBest] = mse; st[kStEsHas] = 1.0f; }
-        else if (mse > st[kStEsBest] * (1.0f - es_min_delta)) {
-            float cnt = st[kStEsCounter] + 1.0f;
-            st[kStEsCounter] = cnt;
-            if (cnt >= (float)es_patience) st[kStStopped] = 1.0f;
-        } else { st[kStEsBest] = mse; st[kStEsCounter] = 0.0f; }
-    }
+    if (MODE == 3 && blockIdx.x == 0 && threadIdx.x == 0) rows[(long)gridDim.x * 5] = sp_total;
 }
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void loss_final2_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk,
@@ -1171,7 +1144,8 @@ int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, 
 
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
     if (H <= 0 || W <= 0 || batch <= 0) return 0;
-    return ((size_t)batch * (grid_blocks(H, W) + lazy_groups((long)H * W)) + (size_t)batch * kRedBlocks * 5) * sizeof(float);
+    return ((size_t)batch * (grid_blocks(H, W) + lazy_groups((long)H * W)) + (size_t)batch * kRedBlocks * 5 +
+            2 * (size_t)batch * kStatsStride /* the step kernel's alternating SaveBest / EarlyStopping state */) * sizeof(float);
 }
 
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* stream) {
@@ -1224,7 +1198,17 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     else
         hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(kBlock), 0, st, sa, q.light, g, tab);
     // 2. loss statistics, SaveBest / EarlyStopping decisions (:388-418, misc.py:37-97)
-    if (stages & MATPBR_STAGE_STATS) {
+    const int step_rows = kStepRows;
+    // [2][B][kStatsStride], at a fixed place (`part` moves with the number of forward sums, which differs between t = 1 and later steps)
+    float* state2 = (float*)q.workspace + (size_t)q.batch * (grid_blocks(q.H, q.W) + lazy_groups(n1)) + (size_t)q.batch * kRedBlocks * 5;
+    if ((stages & MATPBR_STAGE_STATS) && lazy_fused) {
+        // one launch: the partial rows; their fold and the SaveBest / EarlyStopping commit happen at the head of the step kernel
+        if (t == 1 && hipMemcpyAsync(state2, q.stats, sizeof(float) * (size_t)q.batch * kStatsStride, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return MATPBR_ERR_LAUNCH;
+        hipLaunchKernelGGL(loss_sums2_kernel<3>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
+                           (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
+                           (const float*)fwd_sums, nfwd, q.part_mask);
+    } else if (stages & MATPBR_STAGE_STATS) {
     hipLaunchKernelGGL(loss_sums2_kernel<1>, dim3(kRedBlocks, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                        (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
                        (const float*)fwd_sums, nfwd, q.part_mask);
@@ -1254,6 +1238,11 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         ls.pred_next = q.pred_next; ls.block_sums = fwd_sums; ls.n = q.n; ls.dcache = q.dcache; ls.counts = lb.counts; ls.lists = lb.lists; ls.n_sums = lb.nblk;
         ls.tol = q.lazy_tol > 0.0f ? q.lazy_tol : 1.0f;
         ls.attached = (q.flags & MATPBR_FLAG_ATTACHED_SAMPLING) ? 1 : 0;
+        ls.fold_part = part; ls.fold_rows = step_rows;
+        ls.state_old = state2 + (size_t)((t - 1) & 1) * q.batch * kStatsStride;
+        ls.state_new = state2 + (size_t)(t & 1) * q.batch * kStatsStride;
+        ls.stats_out = q.stats; ls.history = q.history; ls.hist_len = q.hist_len; ls.batch = q.batch;
+        ls.es_patience = q.es_patience; ls.es_min_delta = q.es_min_delta;
         hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);
     } else if (lazy)
         hipLaunchKernelGGL((jac_bwd_kernel<true, true>), dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);

@@ -183,6 +183,19 @@ struct LazyStepArgs {
     int n_sums;
     float tol;
     int attached;             // d out / d r through the GGX quadrature nodes: the models' slopes (MATPBR_FLAG_ATTACHED_SAMPLING) instead of dSD, dS1
+    // The iteration's statistics are folded HERE (no loss_final2 launch): every workgroup folds the rows of partial sums that
+    // loss_sums2_kernel<3> left for its image (fixed order: the same bits in every workgroup), forms the iteration's scalars from the OLD
+    // SaveBest / EarlyStopping state (`state_old`) and uses them; workgroup 0 of the image also writes the NEW state to `state_new` and to
+    // the caller's statistics rows (j.stats, written here).  Old and new are different buffers (the caller alternates them): a workgroup
+    // that starts late still reads the state its siblings read.
+    const float* fold_part;   // nullable: then the statistics were committed by loss_final2_kernel and j.stats is read as before
+    int fold_rows;
+    const float* state_old;   // [B][kStatsStride]
+    float* state_new;         // [B][kStatsStride]
+    float* stats_out;         // [B][kStatsStride] the public rows
+    float* history;
+    int hist_len, batch, es_patience;
+    float es_min_delta;
 };
 // LDS exchange between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be held back
 __device__ __forceinline__ void wave_lds_sync() {
@@ -317,13 +330,68 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
     __shared__ float4 s_ring[kMaxRings];
     __shared__ float2 s_saz[kMaxRings * kMaxAz];
     __shared__ float s_rec[kLazyBlockPixels * kRecStride];
+    __shared__ float s_state[kStatsStride];
+    __shared__ float s_fold[4][6];
     const JacBwdArgs& q = qs.j;
     const int b = blockIdx.y;
-    if (q.check_stop && img_stopped_before(q.stats, b)) return;
     const int P = g.H * g.W;
     const int q0 = blockIdx.x * kLazyBlockPixels + threadIdx.x, q1 = q0 + kBlock;
-    const float ratio = q.stats[b * kStatsStride + kStRatio], sr = q.stats[b * kStatsStride + kStSr];
-    const bool improved = q.stats[b * kStatsStride + kStImproved] > 0.5f;
+    float ratio, sr, gt_sum;
+    bool improved;
+    if (qs.fold_part != nullptr) {
+        const float* old = qs.state_old + b * kStatsStride;
+        if (old[kStStopped] > 0.5f) {                          // EarlyStopping fired in an earlier iteration (uniform): nothing to do
+            if (blockIdx.x == 0 && threadIdx.x < kStatsStride) {
+                float v = old[threadIdx.x];
+                if (threadIdx.x == kStStopped) v = 2.0f;
+                if (threadIdx.x == kStImproved) v = 0.0f;
+                qs.state_new[b * kStatsStride + threadIdx.x] = v;
+                qs.stats_out[b * kStatsStride + threadIdx.x] = v;
+            }
+            return;
+        }
+        // fold: thread i takes row i (fold_rows <= kBlock), waves by a fixed DPP tree, the four wave totals in fixed order
+        const float* rows = qs.fold_part + (long)b * step_part_stride(qs.fold_rows);
+        float v[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = threadIdx.x; i < qs.fold_rows; i += kBlock) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] += rows[(long)i * 5 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float w = wave_sum_to_lane63(v[k]);
+            if ((threadIdx.x & 63) == 63) s_fold[threadIdx.x >> 6][k] = w;
+        }
+        if (threadIdx.x < kStatsStride) s_state[threadIdx.x] = old[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) t[k] = (s_fold[0][k] + s_fold[1][k]) + (s_fold[2][k] + s_fold[3][k]);
+            s_state[kStRatio] = s_state[kStGtSum] / rows[(long)qs.fold_rows * 5];
+            const float mse = t[0] * q.inv_n3, l1 = t[1] * q.inv_n3;
+            const float la = (q.part_mask & MATPBR_PART_A) ? t[2] * q.inv_n3 : 0.0f;
+            const float lr = (q.part_mask & MATPBR_PART_R) ? t[3] * q.inv_n1 : 0.0f;
+            const float lm = (q.part_mask & MATPBR_PART_M) ? t[4] * q.inv_n1 : 0.0f;
+            stats_commit(s_state, mse, l1, l1 / mse /* scale_raito, :411 */, la, lr, lm, q.scale_delta, qs.es_patience, qs.es_min_delta,
+                         blockIdx.x == 0 ? qs.history : nullptr, qs.hist_len, qs.batch, b);
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < kStatsStride) {
+            qs.state_new[b * kStatsStride + threadIdx.x] = s_state[threadIdx.x];
+            qs.stats_out[b * kStatsStride + threadIdx.x] = s_state[threadIdx.x];
+        }
+        ratio = s_state[kStRatio];
+        sr = s_state[kStSr];
+        improved = s_state[kStImproved] > 0.5f;
+        gt_sum = s_state[kStGtSum];
+    } else {
+        if (q.check_stop && img_stopped_before(q.stats, b)) return;
+        ratio = q.stats[b * kStatsStride + kStRatio];
+        sr = q.stats[b * kStatsStride + kStSr];
+        improved = q.stats[b * kStatsStride + kStImproved] > 0.5f;
+        gt_sum = q.stats[b * kStatsStride + kStGtSum];
+    }
     if (threadIdx.x < kNL) s_light[threadIdx.x] = light[(long)b * kNL + threadIdx.x] * kShNorm[threadIdx.x / 3];
     if (threadIdx.x < kMaxRings * kMaxAz) s_saz[threadIdx.x] = (&tab.saz[0][0])[threadIdx.x];
     if (threadIdx.x < kMaxRings) s_ring[threadIdx.x] = tab.sring[threadIdx.x];
@@ -357,8 +425,8 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
         __syncthreads();
         float floor_;
         {
-            const float rt = q.stats[b * kStatsStride + kStRatio];
-            floor_ = 0.5f * q.stats[b * kStatsStride + kStGtSum] / (3.0f * (float)P) / (rt > 0.0f ? rt : 1.0f);
+            const float rt = ratio;
+            floor_ = 0.5f * gt_sum / (3.0f * (float)P) / (rt > 0.0f ? rt : 1.0f);
         }
         const float tol_k = qs.tol * kLzTolK, tol_s = qs.tol * kLzTolS;
         const int sub = lane & 7, half = sub >> 2, azi = sub & 3;

@@ -434,6 +434,43 @@ enum { kStRatio = 0, kStMse, kStL1, kStSr, kStLa, kStLr, kStLm, kStLoss, kStImpr
 __device__ __forceinline__ bool img_stopped(const float* stats, int b) { return stats[b * kStatsStride + kStStopped] > 0.5f; }
 __device__ __forceinline__ bool img_stopped_before(const float* stats, int b) { return stats[b * kStatsStride + kStStopped] > 1.5f; }
 
+// Per-image scalars of the iteration, SaveBest's decision, and (es_patience > 0) the EarlyStopping state machine of
+// myutils/misc.py:37-60 kept on the device: once an image has stopped, every later kernel of the fused step skips it, so
+// the host may enqueue iterations ahead and read the flag occasionally without changing any decision.
+// The iteration in which EarlyStopping fires still finishes (snapshot of a new best, optimiser step), as in the reference's
+// loop, which tests early_stop after optimizer.step(): kStStopped goes 0 -> 1 here and 1 -> 2 on the next entry.
+__device__ __forceinline__ bool stats_enter(float* st) {   // true: the image stopped earlier, nothing to do
+    if (st[kStStopped] > 0.5f) {
+        st[kStStopped] = 2.0f;
+        st[kStImproved] = 0.0f;
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ void stats_commit(float* st, float mse, float l1, float sr, float la, float lr, float lm, float scale_delta,
+                                             int es_patience, float es_min_delta, float* history, int hist_len, int batch, int b) {
+    st[kStMse] = mse; st[kStL1] = l1; st[kStSr] = sr; st[kStLa] = la; st[kStLr] = lr; st[kStLm] = lm;
+    st[kStLoss] = 3.0f * sr * mse + l1 + scale_delta * (la + lr + lm);   // :412-414
+    float best = st[kStBest];
+    bool improved = mse < best;                            // SaveBest.update: strict < (myutils/misc.py:75)
+    st[kStImproved] = improved ? 1.0f : 0.0f;
+    st[kStBest] = improved ? mse : best;
+    const int it = (int)st[kStIters];
+    if (history && it < hist_len) history[(long)it * batch + b] = mse;
+    st[kStIters] = (float)(it + 1);
+    if (es_patience > 0) {                                 // EarlyStopping.__call__ (myutils/misc.py:51-60)
+        if (st[kStEsHas] < 0.5f) { st[kStEsBest] = mse; st[kStEsHas] = 1.0f; }
+        else if (mse > st[kStEsBest] * (1.0f - es_min_delta)) {
+            float cnt = st[kStEsCounter] + 1.0f;
+            st[kStEsCounter] = cnt;
+            if (cnt >= (float)es_patience) st[kStStopped] = 1.0f;
+        } else { st[kStEsBest] = mse; st[kStEsCounter] = 0.0f; }
+    }
+}
+// rows of partial sums the step kernel folds itself (one per workgroup of loss_sums2_kernel<3>), and the stride of an image's block
+constexpr int kStepRows = 768;   // (measured 128 / 256 / 384 / 768: the most rows win at one image and at eight)
+__host__ __device__ inline long step_part_stride(int rows) { return (long)rows * 5 + 4; }
+
 // =================================================================================================
 // forward (+ jac) and the material backward of the operator face
 // =================================================================================================
