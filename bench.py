@@ -327,8 +327,8 @@ def main(argv=None):
                   "fused_exact": "the same loop walking the 20 GGX samples of every pixel in every iteration (round 2: render+jac, statistics, streaming backward+Adam)",
                   "fused_b8_exact": "the 8-image shard with exact sampling in every iteration (round 2's fused_b8)",
                   "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
-                  "fused_a": "the same loop in part 'a' of --opt_order 'rm a' (roughness fixed): after the part's first render the specular sums of "
-                             "every pixel are reused (bit-identical to walking the samples), so the forward is a streaming kernel too",
+                  "fused_a": "the same two launches in part 'a' of --opt_order 'rm a' (roughness fixed): no pixel ever leaves its model's interval, "
+                             "nothing is re-sampled after the part's first render",
                   "fused_b8_a": "part 'a' on the 8-image shard (image-iterations/s)",
                   "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
                   "pos_mlp_exact_f32": "the pos_mlp loop with --mlp-products 0: 256-wide layers on the exact-f32 MFMA kernels, autograd composition "

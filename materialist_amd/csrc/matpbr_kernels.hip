@@ -1168,7 +1168,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     if (!fill_rule_table(q.spp, tab)) return MATPBR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     // the parts that move the roughness render from per-pixel local models when the caller provides their storage (matpbr_lazy.hpp)
-    const bool lazy = q.lazy_state != nullptr && (q.part_mask & MATPBR_PART_R) && q.dcache != nullptr &&
+    const bool lazy = q.lazy_state != nullptr && q.dcache != nullptr &&
                       lazy_fwd_blocks((long)q.H * q.W) <= kLazyMaxBlocks;
     const bool lazy_fused = lazy && q.pred_next != nullptr;   // backward of this iteration and forward of the next one in one launch
     const int nfwd = grid_blocks(q.H, q.W) + ((lazy && !(lazy_fused && t > 1)) ? lazy_groups((long)q.H * q.W) : 0);

@@ -303,14 +303,16 @@ class FusedBrdfPhase:
         ph.part_mask = sum(self.PARTS[ch] for ch in optimize_part)
         ph.es_patience, ph.es_min_delta, ph.hist_len = int(patience), float(min_delta), int(history_len)
         # parts that leave the roughness alone: the specular sums of every pixel are constants of the part (kept from its first render)
-        self.s1cache = None if "r" in optimize_part else torch.empty((3,) + tuple(self.jac.shape[1:]), dtype=torch.float32, device=self.jac.device)
+        # lazy (default): every part renders from the per-pixel models -- in a part that leaves the roughness alone no pixel ever leaves its
+        # model's interval, so its iteration is the same two launches with no re-sampling at all
+        self.lazy = bool(self.LAZY if lazy is None else lazy)
+        self.s1cache = None if ("r" in optimize_part or self.lazy) else torch.empty((3,) + tuple(self.jac.shape[1:]), dtype=torch.float32, device=self.jac.device)
         ph.s1cache = P(self.s1cache) if self.s1cache is not None else None
-        self.lazy = bool(self.LAZY if lazy is None else lazy) and "r" in optimize_part
         self.lazy_state = ops.lazy_state(self.p["albedo"]) if self.lazy else None
         ph.lazy_state = P(self.lazy_state) if self.lazy else None
         ph.lazy_tol = float(lazy_tol)
         if attached_sampling and not self.lazy:
-            raise ValueError("attached_sampling needs the lazy path (a part that optimises the roughness)")
+            raise ValueError("attached_sampling needs the lazy path")
         ph.flags = ops.FLAG_ATTACHED_SAMPLING if attached_sampling else 0
         # pixels without geometry (Scene.set_mesh_mask): build what the first step would build, give those pixels constant models
         # (they render the environment along their camera ray and receive no material gradient), and tell the steps so

@@ -522,8 +522,9 @@ def test_fused_phase_with_fixed_roughness_reuses_the_specular_sums_bit_exactly(p
     with torch.no_grad():
         gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
     init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
-    cached = loop.FusedBrdfPhase(scene, gt, *init, optimize_part=part, spp=spp)
-    walked = loop.FusedBrdfPhase(scene, gt, *init, optimize_part=part, spp=spp)
+    # (lazy=False: the phases that walk samples; the default phase renders every part from the per-pixel models, tests/test_gpu_lazy.py)
+    cached = loop.FusedBrdfPhase(scene, gt, *init, optimize_part=part, spp=spp, lazy=False)
+    walked = loop.FusedBrdfPhase(scene, gt, *init, optimize_part=part, spp=spp, lazy=False)
     assert cached.s1cache is not None
     walked._ph.s1cache = None                              # the same phase without the cache: samples walked every iteration
     ref = loop.BrdfPhase(scene, gt, *init, None, optimize_part=part, spp=spp)
