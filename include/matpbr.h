@@ -280,6 +280,17 @@ int matpbr_masked_mean_fill(const float* in, const unsigned char* mask, const fl
                             void* stream);
 int matpbr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
                          void* stream);
+/* One backward step of a small network (M <= 1024 points: the 16 x 32 envmap MLP, mymodels/mlps.py:216-236 under autograd) in ONE launch,
+ * given g = dL/d pre of layer l [M, n_red]:
+ *   d_w[n_red, K]        = g^T x                               (weight gradient of layer l; x[M, K] its input)
+ *   g_prev[M, n_prev]    = (g w) * c_prev, w[n_red, ldw] the layer's FORWARD weight (w == NULL: no input gradient, the first layer);
+ *   colsum_out           = per-row-tile column sums of g_prev ([ceil(M/32)][256] floats: the next step's `colsum_in`, stride 256)
+ *   d_bias[n_red]        = sum over `groups_in` rows of colsum_in (row stride colsum_stride): the bias gradient of layer l from the column
+ *                          sums the step before left (for the output layer: colsum_in = g itself, stride ldg, groups_in = M); NULL: skipped.
+ * colsum_out and colsum_in must be different buffers.  Deterministic. */
+int matpbr_mlp_small_bwd_step(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo, float* colsum_out,
+                              int n_prev, const float* x, int ldx, float* d_w, int ldw_out, int K, const float* colsum_in, int colsum_stride,
+                              int groups_in, float* d_bias, long M, int n_red, void* stream);
 int matpbr_mlp_layer_bwd_input_w(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo,
                                  float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
                                  void* stream);

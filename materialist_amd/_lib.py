@@ -137,6 +137,9 @@ SIGNATURES = {
     "matpbr_sample_brdf": (ctypes.c_int, [_c_f] * 10 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_sh_eval": (ctypes.c_int, [_c_f] * 3 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_depth_to_mesh_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 6),
+    "matpbr_mlp_small_bwd_step": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int,
+                                                 _c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_long, ctypes.c_int,
+                                                 ctypes.c_void_p]),
     "matpbr_masked_mean_fill": (ctypes.c_int, [_c_f, ctypes.c_void_p, _c_f, ctypes.c_float, ctypes.c_float, _c_f, ctypes.c_long, ctypes.c_int,
                                                ctypes.c_void_p]),
     "matpbr_normals_from_depth": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),

@@ -982,12 +982,12 @@ __device__ __forceinline__ float4 ld4_masked(const float* p, int k, int K) {   /
 // EPI_MULC writes per-row-tile column sums to colsum[tile_m][256].
 // BKN: B is given as [K][ldb] (k-major: the forward weight of the layer, used as is by the backward product G W) instead of [N][ldb].
 template <int EPI, bool BKN = false>
-__global__ __launch_bounds__(256) void mlp_small_nt(const NtArgs p) {
+__device__ __forceinline__ void small_nt_body(const NtArgs& p, int block) {
   __shared__ float s_part[4][16 * 64];
   __shared__ float s_col[4][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int tiles_n = (p.N + 31) >> 5;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int tm = block / tiles_n, tn = block - tm * tiles_n;
   const int row = min(tm * 32 + li, p.M - 1), col = min(tn * 32 + li, p.N - 1);
   const float* pa = p.A + (size_t)row * p.lda;
   const float* pb = BKN ? p.B + col : p.B + (size_t)col * p.ldb;
@@ -1061,15 +1061,18 @@ __global__ __launch_bounds__(256) void mlp_small_nt(const NtArgs p) {
   }
 }
 
+template <int EPI, bool BKN = false>
+__global__ __launch_bounds__(256) void mlp_small_nt(const NtArgs p) { small_nt_body<EPI, BKN>(p, (int)blockIdx.x); }
+
 // dW[n][k] = sum_m G[m][n] X[m][k]: one workgroup per 32x32 tile of dW; its four waves split the reduction over m (<= kSmallM)
 // into quarters of <= 256 rows, issue every load of a 128-row half at once (64 + 64 dwords per lane), and fold their partial
 // tiles through LDS in fixed order.
-__global__ __launch_bounds__(256) void mlp_small_tn(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
-                                                    float* __restrict__ dW, int ldw, int M, int N, int K) {
+__device__ __forceinline__ void small_tn_body(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, float* __restrict__ dW,
+                                              int ldw, int M, int N, int K, int block) {
   __shared__ float s_part[3][16 * 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int tiles_k = (K + 31) >> 5;
-  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+  const int tn = block / tiles_k, tk = block - tn * tiles_k;
   const int n = tn * 32 + li, k = tk * 32 + li;
   const bool nok = n < N, kok = k < K;
   const float* pg = G + (nok ? n : N - 1);
@@ -1105,6 +1108,42 @@ __global__ __launch_bounds__(256) void mlp_small_tn(const float* __restrict__ G,
       const int nn = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (nn < N && kok) dW[(size_t)nn * ldw + k] = v;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_small_tn(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                    float* __restrict__ dW, int ldw, int M, int N, int K) {
+  small_tn_body(G, ldg, X, ldx, dW, ldw, M, N, K, (int)blockIdx.x);
+}
+
+// One backward step of a small-M network (the 16 x 32 envmap MLP of hot loop A) in ONE launch.  With g = dL/d pre of layer l in hand, three
+// pieces of work are independent of each other: the weight gradient of layer l (g^T x), the input gradient into layer l - 1 ((g W) * cos,
+// with per-row-tile column sums for that layer's bias gradient), and the fold of the column sums the step BEFORE left behind (= the bias
+// gradient of layer l).  As separate launches they were 3 of the iteration's 26 launches per layer, each a few microseconds of work behind
+// ~6 us of launch; here workgroups take one of the roles by index.
+struct SmallBwdStep {
+  NtArgs d;                 // input gradient (mlp_small_nt<EPI_MULC, BKN>); nD == 0: none
+  int nD;
+  const float* G; int ldg; const float* X; int ldx; float* dW; int ldw; int M, N, K;   // weight gradient (mlp_small_tn)
+  int nW;
+  const float* part_in; int part_stride, groups_in; float* d_bias; int n_bias;          // bias gradient: d_bias[c] = sum_g part_in[g stride + c]
+};
+__global__ __launch_bounds__(256) void mlp_small_bwd_step_kernel(const SmallBwdStep a) {
+  int b = (int)blockIdx.x;
+  if (b < a.nD) {
+    small_nt_body<EPI_MULC, true>(a.d, b);
+    return;
+  }
+  b -= a.nD;
+  if (b < a.nW) {
+    small_tn_body(a.G, a.ldg, a.X, a.ldx, a.dW, a.ldw, a.M, a.N, a.K, b);
+    return;
+  }
+  const int c = (b - a.nW) * 256 + (int)threadIdx.x;        // fixed order over the groups: deterministic
+  if (c < a.n_bias) {
+    float s = 0.f;
+    for (int g = 0; g < a.groups_in; ++g) s += a.part_in[(long)g * a.part_stride + c];
+    a.d_bias[c] = s;
   }
 }
 
@@ -2080,6 +2119,29 @@ int matpbr_mlp_layer_bwd_input_w(const float* g, int ldg, const float* w, int ld
   const int groups = launch_small_nt<EPI_MULC, true>(p, M, (hipStream_t)stream);
   if (d_bias_prev)
     hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_small_bwd_step(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo, float* colsum_out,
+                              int n_prev, const float* x, int ldx, float* d_w, int ldw_out, int K, const float* colsum_in, int colsum_stride,
+                              int groups_in, float* d_bias, long M, int n_red, void* stream) {
+  if (!g || !x || !d_w || M <= 0 || M > kSmallM || n_red <= 0 || n_red > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
+  if ((ldg & 3) || (ldx & 3) || ldg < ((n_red + 3) & ~3) || ldx < ((K + 3) & ~3) || ldw_out < K || !aligned16(g) || !aligned16(x)) return MATPBR_ERR_INVALID_ARG;
+  SmallBwdStep a{};
+  if (w) {
+    if (!c_prev || !g_prev || n_prev <= 0 || n_prev > 256 || ldw < n_prev || ldo < n_prev) return MATPBR_ERR_INVALID_ARG;
+    a.d = NtArgs{g, w, nullptr, c_prev, g_prev, nullptr, colsum_out, (int)M, n_prev, n_red, ldg, ldw, ldo};
+    a.nD = (int)((M + 31) / 32) * ((n_prev + 31) / 32);
+  }
+  a.G = g; a.ldg = ldg; a.X = x; a.ldx = ldx; a.dW = d_w; a.ldw = ldw_out; a.M = (int)M; a.N = n_red; a.K = K;
+  a.nW = ((n_red + 31) / 32) * ((K + 31) / 32);
+  int nB = 0;
+  if (d_bias) {
+    if (!colsum_in || groups_in <= 0 || colsum_stride < n_red) return MATPBR_ERR_INVALID_ARG;
+    a.part_in = colsum_in; a.part_stride = colsum_stride; a.groups_in = groups_in; a.d_bias = d_bias; a.n_bias = n_red;
+    nB = (n_red + 255) / 256;
+  }
+  hipLaunchKernelGGL(mlp_small_bwd_step_kernel, dim3((unsigned)(a.nD + a.nW + nB)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 

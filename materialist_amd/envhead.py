@@ -119,20 +119,28 @@ class EnvMlpPhase:
         self._select_at = len(calls)
         calls.append((lib.matpbr_select_improved, (P(self.best_env_flat), P(self.env), P(self.stats), 0, M * 3)))
         calls.append((lib.matpbr_env_project_bwd, (P(self.y), 4, P(self.proj), P(self.d_light), P(self.g_out), 4, M)))
-        gw, gb = gviews[-1]
-        calls.append((lib.matpbr_column_sum, (P(self.g_out), P(gb), M, 4, None, 0)))
-        calls.append((lib.matpbr_mlp_layer_bwd_weight, (P(self.g_out), 4, P(inps[-1]), inps[-1].stride(0), P(gw), gw.stride(0), None, 0, M,
-                                                        self.n_last, K)))
-        g, ldg, n_red = self.g_out, 4, self.n_last
-        for l in range(self.L - 1, 0, -1):                       # g = dL/d pre of layer l -> dL/d pre of layer l-1 and its bias gradient
-            wp, _ = self.views[l]
-            gw, gb = gviews[l - 1]
-            calls.append((lib.matpbr_mlp_layer_bwd_input_w, (P(g), ldg, P(wp), wp.stride(0), P(self.cbufs[l - 1]), P(self.gbufs[l - 1]),
-                                                             self.gbufs[l - 1].stride(0), P(gb), P(self.ws_in), self.ws_in.numel() * 4, M,
-                                                             ns[l - 1], n_red)))
-            g, ldg, n_red = self.gbufs[l - 1], self.gbufs[l - 1].stride(0), ns[l - 1]
-            calls.append((lib.matpbr_mlp_layer_bwd_weight, (P(g), ldg, P(inps[l - 1]), inps[l - 1].stride(0), P(gw), gw.stride(0), None, 0, M,
-                                                            ns[l - 1], Ks[l - 1])))
+        # backward chain, one launch per layer (matpbr_mlp_small_bwd_step): with g = dL/d pre of a layer in hand, its weight gradient, the input
+        # gradient into the layer below (+ that layer's per-tile column sums) and its own bias gradient (the fold of the column sums the launch
+        # before left; for the output layer the column sums of g itself) are independent pieces of work
+        self.ws_in2 = torch.empty_like(self.ws_in)
+        ws2 = [self.ws_in, self.ws_in2]
+        groups = (M + 31) // 32
+        top = self.L - 1
+        for l in range(top, -1, -1):
+            gw, gb = gviews[l]
+            if l == top:
+                g, ldg, n_red, k_in = self.g_out, 4, self.n_last, K
+                bias_src, bias_stride, bias_groups = self.g_out, 4, M
+            else:
+                g, ldg, n_red, k_in = self.gbufs[l], self.gbufs[l].stride(0), ns[l], Ks[l]
+                bias_src, bias_stride, bias_groups = ws2[(top - l - 1) & 1], 256, groups
+            if l > 0:
+                wp, _ = self.views[l]
+                din = (P(wp), wp.stride(0), P(self.cbufs[l - 1]), P(self.gbufs[l - 1]), self.gbufs[l - 1].stride(0), P(ws2[(top - l) & 1]), ns[l - 1])
+            else:
+                din = (None, 0, None, None, 0, None, 0)
+            calls.append((lib.matpbr_mlp_small_bwd_step, (P(g), ldg) + din + (P(inps[l]), inps[l].stride(0), P(gw), gw.stride(0), k_in, P(bias_src), bias_stride,
+                                                          bias_groups, P(gb), M, n_red)))
         # the update and the step count stop with the image (stats[13] >= 2): the reference breaks right after the stopping iteration (:250-254)
         calls.append((lib.matpbr_adamw_step_snapshot_dev, (P(self.flat), P(self.gflat), P(self.adam_m), P(self.adam_v), self.flat.numel(), P(self.hyper),
                                                            0.9, 0.999, 1e-8, 0.0, None, P(self.stats))))
