@@ -1144,7 +1144,7 @@ int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, 
 
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
     if (H <= 0 || W <= 0 || batch <= 0) return 0;
-    return ((size_t)batch * (grid_blocks(H, W) + lazy_groups((long)H * W)) + (size_t)batch * kRedBlocks * 5 +
+    return ((size_t)batch * (grid_blocks(H, W) + lazy_groups((long)H * W)) + (size_t)batch * step_part_stride(kRedBlocks) +
             2 * (size_t)batch * kStatsStride /* the step kernel's alternating SaveBest / EarlyStopping state */) * sizeof(float);
 }
 
@@ -1200,7 +1200,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     // 2. loss statistics, SaveBest / EarlyStopping decisions (:388-418, misc.py:37-97)
     const int step_rows = kStepRows;
     // [2][B][kStatsStride], at a fixed place (`part` moves with the number of forward sums, which differs between t = 1 and later steps)
-    float* state2 = (float*)q.workspace + (size_t)q.batch * (grid_blocks(q.H, q.W) + lazy_groups(n1)) + (size_t)q.batch * kRedBlocks * 5;
+    float* state2 = (float*)q.workspace + (size_t)q.batch * (grid_blocks(q.H, q.W) + lazy_groups(n1)) + (size_t)q.batch * step_part_stride(kRedBlocks);
     if ((stages & MATPBR_STAGE_STATS) && lazy_fused) {
         // one launch: the partial rows; their fold and the SaveBest / EarlyStopping commit happen at the head of the step kernel
         if (t == 1 && hipMemcpyAsync(state2, q.stats, sizeof(float) * (size_t)q.batch * kStatsStride, hipMemcpyDeviceToDevice, st) != hipSuccess)

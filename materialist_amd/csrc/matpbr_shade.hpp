@@ -468,7 +468,11 @@ __device__ __forceinline__ void stats_commit(float* st, float mse, float l1, flo
     }
 }
 // rows of partial sums the step kernel folds itself (one per workgroup of loss_sums2_kernel<3>), and the stride of an image's block
-constexpr int kStepRows = 768;   // (measured 128 / 256 / 384 / 768: the most rows win at one image and at eight)
+// One value for every batch size, so that an image's statistics do not depend on how many images run beside it (batch = stand-alone
+// bit for bit).  Measured: one 512 x 512 image 128 / 256 / 384 / 768 rows -> 25.9 / 31.0 / 33.3 / 34.1 k it/s (the pass over pred is
+// latency-bound: more rows win); eight images 96 / 192 / 256 / 384 / 768 -> 54.5 / 59.7 / 61.3 / 59.7 / 57.5 k image-it/s (every
+// workgroup of the step kernel folds its image's rows: fewer rows win).
+constexpr int kStepRows = 384;
 __host__ __device__ inline long step_part_stride(int rows) { return (long)rows * 5 + 4; }
 
 // =================================================================================================
