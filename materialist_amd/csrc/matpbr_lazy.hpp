@@ -362,19 +362,26 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
             const float w = wave_sum_to_lane63(v[k]);
             if ((threadIdx.x & 63) == 63) s_fold[threadIdx.x >> 6][k] = w;
         }
-        if (threadIdx.x < kStatsStride) s_state[threadIdx.x] = old[threadIdx.x];
+        float st[kStatsStride];                                // thread 0: the old state in registers (sixteen independent loads, issued
+        const float sp_total = rows[(long)qs.fold_rows * 5];   // before the barrier), the commit on registers, one burst of LDS writes
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < kStatsStride; ++i) st[i] = old[i];
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             float t[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) t[k] = (s_fold[0][k] + s_fold[1][k]) + (s_fold[2][k] + s_fold[3][k]);
-            s_state[kStRatio] = s_state[kStGtSum] / rows[(long)qs.fold_rows * 5];
+            st[kStRatio] = st[kStGtSum] / sp_total;
             const float mse = t[0] * q.inv_n3, l1 = t[1] * q.inv_n3;
             const float la = (q.part_mask & MATPBR_PART_A) ? t[2] * q.inv_n3 : 0.0f;
             const float lr = (q.part_mask & MATPBR_PART_R) ? t[3] * q.inv_n1 : 0.0f;
             const float lm = (q.part_mask & MATPBR_PART_M) ? t[4] * q.inv_n1 : 0.0f;
-            stats_commit(s_state, mse, l1, l1 / mse /* scale_raito, :411 */, la, lr, lm, q.scale_delta, qs.es_patience, qs.es_min_delta,
+            stats_commit(st, mse, l1, l1 / mse /* scale_raito, :411 */, la, lr, lm, q.scale_delta, qs.es_patience, qs.es_min_delta,
                          blockIdx.x == 0 ? qs.history : nullptr, qs.hist_len, qs.batch, b);
+#pragma unroll
+            for (int i = 0; i < kStatsStride; ++i) s_state[i] = st[i];
         }
         __syncthreads();
         if (blockIdx.x == 0 && threadIdx.x < kStatsStride) {

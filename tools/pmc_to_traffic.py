@@ -31,7 +31,7 @@ def bytes_of(tag, kernel, rnd="r03"):
 tj_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 for tag, b in (("b8", 8), ("b1", 1)):
-    for name, kern in (("lazy_step", "matpbr::lazy_step_kernel"), ("loss_sums2", "loss_sums2_kernel<1>")):
+    for name, kern in (("lazy_step", "matpbr::lazy_step_kernel"), ("loss_sums2", "loss_sums2_kernel<")):
         v = bytes_of(tag, kern)
         if v is not None:
             tj[f"{name}_512x512_b{b}_spp64"] = v
