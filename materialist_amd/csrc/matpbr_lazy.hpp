@@ -227,10 +227,17 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
     const uint32_t lohi = ldu(qs.plane[kLzLoHi], o1);
     float Pv[3], SDv[3], S1v[3];
     uint32_t pk[3], sk[3], dk[3];
+    // a part that leaves the roughness alone never moves away from r_ref: the nine planes of slopes (36 of the 80 B/pixel of a model)
+    // multiply r - r_ref = 0 and are not read (uniform branch)
+    const bool slopes = (q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         Pv[c] = as_f(ldu(qs.plane[kLzP + c], o1)); SDv[c] = as_f(ldu(qs.plane[kLzSD + c], o1)); S1v[c] = as_f(ldu(qs.plane[kLzS1 + c], o1));
-        pk[c] = ldu(qs.plane[kLzPk + c], o1); sk[c] = ldu(qs.plane[kLzSk + c], o1); dk[c] = ldu(qs.plane[kLzDk + c], o1);
+        pk[c] = sk[c] = dk[c] = 0u;
+    }
+    if (slopes) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pk[c] = ldu(qs.plane[kLzPk + c], o1); sk[c] = ldu(qs.plane[kLzSk + c], o1); dk[c] = ldu(qs.plane[kLzDk + c], o1); }
     }
     float a[3];
     const float r = fminf(fmaxf(rr, 0.07f), 1.0f), m = fminf(fmaxf(rm, 0.0f), 1.0f);
