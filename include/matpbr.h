@@ -212,9 +212,10 @@ typedef struct MatpbrBrdfPhase {
                                              roughness, normals and light are constants of the part (:317-342): the step with t == 1 walks
                                              the samples and keeps the specular sums here and in `jac`; later steps combine them
                                              (bit-identical render, no samples).  The caller must not touch pr / jac / s1cache in between. */
-    void* lazy_state;                     /* nullable, matpbr_lazy_state_bytes(): when part_mask has MATPBR_PART_R (and dcache is given) the
-                                             render of every step is matpbr_shade_fwd_lazy (the step with t == 1 builds the models) and `jac`
-                                             holds its half-precision planes.  NULL: every step walks the samples of every pixel. */
+    void* lazy_state;                     /* nullable, matpbr_lazy_state_bytes(): with it (and dcache) the render of every step of every part is
+                                             matpbr_shade_fwd_lazy (the step with t == 1 builds the models) and `jac` holds its half-precision
+                                             planes; a part without MATPBR_PART_R never re-samples a pixel after that (s1cache is then not used).
+                                             NULL: every step walks the samples of every pixel (or combines s1cache). */
     float lazy_tol;                       /* scales the interval tolerances of the lazy render; <= 0: 1 */
     float* pred_next;                     /* nullable [B,H,W,3], with lazy_state: the step's last launch is the backward pass + Adam of this iteration AND
                                              the render of the next one from the updated parameters (maps, models and Adam state are read once per
