@@ -404,6 +404,16 @@ int matpbr_mlp_arm_head_fwd(const float* x, int ldx, const float* w, int ldw, co
                             float* map_a, float* map_r, float* map_m, long M, int K, void* stream);
 int matpbr_mlp_arm_head_bwd(const float* g_a, const float* g_r, const float* g_m, const float* th, float* d_x, long M, void* stream);
 size_t matpbr_mlp_skinny_workspace_bytes(int J);
+/* The backward pass of the 'arm' network's OUTPUT layer (mymodels/mlps.py:233-236 under autograd) in one pass over the sines of the last
+ * sine layer, given d_x[M, ldd >= 8] = dL/d(output pre-activations) (J <= 5 valid columns, matpbr_mlp_arm_head_bwd):
+ *   d_w[j * ld_j + c * ld_c] = sum_m d_x[m][j] s_prev[m][c],  d_bias[j] = sum_m d_x[m][j]                  (the layer's own gradients)
+ *   g_prev[m][n] = (sum_j d_x[m][j] w_out[j][n]) * cos(pre_prev[m][n]),  d_bias_prev[n] = sum_m g_prev[m][n], n < n_prev
+ * with cos(pre_prev) = c_prev[M, lds] or, c_prev == NULL, rebuilt from the sign-carrying sines s_prev (matpbr_mlp_layer_fwd_sgn).
+ * = matpbr_mlp_skinny_bwd_weight + matpbr_mlp_layer_bwd_input[_sgn] without reading the 256-wide matrix twice.  All matrices 256
+ * columns wide in memory; workspace of matpbr_mlp_skinny_workspace_bytes(J); deterministic. */
+int matpbr_mlp_out_layer_bwd(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
+                             int ldg, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace, size_t workspace_bytes,
+                             long M, int J, int n_prev, void* stream);
 int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ldb, float* d_w, long ld_j, long ld_c, float* d_bias,
                                  void* workspace, size_t workspace_bytes, long M, int J, int C, void* stream);
 int matpbr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,

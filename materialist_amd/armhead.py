@@ -65,6 +65,7 @@ class ArmMlpPhase:
     """Same interface as `loop.PosMlpBrdfPhase` (step, step_and_check, stats, best, best_img, best_weights, pred, opt.param_groups)."""
 
     PACKED = True     # one float per sine activation (class switch: the tests run both)
+    FUSED_OUT_BWD = True   # the output layer's backward pass in one launch over the last sine layer's activations (class switch)
 
     @staticmethod
     def supported(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> bool:
@@ -229,11 +230,17 @@ class ArmMlpPhase:
                            self.g["metallic"] if "metallic" in live else None, self.th, self.d_x)
         wp, _ = self.views[-1]
         gw, gb = self.gviews[-1]
-        o.mlp_skinny_bwd_weight(self.d_x, self.bufs[-1], gw, 5, 256, d_bias=gb)
-        self.w_out_t[:, :5].copy_(wp.t())
         g_prev = self.gbufs[0]
-        _, gb = self.gviews[self.L - 2]
-        o.mlp_layer_bwd_input(self.d_x, self.w_out_t, self.bufs[-1] if self.packed else self.cbufs[-1], g_prev, self.ns[-1], 5, gb, packed=self.packed)
+        _, gb_prev = self.gviews[self.L - 2]
+        # the output layer in ONE pass over the last sine layer's activations: its weight / bias gradient, dL/d pre of that sine layer and its
+        # bias gradient (separately: a second 268 MB read of the sines, a transposing copy of the output weight, two reduce launches)
+        if self.FUSED_OUT_BWD:
+            o.mlp_out_layer_bwd(self.d_x, self.bufs[-1], None if self.packed else self.cbufs[-1], wp, g_prev, gw, gb, gb_prev, 5, self.ns[-1])
+        else:
+            o.mlp_skinny_bwd_weight(self.d_x, self.bufs[-1], gw, 5, 256, d_bias=gb)
+            self.w_out_t[:, :5].copy_(wp.t())
+            o.mlp_layer_bwd_input(self.d_x, self.w_out_t, self.bufs[-1] if self.packed else self.cbufs[-1], g_prev, self.ns[-1], 5, gb_prev,
+                                  packed=self.packed)
         g, n_red = g_prev, self.ns[-1]
         for l in range(self.L - 2, 0, -1):                       # g = dL/d pre of layer l: its weight gradient, then dL/d pre of layer l-1
             wp, _ = self.views[l]

@@ -1768,12 +1768,14 @@ __global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int til
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+        const bool row_ok = full_rows || row0 + t_row + 8 * ps < p.M;
         if (EPI == EPI_MULC) {
           if (p.cmul_sin) cv[ps] = cos_from_packed_sin(cv[ps]);
           v.x *= cv[ps].x; v.y *= cv[ps].y; v.z *= cv[ps].z; v.w *= cv[ps].w;
+          if (!row_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);   // a row past the end (its cos operand was not read: a packed zero decodes to cos = 1)
           csum[ni].x += v.x; csum[ni].y += v.y; csum[ni].z += v.z; csum[ni].w += v.w;
         }
-        if (full_rows || row0 + t_row + 8 * ps < p.M)
+        if (row_ok)
           store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (ni * 32 + t_col), all_cols);
       }
       if (EPI == EPI_SINCOS && p.out1 != nullptr) {
@@ -1909,9 +1911,19 @@ __global__ __launch_bounds__(256) void arm_head_bwd_kernel(const float* __restri
 // bpart[slab][j] = sum of S[m][j].  Thread (cq, rs): columns 4cq..4cq+3 of B, every 4th row of the slab; the S row is uniform
 // across a wave (scalar loads).  The four row slices are folded through LDS in fixed order.
 constexpr int kSkinnySlabs = 1024;
-template <int J>
+constexpr int kOutJ = 5;                                   // outputs of the 'arm' network's last layer (mymodels/mlps.py:233-236)
+struct SkinnyDgrad {          // the input-gradient half of mlp_skinny_tn_kernel<8, true>
+  const float* W;             // [Jv][ldw] the layer's forward weight (row j = output j, 256 inputs)
+  int ldw, Jv;
+  const float* cmul;          // nullable [M][ldb] cos(pre); null: B holds the sign-packed sines
+  float* G;                   // [M][ldg]
+  int ldg;
+  float* gsum_part;           // [slabs][256]
+};
+template <int J, bool DGRAD = false>
 __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restrict__ S, int lds, const float* __restrict__ B, int ldb,
-                                                            float* __restrict__ partial, float* __restrict__ bpart, long M, long rows_per_slab) {
+                                                            float* __restrict__ partial, float* __restrict__ bpart, long M, long rows_per_slab,
+                                                            const SkinnyDgrad dg) {
   __shared__ float red[3][8][256];                         // the fold runs 8 columns of S at a time (24 KB: four workgroups per CU)
   __shared__ float bred[4][J];
   const int cq = threadIdx.x & 63, rs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1921,6 +1933,14 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
   float bs[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) { acc[j] = make_float4(0.f, 0.f, 0.f, 0.f); bs[j] = 0.f; }
+  // DGRAD (the output layer of the 'arm' network, J = 8, 5 valid): the same pass over the wide matrix B = sines of the last sine layer also
+  // forms that layer's pre-activation gradient G[m][n] = (sum_j S[m][j] W[j][n]) cos(pre[m][n]) and its column sums -- a K = 5 product
+  // is five FMAs per element, and the separate input-gradient pass read the 268 MB of sines a second time
+  float4 wv[DGRAD ? kOutJ : 1], gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (DGRAD) {
+#pragma unroll
+    for (int j = 0; j < kOutJ; ++j) wv[j] = j < dg.Jv ? *reinterpret_cast<const float4*>(dg.W + (size_t)j * dg.ldw + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   constexpr int U = 4;
   for (long m0 = m_begin + rs; m0 < m_end; m0 += 4 * U) {
     float4 b[U];
@@ -1934,6 +1954,7 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
       const long m = m0 + 4 * u < m_end ? m0 + 4 * u : m_end - 1;   // past the end: b is zero, any finite row of S will do
       const float* srow = S + m * lds;
       const bool live = m0 + 4 * u < m_end;
+      float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const float sv = srow[j];
@@ -1942,8 +1963,30 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
         acc[j].z = fmaf(sv, b[u].z, acc[j].z);
         acc[j].w = fmaf(sv, b[u].w, acc[j].w);
         bs[j] += live ? sv : 0.f;
+        if (DGRAD && j < kOutJ) {
+          dot.x = fmaf(sv, wv[j].x, dot.x); dot.y = fmaf(sv, wv[j].y, dot.y); dot.z = fmaf(sv, wv[j].z, dot.z); dot.w = fmaf(sv, wv[j].w, dot.w);
+        }
+      }
+      if (DGRAD && live) {
+        const float4 c = dg.cmul ? *reinterpret_cast<const float4*>(dg.cmul + m * ldb + 4 * cq) : cos_from_packed_sin(b[u]);
+        const float4 gv = make_float4(dot.x * c.x, dot.y * c.y, dot.z * c.z, dot.w * c.w);
+        *reinterpret_cast<float4*>(dg.G + m * dg.ldg + 4 * cq) = gv;
+        gsum.x += gv.x; gsum.y += gv.y; gsum.z += gv.z; gsum.w += gv.w;
       }
     }
+  }
+  if (DGRAD) {                                             // column sums of G over the slab: the four row-waves in fixed order
+    if (rs > 0) *reinterpret_cast<float4*>(&red[rs - 1][0][4 * cq]) = gsum;
+    __syncthreads();
+    if (rs == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 o = *reinterpret_cast<const float4*>(&red[q][0][4 * cq]);
+        gsum.x += o.x; gsum.y += o.y; gsum.z += o.z; gsum.w += o.w;
+      }
+      *reinterpret_cast<float4*>(dg.gsum_part + (size_t)blockIdx.x * 256 + 4 * cq) = gsum;
+    }
+    __syncthreads();
   }
   if (cq == 0) {
 #pragma unroll
@@ -1977,9 +2020,14 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
 // out[j * ld_j + c * ld_c] = sum over slabs of partial[slab][j][c] (j < Jv, c < C); d_b[j] = sum of bpart[slab][j].  One
 // workgroup per (j, 64 columns): 16 slab slices x 64 columns, fixed order.
 __global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __restrict__ partial, const float* __restrict__ bpart, int slabs, int J, int Jv,
-                                                             int C, float* __restrict__ out, long ld_j, long ld_c, float* __restrict__ d_b) {
+                                                             int C, float* __restrict__ out, long ld_j, long ld_c, float* __restrict__ d_b,
+                                                             const float* __restrict__ gsum_part, int C2, float* __restrict__ d_b2) {
   __shared__ float red[16][64];
-  const int j = blockIdx.x >> 2, cl = threadIdx.x & 63, c = (blockIdx.x & 3) * 64 + cl, sl = threadIdx.x >> 6;
+  int j = blockIdx.x >> 2;
+  const int cl = threadIdx.x & 63, c = (blockIdx.x & 3) * 64 + cl, sl = threadIdx.x >> 6;
+  if (j == J) {                                              // the extra workgroups: column sums of the fused input gradient -> its bias gradient
+    partial = gsum_part; J = 1; j = 0; Jv = 1; C = C2; out = d_b2; ld_j = 0; ld_c = 1; d_b = nullptr;
+  }
   if (j >= Jv) return;                                       // uniform per workgroup
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int q = sl;
@@ -2330,7 +2378,9 @@ int matpbr_mlp_arm_head_bwd(const float* g_a, const float* g_r, const float* g_m
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
-size_t matpbr_mlp_skinny_workspace_bytes(int J) { return J > 0 && J <= 16 ? (size_t)kSkinnySlabs * ((J + 7) / 8 * 8) * 257 * sizeof(float) : 0; }
+size_t matpbr_mlp_skinny_workspace_bytes(int J) {   // slab partials [slabs][JP][256], bias partials [slabs][JP], column sums of the fused input gradient [slabs][256]
+  return J > 0 && J <= 16 ? (size_t)kSkinnySlabs * (((J + 7) / 8 * 8) * 257 + 256) * sizeof(float) : 0;
+}
 
 int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ldb, float* d_w, long ld_j, long ld_c, float* d_bias, void* workspace,
                                  size_t workspace_bytes, long M, int J, int C, void* stream) {
@@ -2343,10 +2393,31 @@ int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ld
   const int slabs = (int)((M + rows - 1) / rows);
   float* partial = (float*)workspace;
   float* bpart = partial + (size_t)kSkinnySlabs * JP * 256;
-  if (JP == 8) hipLaunchKernelGGL(mlp_skinny_tn_kernel<8>, dim3(slabs), dim3(256), 0, (hipStream_t)stream, s, lds, b, ldb, partial, bpart, M, rows);
-  else hipLaunchKernelGGL(mlp_skinny_tn_kernel<16>, dim3(slabs), dim3(256), 0, (hipStream_t)stream, s, lds, b, ldb, partial, bpart, M, rows);
+  if (JP == 8) hipLaunchKernelGGL((mlp_skinny_tn_kernel<8>), dim3(slabs), dim3(256), 0, (hipStream_t)stream, s, lds, b, ldb, partial, bpart, M, rows, SkinnyDgrad{});
+  else hipLaunchKernelGGL((mlp_skinny_tn_kernel<16>), dim3(slabs), dim3(256), 0, (hipStream_t)stream, s, lds, b, ldb, partial, bpart, M, rows, SkinnyDgrad{});
   hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(JP * 4), dim3(1024), 0, (hipStream_t)stream, (const float*)partial, (const float*)bpart, slabs, JP, J, C, d_w,
-                     ld_j, ld_c, d_bias);
+                     ld_j, ld_c, d_bias, (const float*)nullptr, 0, (float*)nullptr);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_out_layer_bwd(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
+                             int ldg, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace, size_t workspace_bytes,
+                             long M, int J, int n_prev, void* stream) {
+  if (!d_x || !s_prev || !w_out || !g_prev || !d_w || M <= 0 || J <= 0 || J > kOutJ || n_prev <= 0 || n_prev > 256) return MATPBR_ERR_INVALID_ARG;
+  if (ldd < 8 || lds < 256 || (lds & 3) || ldg < 256 || (ldg & 3) || ldw < 256 || (ldw & 3) || !aligned16(s_prev) || !aligned16(g_prev) || !aligned16(w_out) ||
+      (c_prev && !aligned16(c_prev)))
+    return MATPBR_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < matpbr_mlp_skinny_workspace_bytes(J)) return MATPBR_ERR_WORKSPACE;
+  long rows = (M + kSkinnySlabs - 1) / kSkinnySlabs;
+  rows = (rows + 3) / 4 * 4;
+  const int slabs = (int)((M + rows - 1) / rows);
+  float* partial = (float*)workspace;
+  float* bpart = partial + (size_t)kSkinnySlabs * 8 * 256;
+  float* gsum_part = bpart + (size_t)kSkinnySlabs * 8;
+  SkinnyDgrad dg{w_out, ldw, J, c_prev, g_prev, ldg, gsum_part};
+  hipLaunchKernelGGL((mlp_skinny_tn_kernel<8, true>), dim3(slabs), dim3(256), 0, (hipStream_t)stream, d_x, ldd, s_prev, lds, partial, bpart, M, rows, dg);
+  hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(8 * 4 + (d_bias_prev ? 4 : 0)), dim3(1024), 0, (hipStream_t)stream, (const float*)partial, (const float*)bpart, slabs, 8,
+                     J, 256, d_w, ld_j, ld_c, d_bias, (const float*)gsum_part, n_prev, d_bias_prev);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 

@@ -779,6 +779,24 @@ def mlp_skinny_bwd_weight(s: torch.Tensor, b: torch.Tensor, d_w: torch.Tensor, J
     _lib.check(code, "matpbr_mlp_skinny_bwd_weight")
 
 
+def mlp_out_layer_bwd(d_x: torch.Tensor, s_prev: torch.Tensor, c_prev: Optional[torch.Tensor], w_out: torch.Tensor, g_prev: torch.Tensor,
+                      d_w: torch.Tensor, d_bias: Optional[torch.Tensor], d_bias_prev: Optional[torch.Tensor], J: int, n_prev: int) -> None:
+    """The output layer's backward pass in one pass over the sines of the last sine layer (include/matpbr.h `matpbr_mlp_out_layer_bwd`):
+    the layer's weight / bias gradient, the pre-activation gradient of the layer below and that layer's bias gradient.  c_prev None: s_prev
+    holds the sign-carrying sines."""
+    lib = _lib.load()
+    s_prev, g_prev = _mat2(s_prev, "s_prev"), _mat2(g_prev, "g_prev")
+    M = s_prev.shape[0]
+    if c_prev is not None and _mat2(c_prev, "c_prev").stride(0) != s_prev.stride(0):
+        raise ValueError("mlp_out_layer_bwd: c_prev and s_prev must share their row stride")
+    ws = _mlp_workspace("skinny%d" % ((J + 7) // 8), 0, s_prev.device, lib.matpbr_mlp_skinny_workspace_bytes(J))
+    with torch.cuda.device(s_prev.device):
+        code = lib.matpbr_mlp_out_layer_bwd(_ptr(d_x), d_x.stride(0), _ptr(s_prev), _ptr(c_prev), s_prev.stride(0), _ptr(w_out), w_out.stride(0),
+                                            _ptr(g_prev), g_prev.stride(0), _ptr(d_w), d_w.stride(0), 1, _ptr(d_bias), _ptr(d_bias_prev), _ptr(ws),
+                                            ws.numel() * 4, M, int(J), int(n_prev), _stream(s_prev))
+    _lib.check(code, "matpbr_mlp_out_layer_bwd")
+
+
 LIGHT_SH9, LIGHT_ENV_TEXELS = 1, 2
 
 

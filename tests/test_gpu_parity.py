@@ -1045,6 +1045,45 @@ def test_use_mask_none_mode_phase_matches_the_torch_composition(part):
     assert int(ph.poll()["iters"][0]) == 6
 
 
+@pytest.mark.parametrize("packed", [True, False])
+def test_output_layer_backward_in_one_pass_equals_the_separate_kernels(packed):
+    """matpbr_mlp_out_layer_bwd (weight / bias gradient of the 5-output layer, dL/d pre of the last sine layer and its bias gradient in one
+    pass over that layer's sines) against matpbr_mlp_skinny_bwd_weight + matpbr_mlp_layer_bwd_input on the same operands, and against fp64."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    M, n_prev = 128 * 128 + 4 * 37, 241                    # ragged tiles and slabs, a skip layer's width
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    pre = (torch.randn(M, 256, generator=gen) * 3).to(dev)
+    sin, cos = torch.sin(pre), torch.cos(pre)
+    s_buf = torch.empty(M, 256, device=dev)
+    if packed:                                             # sines that carry the sign of their cosine in the last mantissa bit, as the forward kernels store them
+        bits = (sin.view(torch.int32) & ~1) | (cos < 0).to(torch.int32)
+        s_buf.copy_(bits.view(torch.float32))
+    else:
+        s_buf.copy_(sin)
+    d_x = torch.zeros(M, 8, device=dev)
+    d_x[:, :5] = torch.randn(M, 5, generator=gen).to(dev)
+    w_out = (torch.randn(5, 256, generator=gen) * 0.1).to(dev)
+    g_new, gw_new, gb_new, gbp_new = torch.empty(M, 256, device=dev), torch.empty(5, 256, device=dev), torch.empty(8, device=dev), torch.empty(256, device=dev)
+    ops.mlp_out_layer_bwd(d_x, s_buf, None if packed else cos.contiguous(), w_out, g_new, gw_new, gb_new, gbp_new, 5, n_prev)
+    # the separate kernels
+    g_old, gw_old, gb_old, gbp_old = torch.empty(M, 256, device=dev), torch.empty(5, 256, device=dev), torch.empty(8, device=dev), torch.empty(256, device=dev)
+    ops.mlp_skinny_bwd_weight(d_x, s_buf, gw_old, 5, 256, d_bias=gb_old)
+    w_t = torch.zeros(256, 8, device=dev)
+    w_t[:, :5] = w_out.t()
+    ops.mlp_layer_bwd_input(d_x, w_t, s_buf if packed else cos.contiguous(), g_old, n_prev, 5, gbp_old, packed=packed)
+    assert torch.equal(gw_new, gw_old) and torch.equal(gb_new[:5], gb_old[:5])          # the same pass, the same order
+    ref_g = (d_x[:, :5].double() @ w_out.double()) * cos.double()
+    scale = float(ref_g.abs().max())
+    tol = 3e-6 if not packed else 2e-4                     # packed: |cos| rebuilt from 1 - s^2 (error ~1.5e-7 / |cos|)
+    assert (g_new[:, :n_prev].double() - ref_g[:, :n_prev]).abs().max().item() <= tol * scale
+    assert (g_new[:, :n_prev] - g_old[:, :n_prev]).abs().max().item() <= tol * scale
+    ref_b = ref_g[:, :n_prev].sum(0)
+    assert (gbp_new[:n_prev].double() - ref_b).abs().max().item() <= 1e-5 * float(ref_b.abs().max()) + 5 * tol * scale * M ** 0.5   # a sum of M rounded terms
+    assert (gbp_new[:n_prev] - gbp_old[:n_prev]).abs().max().item() <= 1e-4 * float(ref_b.abs().max())
+
+
 def test_arm_mlp_phase_network_gradients_match_autograd():
     """The network half of ArmMlpPhase on its own, where nothing is chaotic: forward() against the reference module's maps, and
     backward() fed with given map gradients against torch autograd through the reference network (the straight-through clamp has
