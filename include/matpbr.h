@@ -339,6 +339,16 @@ size_t matpbr_mlp_wsplit_bytes(int K);
 int matpbr_mlp_split_weights(const float* w, int ldw, int N, int K, void* wsplit, void* stream);
 int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo, long M,
                             int N, int K, int nprod, void* stream);
+/* The backward pass INTO the first layer of the network on the split-operand kernel, without materialising dL/d pre of that layer
+ * (G0 = (g wt) * cos(pre0), [M, n0]): its only consumers are formed in the epilogue --
+ *   d_w0[k * ld_j + n * ld_c] = sum_m G0[m][n] x0[m][k]   (k < d0 <= 16: the network's input rows x0[M, ldx0 >= 16], zero beyond d0)
+ *   d_bias0[n]                = sum_m G0[m][n]
+ * = matpbr_mlp_layer_bwd_input_bx[_sgn] + matpbr_mlp_skinny_bwd_weight without the 268 MB store and re-read of G0 (512 x 512).
+ * c_prev[M, ldc]: cos(pre0), or with sgn != 0 the sign-carrying sines of the first layer.  workspace: matpbr_mlp_bwd_input_workspace_bytes
+ * (only with d_bias0); workspace2: matpbr_mlp_skinny_workspace_bytes(16).  M a multiple of 128.  Deterministic. */
+int matpbr_mlp_first_layer_bwd_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, int ldc, int sgn, const float* x0, int ldx0,
+                                  float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes, void* workspace2,
+                                  size_t workspace2_bytes, long M, int n0, int n_red, int nprod, void* stream);
 int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo,
                                   float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
                                   int nprod, void* stream);

@@ -143,6 +143,9 @@ SIGNATURES = {
     "matpbr_mlp_out_layer_bwd": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_long,
                                                 ctypes.c_long, _c_f, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_void_p]),
+    "matpbr_mlp_first_layer_bwd_bx": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, _c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_long,
+                                                     ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                                     ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_masked_mean_fill": (ctypes.c_int, [_c_f, ctypes.c_void_p, _c_f, ctypes.c_float, ctypes.c_float, _c_f, ctypes.c_long, ctypes.c_int,
                                                ctypes.c_void_p]),
     "matpbr_normals_from_depth": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),

@@ -66,6 +66,7 @@ class ArmMlpPhase:
 
     PACKED = True     # one float per sine activation (class switch: the tests run both)
     FUSED_OUT_BWD = True   # the output layer's backward pass in one launch over the last sine layer's activations (class switch)
+    FUSED_FIRST_BWD = True # the first layer's weight / bias gradient from the epilogue of the input-gradient kernel above it (class switch)
 
     @staticmethod
     def supported(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> bool:
@@ -247,10 +248,14 @@ class ArmMlpPhase:
             gw, _ = self.gviews[l]
             o.mlp_layer_bwd_weight_bx(g, self.bufs[l - 1], n_red, 256, P, out=gw)
             n_prev = self.ns[l - 1]
-            g_prev = self.gbufs[0] if g is self.gbufs[1] else self.gbufs[1]
             _, gb = self.gviews[l - 1]
-            o.mlp_layer_bwd_input_bx(g, self.wsplit_b[l], self.bufs[l - 1] if self.packed else self.cbufs[l - 1], g_prev, n_prev, n_red, gb, P,
-                                     packed=self.packed)
+            c_prev = self.bufs[l - 1] if self.packed else self.cbufs[l - 1]
+            if l == 1 and self.FUSED_FIRST_BWD:
+                # into the first layer: its pre-activation gradient is not stored, the same launch forms its weight and bias gradient
+                o.mlp_first_layer_bwd_bx(g, self.wsplit_b[l], c_prev, self.x0p, self.gviews[0][0], self.d0, n_prev, n_red, gb, P, packed=self.packed)
+                return
+            g_prev = self.gbufs[0] if g is self.gbufs[1] else self.gbufs[1]
+            o.mlp_layer_bwd_input_bx(g, self.wsplit_b[l], c_prev, g_prev, n_prev, n_red, gb, P, packed=self.packed)
             g, n_red = g_prev, n_prev
         gw, _ = self.gviews[0]
         o.mlp_skinny_bwd_weight(self.x0p, g, gw, self.d0, n_red, transposed_out=True)

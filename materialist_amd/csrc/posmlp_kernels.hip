@@ -164,6 +164,9 @@ struct NtArgs {
   const float* tail;   // nullable [M, ldt]: the values that belong in columns N.. of out0 (x0 of a skip layer).  Given: the epilogue
   int ldt;             // stores whole 16-byte words over them and the caller rewrites them (mlp_tail_copy_kernel); null: they are guarded
   int cmul_sin;        // EPI_MULC: `cmul` holds the SINES of the layer below with the sign of their cosine in the last mantissa bit
+  const float* x0;     // mlp_nt_bx<.., W0>: [M, ldx0 >= 16] the network's input rows (columns beyond d0 zero)
+  int ldx0;
+  float* w0_part;      // mlp_nt_bx<.., W0>: [4 gridDim.x][16][256] partial first-layer weight gradients (the layout of the skinny kernels)
 };
 
 // One float per sine activation instead of two.  The backward pass needs cos(pre) of every hidden unit; sin and cos lie on the unit circle,
@@ -1250,7 +1253,13 @@ constexpr int kBxThreads = 512;
 // 128 rows -- each lane dots the 16-byte words of sines it is about to store with the matching weights (from a 5 KB LDS image), an
 // 8-lane DPP fold and one LDS exchange between the two column halves complete the rows -- and runs the 'arm' head on them: the
 // separate pass over the 268 MB of sines (76 us at 512 x 512) disappears.
-template <int EPI, int NPROD, bool FULL, bool HEAD = false>   // FULL: all 256 output columns exist (N == 256): unguarded 16-byte stores
+// W0 (EPI_MULC, the input gradient INTO THE FIRST LAYER): G' is not stored -- its only consumers are the first layer's bias gradient (the
+// column sums, formed here anyway) and weight gradient dW0[n][k] = sum_m G'[m][n] x0[m][k], k < 16, which the epilogue accumulates
+// itself: each 32 x 32 block of G' sits in the wave's LDS slice for the transposition, the wave's 32 rows of x0 beside it, and sixteen
+// v_mfma_f32_16x16x4f32 per block fold them into 8 x 4 accumulator registers per wave.  Saves the 268 MB store, the 268 MB read of the
+// skinny weight-gradient pass and its launch.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int EPI, int NPROD, bool FULL, bool HEAD = false, bool W0 = false>   // FULL: all 256 output columns exist (N == 256): unguarded 16-byte stores
 __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const uint4* __restrict__ wsplit, const HeadArgs hd) {
   extern __shared__ __align__(16) unsigned char bx_smem[];
   uint4* sB = reinterpret_cast<uint4*>(bx_smem);                         // [2 buffers][kBxStage]
@@ -1258,6 +1267,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
   float* sRed = reinterpret_cast<float*>(bx_smem);                       // [32][256] after the last tile (aliases sB)
   float* sW4 = sScr + 8 * 32 * kLd;                                      // HEAD: [5][256] output-layer weights
   float* sComb = sW4 + 5 * 256;                                          // HEAD: [128 rows][2 column halves][8]
+  float* sX0 = sScr + 8 * 32 * kLd;                     // W0: [8 waves][32 rows][16]  (HEAD and W0 never meet)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int nks = (p.K + 31) / 32;
@@ -1265,6 +1275,13 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
   constexpr int kCopy = kBxStage / kBxThreads;                           // uint4 per thread and super-step of the weight stream
   float bn[4];
   float4 csum4[4];
+  f32x4v acc0[4][2];                                                     // W0: dW0 of this wave's rows: [column block][16-column half], a 16 x 16 tile each
+  if (W0) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc0[ni][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int n = wn * 128 + ni * 32 + li;
@@ -1355,6 +1372,13 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
     float* scr = sScr + wave * (32 * kLd);
     const int t_row = lane >> 3, t_col = (lane & 7) * 4;
     const size_t tile_row = (size_t)(row0 + wm * 32 + t_row) * p.ldo;
+    float* sx = sX0 + wave * (32 * 16);
+    if (W0) {                                                 // this wave's 32 rows of x0: lane = (row, half)
+      const float* xs = p.x0 + (size_t)(row0 + wm * 32 + (lane >> 1)) * p.ldx0 + 8 * (lane & 1);
+      const float4 xa = *reinterpret_cast<const float4*>(xs), xb = *reinterpret_cast<const float4*>(xs + 4);
+      *reinterpret_cast<float4*>(sx + (lane >> 1) * 16 + 8 * (lane & 1)) = xa;
+      *reinterpret_cast<float4*>(sx + (lane >> 1) * 16 + 8 * (lane & 1) + 4) = xb;
+    }
     float hacc[4][5];
     if (HEAD) {
 #pragma unroll
@@ -1396,6 +1420,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
             v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
             csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
           }
+          if (W0) *reinterpret_cast<float4*>(scr + (t_row + 8 * ps) * kLd + t_col) = v;   // G' back into the block, for the product below
           if (HEAD) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -1403,7 +1428,15 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
               hacc[ps][j] = __builtin_fmaf(v.x, w4.x, __builtin_fmaf(v.y, w4.y, __builtin_fmaf(v.z, w4.z, __builtin_fmaf(v.w, w4.w, hacc[ps][j]))));
             }
           }
-          store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);
+          if (!W0) store4_upto(p.out0 + o0 + (size_t)(8 * ps) * p.ldo, v, p.N - (wn * 128 + ni * 32 + t_col), FULL || wn * 128 + ni * 32 + 32 <= p.N);
+        }
+        if (W0) {     // dW0[16 ct + i][j] += sum over the block's 32 rows of G'[row][16 ct + i] x0[row][j]  (A: lane = (i, k), B: lane = (j, k))
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+              acc0[ni][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(scr[(4 * kk + (lane >> 4)) * kLd + 16 * ct + (lane & 15)],
+                                                                  sx[(4 * kk + (lane >> 4)) * 16 + (lane & 15)], acc0[ni][ct], 0, 0, 0);
         }
         if (EPI == EPI_SINCOS && p.out1 != nullptr) {
 #pragma unroll
@@ -1436,6 +1469,16 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
       }
       // sComb is written again at the end of the next tile, eight barriers from here
     }
+  }
+  if (W0) {                                                   // lane holds dW0[n = .. + 4 (lane >> 4) + r][k = lane & 15]
+    const size_t slab = (size_t)blockIdx.x * 4 + wm;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          p.w0_part[(slab * 16 + (lane & 15)) * 256 + wn * 128 + ni * 32 + 16 * ct + 4 * (lane >> 4) + r] = acc0[ni][ct][r];
   }
   if (EPI == EPI_MULC && p.colsum != nullptr) {
     const int t_row = lane >> 3, t_col = (lane & 7) * 4;
@@ -1618,6 +1661,13 @@ template <int EPI, int NPROD, bool FULL>
 bool launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
   if (!lds_opt_in<&mlp_nt_bx<EPI, NPROD, FULL>>(kBxSmem)) return false;
   hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD, FULL>), dim3(grid), dim3(kBxThreads), kBxSmem, stream, p, wsplit, HeadArgs{});
+  return true;
+}
+constexpr size_t kBxSmemW0 = kBxSmem + 8 * 32 * 16 * sizeof(float);                          // + the waves' rows of x0
+template <int NPROD>
+bool launch_nt_bx_w0(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
+  if (!lds_opt_in<&mlp_nt_bx<EPI_MULC, NPROD, true, false, true>>(kBxSmemW0)) return false;
+  hipLaunchKernelGGL((mlp_nt_bx<EPI_MULC, NPROD, true, false, true>), dim3(grid), dim3(kBxThreads), kBxSmemW0, stream, p, wsplit, HeadArgs{});
   return true;
 }
 template <int NPROD>
@@ -2276,6 +2326,28 @@ static int mlp_layer_bwd_input_bx_impl(const float* g, int ldg, const void* wtsp
   if (groups < 0) return MATPBR_ERR_LAUNCH;
   if (d_bias_prev)
     hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_first_layer_bwd_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, int ldc, int sgn, const float* x0, int ldx0,
+                                  float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes, void* workspace2,
+                                  size_t workspace2_bytes, long M, int n0, int n_red, int nprod, void* stream) {
+  if (!g || !wtsplit || !c_prev || !x0 || !d_w0 || M <= 0 || n0 <= 0 || n0 > 256 || n_red <= 0 || n_red > 256 || d0 <= 0 || d0 > 16) return MATPBR_ERR_INVALID_ARG;
+  if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldc < 256 || (ldc & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || ldx0 < 16 || (ldx0 & 3) ||
+      !aligned16(g) || !aligned16(c_prev) || !aligned16(x0))
+    return MATPBR_ERR_UNSUPPORTED;
+  if (d_bias0 && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
+  if (!workspace2 || workspace2_bytes < matpbr_mlp_skinny_workspace_bytes(16)) return MATPBR_ERR_WORKSPACE;
+  NtArgs p{g, nullptr, nullptr, c_prev, nullptr, nullptr, d_bias0 ? (float*)workspace : nullptr, (int)M, n0, n_red, ldg, 0, ldc};
+  p.cmul_sin = sgn;
+  p.x0 = x0; p.ldx0 = ldx0; p.w0_part = (float*)workspace2;
+  const int tiles = (int)(M / kBM);
+  const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+  const bool ok = nprod == 9 ? launch_nt_bx_w0<9>(p, (const uint4*)wtsplit, grid, (hipStream_t)stream) : launch_nt_bx_w0<6>(p, (const uint4*)wtsplit, grid, (hipStream_t)stream);
+  if (!ok) return MATPBR_ERR_LAUNCH;
+  if (d_bias0) hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n0), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid, d_bias0);
+  hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(16 * 4), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace2, (const float*)nullptr, (int)grid * 4, 16, d0, n0,
+                     d_w0, ld_j, ld_c, (float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 

@@ -703,6 +703,22 @@ def mlp_layer_bwd_input_bx(g: torch.Tensor, wtsplit: torch.Tensor, c_prev: torch
     _lib.check(code, "matpbr_mlp_layer_bwd_input_bx")
 
 
+def mlp_first_layer_bwd_bx(g: torch.Tensor, wtsplit: torch.Tensor, c_prev: torch.Tensor, x0: torch.Tensor, d_w0: torch.Tensor, d0: int, n0: int, n_red: int,
+                           d_bias0: Optional[torch.Tensor], nprod: int = 6, packed: bool = False) -> None:
+    """The backward pass into the first layer without its pre-activation gradient in memory (include/matpbr.h `matpbr_mlp_first_layer_bwd_bx`):
+    d_w0 [n0, >= d0] (row n, column k) and d_bias0 [n0] from g = dL/d pre of the second layer.  x0 [M, >= 16] zero beyond d0."""
+    lib = _lib.load()
+    g, c_prev, x0 = _mat2(g, "g"), _mat2(c_prev, "c_prev"), _mat2(x0, "x0")
+    M = g.shape[0]
+    ws = _mlp_workspace("bwd_input", M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
+    ws2 = _mlp_workspace("skinny2", 0, g.device, lib.matpbr_mlp_skinny_workspace_bytes(16))
+    with torch.cuda.device(g.device):
+        code = lib.matpbr_mlp_first_layer_bwd_bx(_ptr(g), g.stride(0), _ptr(wtsplit), _ptr(c_prev), c_prev.stride(0), 1 if packed else 0, _ptr(x0), x0.stride(0),
+                                                 _ptr(d_w0), 1, d_w0.stride(0), int(d0), _ptr(d_bias0), _ptr(ws), ws.numel() * 4, _ptr(ws2), ws2.numel() * 4,
+                                                 M, int(n0), int(n_red), int(nprod), _stream(g))
+    _lib.check(code, "matpbr_mlp_first_layer_bwd_bx")
+
+
 def mlp_layer_bwd_weight(g: torch.Tensor, x: torch.Tensor, N: int, K: int) -> torch.Tensor:
     """d_w [N, K] = g[:, :N]^T x[:, :K] over all rows (deterministic slab partials)."""
     lib = _lib.load()

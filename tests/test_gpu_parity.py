@@ -1084,6 +1084,41 @@ def test_output_layer_backward_in_one_pass_equals_the_separate_kernels(packed):
     assert (gbp_new[:n_prev] - gbp_old[:n_prev]).abs().max().item() <= 1e-4 * float(ref_b.abs().max())
 
 
+@pytest.mark.parametrize("packed", [True, False])
+def test_first_layer_backward_without_its_pre_activation_gradient_in_memory(packed):
+    """matpbr_mlp_first_layer_bwd_bx (the first layer's weight and bias gradient from the epilogue of the split-operand input-gradient
+    kernel above it) against matpbr_mlp_layer_bwd_input_bx + matpbr_mlp_skinny_bwd_weight on the same operands, and against fp64."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    M, n0, n_red, d0 = 128 * 131, 256, 256, 15
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    g = torch.randn(M, 256, generator=gen).to(dev)
+    w1 = (torch.randn(n_red, 256, generator=gen) / 16).to(dev)          # the second layer's forward weight [n_red, K = n0]
+    pre0 = (torch.randn(M, 256, generator=gen) * 3).to(dev)
+    sin, cos = torch.sin(pre0), torch.cos(pre0)
+    c_op = torch.empty(M, 256, device=dev)
+    if packed:
+        c_op.copy_(((sin.view(torch.int32) & ~1) | (cos < 0).to(torch.int32)).view(torch.float32))
+    else:
+        c_op.copy_(cos)
+    x0 = torch.zeros(M, 16, device=dev)
+    x0[:, :d0] = torch.randn(M, d0, generator=gen).to(dev)
+    wts = ops.mlp_split_weights(w1, n0, n_red, transposed=True)          # (W1[:, :n0])^T as the input-gradient operand
+    gw_new, gb_new = torch.zeros(n0, 16, device=dev), torch.empty(n0, device=dev)
+    ops.mlp_first_layer_bwd_bx(g, wts, c_op, x0, gw_new, d0, n0, n_red, gb_new, 6, packed=packed)
+    g0, gb_old, gw_old = torch.empty(M, 256, device=dev), torch.empty(n0, device=dev), torch.zeros(n0, 16, device=dev)
+    ops.mlp_layer_bwd_input_bx(g, wts, c_op, g0, n0, n_red, gb_old, 6, packed=packed)
+    ops.mlp_skinny_bwd_weight(x0, g0, gw_old, d0, n0, transposed_out=True)
+    assert torch.equal(gb_new, gb_old)                                   # the same epilogue sums
+    ref_g0 = (g.double() @ w1.double()) * cos.double()
+    ref_w = ref_g0.t() @ x0.double()[:, :d0]
+    scale = float(ref_w.abs().max())
+    assert (gw_new[:, :d0].double() - ref_w).abs().max().item() <= 2e-5 * scale
+    assert (gw_new[:, :d0] - gw_old[:, :d0]).abs().max().item() <= 2e-5 * scale
+    assert float(gw_new[:, d0:].abs().max()) == 0.0                      # the padding column is never written
+
+
 def test_arm_mlp_phase_network_gradients_match_autograd():
     """The network half of ArmMlpPhase on its own, where nothing is chaotic: forward() against the reference module's maps, and
     backward() fed with given map gradients against torch autograd through the reference network (the straight-through clamp has
