@@ -56,19 +56,20 @@ __global__ __launch_bounds__(kBlock) void loss_final1_kernel(const float* __rest
 }
 // pass 2: sum (xs-gs)^2, sum |xs-gs| over [H,W,3]; sum |a-a0| over [H,W,3]; sum |r-r0|, |m-m0| over [H,W]
 // FROM_FWD: ratio is formed here from the forward kernel's per-workgroup sums and the stored sum(gt) (no pass 1).
-template <int MODE>   // 0: ratio from stats (piecewise API); 1: BRDF phase step (ratio from the forward sums); 3: the same, folded by the step kernel
+template <int MODE>   // 0: ratio from stats (piecewise API); 1: BRDF phase step (ratio from the forward sums); 3: the same, folded by the step kernel; 4: as 3 with the regulariser sums carried by the step kernel (its per-workgroup sums are folded here by workgroup 0)
 __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restrict__ pred, const float* __restrict__ gt_srgb,
                                                             const float* __restrict__ stats, const float* __restrict__ pa,
                                                             const float* __restrict__ a0, const float* __restrict__ pr,
                                                             const float* __restrict__ r0, const float* __restrict__ pm,
                                                             const float* __restrict__ m0, float* __restrict__ part, long n3, long n1,
-                                                            const float* __restrict__ fwd_sums, int n_fwd, unsigned part_mask) {
+                                                            const float* __restrict__ fwd_sums, int n_fwd, unsigned part_mask,
+                                                            const float* __restrict__ reg_sums = nullptr) {
     __shared__ float s_buf[4];
     const int b = blockIdx.y;
     float ratio = 1.0f;
     if (MODE >= 1 && img_stopped(stats, b)) return;
     float sp_total = 0.0f;
-    if (MODE == 1 || MODE == 3) {
+    if (MODE == 1 || MODE >= 3) {
         float sp = 0.0f;
         for (int i = threadIdx.x; i < n_fwd; i += kBlock) sp += fwd_sums[(long)b * n_fwd + i];
         sp_total = block_sum(sp, s_buf);
@@ -82,21 +83,33 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
         float d = xs - gt_srgb[b * n3 + i];
         s[0] = fmaf(d, d, s[0]);
         s[1] += fabsf(d);
-        if (part_mask & MATPBR_PART_A) s[2] += fabsf(fminf(fmaxf(pa[b * n3 + i], 0.0f), 1.0f) - a0[b * n3 + i]);   // a regulariser counts only in its part (:398-409)
+        if (MODE != 4 && (part_mask & MATPBR_PART_A)) s[2] += fabsf(fminf(fmaxf(pa[b * n3 + i], 0.0f), 1.0f) - a0[b * n3 + i]);   // a regulariser counts only in its part (:398-409)
     }
-    if (part_mask & (MATPBR_PART_R | MATPBR_PART_M))
+    if (MODE != 4 && (part_mask & (MATPBR_PART_R | MATPBR_PART_M)))
         for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n1; i += (long)gridDim.x * kBlock) {
             if (part_mask & MATPBR_PART_R) s[3] += fabsf(fminf(fmaxf(pr[b * n1 + i], 0.07f), 1.0f) - r0[b * n1 + i]);
             if (part_mask & MATPBR_PART_M) s[4] += fabsf(fminf(fmaxf(pm[b * n1 + i], 0.0f), 1.0f) - m0[b * n1 + i]);
         }
     // MODE 3: one image's rows are followed by the folded sum of the render (the step kernel forms the ratio from it)
-    float* rows = part + (long)b * (MODE == 3 ? step_part_stride((int)gridDim.x) : (long)gridDim.x * 5);
+    float* rows = part + (long)b * (MODE >= 3 ? step_part_stride((int)gridDim.x) : (long)gridDim.x * 5);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         float v = block_sum(s[k], s_buf);
         if (threadIdx.x == 0) rows[(long)blockIdx.x * 5 + k] = v;
     }
-    if (MODE == 3 && blockIdx.x == 0 && threadIdx.x == 0) rows[(long)gridDim.x * 5] = sp_total;
+    if (MODE >= 3 && blockIdx.x == 0 && threadIdx.x == 0) rows[(long)gridDim.x * 5] = sp_total;
+    if (MODE == 4 && blockIdx.x == 0) {                    // the regulariser sums the step kernel left per workgroup (n_fwd of them per image)
+        float rg[3] = {0.0f, 0.0f, 0.0f};
+        for (int i = threadIdx.x; i < n_fwd; i += kBlock) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rg[k] += reg_sums[((long)b * n_fwd + i) * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = block_sum(rg[k], s_buf);
+            if (threadIdx.x == 0) rows[(long)gridDim.x * 5 + 1 + k] = v;
+        }
+    }
 }
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void loss_final2_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk,
@@ -1145,7 +1158,8 @@ int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, 
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
     if (H <= 0 || W <= 0 || batch <= 0) return 0;
     return ((size_t)batch * (grid_blocks(H, W) + lazy_groups((long)H * W)) + (size_t)batch * step_part_stride(kRedBlocks) +
-            2 * (size_t)batch * kStatsStride /* the step kernel's alternating SaveBest / EarlyStopping state */) * sizeof(float);
+            2 * (size_t)batch * kStatsStride /* the step kernel's alternating SaveBest / EarlyStopping state */ +
+            3 * (size_t)batch * grid_blocks(H, W) /* its per-workgroup regulariser sums */) * sizeof(float);
 }
 
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* stream) {
@@ -1201,13 +1215,19 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     const int step_rows = kStepRows;
     // [2][B][kStatsStride], at a fixed place (`part` moves with the number of forward sums, which differs between t = 1 and later steps)
     float* state2 = (float*)q.workspace + (size_t)q.batch * (grid_blocks(q.H, q.W) + lazy_groups(n1)) + (size_t)q.batch * step_part_stride(kRedBlocks);
+    float* reg_sums = state2 + 2 * (size_t)q.batch * kStatsStride;     // [B][grid_blocks][3]
     if ((stages & MATPBR_STAGE_STATS) && lazy_fused) {
         // one launch: the partial rows; their fold and the SaveBest / EarlyStopping commit happen at the head of the step kernel
         if (t == 1 && hipMemcpyAsync(state2, q.stats, sizeof(float) * (size_t)q.batch * kStatsStride, hipMemcpyDeviceToDevice, st) != hipSuccess)
             return MATPBR_ERR_LAUNCH;
-        hipLaunchKernelGGL(loss_sums2_kernel<3>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
-                           (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
-                           (const float*)fwd_sums, nfwd, q.part_mask);
+        if (t > 1)     // the step before left the regulariser sums of the parameters it wrote: this pass reads pred and the target only
+            hipLaunchKernelGGL(loss_sums2_kernel<4>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
+                               (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
+                               (const float*)fwd_sums, nfwd, q.part_mask, (const float*)reg_sums);
+        else
+            hipLaunchKernelGGL(loss_sums2_kernel<3>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
+                               (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
+                               (const float*)fwd_sums, nfwd, q.part_mask, (const float*)nullptr);
     } else if (stages & MATPBR_STAGE_STATS) {
     hipLaunchKernelGGL(loss_sums2_kernel<1>, dim3(kRedBlocks, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                        (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
@@ -1239,6 +1259,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         ls.tol = q.lazy_tol > 0.0f ? q.lazy_tol : 1.0f;
         ls.attached = (q.flags & MATPBR_FLAG_ATTACHED_SAMPLING) ? 1 : 0;
         ls.fold_part = part; ls.fold_rows = step_rows;
+        ls.reg_sums = reg_sums; ls.reg_from_part = t > 1 ? 1 : 0;
         ls.state_old = state2 + (size_t)((t - 1) & 1) * q.batch * kStatsStride;
         ls.state_new = state2 + (size_t)(t & 1) * q.batch * kStatsStride;
         ls.stats_out = q.stats; ls.history = q.history; ls.hist_len = q.hist_len; ls.batch = q.batch;

@@ -190,6 +190,9 @@ struct LazyStepArgs {
     // that starts late still reads the state its siblings read.
     const float* fold_part;   // nullable: then the statistics were committed by loss_final2_kernel and j.stats is read as before
     int fold_rows;
+    float* reg_sums;          // nullable [B][n_sums][3]: per-workgroup sums of |a - a0|, |r - r0|, |m - m0| at the UPDATED parameters (the next
+                              // iteration's regulariser terms: its statistics pass then reads pred and the target only)
+    int reg_from_part;        // the regulariser sums of THIS iteration are in the tail of fold_part (carried by the step before)
     const float* state_old;   // [B][kStatsStride]
     float* state_new;         // [B][kStatsStride]
     float* stats_out;         // [B][kStatsStride] the public rows
@@ -216,7 +219,8 @@ __device__ __forceinline__ float ldf(const void* base, unsigned off) { return *(
 __device__ __forceinline__ void stf(void* base, unsigned off, float v) { *(float*)((char*)base + off) = v; }
 
 // one pixel of lazy_step_kernel; returns whether the pixel's new roughness has left its model's interval, adds its render to `tot`
-__device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned i, float ratio, float sr, bool improved, float& tot, LazyRecord& rec) {
+__device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned i, float ratio, float sr, bool improved, float& tot, float (&reg)[3],
+                                                LazyRecord& rec) {
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
     const float ra[3] = {ldf(q.a, o3), ldf(q.a, o3 + 4), ldf(q.a, o3 + 8)}, rr = ldf(q.r, o1), rm = ldf(q.m, o1);
@@ -270,11 +274,13 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
     if (q.part_mask & MATPBR_PART_A) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float gsum = da[c] + q.scale_delta * q.inv_n3 * fsign(a[c] - ldf(q.a0, o3 + 4 * c));                                 // :398,418
+            const float a0c = ldf(q.a0, o3 + 4 * c);
+            float gsum = da[c] + q.scale_delta * q.inv_n3 * fsign(a[c] - a0c);                                                   // :398,418
             gsum = (ra[c] >= 0.0f && ra[c] <= 1.0f) ? gsum : 0.0f;                                                               // clamp backward
             if (q.d_a) stf(q.d_a, o3 + 4 * c, gsum);
             if (improved && q.best_a) stf(q.best_a, o3 + 4 * c, a[c]);
             if (q.am[0]) { na[c] = adam_update(ra[c], gsum, q.am[0], q.av[0], (long)i * 3 + c, q); stf(q.pa, o3 + 4 * c, na[c]); }
+            reg[0] += fabsf(fminf(fmaxf(na[c], 0.0f), 1.0f) - a0c);
         }
     } else if (q.d_a) {
 #pragma unroll
@@ -284,8 +290,9 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
 #pragma unroll
         for (int c = 0; c < 3; ++c) stf(q.best_img, o3 + 4 * c, xs_keep[c]);
     }
-    float gr = drr + ((q.part_mask & MATPBR_PART_R) ? q.scale_delta * q.inv_n1 * fsign(r - ldf(q.r0, o1)) : 0.0f);
-    float gm = dm + ((q.part_mask & MATPBR_PART_M) ? q.scale_delta * q.inv_n1 * fsign(m - ldf(q.m0, o1)) : 0.0f);
+    const float r0v = (q.part_mask & MATPBR_PART_R) ? ldf(q.r0, o1) : 0.0f, m0v = (q.part_mask & MATPBR_PART_M) ? ldf(q.m0, o1) : 0.0f;
+    float gr = drr + ((q.part_mask & MATPBR_PART_R) ? q.scale_delta * q.inv_n1 * fsign(r - r0v) : 0.0f);
+    float gm = dm + ((q.part_mask & MATPBR_PART_M) ? q.scale_delta * q.inv_n1 * fsign(m - m0v) : 0.0f);
     gr = (rr >= 0.07f && rr <= 1.0f) ? gr : 0.0f;
     gm = (rm >= 0.0f && rm <= 1.0f) ? gm : 0.0f;
     if (q.d_r) stf(q.d_r, o1, gr);
@@ -296,6 +303,8 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
     if ((q.part_mask & MATPBR_PART_M) && q.am[2]) { nm = adam_update(rm, gm, q.am[2], q.av[2], (long)i, q); stf(q.pm, o1, nm); }
     // ---- forward of iteration t+1 from the same model
     const float r1 = fminf(fmaxf(nr, 0.07f), 1.0f), m1 = fminf(fmaxf(nm, 0.0f), 1.0f), dr1 = r1 - rref, omm1 = 1.0f - m1;
+    if (q.part_mask & MATPBR_PART_R) reg[1] += fabsf(r1 - r0v);
+    if (q.part_mask & MATPBR_PART_M) reg[2] += fabsf(m1 - m0v);
     const bool need = !(dr1 >= -h2_lo(lohi) && dr1 <= h2_hi(lohi));
     rec.r = r1; rec.m = m1; rec.dr = dr1;
 #pragma unroll
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
             for (int k = 0; k < 5; ++k) t[k] = (s_fold[0][k] + s_fold[1][k]) + (s_fold[2][k] + s_fold[3][k]);
             st[kStRatio] = st[kStGtSum] / sp_total;
             const float mse = t[0] * q.inv_n3, l1 = t[1] * q.inv_n3;
+            if (qs.reg_from_part) { t[2] = rows[(long)qs.fold_rows * 5 + 1]; t[3] = rows[(long)qs.fold_rows * 5 + 2]; t[4] = rows[(long)qs.fold_rows * 5 + 3]; }
             const float la = (q.part_mask & MATPBR_PART_A) ? t[2] * q.inv_n3 : 0.0f;
             const float lr = (q.part_mask & MATPBR_PART_R) ? t[3] * q.inv_n1 : 0.0f;
             const float lm = (q.part_mask & MATPBR_PART_M) ? t[4] * q.inv_n1 : 0.0f;
@@ -412,8 +422,16 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
     float tot = 0.0f;
     bool need0 = false, need1 = false;
     LazyRecord rec0, rec1;
-    if (q0 < P) need0 = lazy_step_pixel(qs, (unsigned)(b * P + q0), ratio, sr, improved, tot, rec0);
-    if (q1 < P) need1 = lazy_step_pixel(qs, (unsigned)(b * P + q1), ratio, sr, improved, tot, rec1);
+    float reg[3] = {0.0f, 0.0f, 0.0f};
+    if (q0 < P) need0 = lazy_step_pixel(qs, (unsigned)(b * P + q0), ratio, sr, improved, tot, reg, rec0);
+    if (q1 < P) need1 = lazy_step_pixel(qs, (unsigned)(b * P + q1), ratio, sr, improved, tot, reg, rec1);
+    if (qs.reg_sums) {                                         // fixed order: DPP tree per wave, the four waves in order
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float w = wave_sum_to_lane63(reg[k]);
+            if ((threadIdx.x & 63) == 63) s_fold[threadIdx.x >> 6][k] = w;
+        }
+    }
     const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -599,6 +617,9 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
     if (lane == 63) s_sum[wave] = tot;
     __syncthreads();
     if (threadIdx.x == 0) qs.block_sums[(long)b * qs.n_sums + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    if (qs.reg_sums && threadIdx.x < 3)
+        qs.reg_sums[((long)b * qs.n_sums + blockIdx.x) * 3 + threadIdx.x] =
+            (s_fold[0][threadIdx.x] + s_fold[1][threadIdx.x]) + (s_fold[2][threadIdx.x] + s_fold[3][threadIdx.x]);
 }
 
 // =================================================================================================
