@@ -414,6 +414,10 @@ int matpbr_mlp_arm_head_fwd(const float* x, int ldx, const float* w, int ldw, co
                             float* map_a, float* map_r, float* map_m, long M, int K, void* stream);
 int matpbr_mlp_arm_head_bwd(const float* g_a, const float* g_r, const float* g_m, const float* th, float* d_x, long M, void* stream);
 size_t matpbr_mlp_skinny_workspace_bytes(int J);
+/* The main loop of the split-operand layer kernels (matpbr_mlp_sincos_layer_bx, matpbr_mlp_layer_bwd_input_bx with 256 columns and K a
+ * multiple of 32) takes both operands by LDS-DMA (global_load_lds_dwordx4) by default; on == 0 selects the register-staged loop (same
+ * products in the same order: the same bits).  A measurement switch, process-wide; returns the previous setting. */
+int matpbr_mlp_set_lds_dma(int on);
 /* The backward pass of the 'arm' network's OUTPUT layer (mymodels/mlps.py:233-236 under autograd) in one pass over the sines of the last
  * sine layer, given d_x[M, ldd >= 8] = dL/d(output pre-activations) (J <= 5 valid columns, matpbr_mlp_arm_head_bwd):
  *   d_w[j * ld_j + c * ld_c] = sum_m d_x[m][j] s_prev[m][c],  d_bias[j] = sum_m d_x[m][j]                  (the layer's own gradients)

@@ -105,6 +105,7 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_arm_head_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_long, ctypes.c_void_p]),
     "matpbr_mlp_skinny_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "matpbr_mlp_set_lds_dma": (ctypes.c_int, [ctypes.c_int]),
     "matpbr_mlp_skinny_bwd_weight": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_long, ctypes.c_long, _c_f, ctypes.c_void_p,
                                                    ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_adamw_step_dev": (ctypes.c_int, [_c_f] * 4 + [ctypes.c_long, _c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,

@@ -1259,15 +1259,33 @@ constexpr int kBxThreads = 512;
 // v_mfma_f32_16x16x4f32 per block fold them into 8 x 4 accumulator registers per wave.  Saves the 268 MB store, the 268 MB read of the
 // skinny weight-gradient pass and its launch.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int EPI, int NPROD, bool FULL, bool HEAD = false, bool W0 = false>   // FULL: all 256 output columns exist (N == 256): unguarded 16-byte stores
+// GL: both operands of the main loop arrive by LDS-DMA (global_load_lds_dwordx4: no register round trip, no ds_write, full 128-byte
+// lines of the rows, the rows read once per workgroup instead of once per column half).  Weights: two 48 KB buffers, one super-step
+// ahead; rows: a ring of three 16 KB buffers [128 rows][8 x 16 B] (chunk c of row r at slot c ^ (r >> 1 & 7): the fragment reads of
+// 16 consecutive rows cover 16 distinct 16-byte bank groups), two super-steps ahead.  The loads are inline asm, invisible to hipcc's
+// wait bookkeeping: one counted s_waitcnt vmcnt(2) + s_barrier per super-step retires everything but the two youngest pieces (the
+// rows of step g + 2) and publishes it.  Wave w fills bytes [6144 w, 6144 w + 6144) of a weight buffer and rows [16 w, 16 w + 16) of a
+// row buffer -- and the weight buffer it will fill NEXT is its transposition scratch during the epilogue (same wave, program order).
+__device__ __forceinline__ unsigned lds_byte_address(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+constexpr int kGlRows = 128 * 32 * 4;                                    // bytes of one row buffer
+constexpr size_t kGlSmem = 2 * kBxStage * sizeof(uint4) + 3 * kGlRows;   // 144 KB
+template <int EPI, int NPROD, bool FULL, bool HEAD = false, bool W0 = false, bool GL = false>   // FULL: all 256 output columns exist (N == 256): unguarded 16-byte stores
 __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const uint4* __restrict__ wsplit, const HeadArgs hd) {
   extern __shared__ __align__(16) unsigned char bx_smem[];
   uint4* sB = reinterpret_cast<uint4*>(bx_smem);                         // [2 buffers][kBxStage]
-  float* sScr = reinterpret_cast<float*>(bx_smem + 2 * kBxStage * sizeof(uint4));   // [8 waves][32][kLd]
+  float* sScr = reinterpret_cast<float*>(bx_smem + 2 * kBxStage * sizeof(uint4));   // [8 waves][32][kLd]  (GL: the row ring instead)
   float* sRed = reinterpret_cast<float*>(bx_smem);                       // [32][256] after the last tile (aliases sB)
-  float* sW4 = sScr + 8 * 32 * kLd;                                      // HEAD: [5][256] output-layer weights
+  float* sExtra = GL ? reinterpret_cast<float*>(bx_smem + kGlSmem) : sScr + 8 * 32 * kLd;
+  float* sW4 = sExtra;                                                   // HEAD: [5][256] output-layer weights
   float* sComb = sW4 + 5 * 256;                                          // HEAD: [128 rows][2 column halves][8]
-  float* sX0 = sScr + 8 * 32 * kLd;                     // W0: [8 waves][32 rows][16]  (HEAD and W0 never meet)
+  float* sX0 = sExtra;                                  // W0: [8 waves][32 rows][16]  (HEAD and W0 never meet)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int nks = (p.K + 31) / 32;
@@ -1291,13 +1309,49 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
   const int b_lane = lh * 256 + wn * 128 + li;                           // + ((s * 3 + piece) * 2) * 256 + ni * 32
   // the weights of super-step 0 are resident in buffer 0 at the start of every tile: the stream of super-steps runs across tiles
   uint4 bnext[kCopy];
+  if (!GL) {
 #pragma unroll
-  for (int q = 0; q < kCopy; ++q) sB[tid + kBxThreads * q] = wsplit[tid + kBxThreads * q];
+    for (int q = 0; q < kCopy; ++q) sB[tid + kBxThreads * q] = wsplit[tid + kBxThreads * q];
+  }
   if (HEAD) {
     for (int i = tid; i < 5 * 256; i += kBxThreads) sW4[i] = hd.w[(size_t)(i >> 8) * hd.ldw + (i & 255)];
   }
   __syncthreads();
   int buf = 0;
+  // ---- GL: lane constants of the two streams
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds0 = GL ? lds_byte_address(bx_smem) : 0u;
+  const unsigned gl_w_dst = lds0 + (unsigned)wave_u * 6144u, gl_a_dst = lds0 + 2u * kBxStage * 16u + (unsigned)wave_u * 2048u;
+  const unsigned gl_w_voff = (unsigned)(384 * wave + lane) * 16u;
+  unsigned gl_a_voff[2], gl_rd[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * wave + 8 * j + (lane >> 3);
+    gl_a_voff[j] = (unsigned)(row * p.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4u;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = wm * 32 + li;
+    gl_rd[q] = (unsigned)(2 * kBxStage * 16 + row * 128 + (((4 * lh + q) ^ ((row >> 1) & 7)) * 16));
+  }
+  int a_slot = 0;                                                        // ring slot of the current super-step's rows
+  auto gl_issue_w = [&](int ks_w, int wb) {
+    const char* src = reinterpret_cast<const char*>(wsplit) + (size_t)ks_w * (kBxStage * 16);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) glds16(src + 1024 * j, gl_w_voff, gl_w_dst + (unsigned)wb * (kBxStage * 16u) + 1024u * j);
+  };
+  auto gl_issue_a = [&](int tile_a, int ks_a, int slot) {
+    const float* src = p.A + (size_t)tile_a * kBM * p.lda + 32 * ks_a;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(src, gl_a_voff[j], gl_a_dst + (unsigned)slot * (unsigned)kGlRows + 1024u * j);
+  };
+  if (GL) {
+    const int t0 = blockIdx.x;
+    gl_issue_w(0, 0);
+    gl_issue_a(t0, 0, 0);
+    gl_issue_a(nks > 1 ? t0 : (t0 + (int)gridDim.x < tiles ? t0 + (int)gridDim.x : t0), nks > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+  }
 
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int row0 = tile * kBM;
@@ -1309,11 +1363,23 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
       for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 
     float4 raw[4];
+    if (!GL) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const float4*>(pa0 + 4 * q);
+      for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const float4*>(pa0 + 4 * q);
+    }
     for (int ks = 0; ks < nks; ++ks) {
       const int ksn = ks + 1 < nks ? ks + 1 : 0;                           // next super-step of the stream (wraps into the next tile)
       float4 cur[4];
+      if (GL) {
+        // the weights of the next super-step and the rows of the one after it (beyond this workgroup's last tile: its rows again, unused)
+        int t2 = tile, k2 = ks + 2;
+        if (k2 >= nks) { k2 -= nks; t2 = tile + (int)gridDim.x < tiles ? tile + (int)gridDim.x : tile; }
+        if (k2 >= nks) k2 = 0;                                             // a one-step reduction
+        gl_issue_w(ksn, buf ^ 1);
+        gl_issue_a(t2, k2, a_slot >= 1 ? a_slot - 1 : 2);                  // (a_slot + 2) % 3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const float4*>(bx_smem + gl_rd[q] + a_slot * kGlRows);
+      } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) cur[q] = raw[q];
       // in flight during this super-step's products: the next weights (global -> registers) and the next 16 k of the rows
@@ -1323,6 +1389,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
       if (ks + 1 < nks) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const float4*>(pa0 + 32 * (ks + 1) + 4 * q);
+      }
       }
       if (32 * (ks + 1) > p.K) {                            // ragged reduction (K = 241): columns at and beyond K are scratch, not zeros
 #pragma unroll
@@ -1361,15 +1428,23 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
                                                               acc[ni], 0, 0, 0);
         }
       }
+      if (GL) {
+        // everything but the two youngest pieces (the rows of step + 2) has landed; the barrier publishes it
+        // (lgkmcnt: this wave's fragment reads of the buffers that the next step's DMA overwrites are complete, not merely issued)
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        a_slot = a_slot == 2 ? 0 : a_slot + 1;
+      } else {
       // the other buffer was last read in the previous super-step, and every wave has passed that step's barrier
       uint4* sdst = sB + (buf ^ 1) * kBxStage + tid;
 #pragma unroll
       for (int q = 0; q < kCopy; ++q) sdst[kBxThreads * q] = bnext[q];
       __syncthreads();
+      }
       buf ^= 1;
     }
     // epilogue through a per-wave LDS transpose (16-byte stores / cos loads), as mlp_gemm_nt_wide
-    float* scr = sScr + wave * (32 * kLd);
+    // (GL: in the slice of the weight buffer read last that this wave fills next)
+    float* scr = GL ? reinterpret_cast<float*>(bx_smem + (size_t)(buf ^ 1) * (kBxStage * 16) + wave * 6144) : sScr + wave * (32 * kLd);
     const int t_row = lane >> 3, t_col = (lane & 7) * 4;
     const size_t tile_row = (size_t)(row0 + wm * 32 + t_row) * p.ldo;
     float* sx = sX0 + wave * (32 * 16);
@@ -1469,7 +1544,9 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
       }
       // sComb is written again at the end of the next tile, eight barriers from here
     }
+    if (GL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch slice is the next LDS-DMA target
   }
+  if (GL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the unused look-ahead pieces: nothing may land after the workgroup ends
   if (W0) {                                                   // lane holds dW0[n = .. + 4 (lane >> 4) + r][k = lane & 15]
     const size_t slab = (size_t)blockIdx.x * 4 + wm;
 #pragma unroll
@@ -1646,6 +1723,10 @@ constexpr size_t kBxSmemHead = kBxSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float)
 // More than 64 KB of dynamic LDS needs an opt-in attribute, which HIP keeps per device: one bit per (kernel, device), set under the
 // device that is current at the launch (a process may drive several GPUs through the C ABI, from several threads).  A failure is
 // reported to the caller and retried at the next launch.
+std::atomic<int> g_nt_gl{1};                  // LDS-DMA main loop where the shape allows (matpbr_mlp_set_lds_dma: A/B switch)
+inline bool gl_ok(const NtArgs& p) {
+  return g_nt_gl.load(std::memory_order_relaxed) != 0 && p.K % 32 == 0 && p.K >= 64 && (long)kBM * p.lda * 4 < (1l << 31);
+}
 template <auto Kernel>
 bool lds_opt_in(size_t bytes) {
   static std::atomic<unsigned long long> done{0};
@@ -1659,6 +1740,11 @@ bool lds_opt_in(size_t bytes) {
 }
 template <int EPI, int NPROD, bool FULL>
 bool launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
+  if constexpr (FULL) if (gl_ok(p)) {
+    if (!lds_opt_in<&mlp_nt_bx<EPI, NPROD, true, false, false, true>>(kGlSmem)) return false;
+    hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD, true, false, false, true>), dim3(grid), dim3(kBxThreads), kGlSmem, stream, p, wsplit, HeadArgs{});
+    return true;
+  }
   if (!lds_opt_in<&mlp_nt_bx<EPI, NPROD, FULL>>(kBxSmem)) return false;
   hipLaunchKernelGGL((mlp_nt_bx<EPI, NPROD, FULL>), dim3(grid), dim3(kBxThreads), kBxSmem, stream, p, wsplit, HeadArgs{});
   return true;
@@ -1666,12 +1752,24 @@ bool launch_nt_bx_full(const NtArgs& p, const uint4* wsplit, unsigned grid, hipS
 constexpr size_t kBxSmemW0 = kBxSmem + 8 * 32 * 16 * sizeof(float);                          // + the waves' rows of x0
 template <int NPROD>
 bool launch_nt_bx_w0(const NtArgs& p, const uint4* wsplit, unsigned grid, hipStream_t stream) {
+  if (gl_ok(p)) {
+    constexpr size_t bytes = kGlSmem + 8 * 32 * 16 * sizeof(float);     // 160 KB: the whole LDS of a CU
+    if (!lds_opt_in<&mlp_nt_bx<EPI_MULC, NPROD, true, false, true, true>>(bytes)) return false;
+    hipLaunchKernelGGL((mlp_nt_bx<EPI_MULC, NPROD, true, false, true, true>), dim3(grid), dim3(kBxThreads), bytes, stream, p, wsplit, HeadArgs{});
+    return true;
+  }
   if (!lds_opt_in<&mlp_nt_bx<EPI_MULC, NPROD, true, false, true>>(kBxSmemW0)) return false;
   hipLaunchKernelGGL((mlp_nt_bx<EPI_MULC, NPROD, true, false, true>), dim3(grid), dim3(kBxThreads), kBxSmemW0, stream, p, wsplit, HeadArgs{});
   return true;
 }
 template <int NPROD>
 bool launch_nt_bx_head(const NtArgs& p, const uint4* wsplit, const HeadArgs& hd, unsigned grid, hipStream_t stream) {
+  if (gl_ok(p)) {
+    constexpr size_t bytes = kGlSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float);
+    if (!lds_opt_in<&mlp_nt_bx<EPI_SINCOS, NPROD, true, true, false, true>>(bytes)) return false;
+    hipLaunchKernelGGL((mlp_nt_bx<EPI_SINCOS, NPROD, true, true, false, true>), dim3(grid), dim3(kBxThreads), bytes, stream, p, wsplit, hd);
+    return true;
+  }
   if (!lds_opt_in<&mlp_nt_bx<EPI_SINCOS, NPROD, true, true>>(kBxSmemHead)) return false;
   hipLaunchKernelGGL((mlp_nt_bx<EPI_SINCOS, NPROD, true, true>), dim3(grid), dim3(kBxThreads), kBxSmemHead, stream, p, wsplit, hd);
   return true;
@@ -2120,6 +2218,11 @@ __global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __rest
 }  // namespace
 
 extern "C" {
+
+int matpbr_mlp_set_lds_dma(int on) {
+  const int was = g_nt_gl.exchange(on != 0 ? 1 : 0, std::memory_order_relaxed);
+  return was;
+}
 
 int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, float* c_out, int ldo,
                               const float* tail, int ldt, long M, int N, int K, void* stream) {

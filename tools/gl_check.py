@@ -1,0 +1,30 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import torch
+from materialist_amd import ops, _lib
+lib = _lib.load()
+dev = torch.device("cuda:0")
+torch.manual_seed(1)
+for M in (128 * 5, 128 * 300, 512 * 512):
+    x = torch.randn(M, 256, device=dev); x[:, 0] *= 30
+    w = torch.randn(256, 256, device=dev) / 16
+    b = torch.randn(256, device=dev)
+    g = torch.randn(M, 256, device=dev)
+    ws = ops.mlp_split_weights(w, 256, 256)
+    outs = []
+    for on in (0, 1):
+        lib.matpbr_mlp_set_lds_dma(on)
+        s = torch.zeros(M, 256, device=dev); c = torch.zeros(M, 256, device=dev)
+        sp = torch.zeros(M, 256, device=dev)
+        gp = torch.zeros(M, 256, device=dev); db = torch.zeros(256, device=dev)
+        gq = torch.zeros(M, 256, device=dev); dq = torch.zeros(256, device=dev)
+        for rep in range(3):
+            ops.mlp_layer_fwd_bx(x, ws, b, s, c, 256, 256, 6)
+            ops.mlp_layer_fwd_bx(x, ws, b, sp, None, 256, 256, 6)
+            ops.mlp_layer_bwd_input_bx(g, ws, c, gp, 256, 256, db, 6)
+            ops.mlp_layer_bwd_input_bx(g, ws, sp, gq, 256, 256, dq, 6, packed=True)
+        torch.cuda.synchronize()
+        outs.append((s, c, sp, gp, db, gq, dq))
+    for a, bb, name in zip(outs[0], outs[1], "s c sp gp db gq dq".split()):
+        same = torch.equal(a, bb)
+        print(M, name, "same bits" if same else "DIFF %g" % (a - bb).abs().max().item(), flush=True)

@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from materialist_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1:
+    from materialist_amd import _lib
+    _lib.load().matpbr_mlp_set_lds_dma(int(sys.argv[1]))
 M, N, K = 512 * 512, 256, 256
 x = torch.randn(M, 256, device=dev)
 w = torch.randn(N, 256, device=dev) / 16
