@@ -1259,13 +1259,27 @@ constexpr int kBxThreads = 512;
 // v_mfma_f32_16x16x4f32 per block fold them into 8 x 4 accumulator registers per wave.  Saves the 268 MB store, the 268 MB read of the
 // skinny weight-gradient pass and its launch.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifdef MATPBR_BX_STAMPS   // in-kernel cycle stamps of workgroup 0, waves 0 and 4 (one SIMD), second tile (tools/bx_stamps.py); never in the product build
+__device__ unsigned long long g_bx_stamps[2][8][8];
+#define BX_STAMP(slot)                                                                                         \
+  do {                                                                                                         \
+    if (GL && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && tile == (int)gridDim.x) {                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      g_bx_stamps[wave >> 2][ks_stamp][slot] = __builtin_amdgcn_s_memtime();                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  } while (0)
+#else
+#define BX_STAMP(slot) do { } while (0)
+#endif
 // GL: both operands of the main loop arrive by LDS-DMA (global_load_lds_dwordx4: no register round trip, no ds_write, full 128-byte
 // lines of the rows, the rows read once per workgroup instead of once per column half).  Weights: two 48 KB buffers, one super-step
 // ahead; rows: a ring of three 16 KB buffers [128 rows][8 x 16 B] (chunk c of row r at slot c ^ (r >> 1 & 7): the fragment reads of
 // 16 consecutive rows cover 16 distinct 16-byte bank groups), two super-steps ahead.  The loads are inline asm, invisible to hipcc's
-// wait bookkeeping: one counted s_waitcnt vmcnt(2) + s_barrier per super-step retires everything but the two youngest pieces (the
-// rows of step g + 2) and publishes it.  Wave w fills bytes [6144 w, 6144 w + 6144) of a weight buffer and rows [16 w, 16 w + 16) of a
-// row buffer -- and the weight buffer it will fill NEXT is its transposition scratch during the epilogue (same wave, program order).
+// wait bookkeeping: one counted s_waitcnt vmcnt(4) + s_barrier per super-step retires everything but the four youngest pieces (the
+// rows of step g + 2) and publishes it.  Waves 0-3 issue all sixteen pieces of a step; waves 4-7 (the other wave of each SIMD) go
+// straight to the products.  Slice w of a weight buffer (bytes [6144 w, 6144 w + 6144)) is wave w's transposition scratch during the
+// epilogue, in the buffer that is filled next (one more barrier per tile separates the two uses).
 __device__ __forceinline__ unsigned lds_byte_address(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
@@ -1321,13 +1335,20 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
   // ---- GL: lane constants of the two streams
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = GL ? lds_byte_address(bx_smem) : 0u;
-  const unsigned gl_w_dst = lds0 + (unsigned)wave_u * 6144u, gl_a_dst = lds0 + 2u * kBxStage * 16u + (unsigned)wave_u * 2048u;
-  const unsigned gl_w_voff = (unsigned)(384 * wave + lane) * 16u;
-  unsigned gl_a_voff[2], gl_rd[4];
+  // waves 0-3 issue every piece (their own slices and those of waves 4-7, their partners on the SIMDs): the other four start a
+  // super-step with the fragment reads and the products, so the matrix pipes run while the loads are being issued
+  const bool issuer = wave_u >= 4;
+  const unsigned gl_w_dst = lds0, gl_a_dst = lds0 + 2u * kBxStage * 16u;
+  unsigned gl_w_voff[2], gl_a_voff[2][2], gl_rd[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = 16 * wave + 8 * j + (lane >> 3);
-    gl_a_voff[j] = (unsigned)(row * p.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4u;
+  for (int v = 0; v < 2; ++v) {
+    const int vw = (wave & 3) + 4 * v;                                   // the slice owner this lane copies for
+    gl_w_voff[v] = (unsigned)(384 * vw + lane) * 16u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 16 * vw + 8 * j + (lane >> 3);
+      gl_a_voff[v][j] = (unsigned)(row * p.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4u;
+    }
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1338,19 +1359,28 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
   auto gl_issue_w = [&](int ks_w, int wb) {
     const char* src = reinterpret_cast<const char*>(wsplit) + (size_t)ks_w * (kBxStage * 16);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) glds16(src + 1024 * j, gl_w_voff, gl_w_dst + (unsigned)wb * (kBxStage * 16u) + 1024u * j);
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        glds16(src + 1024 * j, gl_w_voff[v], gl_w_dst + (unsigned)wb * (kBxStage * 16u) + (unsigned)((wave_u & 3) + 4 * v) * 6144u + 1024u * j);
   };
   auto gl_issue_a = [&](int tile_a, int ks_a, int slot) {
     const float* src = p.A + (size_t)tile_a * kBM * p.lda + 32 * ks_a;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(src, gl_a_voff[j], gl_a_dst + (unsigned)slot * (unsigned)kGlRows + 1024u * j);
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        glds16(src, gl_a_voff[v][j], gl_a_dst + (unsigned)slot * (unsigned)kGlRows + (unsigned)((wave_u & 3) + 4 * v) * 2048u + 1024u * j);
   };
   if (GL) {
     const int t0 = blockIdx.x;
-    gl_issue_w(0, 0);
-    gl_issue_a(t0, 0, 0);
-    gl_issue_a(nks > 1 ? t0 : (t0 + (int)gridDim.x < tiles ? t0 + (int)gridDim.x : t0), nks > 1 ? 1 : 0, 1);
-    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    if (issuer) {
+      gl_issue_w(0, 0);
+      gl_issue_a(t0, 0, 0);
+      gl_issue_a(nks > 1 ? t0 : (t0 + (int)gridDim.x < tiles ? t0 + (int)gridDim.x : t0), nks > 1 ? 1 : 0, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");
   }
 
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -1370,13 +1400,18 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
     for (int ks = 0; ks < nks; ++ks) {
       const int ksn = ks + 1 < nks ? ks + 1 : 0;                           // next super-step of the stream (wraps into the next tile)
       float4 cur[4];
+      const int ks_stamp = ks & 7; (void)ks_stamp;
+      BX_STAMP(0);
       if (GL) {
         // the weights of the next super-step and the rows of the one after it (beyond this workgroup's last tile: its rows again, unused)
         int t2 = tile, k2 = ks + 2;
         if (k2 >= nks) { k2 -= nks; t2 = tile + (int)gridDim.x < tiles ? tile + (int)gridDim.x : tile; }
         if (k2 >= nks) k2 = 0;                                             // a one-step reduction
-        gl_issue_w(ksn, buf ^ 1);
-        gl_issue_a(t2, k2, a_slot >= 1 ? a_slot - 1 : 2);                  // (a_slot + 2) % 3
+        if (issuer) {
+          gl_issue_w(ksn, buf ^ 1);
+          gl_issue_a(t2, k2, a_slot >= 1 ? a_slot - 1 : 2);                // (a_slot + 2) % 3
+        }
+        BX_STAMP(1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const float4*>(bx_smem + gl_rd[q] + a_slot * kGlRows);
       } else {
@@ -1428,11 +1463,14 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
                                                               acc[ni], 0, 0, 0);
         }
       }
+      BX_STAMP(2);
       if (GL) {
-        // everything but the two youngest pieces (the rows of step + 2) has landed; the barrier publishes it
+        // everything but the four youngest pieces (the rows of step + 2) has landed; the barrier publishes it
         // (lgkmcnt: this wave's fragment reads of the buffers that the next step's DMA overwrites are complete, not merely issued)
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (issuer) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         a_slot = a_slot == 2 ? 0 : a_slot + 1;
+        BX_STAMP(3);
       } else {
       // the other buffer was last read in the previous super-step, and every wave has passed that step's barrier
       uint4* sdst = sB + (buf ^ 1) * kBxStage + tid;
@@ -1544,7 +1582,8 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
       }
       // sComb is written again at the end of the next tile, eight barriers from here
     }
-    if (GL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch slice is the next LDS-DMA target
+    if (GL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the scratch slices are the next LDS-DMA targets (of waves 0-3)
+    { const int ks_stamp = 0; (void)ks_stamp; BX_STAMP(4); }
   }
   if (GL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the unused look-ahead pieces: nothing may land after the workgroup ends
   if (W0) {                                                   // lane holds dW0[n = .. + 4 (lane >> 4) + r][k = lane & 15]
@@ -2219,6 +2258,9 @@ __global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __rest
 
 extern "C" {
 
+#ifdef MATPBR_BX_STAMPS
+int matpbr_debug_bx_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bx_stamps), sizeof(g_bx_stamps)) == hipSuccess ? 0 : 1; }
+#endif
 int matpbr_mlp_set_lds_dma(int on) {
   const int was = g_nt_gl.exchange(on != 0 ? 1 : 0, std::memory_order_relaxed);
   return was;
