@@ -1261,6 +1261,7 @@ constexpr int kBxThreads = 512;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifdef MATPBR_BX_STAMPS   // in-kernel cycle stamps of workgroup 0, waves 0 and 4 (one SIMD), second tile (tools/bx_stamps.py); never in the product build
 __device__ unsigned long long g_bx_stamps[2][8][8];
+__device__ unsigned long long g_epi_stamp[2];
 #define BX_STAMP(slot)                                                                                         \
   do {                                                                                                         \
     if (GL && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && tile == (int)gridDim.x) {                      \
@@ -1612,6 +1613,239 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
   }
 }
 
+// mlp_nt_gx: the same product as mlp_nt_bx (same pieces, same order of accumulation: the same bits) as TWO independent 256-thread
+// workgroups per CU.  A workgroup owns a 128 x 256 tile with 2 x 2 waves of 64 x 128 (128 accumulator registers per wave): every B
+// fragment read from LDS feeds two products instead of one, and the two workgroups of a CU are not coupled by a barrier -- one's
+// epilogue and LDS round trips run under the other's products.  80 KB of LDS per workgroup: weights in two 24 KB buffers per HALF
+// super-step (16 k), one step ahead; rows in two 16 KB granules of 32 k (full 128-byte lines), one granule ahead; all by LDS-DMA
+// (inline asm, counted by hand: vmcnt(4) after the first half of a granule, vmcnt(0) after the second).  Wave w fills slice w of every
+// buffer; slice w of the weight buffer it fills next is its transposition scratch in the epilogue.  HEAD: the output-layer weights and
+// the row exchange live in the row granule that is free during the epilogue (re-read per tile, two more barriers per tile).
+#ifdef MATPBR_BX_STAMPS
+#define GX_STAMP(ksidx, slot)                                                                                  \
+  do {                                                                                                         \
+    if (blockIdx.x == 0 && wave < 2 && lane == 0 && tile == (int)gridDim.x) {                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      g_bx_stamps[wave][(ksidx) & 7][slot] = __builtin_amdgcn_s_memtime();                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  } while (0)
+#else
+#define GX_STAMP(ksidx, slot) do { } while (0)
+#endif
+constexpr int kGxThreads = 256;
+constexpr int kGxW = kBxStage / 2 * 16;                                  // bytes of one weight buffer (24 KB)
+constexpr size_t kGxSmem = 2 * kGxW + 2 * kGlRows;                       // 80 KB
+template <int EPI, int NPROD, bool HEAD>
+__global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const uint4* __restrict__ wsplit, const HeadArgs hd) {
+  extern __shared__ __align__(16) unsigned char gx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ng = p.K / 32;                                               // granules per tile
+  const int tiles = p.M / kBM;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds0 = lds_byte_address(gx_smem);
+  const unsigned w_dst = lds0 + (unsigned)wave_u * 6144u, a_dst = lds0 + 2u * kGxW + (unsigned)wave_u * 4096u;
+  const unsigned w_voff = (unsigned)(384 * wave + lane) * 16u;
+  unsigned a_voff[4], a_rd[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 32 * wave + 8 * j + (lane >> 3);
+    a_voff[j] = (unsigned)(row * p.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4u;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a_rd[q] = (unsigned)(2 * kGxW + (wm * 64 + li) * 128 + (((4 * lh + q) ^ ((li >> 1) & 7)) * 16));
+  float bn[4];
+  float4 csum4[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    bn[ni] = (EPI != EPI_MULC) ? p.bias[wn * 128 + ni * 32 + li] : 0.f;
+    csum4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int b_lane = lh * 256 + wn * 128 + li;
+  auto issue_w = [&](int step_w, int wb) {                                // step_w: half super-step index within the reduction
+    const char* src = reinterpret_cast<const char*>(wsplit) + (size_t)step_w * kGxW;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) glds16(src + 1024 * j, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW + 1024u * j);
+  };
+  auto issue_a = [&](int tile_a, int g_a, int ab) {
+    const float* src = p.A + (size_t)tile_a * kBM * p.lda + 32 * g_a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(src, a_voff[j], a_dst + (unsigned)ab * (unsigned)kGlRows + 1024u * j);
+  };
+  issue_w(0, 0);
+  issue_a(blockIdx.x, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int wb = 0, ab = 0;
+
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int row0 = tile * kBM;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int g = 0; g < ng; ++g) {
+      int t2 = tile, g2 = g + 1;                                           // the next granule of the stream (beyond the last tile: this one again, unused)
+      if (g2 >= ng) { g2 = 0; t2 = tile + (int)gridDim.x < tiles ? tile + (int)gridDim.x : tile; }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int step_n = s == 0 ? 2 * g + 1 : (g + 1 < ng ? 2 * g + 2 : 0);
+        GX_STAMP(g, 4 * s + 0);
+        issue_w(step_n, wb ^ 1);
+        if (s == 0) issue_a(t2, g2, ab ^ 1);
+        GX_STAMP(g, 4 * s + 1);
+        uint4 aq[2][3];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const float4 u = *reinterpret_cast<const float4*>(gx_smem + a_rd[2 * s] + ab * kGlRows + mi * 4096);
+          const float4 v = *reinterpret_cast<const float4*>(gx_smem + a_rd[2 * s + 1] + ab * kGlRows + mi * 4096);
+          split3(u.x, u.y, aq[mi][0].x, aq[mi][1].x, aq[mi][2].x);
+          split3(u.z, u.w, aq[mi][0].y, aq[mi][1].y, aq[mi][2].y);
+          split3(v.x, v.y, aq[mi][0].z, aq[mi][1].z, aq[mi][2].z);
+          split3(v.z, v.w, aq[mi][0].w, aq[mi][1].w, aq[mi][2].w);
+        }
+        const uint4* sb = reinterpret_cast<const uint4*>(gx_smem + wb * kGxW) + b_lane;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          uint4 bq[3];
+#pragma unroll
+          for (int piece = 0; piece < 3; ++piece) bq[piece] = sb[(piece * 2) * 256 + ni * 32];
+          // products from the smallest terms up, as mlp_nt_bx
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            constexpr int ia[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, ib[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
+            if (NPROD == 6 && t < 3) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[mi][ia[t]]), __builtin_bit_cast(bf16x8, bq[ib[t]]),
+                                                                    acc[mi][ni], 0, 0, 0);
+          }
+        }
+        GX_STAMP(g, 4 * s + 2);
+        if (s == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        GX_STAMP(g, 4 * s + 3);
+        wb ^= 1;
+      }
+      ab ^= 1;
+    }
+    // ---- epilogue.  Scratch: this wave's slice of the weight buffer read last (it fills it next).  HEAD: weights and row exchange in
+    // the row granule read last (the next DMA into it is issued after the barriers below)
+    float* scr = reinterpret_cast<float*>(gx_smem + (size_t)(wb ^ 1) * kGxW + wave * 6144);
+    float* sW4 = reinterpret_cast<float*>(gx_smem + 2 * kGxW + (size_t)(ab ^ 1) * kGlRows);   // [5][256]
+    float* sComb = sW4 + 5 * 256;                                                          // [128 rows][2 column halves][8]
+    const int t_row = lane >> 3, t_col = (lane & 7) * 4;
+    if (HEAD) {
+      for (int i = tid; i < 5 * 256; i += kGxThreads) sW4[i] = hd.w[(size_t)(i >> 8) * hd.ldw + (i & 255)];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const size_t tile_row = (size_t)(row0 + wm * 64 + mi * 32 + t_row) * p.ldo;
+      float hacc[4][5];
+      if (HEAD) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) hacc[ps][j] = 0.f;
+      }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        float4 cv[2][4];
+        if (EPI == EPI_MULC) {
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+              cv[n2][ps] = *reinterpret_cast<const float4*>(p.cmul + tile_row + (size_t)(8 * ps) * p.ldo + wn * 128 + (nh * 2 + n2) * 32 + t_col);
+        }
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int ni = nh * 2 + n2;
+          const size_t o0 = tile_row + wn * 128 + ni * 32 + t_col;
+          float second[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[mi][ni][r];
+            if (EPI == EPI_SINCOS) {
+              sincos_cw(v + bn[ni], v, second[r]);
+              if (p.out1 == nullptr) v = pack_cos_sign(v, second[r]);
+            }
+            scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
+          }
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+            if (EPI == EPI_MULC) {
+              if (p.cmul_sin) cv[n2][ps] = cos_from_packed_sin(cv[n2][ps]);
+              v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
+              csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
+            }
+            if (HEAD) {
+#pragma unroll
+              for (int j = 0; j < 5; ++j) {
+                const float4 w4 = *reinterpret_cast<const float4*>(sW4 + j * 256 + wn * 128 + ni * 32 + t_col);
+                hacc[ps][j] = __builtin_fmaf(v.x, w4.x, __builtin_fmaf(v.y, w4.y, __builtin_fmaf(v.z, w4.z, __builtin_fmaf(v.w, w4.w, hacc[ps][j]))));
+              }
+            }
+            *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+          }
+          if (EPI == EPI_SINCOS && p.out1 != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+              *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+          }
+        }
+      }
+      if (HEAD) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            float v = hacc[ps][j];
+            v = dpp_add_f<0x111>(v);
+            v = dpp_add_f<0x112>(v);
+            v = dpp_add_f<0x114>(v);
+            if ((lane & 7) == 7) sComb[((wm * 64 + mi * 32 + t_row + 8 * ps) * 2 + wn) * 8 + j] = v;
+          }
+      }
+    }
+    if (HEAD) {
+      __syncthreads();
+      if (tid < kBM) {
+        float v5[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v5[j] = (sComb[(tid * 2) * 8 + j] + sComb[(tid * 2 + 1) * 8 + j]) + hd.bias[j];
+        arm_head_store(hd.h, (long)row0 + tid, v5);
+      }
+      __syncthreads();                                        // the granule is the next DMA target
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the scratch slice is this wave's next DMA target
+#ifdef MATPBR_BX_STAMPS
+    if (blockIdx.x == 0 && wave < 2 && lane == 0 && tile == (int)gridDim.x) g_epi_stamp[wave] = __builtin_amdgcn_s_memtime();
+#endif
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the unused look-ahead pieces: nothing may land after the workgroup ends
+  if (EPI == EPI_MULC && p.colsum != nullptr) {
+    float* sRed = reinterpret_cast<float*>(gx_smem);                      // [16][256]
+    const int t_row = lane >> 3, t_col = (lane & 7) * 4;
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      *reinterpret_cast<float4*>(sRed + (wm * 8 + t_row) * 256 + wn * 128 + ni * 32 + t_col) = csum4[ni];
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) t += sRed[sl * 256 + tid];
+    p.colsum[(size_t)blockIdx.x * 256 + tid] = t;
+  }
+}
+
 // dW partials = G^T X over a slab of rows with split operands.  One workgroup owns the whole 256 x 256 output of its slab: eight
 // waves, wave (nq, kq) accumulates 64 x 128 of it (8 accumulator tiles), two waves per SIMD so that one wave's staging work (VALU
 // split, LDS traffic) runs in the shadow of the other's MFMAs.  Both operands are activations laid out [row m][column] with m the
@@ -1762,7 +1996,8 @@ constexpr size_t kBxSmemHead = kBxSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float)
 // More than 64 KB of dynamic LDS needs an opt-in attribute, which HIP keeps per device: one bit per (kernel, device), set under the
 // device that is current at the launch (a process may drive several GPUs through the C ABI, from several threads).  A failure is
 // reported to the caller and retried at the next launch.
-std::atomic<int> g_nt_gl{1};                  // LDS-DMA main loop where the shape allows (matpbr_mlp_set_lds_dma: A/B switch)
+std::atomic<int> g_nt_gl{2};
+std::atomic<int> g_nt_head_gx{0};                  // LDS-DMA main loop where the shape allows (matpbr_mlp_set_lds_dma: A/B switch)
 inline bool gl_ok(const NtArgs& p) {
   return g_nt_gl.load(std::memory_order_relaxed) != 0 && p.K % 32 == 0 && p.K >= 64 && (long)kBM * p.lda * 4 < (1l << 31);
 }
@@ -1819,9 +2054,23 @@ bool launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipSt
   if (p.N >= 256 || EPI == EPI_MULC || p.tail != nullptr) return launch_nt_bx_full<EPI, NPROD, true>(p, wsplit, grid, stream);
   return launch_nt_bx_full<EPI, NPROD, false>(p, wsplit, grid, stream);
 }
+template <int EPI, int NPROD, bool HEAD>
+bool launch_nt_gx(const NtArgs& p, const uint4* wsplit, const HeadArgs& hd, unsigned grid, hipStream_t stream) {
+  if (!lds_opt_in<&mlp_nt_gx<EPI, NPROD, HEAD>>(kGxSmem)) return false;
+  hipLaunchKernelGGL((mlp_nt_gx<EPI, NPROD, HEAD>), dim3(grid), dim3(kGxThreads), kGxSmem, stream, p, wsplit, hd);
+  return true;
+}
+inline bool gx_ok(const NtArgs& p) { return g_nt_gl.load(std::memory_order_relaxed) == 2 && gl_ok(p); }
 template <int EPI>
 int launch_nt_bx(NtArgs p, const uint4* wsplit, int nprod, hipStream_t stream) {   // p.M a multiple of 128; returns the grid, -1 when the launch could not be set up
   const int tiles = p.M / kBM;
+  if constexpr (EPI != EPI_BIAS) {
+    if (gx_ok(p) && (p.N >= 256 || EPI == EPI_MULC || p.tail != nullptr)) {
+      const unsigned grid2 = (unsigned)(tiles < 512 ? tiles : 512);
+      const bool ok2 = nprod == 9 ? launch_nt_gx<EPI, 9, false>(p, wsplit, HeadArgs{}, grid2, stream) : launch_nt_gx<EPI, 6, false>(p, wsplit, HeadArgs{}, grid2, stream);
+      return ok2 ? (int)grid2 : -1;
+    }
+  }
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
   const bool ok = nprod == 9 ? launch_nt_bx_one<EPI, 9>(p, wsplit, grid, stream) : launch_nt_bx_one<EPI, 6>(p, wsplit, grid, stream);
   return ok ? (int)grid : -1;
@@ -2259,10 +2508,14 @@ __global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __rest
 extern "C" {
 
 #ifdef MATPBR_BX_STAMPS
-int matpbr_debug_bx_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bx_stamps), sizeof(g_bx_stamps)) == hipSuccess ? 0 : 1; }
+int matpbr_debug_bx_stamps(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bx_stamps), sizeof(g_bx_stamps)) != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out + 128, HIP_SYMBOL(g_epi_stamp), sizeof(g_epi_stamp)) == hipSuccess ? 0 : 1;
+}
 #endif
-int matpbr_mlp_set_lds_dma(int on) {
-  const int was = g_nt_gl.exchange(on != 0 ? 1 : 0, std::memory_order_relaxed);
+int matpbr_mlp_set_lds_dma(int mode) {
+  g_nt_head_gx.store(mode == 3 ? 1 : 0, std::memory_order_relaxed);
+  const int was = g_nt_gl.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
   return was;
 }
 
@@ -2448,6 +2701,12 @@ int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, co
   const HeadArgs hd{w_out, ldw_out, bias_out, ArmHead{start, lds, th, map_a, map_r, map_m}};
   const int tiles = (int)(M / kBM);
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+  if (gx_ok(p) && g_nt_head_gx.load(std::memory_order_relaxed) != 0) {
+    const unsigned grid2 = (unsigned)(tiles < 512 ? tiles : 512);
+    const bool ok2 = nprod == 9 ? launch_nt_gx<EPI_SINCOS, 9, true>(p, (const uint4*)wsplit, hd, grid2, (hipStream_t)stream)
+                                : launch_nt_gx<EPI_SINCOS, 6, true>(p, (const uint4*)wsplit, hd, grid2, (hipStream_t)stream);
+    return ok2 && hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+  }
   const bool ok = nprod == 9 ? launch_nt_bx_head<9>(p, (const uint4*)wsplit, hd, grid, (hipStream_t)stream)
                              : launch_nt_bx_head<6>(p, (const uint4*)wsplit, hd, grid, (hipStream_t)stream);
   return ok && hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;

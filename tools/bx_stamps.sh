@@ -9,6 +9,5 @@ import os
 cmd = [b._hipcc(), *b.HIPCC_FLAGS, "-DMATPBR_BX_STAMPS", "-o", b.LIB_PATH, *[os.path.join(b.CSRC, s) for s in b.SOURCES]]
 subprocess.run(cmd, check=True)
 PY
-python tools/bx_stamps.py fwd
-python tools/bx_stamps.py bwd
+if [ "$1" = gx ]; then python tools/gx_stamps.py fwd; python tools/gx_stamps.py bwd; else python tools/bx_stamps.py fwd; python tools/bx_stamps.py bwd; fi
 cp /tmp/lib_keep.so materialist_amd/libmatpbr.so

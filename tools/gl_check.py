@@ -12,7 +12,7 @@ for M in (128 * 5, 128 * 300, 512 * 512):
     g = torch.randn(M, 256, device=dev)
     ws = ops.mlp_split_weights(w, 256, 256)
     outs = []
-    for on in (0, 1):
+    for on in (0, 1, 2):
         lib.matpbr_mlp_set_lds_dma(on)
         s = torch.zeros(M, 256, device=dev); c = torch.zeros(M, 256, device=dev)
         sp = torch.zeros(M, 256, device=dev)
@@ -25,6 +25,7 @@ for M in (128 * 5, 128 * 300, 512 * 512):
             ops.mlp_layer_bwd_input_bx(g, ws, sp, gq, 256, 256, dq, 6, packed=True)
         torch.cuda.synchronize()
         outs.append((s, c, sp, gp, db, gq, dq))
-    for a, bb, name in zip(outs[0], outs[1], "s c sp gp db gq dq".split()):
-        same = torch.equal(a, bb)
-        print(M, name, "same bits" if same else "DIFF %g" % (a - bb).abs().max().item(), flush=True)
+    for k in (1, 2):
+        for a, bb, name in zip(outs[0], outs[k], "s c sp gp db gq dq".split()):
+            same = torch.equal(a, bb)
+            print(M, "mode", k, name, "same bits" if same else "DIFF %g (scale %g)" % ((a - bb).abs().max().item(), a.abs().max().item()), flush=True)

@@ -19,7 +19,7 @@ g = torch.randn(M, 256, device=dev)
 s = torch.empty(M, 256, device=dev)
 gp, db = torch.empty(M, 256, device=dev), torch.empty(N, device=dev)
 ws = ops.mlp_split_weights(w, N, K)
-for _ in range(10):
+for _ in range(40):
     ops.mlp_layer_fwd_bx(x, ws, b, s, None, N, K, 6)
     ops.mlp_layer_bwd_input_bx(g, ws, s, gp, N, K, db, 6, packed=True)
     ops.mlp_layer_bwd_weight_bx(g, x, N, K, 6)
