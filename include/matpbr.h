@@ -414,10 +414,15 @@ int matpbr_mlp_arm_head_fwd(const float* x, int ldx, const float* w, int ldw, co
                             float* map_a, float* map_r, float* map_m, long M, int K, void* stream);
 int matpbr_mlp_arm_head_bwd(const float* g_a, const float* g_r, const float* g_m, const float* th, float* d_x, long M, void* stream);
 size_t matpbr_mlp_skinny_workspace_bytes(int J);
-/* The main loop of the split-operand layer kernels (matpbr_mlp_sincos_layer_bx, matpbr_mlp_layer_bwd_input_bx with 256 columns and K a
- * multiple of 32) takes both operands by LDS-DMA (global_load_lds_dwordx4) by default; on == 0 selects the register-staged loop (same
- * products in the same order: the same bits).  A measurement switch, process-wide; returns the previous setting. */
-int matpbr_mlp_set_lds_dma(int on);
+/* The main loop of the split-operand layer kernels (matpbr_mlp_layer_fwd_bx[_tail|_head], matpbr_mlp_layer_bwd_input_bx[_sgn],
+ * matpbr_mlp_first_layer_bwd_bx) with 256 output columns and a reduction that is a multiple of 32:
+ *   2 (default)  operands by LDS-DMA (global_load_lds_dwordx4), two 256-thread workgroups per CU with 64 x 128 wave tiles
+ *                (mlp_nt_gx; the first-layer form and the head form with stored cosines run as mode 1)
+ *   1            operands by LDS-DMA, one 512-thread workgroup per CU (mlp_nt_bx<.., GL>)
+ *   0            register-staged operands (mlp_nt_bx)
+ * The three form the same products in the same order: outputs are the same bits (the bias-gradient column sums are grouped per
+ * workgroup and agree to rounding).  A measurement switch, process-wide; returns the previous setting. */
+int matpbr_mlp_set_lds_dma(int mode);
 /* The backward pass of the 'arm' network's OUTPUT layer (mymodels/mlps.py:233-236 under autograd) in one pass over the sines of the last
  * sine layer, given d_x[M, ldd >= 8] = dL/d(output pre-activations) (J <= 5 valid columns, matpbr_mlp_arm_head_bwd):
  *   d_w[j * ld_j + c * ld_c] = sum_m d_x[m][j] s_prev[m][c],  d_bias[j] = sum_m d_x[m][j]                  (the layer's own gradients)

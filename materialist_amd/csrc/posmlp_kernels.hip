@@ -1636,7 +1636,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
 constexpr int kGxThreads = 256;
 constexpr int kGxW = kBxStage / 2 * 16;                                  // bytes of one weight buffer (24 KB)
 constexpr size_t kGxSmem = 2 * kGxW + 2 * kGlRows;                       // 80 KB
-template <int EPI, int NPROD, bool HEAD>
+template <int EPI, int NPROD, bool HEAD, bool PK>   // PK: the sines carry the sign of their cosine, no cosines are stored (out1 == nullptr)
 __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const uint4* __restrict__ wsplit, const HeadArgs hd) {
   extern __shared__ __align__(16) unsigned char gx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1742,67 +1742,69 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
       for (int i = tid; i < 5 * 256; i += kGxThreads) sW4[i] = hd.w[(size_t)(i >> 8) * hd.ldw + (i & 255)];
       __syncthreads();
     }
+    // eight 32 x 32 blocks per wave, b = (row half mi, column block ni); EPI_MULC: the cos operand of block b + 1 is requested
+    // before block b is worked on (two sets of four registers quadruples: what one column pair took before)
+    float4 cvb[2][4];
+    auto cv_load = [&](int b, float4 (&dst)[4]) {
+      const float* src = p.cmul + (size_t)(row0 + wm * 64 + (b >> 2) * 32 + t_row) * p.ldo + wn * 128 + (b & 3) * 32 + t_col;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const size_t tile_row = (size_t)(row0 + wm * 64 + mi * 32 + t_row) * p.ldo;
-      float hacc[4][5];
-      if (HEAD) {
+      for (int ps = 0; ps < 4; ++ps) dst[ps] = *reinterpret_cast<const float4*>(src + (size_t)(8 * ps) * p.ldo);
+    };
+    if (EPI == EPI_MULC) cv_load(0, cvb[0]);
+    float hacc[4][5];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int mi = b >> 2, ni = b & 3;
+      const size_t o0 = (size_t)(row0 + wm * 64 + mi * 32 + t_row) * p.ldo + wn * 128 + ni * 32 + t_col;
+      if (EPI == EPI_MULC && b + 1 < 8) cv_load(b + 1, cvb[(b + 1) & 1]);
+      if (HEAD && ni == 0) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
           for (int j = 0; j < 5; ++j) hacc[ps][j] = 0.f;
       }
+      float second[16];
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-        float4 cv[2][4];
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[mi][ni][r];
+        if (EPI == EPI_SINCOS) {
+          float c;
+          sincos_cw(v + bn[ni], v, c);
+          if (PK) v = pack_cos_sign(v, c);
+          else second[r] = c;
+        }
+        scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
+      }
+      float4 vrow[4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
         if (EPI == EPI_MULC) {
-#pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps)
-              cv[n2][ps] = *reinterpret_cast<const float4*>(p.cmul + tile_row + (size_t)(8 * ps) * p.ldo + wn * 128 + (nh * 2 + n2) * 32 + t_col);
+          float4 c4 = cvb[b & 1][ps];
+          if (p.cmul_sin) c4 = cos_from_packed_sin(c4);
+          v.x *= c4.x; v.y *= c4.y; v.z *= c4.z; v.w *= c4.w;
+          csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
         }
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
-          const int ni = nh * 2 + n2;
-          const size_t o0 = tile_row + wn * 128 + ni * 32 + t_col;
-          float second[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[mi][ni][r];
-            if (EPI == EPI_SINCOS) {
-              sincos_cw(v + bn[ni], v, second[r]);
-              if (p.out1 == nullptr) v = pack_cos_sign(v, second[r]);
-            }
-            scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
-          }
-#pragma unroll
-          for (int ps = 0; ps < 4; ++ps) {
-            float4 v = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
-            if (EPI == EPI_MULC) {
-              if (p.cmul_sin) cv[n2][ps] = cos_from_packed_sin(cv[n2][ps]);
-              v.x *= cv[n2][ps].x; v.y *= cv[n2][ps].y; v.z *= cv[n2][ps].z; v.w *= cv[n2][ps].w;
-              csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
-            }
-            if (HEAD) {
-#pragma unroll
-              for (int j = 0; j < 5; ++j) {
-                const float4 w4 = *reinterpret_cast<const float4*>(sW4 + j * 256 + wn * 128 + ni * 32 + t_col);
-                hacc[ps][j] = __builtin_fmaf(v.x, w4.x, __builtin_fmaf(v.y, w4.y, __builtin_fmaf(v.z, w4.z, __builtin_fmaf(v.w, w4.w, hacc[ps][j]))));
-              }
-            }
-            *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
-          }
-          if (EPI == EPI_SINCOS && p.out1 != nullptr) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps)
-              *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
-          }
-        }
+        *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+        vrow[ps] = v;
       }
       if (HEAD) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const float4 w4 = *reinterpret_cast<const float4*>(sW4 + j * 256 + wn * 128 + ni * 32 + t_col);
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps)
+            hacc[ps][j] = __builtin_fmaf(vrow[ps].x, w4.x, __builtin_fmaf(vrow[ps].y, w4.y, __builtin_fmaf(vrow[ps].z, w4.z, __builtin_fmaf(vrow[ps].w, w4.w, hacc[ps][j]))));
+        }
+      }
+      if (EPI == EPI_SINCOS && !PK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = second[r];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+          *reinterpret_cast<float4*>(p.out1 + o0 + (size_t)(8 * ps) * p.ldo) = *reinterpret_cast<const float4*>(scr + (t_row + 8 * ps) * kLd + t_col);
+      }
+      if (HEAD && ni == 3) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
@@ -1996,8 +1998,7 @@ constexpr size_t kBxSmemHead = kBxSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float)
 // More than 64 KB of dynamic LDS needs an opt-in attribute, which HIP keeps per device: one bit per (kernel, device), set under the
 // device that is current at the launch (a process may drive several GPUs through the C ABI, from several threads).  A failure is
 // reported to the caller and retried at the next launch.
-std::atomic<int> g_nt_gl{2};
-std::atomic<int> g_nt_head_gx{0};                  // LDS-DMA main loop where the shape allows (matpbr_mlp_set_lds_dma: A/B switch)
+std::atomic<int> g_nt_gl{2};                  // LDS-DMA main loop where the shape allows (matpbr_mlp_set_lds_dma: A/B switch)
 inline bool gl_ok(const NtArgs& p) {
   return g_nt_gl.load(std::memory_order_relaxed) != 0 && p.K % 32 == 0 && p.K >= 64 && (long)kBM * p.lda * 4 < (1l << 31);
 }
@@ -2054,11 +2055,18 @@ bool launch_nt_bx_one(const NtArgs& p, const uint4* wsplit, unsigned grid, hipSt
   if (p.N >= 256 || EPI == EPI_MULC || p.tail != nullptr) return launch_nt_bx_full<EPI, NPROD, true>(p, wsplit, grid, stream);
   return launch_nt_bx_full<EPI, NPROD, false>(p, wsplit, grid, stream);
 }
+template <int EPI, int NPROD, bool HEAD, bool PK>
+bool launch_nt_gx_pk(const NtArgs& p, const uint4* wsplit, const HeadArgs& hd, unsigned grid, hipStream_t stream) {
+  if (!lds_opt_in<&mlp_nt_gx<EPI, NPROD, HEAD, PK>>(kGxSmem)) return false;
+  hipLaunchKernelGGL((mlp_nt_gx<EPI, NPROD, HEAD, PK>), dim3(grid), dim3(kGxThreads), kGxSmem, stream, p, wsplit, hd);
+  return true;
+}
 template <int EPI, int NPROD, bool HEAD>
 bool launch_nt_gx(const NtArgs& p, const uint4* wsplit, const HeadArgs& hd, unsigned grid, hipStream_t stream) {
-  if (!lds_opt_in<&mlp_nt_gx<EPI, NPROD, HEAD>>(kGxSmem)) return false;
-  hipLaunchKernelGGL((mlp_nt_gx<EPI, NPROD, HEAD>), dim3(grid), dim3(kGxThreads), kGxSmem, stream, p, wsplit, hd);
-  return true;
+  if constexpr (EPI == EPI_SINCOS) {
+    if (p.out1 == nullptr) return launch_nt_gx_pk<EPI, NPROD, HEAD, true>(p, wsplit, hd, grid, stream);
+  }
+  return launch_nt_gx_pk<EPI, NPROD, HEAD, false>(p, wsplit, hd, grid, stream);
 }
 inline bool gx_ok(const NtArgs& p) { return g_nt_gl.load(std::memory_order_relaxed) == 2 && gl_ok(p); }
 template <int EPI>
@@ -2514,7 +2522,6 @@ int matpbr_debug_bx_stamps(unsigned long long* out) {
 }
 #endif
 int matpbr_mlp_set_lds_dma(int mode) {
-  g_nt_head_gx.store(mode == 3 ? 1 : 0, std::memory_order_relaxed);
   const int was = g_nt_gl.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
   return was;
 }
@@ -2701,7 +2708,7 @@ int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, co
   const HeadArgs hd{w_out, ldw_out, bias_out, ArmHead{start, lds, th, map_a, map_r, map_m}};
   const int tiles = (int)(M / kBM);
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-  if (gx_ok(p) && g_nt_head_gx.load(std::memory_order_relaxed) != 0) {
+  if (gx_ok(p) && c_out == nullptr) {        // with stored cosines the two-workgroup form spills: the 512-thread kernel
     const unsigned grid2 = (unsigned)(tiles < 512 ? tiles : 512);
     const bool ok2 = nprod == 9 ? launch_nt_gx<EPI_SINCOS, 9, true>(p, (const uint4*)wsplit, hd, grid2, (hipStream_t)stream)
                                 : launch_nt_gx<EPI_SINCOS, 6, true>(p, (const uint4*)wsplit, hd, grid2, (hipStream_t)stream);
