@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
   extern __shared__ __align__(16) unsigned char gx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int ng = p.K / 32;                                               // granules per tile
+  const int ng = (p.K + 31) / 32;                                        // granules per tile (a ragged last one: columns at and beyond K are scratch)
   const int tiles = p.M / kBM;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = lds_byte_address(gx_smem);
@@ -1700,8 +1700,13 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
         uint4 aq[2][3];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-          const float4 u = *reinterpret_cast<const float4*>(gx_smem + a_rd[2 * s] + ab * kGlRows + mi * 4096);
-          const float4 v = *reinterpret_cast<const float4*>(gx_smem + a_rd[2 * s + 1] + ab * kGlRows + mi * 4096);
+          float4 u = *reinterpret_cast<const float4*>(gx_smem + a_rd[2 * s] + ab * kGlRows + mi * 4096);
+          float4 v = *reinterpret_cast<const float4*>(gx_smem + a_rd[2 * s + 1] + ab * kGlRows + mi * 4096);
+          if (32 * (g + 1) > p.K) {                           // uniform: scratch columns are not zeros
+            const int k = 32 * g + 16 * lh + 8 * s;
+            u.x = k < p.K ? u.x : 0.f; u.y = k + 1 < p.K ? u.y : 0.f; u.z = k + 2 < p.K ? u.z : 0.f; u.w = k + 3 < p.K ? u.w : 0.f;
+            v.x = k + 4 < p.K ? v.x : 0.f; v.y = k + 5 < p.K ? v.y : 0.f; v.z = k + 6 < p.K ? v.z : 0.f; v.w = k + 7 < p.K ? v.w : 0.f;
+          }
           split3(u.x, u.y, aq[mi][0].x, aq[mi][1].x, aq[mi][2].x);
           split3(u.z, u.w, aq[mi][0].y, aq[mi][1].y, aq[mi][2].y);
           split3(v.x, v.y, aq[mi][0].z, aq[mi][1].z, aq[mi][2].z);
@@ -2000,7 +2005,7 @@ constexpr size_t kBxSmemHead = kBxSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float)
 // reported to the caller and retried at the next launch.
 std::atomic<int> g_nt_gl{2};                  // LDS-DMA main loop where the shape allows (matpbr_mlp_set_lds_dma: A/B switch)
 inline bool gl_ok(const NtArgs& p) {
-  return g_nt_gl.load(std::memory_order_relaxed) != 0 && p.K % 32 == 0 && p.K >= 64 && (long)kBM * p.lda * 4 < (1l << 31);
+  return g_nt_gl.load(std::memory_order_relaxed) != 0 && p.K > 32 && (long)kBM * p.lda * 4 < (1l << 31);   // (a ragged K: the rows hold 32-column granules, lda >= 32 ceil(K / 32))
 }
 template <auto Kernel>
 bool lds_opt_in(size_t bytes) {

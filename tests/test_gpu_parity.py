@@ -1578,12 +1578,13 @@ def test_split_operand_weight_gradient_ragged_slabs(M):
     assert (dw.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() * max(1.0, (M / 4096) ** 0.5)
 
 
-@pytest.mark.parametrize("M", [128, 128 * 5, 128 * 700])
-def test_split_operand_layer_loops_agree_bit_for_bit(M):
+@pytest.mark.parametrize("M,K", [(128, 256), (128 * 5, 256), (128 * 700, 256), (128 * 300, 241)])
+def test_split_operand_layer_loops_agree_bit_for_bit(M, K):
     """f2: the three main loops of the 256-wide split-operand layers -- register-staged (0), LDS-DMA with one 512-thread workgroup per CU
     (1), LDS-DMA with two 256-thread workgroups per CU and 64 x 128 wave tiles (2, the default) -- form the same products in the same
     order: sines, cosines, packed sines and input gradients are the same bits; the bias gradient (a different grouping of the column
-    sums) agrees to rounding.  One tile, fewer tiles than workgroups, more tiles than workgroups."""
+    sums) agrees to rounding.  One tile, fewer tiles than workgroups, more tiles than workgroups; K = 241: the reduction of the layer
+    after a skip layer's gradient, whose operand columns at and beyond K hold scratch (here NaN) that no loop may read as data."""
     from materialist_amd import _lib, ops
 
     dev = _cuda()
@@ -1594,7 +1595,9 @@ def test_split_operand_layer_loops_agree_bit_for_bit(M):
     w = torch.randn(256, 256, device=dev) / 16
     b = torch.randn(256, device=dev)
     g = torch.randn(M, 256, device=dev)
-    ws = ops.mlp_split_weights(w, 256, 256)
+    x[:, K:] = float("nan")
+    g[:, K:] = float("nan")
+    ws = ops.mlp_split_weights(w, 256, K)
     outs = []
     was = lib.matpbr_mlp_set_lds_dma(0)
     try:
@@ -1604,14 +1607,15 @@ def test_split_operand_layer_loops_agree_bit_for_bit(M):
             gp, gq = torch.zeros(M, 256, device=dev), torch.zeros(M, 256, device=dev)
             db, dq = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
             for _ in range(2):                                   # twice: the persistent loops leave nothing behind
-                ops.mlp_layer_fwd_bx(x, ws, b, s_, c_, 256, 256, 6)
-                ops.mlp_layer_fwd_bx(x, ws, b, sp, None, 256, 256, 6)
-                ops.mlp_layer_bwd_input_bx(g, ws, c_, gp, 256, 256, db, 6)
-                ops.mlp_layer_bwd_input_bx(g, ws, sp, gq, 256, 256, dq, 6, packed=True)
+                ops.mlp_layer_fwd_bx(x, ws, b, s_, c_, 256, K, 6)
+                ops.mlp_layer_fwd_bx(x, ws, b, sp, None, 256, K, 6)
+                ops.mlp_layer_bwd_input_bx(g, ws, c_, gp, 256, K, db, 6)
+                ops.mlp_layer_bwd_input_bx(g, ws, sp, gq, 256, K, dq, 6, packed=True)
             torch.cuda.synchronize()
             outs.append((s_, c_, sp, gp, gq, db, dq))
     finally:
         lib.matpbr_mlp_set_lds_dma(was)
+    assert all(torch.isfinite(t).all() for t in outs[0])
     for mode in (1, 2):
         for k, name in enumerate(("s", "c", "packed s", "g'", "g' (packed)")):
             assert torch.equal(outs[0][k], outs[mode][k]), (mode, name)
