@@ -47,7 +47,7 @@ def parse(argv=None):
     ap.add_argument("--mlp-products", type=int, choices=[0, 6, 9], default=None,
                     help="partial products per f32 product of the 256-wide PosMLP layers: 6 (default) / 9 = split-operand kernels on the bf16 "
                          "matrix pipe (f32-accurate: three bf16 pieces per operand, f32 accumulate), 0 = the exact-f32 MFMA kernels")
-    ap.add_argument("--mlp-lds-dma", type=int, choices=[0, 1, 2], default=None,
+    ap.add_argument("--mlp-lds-dma", type=int, choices=[0, 1, 2, 3], default=None,
                     help="main loop of the split-operand layer kernels: 2 (default) operands by LDS-DMA, two 256-thread workgroups per CU; "
                          "1 LDS-DMA, one 512-thread workgroup per CU; 0 register-staged (same bits; A/B switch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

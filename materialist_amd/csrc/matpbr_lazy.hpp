@@ -224,7 +224,6 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
     const float ra[3] = {ldf(q.a, o3), ldf(q.a, o3 + 4), ldf(q.a, o3 + 8)}, rr = ldf(q.r, o1), rm = ldf(q.m, o1);
-    const float pr[3] = {ldf(q.pred, o3), ldf(q.pred, o3 + 4), ldf(q.pred, o3 + 8)};
     const float gt[3] = {ldf(q.gt_srgb, o3), ldf(q.gt_srgb, o3 + 4), ldf(q.gt_srgb, o3 + 8)};
     // the pixel's model
     const float rref = as_f(ldu(qs.plane[kLzRref], o1));
@@ -252,17 +251,20 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
     float da[3], drr = 0.0f, dm = 0.0f, xs_keep[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float x = pr[c] * ratio;
+        // the render of iteration t is not read back: it IS the model at the current parameters (the expression below is the one that
+        // wrote pred -- the step before, the re-sampling, or the first render -- on the same operands: the same bits)
+        const float dP0 = h2_lo(pk[c]), A2 = h2_hi(pk[c]);
+        const float Pc = fmaf(fmaf(A2, dr, dP0), dr, Pv[c]), dPc = fmaf(2.0f * A2, dr, dP0);
+        const float SD = fmaf(h2_lo(sk[c]), dr, SDv[c]);
+        const float C0 = fmaf(m, a[c], omm * 0.04f);
+        const float prc = fmaf(a[c] * omm, Pc, fmaf(C0, SD, fmaf(h2_hi(sk[c]), dr, S1v[c])));
+        const float x = prc * ratio;
         const float xc = fmaxf(x, kLossEps);
         const float xs = pow_inv_gamma(xc);
         const float d = xs - gt[c];
         const float dxs = x > kLossEps ? xs * rcp(xc) * (1.0f / 2.2f) : 0.0f;
         const float go = ratio * dxs * fmaf(6.0f * sr, d, fsign(d)) * q.inv_n3;
         xs_keep[c] = xs;
-        const float dP0 = h2_lo(pk[c]), A2 = h2_hi(pk[c]);
-        const float Pc = fmaf(fmaf(A2, dr, dP0), dr, Pv[c]), dPc = fmaf(2.0f * A2, dr, dP0);
-        const float SD = fmaf(h2_lo(sk[c]), dr, SDv[c]);
-        const float C0 = fmaf(m, a[c], omm * 0.04f);
         // d out / d r: the stop-gradient convention (dSD, dS1) by default; with `attached` the derivative of the rendered value through
         // the sample directions, which is what the models' slopes are (the live reference's convention, mi_plugin.py:227-230,1335-1341)
         const float JR = fmaf(a[c] * omm, dPc, qs.attached ? fmaf(C0, h2_lo(sk[c]), h2_hi(sk[c])) : fmaf(C0, h2_lo(dk[c]), h2_hi(dk[c])));

@@ -1636,7 +1636,7 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
 constexpr int kGxThreads = 256;
 constexpr int kGxW = kBxStage / 2 * 16;                                  // bytes of one weight buffer (24 KB)
 constexpr size_t kGxSmem = 2 * kGxW + 2 * kGlRows;                       // 80 KB
-template <int EPI, int NPROD, bool HEAD, bool PK>   // PK: the sines carry the sign of their cosine, no cosines are stored (out1 == nullptr)
+template <int EPI, int NPROD, bool HEAD, bool PK, bool W0 = false>   // PK: the sines carry the sign of their cosine, no cosines are stored (out1 == nullptr); W0: as mlp_nt_bx
 __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const uint4* __restrict__ wsplit, const HeadArgs hd) {
   extern __shared__ __align__(16) unsigned char gx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1661,6 +1661,13 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
   for (int ni = 0; ni < 4; ++ni) {
     bn[ni] = (EPI != EPI_MULC) ? p.bias[wn * 128 + ni * 32 + li] : 0.f;
     csum4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f32x4v acc0[4][2];                                                     // W0: dW0 of this wave's rows: [column block][16-column half], a 16 x 16 tile each
+  if (W0) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc0[ni][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
   }
   const int b_lane = lh * 256 + wn * 128 + li;
   auto issue_w = [&](int step_w, int wb) {                                // step_w: half super-step index within the reduction
@@ -1747,6 +1754,13 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
       for (int i = tid; i < 5 * 256; i += kGxThreads) sW4[i] = hd.w[(size_t)(i >> 8) * hd.ldw + (i & 255)];
       __syncthreads();
     }
+    // W0: this wave's 64 rows of x0 in ITS slice of the free row granule (the slice it fills next itself): lane = row
+    float* sx = reinterpret_cast<float*>(gx_smem + 2 * kGxW + (size_t)(ab ^ 1) * kGlRows + wave * 4096);
+    if (W0) {
+      const float* xs = p.x0 + (size_t)(row0 + wm * 64 + lane) * p.ldx0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sx + lane * 16 + 4 * ((q + lane) & 3)) = *reinterpret_cast<const float4*>(xs + 4 * ((q + lane) & 3));
+    }
     // eight 32 x 32 blocks per wave, b = (row half mi, column block ni); EPI_MULC: the cos operand of block b + 1 is requested
     // before block b is worked on (two sets of four registers quadruples: what one column pair took before)
     float4 cvb[2][4];
@@ -1790,8 +1804,17 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
           v.x *= c4.x; v.y *= c4.y; v.z *= c4.z; v.w *= c4.w;
           csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
         }
-        *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
+        if (W0) *reinterpret_cast<float4*>(scr + (t_row + 8 * ps) * kLd + t_col) = v;   // G' back into the block, for the product below
+        else *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
         vrow[ps] = v;
+      }
+      if (W0) {     // dW0[16 ct + i][j] += sum over the block's 32 rows of G'[row][16 ct + i] x0[row][j]  (A: lane = (i, k), B: lane = (j, k))
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk)
+            acc0[ni][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(scr[(4 * kk + (lane >> 4)) * kLd + 16 * ct + (lane & 15)],
+                                                                sx[(mi * 32 + 4 * kk + (lane >> 4)) * 16 + (lane & 15)], acc0[ni][ct], 0, 0, 0);
       }
       if (HEAD) {
 #pragma unroll
@@ -1838,6 +1861,16 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
 #endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the unused look-ahead pieces: nothing may land after the workgroup ends
+  if (W0) {                                                     // lane holds dW0[n = .. + 4 (lane >> 4) + r][k = lane & 15]
+    const size_t slab = (size_t)blockIdx.x * 2 + wm;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          p.w0_part[(slab * 16 + (lane & 15)) * 256 + wn * 128 + ni * 32 + 16 * ct + 4 * (lane >> 4) + r] = acc0[ni][ct][r];
+  }
   if (EPI == EPI_MULC && p.colsum != nullptr) {
     float* sRed = reinterpret_cast<float*>(gx_smem);                      // [16][256]
     const int t_row = lane >> 3, t_col = (lane & 7) * 4;
@@ -2003,7 +2036,8 @@ constexpr size_t kBxSmemHead = kBxSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float)
 // More than 64 KB of dynamic LDS needs an opt-in attribute, which HIP keeps per device: one bit per (kernel, device), set under the
 // device that is current at the launch (a process may drive several GPUs through the C ABI, from several threads).  A failure is
 // reported to the caller and retried at the next launch.
-std::atomic<int> g_nt_gl{2};                  // LDS-DMA main loop where the shape allows (matpbr_mlp_set_lds_dma: A/B switch)
+std::atomic<int> g_nt_gl{2};
+std::atomic<int> g_nt_w0_gx{0};   // measurement: mode 3 of matpbr_mlp_set_lds_dma                  // LDS-DMA main loop where the shape allows (matpbr_mlp_set_lds_dma: A/B switch)
 inline bool gl_ok(const NtArgs& p) {
   return g_nt_gl.load(std::memory_order_relaxed) != 0 && p.K > 32 && (long)kBM * p.lda * 4 < (1l << 31);   // (a ragged K: the rows hold 32-column granules, lda >= 32 ceil(K / 32))
 }
@@ -2527,6 +2561,7 @@ int matpbr_debug_bx_stamps(unsigned long long* out) {
 }
 #endif
 int matpbr_mlp_set_lds_dma(int mode) {
+  g_nt_w0_gx.store(mode == 3 ? 1 : 0, std::memory_order_relaxed);
   const int was = g_nt_gl.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
   return was;
 }
@@ -2758,11 +2793,25 @@ int matpbr_mlp_first_layer_bwd_bx(const float* g, int ldg, const void* wtsplit, 
   p.cmul_sin = sgn;
   p.x0 = x0; p.ldx0 = ldx0; p.w0_part = (float*)workspace2;
   const int tiles = (int)(M / kBM);
-  const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-  const bool ok = nprod == 9 ? launch_nt_bx_w0<9>(p, (const uint4*)wtsplit, grid, (hipStream_t)stream) : launch_nt_bx_w0<6>(p, (const uint4*)wtsplit, grid, (hipStream_t)stream);
+  unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+  int slabs = (int)grid * 4;
+  bool ok;
+  if (gx_ok(p) && g_nt_w0_gx.load(std::memory_order_relaxed) != 0) {
+    grid = (unsigned)(tiles < 512 ? tiles : 512);
+    slabs = (int)grid * 2;
+    if (nprod == 9) {
+      ok = lds_opt_in<&mlp_nt_gx<EPI_MULC, 9, false, false, true>>(kGxSmem);
+      if (ok) hipLaunchKernelGGL((mlp_nt_gx<EPI_MULC, 9, false, false, true>), dim3(grid), dim3(kGxThreads), kGxSmem, (hipStream_t)stream, p, (const uint4*)wtsplit, HeadArgs{});
+    } else {
+      ok = lds_opt_in<&mlp_nt_gx<EPI_MULC, 6, false, false, true>>(kGxSmem);
+      if (ok) hipLaunchKernelGGL((mlp_nt_gx<EPI_MULC, 6, false, false, true>), dim3(grid), dim3(kGxThreads), kGxSmem, (hipStream_t)stream, p, (const uint4*)wtsplit, HeadArgs{});
+    }
+  } else {
+    ok = nprod == 9 ? launch_nt_bx_w0<9>(p, (const uint4*)wtsplit, grid, (hipStream_t)stream) : launch_nt_bx_w0<6>(p, (const uint4*)wtsplit, grid, (hipStream_t)stream);
+  }
   if (!ok) return MATPBR_ERR_LAUNCH;
   if (d_bias0) hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n0), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid, d_bias0);
-  hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(16 * 4), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace2, (const float*)nullptr, (int)grid * 4, 16, d0, n0,
+  hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(16 * 4), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace2, (const float*)nullptr, slabs, 16, d0, n0,
                      d_w0, ld_j, ld_c, (float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
