@@ -420,6 +420,7 @@ size_t matpbr_mlp_skinny_workspace_bytes(int J);
  *                (mlp_nt_gx; the first-layer form and the head form with stored cosines run as mode 1)
  *   1            operands by LDS-DMA, one 512-thread workgroup per CU (mlp_nt_bx<.., GL>)
  *   0            register-staged operands (mlp_nt_bx)
+ *   3            as 2 with the first-layer form on mlp_nt_gx as well (23 spilled registers; measured +0.2 %: not the default)
  * The three form the same products in the same order: outputs are the same bits (the bias-gradient column sums are grouped per
  * workgroup and agree to rounding).  A measurement switch, process-wide; returns the previous setting. */
 int matpbr_mlp_set_lds_dma(int mode);
