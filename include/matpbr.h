@@ -56,6 +56,12 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
 #define MATPBR_FLAG_MODELS_READY 64u /* MatpbrBrdfPhase.flags: the caller has already built (and possibly edited) what the step with t == 1 would
                                         build -- the models in lazy_state (matpbr_shade_fwd_lazy with MATPBR_FLAG_LAZY_FORCE), or jac + s1cache of a
                                         part without MATPBR_PART_R (matpbr_shade_fwd_keep): pixels without geometry are given constant models */
+#define MATPBR_FLAG_ROTATE_BEST 128u /* MatpbrBrdfPhase.flags, pred_next mode only: SaveBest without copies.  The live maps of the part and the render
+                                        live in two buffers each -- (pa, best_a), (pr, best_r), (pm, best_m), (pred, pred_next) -- and an improving
+                                        iteration declares the buffers it has just read "best" and writes the new values into the others (any other
+                                        iteration updates in place); nothing is copied in the loop (20 of 217 B/pixel of an improving 'rm' iteration,
+                                        32 of 150 in an 'a' part).  The caller does NOT swap pred / pred_next between steps and must call
+                                        matpbr_brdf_phase_resolve before it reads pa / pr / pm / best_* / best_img / pred or starts the next part */
 #define MATPBR_FLAG_JAC16 32u      /* matpbr_brdf_loss_bwd_jac: `jac` holds the half-precision planes written by matpbr_shade_fwd_lazy */
 #define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
 #define MATPBR_PART_R 4u
@@ -233,6 +239,11 @@ typedef struct MatpbrBrdfPhase {
 } MatpbrBrdfPhase;
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);
+/* MATPBR_FLAG_ROTATE_BEST: after the step with t = t_done, put everything where the copying form leaves it: current parameters in pa / pr / pm,
+ * SaveBest's snapshots in best_a / best_r / best_m (maps of the part) and best_img (= the tone-mapped render of the best iteration of this
+ * phase; untouched if none improved), the render of the CURRENT parameters (the next iteration's) in `pred`, the best iteration's in
+ * `pred_next`.  The phase may go on afterwards (steps t_done + 1, ...).  Without the flag, or with t_done = 0: nothing to do. */
+int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* phase, int t_done, void* stream);
 /* The same iteration stage by stage (profiling, and callers that interleave their own work): matpbr_brdf_phase_step enqueues all three. */
 #define MATPBR_STAGE_RENDER 1u   /* the render of the iteration (nothing to launch in the pred_next mode after t = 1) */
 #define MATPBR_STAGE_STATS 2u    /* loss statistics, SaveBest / EarlyStopping decisions */

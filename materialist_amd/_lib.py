@@ -66,6 +66,7 @@ SIGNATURES = {
     "matpbr_brdf_phase_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "matpbr_brdf_phase_step": (ctypes.c_int, [ctypes.POINTER(MatpbrBrdfPhase), ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "matpbr_brdf_phase_stages": (ctypes.c_int, [ctypes.POINTER(MatpbrBrdfPhase), ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]),
+    "matpbr_brdf_phase_resolve": (ctypes.c_int, [ctypes.POINTER(MatpbrBrdfPhase), ctypes.c_int, ctypes.c_void_p]),
     "matpbr_env_phase_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "matpbr_env_phase_step": (ctypes.c_int, [_c_f] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

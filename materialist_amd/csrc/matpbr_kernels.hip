@@ -54,6 +54,55 @@ __global__ __launch_bounds__(kBlock) void loss_final1_kernel(const float* __rest
     sg = block_sum(sg, s_buf);
     if (threadIdx.x == 0) stats[b * kStatsStride + 0] = sg / sp;
 }
+// the step kernel's private state rows at the start of a phase: the caller's statistics, current values in buffer 0, no best render yet
+__global__ __launch_bounds__(kBlock) void step_state_init_kernel(const float* __restrict__ stats, float* __restrict__ state, int batch) {
+    for (int i = threadIdx.x; i < batch * kStateStride; i += kBlock) {
+        const int b = i / kStateStride, k = i - b * kStateStride;
+        state[i] = k < kStatsStride ? stats[b * kStatsStride + k] : (k == kStBestRatio ? -1.0f : 0.0f);
+    }
+}
+// MATPBR_FLAG_ROTATE_BEST, matpbr_brdf_phase_resolve: an image whose current values sit in the second buffers gets the two buffers of every
+// live map and of the render exchanged (current values back in the caller's parameter tensors and `pred`, the best ones in best_* and
+// `pred_next`); every image that improved in this phase gets best_img = max(best render x its exposure ratio, eps)^(1/2.2) -- the values the
+// copying form stores in the improving iteration.  One thread per pixel.
+struct ResolveArgs {
+    float *x0[3], *x1[3];   // a, r, m: null for a map the part does not move
+    float *p0, *p1, *best_img;
+    const float* state;     // [B][kStateStride] of the last step
+    long n1;
+};
+__global__ __launch_bounds__(kBlock) void phase_resolve_kernel(const ResolveArgs q) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= q.n1) return;
+    const bool swap = q.state[b * kStateStride + kStSel] > 0.5f;
+    const float bratio = q.state[b * kStateStride + kStBestRatio];
+    const long o1 = b * q.n1 + i, o3 = o1 * 3;
+    if (swap || bratio >= 0.0f) {     // SaveBest keeps the maps the render saw: clamped (the buffers hold raw parameters)
+#pragma unroll
+        for (int z = 0; z < 3; ++z) {
+            if (q.x0[z] == nullptr) continue;
+            const int w = z == 0 ? 3 : 1;
+            const float lo = z == 1 ? 0.07f : 0.0f;
+            for (int c = 0; c < w; ++c) {
+                const long o = (z == 0 ? o3 : o1) + c;
+                float u = q.x0[z][o], v = q.x1[z][o];
+                if (swap) { const float t = u; u = v; v = t; q.x0[z][o] = u; }
+                q.x1[z][o] = bratio >= 0.0f ? fminf(fmaxf(v, lo), 1.0f) : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float u = q.p0[o3 + c], v = q.p1[o3 + c];
+        if (swap) { const float t = u; u = v; v = t; q.p0[o3 + c] = u; q.p1[o3 + c] = v; }
+        if (bratio >= 0.0f && q.best_img) q.best_img[o3 + c] = pow_inv_gamma(fmaxf(v * bratio, kLossEps));
+    }
+}
+__global__ __launch_bounds__(kBlock) void phase_resolve_done_kernel(float* __restrict__ state2, int batch) {   // both copies: current values are in buffer 0 again
+    for (int i = threadIdx.x; i < 2 * batch; i += kBlock) state2[(long)i * kStateStride + kStSel] = 0.0f;
+}
+
 // pass 2: sum (xs-gs)^2, sum |xs-gs| over [H,W,3]; sum |a-a0| over [H,W,3]; sum |r-r0|, |m-m0| over [H,W]
 // FROM_FWD: ratio is formed here from the forward kernel's per-workgroup sums and the stored sum(gt) (no pass 1).
 template <int MODE>   // 0: ratio from stats (piecewise API); 1: BRDF phase step (ratio from the forward sums); 3: the same, folded by the step kernel; 4: as 3 with the regulariser sums carried by the step kernel (its per-workgroup sums are folded here by workgroup 0)
@@ -63,11 +112,14 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
                                                             const float* __restrict__ r0, const float* __restrict__ pm,
                                                             const float* __restrict__ m0, float* __restrict__ part, long n3, long n1,
                                                             const float* __restrict__ fwd_sums, int n_fwd, unsigned part_mask,
-                                                            const float* __restrict__ reg_sums = nullptr) {
+                                                            const float* __restrict__ reg_sums = nullptr, const float* __restrict__ pred_alt = nullptr,
+                                                            const float* __restrict__ state = nullptr) {
     __shared__ float s_buf[4];
     const int b = blockIdx.y;
     float ratio = 1.0f;
     if (MODE >= 1 && img_stopped(stats, b)) return;
+    // MATPBR_FLAG_ROTATE_BEST: the image's current render is in the buffer its state row names (uniform)
+    if (MODE >= 3 && state != nullptr && state[b * kStateStride + kStSel] > 0.5f) pred = pred_alt;
     float sp_total = 0.0f;
     if (MODE == 1 || MODE >= 3) {
         float sp = 0.0f;
@@ -1158,7 +1210,7 @@ int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, 
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
     if (H <= 0 || W <= 0 || batch <= 0) return 0;
     return ((size_t)batch * (grid_blocks(H, W) + lazy_groups((long)H * W)) + (size_t)batch * step_part_stride(kRedBlocks) +
-            2 * (size_t)batch * kStatsStride /* the step kernel's alternating SaveBest / EarlyStopping state */ +
+            2 * (size_t)batch * kStateStride /* the step kernel's alternating SaveBest / EarlyStopping state */ +
             3 * (size_t)batch * grid_blocks(H, W) /* its per-workgroup regulariser sums */) * sizeof(float);
 }
 
@@ -1215,15 +1267,16 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     const int step_rows = kStepRows;
     // [2][B][kStatsStride], at a fixed place (`part` moves with the number of forward sums, which differs between t = 1 and later steps)
     float* state2 = (float*)q.workspace + (size_t)q.batch * (grid_blocks(q.H, q.W) + lazy_groups(n1)) + (size_t)q.batch * step_part_stride(kRedBlocks);
-    float* reg_sums = state2 + 2 * (size_t)q.batch * kStatsStride;     // [B][grid_blocks][3]
+    float* reg_sums = state2 + 2 * (size_t)q.batch * kStateStride;     // [B][grid_blocks][3]
+    const bool rotate = lazy_fused && (q.flags & MATPBR_FLAG_ROTATE_BEST) != 0;
+    const float* state_cur = state2 + (size_t)((t - 1) & 1) * q.batch * kStateStride;   // written by the step before (t = 1: from `stats`, below)
     if ((stages & MATPBR_STAGE_STATS) && lazy_fused) {
         // one launch: the partial rows; their fold and the SaveBest / EarlyStopping commit happen at the head of the step kernel
-        if (t == 1 && hipMemcpyAsync(state2, q.stats, sizeof(float) * (size_t)q.batch * kStatsStride, hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return MATPBR_ERR_LAUNCH;
+        if (t == 1) hipLaunchKernelGGL(step_state_init_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)q.stats, state2, q.batch);
         if (t > 1)     // the step before left the regulariser sums of the parameters it wrote: this pass reads pred and the target only
             hipLaunchKernelGGL(loss_sums2_kernel<4>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                                (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
-                               (const float*)fwd_sums, nfwd, q.part_mask, (const float*)reg_sums);
+                               (const float*)fwd_sums, nfwd, q.part_mask, (const float*)reg_sums, (const float*)q.pred_next, rotate ? state_cur : nullptr);
         else
             hipLaunchKernelGGL(loss_sums2_kernel<3>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                                (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
@@ -1260,8 +1313,15 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         ls.attached = (q.flags & MATPBR_FLAG_ATTACHED_SAMPLING) ? 1 : 0;
         ls.fold_part = part; ls.fold_rows = step_rows;
         ls.reg_sums = reg_sums; ls.reg_from_part = t > 1 ? 1 : 0;
-        ls.state_old = state2 + (size_t)((t - 1) & 1) * q.batch * kStatsStride;
-        ls.state_new = state2 + (size_t)(t & 1) * q.batch * kStatsStride;
+        ls.state_old = state_cur;
+        ls.state_new = state2 + (size_t)(t & 1) * q.batch * kStateStride;
+        ls.rotate = rotate ? 1 : 0;
+        if (rotate) {
+            ls.alt_a = (q.part_mask & MATPBR_PART_A) ? q.best_a : nullptr;
+            ls.alt_r = (q.part_mask & MATPBR_PART_R) ? q.best_r : nullptr;
+            ls.alt_m = (q.part_mask & MATPBR_PART_M) ? q.best_m : nullptr;
+            ls.pred_buf[0] = q.pred; ls.pred_buf[1] = q.pred_next;
+        }
         ls.stats_out = q.stats; ls.history = q.history; ls.hist_len = q.hist_len; ls.batch = q.batch;
         ls.es_patience = q.es_patience; ls.es_min_delta = q.es_min_delta;
         hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);
@@ -1269,6 +1329,29 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         hipLaunchKernelGGL((jac_bwd_kernel<true, true>), dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);
     else
         hipLaunchKernelGGL((jac_bwd_kernel<true, false>), dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);
+    return launch_status();
+}
+
+int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* ph, int t_done, void* stream) {
+    if (!ph || t_done < 0) return MATPBR_ERR_INVALID_ARG;
+    const MatpbrBrdfPhase& q = *ph;
+    if (!(q.flags & MATPBR_FLAG_ROTATE_BEST) || t_done == 0) return MATPBR_OK;       // nothing rotates
+    if (!q.pa || !q.pr || !q.pm || !q.pred || !q.pred_next || !q.lazy_state || !q.workspace || q.batch <= 0 || q.H <= 0 || q.W <= 0) return MATPBR_ERR_INVALID_ARG;
+    if (q.workspace_bytes < matpbr_brdf_phase_workspace_bytes(q.H, q.W, q.batch)) return MATPBR_ERR_WORKSPACE;
+    if (((q.part_mask & MATPBR_PART_A) && !q.best_a) || ((q.part_mask & MATPBR_PART_R) && !q.best_r) || ((q.part_mask & MATPBR_PART_M) && !q.best_m))
+        return MATPBR_ERR_INVALID_ARG;
+    const long n1 = (long)q.H * q.W;
+    float* state2 = (float*)q.workspace + (size_t)q.batch * (grid_blocks(q.H, q.W) + lazy_groups(n1)) + (size_t)q.batch * step_part_stride(kRedBlocks);
+    ResolveArgs ra{};
+    ra.x0[0] = (q.part_mask & MATPBR_PART_A) ? q.pa : nullptr; ra.x1[0] = q.best_a;
+    ra.x0[1] = (q.part_mask & MATPBR_PART_R) ? q.pr : nullptr; ra.x1[1] = q.best_r;
+    ra.x0[2] = (q.part_mask & MATPBR_PART_M) ? q.pm : nullptr; ra.x1[2] = q.best_m;
+    ra.p0 = q.pred; ra.p1 = q.pred_next; ra.best_img = q.best_img;
+    ra.state = state2 + (size_t)(t_done & 1) * q.batch * kStateStride;
+    ra.n1 = n1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(phase_resolve_kernel, dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, ra);
+    hipLaunchKernelGGL(phase_resolve_done_kernel, dim3(1), dim3(kBlock), 0, st, state2, q.batch);
     return launch_status();
 }
 

@@ -193,8 +193,14 @@ struct LazyStepArgs {
     float* reg_sums;          // nullable [B][n_sums][3]: per-workgroup sums of |a - a0|, |r - r0|, |m - m0| at the UPDATED parameters (the next
                               // iteration's regulariser terms: its statistics pass then reads pred and the target only)
     int reg_from_part;        // the regulariser sums of THIS iteration are in the tail of fold_part (carried by the step before)
-    const float* state_old;   // [B][kStatsStride]
-    float* state_new;         // [B][kStatsStride]
+    const float* state_old;   // [B][kStateStride]
+    float* state_new;         // [B][kStateStride]
+    int rotate;               // MATPBR_FLAG_ROTATE_BEST: SaveBest without copies.  The live maps and the render live in two buffers each
+                              // (j.pa / alt_a, ..., pred_buf[0] / pred_buf[1]); the state row says which holds the current values.  An improving
+                              // iteration declares the buffer it has just read "best" and writes the new values into the other one; any
+                              // other iteration updates in place.  matpbr_brdf_phase_resolve puts things where the caller expects them.
+    float *alt_a, *alt_r, *alt_m;   // second buffer of each live map (the caller's best_*), null for a map the part does not move
+    float* pred_buf[2];
     float* stats_out;         // [B][kStatsStride] the public rows
     float* history;
     int hist_len, batch, es_patience;
@@ -219,11 +225,19 @@ __device__ __forceinline__ float ldf(const void* base, unsigned off) { return *(
 __device__ __forceinline__ void stf(void* base, unsigned off, float v) { *(float*)((char*)base + off) = v; }
 
 // one pixel of lazy_step_kernel; returns whether the pixel's new roughness has left its model's interval, adds its render to `tot`
-__device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned i, float ratio, float sr, bool improved, float& tot, float (&reg)[3],
-                                                LazyRecord& rec) {
+struct StepPtrs {             // where this image's iteration reads its parameters and writes the new ones and the next render (uniform)
+    const float *a, *r, *m;
+    float *pa, *pr, *pm, *pred_next;
+};
+__device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, float ratio, float sr, bool improved, float& tot,
+                                                float (&reg)[3], LazyRecord& rec) {
+#ifdef MATPBR_NO_SNAPSHOT   // measurement only (tools/no_snapshot_ab.sh)
+    improved = false;
+#endif
+    if (qs.rotate) improved = false;      // no snapshot stores: the buffer just read IS the snapshot
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
-    const float ra[3] = {ldf(q.a, o3), ldf(q.a, o3 + 4), ldf(q.a, o3 + 8)}, rr = ldf(q.r, o1), rm = ldf(q.m, o1);
+    const float ra[3] = {ldf(sp.a, o3), ldf(sp.a, o3 + 4), ldf(sp.a, o3 + 8)}, rr = ldf(sp.r, o1), rm = ldf(sp.m, o1);
     const float gt[3] = {ldf(q.gt_srgb, o3), ldf(q.gt_srgb, o3 + 4), ldf(q.gt_srgb, o3 + 8)};
     // the pixel's model
     const float rref = as_f(ldu(qs.plane[kLzRref], o1));
@@ -281,7 +295,7 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
             gsum = (ra[c] >= 0.0f && ra[c] <= 1.0f) ? gsum : 0.0f;                                                               // clamp backward
             if (q.d_a) stf(q.d_a, o3 + 4 * c, gsum);
             if (improved && q.best_a) stf(q.best_a, o3 + 4 * c, a[c]);
-            if (q.am[0]) { na[c] = adam_update(ra[c], gsum, q.am[0], q.av[0], (long)i * 3 + c, q); stf(q.pa, o3 + 4 * c, na[c]); }
+            if (q.am[0]) { na[c] = adam_update(ra[c], gsum, q.am[0], q.av[0], (long)i * 3 + c, q); stf(sp.pa, o3 + 4 * c, na[c]); }
             reg[0] += fabsf(fminf(fmaxf(na[c], 0.0f), 1.0f) - a0c);
         }
     } else if (q.d_a) {
@@ -301,8 +315,8 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
     if (q.d_m) stf(q.d_m, o1, gm);
     if (improved && q.best_r) stf(q.best_r, o1, r);
     if (improved && q.best_m) stf(q.best_m, o1, m);
-    if ((q.part_mask & MATPBR_PART_R) && q.am[1]) { nr = adam_update(rr, gr, q.am[1], q.av[1], (long)i, q); stf(q.pr, o1, nr); }
-    if ((q.part_mask & MATPBR_PART_M) && q.am[2]) { nm = adam_update(rm, gm, q.am[2], q.av[2], (long)i, q); stf(q.pm, o1, nm); }
+    if ((q.part_mask & MATPBR_PART_R) && q.am[1]) { nr = adam_update(rr, gr, q.am[1], q.av[1], (long)i, q); stf(sp.pr, o1, nr); }
+    if ((q.part_mask & MATPBR_PART_M) && q.am[2]) { nm = adam_update(rm, gm, q.am[2], q.av[2], (long)i, q); stf(sp.pm, o1, nm); }
     // ---- forward of iteration t+1 from the same model
     const float r1 = fminf(fmaxf(nr, 0.07f), 1.0f), m1 = fminf(fmaxf(nm, 0.0f), 1.0f), dr1 = r1 - rref, omm1 = 1.0f - m1;
     if (q.part_mask & MATPBR_PART_R) reg[1] += fabsf(r1 - r0v);
@@ -318,7 +332,7 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, unsigned
         const float rgb = fmaf(a1 * omm1, Pc, fmaf(C0, SD, S1));
         rec.a[c] = a1;
         if (!need) {
-            stf(qs.pred_next, o3 + 4 * c, rgb);
+            stf(sp.pred_next, o3 + 4 * c, rgb);
             tot += rgb;
         }
     }
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
     __shared__ float4 s_ring[kMaxRings];
     __shared__ float2 s_saz[kMaxRings * kMaxAz];
     __shared__ float s_rec[kLazyBlockPixels * kRecStride];
-    __shared__ float s_state[kStatsStride];
+    __shared__ float s_state[kStateStride];
     __shared__ float s_fold[4][6];
     const JacBwdArgs& q = qs.j;
     const int b = blockIdx.y;
@@ -357,14 +371,14 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
     float ratio, sr, gt_sum;
     bool improved;
     if (qs.fold_part != nullptr) {
-        const float* old = qs.state_old + b * kStatsStride;
+        const float* old = qs.state_old + b * kStateStride;
         if (old[kStStopped] > 0.5f) {                          // EarlyStopping fired in an earlier iteration (uniform): nothing to do
-            if (blockIdx.x == 0 && threadIdx.x < kStatsStride) {
+            if (blockIdx.x == 0 && threadIdx.x < kStateStride) {
                 float v = old[threadIdx.x];
                 if (threadIdx.x == kStStopped) v = 2.0f;
                 if (threadIdx.x == kStImproved) v = 0.0f;
-                qs.state_new[b * kStatsStride + threadIdx.x] = v;
-                qs.stats_out[b * kStatsStride + threadIdx.x] = v;
+                qs.state_new[b * kStateStride + threadIdx.x] = v;
+                if (threadIdx.x < kStatsStride) qs.stats_out[b * kStatsStride + threadIdx.x] = v;
             }
             return;
         }
@@ -382,9 +396,11 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
         }
         float st[kStatsStride];                                // thread 0: the old state in registers (sixteen independent loads, issued
         const float sp_total = rows[(long)qs.fold_rows * 5];   // before the barrier), the commit on registers, one burst of LDS writes
+        float sel_old = 0.0f, bratio = -1.0f;
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int i = 0; i < kStatsStride; ++i) st[i] = old[i];
+            sel_old = old[kStSel]; bratio = old[kStBestRatio];
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -401,11 +417,16 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
                          blockIdx.x == 0 ? qs.history : nullptr, qs.hist_len, qs.batch, b);
 #pragma unroll
             for (int i = 0; i < kStatsStride; ++i) s_state[i] = st[i];
+            const bool imp = st[kStImproved] > 0.5f && qs.rotate != 0;
+            s_state[kStSel] = imp ? 1.0f - sel_old : sel_old;          // the buffer the new values go to: the other one after an improvement
+            s_state[kStBestRatio] = imp ? st[kStRatio] : bratio;
+            s_state[kStSelOld] = sel_old;
+            s_state[kStSelOld + 1] = 0.0f;
         }
         __syncthreads();
-        if (blockIdx.x == 0 && threadIdx.x < kStatsStride) {
-            qs.state_new[b * kStatsStride + threadIdx.x] = s_state[threadIdx.x];
-            qs.stats_out[b * kStatsStride + threadIdx.x] = s_state[threadIdx.x];
+        if (blockIdx.x == 0 && threadIdx.x < kStateStride) {
+            qs.state_new[b * kStateStride + threadIdx.x] = s_state[threadIdx.x];
+            if (threadIdx.x < kStatsStride) qs.stats_out[b * kStatsStride + threadIdx.x] = s_state[threadIdx.x];
         }
         ratio = s_state[kStRatio];
         sr = s_state[kStSr];
@@ -425,8 +446,17 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
     bool need0 = false, need1 = false;
     LazyRecord rec0, rec1;
     float reg[3] = {0.0f, 0.0f, 0.0f};
-    if (q0 < P) need0 = lazy_step_pixel(qs, (unsigned)(b * P + q0), ratio, sr, improved, tot, reg, rec0);
-    if (q1 < P) need1 = lazy_step_pixel(qs, (unsigned)(b * P + q1), ratio, sr, improved, tot, reg, rec1);
+    StepPtrs sp{q.a, q.r, q.m, q.pa, q.pr, q.pm, qs.pred_next};
+    if (qs.rotate) {                                           // uniform per image: scalar selects of the base pointers
+        const bool rd1 = __builtin_amdgcn_readfirstlane((int)(s_state[kStSelOld] > 0.5f)) != 0;
+        const bool wr1 = __builtin_amdgcn_readfirstlane((int)(s_state[kStSel] > 0.5f)) != 0;
+        if (qs.alt_a) { sp.a = rd1 ? qs.alt_a : q.pa; sp.pa = wr1 ? qs.alt_a : q.pa; }
+        if (qs.alt_r) { sp.r = rd1 ? qs.alt_r : q.pr; sp.pr = wr1 ? qs.alt_r : q.pr; }
+        if (qs.alt_m) { sp.m = rd1 ? qs.alt_m : q.pm; sp.pm = wr1 ? qs.alt_m : q.pm; }
+        sp.pred_next = qs.pred_buf[wr1 ? 1 : 0];
+    }
+    if (q0 < P) need0 = lazy_step_pixel(qs, sp, (unsigned)(b * P + q0), ratio, sr, improved, tot, reg, rec0);
+    if (q1 < P) need1 = lazy_step_pixel(qs, sp, (unsigned)(b * P + q1), ratio, sr, improved, tot, reg, rec1);
     if (qs.reg_sums) {                                         // fixed order: DPP tree per wave, the four waves in order
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -603,7 +633,7 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
                     *(uint32_t*)((char*)qs.plane[kLzSk + c] + o1) = pack_h2(gSD[c], gS1[c]);
                     *(uint32_t*)((char*)qs.plane[kLzDk + c] + o1) = pack_h2(dSD[c], dS1v[c]);
                     const float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
-                    stf(qs.pred_next, o3 + 4 * c, rgb);
+                    stf(sp.pred_next, o3 + 4 * c, rgb);
                     tot += rgb;
                 }
             }

@@ -429,6 +429,12 @@ __device__ __forceinline__ void spec_accumulate(const Pixel& px, const LightRegs
 constexpr int kStatsStride = 16;
 enum { kStRatio = 0, kStMse, kStL1, kStSr, kStLa, kStLr, kStLm, kStLoss, kStImproved, kStBest, kStEsCounter, kStEsBest, kStEsHas,
        kStStopped, kStIters, kStGtSum };
+// The step kernel's private copy of a row (two alternating copies in the phase workspace) is four floats longer: with
+// MATPBR_FLAG_ROTATE_BEST the parameters of the live maps and the render live in two buffers each (the caller's tensor and its SaveBest
+// target) and kStSel says which of the two holds the CURRENT values (the other one holds the best so far, or nothing yet); kStBestRatio is
+// the exposure ratio of the best iteration (< 0: no improvement in this phase yet), from which matpbr_brdf_phase_resolve forms best_img.
+constexpr int kStateStride = 20;
+enum { kStSel = 16, kStBestRatio = 17, kStSelOld = 18 /* LDS broadcast only */ };
 // kStStopped: 0 running; 1 = EarlyStopping fired in this iteration (its backward / optimiser step still run, as in the reference's
 // loop, which breaks after optimizer.step()); 2 = stopped in an earlier iteration (every kernel skips the image).
 __device__ __forceinline__ bool img_stopped(const float* stats, int b) { return stats[b * kStatsStride + kStStopped] > 0.5f; }

@@ -243,11 +243,13 @@ class FusedBrdfPhase:
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
                  min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
                  originals: Optional[Dict[str, torch.Tensor]] = None, keep_grads: bool = False, lazy: Optional[bool] = None,
-                 lazy_tol: float = 1.0, attached_sampling: bool = False):
+                 lazy_tol: float = 1.0, attached_sampling: bool = False, rotate_best: Optional[bool] = None):
         """`lazy` (default `FusedBrdfPhase.LAZY`): in parts that move the roughness, render from per-pixel local models in r and walk
         the GGX samples only of the pixels that left their model's validity interval (include/matpbr.h `matpbr_shade_fwd_lazy`).
         `attached_sampling` (lazy parts only): the roughness gradient through the GGX sample directions, the live reference's convention
-        (mi_plugin.py:227-230,1335-1341), instead of the stop-gradient default."""
+        (mi_plugin.py:227-230,1335-1341), instead of the stop-gradient default.
+        `rotate_best` (default: with `lazy`): SaveBest without copies -- MATPBR_FLAG_ROTATE_BEST, include/matpbr.h; False: the step
+        kernel copies the snapshot in every improving iteration (the same values, bit for bit)."""
         import ctypes
 
         from . import _lib, ops
@@ -262,14 +264,15 @@ class FusedBrdfPhase:
         self.B, self.H, self.W = B, self.gt.shape[-3], self.gt.shape[-2]
         self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
         c = lambda t: t.detach().clone().contiguous()
-        self.p = {"albedo": c(albedo), "roughness": c(roughness), "metallic": c(metallic)}
-        self.orig = {k: c(originals[k] if originals is not None and k in originals else v).reshape(v.shape) for k, v in self.p.items()}
-        self.g = {k: torch.empty_like(v) for k, v in self.p.items()} if keep_grads else None
-        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
-        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
-        self.best = {k: c(v) for k, v in self.p.items()}
-        self.best_img = torch.zeros_like(self.gt)
-        self.pred = torch.empty_like(self.gt)
+        self._p = {"albedo": c(albedo), "roughness": c(roughness), "metallic": c(metallic)}
+        self.orig = {k: c(originals[k] if originals is not None and k in originals else v).reshape(v.shape) for k, v in self._p.items()}
+        self.g = {k: torch.empty_like(v) for k, v in self._p.items()} if keep_grads else None
+        self.m = {k: torch.zeros_like(v) for k, v in self._p.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self._p.items()}
+        self._best = {k: c(v) for k, v in self._p.items()}
+        self._best_img = torch.zeros_like(self.gt)
+        self._pred = torch.empty_like(self.gt)
+        self._dirty = False
         self.stats = ops.new_loss_stats(B, dev)
         if best_mse is not None:   # SaveBest.best_loss is global across phases and never reset (F11)
             self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
@@ -284,18 +287,18 @@ class FusedBrdfPhase:
         self.base_lr, self.t = float(lr), 0
         # light and shading normals do not change during the phase: the diffuse lobe reduces to 9 coefficients per pixel
         self.dcache = ops.diffuse_cache(self.n, self.light, self.spp, scene.fov)
-        self.jac = ops.plane9(self.p["albedo"])
+        self.jac = ops.plane9(self._p["albedo"])
         ph = _lib.MatpbrBrdfPhase()
         P = lambda t: ctypes.c_void_p(t.data_ptr())
-        ph.pa, ph.pr, ph.pm = P(self.p["albedo"]), P(self.p["roughness"]), P(self.p["metallic"])
+        ph.pa, ph.pr, ph.pm = P(self._p["albedo"]), P(self._p["roughness"]), P(self._p["metallic"])
         ph.n, ph.light, ph.gt_srgb = P(self.n), P(self.light), P(self.gt_srgb)
         ph.a0, ph.r0, ph.m0 = P(self.orig["albedo"]), P(self.orig["roughness"]), P(self.orig["metallic"])
-        ph.dcache, ph.pred, ph.jac = P(self.dcache), P(self.pred), P(self.jac)
+        ph.dcache, ph.pred, ph.jac = P(self.dcache), P(self._pred), P(self.jac)
         if self.g is not None:
             ph.d_a, ph.d_r, ph.d_m = P(self.g["albedo"]), P(self.g["roughness"]), P(self.g["metallic"])
         for i, k in enumerate(("albedo", "roughness", "metallic")):
             ph.adam_m[i], ph.adam_v[i] = self.m[k].data_ptr(), self.v[k].data_ptr()
-        ph.best_a, ph.best_r, ph.best_m, ph.best_img = P(self.best["albedo"]), P(self.best["roughness"]), P(self.best["metallic"]), P(self.best_img)
+        ph.best_a, ph.best_r, ph.best_m, ph.best_img = P(self._best["albedo"]), P(self._best["roughness"]), P(self._best["metallic"]), P(self._best_img)
         ph.stats, ph.history, ph.workspace = P(self.stats), P(self.hist), P(self.ws)
         ph.workspace_bytes = self.ws.numel() * 4
         ph.H, ph.W, ph.batch, ph.spp = self.H, self.W, B, self.spp
@@ -308,7 +311,7 @@ class FusedBrdfPhase:
         self.lazy = bool(self.LAZY if lazy is None else lazy)
         self.s1cache = None if ("r" in optimize_part or self.lazy) else torch.empty((3,) + tuple(self.jac.shape[1:]), dtype=torch.float32, device=self.jac.device)
         ph.s1cache = P(self.s1cache) if self.s1cache is not None else None
-        self.lazy_state = ops.lazy_state(self.p["albedo"]) if self.lazy else None
+        self.lazy_state = ops.lazy_state(self._p["albedo"]) if self.lazy else None
         ph.lazy_state = P(self.lazy_state) if self.lazy else None
         ph.lazy_tol = float(lazy_tol)
         if attached_sampling and not self.lazy:
@@ -319,21 +322,26 @@ class FusedBrdfPhase:
         self.bg_mask = scene.bg_mask
         if self.bg_mask is not None:
             bg_rgb = scene.background_radiance(self.light)
-            pc = (self.p["albedo"], self.p["roughness"], self.p["metallic"])
+            pc = (self._p["albedo"], self._p["roughness"], self._p["metallic"])
             if self.lazy:
-                ops.shade_fwd_lazy(*pc, self.n, self.light, self.spp, self.dcache, self.lazy_state, out=self.pred, jac16=self.jac.view(torch.int32)[:5],
+                ops.shade_fwd_lazy(*pc, self.n, self.light, self.spp, self.dcache, self.lazy_state, out=self._pred, jac16=self.jac.view(torch.int32)[:5],
                                    force=True, clamp_params=True, stats=self.stats, fov_x_deg=scene.fov)      # per-image parity floor from the statistics row
-                ops.background_into_lazy_state(self.lazy_state, self.p["albedo"], self.bg_mask, bg_rgb, self.p["roughness"])
+                ops.background_into_lazy_state(self.lazy_state, self._p["albedo"], self.bg_mask, bg_rgb, self._p["roughness"])
             elif self.s1cache is not None:
-                ops.shade_fwd(*pc, self.n, self.light, self.spp, scene.fov, clamp_params=True, out=self.pred, dcache=self.dcache, jac=self.jac, s1=self.s1cache)
+                ops.shade_fwd(*pc, self.n, self.light, self.spp, scene.fov, clamp_params=True, out=self._pred, dcache=self.dcache, jac=self.jac, s1=self.s1cache)
                 ops.background_into_jac(self.jac, self.s1cache, self.bg_mask, bg_rgb)
             else:
                 raise NotImplementedError("pixels without geometry need the lazy path in parts that optimise the roughness")
             ph.flags |= ops.FLAG_MODELS_READY
         # lazy: the step's last launch also renders the next iterate (into pred_next); the two render buffers swap roles every step
-        self._pred_bufs = [self.pred, torch.empty_like(self.gt)] if self.lazy else None
+        self._pred_bufs = [self._pred, torch.empty_like(self.gt)] if self.lazy else None
         self._pred_cur = 0
         ph.pred_next = P(self._pred_bufs[1]) if self.lazy else None
+        # lazy: SaveBest without copies (MATPBR_FLAG_ROTATE_BEST): the live maps and the render rotate between two buffers each on the
+        # device; `p`, `best`, `best_img` and `pred` are resolved (one launch) when they are next read
+        self.rotate = self.lazy if rotate_best is None else (bool(rotate_best) and self.lazy)
+        if self.rotate:
+            ph.flags |= ops.FLAG_ROTATE_BEST
         self._ph, self._lib = ph, lib
 
     def lr_at(self, t0: int) -> float:
@@ -352,12 +360,46 @@ class FusedBrdfPhase:
         self._libmod.check(code, "matpbr_brdf_phase_step")
         self._advance()
 
+    def _resolve(self) -> None:
+        if self._dirty:
+            self._dirty = False
+            with torch.cuda.device(self.gt.device):
+                code = self._lib.matpbr_brdf_phase_resolve(self._ct.byref(self._ph), self.t,
+                                                           self._ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
+            self._libmod.check(code, "matpbr_brdf_phase_resolve")
+
+    @property
+    def p(self) -> Dict[str, torch.Tensor]:
+        """The raw parameters after the iterations run so far."""
+        self._resolve()
+        return self._p
+
+    @property
+    def best(self) -> Dict[str, torch.Tensor]:
+        """SaveBest's maps (clamped), as of the best iteration so far."""
+        self._resolve()
+        return self._best
+
+    @property
+    def best_img(self) -> torch.Tensor:
+        self._resolve()
+        return self._best_img
+
+    @property
+    def pred(self) -> torch.Tensor:
+        """Lazy mode: the render of the CURRENT parameters (what the next iteration will judge; the last launch of a step renders it).
+        `lazy=False`: the render the last iteration judged."""
+        self._resolve()
+        return self._pred
+
     def _advance(self) -> None:
         ct = self._ct
         self.t += 1
-        if self._pred_bufs is not None:
+        if self.rotate:
+            self._dirty = True
+        elif self._pred_bufs is not None:
             # self.pred = the render this step evaluated; the buffer its last launch rendered the next iterate into becomes `pred` of the next step
-            self.pred = self._pred_bufs[self._pred_cur]
+            self._pred = self._pred_bufs[self._pred_cur]
             self._pred_cur ^= 1
             self._ph.pred = ct.c_void_p(self._pred_bufs[self._pred_cur].data_ptr())
             self._ph.pred_next = ct.c_void_p(self._pred_bufs[self._pred_cur ^ 1].data_ptr())
@@ -397,7 +439,8 @@ class FusedBrdfPhase:
         return self.hist[: self.t]
 
     def current_maps(self) -> Dict[str, torch.Tensor]:
-        return {"albedo": self.p["albedo"].clamp(0, 1), "roughness": self.p["roughness"].clamp(0.07, 1), "metallic": self.p["metallic"].clamp(0, 1)}
+        p = self.p
+        return {"albedo": p["albedo"].clamp(0, 1), "roughness": p["roughness"].clamp(0.07, 1), "metallic": p["metallic"].clamp(0, 1)}
 
 
 class MaskedBrdfPhase:

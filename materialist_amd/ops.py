@@ -18,6 +18,7 @@ FLAG_ATTACHED_SAMPLING = 2
 FLAG_LAZY_FORCE = 16
 FLAG_JAC16 = 32
 FLAG_MODELS_READY = 64
+FLAG_ROTATE_BEST = 128
 LAZY_NSTATE = 22
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,

@@ -142,7 +142,7 @@ def _phase_setup(dev, H, W, spp, image_id=0):
 
 def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_iteration():
     """THE GATE: 2 000 iterations of part 'rm' at 512 x 512 (lr schedule of inverse_img_w_mi.py:363-365,431-432).  Every iteration's
-    lazy render against the exact render of the same parameters; d out / d r of the just re-sampled pixels against the exact jac."""
+    lazy render (of the parameters the step before it wrote) against the exact render of the same parameters; d out / d r of the just re-sampled pixels against the exact jac."""
     from materialist_amd import loop, ops
 
     dev = _cuda()
@@ -156,8 +156,9 @@ def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_
     nref = torch.zeros(iters, device=dev)
     exact, jac = torch.empty_like(gt), ops.plane9(gt)
     for it in range(iters):
-        pa, pr, pm = ph.p["albedo"].clone(), ph.p["roughness"].clone(), ph.p["metallic"].clone()
         ph.step()
+        # the step's last launch has rendered the parameters it has just written (what the next iteration judges): `pred`
+        pa, pr, pm = ph.p["albedo"].clone(), ph.p["roughness"].clone(), ph.p["metallic"].clone()
         ops.shade_fwd(pa, pr, pm, ph.n, ph.light, spp, clamp_params=True, out=exact, dcache=ph.dcache, jac=jac)
         worst = torch.maximum(worst, _rel(ph.pred, exact))
         # the pixels listed for re-sampling by this step's last launch (their new roughness left the model's interval)
@@ -181,6 +182,44 @@ def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_
     assert float(worst) <= 1e-3
     assert float(worst_dr) <= 2e-3
     assert nref[0] == 1.0 and nref[1:].mean() < 0.1
+
+
+@pytest.mark.parametrize("part", ["rm", "a", "arm"])
+def test_savebest_without_copies_leaves_what_the_copying_step_leaves(part):
+    """MATPBR_FLAG_ROTATE_BEST (the default of the lazy loop): parameters, SaveBest's maps and image, statistics and history against the
+    form whose step kernel copies the snapshot in every improving iteration -- bit for bit, at several points of the phase (a resolve in
+    the middle of a phase must not disturb what follows), with EarlyStopping armed; and a phase that never improves on the best_mse it
+    is given: its best maps and best image must stay what they were."""
+    from materialist_amd import loop, ops
+
+    dev = _cuda()
+    H = W = 96
+    spp = 64
+    scene, gt, init = _phase_setup(dev, H, W, spp, image_id=2)
+    best0 = torch.tensor([1e30], device=dev)
+    kw = dict(optimize_part=part, spp=spp, patience=40, min_delta=1e-3, history_len=400)
+    rot = loop.FusedBrdfPhase(scene, gt, *init, best_mse=best0, **kw)
+    cpy = loop.FusedBrdfPhase(scene, gt, *init, best_mse=best0, rotate_best=False, **kw)
+    assert rot.rotate and not cpy.rotate
+    done = 0
+    for upto in (1, 2, 7, 60, 61, 300):
+        rot.run(upto - done)
+        cpy.run(upto - done)
+        done = upto
+        for name in ("albedo", "roughness", "metallic"):
+            assert torch.equal(rot.p[name], cpy.p[name]), (upto, name)
+            assert torch.equal(rot.best[name], cpy.best[name]), (upto, name)
+        assert torch.equal(rot.best_img, cpy.best_img), upto
+        assert torch.equal(rot.stats, cpy.stats), upto
+        assert torch.equal(rot.history(), cpy.history()), upto
+    # an image that cannot improve: the snapshots it came with survive the phase
+    tiny = torch.tensor([0.0], device=dev)
+    keep = loop.FusedBrdfPhase(scene, gt, *init, best_mse=tiny, optimize_part=part, spp=spp)
+    b0 = {k: v.clone() for k, v in keep.best.items()}
+    img0 = keep.best_img.clone()
+    keep.run(25)
+    assert all(torch.equal(keep.best[k], b0[k]) for k in b0) and torch.equal(keep.best_img, img0)
+    assert float(keep.stats[0, ops.STAT_BEST]) == 0.0
 
 
 def test_lazy_phase_lands_where_the_phase_that_walks_every_sample_lands():

@@ -1,0 +1,17 @@
+#!/bin/bash
+# upper bound of what SaveBest-without-copies could gain in the none-mode step: the same loop with the snapshot stores compiled out
+cd "$GRAFT_REPO_ROOT" || exit 1
+cp materialist_amd/libmatpbr.so /tmp/lib_keep.so
+python - <<'PY'
+import subprocess, os
+from materialist_amd import build as b
+cmd = [b._hipcc(), *b.HIPCC_FLAGS, "-DMATPBR_NO_SNAPSHOT", "-o", "/tmp/lib_nosnap.so", *[os.path.join(b.CSRC, s) for s in b.SOURCES]]
+subprocess.run(cmd, check=True)
+PY
+for round in 1 2; do
+  for v in nosnap keep; do
+    cp /tmp/lib_$v.so materialist_amd/libmatpbr.so
+    python bench.py --no-cpu-baseline --no-relight --steps 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', {k: round(v['it_per_s']) for k, v in d['modes'].items() if k.startswith('fused') and 'exact' not in k}, round(d['roofline']['avg_launch_ms']*1e3,1))"
+  done
+done
+cp /tmp/lib_keep.so materialist_amd/libmatpbr.so
