@@ -447,7 +447,7 @@ def main(argv=None):
                 "traffic": traffic, "traffic_source": pmc.get("source_r03") if traffic else None,
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "
-                        "really moves per launch (PMC: maps, the 80 B/pixel models, target, pred in and out, anchors, Adam moments, snapshots), "
+                        "really moves per launch (PMC: maps, the 80 B/pixel models, target, the next render, anchors, Adam moments), "
                         "own_traffic_frac = traffic / duration / peak: how close the launch is to the HBM limit on its OWN bytes"}
         ex = entry(px, tk["fwd_loop"], tk["bwd_loop"],
                    "round 2's pair (FusedBrdfPhase(lazy=False)): shade_kernel<jac> walks the 20 GGX samples of every pixel (cached diffuse lobe) + "
