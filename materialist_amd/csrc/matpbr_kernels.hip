@@ -130,6 +130,22 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
         ratio = stats[b * kStatsStride + kStRatio];
     }
     float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (MODE == 4 && (n3 & 3) == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(gt_srgb)) & 15) == 0) {
+        // the pass of every iteration after a phase's first: render and target only, 16 bytes per lane and load (fixed order: the four
+        // components of a word in turn, the words of a thread in turn)
+        const float4* p4 = reinterpret_cast<const float4*>(pred + b * n3);
+        const float4* g4 = reinterpret_cast<const float4*>(gt_srgb + b * n3);
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < (n3 >> 2); i += (long)gridDim.x * kBlock) {
+            const float4 pv = p4[i], gv = g4[i];
+            const float px[4] = {pv.x, pv.y, pv.z, pv.w}, gx[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = pow_inv_gamma(fmaxf(px[e] * ratio, kLossEps)) - gx[e];
+                s[0] = fmaf(d, d, s[0]);
+                s[1] += fabsf(d);
+            }
+        }
+    } else
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (long)gridDim.x * kBlock) {
         float xs = pow_inv_gamma(fmaxf(pred[b * n3 + i] * ratio, kLossEps));
         float d = xs - gt_srgb[b * n3 + i];
