@@ -120,6 +120,19 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
     if (MODE >= 1 && img_stopped(stats, b)) return;
     // MATPBR_FLAG_ROTATE_BEST: the image's current render is in the buffer its state row names (uniform)
     if (MODE >= 3 && state != nullptr && state[b * kStateStride + kStSel] > 0.5f) pred = pred_alt;
+    // MODE 4: the first two words of this thread are requested before the fold of the forward sums below (they do not depend on it)
+    const bool vec4 = MODE == 4 && (n3 & 3) == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(gt_srgb)) & 15) == 0;
+    const long stride4 = (long)gridDim.x * kBlock, first4 = (long)blockIdx.x * kBlock + threadIdx.x;
+    float4 pre_p[2], pre_g[2];
+    if (vec4) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long i = first4 + u * stride4;
+            const long ic = i < (n3 >> 2) ? i : 0;
+            pre_p[u] = reinterpret_cast<const float4*>(pred + b * n3)[ic];
+            pre_g[u] = reinterpret_cast<const float4*>(gt_srgb + b * n3)[ic];
+        }
+    }
     float sp_total = 0.0f;
     if (MODE == 1 || MODE >= 3) {
         float sp = 0.0f;
@@ -130,13 +143,12 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
         ratio = stats[b * kStatsStride + kStRatio];
     }
     float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (MODE == 4 && (n3 & 3) == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(gt_srgb)) & 15) == 0) {
+    if (vec4) {
         // the pass of every iteration after a phase's first: render and target only, 16 bytes per lane and load (fixed order: the four
         // components of a word in turn, the words of a thread in turn)
         const float4* p4 = reinterpret_cast<const float4*>(pred + b * n3);
         const float4* g4 = reinterpret_cast<const float4*>(gt_srgb + b * n3);
-        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < (n3 >> 2); i += (long)gridDim.x * kBlock) {
-            const float4 pv = p4[i], gv = g4[i];
+        auto word = [&](const float4 pv, const float4 gv) {
             const float px[4] = {pv.x, pv.y, pv.z, pv.w}, gx[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -144,7 +156,11 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
                 s[0] = fmaf(d, d, s[0]);
                 s[1] += fabsf(d);
             }
-        }
+        };
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (first4 + u * stride4 < (n3 >> 2)) word(pre_p[u], pre_g[u]);
+        for (long i = first4 + 2 * stride4; i < (n3 >> 2); i += stride4) word(p4[i], g4[i]);
     } else
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (long)gridDim.x * kBlock) {
         float xs = pow_inv_gamma(fmaxf(pred[b * n3 + i] * ratio, kLossEps));
