@@ -1289,6 +1289,19 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// three / four consecutive 1 KB pieces under one M0: the instruction offset advances the global AND the LDS address
+__device__ __forceinline__ void glds16_x3(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds16_x4v(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_dst) {   // v_j: the lane's offset of piece j MINUS 1024 j
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+               "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_dst) : "memory");
+}
 constexpr int kGlRows = 128 * 32 * 4;                                    // bytes of one row buffer
 constexpr size_t kGlSmem = 2 * kBxStage * sizeof(uint4) + 3 * kGlRows;   // 144 KB
 template <int EPI, int NPROD, bool FULL, bool HEAD = false, bool W0 = false, bool GL = false>   // FULL: all 256 output columns exist (N == 256): unguarded 16-byte stores
@@ -1672,13 +1685,12 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
   const int b_lane = lh * 256 + wn * 128 + li;
   auto issue_w = [&](int step_w, int wb) {                                // step_w: half super-step index within the reduction
     const char* src = reinterpret_cast<const char*>(wsplit) + (size_t)step_w * kGxW;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) glds16(src + 1024 * j, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW + 1024u * j);
+    glds16_x3(src, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW);
+    glds16_x3(src + 3072, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW + 3072u);
   };
   auto issue_a = [&](int tile_a, int g_a, int ab) {
     const float* src = p.A + (size_t)tile_a * kBM * p.lda + 32 * g_a;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(src, a_voff[j], a_dst + (unsigned)ab * (unsigned)kGlRows + 1024u * j);
+    glds16_x4v(src, a_voff[0], a_voff[1] - 1024u, a_voff[2] - 2048u, a_voff[3] - 3072u, a_dst + (unsigned)ab * (unsigned)kGlRows);
   };
   issue_w(0, 0);
   issue_a(blockIdx.x, 0, 0);
