@@ -238,6 +238,7 @@ class FusedBrdfPhase:
 
     PARTS = {"a": 2, "r": 4, "m": 8}
     LAZY = True
+    ROTATE_BEST = True      # SaveBest without copies in the lazy loop (MATPBR_FLAG_ROTATE_BEST); False: the copying step
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
@@ -339,7 +340,7 @@ class FusedBrdfPhase:
         ph.pred_next = P(self._pred_bufs[1]) if self.lazy else None
         # lazy: SaveBest without copies (MATPBR_FLAG_ROTATE_BEST): the live maps and the render rotate between two buffers each on the
         # device; `p`, `best`, `best_img` and `pred` are resolved (one launch) when they are next read
-        self.rotate = self.lazy if rotate_best is None else (bool(rotate_best) and self.lazy)
+        self.rotate = (self.lazy and self.ROTATE_BEST) if rotate_best is None else (bool(rotate_best) and self.lazy)
         if self.rotate:
             ph.flags |= ops.FLAG_ROTATE_BEST
         self._ph, self._lib = ph, lib
