@@ -226,10 +226,12 @@ typedef struct MatpbrBrdfPhase {
     float* pred_next;                     /* nullable [B,H,W,3], with lazy_state: the step's last launch is the backward pass + Adam of this iteration AND
                                              the render of the next one from the updated parameters (maps, models and Adam state are read once per
                                              iteration; no jac planes).  On return `pred` holds this iteration's render as always and `pred_next` the
-                                             next one (pixels that left their model's interval pending); the caller SWAPS pred and pred_next before the
+                                             next one (complete after the resampling stage); the caller SWAPS pred and pred_next before the
                                              next step, calls the steps with t = 1, 2, 3, ... and leaves workspace / lazy_state / pr / pm alone in between.
                                              The SaveBest snapshot of a map that the part does not optimise is not rewritten.
-                                             An iteration is then TWO launches: the partial sums of the loss statistics, and this launch, at whose head
+                                             An iteration is then two launches -- and a third in a part that moves the roughness: the pixels the backward
+                                             launch lists (their roughness left their model's interval) are re-sampled by a launch of their own,
+                                             MATPBR_STAGE_RESAMPLE -- : the partial sums of the loss statistics, and this launch, at whose head
                                              every workgroup folds them (fixed order) and forms the iteration's scalars from the SaveBest / EarlyStopping
                                              state of the iteration before, which lives in `workspace` in two alternating copies (read t-1, written t:
                                              the step with t = 1 copies `stats` in); `stats` is rewritten by one workgroup per image at every step. */
@@ -244,10 +246,12 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* 
  * phase; untouched if none improved), the render of the CURRENT parameters (the next iteration's) in `pred`, the best iteration's in
  * `pred_next`.  The phase may go on afterwards (steps t_done + 1, ...).  Without the flag, or with t_done = 0: nothing to do. */
 int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* phase, int t_done, void* stream);
-/* The same iteration stage by stage (profiling, and callers that interleave their own work): matpbr_brdf_phase_step enqueues all three. */
+/* The same iteration stage by stage (profiling, and callers that interleave their own work): matpbr_brdf_phase_step enqueues all of them. */
 #define MATPBR_STAGE_RENDER 1u   /* the render of the iteration (nothing to launch in the pred_next mode after t = 1) */
 #define MATPBR_STAGE_STATS 2u    /* loss statistics, SaveBest / EarlyStopping decisions */
 #define MATPBR_STAGE_BACKWARD 4u /* loss backward + Adam (+ the next iteration's render in the pred_next mode) */
+#define MATPBR_STAGE_RESAMPLE 8u /* pred_next mode: the pixels the backward launch listed (their roughness left their model's interval) are re-sampled,
+                                    their models rebuilt and their render written (nothing to launch in the other modes) */
 int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* phase, int t, float lr, uint32_t stages, void* stream);
 
 /* One evaluation of hot loop A (inverse_img_w_mi.py:238-250) for a candidate light.  Materials and normals are fixed during the

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
                                                             const float* __restrict__ m0, float* __restrict__ part, long n3, long n1,
                                                             const float* __restrict__ fwd_sums, int n_fwd, unsigned part_mask,
                                                             const float* __restrict__ reg_sums = nullptr, const float* __restrict__ pred_alt = nullptr,
-                                                            const float* __restrict__ state = nullptr) {
+                                                            const float* __restrict__ state = nullptr, int n_reg = 0) {
     __shared__ float s_buf[4];
     const int b = blockIdx.y;
     float ratio = 1.0f;
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
     if (MODE >= 3 && blockIdx.x == 0 && threadIdx.x == 0) rows[(long)gridDim.x * 5] = sp_total;
     if (MODE == 4 && blockIdx.x == 0) {                    // the regulariser sums the step kernel left per workgroup (n_fwd of them per image)
         float rg[3] = {0.0f, 0.0f, 0.0f};
-        for (int i = threadIdx.x; i < n_fwd; i += kBlock) {
+        for (int i = threadIdx.x; i < n_reg; i += kBlock) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) rg[k] += reg_sums[((long)b * n_fwd + i) * 3 + k];
+            for (int k = 0; k < 3; ++k) rg[k] += reg_sums[((long)b * n_reg + i) * 3 + k];
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -879,6 +879,13 @@ bool make_geom(int H, int W, const MatpbrCamera* cam, Geom& g) {
 }
 // two pixels per lane: a 256-thread workgroup covers 512 pixels
 int grid_blocks(int H, int W) { return (int)(((long)H * W + 2 * kBlock - 1) / (2 * kBlock)); }
+// per-image capacity of the forward sums at the head of the phase workspace: the stand-alone lazy render leaves grid_blocks + lazy_groups of
+// them (streaming workgroups + refresh groups), the fused step 2 grid_blocks (the step kernel's workgroups + the resampling launch's)
+int fwd_sums_cap(int H, int W) {
+    const int nb = grid_blocks(H, W), ng = lazy_groups((long)H * W);
+    const int nr = nb < kResampleWaves ? nb : kResampleWaves;
+    return nb + (ng > nr ? ng : nr);
+}
 bool valid_spp(int spp) { return spp >= 2 && spp <= MATPBR_MAX_SPP && (spp % 2) == 0; }
 int launch_status() { return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH; }
 bool sh25(int light_kind, int n_light) { return light_kind == MATPBR_LIGHT_SH25 && n_light == MATPBR_NSH; }
@@ -1241,13 +1248,13 @@ int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, 
 
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
     if (H <= 0 || W <= 0 || batch <= 0) return 0;
-    return ((size_t)batch * (grid_blocks(H, W) + lazy_groups((long)H * W)) + (size_t)batch * step_part_stride(kRedBlocks) +
+    return ((size_t)batch * fwd_sums_cap(H, W) + (size_t)batch * step_part_stride(kRedBlocks) +
             2 * (size_t)batch * kStateStride /* the step kernel's alternating SaveBest / EarlyStopping state */ +
             3 * (size_t)batch * grid_blocks(H, W) /* its per-workgroup regulariser sums */) * sizeof(float);
 }
 
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* stream) {
-    return matpbr_brdf_phase_stages(ph, t, lr, MATPBR_STAGE_RENDER | MATPBR_STAGE_STATS | MATPBR_STAGE_BACKWARD, stream);
+    return matpbr_brdf_phase_stages(ph, t, lr, MATPBR_STAGE_RENDER | MATPBR_STAGE_STATS | MATPBR_STAGE_BACKWARD | MATPBR_STAGE_RESAMPLE, stream);
 }
 
 int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_t stages, void* stream) {
@@ -1269,7 +1276,10 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     const bool lazy = q.lazy_state != nullptr && q.dcache != nullptr &&
                       lazy_fwd_blocks((long)q.H * q.W) <= kLazyMaxBlocks;
     const bool lazy_fused = lazy && q.pred_next != nullptr;   // backward of this iteration and forward of the next one in one launch
-    const int nfwd = grid_blocks(q.H, q.W) + ((lazy && !(lazy_fused && t > 1)) ? lazy_groups((long)q.H * q.W) : 0);
+    // forward sums per image: t > 1 of the fused step: its workgroups' and the resampling launch's
+    const bool resample = lazy_fused && ((q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr);   // otherwise no pixel ever leaves its model's interval
+    const int nres = grid_blocks(q.H, q.W) < kResampleWaves ? grid_blocks(q.H, q.W) : kResampleWaves;   // waves of the resampling launch per image
+    const int nfwd = grid_blocks(q.H, q.W) + ((lazy_fused && t > 1) ? (resample ? nres : 0) : (lazy ? lazy_groups((long)q.H * q.W) : 0));
     float* fwd_sums = (float*)q.workspace;
     float* part = fwd_sums + (size_t)q.batch * nfwd;
     const long n1 = (long)q.H * q.W, n3 = n1 * 3;
@@ -1298,7 +1308,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     // 2. loss statistics, SaveBest / EarlyStopping decisions (:388-418, misc.py:37-97)
     const int step_rows = kStepRows;
     // [2][B][kStatsStride], at a fixed place (`part` moves with the number of forward sums, which differs between t = 1 and later steps)
-    float* state2 = (float*)q.workspace + (size_t)q.batch * (grid_blocks(q.H, q.W) + lazy_groups(n1)) + (size_t)q.batch * step_part_stride(kRedBlocks);
+    float* state2 = (float*)q.workspace + (size_t)q.batch * fwd_sums_cap(q.H, q.W) + (size_t)q.batch * step_part_stride(kRedBlocks);
     float* reg_sums = state2 + 2 * (size_t)q.batch * kStateStride;     // [B][grid_blocks][3]
     const bool rotate = lazy_fused && (q.flags & MATPBR_FLAG_ROTATE_BEST) != 0;
     const float* state_cur = state2 + (size_t)((t - 1) & 1) * q.batch * kStateStride;   // written by the step before (t = 1: from `stats`, below)
@@ -1308,7 +1318,8 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         if (t > 1)     // the step before left the regulariser sums of the parameters it wrote: this pass reads pred and the target only
             hipLaunchKernelGGL(loss_sums2_kernel<4>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                                (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
-                               (const float*)fwd_sums, nfwd, q.part_mask, (const float*)reg_sums, (const float*)q.pred_next, rotate ? state_cur : nullptr);
+                               (const float*)fwd_sums, nfwd, q.part_mask, (const float*)reg_sums, (const float*)q.pred_next, rotate ? state_cur : nullptr,
+                               grid_blocks(q.H, q.W));
         else
             hipLaunchKernelGGL(loss_sums2_kernel<3>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                                (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
@@ -1321,7 +1332,8 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
                        1.0f / (float)n3, 1.0f / (float)n1, q.scale_delta, q.part_mask, q.es_patience, q.es_min_delta, (const float*)fwd_sums, nfwd,
                        q.history, q.hist_len, q.batch);
     }
-    if (!(stages & MATPBR_STAGE_BACKWARD)) return launch_status();
+    if (!(stages & (MATPBR_STAGE_BACKWARD | MATPBR_STAGE_RESAMPLE))) return launch_status();
+    if (!lazy_fused && !(stages & MATPBR_STAGE_BACKWARD)) return launch_status();
     // 3. backward of the loss through the render (:420) from the jac planes, regularisers, clamp gating, best-so-far snapshot,
     //    and the Adam update of the maps of this part (:359,429) in the same pass
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
@@ -1340,7 +1352,8 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         LazyStepArgs ls{};
         ls.j = jb;
         for (int k = 0; k < kLzPlanes; ++k) ls.plane[k] = lb.planes + (size_t)k * (size_t)q.batch * (size_t)n1;
-        ls.pred_next = q.pred_next; ls.block_sums = fwd_sums; ls.n = q.n; ls.dcache = q.dcache; ls.counts = lb.counts; ls.lists = lb.lists; ls.n_sums = lb.nblk;
+        ls.pred_next = q.pred_next; ls.block_sums = fwd_sums; ls.n = q.n; ls.dcache = q.dcache; ls.counts = lb.counts; ls.lists = lb.lists;
+        ls.n_sums = resample ? lb.nblk + nres : lb.nblk;     // per image: the step kernel's workgroups, then the resampling launch's waves
         ls.tol = q.lazy_tol > 0.0f ? q.lazy_tol : 1.0f;
         ls.attached = (q.flags & MATPBR_FLAG_ATTACHED_SAMPLING) ? 1 : 0;
         ls.fold_part = part; ls.fold_rows = step_rows;
@@ -1356,7 +1369,10 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         }
         ls.stats_out = q.stats; ls.history = q.history; ls.hist_len = q.hist_len; ls.batch = q.batch;
         ls.es_patience = q.es_patience; ls.es_min_delta = q.es_min_delta;
-        hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);
+        if (stages & MATPBR_STAGE_BACKWARD)
+            hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);
+        if ((stages & MATPBR_STAGE_RESAMPLE) && resample)
+            hipLaunchKernelGGL(lazy_resample_kernel, dim3((unsigned)nres, (unsigned)q.batch), dim3(64), (size_t)(lb.nblk + 1) * sizeof(int), st, ls, q.light, g, tab);
     } else if (lazy)
         hipLaunchKernelGGL((jac_bwd_kernel<true, true>), dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, jb, n1);
     else
@@ -1373,7 +1389,7 @@ int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* ph, int t_done, void* strea
     if (((q.part_mask & MATPBR_PART_A) && !q.best_a) || ((q.part_mask & MATPBR_PART_R) && !q.best_r) || ((q.part_mask & MATPBR_PART_M) && !q.best_m))
         return MATPBR_ERR_INVALID_ARG;
     const long n1 = (long)q.H * q.W;
-    float* state2 = (float*)q.workspace + (size_t)q.batch * (grid_blocks(q.H, q.W) + lazy_groups(n1)) + (size_t)q.batch * step_part_stride(kRedBlocks);
+    float* state2 = (float*)q.workspace + (size_t)q.batch * fwd_sums_cap(q.H, q.W) + (size_t)q.batch * step_part_stride(kRedBlocks);
     ResolveArgs ra{};
     ra.x0[0] = (q.part_mask & MATPBR_PART_A) ? q.pa : nullptr; ra.x1[0] = q.best_a;
     ra.x0[1] = (q.part_mask & MATPBR_PART_R) ? q.pr : nullptr; ra.x1[1] = q.best_r;

@@ -214,6 +214,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 // what the lane that owns a pixel hands to the lanes that walk its samples
 struct LazyRecord { float a[3], r, m, dr; };
+constexpr int kResampleWaves = 256;    // waves (64-thread workgroups) of lazy_resample_kernel per image at most, eight listed pixels each per pass
 constexpr int kRecStride = 7;         // floats per record: pixel, a (clamped, updated), r, m, r - r_ref (odd stride: conflict-free)
 constexpr int kWalkVals = 20;         // per-sample contributions: S0, S1, dS0, dS1 at r (12), S0, S1 at r + dir h (6), interval lo / hi
 
@@ -321,7 +322,13 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const St
     const float r1 = fminf(fmaxf(nr, 0.07f), 1.0f), m1 = fminf(fmaxf(nm, 0.0f), 1.0f), dr1 = r1 - rref, omm1 = 1.0f - m1;
     if (q.part_mask & MATPBR_PART_R) reg[1] += fabsf(r1 - r0v);
     if (q.part_mask & MATPBR_PART_M) reg[2] += fabsf(m1 - m0v);
+#if defined(MATPBR_EXP_NORESAMPLE)   // measurement only (tools/step_parts_ab.sh): the walk compiled out / never taken at run time
+    const bool need = false;
+#elif defined(MATPBR_EXP_NORESAMPLE_RT)
+    const bool need = !(dr1 >= -h2_lo(lohi) && dr1 <= h2_hi(lohi)) && qs.n_sums < 0;
+#else
     const bool need = !(dr1 >= -h2_lo(lohi) && dr1 <= h2_hi(lohi));
+#endif
     rec.r = r1; rec.m = m1; rec.dr = dr1;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -358,10 +365,6 @@ struct RadianceLdsUse {
 __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
     __shared__ float s_sum[4];
     __shared__ int s_cnt[4];
-    __shared__ float s_light[kNL + 1];
-    __shared__ float4 s_ring[kMaxRings];
-    __shared__ float2 s_saz[kMaxRings * kMaxAz];
-    __shared__ float s_rec[kLazyBlockPixels * kRecStride];
     __shared__ float s_state[kStateStride];
     __shared__ float s_fold[4][6];
     const JacBwdArgs& q = qs.j;
@@ -385,10 +388,14 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
         // fold: thread i takes row i (fold_rows <= kBlock), waves by a fixed DPP tree, the four wave totals in fixed order
         const float* rows = qs.fold_part + (long)b * step_part_stride(qs.fold_rows);
         float v[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef MATPBR_EXP_NOFOLD   // measurement only (tools/step_parts_ab.sh)
         for (int i = threadIdx.x; i < qs.fold_rows; i += kBlock) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] += rows[(long)i * 5 + k];
         }
+#else
+        v[0] = 1.0f; v[1] = 1.0f;
+#endif
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const float w = wave_sum_to_lane63(v[k]);
@@ -439,9 +446,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
         improved = q.stats[b * kStatsStride + kStImproved] > 0.5f;
         gt_sum = q.stats[b * kStatsStride + kStGtSum];
     }
-    if (threadIdx.x < kNL) s_light[threadIdx.x] = light[(long)b * kNL + threadIdx.x] * kShNorm[threadIdx.x / 3];
-    if (threadIdx.x < kMaxRings * kMaxAz) s_saz[threadIdx.x] = (&tab.saz[0][0])[threadIdx.x];
-    if (threadIdx.x < kMaxRings) s_ring[threadIdx.x] = tab.sring[threadIdx.x];
     float tot = 0.0f;
     bool need0 = false, need1 = false;
     LazyRecord rec0, rec1;
@@ -475,18 +479,104 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
     for (int w = 0; w < 4; ++w) base += w < wave ? s_cnt[w] : 0;
     const int count = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
     const int idx0 = base + __popcll(b0 & below), idx1 = base + n0 + __popcll(b1 & below);   // fixed order: wave, first / second pixel, lane
-    if (count > 0) {
-        // the owners hand their pixels over (records in list order) and are done with them
-        auto deposit = [&](bool need, int idx, int local, const LazyRecord& rc) {
-            if (need) {
-                float* o = s_rec + idx * kRecStride;
-                o[0] = __builtin_bit_cast(float, local);
-                o[1] = rc.a[0]; o[2] = rc.a[1]; o[3] = rc.a[2]; o[4] = rc.r; o[5] = rc.m; o[6] = rc.dr;
-            }
-        };
-        deposit(need0, idx0, (int)threadIdx.x, rec0);
-        deposit(need1, idx1, (int)(kBlock + threadIdx.x), rec1);
-        __syncthreads();
+    if (qs.lists) {
+        uint16_t* list = qs.lists + ((long)b * gridDim.x + blockIdx.x) * kLazyBlockPixels;
+        if (need0) list[idx0] = (uint16_t)threadIdx.x;
+        if (need1) list[idx1] = (uint16_t)(kBlock + threadIdx.x);
+        if (threadIdx.x == 0) qs.counts[(long)b * gridDim.x + blockIdx.x] = (uint32_t)count;
+    }
+    tot = wave_sum_to_lane63(tot);
+    if (lane == 63) s_sum[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) qs.block_sums[(long)b * qs.n_sums + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    if (qs.reg_sums && threadIdx.x < 3)
+        qs.reg_sums[((long)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] =
+            (s_fold[0][threadIdx.x] + s_fold[1][threadIdx.x]) + (s_fold[2][threadIdx.x] + s_fold[3][threadIdx.x]);
+}
+
+// The pixels the step kernel listed (their new roughness has left their model's interval: a few of a workgroup's 512 per iteration) are
+// re-sampled by this launch, one workgroup per workgroup of the step kernel: eight lanes per pixel, four azimuths x (r, r + dir h: the
+// one-sided difference that gives the slopes), each lane walking the rings of its azimuth, contributions folded by a fixed butterfly.
+// It rebuilds their models, writes their render and leaves the sum of it beside the step kernel's sums (slot nblk + blockIdx.x of the
+// image).  64-thread workgroups, kResampleWaves per image, eight items per wave and pass.  Inside the step kernel the same walk cost 29 of its 111 us at 8 x 512^2 (tools/step_parts_ab.sh): three
+// quarters of the workgroups list a pixel or two, and a workgroup that walks holds its registers and LDS through two more memory round
+// trips while nothing of it streams; here the walkers are a launch of their own and the step kernel is a pure streaming pass (80
+// registers, no spills).
+__global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
+    __shared__ float s_light[kNL + 1];
+    __shared__ float4 s_ring[kMaxRings];
+    __shared__ float2 s_saz[kMaxRings * kMaxAz];
+    const JacBwdArgs& q = qs.j;
+    const int b = blockIdx.y;
+    const int P = g.H * g.W;
+    // one round trip for everything that depends on nothing: the stop flag, the counts, the committed state, the tables
+    extern __shared__ int s_pref[];                                        // [nblk + 1]
+    const int nblk = qs.n_sums - (int)gridDim.x;
+    const float stopped = qs.state_old[b * kStateStride + kStStopped];
+    const float* st = qs.state_new + b * kStateStride;                     // the state the step kernel has just committed
+    const float ratio = st[kStRatio], gt_sum = st[kStGtSum], sel_f = st[kStSel];
+    const float lt0 = light[(long)b * kNL + threadIdx.x], lt1 = threadIdx.x + 64 < kNL ? light[(long)b * kNL + threadIdx.x + 64] : 0.0f;
+    static_assert(kNL <= 128 && kMaxRings <= 64 && kMaxRings * kMaxAz <= 256, "table loads below");
+    float2 saz_v[(kMaxRings * kMaxAz + 63) / 64];
+#pragma unroll
+    for (int u = 0; u < (kMaxRings * kMaxAz + 63) / 64; ++u) {
+        const int i = (int)threadIdx.x + 64 * u;
+        saz_v[u] = (&tab.saz[0][0])[i < kMaxRings * kMaxAz ? i : 0];
+    }
+    const float4 ring_v = tab.sring[threadIdx.x < kMaxRings ? threadIdx.x : 0];
+    // The image's work list is the concatenation of its workgroups' lists: every wave forms the exclusive prefix of the counts in LDS
+    // (2 KB at 512 x 512; no second launch) and takes the items 8 blockIdx.x + 8 gridDim.x k .. + 7, eight lanes each -- lists are short
+    // but bursty (a few pixels of one neighbourhood cross together): the items are spread evenly whatever their lists.
+    const int per = (nblk + 63) / 64, first = (int)threadIdx.x * per;
+    int mine = 0;
+    for (int j0 = 0; j0 < per; j0 += 8) {                                  // eight counts in flight at once (the loop of one: eight round trips)
+        int c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int blk = first + j0 + u;
+            c[u] = (j0 + u < per && blk < nblk) ? (int)qs.counts[(long)b * nblk + (blk < nblk ? blk : 0)] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int blk = first + j0 + u;
+            if (j0 + u < per && blk < nblk) s_pref[blk] = mine;
+            mine += c[u];
+        }
+    }
+    if (stopped > 0.5f) return;                                            // the step kernel skipped the image (uniform)
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if ((int)threadIdx.x >= d) incl += v;
+    }
+    const int T = __shfl(incl, 63);                                        // all the image's items (uniform)
+    if (T == 0 || (long)blockIdx.x * 8 >= T) {
+        if (threadIdx.x == 0) qs.block_sums[(long)b * qs.n_sums + nblk + blockIdx.x] = 0.0f;
+        return;
+    }
+    for (int j = 0; j < per; ++j)
+        if (first + j < nblk) s_pref[first + j] += incl - mine;
+    if (threadIdx.x == 0) s_pref[nblk] = T;
+    s_light[threadIdx.x] = lt0 * kShNorm[threadIdx.x / 3];
+    if (threadIdx.x + 64 < kNL) s_light[threadIdx.x + 64] = lt1 * kShNorm[(threadIdx.x + 64) / 3];
+#pragma unroll
+    for (int u = 0; u < (kMaxRings * kMaxAz + 63) / 64; ++u)
+        if ((int)threadIdx.x + 64 * u < kMaxRings * kMaxAz) s_saz[threadIdx.x + 64 * u] = saz_v[u];
+    if (threadIdx.x < kMaxRings) s_ring[threadIdx.x] = ring_v;
+    StepPtrs sp{q.pa, q.pr, q.pm, q.pa, q.pr, q.pm, qs.pred_next};          // the parameters as WRITTEN by the step (a map the part does not move: as read)
+    if (qs.rotate) {
+        const bool wr1 = __builtin_amdgcn_readfirstlane((int)(sel_f > 0.5f)) != 0;
+        if (qs.alt_a) sp.a = wr1 ? qs.alt_a : q.pa;
+        if (qs.alt_r) sp.r = wr1 ? qs.alt_r : q.pr;
+        if (qs.alt_m) sp.m = wr1 ? qs.alt_m : q.pm;
+        sp.pred_next = qs.pred_buf[wr1 ? 1 : 0];
+    }
+    const uint16_t* lists = qs.lists + (long)b * nblk * kLazyBlockPixels;
+    const int lane = threadIdx.x;                                          // one wave per list: eight lanes per pixel, eight pixels per pass
+    float tot = 0.0f;
+    __syncthreads();
+    {
         float floor_;
         {
             const float rt = ratio;
@@ -495,16 +585,28 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
         const float tol_k = qs.tol * kLzTolK, tol_s = qs.tol * kLzTolS;
         const int sub = lane & 7, half = sub >> 2, azi = sub & 3;
         const long BPl = (long)gridDim.y * P;
-        // a wave walks the items of its own lane groups and exchanges through its own slice of s_red: no workgroup barrier, and a
-        // wave without items is done
-        // eight lanes per pixel: 32 pixels per pass of the workgroup, a wave whose lanes have no pixel left is done
-        for (int ib = wave * 8; ib < count; ib += 32) {
+        // eight lanes per pixel, eight pixels per wave and pass (one sample per lane -- 40 lanes per pixel, one pixel per wave -- was
+        // slower: every wave pays the prefix over the image's counts)
+        for (int ib = blockIdx.x * 8; ib < T; ib += gridDim.x * 8) {
             const int item = ib + (lane >> 3);
-            const bool item_ok = item < count;
-            const float* rc = s_rec + (item_ok ? item : ib) * kRecStride;
-            const int p = blockIdx.x * kLazyBlockPixels + __builtin_bit_cast(int, rc[0]);
+            const bool item_ok = item < T;
+            // the pixel's record, as the step kernel formed it: the clamped parameters it has just written, the distance to the old model
+            const int it = item_ok ? item : ib;
+            int lo_b = 0, hi_b = nblk;                           // the list the item is in: the largest blk with s_pref[blk] <= it
+            while (hi_b - lo_b > 1) {
+                const int mid = (lo_b + hi_b) >> 1;
+                if (s_pref[mid] <= it) lo_b = mid; else hi_b = mid;
+            }
+            const int p = lo_b * kLazyBlockPixels + (int)lists[(long)lo_b * kLazyBlockPixels + (it - s_pref[lo_b])];
             const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
+            float rc[7];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rc[1 + c] = fminf(fmaxf(ldf(sp.a, o3 + 4 * c), 0.0f), 1.0f);
+            rc[4] = fminf(fmaxf(ldf(sp.r, o1), 0.07f), 1.0f);
+            rc[5] = fminf(fmaxf(ldf(sp.m, o1), 0.0f), 1.0f);
+            rc[6] = rc[4] - as_f(ldu(qs.plane[kLzRref], o1));
             const float rc_r = rc[4], mv = rc[5], dr = rc[6];
+            const float rho_old = as_f(ldu(qs.plane[kLzRho], o1));
             // geometry of the pixel (the same at r and at r + dir h: plain floats), as load_pixel forms it
             float nn[3], ss[3], tt[3], vx, vy, vz, NoV;
             {
@@ -552,7 +654,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
                     const float gq = r3x4 * rg.x * rq * cos2;      // d sin^2 theta_h / dr  (mi_specular_sampler :232-233)
                     const float stp = 0.5f * gq * rcp(st), ctp = -0.5f * gq * rcp(ct);
                     for (int j = azi; j < tab.nphi_s; j += 4) {
-                        asm volatile("" ::: "memory");   // keeps the 75 coefficient reads below inside the loop (hoisted, they pin 75 VGPRs)
                         const float2 az = s_saz[ring * kMaxAz + j];
                         const float whx = st * az.x, why = st * az.y;
                         const float d = fmaf(ct, vz, fmaf(why, vy, whx * vx)), d2 = d + d;
@@ -612,7 +713,7 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
                     dSD[c] = fv[6 + c] - fv[9 + c];
                     dS1v[c] = fv[9 + c];
                 }
-                float rho = as_f(ldu(qs.plane[kLzRho], o1));
+                float rho = rho_old;
                 if (fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
                     float e = 0.0f;
 #pragma unroll
@@ -639,19 +740,8 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
             }
         }
     }
-    if (qs.lists) {
-        uint16_t* list = qs.lists + ((long)b * gridDim.x + blockIdx.x) * kLazyBlockPixels;
-        if (need0) list[idx0] = (uint16_t)threadIdx.x;
-        if (need1) list[idx1] = (uint16_t)(kBlock + threadIdx.x);
-        if (threadIdx.x == 0) qs.counts[(long)b * gridDim.x + blockIdx.x] = (uint32_t)count;
-    }
     tot = wave_sum_to_lane63(tot);
-    if (lane == 63) s_sum[wave] = tot;
-    __syncthreads();
-    if (threadIdx.x == 0) qs.block_sums[(long)b * qs.n_sums + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
-    if (qs.reg_sums && threadIdx.x < 3)
-        qs.reg_sums[((long)b * qs.n_sums + blockIdx.x) * 3 + threadIdx.x] =
-            (s_fold[0][threadIdx.x] + s_fold[1][threadIdx.x]) + (s_fold[2][threadIdx.x] + s_fold[3][threadIdx.x]);
+    if (lane == 63) qs.block_sums[(long)b * qs.n_sums + nblk + blockIdx.x] = tot;
 }
 
 // =================================================================================================

@@ -406,7 +406,8 @@ class FusedBrdfPhase:
             self._ph.pred_next = ct.c_void_p(self._pred_bufs[self._pred_cur ^ 1].data_ptr())
 
     def launch_stage(self, stages: int) -> None:
-        """Enqueue some stages of the NEXT iteration without advancing the phase (1 render, 2 statistics, 4 backward + Adam; kernel timing)."""
+        """Enqueue some stages of the NEXT iteration without advancing the phase (1 render, 2 statistics, 4 backward + Adam, 8 the lazy
+        mode's resampling launch; kernel timing)."""
         ct = self._ct
         with torch.cuda.device(self.gt.device):
             code = self._lib.matpbr_brdf_phase_stages(ct.byref(self._ph), self.t + 1, self.lr_at(self.t), int(stages),
@@ -421,6 +422,7 @@ class FusedBrdfPhase:
         e0.record()
         self.launch_stage(4)
         e1.record()
+        self.launch_stage(8)             # the resampling launch of the lazy mode (nothing otherwise)
         events.append((e0, e1))
         self._advance()
 
