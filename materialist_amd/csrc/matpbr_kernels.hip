@@ -178,6 +178,10 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
     float* rows = part + (long)b * (MODE >= 3 ? step_part_stride((int)gridDim.x) : (long)gridDim.x * 5);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
+        if (MODE == 4 && k >= 2) {                             // the regulariser columns are not formed here: zeros, no reduction
+            if (threadIdx.x == 0) rows[(long)blockIdx.x * 5 + k] = 0.0f;
+            continue;
+        }
         float v = block_sum(s[k], s_buf);
         if (threadIdx.x == 0) rows[(long)blockIdx.x * 5 + k] = v;
     }
