@@ -1384,6 +1384,9 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     return launch_status();
 }
 
+#ifdef MATPBR_RS_STAMPS
+int matpbr_debug_rs_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_stamps), sizeof(g_rs_stamps)) == hipSuccess ? 0 : 1; }
+#endif
 int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* ph, int t_done, void* stream) {
     if (!ph || t_done < 0) return MATPBR_ERR_INVALID_ARG;
     const MatpbrBrdfPhase& q = *ph;

@@ -502,6 +502,12 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
 // quarters of the workgroups list a pixel or two, and a workgroup that walks holds its registers and LDS through two more memory round
 // trips while nothing of it streams; here the walkers are a launch of their own and the step kernel is a pure streaming pass (80
 // registers, no spills).
+#ifdef MATPBR_RS_STAMPS   // cycle stamps of one wave of the resampling launch (tools/rs_stamps.sh); never in the product build
+__device__ unsigned long long g_rs_stamps[8];
+#define RS_STAMP(k) do { if (blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); g_rs_stamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define RS_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
     __shared__ float s_light[kNL + 1];
     __shared__ float4 s_ring[kMaxRings];
@@ -509,6 +515,7 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
     const JacBwdArgs& q = qs.j;
     const int b = blockIdx.y;
     const int P = g.H * g.W;
+    RS_STAMP(0);
     // one round trip for everything that depends on nothing: the stop flag, the counts, the committed state, the tables
     extern __shared__ int s_pref[];                                        // [nblk + 1]
     const int nblk = qs.n_sums - (int)gridDim.x;
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int blk = first + j0 + u;
-            if (j0 + u < per && blk < nblk) s_pref[blk] = mine;
+            if (j0 + u < per && blk < nblk) s_pref[blk] = c[u];       // the raw counts: a lane's run is scanned linearly by whoever lands in it
             mine += c[u];
         }
     }
@@ -551,13 +558,11 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
         if ((int)threadIdx.x >= d) incl += v;
     }
     const int T = __shfl(incl, 63);                                        // all the image's items (uniform)
+    RS_STAMP(1);
     if (T == 0 || (long)blockIdx.x * 8 >= T) {
         if (threadIdx.x == 0) qs.block_sums[(long)b * qs.n_sums + nblk + blockIdx.x] = 0.0f;
         return;
     }
-    for (int j = 0; j < per; ++j)
-        if (first + j < nblk) s_pref[first + j] += incl - mine;
-    if (threadIdx.x == 0) s_pref[nblk] = T;
     s_light[threadIdx.x] = lt0 * kShNorm[threadIdx.x / 3];
     if (threadIdx.x + 64 < kNL) s_light[threadIdx.x + 64] = lt1 * kShNorm[(threadIdx.x + 64) / 3];
 #pragma unroll
@@ -592,12 +597,25 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
             const bool item_ok = item < T;
             // the pixel's record, as the step kernel formed it: the clamped parameters it has just written, the distance to the old model
             const int it = item_ok ? item : ib;
-            int lo_b = 0, hi_b = nblk;                           // the list the item is in: the largest blk with s_pref[blk] <= it
-            while (hi_b - lo_b > 1) {
-                const int mid = (lo_b + hi_b) >> 1;
-                if (s_pref[mid] <= it) lo_b = mid; else hi_b = mid;
+            // the list the item is in: the lane whose run of counts contains it (one ballot per pixel slot on the inclusive scan the lanes
+            // hold), then a linear scan of that run's raw counts in LDS
+            int run = 0, rel = 0;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const int it_s = __shfl(it, 8 * sl);                            // uniform
+                const unsigned long long above = __ballot(incl > it_s);         // lanes whose runs end beyond the item
+                const int rn = above ? (int)__builtin_ctzll(above) : 63;
+                const int ex = __shfl(incl - mine, rn);                         // items before that run
+                if ((lane >> 3) == sl) { run = rn; rel = it_s - ex; }
             }
-            const int p = lo_b * kLazyBlockPixels + (int)lists[(long)lo_b * kLazyBlockPixels + (it - s_pref[lo_b])];
+            int lo_b = run * per;
+            for (int j = 0; j + 1 < per; ++j) {
+                const int cj = s_pref[lo_b < nblk ? lo_b : nblk - 1];
+                if (rel < cj) break;
+                rel -= cj; ++lo_b;
+            }
+            const int p = lo_b * kLazyBlockPixels + (int)lists[(long)lo_b * kLazyBlockPixels + rel];
+            RS_STAMP(2);
             const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
             float rc[7];
 #pragma unroll
@@ -637,6 +655,7 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
                 C0[c] = fmaf(mv, rc[1 + c], (1.0f - mv) * 0.04f);
                 iscale[c] = 1.0f / fmaxf(fabsf(fmaf(kd[c], Pc[c], fmaf(C0[c], pSD[c], pS1[c]))), floor_);
             }
+            RS_STAMP(3);
             // ---- this lane's samples: one azimuth of every ring, at r (sub 0-3) or at r + dir h (sub 4-7)  (spec_ring / spec_sample /
             // spec_accumulate of matpbr_shade.hpp, one value per lane)
             float S0[3] = {0, 0, 0}, S1[3] = {0, 0, 0}, dS0[3] = {0, 0, 0}, dS1[3] = {0, 0, 0}, klo = 1e30f, khi = 1e30f;
@@ -687,6 +706,7 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
                     }
                 }
             }
+            RS_STAMP(4);
             // fold over the four azimuth lanes with a fixed butterfly (the same tree for every pixel: reproducible)
             float fv[kWalkVals];
 #pragma unroll
@@ -740,6 +760,7 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
             }
         }
     }
+    RS_STAMP(5);
     tot = wave_sum_to_lane63(tot);
     if (lane == 63) qs.block_sums[(long)b * qs.n_sums + nblk + blockIdx.x] = tot;
 }
