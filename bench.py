@@ -418,10 +418,11 @@ def main(argv=None):
             for _ in range(200):
                 ph.step_timed(ev)             # the real loop, HIP events around the launch in question (on the launch stream)
             torch.cuda.synchronize()
-            t_step = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            t_step = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
+            t_res = sum(e[1].elapsed_time(e[2]) for e in ev) / len(ev)
             _, ref = ops.lazy_state_unpack(ph.lazy_state, ph.p["albedo"])
             t_stats = back_to_back(lambda: ph.launch_stage(2))
-            return t_step, t_stats, float(ref.float().mean())
+            return t_step, t_stats, float(ref.float().mean()), t_res
 
         wr = wl8 if wl8 is not None else wl
         tk = kernel_times(wr)
@@ -434,16 +435,17 @@ def main(argv=None):
             except Exception:
                 pmc = {}
         key = f"{H}x{W}_b{wr.B}_spp{args.spp}"
-        t_step, t_stats, resampled = lazy_step_times(wr)
+        t_step, t_stats, resampled, t_res = lazy_step_times(wr)
         ach = (BYTES_FWD + BYTES_BWD_ARM) * px / (t_step * 1e-3) / 1e9
         traffic = pmc.get(f"lazy_step_{key}")
         roof = {"bound": "hbm", "kernel": "lazy_step_kernel: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, SaveBest "
-                                          "snapshot, Adam) + render of iteration t+1 from per-pixel local models in the roughness, pixels that left their "
-                                          "model's interval re-sampled (20 GGX samples) in the same launch",
+                                          "by buffer rotation, Adam) + render of iteration t+1 from per-pixel local models in the roughness; the pixels "
+                                          "that left their model's interval are listed and re-sampled (20 GGX samples) by the small launch behind it "
+                                          "(resample_launch_ms)",
                 "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / (HBM_PEAK / 1e9), "avg_launch_ms": t_step,
                 "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM,
                 "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
-                "resampled_fraction": resampled, "stats_launches_ms": t_stats,
+                "resampled_fraction": resampled, "stats_launches_ms": t_stats, "resample_launch_ms": t_res,
                 "traffic": traffic, "traffic_source": pmc.get("source_r03") if traffic else None,
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "
@@ -467,9 +469,9 @@ def main(argv=None):
                                                     "part's first render (bit-identical to walking the samples) + jac_bwd_kernel<fused>; both streaming"),
                      "diffuse_cache_ms": tk["diffuse_cache"]})
         if wr is not wl:
-            t1, ts1, rs1 = lazy_step_times(wl)
+            t1, ts1, rs1, tr1 = lazy_step_times(wl)
             a1 = (BYTES_FWD + BYTES_BWD_ARM) * H * W * wl.B / (t1 * 1e-3) / 1e9
-            roof["single_image"] = {"achieved": a1, "frac": a1 / (HBM_PEAK / 1e9), "avg_launch_ms": t1, "stats_launches_ms": ts1, "resampled_fraction": rs1,
+            roof["single_image"] = {"achieved": a1, "frac": a1 / (HBM_PEAK / 1e9), "avg_launch_ms": t1, "stats_launches_ms": ts1, "resample_launch_ms": tr1, "resampled_fraction": rs1,
                                     "note": f"lazy_step_kernel on {wl.B} x {H}x{W} (working set inside the 256 MB Infinity Cache: launch-latency territory)"}
         # hot loop A: one pass over the radiance transfer per iteration (HBM-bound by construction)
         ph_e = wl.phase("env") if B == 1 else None

@@ -415,15 +415,17 @@ class FusedBrdfPhase:
         self._libmod.check(code, "matpbr_brdf_phase_stages")
 
     def step_timed(self, events: list) -> None:
-        """`step()` with a pair of HIP events around its last launch (the backward pass + Adam, in the lazy mode also the next render),
-        appended to `events`: the in-loop duration of that launch for bench.py's roofline."""
+        """`step()` with HIP events around its backward launch (the backward pass + Adam, in the lazy mode also the next render) and behind
+        the resampling launch that follows it, appended to `events` as (before, between, after): the in-loop durations for bench.py's roofline."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.launch_stage(1 | 2)
         e0.record()
         self.launch_stage(4)
         e1.record()
         self.launch_stage(8)             # the resampling launch of the lazy mode (nothing otherwise)
-        events.append((e0, e1))
+        e2 = torch.cuda.Event(enable_timing=True)
+        e2.record()
+        events.append((e0, e1, e2))
         self._advance()
 
     def run(self, n: int) -> None:
