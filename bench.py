@@ -286,6 +286,14 @@ def main(argv=None):
                 pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = self.gt
                 enet = posmlp.envmap_net().to(dev)
                 return EnvMlpPhase(s_env, self.gt_image, enet, torch.ones(512, 3, device=dev), spp=args.spp, lr=1e-3, use_graph=True)
+            if mode == "env_texels":
+                from materialist_amd.envhead import EnvTexelPhase
+
+                s_env = render.load_estimated_mesh(self.depth, use_mesh_normal=True)
+                pr = render.traverse(s_env)
+                pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = self.gt
+                raw = torch.zeros(16, 32, 3, device=dev, requires_grad=True)
+                return EnvTexelPhase(s_env, self.gt_image, raw, spp=args.spp, lr=1e-3, use_graph=True)
             return loop.BrdfPhase(self.scene, self.gt_image, *self.init, None, optimize_part="rm", spp=args.spp)
 
     wl = Workload(args.images_per_gpu)
@@ -319,7 +327,7 @@ def main(argv=None):
     modes = {mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3, "images_per_gpu": B}}
     wl8 = None
     if not args.no_extras and mode != "torch":
-        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("pos_mlp", 100), ("env", 500)):
+        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("pos_mlp", 100), ("env", 500), ("env_texels", 1000)):
             if extra == mode or (not extra.startswith("fused") and B > 1):
                 continue
             e_el, _ = proto.timed(stepper(wl.phase(extra)), 10, steps)
@@ -354,6 +362,8 @@ def main(argv=None):
                   "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
                   "pos_mlp_exact_f32": "the pos_mlp loop with --mlp-products 0: 256-wide layers on the exact-f32 MFMA kernels, autograd composition "
                                        "(loop.PosMlpBrdfPhase); the default differs from it only in how the f32 products are formed (same error vs fp64)",
+                  "env_texels": "hot loop A of --model_name none (envhead.EnvTexelPhase): the 16 x 32 texels through a softplus + SH projection + one pass over "
+                                "the radiance transfer + the projection's backward + Adam, seven kernels from a hipGraph",
                   "env": "hot loop A: envmap PosMLP (small-tile MFMA layers) + softplus / SH projection + one pass over the radiance transfer + "
                          "backward + Adam, 27 launches of libmatpbr.so replayed from a hipGraph",
                   "torch": "hot loop B composed from torch ops"}

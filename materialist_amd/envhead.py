@@ -205,3 +205,80 @@ class EnvMlpPhase:
 
     def history(self) -> torch.Tensor:
         return self.hist[: self.t]
+
+
+class EnvTexelPhase:
+    """Hot loop A with the `--model_name none` parameterisation of the light -- the 16 x 32 texels themselves through a softplus
+    (optimize.py: `env_raw`; inverse_img_w_mi.py:225-254 with the MLP replaced by its output activation) -- launch by launch on the C
+    ABI: softplus + SH projection, the pass over the radiance transfer (render, loss, SaveBest / EarlyStopping, d loss / d light), the
+    snapshot of the best envmap, the projection's backward and one Adam launch whose step count and learning rate live in device
+    memory: seven kernels per iteration, captured into a hipGraph.  (`loop.FusedEnvPhase` runs the same iteration with the head, its
+    backward and the optimiser as framework ops: a dozen small launches more.)  `raw` ([He, We, 3], a leaf tensor) is updated in place
+    when the phase ends (`sync_params()`), as an optimiser over it would have left it."""
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, raw: torch.Tensor, spp: int = 64, lr: float = 1e-3, patience: int = 0,
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000, use_graph: bool = True):
+        if gt_image.ndim != 3 or raw.ndim != 3 or raw.shape[-1] != 3:
+            raise NotImplementedError("EnvTexelPhase: one image, one [He, We, 3] envmap")
+        self.scene, self.spp, self.raw = scene, int(spp), raw
+        self.gt = gt_image.contiguous()
+        dev = self.dev = self.gt.device
+        self.H, self.W = self.gt.shape[0], self.gt.shape[1]
+        self.env_size = tuple(raw.shape[:2])
+        M = self.M = self.env_size[0] * self.env_size[1]
+        if M > 1024:
+            raise ValueError("at most 1024 texels")
+        self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
+        self.lib = _lib.load()
+        self.use_graph, self._graph, self._warm, self.t = bool(use_graph), None, 0, 0
+        self.patience, self.min_delta = int(patience), float(min_delta)
+        E = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.y = E(M, 4)                                          # the parameters, rows padded to 16 bytes (the padding column stays zero)
+        self.y[:, :3] = raw.detach().reshape(M, 3).to(dev, torch.float32)
+        self.g = E(M, 4)
+        self.adam_m, self.adam_v = E(M, 4), E(M, 4)               # a fresh Adam per phase (:225-229)
+        self.hyper = torch.tensor([float(lr), 0.0], dtype=torch.float32, device=dev)
+        self.env, self.best_env_flat = E(M, 3), E(M, 3)
+        self.light, self.d_light = E(25, 3), E(25, 3)
+        self.proj = scene.projection(*self.env_size).contiguous()
+        self.stats = ops.new_loss_stats(1, dev)
+        if best_mse is not None:
+            self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
+        self.hist = E(history_len, 1)
+        self.ws_env = E(int(self.lib.matpbr_env_phase_workspace_bytes(self.H, self.W, 1)) // 4 + 1)
+        shp = (self.H, self.W)
+        self.T = ops.shade_transfer(scene.a.contiguous(), scene.r.reshape(shp + (1,)).contiguous(), scene.m.reshape(shp + (1,)).contiguous(),
+                                    scene.shading_normal().contiguous(), self.spp, scene.fov)
+        if scene.bg_mask is not None:    # pixels without geometry see the environment along their camera ray: their transfer is the SH basis there
+            ops.background_into_transfer(self.T, self.H, self.W, scene.bg_basis)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        lib = self.lib
+        self._calls = [
+            (lib.matpbr_env_project, (P(self.y), 4, P(self.proj), P(self.env), P(self.light), M)),
+            (lib.matpbr_env_phase_step, (P(self.T), P(self.light), P(self.gt_srgb), None, P(self.d_light), P(self.stats), P(self.hist), history_len,
+                                         self.patience, self.min_delta, P(self.ws_env), self.ws_env.numel() * 4, self.H, self.W, 1)),
+            (lib.matpbr_select_improved, (P(self.best_env_flat), P(self.env), P(self.stats), 0, M * 3)),
+            (lib.matpbr_env_project_bwd, (P(self.y), 4, P(self.proj), P(self.d_light), P(self.g), 4, M)),
+            # the update and the step count stop with the image (stats[13] >= 2): the reference breaks right after the stopping iteration (:250-254)
+            (lib.matpbr_adamw_step_snapshot_dev, (P(self.y), P(self.g), P(self.adam_m), P(self.adam_v), self.y.numel(), P(self.hyper), 0.9, 0.999, 1e-8,
+                                                  0.0, None, P(self.stats))),
+        ]
+        self._select_at, self._first = 2, True
+
+    set_lr = EnvMlpPhase.set_lr
+    _body = EnvMlpPhase._body
+    step = EnvMlpPhase.step
+    poll = EnvMlpPhase.poll
+    history = EnvMlpPhase.history
+    best_env = EnvMlpPhase.best_env
+    best_img = EnvMlpPhase.best_img
+    pred = EnvMlpPhase.pred
+
+    def head(self) -> torch.Tensor:
+        """The envmap of the last executed iteration, [He, We, 3]."""
+        return self.env.view(self.env_size + (3,))
+
+    def sync_params(self) -> None:
+        """Write the parameters back into the caller's tensor (call when the phase is over)."""
+        with torch.no_grad():
+            self.raw.copy_(self.y[:, :3].reshape(self.raw.shape))

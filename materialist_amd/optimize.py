@@ -134,6 +134,13 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             ph = EnvMlpPhase(scene, gt, env_net, start_envmap, spp=spp, lr=lr_of(0), patience=patience, min_delta=min_delta,
                              best_mse=saver.best_loss, history_len=max_epochs, use_graph=graph, env_size=env_size)
             set_lr, head_now = ph.set_lr, (lambda: ph.head())
+        elif gt.ndim == 3 and gt.is_cuda and tuple(env_size)[0] * tuple(env_size)[1] <= 1024:
+            # the texels themselves through a softplus: head, its backward and Adam on the C ABI too (seven kernels per iteration)
+            from .envhead import EnvTexelPhase
+
+            ph = EnvTexelPhase(scene, gt, env_raw, spp=spp, lr=lr_of(0), patience=patience, min_delta=min_delta, best_mse=saver.best_loss,
+                               history_len=max_epochs, use_graph=graph)
+            set_lr, head_now = ph.set_lr, (lambda: ph.head())
         else:
             opt = _loop.capturable_adam(env_params, lr_of(0)) if graph else torch.optim.Adam(env_params, lr=lr_of(0))   # fresh Adam per loop (:225-229)
             ph = _loop.FusedEnvPhase(scene, gt, env_head, opt, spp=spp, patience=patience,
@@ -155,6 +162,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 stop = "early_stop"
                 break
         info = ph.poll()
+        if hasattr(ph, "sync_params"):
+            ph.sync_params()                                                         # env_raw as an optimiser over it would have left it
         iters = int(info["iters"].max())
         prev = saver.best_loss if saver.best_loss is not None else torch.full_like(info["best_mse"].to(dev), float("inf"))
         imp = info["best_mse"].to(dev) < prev

@@ -610,6 +610,49 @@ def test_optimize_envmap_ARMN_smoke():
     assert out["albedo"].shape == (H, W, 3) and out["envmap"].shape == (16, 32, 3)
 
 
+def test_env_texel_phase_matches_the_framework_composition():
+    """Hot loop A of `--model_name none` (texels through a softplus) entirely on the C ABI, `envhead.EnvTexelPhase`, against
+    `loop.FusedEnvPhase` whose head, head backward and Adam are framework ops: parameters, history, statistics and the best envmap over
+    iterations that cross a learning-rate change and the hipGraph capture; the caller's tensor is updated by sync_params()."""
+    from materialist_amd import loop, ops, render, synthetic
+    from materialist_amd.envhead import EnvTexelPhase
+
+    dev = _cuda()
+    H = W = 64
+    spp = 16
+    sc = synthetic.make_scene(8, H, W)
+
+    def make_scene():
+        s = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+        p = render.traverse(s)
+        p["shape.bsdf.a"], p["shape.bsdf.r"], p["shape.bsdf.m"] = _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev)
+        return s
+
+    with torch.no_grad():
+        gt = render.render_envmap(make_scene(), _t(sc.light, dev), spp).clone()
+    torch.manual_seed(2)
+    raw0 = torch.randn(16, 32, 3, device=dev) * 0.3
+    raw_a = raw0.clone().requires_grad_(True)
+    opt_a = torch.optim.Adam([raw_a], lr=1e-2)
+    ref = loop.FusedEnvPhase(make_scene(), gt, lambda: torch.nn.functional.softplus(raw_a), opt_a, spp=spp, patience=50, min_delta=1e-3)
+    raw_b = raw0.clone().requires_grad_(True)
+    tex = EnvTexelPhase(make_scene(), gt, raw_b, spp=spp, lr=1e-2, patience=50, min_delta=1e-3, use_graph=True)
+    for it in range(12):
+        if it == 7:
+            loop.set_lr(opt_a, 4e-3)
+            tex.set_lr(4e-3)
+        ref.step()
+        tex.step()
+    assert tex._graph is not None
+    tex.sync_params()
+    # Adam turns a rounding-level difference of a near-zero gradient (texels the image barely sees) into a step of the order of lr
+    assert (raw_a.detach() - raw_b.detach()).abs().max().item() < 1e-4 and (raw_a.detach() - raw_b.detach()).abs().mean().item() < 1e-6
+    assert torch.allclose(tex.history(), ref.history(), rtol=2e-5)
+    assert torch.allclose(tex.stats[:, : ops.STAT_BEST + 1], ref.stats[:, : ops.STAT_BEST + 1], rtol=2e-5, atol=1e-8)
+    assert (tex.best_env - ref.best_env).abs().max().item() < 1e-4 and (tex.best_env - ref.best_env).abs().mean().item() < 1e-6   # softplus of the parameters above
+    assert tex.poll()["iters"].tolist() == [12]
+
+
 def test_fused_env_phase_matches_torch_composition():
     """FusedEnvPhase (one matpbr_env_phase_step per iteration) against EnvPhase (autograd render + torch loss): texel light
     through softplus + SH projection, Adam in torch on both sides."""
