@@ -1816,6 +1816,15 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
           v.x *= c4.x; v.y *= c4.y; v.z *= c4.z; v.w *= c4.w;
           csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
         }
+        if (EPI == EPI_SINCOS && !HEAD && ni == 3 && p.tail != nullptr && wn == 1) {
+            // a skip layer's buffer: the columns at and beyond N hold x0 (mymodels/mlps.py:214-217), written here instead of by a copy launch
+            const int col = 224 + t_col;
+            const float* tl = p.tail + (size_t)(row0 + wm * 64 + mi * 32 + t_row + 8 * ps) * p.ldt - p.N;
+            if (col >= p.N) v.x = tl[col];
+            if (col + 1 >= p.N) v.y = tl[col + 1];
+            if (col + 2 >= p.N) v.z = tl[col + 2];
+            if (col + 3 >= p.N) v.w = tl[col + 3];
+        }
         if (W0) *reinterpret_cast<float4*>(scr + (t_row + 8 * ps) * kLd + t_col) = v;   // G' back into the block, for the product below
         else *reinterpret_cast<float4*>(p.out0 + o0 + (size_t)(8 * ps) * p.ldo) = v;
         vrow[ps] = v;
@@ -2742,7 +2751,7 @@ int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, co
   NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, N, K, ldx, 0, ldo};
   p.tail = tail; p.ldt = ldt;
   if (launch_nt_bx<EPI_SINCOS>(p, (const uint4*)wsplit, nprod, (hipStream_t)stream) < 0) return MATPBR_ERR_LAUNCH;
-  if (tail && N < 256)
+  if (tail && N < 256 && !(gx_ok(p) && N > 224))     // mlp_nt_gx writes the tail in its epilogue (it sits in the last 32-column block)
     hipLaunchKernelGGL(mlp_tail_copy_kernel, dim3((unsigned)((M * (256 - N) + 255) / 256 < 2048 ? (M * (256 - N) + 255) / 256 : 2048)), dim3(256), 0,
                        (hipStream_t)stream, s_out, ldo, tail, ldt, M, N);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
