@@ -62,6 +62,8 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
                                         iteration updates in place); nothing is copied in the loop (20 of 217 B/pixel of an improving 'rm' iteration,
                                         32 of 150 in an 'a' part).  The caller does NOT swap pred / pred_next between steps and must call
                                         matpbr_brdf_phase_resolve before it reads pa / pr / pm / best_* / best_img / pred or starts the next part */
+#define MATPBR_FLAG_GENERIC_STEP 256u /* MatpbrBrdfPhase.flags: keep the pred_next step on the generic models even where the part has a folded form
+                                        (`lazy_fold`): A/B measurements and tests of one form against the other */
 #define MATPBR_FLAG_JAC16 32u      /* matpbr_brdf_loss_bwd_jac: `jac` holds the half-precision planes written by matpbr_shade_fwd_lazy */
 #define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
 #define MATPBR_PART_R 4u
@@ -136,6 +138,10 @@ int matpbr_shade_fwd_cached(const float* a, const float* m, const float* jac, co
  *                             dSD, dS1) and / or refreshed[B*H*W] = 1 for the pixels whose samples the last call walked
  *   matpbr_jac16_unpack       jac16 -> the nine fp32 planes of matpbr_shade_fwd_ex's `jac` */
 size_t matpbr_lazy_state_bytes(int H, int W, int batch);
+/* Storage of a part's FOLDED models (MatpbrBrdfPhase.lazy_fold; opaque, caller-owned, 64 B/pixel): inside one part of --opt_order
+ * (inverse_img_w_mi.py:343-357) the maps the part does not move are constants and fold into the per-pixel models -- the albedo in parts of
+ * r / m, roughness and metallic in part 'a' -- so the step reads 64 (24) instead of 80 + 12 bytes of model and map per pixel. */
+size_t matpbr_lazy_fold_bytes(int H, int W, int batch);
 int matpbr_lazy_sums_count(int H, int W);
 int matpbr_shade_fwd_lazy(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind, int n_light,
                           const float* dcache, void* lazy_state, float* out_rgb, void* jac16, const float* stats, float* sums, int H, int W,
@@ -238,6 +244,13 @@ typedef struct MatpbrBrdfPhase {
     uint32_t flags;                       /* MATPBR_FLAG_MODELS_READY; MATPBR_FLAG_ATTACHED_SAMPLING (pred_next mode only): d loss / d r through the GGX quadrature nodes -- the models'
                                              slopes are that derivative -- i.e. the live reference's gradient convention (myutils/mi_plugin.py:227-230,
                                              1335-1341) instead of the stop-gradient default */
+    void* lazy_fold;                      /* nullable, matpbr_lazy_fold_bytes(), pred_next mode only: room for the part's folded models.  With it a part
+                                             of r / m (d_a not requested) or part 'a' (d_r, d_m not requested) runs its iteration as TWO launches: the
+                                             statistics pass and one persistent streaming launch (at most 1024 workgroups, each streaming up to four
+                                             512-pixel blocks from two register sets and walking the samples of the pixels it listed at its end: no
+                                             MATPBR_STAGE_RESAMPLE launch); 144 ('rm') / 132 ('a') instead of 172 / 160 B/pixel.  The step with t == 1
+                                             derives the folded planes from the generic ones; the generic ones stay current (re-sampled pixels rewrite
+                                             both).  Other parts, and MATPBR_FLAG_GENERIC_STEP, run the generic step. */
 } MatpbrBrdfPhase;
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);

@@ -24,7 +24,7 @@ class MatpbrBrdfPhase(ctypes.Structure):
                 [("workspace_bytes", ctypes.c_size_t), ("H", ctypes.c_int), ("W", ctypes.c_int), ("batch", ctypes.c_int), ("spp", ctypes.c_int),
                  ("fov_x_deg", ctypes.c_float), ("scale_delta", ctypes.c_float), ("part_mask", ctypes.c_uint32), ("es_patience", ctypes.c_int),
                  ("es_min_delta", ctypes.c_float), ("hist_len", ctypes.c_int), ("s1cache", ctypes.c_void_p), ("lazy_state", ctypes.c_void_p),
-                 ("lazy_tol", ctypes.c_float), ("pred_next", ctypes.c_void_p), ("flags", ctypes.c_uint32)])
+                 ("lazy_tol", ctypes.c_float), ("pred_next", ctypes.c_void_p), ("flags", ctypes.c_uint32), ("lazy_fold", ctypes.c_void_p)])
 
 
 class MatpbrError(RuntimeError):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "matpbr_diffuse_cache": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(MatpbrCamera), ctypes.c_void_p]),
     "matpbr_lazy_state_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "matpbr_lazy_fold_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "matpbr_lazy_sums_count": (ctypes.c_int, [ctypes.c_int] * 2),
     "matpbr_shade_fwd_lazy": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(MatpbrCamera), ctypes.c_uint32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),

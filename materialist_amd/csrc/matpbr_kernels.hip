@@ -21,6 +21,7 @@
 #include "matpbr_device.hpp"
 #include "matpbr_shade.hpp"
 #include "matpbr_lazy.hpp"
+#include "matpbr_pstep.hpp"
 
 using namespace matpbr;
 
@@ -1111,6 +1112,10 @@ size_t matpbr_lazy_state_bytes(int H, int W, int batch) {
     const long P = (long)H * W;
     return lazy_planes_bytes(P, batch) + lazy_counts_bytes(P, batch) + lazy_lists_bytes(P, batch);
 }
+size_t matpbr_lazy_fold_bytes(int H, int W, int batch) {
+    if (H <= 0 || W <= 0 || batch <= 0) return 0;
+    return lazy_fold_bytes((long)H * W, batch);
+}
 int matpbr_lazy_sums_count(int H, int W) {
     if (H <= 0 || W <= 0) return 0;
     return lazy_fwd_blocks((long)H * W) + lazy_groups((long)H * W);
@@ -1280,10 +1285,17 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     const bool lazy = q.lazy_state != nullptr && q.dcache != nullptr &&
                       lazy_fwd_blocks((long)q.H * q.W) <= kLazyMaxBlocks;
     const bool lazy_fused = lazy && q.pred_next != nullptr;   // backward of this iteration and forward of the next one in one launch
+    // the folded, persistent form of that launch (matpbr_pstep.hpp) where the part has one: parts of r / m with the albedo folded into the
+    // models, part 'a' with roughness and metallic folded in; a caller that wants a gradient the folded form does not have stays generic
+    int fold = kFoldNone;
+    if (lazy_fused && q.lazy_fold != nullptr && !(q.flags & MATPBR_FLAG_GENERIC_STEP)) {
+        if (!(q.part_mask & MATPBR_PART_A) && (q.part_mask & (MATPBR_PART_R | MATPBR_PART_M)) && q.d_a == nullptr) fold = kFoldXY;
+        else if (q.part_mask == MATPBR_PART_A && q.d_r == nullptr && q.d_m == nullptr) fold = kFoldGH;
+    }
     // forward sums per image: t > 1 of the fused step: its workgroups' and the resampling launch's
-    const bool resample = lazy_fused && ((q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr);   // otherwise no pixel ever leaves its model's interval
+    const bool resample = lazy_fused && fold == kFoldNone && ((q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr);   // otherwise no pixel ever leaves its model's interval (folded step: walked in-kernel)
     const int nres = grid_blocks(q.H, q.W) < kResampleWaves ? grid_blocks(q.H, q.W) : kResampleWaves;   // waves of the resampling launch per image
-    const int nfwd = grid_blocks(q.H, q.W) + ((lazy_fused && t > 1) ? (resample ? nres : 0) : (lazy ? lazy_groups((long)q.H * q.W) : 0));
+    const int nfwd = grid_blocks(q.H, q.W) + (fold != kFoldNone ? 0 : ((lazy_fused && t > 1) ? (resample ? nres : 0) : (lazy ? lazy_groups((long)q.H * q.W) : 0)));
     float* fwd_sums = (float*)q.workspace;
     float* part = fwd_sums + (size_t)q.batch * nfwd;
     const long n1 = (long)q.H * q.W, n3 = n1 * 3;
@@ -1305,6 +1317,17 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         const int rc = lazy_forward(q.pa, q.pr, q.pm, q.n, q.light, q.dcache, q.lazy_state, q.pred, q.jac, q.stats, fwd_sums, g, tab, q.batch, 1,
                                     (t == 1 && !(q.flags & MATPBR_FLAG_MODELS_READY)) ? 1 : 0, 0.0f, q.lazy_tol, st);
         if (rc != MATPBR_OK) return rc;
+        if (fold != kFoldNone) {
+            // the part's folded planes from the generic models just built, the render of these parameters in the folded expression (what the
+            // step recomputes instead of reading pred back) and its per-block sums
+            const LazyBuffers lb = lazy_buffers(q.lazy_state, n1, q.batch);
+            LazyFoldArgs fa{};
+            fa.a = q.pa; fa.r = q.pr; fa.m = q.pm; fa.out = q.pred; fa.block_sums = fwd_sums; fa.stats = q.stats;
+            for (int k = 0; k < kLzPlanes; ++k) fa.plane[k] = lb.planes + (size_t)k * (size_t)q.batch * (size_t)n1;
+            for (int k = 0; k < kFxPlanes; ++k) fa.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
+            if (fold == kFoldXY) hipLaunchKernelGGL(lazy_fold_kernel<kFoldXY>, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, fa, (int)n1);
+            else hipLaunchKernelGGL(lazy_fold_kernel<kFoldGH>, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, fa, (int)n1);
+        }
     } else if (r_fixed && (t > 1 || (q.flags & MATPBR_FLAG_MODELS_READY)))
         hipLaunchKernelGGL(shade_cached_kernel, grid, dim3(kBlock), 0, st, sa, g);
     else
@@ -1373,7 +1396,21 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         }
         ls.stats_out = q.stats; ls.history = q.history; ls.hist_len = q.hist_len; ls.batch = q.batch;
         ls.es_patience = q.es_patience; ls.es_min_delta = q.es_min_delta;
-        if (stages & MATPBR_STAGE_BACKWARD)
+        if (fold != kFoldNone) {
+            for (int k = 0; k < kFxPlanes; ++k) ls.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
+            // at most 1024 workgroups (four per CU, all resident), each with up to kPstepMaxBlocks consecutive 512-pixel blocks of one image
+            long wg_cap = 1024;
+#ifdef MATPBR_EXP_TUNE   // measurement builds only (tools/r4_variant.sh)
+            if (const char* e = std::getenv("MATPBR_PSTEP_WGS")) wg_cap = std::atol(e) > 0 ? std::atol(e) : wg_cap;
+#endif
+            int bpw = (int)(((long)lb.nblk * q.batch + wg_cap - 1) / wg_cap);
+            bpw = bpw < 1 ? 1 : (bpw > kPstepMaxBlocks ? kPstepMaxBlocks : bpw);
+            ls.tiles_per_wg = 2 * bpw; ls.n_tiles = 2 * lb.nblk;
+            const dim3 pgrid((unsigned)((lb.nblk + bpw - 1) / bpw), (unsigned)q.batch);
+            if (!(stages & MATPBR_STAGE_BACKWARD)) {
+            } else if (fold == kFoldXY) hipLaunchKernelGGL(lazy_pstep_kernel<kFoldXY>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
+            else hipLaunchKernelGGL(lazy_pstep_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
+        } else if (stages & MATPBR_STAGE_BACKWARD)
             hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);
         if ((stages & MATPBR_STAGE_RESAMPLE) && resample)
             hipLaunchKernelGGL(lazy_resample_kernel, dim3((unsigned)nres, (unsigned)q.batch), dim3(64), (size_t)(lb.nblk + 1) * sizeof(int), st, ls, q.light, g, tab);

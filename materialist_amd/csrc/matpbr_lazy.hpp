@@ -34,6 +34,39 @@ __device__ __forceinline__ float h2_hi(uint32_t u) { return (float)__builtin_bit
 __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+// ---- folded models of the persistent step kernel (lazy_pstep_kernel) -------------------------------------------------------------
+// A part of --opt_order moves some of the maps and leaves the others alone (inverse_img_w_mi.py:343-357); what it leaves alone folds into
+// the pixel's model, and the step reads fewer planes:
+//   kFoldXY (parts of r / m: the albedo is a constant of the part)   out_c = X_c(dr) + m Y_c(dr),   dr = r - r_ref,
+//       X_c = a_c P_c + 0.04 SD_c + S1_c,   Y_c = (a_c - 0.04) SD_c - a_c P_c      (C0 = 0.04 (1 - m) + m a, :1412)
+//       X_c(dr) = X0 + X1 dr + X2 dr^2,  Y_c(dr) = Y0 + Y1 dr - X2 dr^2  (X2 = a_c A2_c: P is an exact quadratic in r),
+//       d out_c / d m = Y_c(dr);  d out_c / d r = JX_c + m JY_c with JX = JX0 + 2 X2 dr, JY = JY0 - 2 X2 dr: the stop-gradient convention
+//       (JX0 = a dP + 0.04 dSD + dS1, JY0 = (a - 0.04) dSD - a dP); with attached sampling the models' slopes X1, Y1 take their place.
+//       16 planes = 64 B/pixel (the generic model: 80 B/pixel + the 12 B/pixel of the albedo it is combined with).
+//   kFoldGH (part 'a': roughness and metallic are constants of the part)   out_c = a_c G_c + H_c,   d out_c / d a_c = G_c,
+//       G_c = (1 - m) P_c(dr) + m SD_c(dr),   H_c = 0.04 (1 - m) SD_c(dr) + S1_c(dr):  6 planes = 24 B/pixel, never re-sampled.
+// The generic planes stay the specification (oracle/matpbr_oracle.c); the folded ones are derived from them by lazy_fold_kernel at the
+// start of a part and rewritten together with them for every re-sampled pixel.
+enum { kFoldNone = 0, kFoldXY = 1, kFoldGH = 2 };
+enum { kFxRref = 0, kFxLoHi = 1, kFxX0 = 2 /* X0_c at 2 + 2c, Y0_c at 3 + 2c */, kFxS = 8 /* half2 (X1_c, Y1_c) */, kFxJ = 11 /* half2 (JX0_c, JY0_c) */,
+       kFxQ = 14 /* half2 (X2_0, X2_1), half2 (X2_2, 0) */, kFxPlanes = 16 };
+enum { kFgG = 0, kFgH = 3, kFgPlanes = 6 };
+struct FoldXY { float X0, Y0, X1, Y1, JX0, JY0, X2; };
+__device__ __forceinline__ void fold_xy(float a, float P, float SD, float S1, float dP, float A2, float gSD, float gS1, float dSD, float dS1, FoldXY& f) {
+    const float am = a - 0.04f, naP = -(a * P), nadP = -(a * dP);
+    f.X0 = fmaf(a, P, fmaf(0.04f, SD, S1));
+    f.Y0 = fmaf(am, SD, naP);
+    f.X1 = fmaf(a, dP, fmaf(0.04f, gSD, gS1));
+    f.Y1 = fmaf(am, gSD, nadP);
+    f.JX0 = fmaf(a, dP, fmaf(0.04f, dSD, dS1));
+    f.JY0 = fmaf(am, dSD, nadP);
+    f.X2 = a * A2;
+}
+constexpr int kTile = kBlock;          // pixels of a tile of lazy_pstep_kernel: one per thread
+constexpr int kMaxTilesPerWg = 8;      // tiles a workgroup of lazy_pstep_kernel streams at most (its LDS lists are sized for them)
+__host__ __device__ inline int lazy_tiles(long P) { return (int)((P + kTile - 1) / kTile); }
+inline size_t lazy_fold_bytes(long P, int batch) { return (size_t)kFxPlanes * (size_t)batch * (size_t)P * 4; }
+
 __host__ __device__ inline int lazy_fwd_blocks(long P) { return (int)((P + kLazyBlockPixels - 1) / kLazyBlockPixels); }
 // workgroups of the refresh kernel per image (each takes every lazy_groups()-th chunk of the image's work list; also the number of
 // partial sums it contributes): enough to fill the GPU when a few per cent of a 512 x 512 image are listed, few enough to be cheap when none is
@@ -205,6 +238,9 @@ struct LazyStepArgs {
     float* history;
     int hist_len, batch, es_patience;
     float es_min_delta;
+    // lazy_pstep_kernel (the folded, persistent form of the step): the folded planes, tiles per workgroup, tiles per image
+    uint32_t* fplane[kFxPlanes];
+    int tiles_per_wg, n_tiles;
 };
 // LDS exchange between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be held back
 __device__ __forceinline__ void wave_lds_sync() {
@@ -508,6 +544,185 @@ __device__ unsigned long long g_rs_stamps[8];
 #else
 #define RS_STAMP(k) do { } while (0)
 #endif
+// One listed pixel re-sampled by the eight lanes `sub` = 0..7 of its group (four azimuths x (r, r + dir h: the one-sided difference that gives
+// the slopes), each lane walking the rings of its azimuth, contributions folded by a fixed butterfly): rebuilds the pixel's model, writes its
+// render into sp.pred_next and adds it to `tot` (lane sub == 0 of an item that exists; the other lanes return without side effects).
+// Shared by lazy_resample_kernel (FOLD = false) and the in-kernel walk of lazy_pstep_kernel (FOLD = true: the folded planes are rewritten too
+// and the render is the folded expression).  Tables in LDS: light coefficients x basis normalisation, GGX rings, azimuths.
+template <bool FOLD>
+__device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, const StepPtrs& sp, const float* s_light, const float4* s_ring,
+                                                    const float2* s_saz, const Geom& g, const RuleTable& tab, int b, int P, long BPl, int p,
+                                                    bool item_ok, int sub, float floor_, float tol_k, float tol_s, float& tot) {
+    const JacBwdArgs& q = qs.j;
+    (void)q;
+    const int half = sub >> 2, azi = sub & 3;
+    const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
+    float rc[7];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rc[1 + c] = fminf(fmaxf(ldf(sp.a, o3 + 4 * c), 0.0f), 1.0f);
+    rc[4] = fminf(fmaxf(ldf(sp.r, o1), 0.07f), 1.0f);
+    rc[5] = fminf(fmaxf(ldf(sp.m, o1), 0.0f), 1.0f);
+    rc[6] = rc[4] - as_f(ldu(qs.plane[kLzRref], o1));
+    const float rc_r = rc[4], mv = rc[5], dr = rc[6];
+    const float rho_old = as_f(ldu(qs.plane[kLzRho], o1));
+    // geometry of the pixel (the same at r and at r + dir h: plain floats), as load_pixel forms it
+    float nn[3], ss[3], tt[3], vx, vy, vz, NoV;
+    {
+        float nv[3] = {ldf(qs.n, o3), ldf(qs.n, o3 + 4), ldf(qs.n, o3 + 8)};
+        const float inl = rsq(fmaxf(dot3(nv, nv), 1e-30f));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nn[c] = nv[c] * inl;
+        const float fi = (float)(p / g.W), fj = (float)(p % g.W);
+        const float x = (g.cx - fj) * g.inv_f, y = (fi - g.cy) * g.inv_f, il = rsq(fmaf(x, x, fmaf(y, y, 1.0f)));
+        const float wo[3] = {x * il, y * il, il};
+        frame(nn, ss, tt);
+        vx = dot3(ss, wo); vy = dot3(tt, wo); vz = dot3(nn, wo);
+        NoV = fmaxf(vz, 0.0f);
+    }
+    float dir = dr < 0.0f ? -1.0f : 1.0f;
+    if (rc_r + dir * kLzH > 1.0f || rc_r + dir * kLzH < 0.07f) dir = -dir;
+    float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3], pSD[3], pS1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float A0 = ldf(qs.dcache + c * BPl, o1), A1 = ldf(qs.dcache + (3 + c) * BPl, o1);
+        A2[c] = ldf(qs.dcache + (6 + c) * BPl, o1);
+        const uint32_t sk = ldu(qs.plane[kLzSk + c], o1);      // what the old model predicts at the new roughness
+        pSD[c] = fmaf(h2_lo(sk), dr, as_f(ldu(qs.plane[kLzSD + c], o1)));
+        pS1[c] = fmaf(h2_hi(sk), dr, as_f(ldu(qs.plane[kLzS1 + c], o1)));
+        Pc[c] = fmaf(fmaf(A2[c], rc_r, A1), rc_r, A0);
+        dP[c] = fmaf(2.0f * rc_r, A2[c], A1);
+        kd[c] = rc[1 + c] * (1.0f - mv);
+        C0[c] = fmaf(mv, rc[1 + c], (1.0f - mv) * 0.04f);
+        iscale[c] = 1.0f / fmaxf(fabsf(fmaf(kd[c], Pc[c], fmaf(C0[c], pSD[c], pS1[c]))), floor_);
+    }
+    RS_STAMP(3);
+    // ---- this lane's samples: one azimuth of every ring, at r (sub 0-3) or at r + dir h (sub 4-7)  (spec_ring / spec_sample /
+    // spec_accumulate of matpbr_shade.hpp, one value per lane)
+    float S0[3] = {0, 0, 0}, S1[3] = {0, 0, 0}, dS0[3] = {0, 0, 0}, dS1[3] = {0, 0, 0}, klo = 1e30f, khi = 1e30f;
+    {
+        const float rr = rc_r + (half ? dir * kLzH : 0.0f);
+        const float alpha2 = pow4(rr), am1 = alpha2 - 1.0f, rp1 = rr + 1.0f, kk = (rp1 * rp1) * 0.125f;
+        const float omk = 1.0f - kk, kpe = kk + 1e-6f, dk_dr = rp1 * 0.25f, g1v = rcp(fmaf(NoV, omk, kpe));
+        const float four_over_r = 4.0f * rcp(rr), cv = dk_dr * g1v * (1.0f - NoV), r3x4 = 4.0f * rr * rr * rr, g1l0 = rcp(kpe);
+        for (int ring = 0; ring < tab.nu_s; ++ring) {
+            const float4 rg = s_ring[ring];
+            const float rq = rcp(fmaf(am1, rg.x, 1.0f));
+            const float cos2 = rq * rg.y, sin2 = (alpha2 * rg.x) * rq, ict = rsq(cos2);
+            const float ct = cos2 * ict, st = sin2 * rsq(sin2), ringw = (g1v * rg.z) * ict, idq = rcp(rq + 1e-6f * rcp(alpha2));
+            const float lam0 = fmaf(four_over_r, fmaf(rq * idq, -2.0f * rg.y, 1.0f), -cv);
+            const float gq = r3x4 * rg.x * rq * cos2;      // d sin^2 theta_h / dr  (mi_specular_sampler :232-233)
+            const float stp = 0.5f * gq * rcp(st), ctp = -0.5f * gq * rcp(ct);
+            for (int j = azi; j < tab.nphi_s; j += 4) {
+                const float2 az = s_saz[ring * kMaxAz + j];
+                const float whx = st * az.x, why = st * az.y;
+                const float d = fmaf(ct, vz, fmaf(why, vy, whx * vx)), d2 = d + d;
+                const float wlx = fmaf(d2, whx, -vx), wly = fmaf(d2, why, -vy), wlz = fmaf(d2, ct, -vz);      // 2 (wo.wh) wh - wo  (:245)
+                float wi[3], B[kNSH], L[3] = {0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wi[c] = fmaf(wlz, nn[c], fmaf(wly, tt[c], wlx * ss[c]));
+                const float NoL = fmaxf(wlz, 0.0f), dpos = fmaxf(d, 0.0f), g1l = rcp(fmaf(NoL, omk, kpe)), x5 = pow5(1.0f - dpos);
+                const float wgt = (ringw * g1l) * (NoL * dpos);
+                sh_poly(wi, B);
+                // FOLD (the walk inside the streaming step kernel, 128 registers): the 75 coefficients are read from LDS per sample -- left to
+                // itself the compiler keeps them in registers across the ring loop (they are loop invariants) and spills a hundred others
+                // (an opaque ZERO OFFSET, not an opaque pointer: the address must stay an LDS address -- a laundered pointer is a generic one,
+                // and every read becomes a flat load with a full wait behind it)
+                unsigned zoff = 0u;
+                if (FOLD) asm volatile("" : "+v"(zoff));
+                const float* lp = s_light + (zoff << 2);
+#pragma unroll
+                for (int k = 0; k < kNSH; ++k) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) L[c] = fmaf(B[k], lp[3 * k + c], L[c]);
+                }
+                const float wx = wgt * x5, wl = wgt * fmaf(dk_dr * g1l, NoL - 1.0f, lam0), wlx5 = wl * x5;
+                float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    S0[c] = fmaf(wgt, L[c], S0[c]); S1[c] = fmaf(wx, L[c], S1[c]);
+                    dS0[c] = fmaf(wl, L[c], dS0[c]); dS1[c] = fmaf(wlx5, L[c], dS1[c]);
+                    const float aL = fabsf(L[c]) * iscale[c];
+                    m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL);
+                    m2 = fmaxf(m2, aL);
+                }
+                // where this sample's clamped variables n.wi and wo.h cross zero, to first order in r
+                const float dp = fmaf(stp, fmaf(az.x, vx, az.y * vy), ctp * vz);
+                const float wlzp = 2.0f * fmaf(dp, ct, d * ctp);
+                lazy_kink(wlz, wlzp, ringw * g1l0 * dpos * m1 * fabsf(wlzp), tol_k, klo, khi);
+                lazy_kink(d, dp, ringw * g1l * NoL * m2 * fabsf(dp), tol_k, klo, khi);
+            }
+        }
+    }
+    RS_STAMP(4);
+    // fold over the four azimuth lanes with a fixed butterfly (the same tree for every pixel: reproducible)
+    float fv[kWalkVals];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        fv[c] = lane_group_sum<4>(S0[c]); fv[3 + c] = lane_group_sum<4>(S1[c]);
+        fv[6 + c] = lane_group_sum<4>(dS0[c]); fv[9 + c] = lane_group_sum<4>(dS1[c]);
+    }
+    fv[18] = lane_group_min<4>(klo);
+    fv[19] = lane_group_min<4>(khi);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {   // the sums at r + dir h, from the lanes four further up
+        fv[12 + c] = __shfl_down(fv[c], 4);
+        fv[15 + c] = __shfl_down(fv[3 + c], 4);
+    }
+    if (item_ok && sub == 0) {
+        const float ih = dir * (1.0f / kLzH);
+        float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3], x2h[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            vSD[c] = fv[c] - fv[3 + c];
+            vS1[c] = fv[3 + c];
+            gSD[c] = ((fv[12 + c] - fv[15 + c]) - vSD[c]) * ih;
+            gS1[c] = (fv[15 + c] - fv[3 + c]) * ih;
+            dSD[c] = fv[6 + c] - fv[9 + c];
+            dS1v[c] = fv[9 + c];
+        }
+        float rho = rho_old;
+        if (fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
+            float e = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) e = fmaxf(e, fabsf(fmaf(C0[c], pSD[c] - vSD[c], pS1[c] - vS1[c])) * iscale[c]);
+            const float want = 0.9f * fabsf(dr) * fsqrt(tol_s / fmaxf(e, 1e-12f));
+            rho = fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
+        }
+        rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
+        *(uint32_t*)((char*)qs.plane[kLzRref] + o1) = as_u(rc_r);
+        *(uint32_t*)((char*)qs.plane[kLzLoHi] + o1) = pack_h2(0.998f * fminf(fv[18], rho), 0.998f * fminf(fv[19], rho));
+        *(uint32_t*)((char*)qs.plane[kLzRho] + o1) = as_u(rho);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            *(uint32_t*)((char*)qs.plane[kLzP + c] + o1) = as_u(Pc[c]);
+            *(uint32_t*)((char*)qs.plane[kLzSD + c] + o1) = as_u(vSD[c]);
+            *(uint32_t*)((char*)qs.plane[kLzS1 + c] + o1) = as_u(vS1[c]);
+            *(uint32_t*)((char*)qs.plane[kLzPk + c] + o1) = pack_h2(dP[c], A2[c]);
+            *(uint32_t*)((char*)qs.plane[kLzSk + c] + o1) = pack_h2(gSD[c], gS1[c]);
+            *(uint32_t*)((char*)qs.plane[kLzDk + c] + o1) = pack_h2(dSD[c], dS1v[c]);
+            float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
+            if (FOLD) {      // the folded planes of lazy_pstep_kernel<kFoldXY> (fold_xy_*: one definition for the fold kernel and this one)
+                FoldXY f;
+                fold_xy(rc[1 + c], Pc[c], vSD[c], vS1[c], dP[c], A2[c], gSD[c], gS1[c], dSD[c], dS1v[c], f);
+                x2h[c] = f.X2;
+                *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c] + o1) = as_u(f.X0);
+                *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c + 1] + o1) = as_u(f.Y0);
+                *(uint32_t*)((char*)qs.fplane[kFxS + c] + o1) = pack_h2(f.X1, f.Y1);
+                *(uint32_t*)((char*)qs.fplane[kFxJ + c] + o1) = pack_h2(f.JX0, f.JY0);
+                rgb = fmaf(mv, f.Y0, f.X0);
+            }
+            stf(sp.pred_next, o3 + 4 * c, rgb);
+            tot += rgb;
+        }
+        if (FOLD) {
+            *(uint32_t*)((char*)qs.fplane[kFxRref] + o1) = as_u(rc_r);
+            *(uint32_t*)((char*)qs.fplane[kFxLoHi] + o1) = pack_h2(0.998f * fminf(fv[18], rho), 0.998f * fminf(fv[19], rho));
+            *(uint32_t*)((char*)qs.fplane[kFxQ] + o1) = pack_h2(x2h[0], x2h[1]);
+            *(uint32_t*)((char*)qs.fplane[kFxQ + 1] + o1) = pack_h2(x2h[2], 0.0f);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
     __shared__ float s_light[kNL + 1];
     __shared__ float4 s_ring[kMaxRings];
@@ -588,7 +803,7 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
             floor_ = 0.5f * gt_sum / (3.0f * (float)P) / (rt > 0.0f ? rt : 1.0f);
         }
         const float tol_k = qs.tol * kLzTolK, tol_s = qs.tol * kLzTolS;
-        const int sub = lane & 7, half = sub >> 2, azi = sub & 3;
+        const int sub = lane & 7;
         const long BPl = (long)gridDim.y * P;
         // eight lanes per pixel, eight pixels per wave and pass (one sample per lane -- 40 lanes per pixel, one pixel per wave -- was
         // slower: every wave pays the prefix over the image's counts)
@@ -616,148 +831,7 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
             }
             const int p = lo_b * kLazyBlockPixels + (int)lists[(long)lo_b * kLazyBlockPixels + rel];
             RS_STAMP(2);
-            const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
-            float rc[7];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rc[1 + c] = fminf(fmaxf(ldf(sp.a, o3 + 4 * c), 0.0f), 1.0f);
-            rc[4] = fminf(fmaxf(ldf(sp.r, o1), 0.07f), 1.0f);
-            rc[5] = fminf(fmaxf(ldf(sp.m, o1), 0.0f), 1.0f);
-            rc[6] = rc[4] - as_f(ldu(qs.plane[kLzRref], o1));
-            const float rc_r = rc[4], mv = rc[5], dr = rc[6];
-            const float rho_old = as_f(ldu(qs.plane[kLzRho], o1));
-            // geometry of the pixel (the same at r and at r + dir h: plain floats), as load_pixel forms it
-            float nn[3], ss[3], tt[3], vx, vy, vz, NoV;
-            {
-                float nv[3] = {ldf(qs.n, o3), ldf(qs.n, o3 + 4), ldf(qs.n, o3 + 8)};
-                const float inl = rsq(fmaxf(dot3(nv, nv), 1e-30f));
-#pragma unroll
-                for (int c = 0; c < 3; ++c) nn[c] = nv[c] * inl;
-                const float fi = (float)(p / g.W), fj = (float)(p % g.W);
-                const float x = (g.cx - fj) * g.inv_f, y = (fi - g.cy) * g.inv_f, il = rsq(fmaf(x, x, fmaf(y, y, 1.0f)));
-                const float wo[3] = {x * il, y * il, il};
-                frame(nn, ss, tt);
-                vx = dot3(ss, wo); vy = dot3(tt, wo); vz = dot3(nn, wo);
-                NoV = fmaxf(vz, 0.0f);
-            }
-            float dir = dr < 0.0f ? -1.0f : 1.0f;
-            if (rc_r + dir * kLzH > 1.0f || rc_r + dir * kLzH < 0.07f) dir = -dir;
-            float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3], pSD[3], pS1[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float A0 = ldf(qs.dcache + c * BPl, o1), A1 = ldf(qs.dcache + (3 + c) * BPl, o1);
-                A2[c] = ldf(qs.dcache + (6 + c) * BPl, o1);
-                const uint32_t sk = ldu(qs.plane[kLzSk + c], o1);      // what the old model predicts at the new roughness
-                pSD[c] = fmaf(h2_lo(sk), dr, as_f(ldu(qs.plane[kLzSD + c], o1)));
-                pS1[c] = fmaf(h2_hi(sk), dr, as_f(ldu(qs.plane[kLzS1 + c], o1)));
-                Pc[c] = fmaf(fmaf(A2[c], rc_r, A1), rc_r, A0);
-                dP[c] = fmaf(2.0f * rc_r, A2[c], A1);
-                kd[c] = rc[1 + c] * (1.0f - mv);
-                C0[c] = fmaf(mv, rc[1 + c], (1.0f - mv) * 0.04f);
-                iscale[c] = 1.0f / fmaxf(fabsf(fmaf(kd[c], Pc[c], fmaf(C0[c], pSD[c], pS1[c]))), floor_);
-            }
-            RS_STAMP(3);
-            // ---- this lane's samples: one azimuth of every ring, at r (sub 0-3) or at r + dir h (sub 4-7)  (spec_ring / spec_sample /
-            // spec_accumulate of matpbr_shade.hpp, one value per lane)
-            float S0[3] = {0, 0, 0}, S1[3] = {0, 0, 0}, dS0[3] = {0, 0, 0}, dS1[3] = {0, 0, 0}, klo = 1e30f, khi = 1e30f;
-            {
-                const float rr = rc_r + (half ? dir * kLzH : 0.0f);
-                const float alpha2 = pow4(rr), am1 = alpha2 - 1.0f, rp1 = rr + 1.0f, kk = (rp1 * rp1) * 0.125f;
-                const float omk = 1.0f - kk, kpe = kk + 1e-6f, dk_dr = rp1 * 0.25f, g1v = rcp(fmaf(NoV, omk, kpe));
-                const float four_over_r = 4.0f * rcp(rr), cv = dk_dr * g1v * (1.0f - NoV), r3x4 = 4.0f * rr * rr * rr, g1l0 = rcp(kpe);
-                for (int ring = 0; ring < tab.nu_s; ++ring) {
-                    const float4 rg = s_ring[ring];
-                    const float rq = rcp(fmaf(am1, rg.x, 1.0f));
-                    const float cos2 = rq * rg.y, sin2 = (alpha2 * rg.x) * rq, ict = rsq(cos2);
-                    const float ct = cos2 * ict, st = sin2 * rsq(sin2), ringw = (g1v * rg.z) * ict, idq = rcp(rq + 1e-6f * rcp(alpha2));
-                    const float lam0 = fmaf(four_over_r, fmaf(rq * idq, -2.0f * rg.y, 1.0f), -cv);
-                    const float gq = r3x4 * rg.x * rq * cos2;      // d sin^2 theta_h / dr  (mi_specular_sampler :232-233)
-                    const float stp = 0.5f * gq * rcp(st), ctp = -0.5f * gq * rcp(ct);
-                    for (int j = azi; j < tab.nphi_s; j += 4) {
-                        const float2 az = s_saz[ring * kMaxAz + j];
-                        const float whx = st * az.x, why = st * az.y;
-                        const float d = fmaf(ct, vz, fmaf(why, vy, whx * vx)), d2 = d + d;
-                        const float wlx = fmaf(d2, whx, -vx), wly = fmaf(d2, why, -vy), wlz = fmaf(d2, ct, -vz);      // 2 (wo.wh) wh - wo  (:245)
-                        float wi[3], B[kNSH], L[3] = {0, 0, 0};
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) wi[c] = fmaf(wlz, nn[c], fmaf(wly, tt[c], wlx * ss[c]));
-                        const float NoL = fmaxf(wlz, 0.0f), dpos = fmaxf(d, 0.0f), g1l = rcp(fmaf(NoL, omk, kpe)), x5 = pow5(1.0f - dpos);
-                        const float wgt = (ringw * g1l) * (NoL * dpos);
-                        sh_poly(wi, B);
-#pragma unroll
-                        for (int k = 0; k < kNSH; ++k) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) L[c] = fmaf(B[k], s_light[3 * k + c], L[c]);
-                        }
-                        const float wx = wgt * x5, wl = wgt * fmaf(dk_dr * g1l, NoL - 1.0f, lam0), wlx5 = wl * x5;
-                        float m1 = 0.0f, m2 = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            S0[c] = fmaf(wgt, L[c], S0[c]); S1[c] = fmaf(wx, L[c], S1[c]);
-                            dS0[c] = fmaf(wl, L[c], dS0[c]); dS1[c] = fmaf(wlx5, L[c], dS1[c]);
-                            const float aL = fabsf(L[c]) * iscale[c];
-                            m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL);
-                            m2 = fmaxf(m2, aL);
-                        }
-                        // where this sample's clamped variables n.wi and wo.h cross zero, to first order in r
-                        const float dp = fmaf(stp, fmaf(az.x, vx, az.y * vy), ctp * vz);
-                        const float wlzp = 2.0f * fmaf(dp, ct, d * ctp);
-                        lazy_kink(wlz, wlzp, ringw * g1l0 * dpos * m1 * fabsf(wlzp), tol_k, klo, khi);
-                        lazy_kink(d, dp, ringw * g1l * NoL * m2 * fabsf(dp), tol_k, klo, khi);
-                    }
-                }
-            }
-            RS_STAMP(4);
-            // fold over the four azimuth lanes with a fixed butterfly (the same tree for every pixel: reproducible)
-            float fv[kWalkVals];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                fv[c] = lane_group_sum<4>(S0[c]); fv[3 + c] = lane_group_sum<4>(S1[c]);
-                fv[6 + c] = lane_group_sum<4>(dS0[c]); fv[9 + c] = lane_group_sum<4>(dS1[c]);
-            }
-            fv[18] = lane_group_min<4>(klo);
-            fv[19] = lane_group_min<4>(khi);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {   // the sums at r + dir h, from the lanes four further up
-                fv[12 + c] = __shfl_down(fv[c], 4);
-                fv[15 + c] = __shfl_down(fv[3 + c], 4);
-            }
-            if (item_ok && sub == 0) {
-                const float ih = dir * (1.0f / kLzH);
-                float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    vSD[c] = fv[c] - fv[3 + c];
-                    vS1[c] = fv[3 + c];
-                    gSD[c] = ((fv[12 + c] - fv[15 + c]) - vSD[c]) * ih;
-                    gS1[c] = (fv[15 + c] - fv[3 + c]) * ih;
-                    dSD[c] = fv[6 + c] - fv[9 + c];
-                    dS1v[c] = fv[9 + c];
-                }
-                float rho = rho_old;
-                if (fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
-                    float e = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) e = fmaxf(e, fabsf(fmaf(C0[c], pSD[c] - vSD[c], pS1[c] - vS1[c])) * iscale[c]);
-                    const float want = 0.9f * fabsf(dr) * fsqrt(tol_s / fmaxf(e, 1e-12f));
-                    rho = fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
-                }
-                rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
-                *(uint32_t*)((char*)qs.plane[kLzRref] + o1) = as_u(rc_r);
-                *(uint32_t*)((char*)qs.plane[kLzLoHi] + o1) = pack_h2(0.998f * fminf(fv[18], rho), 0.998f * fminf(fv[19], rho));
-                *(uint32_t*)((char*)qs.plane[kLzRho] + o1) = as_u(rho);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    *(uint32_t*)((char*)qs.plane[kLzP + c] + o1) = as_u(Pc[c]);
-                    *(uint32_t*)((char*)qs.plane[kLzSD + c] + o1) = as_u(vSD[c]);
-                    *(uint32_t*)((char*)qs.plane[kLzS1 + c] + o1) = as_u(vS1[c]);
-                    *(uint32_t*)((char*)qs.plane[kLzPk + c] + o1) = pack_h2(dP[c], A2[c]);
-                    *(uint32_t*)((char*)qs.plane[kLzSk + c] + o1) = pack_h2(gSD[c], gS1[c]);
-                    *(uint32_t*)((char*)qs.plane[kLzDk + c] + o1) = pack_h2(dSD[c], dS1v[c]);
-                    const float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
-                    stf(sp.pred_next, o3 + 4 * c, rgb);
-                    tot += rgb;
-                }
-            }
+            resample_walk_pixel<false>(qs, sp, s_light, s_ring, s_saz, g, tab, b, P, BPl, p, item_ok, sub, floor_, tol_k, tol_s, tot);
         }
     }
     RS_STAMP(5);

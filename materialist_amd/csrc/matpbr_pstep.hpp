@@ -1,0 +1,485 @@
+// matpbr_pstep.hpp -- the step of hot loop B (`--model_name none`, inverse_img_w_mi.py:371-432) on FOLDED per-pixel models, as a persistent
+// streaming kernel (gfx950, wave64, fp32).
+//
+// lazy_step_kernel (matpbr_lazy.hpp) reads, per pixel and iteration, the three maps, the 80-byte generic model, the target, the anchors and the
+// Adam moments: 172.6 B/pixel in an 'rm' part against the 108 B/pixel of the canonical forward + backward pair.  Two things are wrong with that:
+//   * bytes: a part moves SOME of the maps (--opt_order 'rm a', :343-357); what it leaves alone is a constant that folds into the model
+//     (kFoldXY: the albedo, 64 B/pixel of model and no albedo read; kFoldGH: roughness and metallic, 24 B/pixel of model and neither map read).
+//     'rm': r 4 + m 4 read, 8 written, model 64, target 12, render 12, anchors 8, Adam moments 32 = 144 B/pixel (was 172);
+//     'a' : a 12 read, 12 written, model 24, target 12, render 12, anchors 12, Adam moments 48 = 132 B/pixel (was 160);
+//   * shape: 4096 workgroups of 512 pixels each fold the iteration's statistics before their first load, and the few pixels that leave their
+//     model's interval are a launch of their own (a 20 us latency chain at 8 x 512^2).  Here a workgroup takes up to four consecutive 512-pixel
+//     blocks (at most 1024 workgroups: all resident at four per CU), requests its first two tiles BEFORE it folds the statistics, streams tile
+//     after tile from two statically named register sets (the loads of the tile after next are in flight while a tile is computed), and walks
+//     the samples of the pixels it listed at its end, from LDS lists (eight lanes per pixel: resample_walk_pixel) -- no counts, no prefix over
+//     an image's lists, no second launch, and the render it leaves behind is complete.
+// Thread t of a workgroup owns the pixels t and t + 256 of each of its blocks, as in lazy_step_kernel: per-block sums (render, regularisers)
+// are formed in the same order whatever the batch size and the number of blocks per workgroup (batch = stand-alone, bit for bit).
+// The arithmetic of a pixel is that of lazy_step_pixel with the folded expressions (matpbr_lazy.hpp, "folded models"); parts that move the
+// albedo together with another map, and callers that ask for a gradient the folded form does not have, stay on lazy_step_kernel.
+#pragma once
+#include "matpbr_lazy.hpp"
+
+namespace matpbr {
+
+// 12 bytes per lane of an HWC map: global_load_dwordx3 / global_store_dwordx3 at (uniform base) + (32-bit lane offset)
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3(const void* base, unsigned off) { return *(const F3*)((const char*)base + off); }
+__device__ __forceinline__ void st3(void* base, unsigned off, float x, float y, float z) { *(F3*)((char*)base + off) = F3{x, y, z}; }
+__device__ __forceinline__ void stu(void* base, unsigned off, uint32_t v) { *(uint32_t*)((char*)base + off) = v; }
+
+__device__ __forceinline__ float xy_x2(uint32_t q0, uint32_t q1, int c) { return c == 0 ? h2_lo(q0) : (c == 1 ? h2_hi(q0) : h2_lo(q1)); }
+// X_c(dr), Y_c(dr) of a kFoldXY model from its stored words (s = half2 (X1, Y1))
+__device__ __forceinline__ void xy_eval(float X0, float Y0, uint32_t s, float x2, float dr, float& X, float& Y) {
+    X = fmaf(fmaf(x2, dr, h2_lo(s)), dr, X0);
+    Y = fmaf(fmaf(-x2, dr, h2_hi(s)), dr, Y0);
+}
+
+// =================================================================================================
+// generic planes -> folded planes, at the start of a part (and the render of the part's first iteration in the folded expression)
+// =================================================================================================
+struct LazyFoldArgs {
+    const float *a, *r, *m;           // the part's start parameters (raw: clamped here as every render clamps them)
+    const uint32_t* plane[kLzPlanes];
+    uint32_t* fplane[kFxPlanes];
+    float* out;                       // [B,H,W,3] the render of these parameters
+    float* block_sums;                // [B][nblk]: sum of the rgb of each 512-pixel block
+    const float* stats;               // nullable: skip images whose EarlyStopping has fired
+};
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q, int P) {
+    __shared__ float s_sum[4];
+    const int b = blockIdx.y;
+    if (q.stats && img_stopped(q.stats, b)) return;
+    float tot = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = blockIdx.x * kLazyBlockPixels + h * kBlock + (int)threadIdx.x;
+        if (p >= P) continue;
+        const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
+        const F3 av = ld3(q.a, o3);
+        const float a[3] = {fminf(fmaxf(av.x, 0.0f), 1.0f), fminf(fmaxf(av.y, 0.0f), 1.0f), fminf(fmaxf(av.z, 0.0f), 1.0f)};
+        const float r = fminf(fmaxf(ldf(q.r, o1), 0.07f), 1.0f), m = fminf(fmaxf(ldf(q.m, o1), 0.0f), 1.0f), omm = 1.0f - m;
+        const float rref = as_f(ldu(q.plane[kLzRref], o1));
+        const float dr = r - rref;
+        float rgb[3], x2h[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float Pv = as_f(ldu(q.plane[kLzP + c], o1)), SDv = as_f(ldu(q.plane[kLzSD + c], o1)), S1v = as_f(ldu(q.plane[kLzS1 + c], o1));
+            const uint32_t pk = ldu(q.plane[kLzPk + c], o1), sk = ldu(q.plane[kLzSk + c], o1), dk = ldu(q.plane[kLzDk + c], o1);
+            if (MODE == kFoldXY) {
+                FoldXY f;
+                fold_xy(a[c], Pv, SDv, S1v, h2_lo(pk), h2_hi(pk), h2_lo(sk), h2_hi(sk), h2_lo(dk), h2_hi(dk), f);
+                const uint32_t s = pack_h2(f.X1, f.Y1);
+                x2h[c] = f.X2;
+                stu(q.fplane[kFxX0 + 2 * c], o1, as_u(f.X0));
+                stu(q.fplane[kFxX0 + 2 * c + 1], o1, as_u(f.Y0));
+                stu(q.fplane[kFxS + c], o1, s);
+                stu(q.fplane[kFxJ + c], o1, pack_h2(f.JX0, f.JY0));
+                float X, Y;
+                xy_eval(f.X0, f.Y0, s, (float)(_Float16)f.X2, dr, X, Y);      // the stored (half) words, as the step kernel reads them
+                rgb[c] = fmaf(m, Y, X);
+            } else {
+                const float Pc = fmaf(fmaf(h2_hi(pk), dr, h2_lo(pk)), dr, Pv);
+                const float SD = fmaf(h2_lo(sk), dr, SDv), S1 = fmaf(h2_hi(sk), dr, S1v);
+                const float G = fmaf(m, SD, omm * Pc), Hc = fmaf(omm * 0.04f, SD, S1);
+                stu(q.fplane[kFgG + c], o1, as_u(G));
+                stu(q.fplane[kFgH + c], o1, as_u(Hc));
+                rgb[c] = fmaf(a[c], G, Hc);
+            }
+            tot += rgb[c];
+        }
+        if (MODE == kFoldXY) {
+            stu(q.fplane[kFxRref], o1, as_u(rref));
+            stu(q.fplane[kFxLoHi], o1, ldu(q.plane[kLzLoHi], o1));
+            stu(q.fplane[kFxQ], o1, pack_h2(x2h[0], x2h[1]));
+            stu(q.fplane[kFxQ + 1], o1, pack_h2(x2h[2], 0.0f));
+        }
+        st3(q.out, o3, rgb[0], rgb[1], rgb[2]);
+    }
+    tot = wave_sum_to_lane63(tot);
+    if ((threadIdx.x & 63) == 63) s_sum[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) q.block_sums[(long)b * gridDim.x + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+}
+
+// =================================================================================================
+// the persistent step
+// =================================================================================================
+// what one pixel of a tile loads (one statically named set per tile parity: no register copies between the request and the use)
+struct PxXY {
+    float r, m, rref;
+    uint32_t lohi;
+    float X0[3], Y0[3];
+    uint32_t s[3], j[3], q0, q1;
+    F3 gt;
+    float r0, m0, mr, vr, mm, vm;
+};
+struct PxGH {
+    F3 a, gt, a0, ma, va;
+    float G[3], H[3];
+};
+struct PStepFlags { bool part_r, part_m, slopes, att; };
+
+__device__ __forceinline__ void pstep_load(PxXY& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags f) {
+    const JacBwdArgs& q = qs.j;
+    const unsigned o1 = i * 4u, o3 = i * 12u;
+    x.r = ldf(sp.r, o1); x.m = ldf(sp.m, o1);
+    x.gt = ld3(q.gt_srgb, o3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x.X0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c], o1)); x.Y0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c + 1], o1)); }
+    x.rref = 0.0f; x.lohi = 0u; x.q0 = x.q1 = 0u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x.s[c] = x.j[c] = 0u;
+    if (f.slopes) {           // a part that leaves the roughness alone never moves away from r_ref (uniform branch)
+        x.rref = as_f(ldu(qs.fplane[kFxRref], o1)); x.lohi = ldu(qs.fplane[kFxLoHi], o1);
+        x.q0 = ldu(qs.fplane[kFxQ], o1); x.q1 = ldu(qs.fplane[kFxQ + 1], o1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x.s[c] = ldu(qs.fplane[kFxS + c], o1);
+        if (f.att) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x.j[c] = x.s[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x.j[c] = ldu(qs.fplane[kFxJ + c], o1);
+        }
+    }
+    x.r0 = x.m0 = x.mr = x.vr = x.mm = x.vm = 0.0f;
+    if (f.part_r) { x.r0 = ldf(q.r0, o1); if (q.am[1]) { x.mr = ldf(q.am[1], o1); x.vr = ldf(q.av[1], o1); } }
+    if (f.part_m) { x.m0 = ldf(q.m0, o1); if (q.am[2]) { x.mm = ldf(q.am[2], o1); x.vm = ldf(q.av[2], o1); } }
+}
+__device__ __forceinline__ void pstep_load(PxGH& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags) {
+    const JacBwdArgs& q = qs.j;
+    const unsigned o1 = i * 4u, o3 = i * 12u;
+    x.a = ld3(sp.a, o3);
+    x.gt = ld3(q.gt_srgb, o3);
+    x.a0 = ld3(q.a0, o3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x.G[c] = as_f(ldu(qs.fplane[kFgG + c], o1)); x.H[c] = as_f(ldu(qs.fplane[kFgH + c], o1)); }
+    x.ma = F3{0.0f, 0.0f, 0.0f}; x.va = F3{0.0f, 0.0f, 0.0f};
+    if (q.am[0]) { x.ma = ld3(q.am[0], o3); x.va = ld3(q.av[0], o3); }
+}
+
+// torch.optim.Adam on one element (adam_update of matpbr_shade.hpp with the moments in registers)
+__device__ __forceinline__ float adam_apply(float p, float gi, float m_old, float v_old, const JacBwdArgs& q, float& mi, float& vi) {
+    mi = fmaf(q.b1, m_old, (1.0f - q.b1) * gi);
+    vi = fmaf(q.b2, v_old, (1.0f - q.b2) * gi * gi);
+    return p - q.lr_over_bc1 * mi / fmaf(fsqrt(vi), q.inv_sqrt_bc2, q.eps);
+}
+// d loss / d pred of 3 (l1/mse) mse + l1 on xs = max(pred ratio, eps)^(1/2.2)  (:388-418), as lazy_step_pixel forms it
+__device__ __forceinline__ float loss_go(float prc, float gt, float ratio, float sr, float inv_n3, float& xs) {
+    const float x = prc * ratio;
+    const float xc = fmaxf(x, kLossEps);
+    xs = pow_inv_gamma(xc);
+    const float d = xs - gt;
+    const float dxs = x > kLossEps ? xs * rcp(xc) * (1.0f / 2.2f) : 0.0f;
+    return ratio * dxs * fmaf(6.0f * sr, d, fsign(d)) * inv_n3;
+}
+
+// one pixel of a kFoldXY part; returns whether its new roughness has left its model's interval
+__device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags f, float ratio,
+                                            float sr, bool improved, float& tot, float (&reg)[3]) {
+    const JacBwdArgs& q = qs.j;
+    const unsigned o1 = i * 4u, o3 = i * 12u;
+    if (qs.rotate) improved = false;      // no snapshot stores: the buffer just read IS the snapshot
+    const float r = fminf(fmaxf(x.r, 0.07f), 1.0f), m = fminf(fmaxf(x.m, 0.0f), 1.0f);
+    const float dr = r - x.rref;
+    const float gt[3] = {x.gt.x, x.gt.y, x.gt.z};
+    float drr = 0.0f, dm = 0.0f, xs_keep[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        // the render of iteration t is not read back: it IS the model at the current parameters (the expression that wrote pred -- the step
+        // before, the walk at dr = 0, or lazy_fold_kernel -- on the same operands: the same bits)
+        const float x2 = xy_x2(x.q0, x.q1, c);
+        float X, Y;
+        xy_eval(x.X0[c], x.Y0[c], x.s[c], x2, dr, X, Y);
+        const float go = loss_go(fmaf(m, Y, X), gt[c], ratio, sr, q.inv_n3, xs_keep[c]);
+        const float JX = fmaf(2.0f * x2, dr, h2_lo(x.j[c])), JY = fmaf(-2.0f * x2, dr, h2_hi(x.j[c]));
+        drr = fmaf(go, fmaf(m, JY, JX), drr);
+        dm = fmaf(go, Y, dm);
+    }
+    if (improved && q.best_img) st3(q.best_img, o3, xs_keep[0], xs_keep[1], xs_keep[2]);
+    float gr = drr + (f.part_r ? q.scale_delta * q.inv_n1 * fsign(r - x.r0) : 0.0f);
+    float gm = dm + (f.part_m ? q.scale_delta * q.inv_n1 * fsign(m - x.m0) : 0.0f);
+    gr = (x.r >= 0.07f && x.r <= 1.0f) ? gr : 0.0f;
+    gm = (x.m >= 0.0f && x.m <= 1.0f) ? gm : 0.0f;
+    if (q.d_r) stf(q.d_r, o1, gr);
+    if (q.d_m) stf(q.d_m, o1, gm);
+    if (improved && q.best_r) stf(q.best_r, o1, r);
+    if (improved && q.best_m) stf(q.best_m, o1, m);
+    float nr = x.r, nm = x.m;
+    if (f.part_r && q.am[1]) {
+        float mi, vi;
+        nr = adam_apply(x.r, gr, x.mr, x.vr, q, mi, vi);
+        stf(q.am[1], o1, mi); stf(q.av[1], o1, vi); stf(sp.pr, o1, nr);
+    }
+    if (f.part_m && q.am[2]) {
+        float mi, vi;
+        nm = adam_apply(x.m, gm, x.mm, x.vm, q, mi, vi);
+        stf(q.am[2], o1, mi); stf(q.av[2], o1, vi); stf(sp.pm, o1, nm);
+    }
+    // ---- forward of iteration t+1 from the same model
+    const float r1 = fminf(fmaxf(nr, 0.07f), 1.0f), m1 = fminf(fmaxf(nm, 0.0f), 1.0f), dr1 = r1 - x.rref;
+    if (f.part_r) reg[1] += fabsf(r1 - x.r0);
+    if (f.part_m) reg[2] += fabsf(m1 - x.m0);
+    const bool need = f.slopes && !(dr1 >= -h2_lo(x.lohi) && dr1 <= h2_hi(x.lohi));
+    if (!need) {
+        float rgb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float X, Y;
+            xy_eval(x.X0[c], x.Y0[c], x.s[c], xy_x2(x.q0, x.q1, c), dr1, X, Y);
+            rgb[c] = fmaf(m1, Y, X);
+            tot += rgb[c];
+        }
+        st3(sp.pred_next, o3, rgb[0], rgb[1], rgb[2]);
+    }
+    return need;
+}
+// one pixel of a kFoldGH part (never leaves its model: nothing of it depends on the roughness)
+__device__ __forceinline__ bool pstep_pixel(const PxGH& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags, float ratio,
+                                            float sr, bool improved, float& tot, float (&reg)[3]) {
+    const JacBwdArgs& q = qs.j;
+    const unsigned o3 = i * 12u;
+    if (qs.rotate) improved = false;
+    const float ra[3] = {x.a.x, x.a.y, x.a.z}, gt[3] = {x.gt.x, x.gt.y, x.gt.z}, a0[3] = {x.a0.x, x.a0.y, x.a0.z};
+    const float ma[3] = {x.ma.x, x.ma.y, x.ma.z}, va[3] = {x.va.x, x.va.y, x.va.z};
+    float na[3], mi[3], vi[3], xs_keep[3], gs[3], ac[3], rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ac[c] = fminf(fmaxf(ra[c], 0.0f), 1.0f);
+        const float go = loss_go(fmaf(ac[c], x.G[c], x.H[c]), gt[c], ratio, sr, q.inv_n3, xs_keep[c]);
+        float gsum = go * x.G[c] + q.scale_delta * q.inv_n3 * fsign(ac[c] - a0[c]);                                                  // :398,418
+        gsum = (ra[c] >= 0.0f && ra[c] <= 1.0f) ? gsum : 0.0f;                                                                         // clamp backward
+        gs[c] = gsum;
+        na[c] = ra[c]; mi[c] = ma[c]; vi[c] = va[c];
+        if (q.am[0]) na[c] = adam_apply(ra[c], gsum, ma[c], va[c], q, mi[c], vi[c]);
+        const float a1 = fminf(fmaxf(na[c], 0.0f), 1.0f);
+        reg[0] += fabsf(a1 - a0[c]);
+        rgb[c] = fmaf(a1, x.G[c], x.H[c]);
+        tot += rgb[c];
+    }
+    if (q.d_a) st3(q.d_a, o3, gs[0], gs[1], gs[2]);
+    if (improved && q.best_a) st3(q.best_a, o3, ac[0], ac[1], ac[2]);
+    if (improved && q.best_img) st3(q.best_img, o3, xs_keep[0], xs_keep[1], xs_keep[2]);
+    if (q.am[0]) {
+        st3(q.am[0], o3, mi[0], mi[1], mi[2]);
+        st3(q.av[0], o3, vi[0], vi[1], vi[2]);
+        st3(sp.pa, o3, na[0], na[1], na[2]);
+    }
+    st3(sp.pred_next, o3, rgb[0], rgb[1], rgb[2]);
+    return false;
+}
+
+template <int MODE> struct PStepPx;
+template <> struct PStepPx<kFoldXY> { typedef PxXY type; };
+template <> struct PStepPx<kFoldGH> { typedef PxGH type; };
+
+constexpr int kPstepListCap = kMaxTilesPerWg * 64;     // entries of a wave's list: every pixel it owns in the workgroup's tiles
+constexpr int kPstepMaxBlocks = kMaxTilesPerWg / 2;
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
+    typedef typename PStepPx<MODE>::type Px;
+    __shared__ float s_state[kStateStride];
+    __shared__ float s_fold[4][6];
+    __shared__ float s_bsum[kPstepMaxBlocks][4];
+    __shared__ float s_breg[kPstepMaxBlocks][4][3];
+    __shared__ int s_cnt[4];
+    __shared__ uint16_t s_list[MODE == kFoldXY ? 4 : 1][MODE == kFoldXY ? kPstepListCap : 1];
+    __shared__ float s_res[MODE == kFoldXY ? kMaxTilesPerWg * kTile : 1];
+    __shared__ __attribute__((aligned(16))) float s_light[kNL + 1];
+    __shared__ float4 s_ring[kMaxRings];
+    __shared__ float2 s_saz[kMaxRings * kMaxAz];
+    const JacBwdArgs& q = qs.j;
+    const int b = blockIdx.y;
+    const int P = g.H * g.W;
+    const int nblk_img = lazy_fwd_blocks(P);
+    // this workgroup's blocks: blockIdx.x, blockIdx.x + gridDim.x, ... (>= 1 by the launch geometry).  Interleaved, not consecutive: the
+    // workgroups that run side by side stream neighbouring blocks, and the pixels that leave their intervals together (a neighbourhood of
+    // the image) are spread over many workgroups' lists
+    const int nb = (nblk_img - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int ntile = 2 * nb;
+    auto tile_px0 = [&](int t) -> int { return ((int)blockIdx.x + (t >> 1) * (int)gridDim.x) * kLazyBlockPixels + (t & 1) * kTile; };
+    const float* old = qs.state_old + b * kStateStride;
+    if (old[kStStopped] > 0.5f) {                          // EarlyStopping fired in an earlier iteration (uniform): nothing to do
+        if (blockIdx.x == 0 && threadIdx.x < kStateStride) {
+            float v = old[threadIdx.x];
+            if (threadIdx.x == kStStopped) v = 2.0f;
+            if (threadIdx.x == kStImproved) v = 0.0f;
+            qs.state_new[b * kStateStride + threadIdx.x] = v;
+            if (threadIdx.x < kStatsStride) qs.stats_out[b * kStatsStride + threadIdx.x] = v;
+        }
+        return;
+    }
+    PStepFlags f;
+    f.part_r = (q.part_mask & MATPBR_PART_R) != 0;
+    f.part_m = (q.part_mask & MATPBR_PART_M) != 0;
+    f.slopes = f.part_r || q.d_r != nullptr;
+    f.att = qs.attached != 0;
+    // where this image's iteration reads its parameters and writes the new ones: MATPBR_FLAG_ROTATE_BEST keeps them in two buffers each and
+    // the OLD state row says which holds the current values (the new selector is known after the commit below: the writes wait for it)
+    const float sel_old = old[kStSel];
+    StepPtrs sp{q.a, q.r, q.m, q.pa, q.pr, q.pm, qs.pred_next};
+    if (qs.rotate) {
+        const bool rd1 = __builtin_amdgcn_readfirstlane((int)(sel_old > 0.5f)) != 0;
+        if (qs.alt_a) sp.a = rd1 ? qs.alt_a : q.pa;
+        if (qs.alt_r) sp.r = rd1 ? qs.alt_r : q.pr;
+        if (qs.alt_m) sp.m = rd1 ? qs.alt_m : q.pm;
+    }
+    // ---- the first two tiles are requested before anything else: their latency runs under the fold of the statistics
+    auto pix = [&](int t) -> int { const int p = tile_px0(t) + (int)threadIdx.x; return p < P ? p : P - 1; };
+    Px A, B;
+    pstep_load(A, qs, sp, (unsigned)(b * P + pix(0)), f);
+    pstep_load(B, qs, sp, (unsigned)(b * P + pix(1)), f);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the iteration's statistics: every workgroup folds the rows of partial sums of its image (fixed order: the same bits everywhere),
+    // forms the scalars from the OLD SaveBest / EarlyStopping state; workgroup 0 of the image writes the NEW state and the caller's row
+    float ratio, sr;
+    bool improved;
+    {
+        const float* rows = qs.fold_part + (long)b * step_part_stride(qs.fold_rows);
+        float v[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = threadIdx.x; i < qs.fold_rows; i += kBlock) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] += rows[(long)i * 5 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float w = wave_sum_to_lane63(v[k]);
+            if ((threadIdx.x & 63) == 63) s_fold[threadIdx.x >> 6][k] = w;
+        }
+        float st[kStatsStride];
+        const float sp_total = rows[(long)qs.fold_rows * 5];
+        float bratio = -1.0f;
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < kStatsStride; ++i) st[i] = old[i];
+            bratio = old[kStBestRatio];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) t[k] = (s_fold[0][k] + s_fold[1][k]) + (s_fold[2][k] + s_fold[3][k]);
+            st[kStRatio] = st[kStGtSum] / sp_total;
+            const float mse = t[0] * q.inv_n3, l1 = t[1] * q.inv_n3;
+            if (qs.reg_from_part) { t[2] = rows[(long)qs.fold_rows * 5 + 1]; t[3] = rows[(long)qs.fold_rows * 5 + 2]; t[4] = rows[(long)qs.fold_rows * 5 + 3]; }
+            const float la = (q.part_mask & MATPBR_PART_A) ? t[2] * q.inv_n3 : 0.0f;
+            const float lr = (q.part_mask & MATPBR_PART_R) ? t[3] * q.inv_n1 : 0.0f;
+            const float lm = (q.part_mask & MATPBR_PART_M) ? t[4] * q.inv_n1 : 0.0f;
+            stats_commit(st, mse, l1, l1 / mse /* scale_raito, :411 */, la, lr, lm, q.scale_delta, qs.es_patience, qs.es_min_delta,
+                         blockIdx.x == 0 ? qs.history : nullptr, qs.hist_len, qs.batch, b);
+#pragma unroll
+            for (int i = 0; i < kStatsStride; ++i) s_state[i] = st[i];
+            const bool imp = st[kStImproved] > 0.5f && qs.rotate != 0;
+            s_state[kStSel] = imp ? 1.0f - sel_old : sel_old;          // the buffer the new values go to: the other one after an improvement
+            s_state[kStBestRatio] = imp ? st[kStRatio] : bratio;
+            s_state[kStSelOld] = sel_old;
+            s_state[kStSelOld + 1] = 0.0f;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < kStateStride) {
+            qs.state_new[b * kStateStride + threadIdx.x] = s_state[threadIdx.x];
+            if (threadIdx.x < kStatsStride) qs.stats_out[b * kStatsStride + threadIdx.x] = s_state[threadIdx.x];
+        }
+        ratio = s_state[kStRatio];
+        sr = s_state[kStSr];
+        improved = s_state[kStImproved] > 0.5f;
+    }
+    const float gt_sum = s_state[kStGtSum];
+    if (qs.rotate) {                                           // uniform per image: scalar selects of the base pointers
+        const bool wr1 = __builtin_amdgcn_readfirstlane((int)(s_state[kStSel] > 0.5f)) != 0;
+        if (qs.alt_a) sp.pa = wr1 ? qs.alt_a : q.pa;
+        if (qs.alt_r) sp.pr = wr1 ? qs.alt_r : q.pr;
+        if (qs.alt_m) sp.pm = wr1 ? qs.alt_m : q.pm;
+        sp.pred_next = qs.pred_buf[wr1 ? 1 : 0];
+    }
+    // ---- the tiles: set A holds the even ones, set B the odd ones; a set is requested again as soon as its tile is done
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int cntw = 0;                                              // entries of this wave's list (uniform)
+    for (int t = 0; t < ntile; t += 2) {
+        float tot = 0.0f, reg[3] = {0.0f, 0.0f, 0.0f};
+        bool need0 = false, need1 = false;
+        const int p0 = tile_px0(t) + (int)threadIdx.x, p1 = p0 + kTile;
+        if (p0 < P) need0 = pstep_pixel(A, qs, sp, (unsigned)(b * P + p0), f, ratio, sr, improved, tot, reg);
+        if (t + 2 < ntile) pstep_load(A, qs, sp, (unsigned)(b * P + pix(t + 2)), f);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p1 < P) need1 = pstep_pixel(B, qs, sp, (unsigned)(b * P + p1), f, ratio, sr, improved, tot, reg);
+        if (t + 3 < ntile) pstep_load(B, qs, sp, (unsigned)(b * P + pix(t + 3)), f);
+        __builtin_amdgcn_sched_barrier(0);
+        // the block's sums: DPP tree per wave here, the four waves in order at the end (fixed order)
+        const int bl = t >> 1;
+        const float w = wave_sum_to_lane63(tot);
+        if (lane == 63) s_bsum[bl][wave] = w;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float wr = wave_sum_to_lane63(reg[k]);
+            if (lane == 63) s_breg[bl][wave][k] = wr;
+        }
+        if (MODE == kFoldXY) {                                 // listed pixels, in a fixed order: tile, then lane
+            const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
+            const int n0 = __popcll(b0);
+            if (need0) s_list[wave][cntw + __popcll(b0 & below)] = (uint16_t)(t * kTile + (int)threadIdx.x);
+            if (need1) s_list[wave][cntw + n0 + __popcll(b1 & below)] = (uint16_t)((t + 1) * kTile + (int)threadIdx.x);
+            cntw += n0 + __popcll(b1);
+        }
+    }
+    if (lane == 0) s_cnt[wave] = cntw;
+    __syncthreads();
+    const int c0 = s_cnt[0], c1 = c0 + s_cnt[1], c2 = c1 + s_cnt[2], T = c2 + s_cnt[3];
+    if (MODE == kFoldXY && T > 0) {
+        // ---- the pixels whose new roughness has left their model's interval: eight lanes per pixel, 32 pixels per pass (uniform branch)
+        if (threadIdx.x < kNL) s_light[threadIdx.x] = light[(long)b * kNL + threadIdx.x] * kShNorm[threadIdx.x / 3];
+        if (threadIdx.x < kMaxRings * kMaxAz) s_saz[threadIdx.x] = (&tab.saz[0][0])[threadIdx.x];
+        if (threadIdx.x < kMaxRings) s_ring[threadIdx.x] = tab.sring[threadIdx.x];
+        __syncthreads();
+        const float floor_ = 0.5f * gt_sum / (3.0f * (float)P) / (ratio > 0.0f ? ratio : 1.0f);
+        const float tol_k = qs.tol * kLzTolK, tol_s = qs.tol * kLzTolS;
+        const long BPl = (long)gridDim.y * P;
+        const StepPtrs spw{sp.a, sp.pr, sp.pm, sp.pa, sp.pr, sp.pm, sp.pred_next};     // the parameters as this launch has WRITTEN them
+        const int sub = threadIdx.x & 7;
+        for (int base = 0; base < T; base += kBlock / 8) {
+            if (base + 8 * wave >= T) break;                   // a wave without items leaves (uniform per wave; the walk shuffles within groups of 8 lanes)
+            const int k = base + ((int)threadIdx.x >> 3);
+            const bool ok = k < T;
+            const int kk = ok ? k : T - 1;
+            const int w = kk < c0 ? 0 : (kk < c1 ? 1 : (kk < c2 ? 2 : 3));
+            const int id = (int)s_list[w][kk - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)))];
+            float rs = 0.0f;
+#ifndef MATPBR_EXP_NOWALK   // measurement only: the streaming part's registers and duration without the walk's code
+            resample_walk_pixel<true>(qs, spw, s_light, s_ring, s_saz, g, tab, b, P, BPl, tile_px0(id >> 8) + (id & (kTile - 1)), ok, sub, floor_, tol_k, tol_s, rs);
+#endif
+            if (ok && sub == 0) s_res[k] = rs;
+        }
+        __syncthreads();
+    }
+    // ---- per-block results: the sum of the render (streamed pixels by wave, then the re-sampled ones in list order), the regulariser sums,
+    // and the lists in the layout matpbr_lazy_state_unpack reads (inspection)
+    if ((int)threadIdx.x < nb) {
+        const int bl = threadIdx.x;
+        float s = (s_bsum[bl][0] + s_bsum[bl][1]) + (s_bsum[bl][2] + s_bsum[bl][3]);
+        int cnt = 0;
+        if (MODE == kFoldXY) {
+            uint16_t* list = qs.lists ? qs.lists + ((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * kLazyBlockPixels : nullptr;
+            for (int k = 0; k < T; ++k) {
+                const int w = k < c0 ? 0 : (k < c1 ? 1 : (k < c2 ? 2 : 3));
+                const int id = (int)s_list[w][k - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)))];
+                if ((id >> 9) == bl) {
+                    s += s_res[k];
+                    if (list) list[cnt] = (uint16_t)(id & (kLazyBlockPixels - 1));
+                    ++cnt;
+                }
+            }
+        }
+        if (qs.counts) qs.counts[(long)b * nblk_img + blockIdx.x + bl * gridDim.x] = (uint32_t)cnt;
+        qs.block_sums[(long)b * qs.n_sums + blockIdx.x + bl * gridDim.x] = s;
+    }
+    if (qs.reg_sums && (int)threadIdx.x < 3 * nb) {
+        const int bl = threadIdx.x / 3, k = threadIdx.x - 3 * bl;
+        qs.reg_sums[((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * 3 + k] = (s_breg[bl][0][k] + s_breg[bl][1][k]) + (s_breg[bl][2][k] + s_breg[bl][3][k]);
+    }
+}
+
+}  // namespace matpbr

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(kBlock, 2) void shade_kernel(const ShadeArgs q, con
     const int P = g.H * g.W;
     const long BP = (long)gridDim.y * P;
     const int q0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
-    if (!q.block_sums && q0 >= P) return;
+    // (no early exit of the lanes beyond the image: the sample loop reads the rule table out of EVERY lane's registers, and hipcc is free to
+    // sink their loads below a divergent return -- the lanes that left would then never have loaded their entries)
     const bool act0 = q0 < P, two = q0 + 1 < P;
     const int p0 = act0 ? q0 : P - 1, p1 = two ? q0 + 1 : p0;
     const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
@@ -636,10 +637,9 @@ __global__ __launch_bounds__(kBlock, 2) void diffuse_cache_kernel(const float* _
     const int b = blockIdx.y;
     const int P = g.H * g.W;
     const long BP = (long)gridDim.y * P;
-    const int p0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
-    if (p0 >= P) return;
-    const bool two = p0 + 1 < P;
-    const int p1 = two ? p0 + 1 : p0;
+    const int q0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
+    const bool act0 = q0 < P, two = q0 + 1 < P;            // lanes beyond the image stay (shade_kernel: the rule table lives in every lane)
+    const int p0 = act0 ? q0 : P - 1, p1 = two ? q0 + 1 : p0;
     const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
     // materials do not enter the coefficients: load the normal only
     Pixel px;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(kBlock, 2) void diffuse_cache_kernel(const float* _
     diffuse_coef(px, lr, tab, rr, A);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        dcache[c * BP + i0] = A.A0[c].x; dcache[(3 + c) * BP + i0] = A.A1[c].x; dcache[(6 + c) * BP + i0] = A.A2[c].x;
+        if (act0) { dcache[c * BP + i0] = A.A0[c].x; dcache[(3 + c) * BP + i0] = A.A1[c].x; dcache[(6 + c) * BP + i0] = A.A2[c].x; }
         if (two) { dcache[c * BP + i1] = A.A0[c].y; dcache[(3 + c) * BP + i1] = A.A1[c].y; dcache[(6 + c) * BP + i1] = A.A2[c].y; }
     }
 }
@@ -1013,10 +1013,9 @@ __global__ __launch_bounds__(kBlock, 2) void shade_transfer_kernel(const float* 
     load_rule_regs(tab, rr);
     const int b = blockIdx.y;
     const int P = g.H * g.W;
-    const int p0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
-    if (p0 >= P) return;
-    const bool two = p0 + 1 < P;
-    const int p1 = two ? p0 + 1 : p0;
+    const int q0 = 2 * (blockIdx.x * kBlock + threadIdx.x);
+    const bool act0 = q0 < P, two = q0 + 1 < P;            // lanes beyond the image stay (shade_kernel: the rule table lives in every lane)
+    const int p0 = act0 ? q0 : P - 1, p1 = two ? q0 + 1 : p0;
     const long i0 = (long)b * P + p0, i1 = (long)b * P + p1;
     Pixel px;
     load_pixel(px, a, r, m, n, i0, i1, p0, p1, g, false);
@@ -1034,7 +1033,7 @@ __global__ __launch_bounds__(kBlock, 2) void shade_transfer_kernel(const float* 
         for (int c = 0; c < 3; ++c) {
             f2 v = acc[k * 3 + c] * sc;
             const int j = (K0 + k) * 3 + c;
-            T[transfer_index(b, p0, j, P)] = v.x;
+            if (act0) T[transfer_index(b, p0, j, P)] = v.x;
             if (two) T[transfer_index(b, p1, j, P)] = v.y;
         }
     }

@@ -239,18 +239,22 @@ class FusedBrdfPhase:
     PARTS = {"a": 2, "r": 4, "m": 8}
     LAZY = True
     ROTATE_BEST = True      # SaveBest without copies in the lazy loop (MATPBR_FLAG_ROTATE_BEST); False: the copying step
+    FOLD = True             # the folded, persistent step where the part has one (MatpbrBrdfPhase.lazy_fold); False: the generic step
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
                  min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
                  originals: Optional[Dict[str, torch.Tensor]] = None, keep_grads: bool = False, lazy: Optional[bool] = None,
-                 lazy_tol: float = 1.0, attached_sampling: bool = False, rotate_best: Optional[bool] = None):
+                 lazy_tol: float = 1.0, attached_sampling: bool = False, rotate_best: Optional[bool] = None, fold: Optional[bool] = None):
         """`lazy` (default `FusedBrdfPhase.LAZY`): in parts that move the roughness, render from per-pixel local models in r and walk
         the GGX samples only of the pixels that left their model's validity interval (include/matpbr.h `matpbr_shade_fwd_lazy`).
         `attached_sampling` (lazy parts only): the roughness gradient through the GGX sample directions, the live reference's convention
         (mi_plugin.py:227-230,1335-1341), instead of the stop-gradient default.
         `rotate_best` (default: with `lazy`): SaveBest without copies -- MATPBR_FLAG_ROTATE_BEST, include/matpbr.h; False: the step
-        kernel copies the snapshot in every improving iteration (the same values, bit for bit)."""
+        kernel copies the snapshot in every improving iteration (the same values, bit for bit).
+        `fold` (default `FusedBrdfPhase.FOLD`, lazy parts only): parts of r / m and part 'a' run the folded, persistent step
+        (csrc/matpbr_pstep.hpp: the maps the part leaves alone are folded into the per-pixel models; two launches per iteration, the listed
+        pixels walked inside the step launch); with `keep_grads` it forms the gradients of the maps the part moves only."""
         import ctypes
 
         from . import _lib, ops
@@ -295,8 +299,19 @@ class FusedBrdfPhase:
         ph.n, ph.light, ph.gt_srgb = P(self.n), P(self.light), P(self.gt_srgb)
         ph.a0, ph.r0, ph.m0 = P(self.orig["albedo"]), P(self.orig["roughness"]), P(self.orig["metallic"])
         ph.dcache, ph.pred, ph.jac = P(self.dcache), P(self._pred), P(self.jac)
+        self.lazy = bool(self.LAZY if lazy is None else lazy)
+        # the folded step has the gradients of the maps its part moves; a caller that wants all three keeps the generic step
+        self.fold = self.lazy and bool(self.FOLD if fold is None else fold) and optimize_part in ("r", "m", "rm", "mr", "a")
         if self.g is not None:
-            ph.d_a, ph.d_r, ph.d_m = P(self.g["albedo"]), P(self.g["roughness"]), P(self.g["metallic"])
+            if self.fold:
+                for k in self.g:
+                    self.g[k].zero_()
+                if "a" in optimize_part:
+                    ph.d_a = P(self.g["albedo"])
+                else:
+                    ph.d_r, ph.d_m = P(self.g["roughness"]), P(self.g["metallic"])
+            else:
+                ph.d_a, ph.d_r, ph.d_m = P(self.g["albedo"]), P(self.g["roughness"]), P(self.g["metallic"])
         for i, k in enumerate(("albedo", "roughness", "metallic")):
             ph.adam_m[i], ph.adam_v[i] = self.m[k].data_ptr(), self.v[k].data_ptr()
         ph.best_a, ph.best_r, ph.best_m, ph.best_img = P(self._best["albedo"]), P(self._best["roughness"]), P(self._best["metallic"]), P(self._best_img)
@@ -309,15 +324,16 @@ class FusedBrdfPhase:
         # parts that leave the roughness alone: the specular sums of every pixel are constants of the part (kept from its first render)
         # lazy (default): every part renders from the per-pixel models -- in a part that leaves the roughness alone no pixel ever leaves its
         # model's interval, so its iteration is the same two launches with no re-sampling at all
-        self.lazy = bool(self.LAZY if lazy is None else lazy)
         self.s1cache = None if ("r" in optimize_part or self.lazy) else torch.empty((3,) + tuple(self.jac.shape[1:]), dtype=torch.float32, device=self.jac.device)
         ph.s1cache = P(self.s1cache) if self.s1cache is not None else None
         self.lazy_state = ops.lazy_state(self._p["albedo"]) if self.lazy else None
         ph.lazy_state = P(self.lazy_state) if self.lazy else None
         ph.lazy_tol = float(lazy_tol)
+        self.lazy_fold = ops.lazy_fold(self._p["albedo"]) if self.fold else None
+        ph.lazy_fold = P(self.lazy_fold) if self.fold else None
         if attached_sampling and not self.lazy:
             raise ValueError("attached_sampling needs the lazy path")
-        ph.flags = ops.FLAG_ATTACHED_SAMPLING if attached_sampling else 0
+        ph.flags = (ops.FLAG_ATTACHED_SAMPLING if attached_sampling else 0) | (0 if self.fold else ops.FLAG_GENERIC_STEP)
         # pixels without geometry (Scene.set_mesh_mask): build what the first step would build, give those pixels constant models
         # (they render the environment along their camera ray and receive no material gradient), and tell the steps so
         self.bg_mask = scene.bg_mask

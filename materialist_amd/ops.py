@@ -19,6 +19,7 @@ FLAG_LAZY_FORCE = 16
 FLAG_JAC16 = 32
 FLAG_MODELS_READY = 64
 FLAG_ROTATE_BEST = 128
+FLAG_GENERIC_STEP = 256
 LAZY_NSTATE = 22
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
@@ -169,6 +170,12 @@ def shade_fwd(a, r, m, n, light, spp: int, fov_x_deg: float = 35.0, clamp_params
                                            H, W, B, check_spp(spp), ctypes.byref(cam), FLAG_CLAMP_PARAMS if clamp_params else 0, _stream(a))
     _lib.check(code, "matpbr_shade_fwd_ex")
     return out
+
+
+def lazy_fold(a: torch.Tensor) -> torch.Tensor:
+    """Room for a part's folded per-pixel models (`MatpbrBrdfPhase.lazy_fold`, include/matpbr.h), for maps shaped like `a` [B,]H,W,3."""
+    B, H, W = _bhw(a)
+    return torch.empty(int(_lib.load().matpbr_lazy_fold_bytes(H, W, B)), dtype=torch.uint8, device=a.device)
 
 
 def lazy_state(a: torch.Tensor) -> torch.Tensor:

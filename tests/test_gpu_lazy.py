@@ -272,6 +272,68 @@ def test_fixed_roughness_parts_run_on_the_models_without_ever_resampling():
         assert int(refreshed.sum()) == 0                       # nothing was re-sampled in the last launch (nor in any after the first)
 
 
+@pytest.mark.parametrize("part", ["rm", "r", "m", "a"])
+def test_folded_persistent_step_is_the_generic_step(part):
+    """The folded, persistent step (csrc/matpbr_pstep.hpp: the maps a part leaves alone folded into the per-pixel models, listed pixels
+    walked inside the step launch) against the generic step + resampling launch on the same part: the same loss curve, the same pixels
+    re-sampled (up to the few whose roughness sits on an interval's edge), parameters, SaveBest's maps and image within the rounding of the two
+    expressions pushed through 150 Adam steps.  An image size that is not a multiple of the 512-pixel block exercises the ragged tail."""
+    from materialist_amd import loop, ops
+
+    dev = _cuda()
+    H, W, spp, iters = 96, 131, 64, 150
+    scene, gt, init = _phase_setup(dev, H, W, spp, image_id=3)
+    kw = dict(optimize_part=part, spp=spp, history_len=iters, patience=50, min_delta=1e-3)
+    fo = loop.FusedBrdfPhase(scene, gt, *init, fold=True, **kw)
+    ge = loop.FusedBrdfPhase(scene, gt, *init, fold=False, **kw)
+    assert fo.fold and not ge.fold
+    n_f = n_g = 0
+    for it in range(iters):
+        fo.step()
+        ge.step()
+        _, rf = ops.lazy_state_unpack(fo.lazy_state, fo.p["albedo"])
+        _, rg = ops.lazy_state_unpack(ge.lazy_state, ge.p["albedo"])
+        n_f, n_g = n_f + int(rf.sum()), n_g + int(rg.sum())
+        if it in (0, 1, 10, iters - 1):      # the render of the current parameters (what the next iteration judges); Adam normalises the
+            # gradient, so where it is nearly zero rounding decides a step's sign and single pixels part ways over 150 steps
+            worst = (fo.pred - ge.pred).abs() / ge.pred.abs().mean()
+            assert float(worst.max()) < {0: 2e-6, 1: 2e-4, 10: 1e-3}.get(it, 3e-2) and float(worst.mean()) < 2e-4, (it, float(worst.max()), float(worst.mean()))
+    h_f, h_g = fo.history()[:, 0].cpu().numpy(), ge.history()[:, 0].cpu().numpy()
+    assert np.abs(h_f - h_g).max() <= 5e-4 * h_g.max()
+    assert abs(n_f - n_g) <= 0.01 * n_g + 2 and (n_g > 0) == ("r" in part)
+    for src_f, src_g in ((fo.p, ge.p), (fo.best, ge.best)):
+        for k in ("albedo", "roughness", "metallic"):
+            d = (src_f[k] - src_g[k]).abs()
+            assert float(d.mean()) < 1e-4 and float((d < 5e-4).float().mean()) > 0.98, (part, k, float(d.mean()), float(d.max()))
+    assert float((fo.best_img - ge.best_img).abs().max()) < 5e-3
+    assert torch.allclose(fo.stats, ge.stats, rtol=2e-3, atol=1e-6)
+    # maps the part does not move are left alone, bit for bit
+    for k, ch in (("albedo", "a"), ("roughness", "r"), ("metallic", "m")):
+        if ch not in part:
+            assert torch.equal(fo.p[k], init[{"albedo": 0, "roughness": 1, "metallic": 2}[k]].reshape(fo.p[k].shape)), k
+
+
+def test_folded_step_gradients_are_the_generic_steps():
+    """`keep_grads`: the folded step forms the gradients of the maps its part moves; = the generic step's at the same parameters (the first
+    iteration of a phase: both start from the same models)."""
+    from materialist_amd import loop
+
+    dev = _cuda()
+    H, W, spp = 128, 128, 64
+    scene, gt, init = _phase_setup(dev, H, W, spp, image_id=5)
+    for part, keys in (("rm", ("roughness", "metallic")), ("a", ("albedo",))):
+        g = {}
+        for fold in (True, False):
+            ph = loop.FusedBrdfPhase(scene, gt, *init, optimize_part=part, spp=spp, keep_grads=True, fold=fold)
+            assert ph.fold == fold
+            ph.step()
+            g[fold] = {k: ph.g[k].clone() for k in keys}
+        for k in keys:
+            e = (g[True][k] - g[False][k]).abs() / torch.maximum(g[False][k].abs(), g[False][k].abs().mean())
+            # d out / d r travels in half precision in both forms (generic: dSD, dS1 each; folded: their combinations JX0, JY0)
+            assert float(e.max()) < (2e-3 if k == "roughness" else 2e-4), (part, k, float(e.max()))
+
+
 def test_lazy_phase_early_stopping_and_batch():
     """The device-side EarlyStopping and the per-image skip work the same on the lazy path; a batched lazy phase equals its images
     run alone, bit for bit."""

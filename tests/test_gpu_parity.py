@@ -1460,6 +1460,30 @@ def test_transfer_relight_equals_direct_render():
         np.testing.assert_allclose(rot, lights[shift], atol=1e-10)
 
 
+@pytest.mark.parametrize("hw", [(96, 131), (33, 47), (5, 7)])
+def test_image_sizes_that_leave_the_last_wave_partly_empty(hw):
+    """Image sizes whose pixel count is not a multiple of 128 (two pixels per lane, 64 lanes): the kernels that read the quadrature table
+    out of every lane's registers (diffuse cache, cached-diffuse render, radiance transfer) must keep the lanes beyond the image alive --
+    with a divergent early exit their table entries were never loaded and the last pixels of the image came out NaN (round 4 finding)."""
+    from materialist_amd import ops, synthetic
+
+    dev = _cuda()
+    H, W = hw
+    spp = 64
+    sc, n = _scene_arrays(H, W, image_id=12)
+    a, r, m, nn, light = (_t(x, dev) for x in (sc.albedo, sc.roughness, sc.metallic, n, sc.light))
+    direct = ops.shade_fwd(a, r, m, nn, light, spp)
+    dcache = ops.diffuse_cache(nn, light, spp)
+    assert bool(torch.isfinite(dcache).all())
+    jac = ops.plane9(a)
+    cached = ops.shade_fwd(a, r, m, nn, light, spp, dcache=dcache, jac=jac)
+    assert bool(torch.isfinite(jac).all())
+    assert (cached - direct).abs().max().item() <= 2e-5 * direct.abs().max().item()
+    T = ops.shade_transfer(a, r, m, nn, spp)
+    out = ops.relight(T, light.reshape(1, 25, 3).contiguous(), H, W)
+    assert (out[0] - direct).abs().max().item() <= 2e-5 * direct.abs().max().item()
+
+
 def test_materialnet_runs_on_the_gpu(tmp_path):
     """f3 on PyTorch-ROCm: random-weight MaterialNet through the pipeline's initial-guess path (SDPA attention on the GPU)."""
     from PIL import Image
