@@ -304,7 +304,9 @@ int matpbr_select_improved(float* dst, const float* src, const float* stats, int
  *   backward (gate != NULL): out[i] = mask[i] ? (lo <= gate[i] <= hi ? mean over the mask of in[j] : 0) : in[i], with in = d loss / d out of
  *                            the forward and gate = the forward's input: the gradient of every masked entry is the mean of the masked
  *                            gradients, through the clamp of its own input.
- * mask: one byte per pixel (0 / non-zero).  A mask without pixels leaves the map as it is. */
+ * mask: one byte per pixel (0 / non-zero).  A mask without pixels leaves the map as it is.  Entries outside the mask are copied RAW in both
+ * forms (lo / hi apply to the masked entries only: the consumers clamp again, as the reference's loop does, :372-381); out == in is supported
+ * in both forms. */
 int matpbr_masked_mean_fill(const float* in, const unsigned char* mask, const float* gate, float lo, float hi, float* out, long n, int batch,
                             void* stream);
 int matpbr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,

@@ -114,7 +114,7 @@ class ArmMlpPhase:
         self.adam_m, self.adam_v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)       # a fresh AdamW per part (:470)
         self.hyper = torch.tensor([float(lr), 0.0], dtype=torch.float32, device=dev)
         self.weight_decay = float(weight_decay)
-        self._lr, self._sched_epoch = float(lr), 0
+        self._lr, self._sched_epoch, self.base_lr = float(lr), 0, float(lr)
         self.opt = types.SimpleNamespace(param_groups=[{"lr": float(lr)}])                        # what the callers read back
         self.gviews, off = [], 0
         for wp, bp in self.views:
@@ -183,8 +183,10 @@ class ArmMlpPhase:
         self.s1 = None if "roughness" in self.live else torch.empty((3, 1, H, W), dtype=torch.float32, device=dev)
         self._bg_mask = scene.bg_mask
         if self._bg_mask is not None:
-            self._bg_flat = self._bg_mask.reshape(-1)
             self._bg_rgb = (scene.bg_basis @ self._light.reshape(25, 3)).contiguous()
+            self._bg_idx = ops.background_index(self._bg_mask)          # once: boolean-mask indexing would synchronise with the host every iteration
+            self._bg_rows = self._bg_rgb.reshape(-1, 3)[self._bg_idx].contiguous()
+            self._bg_rows_t = self._bg_rows.t().contiguous()
         # --use_mask (:509-511): inside the mask roughness and metallic are their masked means (of the clamped maps); the render, the loss and
         # the snapshots see the filled maps, the network receives the mean of the masked gradients through each entry's own clamp
         self._mask_u8 = None if mask is None else mask.to(dev).reshape(H, W).to(torch.uint8).contiguous()
@@ -275,8 +277,8 @@ class ArmMlpPhase:
                         dcache=self.dcache, jac=self.jac, s1=self.s1)
         if self._bg_mask is not None and not (self.s1 is not None and self.t > 0):
             # pixels without geometry: the environment along the camera ray, no material gradient (after the kernels have written these buffers)
-            self.pred.view(-1, 3)[self._bg_flat] = self._bg_rgb[self._bg_flat]
-            o.background_into_jac(self.jac, self.s1, self._bg_mask, self._bg_rgb)
+            self.pred.view(-1, 3).index_copy_(0, self._bg_idx, self._bg_rows)
+            o.background_into_jac(self.jac, self.s1, self._bg_mask, self._bg_rgb, self._bg_idx, self._bg_rows_t)
         o.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
                           self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part,
                           es_patience=self.patience, es_min_delta=self.min_delta, history=self.hist)
@@ -336,6 +338,14 @@ class ArmMlpPhase:
     @property
     def iterations_run(self) -> int:
         return int(self.stats[0, ops.STAT_ITERS])
+
+    def lr_at(self, t0: int) -> float:
+        """Learning rate of the iteration with 0-based index t0: StepLR(100, 0.8) stepped only while lr > 1.5e-4 (:471,553-554)."""
+        lr, k = self.base_lr, 0
+        while lr > 1.5e-4 and (k + 1) * 100 <= t0:
+            lr *= 0.8
+            k += 1
+        return lr
 
     def history(self) -> torch.Tensor:
         return self.hist[: self.t]

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
                                                             const float* __restrict__ m0, float* __restrict__ part, long n3, long n1,
                                                             const float* __restrict__ fwd_sums, int n_fwd, unsigned part_mask,
                                                             const float* __restrict__ reg_sums = nullptr, const float* __restrict__ pred_alt = nullptr,
-                                                            const float* __restrict__ state = nullptr, int n_reg = 0) {
+                                                            const float* __restrict__ state = nullptr, int n_reg = 0,
+                                                            const long long* __restrict__ walk_fix = nullptr) {
     __shared__ float s_buf[4];
     const int b = blockIdx.y;
     float ratio = 1.0f;
@@ -137,7 +138,9 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
     float sp_total = 0.0f;
     if (MODE == 1 || MODE >= 3) {
         float sp = 0.0f;
-        for (int i = threadIdx.x; i < n_fwd; i += kBlock) sp += fwd_sums[(long)b * n_fwd + i];
+        // (walk_fix: the folded step's re-sampled pixels, summed per block in fixed point by lazy_pwalk_kernel -- one slot per forward sum)
+        for (int i = threadIdx.x; i < n_fwd; i += kBlock)
+            sp += fwd_sums[(long)b * n_fwd + i] + (MODE == 4 && walk_fix ? (float)((double)walk_fix[(long)b * n_fwd + i] * (1.0 / kWalkFix)) : 0.0f);
         sp_total = block_sum(sp, s_buf);
         ratio = stats[b * kStatsStride + kStGtSum] / sp_total;
     } else if (MODE == 0) {
@@ -1295,7 +1298,10 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     // forward sums per image: t > 1 of the fused step: its workgroups' and the resampling launch's
     const bool resample = lazy_fused && fold == kFoldNone && ((q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr);   // otherwise no pixel ever leaves its model's interval (folded step: walked in-kernel)
     const int nres = grid_blocks(q.H, q.W) < kResampleWaves ? grid_blocks(q.H, q.W) : kResampleWaves;   // waves of the resampling launch per image
-    const int nfwd = grid_blocks(q.H, q.W) + (fold != kFoldNone ? 0 : ((lazy_fused && t > 1) ? (resample ? nres : 0) : (lazy ? lazy_groups((long)q.H * q.W) : 0)));
+    // the folded step walks the pixels it lists in a launch of two waves per block (lazy_pwalk_kernel), which adds to the blocks' sums
+    const bool pwalk = fold == kFoldXY && ((q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr);
+    const int nfwd = fold != kFoldNone ? grid_blocks(q.H, q.W)
+                                       : grid_blocks(q.H, q.W) + ((lazy_fused && t > 1) ? (resample ? nres : 0) : (lazy ? lazy_groups((long)q.H * q.W) : 0));
     float* fwd_sums = (float*)q.workspace;
     float* part = fwd_sums + (size_t)q.batch * nfwd;
     const long n1 = (long)q.H * q.W, n3 = n1 * 3;
@@ -1323,6 +1329,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             const LazyBuffers lb = lazy_buffers(q.lazy_state, n1, q.batch);
             LazyFoldArgs fa{};
             fa.a = q.pa; fa.r = q.pr; fa.m = q.pm; fa.out = q.pred; fa.block_sums = fwd_sums; fa.stats = q.stats;
+            fa.walk_cnt = (uint32_t*)((char*)q.lazy_fold + lazy_fold_planes_bytes(n1, q.batch) + (size_t)q.batch * lb.nblk * sizeof(long long));
             for (int k = 0; k < kLzPlanes; ++k) fa.plane[k] = lb.planes + (size_t)k * (size_t)q.batch * (size_t)n1;
             for (int k = 0; k < kFxPlanes; ++k) fa.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
             if (fold == kFoldXY) hipLaunchKernelGGL(lazy_fold_kernel<kFoldXY>, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, fa, (int)n1);
@@ -1346,7 +1353,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             hipLaunchKernelGGL(loss_sums2_kernel<4>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                                (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
                                (const float*)fwd_sums, nfwd, q.part_mask, (const float*)reg_sums, (const float*)q.pred_next, rotate ? state_cur : nullptr,
-                               grid_blocks(q.H, q.W));
+                               grid_blocks(q.H, q.W), pwalk ? (const long long*)((const char*)q.lazy_fold + lazy_fold_planes_bytes(n1, q.batch)) : nullptr);
         else
             hipLaunchKernelGGL(loss_sums2_kernel<3>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                                (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
@@ -1380,7 +1387,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         ls.j = jb;
         for (int k = 0; k < kLzPlanes; ++k) ls.plane[k] = lb.planes + (size_t)k * (size_t)q.batch * (size_t)n1;
         ls.pred_next = q.pred_next; ls.block_sums = fwd_sums; ls.n = q.n; ls.dcache = q.dcache; ls.counts = lb.counts; ls.lists = lb.lists;
-        ls.n_sums = resample ? lb.nblk + nres : lb.nblk;     // per image: the step kernel's workgroups, then the resampling launch's waves
+        ls.n_sums = resample ? lb.nblk + nres : lb.nblk;     // per image: the step kernel's blocks / workgroups, then the resampling launch's waves
         ls.tol = q.lazy_tol > 0.0f ? q.lazy_tol : 1.0f;
         ls.attached = (q.flags & MATPBR_FLAG_ATTACHED_SAMPLING) ? 1 : 0;
         ls.fold_part = part; ls.fold_rows = step_rows;
@@ -1398,6 +1405,10 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         ls.es_patience = q.es_patience; ls.es_min_delta = q.es_min_delta;
         if (fold != kFoldNone) {
             for (int k = 0; k < kFxPlanes; ++k) ls.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
+            ls.walk_fix = (long long*)((char*)q.lazy_fold + lazy_fold_planes_bytes(n1, q.batch));
+            ls.walk_cnt = (uint32_t*)(ls.walk_fix + (size_t)q.batch * lb.nblk);
+            ls.walk_queue = ls.walk_cnt + (size_t)q.batch * 4;
+            ls.walk_par = t & 1;
             // at most 1024 workgroups (four per CU, all resident), each with up to kPstepMaxBlocks consecutive 512-pixel blocks of one image
             long wg_cap = 1024;
 #ifdef MATPBR_EXP_TUNE   // measurement builds only (tools/r4_variant.sh)
@@ -1410,6 +1421,10 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             if (!(stages & MATPBR_STAGE_BACKWARD)) {
             } else if (fold == kFoldXY) hipLaunchKernelGGL(lazy_pstep_kernel<kFoldXY>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
             else hipLaunchKernelGGL(lazy_pstep_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
+            if ((stages & MATPBR_STAGE_RESAMPLE) && pwalk) {     // one wave per chunk of eight listed pixels; 256 waves per image take a queue of any length
+                const int nw = lb.nblk < 256 ? lb.nblk : 256;
+                hipLaunchKernelGGL(lazy_pwalk_kernel, dim3((unsigned)nw, pgrid.y), dim3(64), 0, st, ls, q.light, g, tab);
+            }
         } else if (stages & MATPBR_STAGE_BACKWARD)
             hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);
         if ((stages & MATPBR_STAGE_RESAMPLE) && resample)
@@ -1421,6 +1436,9 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     return launch_status();
 }
 
+#ifdef MATPBR_PS_STAMPS
+int matpbr_debug_ps_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_stamps), sizeof(g_ps_stamps)) == hipSuccess ? 0 : 1; }
+#endif
 #ifdef MATPBR_RS_STAMPS
 int matpbr_debug_rs_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_stamps), sizeof(g_rs_stamps)) == hipSuccess ? 0 : 1; }
 #endif
@@ -1576,7 +1594,8 @@ int matpbr_sin_bwd(const float* d_y, long ld_d, const float* pre, long ld_p, flo
 constexpr int kColsumBlocks = 512;
 // ---- --use_mask: masked entries of a map become their mean (include/matpbr.h matpbr_masked_mean_fill) -------------------------------
 constexpr int kMaskThreads = 1024;
-__global__ __launch_bounds__(kMaskThreads) void masked_mean_fill_kernel(const float* __restrict__ in, const unsigned char* __restrict__ mask,
+// (`in` is NOT __restrict__: the gradient form runs in place, out == in; every thread re-reads only the entries it writes, behind the barrier)
+__global__ __launch_bounds__(kMaskThreads) void masked_mean_fill_kernel(const float* in, const unsigned char* __restrict__ mask,
                                                                         const float* __restrict__ gate, float lo, float hi, float* out, long n) {
     __shared__ float s_sum[kMaskThreads / 64];
     __shared__ float s_cnt[kMaskThreads / 64];

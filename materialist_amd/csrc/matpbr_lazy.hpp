@@ -65,7 +65,21 @@ __device__ __forceinline__ void fold_xy(float a, float P, float SD, float S1, fl
 constexpr int kTile = kBlock;          // pixels of a tile of lazy_pstep_kernel: one per thread
 constexpr int kMaxTilesPerWg = 8;      // tiles a workgroup of lazy_pstep_kernel streams at most (its LDS lists are sized for them)
 __host__ __device__ inline int lazy_tiles(long P) { return (int)((P + kTile - 1) / kTile); }
-inline size_t lazy_fold_bytes(long P, int batch) { return (size_t)kFxPlanes * (size_t)batch * (size_t)P * 4; }
+// [16 planes][walk sums: B * nblk int64].  The walk sums: the render of the pixels lazy_pwalk_kernel re-samples, summed per 512-pixel block in
+// FIXED POINT (units of 2^-32) by integer atomics -- integer addition is associative, so the sum does not depend on which wave adds first
+// (and is the same whatever the batch size); the statistics pass adds it to the block's floating-point sum of the streamed pixels.
+// Behind them the WALK QUEUE of lazy_pstep_kernel / lazy_pwalk_kernel: per image two counters (one per iteration parity: the step kernel of
+// iteration t fills the queue of parity t & 1 and clears the other counter) and chunks of eight pixel indices (0xffffffff = none), room for
+// every pixel of the image plus one partial chunk per block.
+constexpr double kWalkFix = 4294967296.0;
+constexpr uint32_t kWalkNone = 0xffffffffu;
+inline size_t lazy_fold_planes_bytes(long P, int batch) { return (size_t)kFxPlanes * (size_t)batch * (size_t)P * 4; }
+__host__ __device__ inline long walk_queue_chunks(long P) { return (P + 7) / 8 + (P + 2 * kBlock - 1) / (2 * kBlock); }
+inline size_t lazy_fold_bytes(long P, int batch) {
+    const size_t nblk = (size_t)((P + 2 * kBlock - 1) / (2 * kBlock));
+    return lazy_fold_planes_bytes(P, batch) + (size_t)batch * nblk * sizeof(long long) + (size_t)batch * 4 * sizeof(uint32_t) +
+           (size_t)batch * (size_t)walk_queue_chunks(P) * 8 * sizeof(uint32_t);
+}
 
 __host__ __device__ inline int lazy_fwd_blocks(long P) { return (int)((P + kLazyBlockPixels - 1) / kLazyBlockPixels); }
 // workgroups of the refresh kernel per image (each takes every lazy_groups()-th chunk of the image's work list; also the number of
@@ -240,7 +254,11 @@ struct LazyStepArgs {
     float es_min_delta;
     // lazy_pstep_kernel (the folded, persistent form of the step): the folded planes, tiles per workgroup, tiles per image
     uint32_t* fplane[kFxPlanes];
+    long long* walk_fix;      // [B][nblk] fixed-point sums of the re-sampled pixels' render (lazy_fold_bytes)
     int tiles_per_wg, n_tiles;
+    uint32_t* walk_cnt;       // [B][4]: chunks in the walk queue, per iteration parity (two words used)
+    uint32_t* walk_queue;     // [B][walk_queue_chunks(P)][8] pixel indices
+    int walk_par;             // this iteration's parity
 };
 // LDS exchange between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be held back
 __device__ __forceinline__ void wave_lds_sync() {
@@ -540,16 +558,19 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
 // registers, no spills).
 #ifdef MATPBR_RS_STAMPS   // cycle stamps of one wave of the resampling launch (tools/rs_stamps.sh); never in the product build
 __device__ unsigned long long g_rs_stamps[8];
-#define RS_STAMP(k) do { if (blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); g_rs_stamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#ifndef MATPBR_RS_BLOCK
+#define MATPBR_RS_BLOCK 3
+#endif
+#define RS_STAMP(k) do { if (blockIdx.x == MATPBR_RS_BLOCK && blockIdx.y == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); g_rs_stamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define RS_STAMP(k) do { } while (0)
 #endif
 // One listed pixel re-sampled by the eight lanes `sub` = 0..7 of its group (four azimuths x (r, r + dir h: the one-sided difference that gives
 // the slopes), each lane walking the rings of its azimuth, contributions folded by a fixed butterfly): rebuilds the pixel's model, writes its
 // render into sp.pred_next and adds it to `tot` (lane sub == 0 of an item that exists; the other lanes return without side effects).
-// Shared by lazy_resample_kernel (FOLD = false) and the in-kernel walk of lazy_pstep_kernel (FOLD = true: the folded planes are rewritten too
-// and the render is the folded expression).  Tables in LDS: light coefficients x basis normalisation, GGX rings, azimuths.
-template <bool FOLD>
+// Shared by lazy_resample_kernel (FOLD = false) and lazy_pwalk_kernel behind lazy_pstep_kernel (FOLD = true: the folded planes are rewritten
+// too and the render is the folded expression).  Tables in LDS: light coefficients x basis normalisation, GGX rings, azimuths.
+template <bool FOLD, bool LEAN = false>
 __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, const StepPtrs& sp, const float* s_light, const float4* s_ring,
                                                     const float2* s_saz, const Geom& g, const RuleTable& tab, int b, int P, long BPl, int p,
                                                     bool item_ok, int sub, float floor_, float tol_k, float tol_s, float& tot) {
@@ -623,12 +644,12 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
                 const float NoL = fmaxf(wlz, 0.0f), dpos = fmaxf(d, 0.0f), g1l = rcp(fmaf(NoL, omk, kpe)), x5 = pow5(1.0f - dpos);
                 const float wgt = (ringw * g1l) * (NoL * dpos);
                 sh_poly(wi, B);
-                // FOLD (the walk inside the streaming step kernel, 128 registers): the 75 coefficients are read from LDS per sample -- left to
-                // itself the compiler keeps them in registers across the ring loop (they are loop invariants) and spills a hundred others
-                // (an opaque ZERO OFFSET, not an opaque pointer: the address must stay an LDS address -- a laundered pointer is a generic one,
-                // and every read becomes a flat load with a full wait behind it)
+                // LEAN (a caller short of registers): the 75 coefficients are read from LDS per sample -- left to itself the compiler keeps them
+                // in registers across the ring loop (they are loop invariants: 243 registers, the fastest walk).  Through an opaque ZERO OFFSET,
+                // not an opaque pointer: the address must stay an LDS address -- a laundered pointer is a generic one, and every read becomes a
+                // flat load with a full wait behind it
                 unsigned zoff = 0u;
-                if (FOLD) asm volatile("" : "+v"(zoff));
+                if (LEAN) asm volatile("" : "+v"(zoff));
                 const float* lp = s_light + (zoff << 2);
 #pragma unroll
                 for (int k = 0; k < kNSH; ++k) {

@@ -39,6 +39,7 @@ __device__ __forceinline__ void xy_eval(float X0, float Y0, uint32_t s, float x2
 // generic planes -> folded planes, at the start of a part (and the render of the part's first iteration in the folded expression)
 // =================================================================================================
 struct LazyFoldArgs {
+    uint32_t* walk_cnt;               // [B][4] the walk queue's counters (cleared here, at the start of a part)
     const float *a, *r, *m;           // the part's start parameters (raw: clamped here as every render clamps them)
     const uint32_t* plane[kLzPlanes];
     uint32_t* fplane[kFxPlanes];
@@ -50,6 +51,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q, int P) {
     __shared__ float s_sum[4];
     const int b = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x < 4) q.walk_cnt[b * 4 + threadIdx.x] = 0u;
     if (q.stats && img_stopped(q.stats, b)) return;
     float tot = 0.0f;
 #pragma unroll
@@ -275,6 +277,14 @@ template <int MODE> struct PStepPx;
 template <> struct PStepPx<kFoldXY> { typedef PxXY type; };
 template <> struct PStepPx<kFoldGH> { typedef PxGH type; };
 
+#ifdef MATPBR_PS_STAMPS   // cycle stamps of one workgroup of the persistent step (tools/ps_stamps.sh); never in the product build
+__device__ unsigned long long g_ps_stamps[16];
+#define PS_STAMP(k) do { if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); g_ps_stamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PS_NOTE(k, v) do { if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) g_ps_stamps[k] = (unsigned long long)(v); } while (0)
+#else
+#define PS_STAMP(k) do { } while (0)
+#define PS_NOTE(k, v) do { } while (0)
+#endif
 constexpr int kPstepListCap = kMaxTilesPerWg * 64;     // entries of a wave's list: every pixel it owns in the workgroup's tiles
 constexpr int kPstepMaxBlocks = kMaxTilesPerWg / 2;
 
@@ -285,16 +295,15 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     __shared__ float s_fold[4][6];
     __shared__ float s_bsum[kPstepMaxBlocks][4];
     __shared__ float s_breg[kPstepMaxBlocks][4][3];
-    __shared__ int s_cnt[4];
+    __shared__ uint16_t s_wcnt[kPstepMaxBlocks][4];            // listed pixels per (block, wave)
+    __shared__ uint32_t s_qbase;
     __shared__ uint16_t s_list[MODE == kFoldXY ? 4 : 1][MODE == kFoldXY ? kPstepListCap : 1];
-    __shared__ float s_res[MODE == kFoldXY ? kMaxTilesPerWg * kTile : 1];
-    __shared__ __attribute__((aligned(16))) float s_light[kNL + 1];
-    __shared__ float4 s_ring[kMaxRings];
-    __shared__ float2 s_saz[kMaxRings * kMaxAz];
     const JacBwdArgs& q = qs.j;
     const int b = blockIdx.y;
     const int P = g.H * g.W;
     const int nblk_img = lazy_fwd_blocks(P);
+    PS_STAMP(0);
+    PS_NOTE(12, __builtin_amdgcn_s_memrealtime());
     // this workgroup's blocks: blockIdx.x, blockIdx.x + gridDim.x, ... (>= 1 by the launch geometry).  Interleaved, not consecutive: the
     // workgroups that run side by side stream neighbouring blocks, and the pixels that leave their intervals together (a neighbourhood of
     // the image) are spread over many workgroups' lists
@@ -333,6 +342,7 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     pstep_load(A, qs, sp, (unsigned)(b * P + pix(0)), f);
     pstep_load(B, qs, sp, (unsigned)(b * P + pix(1)), f);
     __builtin_amdgcn_sched_barrier(0);
+    PS_STAMP(1);
     // ---- the iteration's statistics: every workgroup folds the rows of partial sums of its image (fixed order: the same bits everywhere),
     // forms the scalars from the OLD SaveBest / EarlyStopping state; workgroup 0 of the image writes the NEW state and the caller's row
     float ratio, sr;
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         sr = s_state[kStSr];
         improved = s_state[kStImproved] > 0.5f;
     }
-    const float gt_sum = s_state[kStGtSum];
+    PS_STAMP(2);
     if (qs.rotate) {                                           // uniform per image: scalar selects of the base pointers
         const bool wr1 = __builtin_amdgcn_readfirstlane((int)(s_state[kStSel] > 0.5f)) != 0;
         if (qs.alt_a) sp.pa = wr1 ? qs.alt_a : q.pa;
@@ -424,62 +434,141 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
             if (need0) s_list[wave][cntw + __popcll(b0 & below)] = (uint16_t)(t * kTile + (int)threadIdx.x);
             if (need1) s_list[wave][cntw + n0 + __popcll(b1 & below)] = (uint16_t)((t + 1) * kTile + (int)threadIdx.x);
             cntw += n0 + __popcll(b1);
+            if (lane == 0) s_wcnt[bl][wave] = (uint16_t)(n0 + __popcll(b1));
         }
     }
-    if (lane == 0) s_cnt[wave] = cntw;
+    PS_STAMP(3);
     __syncthreads();
-    const int c0 = s_cnt[0], c1 = c0 + s_cnt[1], c2 = c1 + s_cnt[2], T = c2 + s_cnt[3];
-    if (MODE == kFoldXY && T > 0) {
-        // ---- the pixels whose new roughness has left their model's interval: eight lanes per pixel, 32 pixels per pass (uniform branch)
-        if (threadIdx.x < kNL) s_light[threadIdx.x] = light[(long)b * kNL + threadIdx.x] * kShNorm[threadIdx.x / 3];
-        if (threadIdx.x < kMaxRings * kMaxAz) s_saz[threadIdx.x] = (&tab.saz[0][0])[threadIdx.x];
-        if (threadIdx.x < kMaxRings) s_ring[threadIdx.x] = tab.sring[threadIdx.x];
-        __syncthreads();
-        const float floor_ = 0.5f * gt_sum / (3.0f * (float)P) / (ratio > 0.0f ? ratio : 1.0f);
-        const float tol_k = qs.tol * kLzTolK, tol_s = qs.tol * kLzTolS;
-        const long BPl = (long)gridDim.y * P;
-        const StepPtrs spw{sp.a, sp.pr, sp.pm, sp.pa, sp.pr, sp.pm, sp.pred_next};     // the parameters as this launch has WRITTEN them
-        const int sub = threadIdx.x & 7;
-        for (int base = 0; base < T; base += kBlock / 8) {
-            if (base + 8 * wave >= T) break;                   // a wave without items leaves (uniform per wave; the walk shuffles within groups of 8 lanes)
-            const int k = base + ((int)threadIdx.x >> 3);
-            const bool ok = k < T;
-            const int kk = ok ? k : T - 1;
-            const int w = kk < c0 ? 0 : (kk < c1 ? 1 : (kk < c2 ? 2 : 3));
-            const int id = (int)s_list[w][kk - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)))];
-            float rs = 0.0f;
-#ifndef MATPBR_EXP_NOWALK   // measurement only: the streaming part's registers and duration without the walk's code
-            resample_walk_pixel<true>(qs, spw, s_light, s_ring, s_saz, g, tab, b, P, BPl, tile_px0(id >> 8) + (id & (kTile - 1)), ok, sub, floor_, tol_k, tol_s, rs);
-#endif
-            if (ok && sub == 0) s_res[k] = rs;
+    // ---- per-block results: the sum of the render of the streamed pixels (the four waves in order) and the regulariser sums; the listed
+    // pixels of a block, compacted in a fixed order (wave, tile, lane: whatever the batch size and the blocks per workgroup), go to the block's
+    // list in lazy_state -- the work list of lazy_pwalk_kernel, and what matpbr_lazy_state_unpack reads
+    if (MODE == kFoldXY) {
+        // this wave's entries are ordered by tile, hence by block: entry e of the wave sits in block bl at position
+        // (entries of earlier waves in bl) + (e - entries of this wave in earlier blocks)
+        int start = 0;
+        for (int bl = 0; bl < nb; ++bl) {
+            const int mine = (int)s_wcnt[bl][wave];
+            int before = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) before += w < wave ? (int)s_wcnt[bl][w] : 0;
+            uint16_t* list = qs.lists + ((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * kLazyBlockPixels;
+            for (int e = lane; e < mine; e += 64) list[before + e] = (uint16_t)((int)s_list[wave][start + e] & (kLazyBlockPixels - 1));
+            start += mine;
+        }
+    }
+    if (MODE == kFoldXY) {
+        // ... and, eight at a time, to the image's WALK QUEUE (one atomic per workgroup that lists anything; which chunk lands where does not
+        // matter: a pixel's new model depends on the pixel alone and the walk sums are order-free)
+        int cw[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            cw[w] = 0;
+            for (int bl = 0; bl < nb; ++bl) cw[w] += (int)s_wcnt[bl][w];
+        }
+        const int c0 = cw[0], c1 = c0 + cw[1], c2 = c1 + cw[2], T = c2 + cw[3];
+        const int nch = (T + 7) >> 3;
+        if (threadIdx.x == 0) {
+            s_qbase = nch ? atomicAdd(qs.walk_cnt + b * 4 + qs.walk_par, (uint32_t)nch) : 0u;
+            if (blockIdx.x == 0) qs.walk_cnt[b * 4 + (qs.walk_par ^ 1)] = 0u;      // the next iteration's counter (its last reader has long finished)
         }
         __syncthreads();
+        uint32_t* qd = qs.walk_queue + ((long)b * walk_queue_chunks(P) + s_qbase) * 8;
+        for (int e = threadIdx.x; e < 8 * nch; e += kBlock) {
+            uint32_t pix = kWalkNone;
+            if (e < T) {
+                const int w = e < c0 ? 0 : (e < c1 ? 1 : (e < c2 ? 2 : 3));
+                const int id = (int)s_list[w][e - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)))];
+                pix = (uint32_t)(tile_px0(id >> 8) + (id & (kTile - 1)));
+            }
+            qd[e] = pix;
+        }
+        PS_NOTE(15, T);
     }
-    // ---- per-block results: the sum of the render (streamed pixels by wave, then the re-sampled ones in list order), the regulariser sums,
-    // and the lists in the layout matpbr_lazy_state_unpack reads (inspection)
     if ((int)threadIdx.x < nb) {
         const int bl = threadIdx.x;
-        float s = (s_bsum[bl][0] + s_bsum[bl][1]) + (s_bsum[bl][2] + s_bsum[bl][3]);
-        int cnt = 0;
-        if (MODE == kFoldXY) {
-            uint16_t* list = qs.lists ? qs.lists + ((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * kLazyBlockPixels : nullptr;
-            for (int k = 0; k < T; ++k) {
-                const int w = k < c0 ? 0 : (k < c1 ? 1 : (k < c2 ? 2 : 3));
-                const int id = (int)s_list[w][k - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)))];
-                if ((id >> 9) == bl) {
-                    s += s_res[k];
-                    if (list) list[cnt] = (uint16_t)(id & (kLazyBlockPixels - 1));
-                    ++cnt;
-                }
-            }
-        }
-        if (qs.counts) qs.counts[(long)b * nblk_img + blockIdx.x + bl * gridDim.x] = (uint32_t)cnt;
-        qs.block_sums[(long)b * qs.n_sums + blockIdx.x + bl * gridDim.x] = s;
+        qs.block_sums[(long)b * qs.n_sums + blockIdx.x + bl * gridDim.x] = (s_bsum[bl][0] + s_bsum[bl][1]) + (s_bsum[bl][2] + s_bsum[bl][3]);
+        if (MODE == kFoldXY) qs.walk_fix[(long)b * nblk_img + blockIdx.x + bl * gridDim.x] = 0;      // lazy_pwalk_kernel adds to it
+        if (qs.counts)
+            qs.counts[(long)b * nblk_img + blockIdx.x + bl * gridDim.x] =
+                MODE == kFoldXY ? (uint32_t)(((int)s_wcnt[bl][0] + (int)s_wcnt[bl][1]) + ((int)s_wcnt[bl][2] + (int)s_wcnt[bl][3])) : 0u;
     }
     if (qs.reg_sums && (int)threadIdx.x < 3 * nb) {
         const int bl = threadIdx.x / 3, k = threadIdx.x - 3 * bl;
         qs.reg_sums[((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * 3 + k] = (s_breg[bl][0][k] + s_breg[bl][1][k]) + (s_breg[bl][2][k] + s_breg[bl][3][k]);
     }
+    PS_STAMP(8);
+    PS_NOTE(13, __builtin_amdgcn_s_memrealtime());
+}
+
+// =================================================================================================
+// the pixels lazy_pstep_kernel<kFoldXY> listed, re-sampled
+// =================================================================================================
+// One wave (a 64-thread workgroup) per chunk of the image's walk queue: eight pixels, eight lanes each (resample_walk_pixel).  The walked
+// pixels' models are rebuilt (generic AND folded planes), their render written, and the sum of it added to its block's walk sum in fixed
+// point (integer atomics: order-free, hence reproducible and the same for every batch size).  A wave's chain is (counter, chunk) -> pixel ->
+// walk -> stores -- no prefix over an image's lists, no search (lazy_resample_kernel: 12 k of a wave's 28 k cycles) -- and the chunks are
+// full but for one per workgroup of the step kernel: ~190 waves per 512 x 512 image and iteration walk, the others leave after one round
+// trip.  What was tried on the way: one wave per 512-pixel block (3 600 eleven-thousand-cycle walks per iteration at 8 x 512^2 for two
+// pixels each: VALU-bound, 40 us); a fixed number of waves per group of four blocks (the longest of 1024 lists has ~46 entries: a second
+// pass nearly every iteration with four waves, 31 us; with eight, 8192 workgroups whose dispatch alone is 20 us); waves packed four to a
+// workgroup (a 240-register wave needs half a SIMD: a workgroup is placed only where all four SIMDs have room, 40 us); the walk inside the
+// step kernel (128 registers: 25 k cycles per walk, 16 us of tail).
+__global__ __launch_bounds__(64) void lazy_pwalk_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
+    __shared__ float s_light[kNL + 1];
+    __shared__ float4 s_ring[kMaxRings];
+    __shared__ float2 s_saz[kMaxRings * kMaxAz];
+    const JacBwdArgs& q = qs.j;
+    const int b = blockIdx.y;
+    const int P = g.H * g.W;
+    const int nblk = lazy_fwd_blocks(P);
+    const int lane = threadIdx.x;
+    RS_STAMP(0);
+    // one round trip for everything that depends on nothing: the stop flag, the queue's length, this wave's first chunk, the state, the tables
+    const float stopped = qs.state_old[b * kStateStride + kStStopped];
+    const int n = (int)qs.walk_cnt[b * 4 + qs.walk_par];
+    const uint32_t* queue = qs.walk_queue + (long)b * walk_queue_chunks(P) * 8;
+    uint32_t pix = queue[(long)blockIdx.x * 8 + (lane >> 3)];               // (inside the queue's storage whatever n is)
+    const float* st = qs.state_new + b * kStateStride;                     // the state the step kernel has just committed
+    const float ratio = st[kStRatio], gt_sum = st[kStGtSum], sel_f = st[kStSel];
+    const float lt0 = light[(long)b * kNL + lane], lt1 = lane + 64 < kNL ? light[(long)b * kNL + lane + 64] : 0.0f;
+    const float2 saz_v = (&tab.saz[0][0])[lane];
+    const float4 ring_v = tab.sring[lane < kMaxRings ? lane : 0];
+    if (stopped > 0.5f || (int)blockIdx.x >= n) return;                    // the step kernel skipped the image / nothing for this wave (uniform)
+    RS_STAMP(1);
+    s_light[lane] = lt0 * kShNorm[lane / 3];
+    if (lane + 64 < kNL) s_light[lane + 64] = lt1 * kShNorm[(lane + 64) / 3];
+    s_saz[lane] = saz_v;
+    if (lane < kMaxRings) s_ring[lane] = ring_v;
+    StepPtrs sp{q.pa, q.pr, q.pm, q.pa, q.pr, q.pm, qs.pred_next};          // the parameters as WRITTEN by the step (a map the part does not move: as read)
+    if (qs.rotate) {
+        const bool wr1 = __builtin_amdgcn_readfirstlane((int)(sel_f > 0.5f)) != 0;
+        if (qs.alt_a) sp.a = wr1 ? qs.alt_a : q.pa;
+        if (qs.alt_r) sp.r = wr1 ? qs.alt_r : q.pr;
+        if (qs.alt_m) sp.m = wr1 ? qs.alt_m : q.pm;
+        sp.pred_next = qs.pred_buf[wr1 ? 1 : 0];
+    }
+    __syncthreads();
+    const float floor_ = 0.5f * gt_sum / (3.0f * (float)P) / (ratio > 0.0f ? ratio : 1.0f);
+    const float tol_k = qs.tol * kLzTolK, tol_s = qs.tol * kLzTolS;
+    const long BPl = (long)gridDim.y * P;
+    const int sub = lane & 7;
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {                      // (one pass unless the queue is longer than the grid)
+        if (c != (int)blockIdx.x) pix = queue[(long)c * 8 + (lane >> 3)];
+        const bool ok = pix != kWalkNone;
+        const uint32_t first = (uint32_t)__shfl((int)pix, 0);               // a chunk's first entry always exists
+        const int p = (int)(ok ? pix : first);
+#ifdef MATPBR_EXP_PWALK_DRY
+        if (ok && sub == 0 && p >= 0 && p < P) atomicAdd((unsigned long long*)(qs.walk_fix + (long)b * nblk + p / kLazyBlockPixels), 1ull);
+        continue;
+#endif
+        RS_STAMP(2);
+        float rs = 0.0f;
+        resample_walk_pixel<true>(qs, sp, s_light, s_ring, s_saz, g, tab, b, P, BPl, p, ok, sub, floor_, tol_k, tol_s, rs);
+        RS_STAMP(5);
+        if (ok && sub == 0)
+            atomicAdd((unsigned long long*)(qs.walk_fix + (long)b * nblk + p / kLazyBlockPixels), (unsigned long long)(long long)__double2ll_rn((double)rs * kWalkFix));
+    }
+    RS_STAMP(6);
 }
 
 }  // namespace matpbr

@@ -60,18 +60,25 @@ def broadcast_state_dict(state_dict, device, src: int = 0):
         return {k: v.to(device) for k, v in state_dict.items()}
     rank = dist.get_rank()
     layout = broadcast_config([(k, tuple(v.shape), str(v.dtype)) for k, v in state_dict.items()] if rank == src else None, src=src)
-    total = sum(int(torch.Size(shape).numel()) for _, shape, _ in layout)
-    flat = torch.empty(total, dtype=torch.float32, device=device)
-    if rank == src:
+    # one flat buffer PER DTYPE, each in its own type: integer buffers (BatchNorm's num_batches_tracked, index tables) and float64 entries
+    # arrive exactly -- a single fp32 buffer is exact for integers only up to 2^24 and rounds doubles
+    out = {}
+    for dtype in sorted({d for _, _, d in layout}):
+        td = getattr(torch, dtype.split(".")[-1])
+        group = [(k, shape) for k, shape, d in layout if d == dtype]
+        total = sum(int(torch.Size(shape).numel()) for _, shape in group)
+        wire = torch.uint8 if td == torch.bool else td                     # collectives do not take bool
+        flat = torch.empty(total, dtype=wire, device=device)
+        if rank == src:
+            off = 0
+            for k, shape in group:
+                n = int(torch.Size(shape).numel())
+                flat[off:off + n] = state_dict[k].detach().reshape(-1).to(device, wire)
+                off += n
+        dist.broadcast(flat, src=src)
         off = 0
-        for k, shape, _ in layout:
+        for k, shape in group:
             n = int(torch.Size(shape).numel())
-            flat[off:off + n] = state_dict[k].detach().reshape(-1).to(device, torch.float32)
+            out[k] = flat[off:off + n].view(shape).to(td)
             off += n
-    dist.broadcast(flat, src=src)
-    out, off = {}, 0
-    for k, shape, dtype in layout:
-        n = int(torch.Size(shape).numel())
-        out[k] = flat[off:off + n].view(shape).to(getattr(torch, dtype.split(".")[-1]))
-        off += n
-    return out
+    return {k: out[k] for k, _, _ in layout}

@@ -404,8 +404,8 @@ class FusedBrdfPhase:
 
     @property
     def pred(self) -> torch.Tensor:
-        """Lazy mode: the render of the CURRENT parameters (what the next iteration will judge; the last launch of a step renders it).
-        `lazy=False`: the render the last iteration judged."""
+        """Lazy mode (with either form of SaveBest): the render of the CURRENT parameters (what the next iteration will judge; the last launch
+        of a step renders it).  `lazy=False`: the render the last iteration judged."""
         self._resolve()
         return self._pred
 
@@ -415,9 +415,10 @@ class FusedBrdfPhase:
         if self.rotate:
             self._dirty = True
         elif self._pred_bufs is not None:
-            # self.pred = the render this step evaluated; the buffer its last launch rendered the next iterate into becomes `pred` of the next step
-            self._pred = self._pred_bufs[self._pred_cur]
+            # the buffer the step's last launch rendered the next iterate into becomes `pred` of the next step -- and `self.pred`, as in the
+            # rotating form: the render of the current parameters
             self._pred_cur ^= 1
+            self._pred = self._pred_bufs[self._pred_cur]
             self._ph.pred = ct.c_void_p(self._pred_bufs[self._pred_cur].data_ptr())
             self._ph.pred_next = ct.c_void_p(self._pred_bufs[self._pred_cur ^ 1].data_ptr())
 
@@ -529,8 +530,10 @@ class MaskedBrdfPhase:
         self.s1 = None if "roughness" in self.live else torch.empty((3, 1, H, W), dtype=torch.float32, device=dev)
         self._bg_mask = scene.bg_mask
         if self._bg_mask is not None:
-            self._bg_flat = self._bg_mask.reshape(-1)
             self._bg_rgb = scene.background_radiance(self._light).reshape(-1, 3).contiguous()
+            self._bg_idx = ops.background_index(self._bg_mask)          # once: boolean-mask indexing would synchronise with the host every iteration
+            self._bg_rows = self._bg_rgb[self._bg_idx].contiguous()
+            self._bg_rows_t = self._bg_rows.t().contiguous()
         self.t = 0
 
     lr_at = FusedBrdfPhase.lr_at
@@ -555,8 +558,8 @@ class MaskedBrdfPhase:
             o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], self._n, self._light, self.spp, sc.fov, clamp_params=True, out=self.pred,
                         dcache=self.dcache, jac=self.jac, s1=self.s1)
         if self._bg_mask is not None and not (self.s1 is not None and self.t > 0):
-            self.pred.view(-1, 3)[self._bg_flat] = self._bg_rgb[self._bg_flat]
-            o.background_into_jac(self.jac, self.s1, self._bg_mask, self._bg_rgb)
+            self.pred.view(-1, 3).index_copy_(0, self._bg_idx, self._bg_rows)
+            o.background_into_jac(self.jac, self.s1, self._bg_mask, self._bg_rgb, self._bg_idx, self._bg_rows_t)
         o.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], self.orig["albedo"],
                           self.orig["roughness"], self.orig["metallic"], self.scale_delta, self.stats, self.ws, optimize_part=self.part,
                           es_patience=self.patience, es_min_delta=self.min_delta, history=self.hist)

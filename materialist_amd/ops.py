@@ -269,12 +269,21 @@ def background_into_lazy_state(state: torch.Tensor, a: torch.Tensor, bg_mask: to
     planes[12:21, idx] = 0
 
 
-def background_into_jac(jac: torch.Tensor, s1: Optional[torch.Tensor], bg_mask: torch.Tensor, bg_rgb: torch.Tensor) -> None:
-    """The same for the fp32 jac planes ([9, 1, H, W]: P, SD, d out/d r) and, if kept, the S1 planes ([3, 1, H, W])."""
-    m = bg_mask.reshape(-1)
-    jac.view(9, -1)[:, m] = 0.0
+def background_index(bg_mask: torch.Tensor) -> torch.Tensor:
+    """Flat indices of the masked pixels -- computed ONCE per phase (`nonzero` synchronises with the host): the per-iteration patches below
+    then use index_fill_ / index_copy_, which enqueue without a round trip."""
+    return bg_mask.reshape(-1).nonzero().reshape(-1)
+
+
+def background_into_jac(jac: torch.Tensor, s1: Optional[torch.Tensor], bg_mask: torch.Tensor, bg_rgb: torch.Tensor,
+                        idx: Optional[torch.Tensor] = None, rows_t: Optional[torch.Tensor] = None) -> None:
+    """The same for the fp32 jac planes ([9, 1, H, W]: P, SD, d out/d r) and, if kept, the S1 planes ([3, 1, H, W]).  `idx` =
+    background_index(bg_mask) and `rows_t` = bg_rgb[idx].t() (3, n) when the caller patches every iteration."""
+    if idx is None:
+        idx = background_index(bg_mask)
+    jac.view(9, -1).index_fill_(1, idx, 0.0)
     if s1 is not None:
-        s1.view(3, -1)[:, m] = bg_rgb.reshape(-1, 3)[m].t()
+        s1.view(3, -1).index_copy_(1, idx, rows_t if rows_t is not None else bg_rgb.reshape(-1, 3)[idx].t().contiguous())
 
 
 def background_into_transfer(T: torch.Tensor, H: int, W: int, bg_basis: torch.Tensor) -> None:

@@ -226,8 +226,15 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             state["best_brdf_weights"] = ph.best_weights
         if state["best_brdf_weights"] is not None:
             brdf_net.load_state_dict(state["best_brdf_weights"])                    # :586-587: reloaded after every part
+        # the device-side EarlyStopping is polled every few iterations: the iterations enqueued between the stop and the poll were no-ops,
+        # so the epoch and the learning rate reported are those of the last iteration that really ran
+        if hasattr(ph, "iterations_run"):
+            it = max(ph.iterations_run - 1, 0)
+            lr_end = ph.lr_at(it) if hasattr(ph, "lr_at") else ph.opt.param_groups[0]["lr"]
+        else:
+            lr_end = ph.opt.param_groups[0]["lr"]
         say(f"loop {loop_num}: part {part!r} (pos_mlp) ran {it + 1} iterations ({stop}), best mse {float(best.min()):.5f}")
-        return it, ph.opt.param_groups[0]["lr"], stop
+        return it, lr_end, stop
 
     def brdf_part_runner_normal(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
         """Parts that optimise the normal map (output_type 'armn', use_mesh_normal False; :335-340,378-379,406-409), and `--use_mask` on
@@ -311,7 +318,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             done += k
             info = ph.poll()
             if frames is not None and gt.ndim == 3 and frames.due("mat"):
-                frames.mat_frame(loop_num, part, done - 1, gt, _loss.linear_to_srgb((ph.pred * ph.stats[0, 0]).clamp_min(1e-8)),
+                shown = ph.pred                                # lazy loop: the render of the current parameters (the next iteration's)
+                frames.mat_frame(loop_num, part, done - 1, gt, _loss.linear_to_srgb((shown * (gt.mean() / shown.mean())).clamp_min(1e-8)),   # its own exposure ratio (:388)
                                  ph.current_maps(), shading_normal if shading_normal is not None else scene.shading_normal())
             if bool(info["stopped"].all()):
                 stop = "early_stop"

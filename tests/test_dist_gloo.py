@@ -168,8 +168,13 @@ def _weights_worker(rank, world, port, path, out_q):
 def test_network_weights_leave_rank_0_once_as_a_flat_buffer(tmp_path):
     """rank 0 loads MaterialNet / PosMLP weights and broadcasts ONE flat buffer; every rank ends with the same state_dict."""
     torch.manual_seed(3)
+    # every dtype arrives exactly: an integer buffer beyond 2^24 (BatchNorm's num_batches_tracked), a float64 entry with more digits than
+    # fp32 holds, a half-precision tensor and a bool mask travel in buffers of their own type
     sd = {"pretrained.blocks.0.attn.qkv.weight": torch.randn(12, 4), "pretrained.blocks.0.attn.qkv.bias": torch.randn(12),
-          "depth_head.scratch.output_conv2.0.weight": torch.randn(2, 3, 3, 3), "empty": torch.zeros(0)}
+          "depth_head.scratch.output_conv2.0.weight": torch.randn(2, 3, 3, 3), "empty": torch.zeros(0),
+          "bn.num_batches_tracked": torch.tensor(2 ** 24 + 1, dtype=torch.int64), "table": torch.tensor([2 ** 40 + 3, -7], dtype=torch.int64),
+          "stats.mean64": torch.tensor([1.0 + 2.0 ** -40, 3.141592653589793], dtype=torch.float64),
+          "half.w": torch.randn(5, 3).half(), "keep": torch.tensor([True, False, True])}
     path = str(tmp_path / "w.pth")
     torch.save(sd, path)
     ctx = mp.get_context("spawn")

@@ -210,6 +210,7 @@ def test_savebest_without_copies_leaves_what_the_copying_step_leaves(part):
             assert torch.equal(rot.p[name], cpy.p[name]), (upto, name)
             assert torch.equal(rot.best[name], cpy.best[name]), (upto, name)
         assert torch.equal(rot.best_img, cpy.best_img), upto
+        assert torch.equal(rot.pred, cpy.pred), upto              # one meaning in both forms: the render of the current parameters
         assert torch.equal(rot.stats, cpy.stats), upto
         assert torch.equal(rot.history(), cpy.history()), upto
     # an image that cannot improve: the snapshots it came with survive the phase
