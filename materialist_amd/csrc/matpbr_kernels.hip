@@ -1407,7 +1407,7 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             for (int k = 0; k < kFxPlanes; ++k) ls.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
             ls.walk_fix = (long long*)((char*)q.lazy_fold + lazy_fold_planes_bytes(n1, q.batch));
             ls.walk_cnt = (uint32_t*)(ls.walk_fix + (size_t)q.batch * lb.nblk);
-            ls.walk_queue = ls.walk_cnt + (size_t)q.batch * 4;
+            ls.walk_queue = ls.walk_cnt + (size_t)q.batch * 2 * kWalkShards;
             ls.walk_par = t & 1;
             // at most 1024 workgroups (four per CU, all resident), each with up to kPstepMaxBlocks consecutive 512-pixel blocks of one image
             long wg_cap = 1024;
@@ -1422,8 +1422,12 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             } else if (fold == kFoldXY) hipLaunchKernelGGL(lazy_pstep_kernel<kFoldXY>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
             else hipLaunchKernelGGL(lazy_pstep_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
             if ((stages & MATPBR_STAGE_RESAMPLE) && pwalk) {     // one wave per chunk of eight listed pixels; 256 waves per image take a queue of any length
-                const int nw = lb.nblk < 256 ? lb.nblk : 256;
-                hipLaunchKernelGGL(lazy_pwalk_kernel, dim3((unsigned)nw, pgrid.y), dim3(64), 0, st, ls, q.light, g, tab);
+                // waves per image: a multiple of the shards, 2048 in all at most (a long queue -- the first iterations of a part -- is walked in passes)
+                int nw = 2048 / q.batch / kWalkShards * kWalkShards;
+                const int most = (int)((walk_shard_cap(n1) + 7) / 8) * kWalkShards;
+                nw = nw < kWalkShards ? kWalkShards : (nw > 1024 ? 1024 : nw);
+                nw = nw > most ? most : nw;
+                hipLaunchKernelGGL(lazy_pwalk_kernel, dim3((unsigned)(nw * q.batch)), dim3(64), 0, st, ls, q.light, g, tab);
             }
         } else if (stages & MATPBR_STAGE_BACKWARD)
             hipLaunchKernelGGL(lazy_step_kernel, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, ls, q.light, g, tab);

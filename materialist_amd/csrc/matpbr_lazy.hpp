@@ -68,17 +68,19 @@ __host__ __device__ inline int lazy_tiles(long P) { return (int)((P + kTile - 1)
 // [16 planes][walk sums: B * nblk int64].  The walk sums: the render of the pixels lazy_pwalk_kernel re-samples, summed per 512-pixel block in
 // FIXED POINT (units of 2^-32) by integer atomics -- integer addition is associative, so the sum does not depend on which wave adds first
 // (and is the same whatever the batch size); the statistics pass adds it to the block's floating-point sum of the streamed pixels.
-// Behind them the WALK QUEUE of lazy_pstep_kernel / lazy_pwalk_kernel: per image two counters (one per iteration parity: the step kernel of
-// iteration t fills the queue of parity t & 1 and clears the other counter) and chunks of eight pixel indices (0xffffffff = none), room for
-// every pixel of the image plus one partial chunk per block.
+// Behind them the WALK QUEUE of lazy_pstep_kernel / lazy_pwalk_kernel: per image kWalkShards flat lists of pixel indices, each with two
+// counters (one per iteration parity: the step kernel of iteration t appends to the lists of parity t & 1 -- a wave reserves room for all its
+// pixels with ONE atomic on the counter of its shard, when it has streamed its last tile -- and clears the other parity's counters).
 constexpr double kWalkFix = 4294967296.0;
-constexpr uint32_t kWalkNone = 0xffffffffu;
+constexpr int kWalkShards = 32;
 inline size_t lazy_fold_planes_bytes(long P, int batch) { return (size_t)kFxPlanes * (size_t)batch * (size_t)P * 4; }
-__host__ __device__ inline long walk_queue_chunks(long P) { return (P + 7) / 8 + (P + 2 * kBlock - 1) / (2 * kBlock); }
+// entries of one shard: the pixels of every wave that may append to it (wave v of the 4 gridDim.x of an image: shard v % kWalkShards; a wave
+// owns 128 pixels of each of its workgroup's <= 4 blocks: <= 16 nblk + 576 pixels per shard whatever the launch geometry)
+__host__ __device__ inline long walk_shard_cap(long P) { return (P + 2 * kBlock - 1) / (2 * kBlock) * (2 * kBlock / kWalkShards) + 1024; }
 inline size_t lazy_fold_bytes(long P, int batch) {
     const size_t nblk = (size_t)((P + 2 * kBlock - 1) / (2 * kBlock));
-    return lazy_fold_planes_bytes(P, batch) + (size_t)batch * nblk * sizeof(long long) + (size_t)batch * 4 * sizeof(uint32_t) +
-           (size_t)batch * (size_t)walk_queue_chunks(P) * 8 * sizeof(uint32_t);
+    return lazy_fold_planes_bytes(P, batch) + (size_t)batch * nblk * sizeof(long long) + (size_t)batch * 2 * kWalkShards * sizeof(uint32_t) +
+           (size_t)batch * kWalkShards * (size_t)walk_shard_cap(P) * sizeof(uint32_t);
 }
 
 __host__ __device__ inline int lazy_fwd_blocks(long P) { return (int)((P + kLazyBlockPixels - 1) / kLazyBlockPixels); }
@@ -256,8 +258,8 @@ struct LazyStepArgs {
     uint32_t* fplane[kFxPlanes];
     long long* walk_fix;      // [B][nblk] fixed-point sums of the re-sampled pixels' render (lazy_fold_bytes)
     int tiles_per_wg, n_tiles;
-    uint32_t* walk_cnt;       // [B][4]: chunks in the walk queue, per iteration parity (two words used)
-    uint32_t* walk_queue;     // [B][walk_queue_chunks(P)][8] pixel indices
+    uint32_t* walk_cnt;       // [B][2][kWalkShards]: entries of the walk queue's lists, per iteration parity
+    uint32_t* walk_queue;     // [B][kWalkShards][walk_shard_cap(P)] pixel indices
     int walk_par;             // this iteration's parity
 };
 // LDS exchange between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be held back

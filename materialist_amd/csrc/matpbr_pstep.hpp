@@ -39,7 +39,7 @@ __device__ __forceinline__ void xy_eval(float X0, float Y0, uint32_t s, float x2
 // generic planes -> folded planes, at the start of a part (and the render of the part's first iteration in the folded expression)
 // =================================================================================================
 struct LazyFoldArgs {
-    uint32_t* walk_cnt;               // [B][4] the walk queue's counters (cleared here, at the start of a part)
+    uint32_t* walk_cnt;               // [B][2][kWalkShards] the walk queue's counters (cleared here, at the start of a part)
     const float *a, *r, *m;           // the part's start parameters (raw: clamped here as every render clamps them)
     const uint32_t* plane[kLzPlanes];
     uint32_t* fplane[kFxPlanes];
@@ -51,7 +51,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q, int P) {
     __shared__ float s_sum[4];
     const int b = blockIdx.y;
-    if (blockIdx.x == 0 && threadIdx.x < 4) q.walk_cnt[b * 4 + threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 2 * kWalkShards) q.walk_cnt[b * 2 * kWalkShards + threadIdx.x] = 0u;
     if (q.stats && img_stopped(q.stats, b)) return;
     float tot = 0.0f;
 #pragma unroll
@@ -296,7 +296,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     __shared__ float s_bsum[kPstepMaxBlocks][4];
     __shared__ float s_breg[kPstepMaxBlocks][4][3];
     __shared__ uint16_t s_wcnt[kPstepMaxBlocks][4];            // listed pixels per (block, wave)
-    __shared__ uint32_t s_qbase;
     __shared__ uint16_t s_list[MODE == kFoldXY ? 4 : 1][MODE == kFoldXY ? kPstepListCap : 1];
     const JacBwdArgs& q = qs.j;
     const int b = blockIdx.y;
@@ -437,6 +436,26 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
             if (lane == 0) s_wcnt[bl][wave] = (uint16_t)(n0 + __popcll(b1));
         }
     }
+    if (MODE == kFoldXY) {
+        // ---- the pixels this wave listed go to the image's WALK QUEUE, before the workgroup's last barrier: room for all of them is reserved
+        // with one atomic (shard: this wave's number among the image's, modulo kWalkShards -- 2048 waves on one word would queue for 20 us),
+        // whose round trip runs under the other waves' last tiles.  Where a pixel lands in the queue does not matter: its new model depends on
+        // the pixel alone, and the walk sums are order-free.
+        if (blockIdx.x == 0 && threadIdx.x < kWalkShards)          // the next iteration's counters (their last reader has long finished)
+            qs.walk_cnt[(b * 2 + (qs.walk_par ^ 1)) * kWalkShards + threadIdx.x] = 0u;
+        if (cntw > 0) {                                            // (uniform per wave)
+            const int shard = ((int)blockIdx.x * 4 + wave) % kWalkShards;
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(qs.walk_cnt + (b * 2 + qs.walk_par) * kWalkShards + shard, (uint32_t)cntw);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            uint32_t* qd = qs.walk_queue + ((long)b * kWalkShards + shard) * walk_shard_cap(P) + base;
+            for (int e = lane; e < cntw; e += 64) {
+                const int id = (int)s_list[wave][e];
+                qd[e] = (uint32_t)(tile_px0(id >> 8) + (id & (kTile - 1)));
+            }
+        }
+        PS_NOTE(15, cntw);
+    }
     PS_STAMP(3);
     __syncthreads();
     // ---- per-block results: the sum of the render of the streamed pixels (the four waves in order) and the regulariser sums; the listed
@@ -455,34 +474,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
             for (int e = lane; e < mine; e += 64) list[before + e] = (uint16_t)((int)s_list[wave][start + e] & (kLazyBlockPixels - 1));
             start += mine;
         }
-    }
-    if (MODE == kFoldXY) {
-        // ... and, eight at a time, to the image's WALK QUEUE (one atomic per workgroup that lists anything; which chunk lands where does not
-        // matter: a pixel's new model depends on the pixel alone and the walk sums are order-free)
-        int cw[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            cw[w] = 0;
-            for (int bl = 0; bl < nb; ++bl) cw[w] += (int)s_wcnt[bl][w];
-        }
-        const int c0 = cw[0], c1 = c0 + cw[1], c2 = c1 + cw[2], T = c2 + cw[3];
-        const int nch = (T + 7) >> 3;
-        if (threadIdx.x == 0) {
-            s_qbase = nch ? atomicAdd(qs.walk_cnt + b * 4 + qs.walk_par, (uint32_t)nch) : 0u;
-            if (blockIdx.x == 0) qs.walk_cnt[b * 4 + (qs.walk_par ^ 1)] = 0u;      // the next iteration's counter (its last reader has long finished)
-        }
-        __syncthreads();
-        uint32_t* qd = qs.walk_queue + ((long)b * walk_queue_chunks(P) + s_qbase) * 8;
-        for (int e = threadIdx.x; e < 8 * nch; e += kBlock) {
-            uint32_t pix = kWalkNone;
-            if (e < T) {
-                const int w = e < c0 ? 0 : (e < c1 ? 1 : (e < c2 ? 2 : 3));
-                const int id = (int)s_list[w][e - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)))];
-                pix = (uint32_t)(tile_px0(id >> 8) + (id & (kTile - 1)));
-            }
-            qd[e] = pix;
-        }
-        PS_NOTE(15, T);
     }
     if ((int)threadIdx.x < nb) {
         const int bl = threadIdx.x;
@@ -503,37 +494,41 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
 // =================================================================================================
 // the pixels lazy_pstep_kernel<kFoldXY> listed, re-sampled
 // =================================================================================================
-// One wave (a 64-thread workgroup) per chunk of the image's walk queue: eight pixels, eight lanes each (resample_walk_pixel).  The walked
-// pixels' models are rebuilt (generic AND folded planes), their render written, and the sum of it added to its block's walk sum in fixed
-// point (integer atomics: order-free, hence reproducible and the same for every batch size).  A wave's chain is (counter, chunk) -> pixel ->
-// walk -> stores -- no prefix over an image's lists, no search (lazy_resample_kernel: 12 k of a wave's 28 k cycles) -- and the chunks are
-// full but for one per workgroup of the step kernel: ~190 waves per 512 x 512 image and iteration walk, the others leave after one round
-// trip.  What was tried on the way: one wave per 512-pixel block (3 600 eleven-thousand-cycle walks per iteration at 8 x 512^2 for two
-// pixels each: VALU-bound, 40 us); a fixed number of waves per group of four blocks (the longest of 1024 lists has ~46 entries: a second
-// pass nearly every iteration with four waves, 31 us; with eight, 8192 workgroups whose dispatch alone is 20 us); waves packed four to a
-// workgroup (a 240-register wave needs half a SIMD: a workgroup is placed only where all four SIMDs have room, 40 us); the walk inside the
-// step kernel (128 registers: 25 k cycles per walk, 16 us of tail).
+// One wave (a 64-thread workgroup) per eight entries of the image's walk queue (wave w: shard w % kWalkShards, entries 8 (w / kWalkShards) ..):
+// eight pixels, eight lanes each (resample_walk_pixel).  The walked pixels' models are rebuilt (generic AND folded planes), their render
+// written, and the sum of it added to its block's walk sum in fixed point (integer atomics: order-free, hence reproducible and the same
+// for every batch size).  A wave's chain is (counter, entries) -> pixel -> walk -> stores -- no prefix over an image's lists, no search
+// (lazy_resample_kernel: 12 k of a wave's 28 k cycles) -- and the waves are full but for one per shard: ~100 waves per 512 x 512 image and
+// iteration walk, the others leave after one round trip.  What was tried on the way: one wave per 512-pixel block (3 600 eleven-thousand-
+// cycle walks per iteration at 8 x 512^2 for two pixels each: VALU-bound, 40 us); a fixed number of waves per group of four blocks (the
+// longest of 1024 lists has ~46 entries: a second pass nearly every iteration with four waves, 31 us; with eight, 8192 workgroups whose
+// dispatch alone is 20 us); waves packed four to a workgroup (a 240-register wave needs half a SIMD: a workgroup is placed only where all
+// four SIMDs have room, 40 us); chunks of eight filled per workgroup of the step kernel (mostly two or three pixels per chunk: twice the
+// waves, and at one image more chunks than waves); the walk inside the step kernel (128 registers: 25 k cycles per walk, 16 us of tail).
 __global__ __launch_bounds__(64) void lazy_pwalk_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
     __shared__ float s_light[kNL + 1];
     __shared__ float4 s_ring[kMaxRings];
     __shared__ float2 s_saz[kMaxRings * kMaxAz];
     const JacBwdArgs& q = qs.j;
-    const int b = blockIdx.y;
+    // workgroup -> (image, wave of the image), the image running fastest: the waves that have entries (the first ones of every image) are
+    // then the first the dispatcher starts (image by image, the last image's would wait for 1800 empty workgroups: 5 us)
+    const int B = qs.batch, b = (int)blockIdx.x % B, wv = (int)blockIdx.x / B, nwv = (int)gridDim.x / B;
     const int P = g.H * g.W;
     const int nblk = lazy_fwd_blocks(P);
     const int lane = threadIdx.x;
+    const int shard = wv % kWalkShards, k0 = wv / kWalkShards, kstep = nwv / kWalkShards;
     RS_STAMP(0);
-    // one round trip for everything that depends on nothing: the stop flag, the queue's length, this wave's first chunk, the state, the tables
+    // one round trip for everything that depends on nothing: the stop flag, the list's length, this wave's first entries, the state, the tables
     const float stopped = qs.state_old[b * kStateStride + kStStopped];
-    const int n = (int)qs.walk_cnt[b * 4 + qs.walk_par];
-    const uint32_t* queue = qs.walk_queue + (long)b * walk_queue_chunks(P) * 8;
-    uint32_t pix = queue[(long)blockIdx.x * 8 + (lane >> 3)];               // (inside the queue's storage whatever n is)
+    const int n = (int)qs.walk_cnt[(b * 2 + qs.walk_par) * kWalkShards + shard];
+    const uint32_t* queue = qs.walk_queue + ((long)b * kWalkShards + shard) * walk_shard_cap(P);
+    uint32_t pix = queue[8 * k0 + (lane >> 3)];                             // (inside the list's storage whatever n is)
     const float* st = qs.state_new + b * kStateStride;                     // the state the step kernel has just committed
     const float ratio = st[kStRatio], gt_sum = st[kStGtSum], sel_f = st[kStSel];
     const float lt0 = light[(long)b * kNL + lane], lt1 = lane + 64 < kNL ? light[(long)b * kNL + lane + 64] : 0.0f;
     const float2 saz_v = (&tab.saz[0][0])[lane];
     const float4 ring_v = tab.sring[lane < kMaxRings ? lane : 0];
-    if (stopped > 0.5f || (int)blockIdx.x >= n) return;                    // the step kernel skipped the image / nothing for this wave (uniform)
+    if (stopped > 0.5f || 8 * k0 >= n) return;                             // the step kernel skipped the image / nothing for this wave (uniform)
     RS_STAMP(1);
     s_light[lane] = lt0 * kShNorm[lane / 3];
     if (lane + 64 < kNL) s_light[lane + 64] = lt1 * kShNorm[(lane + 64) / 3];
@@ -550,17 +545,13 @@ __global__ __launch_bounds__(64) void lazy_pwalk_kernel(const LazyStepArgs qs, c
     __syncthreads();
     const float floor_ = 0.5f * gt_sum / (3.0f * (float)P) / (ratio > 0.0f ? ratio : 1.0f);
     const float tol_k = qs.tol * kLzTolK, tol_s = qs.tol * kLzTolS;
-    const long BPl = (long)gridDim.y * P;
+    const long BPl = (long)B * P;
     const int sub = lane & 7;
-    for (int c = blockIdx.x; c < n; c += gridDim.x) {                      // (one pass unless the queue is longer than the grid)
-        if (c != (int)blockIdx.x) pix = queue[(long)c * 8 + (lane >> 3)];
-        const bool ok = pix != kWalkNone;
-        const uint32_t first = (uint32_t)__shfl((int)pix, 0);               // a chunk's first entry always exists
-        const int p = (int)(ok ? pix : first);
-#ifdef MATPBR_EXP_PWALK_DRY
-        if (ok && sub == 0 && p >= 0 && p < P) atomicAdd((unsigned long long*)(qs.walk_fix + (long)b * nblk + p / kLazyBlockPixels), 1ull);
-        continue;
-#endif
+    for (int k = k0; 8 * k < n; k += kstep) {                              // (one pass unless a list is longer than 8 gridDim.x / kWalkShards)
+        if (k != k0) pix = queue[8 * k + (lane >> 3)];
+        const bool ok = 8 * k + (lane >> 3) < n;
+        const int first = __shfl((int)pix, 0);                             // entry 8 k exists; (unconditionally: a shuffle inside the select below
+        const int p = ok ? (int)pix : first;                               //  would read lane 0 while it is masked off)
         RS_STAMP(2);
         float rs = 0.0f;
         resample_walk_pixel<true>(qs, sp, s_light, s_ring, s_saz, g, tab, b, P, BPl, p, ok, sub, floor_, tol_k, tol_s, rs);
