@@ -14,7 +14,9 @@
  *     theta = acos(y), phi = atan2(x,-z) (myutils/envmap_utils.py:29-36).
  *   - `stream` is the caller's hipStream_t (NULL = default stream).  Entry points only enqueue work:
  *     no allocation, no synchronisation, no global mutable state -> usable under hipGraph capture
- *     and re-entrant per stream.
+ *     and re-entrant per stream.  The ONE exception is declared as such: matpbr_mlp_set_lds_dma, a process-wide
+ *     measurement switch between three main loops of the 256-wide layer kernels that produce the same bits (two
+ *     relaxed atomics read at launch time; no result depends on it, nothing else in the library is global).
  *   - Return value: 0 = MATPBR_OK, negative = error (matpbr_strerror); nothing throws.
  *   - `spp` (even, 2..MATPBR_MAX_SPP) is the reference's samples-per-pixel argument
  *     (inverse_img_w_mi.py:59,69,625): here it sizes the deterministic quadrature rules of the two BRDF lobes
@@ -64,6 +66,9 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
                                         matpbr_brdf_phase_resolve before it reads pa / pr / pm / best_* / best_img / pred or starts the next part */
 #define MATPBR_FLAG_GENERIC_STEP 256u /* MatpbrBrdfPhase.flags: keep the pred_next step on the generic models even where the part has a folded form
                                         (`lazy_fold`): A/B measurements and tests of one form against the other */
+#define MATPBR_FLAG_JAC32 512u     /* matpbr_shade_fwd_lazy: `jac16` receives the NINE fp32 planes of matpbr_shade_fwd_ex's `jac` instead (matpbr_plane9_bytes()):
+                                        what matpbr_shade_bwd_jac reads -- the operator face (render_w_brdf under autograd, inverse_img_w_mi.py:69-80)
+                                        differentiates with full-precision P and S0 - S1 (d out / d m is a difference of the two) */
 #define MATPBR_FLAG_JAC16 32u      /* matpbr_brdf_loss_bwd_jac: `jac` holds the half-precision planes written by matpbr_shade_fwd_lazy */
 #define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
 #define MATPBR_PART_R 4u

@@ -1137,13 +1137,13 @@ static LazyBuffers lazy_buffers(void* lazy_state, long P, int batch) {
 // re-sample the pixels of the current work lists, rebuild their models, patch out / jac16 / sums
 static int lazy_refresh(const float* a, const float* r, const float* m, const float* n, const float* light, const float* dcache, void* lazy_state,
                         float* out_rgb, void* jac16, const float* stats, float* sums, const Geom& g, const RuleTable& tab, int batch, int clamp,
-                        int force, float floor_, float tol, hipStream_t st) {
+                        int force, float floor_, float tol, hipStream_t st, int jac32 = 0) {
     const long P = (long)g.H * g.W;
     const LazyBuffers lb = lazy_buffers(lazy_state, P, batch);
     LazyRefreshArgs ra{};
     ra.a = a; ra.r = r; ra.m = m; ra.n = n; ra.dcache = dcache; ra.state = lb.planes; ra.out = out_rgb; ra.jac16 = (uint32_t*)jac16; ra.stats = stats;
     ra.block_sums = sums; ra.counts = lb.counts; ra.lists = lb.lists; ra.clamp = clamp; ra.force = force; ra.n_sums = lb.nblk + lb.ngrp;
-    ra.n_fwd = lb.nblk; ra.nblk = lb.nblk; ra.floor = floor_; ra.tol = tol > 0.0f ? tol : 1.0f;
+    ra.n_fwd = lb.nblk; ra.nblk = lb.nblk; ra.floor = floor_; ra.tol = tol > 0.0f ? tol : 1.0f; ra.jac32 = jac32;
     if (tab.nphi_s <= 4)
         hipLaunchKernelGGL(lazy_refresh_kernel<4>, dim3((unsigned)lb.ngrp, (unsigned)batch), dim3(kBlock), 0, st, ra, light, g, tab);
     else
@@ -1152,15 +1152,15 @@ static int lazy_refresh(const float* a, const float* r, const float* m, const fl
 }
 static int lazy_forward(const float* a, const float* r, const float* m, const float* n, const float* light, const float* dcache, void* lazy_state,
                         float* out_rgb, void* jac16, const float* stats, float* sums, const Geom& g, const RuleTable& tab, int batch, int clamp,
-                        int force, float floor_, float tol, hipStream_t st) {
+                        int force, float floor_, float tol, hipStream_t st, int jac32 = 0) {
     const long P = (long)g.H * g.W;
     const LazyBuffers lb = lazy_buffers(lazy_state, P, batch);
     if (lb.nblk > kLazyMaxBlocks) return MATPBR_ERR_UNSUPPORTED;
     LazyFwdArgs fa{};
     fa.a = a; fa.r = r; fa.m = m; fa.state = lb.planes; fa.out = out_rgb; fa.jac16 = (uint32_t*)jac16; fa.stats = stats; fa.block_sums = sums;
-    fa.counts = lb.counts; fa.lists = lb.lists; fa.clamp = clamp; fa.force = force; fa.n_sums = lb.nblk + lb.ngrp;
+    fa.counts = lb.counts; fa.lists = lb.lists; fa.clamp = clamp; fa.force = force; fa.n_sums = lb.nblk + lb.ngrp; fa.jac32 = jac32;
     hipLaunchKernelGGL(lazy_fwd_kernel, dim3((unsigned)lb.nblk, (unsigned)batch), dim3(kBlock), 0, st, fa, (int)P);
-    return lazy_refresh(a, r, m, n, light, dcache, lazy_state, out_rgb, jac16, stats, sums, g, tab, batch, clamp, force, floor_, tol, st);
+    return lazy_refresh(a, r, m, n, light, dcache, lazy_state, out_rgb, jac16, stats, sums, g, tab, batch, clamp, force, floor_, tol, st, jac32);
 }
 
 int matpbr_shade_fwd_lazy(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind, int n_light,
@@ -1175,7 +1175,7 @@ int matpbr_shade_fwd_lazy(const float* a, const float* r, const float* m, const 
     if (!make_geom(H, W, cam, g)) return MATPBR_ERR_INVALID_ARG;
     if (!fill_rule_table(spp, tab)) return MATPBR_ERR_UNSUPPORTED;
     return lazy_forward(a, r, m, n, light, dcache, lazy_state, out_rgb, jac16, stats, sums, g, tab, batch, (flags & MATPBR_FLAG_CLAMP_PARAMS) ? 1 : 0,
-                        (flags & MATPBR_FLAG_LAZY_FORCE) ? 1 : 0, floor_, tol, (hipStream_t)stream);
+                        (flags & MATPBR_FLAG_LAZY_FORCE) ? 1 : 0, floor_, tol, (hipStream_t)stream, (flags & MATPBR_FLAG_JAC32) ? 1 : 0);
 }
 
 int matpbr_lazy_state_unpack(const void* lazy_state, float* state22, int* refreshed, int H, int W, int batch, void* stream) {

@@ -105,6 +105,7 @@ struct LazyFwdArgs {
     uint32_t* counts;
     uint16_t* lists;
     int clamp, force, n_sums;
+    int jac32;                // `jac16` holds NINE fp32 planes instead (P, SD, d out / d r: the layout of matpbr_shade_fwd_ex's jac)
 };
 
 __global__ __launch_bounds__(kBlock) void lazy_fwd_kernel(const LazyFwdArgs q, int P) {
@@ -152,11 +153,20 @@ __global__ __launch_bounds__(kBlock) void lazy_fwd_kernel(const LazyFwdArgs q, i
             const f2 C0 = vfma(m, a[c], omm * 0.04f);                                // :1412
             const f2 rgb = vfma(a[c] * omm, Pc, vfma(C0, SD, S1));
             JR[c] = vfma(a[c] * omm, dP, vfma(C0, f2{h2_lo(dk0), h2_lo(dk1)}, f2{h2_hi(dk0), h2_hi(dk1)}));
-            if (act0 && !need0) { q.out[i0 * 3 + c] = rgb.x; q.jac16[c * BP + i0] = pack_h2(Pc.x, SD.x); tot += rgb.x; }
-            if (two && !need1) { q.out[i1 * 3 + c] = rgb.y; q.jac16[c * BP + i1] = pack_h2(Pc.y, SD.y); tot += rgb.y; }
+            if (act0 && !need0) { q.out[i0 * 3 + c] = rgb.x; tot += rgb.x; }
+            if (two && !need1) { q.out[i1 * 3 + c] = rgb.y; tot += rgb.y; }
+            if (q.jac32) {
+                if (act0 && !need0) { q.jac16[c * BP + i0] = as_u(Pc.x); q.jac16[(3 + c) * BP + i0] = as_u(SD.x); q.jac16[(6 + c) * BP + i0] = as_u(JR[c].x); }
+                if (two && !need1) { q.jac16[c * BP + i1] = as_u(Pc.y); q.jac16[(3 + c) * BP + i1] = as_u(SD.y); q.jac16[(6 + c) * BP + i1] = as_u(JR[c].y); }
+            } else {
+                if (act0 && !need0) q.jac16[c * BP + i0] = pack_h2(Pc.x, SD.x);
+                if (two && !need1) q.jac16[c * BP + i1] = pack_h2(Pc.y, SD.y);
+            }
         }
-        if (act0 && !need0) { q.jac16[3 * BP + i0] = pack_h2(JR[0].x, JR[1].x); q.jac16[4 * BP + i0] = pack_h2(JR[2].x, 0.0f); }
-        if (two && !need1) { q.jac16[3 * BP + i1] = pack_h2(JR[0].y, JR[1].y); q.jac16[4 * BP + i1] = pack_h2(JR[2].y, 0.0f); }
+        if (!q.jac32) {
+            if (act0 && !need0) { q.jac16[3 * BP + i0] = pack_h2(JR[0].x, JR[1].x); q.jac16[4 * BP + i0] = pack_h2(JR[2].x, 0.0f); }
+            if (two && !need1) { q.jac16[3 * BP + i1] = pack_h2(JR[0].y, JR[1].y); q.jac16[4 * BP + i1] = pack_h2(JR[2].y, 0.0f); }
+        }
     }
     // the pixels that left their interval, compacted in a fixed order (wave, then first / second pixel of the lanes): the list's
     // order never enters a result, and it is reproducible all the same
@@ -879,6 +889,7 @@ struct LazyRefreshArgs {
     const uint16_t* lists;
     int clamp, force, n_sums, n_fwd, nblk;
     float floor, tol;
+    int jac32;                // as LazyFwdArgs
 };
 
 constexpr int kLazyMaxBlocks = 8192;   // forward workgroups per image whose counts fit the LDS prefix (512 x 8192 pixels = 2048 x 2048)
@@ -1062,10 +1073,11 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     const float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
                     q.out[i * 3 + c] = rgb;
                     tot += rgb;
-                    if (q.jac16) q.jac16[c * BP + i] = pack_h2(Pc[c], vSD[c]);
                     jr[c] = fmaf(kd[c], dP[c], fmaf(C0[c], dSD[c], dS1v[c]));
+                    if (q.jac16 && q.jac32) { q.jac16[c * BP + i] = as_u(Pc[c]); q.jac16[(3 + c) * BP + i] = as_u(vSD[c]); q.jac16[(6 + c) * BP + i] = as_u(jr[c]); }
+                    else if (q.jac16) q.jac16[c * BP + i] = pack_h2(Pc[c], vSD[c]);
                 }
-                if (q.jac16) {
+                if (q.jac16 && !q.jac32) {
                     q.jac16[3 * BP + i] = pack_h2(jr[0], jr[1]);
                     q.jac16[4 * BP + i] = pack_h2(jr[2], 0.0f);
                 }

@@ -20,6 +20,7 @@ FLAG_JAC16 = 32
 FLAG_MODELS_READY = 64
 FLAG_ROTATE_BEST = 128
 FLAG_GENERIC_STEP = 256
+FLAG_JAC32 = 512
 LAZY_NSTATE = 22
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
@@ -186,7 +187,8 @@ def lazy_state(a: torch.Tensor) -> torch.Tensor:
 
 def shade_fwd_lazy(a, r, m, n, light, spp: int, dcache: torch.Tensor, state: torch.Tensor, out: Optional[torch.Tensor] = None,
                    jac16: Optional[torch.Tensor] = None, force: bool = False, clamp_params: bool = False, floor: Optional[float] = None,
-                   stats: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None, tol: float = 1.0, fov_x_deg: float = 35.0):
+                   stats: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None, tol: float = 1.0, fov_x_deg: float = 35.0,
+                   jac32: bool = False):
     """The render from per-pixel local models in the roughness (include/matpbr.h `matpbr_shade_fwd_lazy`): pixels whose roughness is
     still inside the validity interval of their model are a streaming evaluation, the others are re-sampled and their models rebuilt
     in `state` (from `lazy_state`).  `force=True` on the first call (and whenever light / normals / dcache changed).  Returns
@@ -208,12 +210,12 @@ def shade_fwd_lazy(a, r, m, n, light, spp: int, dcache: torch.Tensor, state: tor
         raise ValueError("shade_fwd_lazy: give the mean-radiance floor of the parity scale (or the statistics buffer)")
     if out is None:
         out = torch.empty_like(a)
-    if jac16 is None:
-        jac16 = torch.empty((5, B, H, W), dtype=torch.int32, device=a.device)
+    if jac16 is None:      # jac32: the nine fp32 planes of `shade_fwd(jac=...)` instead (what `shade_bwd_jac` reads)
+        jac16 = torch.empty((9, B, H, W), dtype=torch.float32, device=a.device) if jac32 else torch.empty((5, B, H, W), dtype=torch.int32, device=a.device)
     if sums is not None and sums.numel() < B * int(lib.matpbr_lazy_sums_count(H, W)):
         raise ValueError("shade_fwd_lazy: sums too small")
     cam = MatpbrCamera(float(fov_x_deg))
-    flags = (FLAG_CLAMP_PARAMS if clamp_params else 0) | (FLAG_LAZY_FORCE if force else 0)
+    flags = (FLAG_CLAMP_PARAMS if clamp_params else 0) | (FLAG_LAZY_FORCE if force else 0) | (FLAG_JAC32 if jac32 else 0)
     with torch.cuda.device(a.device), _timed("shade_fwd"):
         code = lib.matpbr_shade_fwd_lazy(_ptr(a), _ptr(r), _ptr(m), _ptr(n), _ptr(light), LIGHT_SH25, NSH, _ptr(dcache), _ptr(state), _ptr(out),
                                          _ptr(jac16), _ptr(stats), _ptr(sums), H, W, B, check_spp(spp), ctypes.byref(cam), flags,

@@ -67,6 +67,45 @@ class _ShadeFn(torch.autograd.Function):
                 d_n if need[3] else None, d_l if need[4] else None, None, None, None)
 
 
+# What the operator face keeps between calls (the scene is stateful -- "the arguments of one call persist for the next").  The
+# reference's loop calls render_w_brdf thousands of times under ONE light and ONE set of shading normals (inverse_img_w_mi.py:317-342,
+# 384-386, 513-515), so everything that depends on (normals, view, light) alone is computed once per (light, normals) VERSION -- tensor
+# identity + autograd version counter, so an in-place optimiser step on either invalidates it -- and reused:
+#   "none"     every call walks both lobes of every pixel (rounds 1-3)
+#   "diffuse"  the nine diffuse-lobe coefficients per pixel (matpbr_diffuse_cache): calls walk the GGX samples only
+#   "lazy"     (default) additionally the per-pixel local models in the roughness of matpbr_shade_fwd_lazy, for calls that need material
+#              gradients only: the forward pass renders from the models (pixels whose roughness left its model's interval are re-sampled:
+#              |render - exact| <= 1e-3 max(|exact|, mean|exact|), tests/test_gpu_lazy.py), the backward pass streams the jac planes it leaves
+# Calls that need d/d normal or d/d light, and scenes with ATTACHED_SAMPLING, take the round-3 path.
+OPERATOR_CACHE = "lazy"
+
+
+class _ShadeLazyFn(torch.autograd.Function):
+    """R(a, r, m | n, light fixed) from the scene's cached models; gradients w.r.t. the materials only."""
+
+    @staticmethod
+    def forward(ctx, a, r, m, n, light, spp, fov, cache):
+        a, r, m = (t.contiguous() for t in (a, r, m))
+        out, jac = ops.shade_fwd_lazy(a, r, m, n, light, spp, cache["dcache"], cache["state"], force=cache["fresh"], stats=cache["stats"],
+                                      fov_x_deg=fov, jac32=True)
+        if cache["fresh"]:
+            # the parity floor of later calls: half the mean radiance of this (exact) render, per image, kept on the device
+            B = cache["stats"].shape[0]
+            cache["stats"][:, ops.STAT_GT_SUM] = out.reshape(B, -1).sum(dim=1)
+            cache["fresh"] = False
+        ctx.save_for_backward(a, r, m)
+        ctx.jac = jac
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        a, r, m = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        d_a, d_r, d_m = ops.shade_bwd_jac(a, r, m, ctx.jac, d_out.contiguous())
+        return (d_a if need[0] else None, d_r.reshape(r.shape) if need[1] else None, d_m.reshape(m.shape) if need[2] else None,
+                None, None, None, None, None)
+
+
 class SceneParameters(dict):
     """`mi.traverse(scene)` stand-in: assignment stores, `update()` is accepted for source compatibility."""
 
@@ -114,6 +153,9 @@ class Scene:
         self.light[..., 0, :] = float(np.sqrt(4 * np.pi))  # unit white radiance until the caller sets emitter.data
         self.emitter_data = self.light
         self._ws = {"ws": None}
+        self._cache: Optional[dict] = None               # OPERATOR_CACHE: what was computed for (light, normals) of `_cache["key"]`
+        self._seen_key = None
+        self.cache_builds = 0                            # how many times it was (re)built (tests, profiling)
         self.bg_mask: Optional[torch.Tensor] = None      # [H,W] bool: pixels without geometry (mesh_mask.png)
         self.bg_basis: Optional[torch.Tensor] = None     # [H*W,25]: Y_k(camera ray) on those pixels, 0 elsewhere
 
@@ -180,6 +222,28 @@ class Scene:
         # use_mesh_normal=True shades with the geometric normal, not the n map (F10; mi_plugin.py:1386-1389)
         return self.geo_normal if self.use_mesh_normal else self.n
 
+    def _cached(self, light: torch.Tensor, nrm: torch.Tensor, spp: int) -> Optional[dict]:
+        """The per-(light, normals) cache, rebuilt when either changed (identity or in-place version) or `spp` did.  None when the light or
+        the normals take part in autograd (they are not constants of the call) or caching is off."""
+        if OPERATOR_CACHE == "none" or ATTACHED_SAMPLING or light.requires_grad or nrm.requires_grad or not light.is_cuda:
+            return None
+        key = (light.data_ptr(), light._version, tuple(light.shape), nrm.data_ptr(), nrm._version, int(spp), self.fov)
+        if self._cache is not None and self._cache["key"] == key:
+            return self._cache
+        if key != self._seen_key:          # a light used once (an env-phase iteration, a relit frame) is not worth nine planes per pixel:
+            self._seen_key = key           # the cache is built when the same (light, normals) come back
+            self._cache = None
+            return None
+        if True:
+            lc, nc = light.detach().contiguous(), nrm.detach().contiguous()
+            stats = ops.new_loss_stats(self.B, self.device)
+            stats[:, ops.STAT_RATIO] = 1.0
+            stats[:, ops.STAT_GT_SUM] = 1e-6          # first (forced) build: every interval against the render itself (a conservative floor)
+            self._cache = {"key": key, "light": lc, "n": nc, "dcache": ops.diffuse_cache(nc, lc, int(spp), self.fov), "state": None,
+                           "stats": stats, "fresh": True}
+            self.cache_builds += 1
+        return self._cache
+
     def render(self, spp: int) -> torch.Tensor:
         shp = (self.B, self.H, self.W) if self.B > 1 else (self.H, self.W)
         light = self.light
@@ -187,7 +251,19 @@ class Scene:
             light = light.unsqueeze(0).expand(self.B, -1, -1)
         r = self.r.reshape(shp + (1,))
         m = self.m.reshape(shp + (1,))
-        img = _ShadeFn.apply(self.a, r, m, self.shading_normal(), light, int(spp), self.fov, self._ws)
+        nrm = self.shading_normal()
+        cache = self._cached(light, nrm, spp)
+        want_mat = torch.is_grad_enabled() and any(t.requires_grad for t in (self.a, r, m))
+        if cache is not None and want_mat and OPERATOR_CACHE == "lazy":
+            if cache["state"] is None:
+                cache["state"] = ops.lazy_state(cache["n"])
+            img = _ShadeLazyFn.apply(self.a, r, m, cache["n"], cache["light"], int(spp), self.fov, cache)
+        elif cache is not None and not want_mat:
+            # no gradient asked for: the exact render, GGX samples only (the diffuse lobe from its cached coefficients)
+            img = ops.shade_fwd(self.a.detach().contiguous(), r.detach().contiguous(), m.detach().contiguous(), cache["n"], cache["light"],
+                                int(spp), self.fov, dcache=cache["dcache"])
+        else:
+            img = _ShadeFn.apply(self.a, r, m, nrm, light, int(spp), self.fov, self._ws)
         if self.bg_mask is not None:
             img = torch.where(self.bg_mask.unsqueeze(-1), self.background_radiance(light), img)
         return img

@@ -353,15 +353,24 @@ def test_rccl_path_of_the_bench_at_world_size_one():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--force-dist", "--gpus", "1", "--mode", "fused", "--images-per-gpu", "8", "--no-extras", "--no-cpu-baseline",
-           "--steps", "30", "--warmup", "5"]
+           "--steps", "300", "--warmup", "10"]           # the default line's `fused_b8` protocol (a phase's first iterations re-sample the most)
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)      # a child process: never an exec from a GPU-initialised one
     assert res.returncode == 0, res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["world_size"] == 1 and out["n_gpus"] == 1 and out["collective_backend"] == "nccl"
     assert out["config"]["images_per_gpu"] == 8 and out["config"]["mode"] == "fused"
-    assert out["value"] == pytest.approx(30 * 8 / (out["ms_per_step"] * 30 * 1e-3), rel=1e-6)       # image-iterations/s over all ranks
+    assert out["value"] == pytest.approx(300 * 8 / (out["ms_per_step"] * 300 * 1e-3), rel=1e-6)     # image-iterations/s over all ranks
     assert len(out["ranks"]) == 1 and out["value"] > 1000
+    assert out["cold_first_process_it_per_s"] > 0
+    # the same workload is `modes.fused_b8` of the default line (one rank, no RCCL): the two agree up to the run-to-run spread of a box
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-relight", "--steps", "5", "--warmup", "2"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    default = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    b8 = default["modes"]["fused_b8"]
+    assert b8["images_per_gpu"] == 8 and out["value"] == pytest.approx(b8["it_per_s"], rel=0.25), (out["value"], b8["it_per_s"])
+    assert default["roofline"]["frac"] > 0.3 and default["cold_first_process_it_per_s"] > 0
 
 
 def test_run_batch_takes_predictions_and_runs_a_shard_of_photographs_as_one_batch(golden_dir, tmp_path):

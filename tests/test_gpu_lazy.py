@@ -140,23 +140,60 @@ def _phase_setup(dev, H, W, spp, image_id=0):
     return scene, gt, init
 
 
-def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_iteration():
-    """THE GATE: 2 000 iterations of part 'rm' at 512 x 512 (lr schedule of inverse_img_w_mi.py:363-365,431-432).  Every iteration's
-    lazy render (of the parameters the step before it wrote) against the exact render of the same parameters; d out / d r of the just re-sampled pixels against the exact jac."""
+def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_iteration(oracle64):
+    """THE GATE: 2 000 iterations of part 'rm' at 512 x 512 (lr schedule of inverse_img_w_mi.py:363-365,431-432), on the default path (the
+    folded, persistent step).  Every iteration's lazy render (of the parameters the step before it wrote) against the exact render of the same
+    parameters; d out / d r of the just re-sampled pixels against the exact jac; every 50th iteration the loss GRADIENTS the step formed
+    (d loss / d r, d loss / d m, every pixel) against the streaming backward pass on the exact jac of the same parameters; and at iteration
+    500 the render of a 64 x 64 window against the oracle's evaluation of the models as they stand (the specification, fp64)."""
     from materialist_amd import loop, ops
 
     dev = _cuda()
     H = W = 512
     spp, iters = 64, 2000
     scene, gt, init = _phase_setup(dev, H, W, spp)
-    ph = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp, lazy=True, history_len=iters)
-    assert ph.lazy and ph.lazy_state is not None
+    ph = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp, lazy=True, history_len=iters, keep_grads=True)
+    assert ph.lazy and ph.lazy_state is not None and ph.fold
     worst = torch.zeros((), device=dev)
     worst_dr = torch.zeros((), device=dev)
+    worst_g = {k: {"max": 0.0, "l2": 0.0, "median": 0.0, "cos": 1.0} for k in ("roughness", "metallic")}
     nref = torch.zeros(iters, device=dev)
     exact, jac = torch.empty_like(gt), ops.plane9(gt)
+    g_ref = {k: torch.empty_like(v) for k, v in ph.g.items()}
     for it in range(iters):
+        if it % 50 == 0:          # the parameters this step differentiates at
+            p_at = [ph.p[k].clone() for k in ("albedo", "roughness", "metallic")]
         ph.step()
+        if it % 50 == 0:
+            # the same gradient from the exact jac of these parameters, the statistics row the step committed (ratio, l1 / mse) and the
+            # same regularisers / clamp gating: matpbr_brdf_loss_bwd_jac, the backward pass of the loop that walks every sample
+            ops.shade_fwd(*p_at, ph.n, ph.light, spp, clamp_params=True, out=exact, dcache=ph.dcache, jac=jac)
+            ops.brdf_loss_bwd_jac(*p_at, jac, exact, ph.gt_srgb, ph.stats, ph.orig["albedo"], ph.orig["roughness"], ph.orig["metallic"], 0.1,
+                                  g_ref["albedo"], g_ref["roughness"], g_ref["metallic"], optimize_part="rm")
+            for k, w in worst_g.items():
+                e = (ph.g[k] - g_ref[k]).abs() / torch.maximum(g_ref[k].abs(), g_ref[k].abs().mean())
+                w["max"] = max(w["max"], float(e.max()))
+                w["median"] = max(w["median"], float(e.median()))
+                w["l2"] = max(w["l2"], float((ph.g[k] - g_ref[k]).norm() / g_ref[k].norm()))
+                w["cos"] = min(w["cos"], float((ph.g[k] * g_ref[k]).sum() / (ph.g[k].norm() * g_ref[k].norm())))
+        if it == 500:
+            # the specification on a window of the state as it stands: the oracle evaluates the (generic) models of these pixels at the
+            # current parameters; pixels it would re-sample (their roughness sits on an interval's edge) are left out
+            st, _ = ops.lazy_state_unpack(ph.lazy_state, ph.p["albedo"])
+            i0, j0, n = 200, 300, 64
+            win = lambda x: x.reshape(H, W, -1)[i0:i0 + n, j0:j0 + n].reshape(n * n, -1).cpu().numpy().astype(np.float64)
+            ii, jj = np.meshgrid(np.arange(i0, i0 + n), np.arange(j0, j0 + n), indexing="ij")
+            f = (0.5 * W) / np.tan(0.5 * np.deg2rad(35.0))
+            wo = np.stack([(0.5 * (W - 1) - jj) / f, (ii - 0.5 * (H - 1)) / f, np.ones_like(ii, dtype=np.float64)], -1).reshape(-1, 3)
+            wo /= np.linalg.norm(wo, axis=-1, keepdims=True)
+            cm = ph.current_maps()
+            st_w = np.ascontiguousarray(win(st[0]))
+            out_o, _, ref_o = oracle64.lazy_fwd_lanes(win(cm["albedo"]), win(cm["roughness"]), win(cm["metallic"]), win(ph.n), wo,
+                                                      ph.light.cpu().numpy().astype(np.float64), st_w, spp, 0.5 * float(gt.mean()))
+            keep = ref_o == 0
+            got = win(ph.pred)
+            e_spec = np.abs(got - out_o)[keep] / (np.abs(out_o)[keep] + np.abs(out_o).mean())
+            assert keep.mean() > 0.9 and e_spec.max() < 2e-4, (keep.mean(), e_spec.max())
         # the step's last launch has rendered the parameters it has just written (what the next iteration judges): `pred`
         pa, pr, pm = ph.p["albedo"].clone(), ph.p["roughness"].clone(), ph.p["metallic"].clone()
         ops.shade_fwd(pa, pr, pm, ph.n, ph.light, spp, clamp_params=True, out=exact, dcache=ph.dcache, jac=jac)
@@ -179,8 +216,17 @@ def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_
     nref = nref.cpu().numpy()
     print(f"lazy gate: worst |lazy - exact| / scale over {iters} iterations = {float(worst):.3e}; d_r at refresh points {float(worst_dr):.3e}; "
           f"re-sampled fraction: first 100 its {nref[1:100].mean():.4f}, 100-500 {nref[100:500].mean():.4f}, 500-2000 {nref[500:].mean():.4f}")
+    print("lazy gate: loss gradients against the exact backward pass, worst of 40 checks (every 50th iteration, every pixel): " +
+          "; ".join(f"{k}: rel. L2 {w['l2']:.4f}, cosine {w['cos']:.6f}, median pixel {w['median']:.2e}, worst pixel {w['max']:.3f}" for k, w in worst_g.items()))
     assert float(worst) <= 1e-3
     assert float(worst_dr) <= 2e-3
+    # What the models guarantee is the RENDER (their intervals bound its error); between two re-samplings the gradients are those of the
+    # model: d out / d r is the detached derivative at r_ref (zeroth order in r - r_ref, half precision) and d out / d m weighs S0 - S1 by
+    # (a - 0.04) where the render weighs it by C0 ~ 0.05.  As a FIELD the gradient stays within 5 % (d_r) / 1 % (d_m) in L2 of the exact one, with single
+    # pixels near a highlight further off (DESIGN.md section 5 records the measured values); the first iteration of a part (r = r_ref) is exact
+    # to 2e-3.  The reference's own gradient is a 64-sample Monte-Carlo estimate (relative error 5-90 % per component).
+    assert worst_g["roughness"]["l2"] <= 6e-2 and worst_g["roughness"]["cos"] >= 0.998 and worst_g["roughness"]["median"] <= 5e-4, worst_g
+    assert worst_g["metallic"]["l2"] <= 1.5e-2 and worst_g["metallic"]["cos"] >= 0.9999 and worst_g["metallic"]["median"] <= 1e-5, worst_g
     assert nref[0] == 1.0 and nref[1:].mean() < 0.1
 
 

@@ -346,6 +346,59 @@ def test_autograd_operator_face(oracle64):
     assert_close(img2, oracle64.shade_fwd(sc.albedo, sc.roughness, sc.metallic, geo, coef, spp), what="mesh-normal render")
 
 
+def test_operator_face_keeps_its_models_between_calls_and_rebuilds_them_when_the_light_changes():
+    """render_w_brdf called again and again under one light (the reference's BRDF loop, inverse_img_w_mi.py:384-386): from the second call
+    with the same (light, normals) on, the scene renders from cached per-pixel models and differentiates through their jac planes -- within
+    1e-3 of the exact render, 3e-3 of the exact d_a / d_m and 3e-2 of the exact d_r (worst pixel); a new light (another tensor, or the same tensor modified in place)
+    invalidates the cache, and the renders follow the new light."""
+    from materialist_amd import ops, render
+
+    dev = _cuda()
+    H, W, spp = 64, 96, 64
+    sc, n = _scene_arrays(H, W, image_id=6)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    nrm = scene.shading_normal()
+    L1 = _t(sc.light, dev)
+    L2 = (L1 * 0.7 + 0.05 * torch.randn_like(L1)).contiguous()
+    L2[0] = L1[0]
+    scene._set("emitter.data", L1)
+    a0, r0, m0 = (_t(x, dev) for x in (sc.albedo, sc.roughness, sc.metallic))
+
+    def call(light, step):
+        a, r, m = (x.clone().requires_grad_(True) for x in (a0, (r0 + 2e-4 * step).clamp(0.07, 1.0), m0))
+        img = render.render_w_brdf(scene, a, r, m, None, spp)
+        g_out = torch.ones_like(img)
+        img.backward(g_out)
+        jac = ops.plane9(a0)
+        exact = ops.shade_fwd(a.detach(), r.detach(), m.detach(), nrm, light, spp, jac=jac)
+        d_a, d_r, d_m = ops.shade_bwd_jac(a.detach(), r.detach(), m.detach(), jac, g_out)
+        e_img = float(((img.detach() - exact).abs() / torch.maximum(exact.abs(), exact.abs().mean())).max())
+        err = lambda got, ref: float(((got - ref.reshape(got.shape)).abs() / torch.maximum(ref.abs(), ref.abs().mean()).reshape(got.shape)).max())
+        # d out / d r of a model is the detached derivative AT ITS REFERENCE ROUGHNESS (half precision, zeroth order in r - r_ref, as in the
+        # fused loops): a few 1e-3 a step away from r_ref where the specular sums bend fastest; d_a and d_m come from fp32 P and S0 - S1
+        return e_img, max(err(a.grad, d_a), err(m.grad, d_m), err(r.grad, d_r) / 10.0)
+
+    for step in range(4):                       # call 0: a light seen for the first time (direct); call 1 builds the cache; 2, 3 render from it
+        e_img, e_g = call(L1, step)
+        assert e_img < 1e-3 and e_g < 3e-3, (step, e_img, e_g)
+    assert scene.cache_builds == 1
+    scene._set("emitter.data", L2)              # another light: the models of L1 must not be used
+    for step in range(3):
+        e_img, e_g = call(L2, step)
+        assert e_img < 1e-3 and e_g < 3e-3, ("L2", step, e_img, e_g)
+    assert scene.cache_builds == 2
+    L2.mul_(1.25)                               # the same tensor, modified in place (an optimiser step): a new version
+    for step in range(3):
+        e_img, e_g = call(L2, step)
+        assert e_img < 1e-3 and e_g < 3e-3, ("L2 in place", step, e_img, e_g)
+    assert scene.cache_builds == 3
+    # a call without gradients under a cached light: the exact render (GGX samples + cached diffuse coefficients)
+    with torch.no_grad():
+        img = render.render_w_brdf(scene, a0, r0, m0, None, spp)
+    exact = ops.shade_fwd(a0, r0, m0, nrm, L2, spp)
+    assert float(((img - exact).abs() / torch.maximum(exact.abs(), exact.abs().mean())).max()) < 2e-5
+
+
 # ------------------------------------------------------------------------- size-independent properties @ 512^2
 def test_full_size_properties():
     from materialist_amd import ops, synthetic
