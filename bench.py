@@ -353,10 +353,12 @@ def main(argv=None):
             modes["fused_b8_a"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
             e_el, _ = proto.timed(wl8.phase("fused_exact").step, 10, 100)
             modes["fused_b8_exact"] = {"it_per_s": 100 * 8 * world / e_el, "ms_per_step": e_el / 100 * 1e3, "images_per_gpu": 8}
-    mode_names = {"fused": "hot loop B, --model_name none, whole iteration in libmatpbr.so, TWO launches: the partial sums of the loss statistics, "
-                           "then ONE launch that folds them (every workgroup, fixed order), commits SaveBest / EarlyStopping and runs the backward pass, "
-                           "Adam and the next iteration's render from per-pixel local models in the roughness (pixels that left their model's interval "
-                           "are re-sampled in the same launch; |render - exact sampling| <= 1e-3 on every pixel of every iteration, tests/test_gpu_lazy.py)",
+    mode_names = {"fused": "hot loop B, --model_name none, whole iteration in libmatpbr.so, THREE launches in a part that moves the roughness, two otherwise: the "
+                           "partial sums of the loss statistics; the folded, persistent step (csrc/matpbr_pstep.hpp: at most 1024 workgroups stream the image "
+                           "from two register sets, fold the statistics, commit SaveBest / EarlyStopping, run the backward pass, Adam and the next iteration's "
+                           "render from per-pixel models into which the maps the part leaves alone are folded); the walk of the pixels that left their "
+                           "model's interval, eight per wave from a queue (|render - exact sampling| <= 1e-3 on every pixel of every iteration, "
+                           "tests/test_gpu_lazy.py)",
                   "fused_exact": "the same loop walking the 20 GGX samples of every pixel in every iteration (round 2: render+jac, statistics, streaming backward+Adam)",
                   "fused_b8_exact": "the 8-image shard with exact sampling in every iteration (round 2's fused_b8)",
                   "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
@@ -465,19 +467,20 @@ def main(argv=None):
         key = f"{H}x{W}_b{wr.B}_spp{args.spp}"
         t_step, t_stats, resampled, t_res = lazy_step_times(wr)
         ach = (BYTES_FWD + BYTES_BWD_ARM) * px / (t_step * 1e-3) / 1e9
-        traffic = pmc.get(f"lazy_step_{key}")
-        roof = {"bound": "hbm", "kernel": "lazy_step_kernel: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, SaveBest "
-                                          "by buffer rotation, Adam) + render of iteration t+1 from per-pixel local models in the roughness; the pixels "
-                                          "that left their model's interval are listed and re-sampled (20 GGX samples) by the small launch behind it "
-                                          "(resample_launch_ms)",
+        traffic = pmc.get(f"lazy_pstep_{key}")
+        roof = {"bound": "hbm", "kernel": "lazy_pstep_kernel<kFoldXY>: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, "
+                                          "SaveBest by buffer rotation, Adam) + render of iteration t+1 from per-pixel local models in the roughness with the part's "
+                                          "constant albedo folded in (64 B/pixel of model); the pixels that left their model's interval are queued and re-sampled "
+                                          "(20 GGX samples) by the small launch behind it (resample_launch_ms)",
                 "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / (HBM_PEAK / 1e9), "avg_launch_ms": t_step,
                 "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM,
                 "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
                 "resampled_fraction": resampled, "stats_launches_ms": t_stats, "resample_launch_ms": t_res,
-                "traffic": traffic, "traffic_source": pmc.get("source_r03") if traffic else None,
+                "traffic": traffic, "traffic_source": pmc.get("source_r04") if traffic else None,
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "
-                        "really moves per launch (PMC: maps, the 80 B/pixel models, target, the next render, anchors, Adam moments), "
+                        "really moves per launch (PMC; by construction 144 B/pixel in an 'rm' part: r, m read and written 16, the folded models 64, target 12, the "
+                        "next render 12, anchors 8, Adam moments 32), "
                         "own_traffic_frac = traffic / duration / peak: how close the launch is to the HBM limit on its OWN bytes"}
         ex = entry(px, tk["fwd_loop"], tk["bwd_loop"],
                    "round 2's pair (FusedBrdfPhase(lazy=False)): shade_kernel<jac> walks the 20 GGX samples of every pixel (cached diffuse lobe) + "
@@ -504,7 +507,7 @@ def main(argv=None):
             t1, ts1, rs1, tr1 = lazy_step_times(wl)
             a1 = (BYTES_FWD + BYTES_BWD_ARM) * H * W * wl.B / (t1 * 1e-3) / 1e9
             roof["single_image"] = {"achieved": a1, "frac": a1 / (HBM_PEAK / 1e9), "avg_launch_ms": t1, "stats_launches_ms": ts1, "resample_launch_ms": tr1, "resampled_fraction": rs1,
-                                    "note": f"lazy_step_kernel on {wl.B} x {H}x{W} (working set inside the 256 MB Infinity Cache: launch-latency territory)"}
+                                    "note": f"lazy_pstep_kernel on {wl.B} x {H}x{W} (working set inside the 256 MB Infinity Cache: launch-latency territory)"}
         # hot loop A: one pass over the radiance transfer per iteration (HBM-bound by construction)
         ph_e = wl.phase("env") if B == 1 else None
         if ph_e is not None:
@@ -558,16 +561,25 @@ def main(argv=None):
                 "forward_sincos": {"avg_launch_ms": ms_fwd, "achieved": tf(ms_fwd)},
                 "bwd_input_mulcos_colsum": {"avg_launch_ms": ms_din, "achieved": tf(ms_din)},
                 "bwd_weight": {"avg_launch_ms": ms_dw, "achieved": tf(ms_dw)}}
-        gemm = {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
-                "peak_note": "dense f32 MFMA peak; 'achieved' counts f32-equivalent flop (2 M N K per product).  The split-operand kernels "
-                             "issue 6 bf16 MFMA products per f32 product (bf16 dense peak 2500): their own matrix-pipe fraction is 6 x achieved / 2500",
-                "kernel": "mlp_nt_bx<sincos> / <mul cos> / mlp_wgrad_bx: [H*W,256]x[256,256], operands split into three bf16 pieces, f32 accumulate"
-                          if bx else f32k["kernel"],
-                "achieved": (bx or f32k)["achieved"], "split_operand": bx, "exact_f32": f32k,
-                "blas_product_same_shape": {"avg_launch_ms": ms_g, "achieved": tf(ms_g), "kernel": "hipBLASLt f32 (PyTorch-ROCm), no epilogue"}}
-        gemm["frac"] = gemm["achieved"] / gemm["peak"]
         if bx:
-            gemm["bf16_pipe_frac"] = P * bx["achieved"] / 2500.0
+            # the kernels the iteration runs issue P bf16 MFMA products per f32 product: their roofline is the bf16 matrix pipe
+            gemm = {"bound": "mfma", "unit": "TFLOP/s", "peak": 2500.0, "achieved": P * bx["achieved"],
+                    "peak_note": f"dense bf16 MFMA peak; `achieved` = the bf16 matrix-pipe flop the split-operand kernels issue ({P} partial products per f32 "
+                                 "product, v_mfma_f32_32x32x16_bf16, f32 accumulate) per second, epilogues included.  In f32-EQUIVALENT terms (2 M N K per "
+                                 f"product) that is `f32_equivalent.achieved`; its ceiling is 2500 / {P} TFLOP/s, not the 157.3 of the f32 pipe",
+                    "kernel": "mlp_nt_gx<sincos> / <mul cos> / mlp_wgrad_bx: [H*W,256]x[256,256], operands split into three bf16 pieces, f32 accumulate",
+                    "f32_equivalent": {"achieved": bx["achieved"], "ceiling_of_the_scheme": 2500.0 / P, "f32_mfma_peak_for_reference": 157.3},
+                    "split_operand": bx, "exact_f32": f32k,
+                    "stand_alone_vs_in_loop": "these legs run each kernel 20 times back to back on N(0,1) data: 255-270 us per forward layer, against 200-215 us "
+                                              "for the same launch inside the traced iteration.  Measured (tools/layer_gap.py): the same kernel on zeros 205 us, on "
+                                              "sin(.) inputs 255 us, on N(0,1) 269 us (the chip holds a lower clock under sustained matrix work on wide-range data); "
+                                              "two chained layers (the second reads what the first wrote: Infinity Cache) 224 us each",
+                    "blas_product_same_shape": {"avg_launch_ms": ms_g, "achieved": tf(ms_g), "kernel": "hipBLASLt f32 (PyTorch-ROCm), no epilogue"}}
+        else:
+            gemm = {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "peak_note": "dense f32 MFMA peak (exact-f32 kernels)", "kernel": f32k["kernel"],
+                    "achieved": f32k["achieved"], "exact_f32": f32k,
+                    "blas_product_same_shape": {"avg_launch_ms": ms_g, "achieved": tf(ms_g), "kernel": "hipBLASLt f32 (PyTorch-ROCm), no epilogue"}}
+        gemm["frac"] = gemm["achieved"] / gemm["peak"]
         del xg, gg, wg, sg, cg, gp, dwg
 
     # BASELINE configs[4]: forward-only relighting, 2048x2048, 360 lights, through the precomputed transfer (HBM-bound kernel)

@@ -1423,7 +1423,11 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             else hipLaunchKernelGGL(lazy_pstep_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
             if ((stages & MATPBR_STAGE_RESAMPLE) && pwalk) {     // one wave per chunk of eight listed pixels; 256 waves per image take a queue of any length
                 // waves per image: a multiple of the shards, 2048 in all at most (a long queue -- the first iterations of a part -- is walked in passes)
-                int nw = 2048 / q.batch / kWalkShards * kWalkShards;
+                int walk_cap = 2048;
+#ifdef MATPBR_EXP_TUNE   // measurement builds only (tools/r4_tune.sh)
+                if (const char* e = std::getenv("MATPBR_PWALK_WGS")) walk_cap = std::atoi(e) > 0 ? std::atoi(e) : walk_cap;
+#endif
+                int nw = walk_cap / q.batch / kWalkShards * kWalkShards;
                 const int most = (int)((walk_shard_cap(n1) + 7) / 8) * kWalkShards;
                 nw = nw < kWalkShards ? kWalkShards : (nw > 1024 ? 1024 : nw);
                 nw = nw > most ? most : nw;

@@ -19,6 +19,8 @@ ws = ops.mlp_split_weights(w, N, K)
 for _ in range(4):
     ops.mlp_layer_fwd(x, w, b, s, c, K)
     ops.mlp_layer_fwd_bx(x, ws, b, s, c, N, K, 6)
+    ops.mlp_layer_fwd_bx(x, ws, b, s, None, N, K, 6)                            # as the iteration runs it: sign-packed sines (mlp_nt_gx)
+    ops.mlp_layer_bwd_input_bx(g, ws, s, gp, N, K, db, 6, packed=True)          # the input gradient on the packed sines (mlp_nt_gx<mul cos>)
     ops.mlp_layer_bwd_input_bx(g, ws, c, gp, N, K, db, 6)
     ops.mlp_layer_bwd_weight(g, x, N, K)
     ops.mlp_layer_bwd_weight_bx(g, x, N, K, 6)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# end-of-round measurements in one gpurun call: GPU tests, traces and counter passes, then the default bench line (which reads the
+# per-launch traffic the counter passes of THIS build produced); everything lands in gpurun_out/ and is copied to profiles/ by hand
+cd "$GRAFT_REPO_ROOT" || exit 1
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/r04_gpu_tests.txt
+timeout 400 bash tools/trace_pos_mlp.sh r04 > /dev/null 2>&1
+bash tools/pmc_passes_r04.sh > gpurun_out/r04_pmc.log 2>&1
+python tools/pmc_to_traffic.py gpurun_out --write > /dev/null && cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
+timeout 600 python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err
+for s in indoor2:none indoor2:pos_mlp jinjya:none; do
+  timeout 300 python tools/real_image.py --sample ${s%%:*} --model_name ${s##*:} --out /tmp/real_image > /dev/null 2>&1
+done
+cp /tmp/real_image/real_image_*.json gpurun_out/ 2>/dev/null
+tail -2 gpurun_out/r04_gpu_tests.txt
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r04_bench.json"))
+r = d["roofline"]
+print(d["value"], d["ms_per_step"], r["frac"], r["avg_launch_ms"], r["traffic"], r["own_traffic_frac"], d["cpu_baseline"]["value"])
+print({k: round(v["it_per_s"]) for k, v in d["modes"].items()})
+PY

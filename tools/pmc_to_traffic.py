@@ -30,6 +30,19 @@ def bytes_of(tag, kernel, rnd="r03"):
 
 tj_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+# round 4: the folded, persistent step (lazy_pstep_kernel), the walk launch behind it, the statistics pass
+for tag, b in (("b8", 8), ("b1", 1)):
+    for name, kern in (("lazy_pstep", "matpbr::lazy_pstep_kernel"), ("lazy_pwalk", "matpbr::lazy_pwalk_kernel"), ("loss_sums2_r04", "loss_sums2_kernel<")):
+        v = bytes_of(tag, kern, "r04")
+        if v is not None:
+            tj[f"{name}_512x512_b{b}_spp64"] = v
+if os.path.exists(os.path.join(d, "r04_pmc_b8_FETCH_SIZE.csv")):
+    tj["source_r04"] = ("profiles/r04_pmc_{b1,b8}_{FETCH_SIZE,WRITE_SIZE}.csv (rocprofv3 --kernel-trace --pmc, separate passes, tools/pmc_passes_r04.sh); "
+                        "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB), the gfx950 correction of MI355X_MICROARCH.md as calibrated in round 2")
+sq4 = counters(os.path.join(d, "r04_pmc_b8_sq.csv"), "matpbr::lazy_pstep_kernel")
+gr4 = counters(os.path.join(d, "r04_pmc_b8_grbm.csv"), "matpbr::lazy_pstep_kernel")
+if "SQ_ACTIVE_INST_VALU" in sq4 and "GRBM_GUI_ACTIVE" in gr4:
+    tj["lazy_pstep_valu_active_frac"] = sq4["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * gr4["GRBM_GUI_ACTIVE"] / 8.0)
 for tag, b in (("b8", 8), ("b1", 1)):
     for name, kern in (("lazy_step", "matpbr::lazy_step_kernel"), ("loss_sums2", "loss_sums2_kernel<")):
         v = bytes_of(tag, kern)
@@ -47,6 +60,6 @@ sq3 = counters(os.path.join(d, "r03_pmc_b8_sq.csv"), "matpbr::lazy_step_kernel")
 gr3 = counters(os.path.join(d, "r03_pmc_b8_grbm.csv"), "matpbr::lazy_step_kernel")
 if "SQ_ACTIVE_INST_VALU" in sq3 and "GRBM_GUI_ACTIVE" in gr3:
     tj["lazy_step_valu_active_frac"] = sq3["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * gr3["GRBM_GUI_ACTIVE"] / 8.0)
-print(json.dumps({k: v for k, v in tj.items() if "r03" in k or "lazy" in k or "valu" in k or "sums2" in k}, indent=1))
+print(json.dumps({k: v for k, v in tj.items() if "r03" in k or "r04" in k or "lazy" in k or "valu" in k or "sums2" in k}, indent=1))
 if "--write" in sys.argv:
     json.dump(tj, open(tj_path, "w"), indent=1)
