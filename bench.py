@@ -334,7 +334,13 @@ def main(argv=None):
         for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("torch", 300), ("pos_mlp", 100), ("env", 500), ("env_texels", 1000)):
             if extra == mode or (not extra.startswith("fused") and B > 1):
                 continue
-            e_el, _ = proto.timed(stepper(wl.phase(extra)), 10, steps)
+            ph_x = wl.phase(extra)
+            if hasattr(ph_x, "step_many"):            # hot loop A as optimize.env_phase_runner drives it: 10 iterations per poll (pipeline.py sync_every)
+                for _ in range(4):
+                    ph_x.step()
+                e_el, _ = proto.timed(lambda: (ph_x.step_many(10), ph_x.poll()), 1, steps // 10)
+            else:
+                e_el, _ = proto.timed(stepper(ph_x), 10, steps)
             modes[extra] = {"it_per_s": steps * B * world / e_el, "ms_per_step": e_el / steps * 1e3, "images_per_gpu": B}
         if mode == "pos_mlp" and _posmlp._PosMlpHipFn.PRODUCTS:
             # the same loop with the 256-wide layers on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), for the record
@@ -368,8 +374,9 @@ def main(argv=None):
                   "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
                   "pos_mlp_exact_f32": "the pos_mlp loop with --mlp-products 0: 256-wide layers on the exact-f32 MFMA kernels, autograd composition "
                                        "(loop.PosMlpBrdfPhase); the default differs from it only in how the f32 products are formed (same error vs fp64)",
-                  "env_texels": "hot loop A of --model_name none (envhead.EnvTexelPhase): the 16 x 32 texels through a softplus + SH projection + one pass over "
-                                "the radiance transfer + the projection's backward + Adam, seven kernels from a hipGraph",
+                  "env_texels": "hot loop A of --model_name none (envhead.EnvTexelPhase): one pass over the radiance transfer, then ONE workgroup that folds its "
+                                "partial sums, commits SaveBest / EarlyStopping, snapshots the best envmap, back-propagates through the SH projection and the "
+                                "softplus and applies Adam (matpbr_env_texel_phase_step), then the next envmap's projection: three kernels from a hipGraph, seven in round 3",
                   "env": "hot loop A: envmap PosMLP (small-tile MFMA layers) + softplus / SH projection + one pass over the radiance transfer + "
                          "backward + Adam, 27 launches of libmatpbr.so replayed from a hipGraph",
                   "torch": "hot loop B as the reference's loop body runs it UNCHANGED on the operator face (loop.BrdfPhase: clamp, render_w_brdf with autograd, "

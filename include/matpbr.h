@@ -284,6 +284,17 @@ int matpbr_env_phase_step(const float* T, const float* light, const float* gt_sr
                           float* history, int hist_len, int es_patience, float es_min_delta, void* workspace,
                           size_t workspace_bytes, int H, int W, int batch, void* stream);
 
+/* One iteration of hot loop A with the `--model_name none` parameterisation of the light (inverse_img_w_mi.py:225-254 with the envmap MLP
+ * replaced by its output activation: the 16 x 32 texels y[T, ldy] through a softplus) in THREE launches: the pass over the radiance transfer
+ * under `light` (matpbr_env_phase_step's first kernel), one workgroup that folds its partial sums, commits SaveBest / EarlyStopping,
+ * snapshots the best envmap (`best_env`; `first` != 0: unconditionally), back-propagates d_light through the SH projection and the softplus
+ * and applies Adam (hyper[0] = lr, hyper[1] = step count, both in device memory), and the NEXT iteration's `env` = softplus(y) and
+ * `light` = proj @ env.  = matpbr_env_phase_step + matpbr_select_improved + matpbr_env_project_bwd + matpbr_adam_step_dev + matpbr_env_project,
+ * the same bits.  The caller runs matpbr_env_project once before the first iteration; T <= 1024 texels, one image. */
+int matpbr_env_texel_phase_step(const float* T, const float* gt_srgb, float* pred, float* d_light, float* stats, float* history, int hist_len,
+                                int es_patience, float es_min_delta, void* workspace, size_t workspace_bytes, int H, int W, float* y, int ldy,
+                                const float* proj, float* env, float* best_env, float* light, float* g, float* adam_m, float* adam_v, float* hyper,
+                                float beta1, float beta2, float eps, int n_texels, int first, void* stream);
 /* The envmap head of hot loop A without a framework in between (inverse_img_w_mi.py:117-124,238-254): the 16x32 envmap is
  * softplus(envmap_net(start_envmap)) (mymodels/mlps.py:230-232) and the kernels integrate its SH projection.
  *   matpbr_env_project      env[T,3] = softplus(y[T, ldy]), light[25,3] = proj[25,T] env      (T <= 1024 texels)

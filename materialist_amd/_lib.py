@@ -51,6 +51,9 @@ SIGNATURES = {
                                            ctypes.POINTER(MatpbrCamera), ctypes.c_void_p]),
     "matpbr_lazy_state_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "matpbr_lazy_fold_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "matpbr_env_texel_phase_step": (ctypes.c_int, [_c_f] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                                   ctypes.c_int, _c_f, ctypes.c_int] + [_c_f] * 8 + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_int,
+                                                                                                                          ctypes.c_void_p]),
     "matpbr_lazy_sums_count": (ctypes.c_int, [ctypes.c_int] * 2),
     "matpbr_shade_fwd_lazy": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(MatpbrCamera), ctypes.c_uint32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),

@@ -286,6 +286,92 @@ __global__ __launch_bounds__(kEnvFinalThreads) void env_final_kernel(const float
     }
 }
 
+// Hot loop A of `--model_name none` behind its one pass over the transfer, in ONE launch (one workgroup, one image): env_final_kernel's fold
+// and SaveBest / EarlyStopping commit, the snapshot of the best envmap (select_copy_kernel), the projection's backward
+// (env_project_bwd_kernel) and Adam with its step count in device memory (adam_dev_kernel + tick) -- the same operations in the same order as
+// those five launches (the same bits), without the kernel boundaries between them (an iteration was 44 us, 18 of them the pass over the
+// transfer).  matpbr_env_texel_phase_step then projects the NEXT iteration's envmap (env_project_kernel): on return `env` / `light` hold the
+// envmap and the light of the parameters as Adam has just left them.
+struct EnvTexelTailArgs {
+    const float* part;        // env_prt_kernel's per-workgroup partials [nblk][kEnvPart]
+    float* stats;             // [MATPBR_STATS_STRIDE]
+    float* d_light;           // [25,3] (kept: inspection)
+    float *y, *g, *adam_m, *adam_v;   // texel parameters [T, ldy], their gradient and Adam moments (same shape)
+    const float* proj;        // [25, T]
+    float *env, *best_env, *light;    // [T,3], [T,3], [25,3]
+    float* hyper;             // lr, step count
+    float* history;
+    int nblk, T, ldy, first, es_patience, hist_len;
+    float inv_n3, es_min_delta, b1, b2, eps;
+};
+__global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const EnvTexelTailArgs q) {
+    __shared__ float s_red[kEnvFinalSlices][kEnvPart];
+    __shared__ float s_dl[kNL];
+    __shared__ int s_flag[2];
+    float* st = q.stats;
+    const float lr = q.hyper[0], t_adam = q.hyper[1] + 1.0f;            // (read before thread 0 advances the count at the end)
+    if (threadIdx.x == 0) s_flag[0] = stats_enter(st) ? 1 : 0;
+    __syncthreads();
+    if (s_flag[0]) {   // a stopped image: no gradient, no update; env / light stay what they are
+        if (threadIdx.x < kNL) q.d_light[threadIdx.x] = 0.0f;
+        return;
+    }
+    // ---- env_final_kernel: the partial rows folded 13-way in parallel, fixed order
+    const int col = threadIdx.x % kEnvPart, slice = threadIdx.x / kEnvPart;
+    if (slice < kEnvFinalSlices) {
+        const float* __restrict__ p = q.part + col;
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+        int i = slice;
+        for (; i + 3 * kEnvFinalSlices < q.nblk; i += 4 * kEnvFinalSlices) {
+            v0 += p[(long)i * kEnvPart];
+            v1 += p[(long)(i + kEnvFinalSlices) * kEnvPart];
+            v2 += p[(long)(i + 2 * kEnvFinalSlices) * kEnvPart];
+            v3 += p[(long)(i + 3 * kEnvFinalSlices) * kEnvPart];
+        }
+        for (; i < q.nblk; i += kEnvFinalSlices) v0 += p[(long)i * kEnvPart];
+        s_red[slice][col] = (v0 + v1) + (v2 + v3);
+    }
+    __syncthreads();
+    if (threadIdx.x < kEnvPart) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kEnvFinalSlices; ++k) v += s_red[k][threadIdx.x];
+        if (threadIdx.x < kNL) { q.d_light[threadIdx.x] = v; s_dl[threadIdx.x] = v; }
+        s_red[0][threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st[kStRatio] = 1.0f;
+        stats_commit(st, s_red[0][kNL] * q.inv_n3, s_red[0][kNL + 1] * q.inv_n3, 1.0f / 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, q.es_patience, q.es_min_delta,
+                     q.history, q.hist_len, 1, 0);
+        s_flag[1] = (q.first || st[kStImproved] > 0.5f) ? 1 : 0;
+    }
+    __syncthreads();
+    // ---- select_copy_kernel: SaveBest's envmap snapshot (:247): the envmap this iteration was rendered under
+    if (s_flag[1])
+        for (int i = threadIdx.x; i < q.T * 3; i += kEnvFinalThreads) q.best_env[i] = q.env[i];
+    // ---- env_project_bwd_kernel + adam_dev_kernel (no weight decay, no snapshot of the parameters)
+    const float bc1 = 1.0f - powf(q.b1, t_adam), bc2 = 1.0f - powf(q.b2, t_adam);
+    const float lr_over_bc1 = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    for (int i = threadIdx.x; i < q.T * q.ldy; i += kEnvFinalThreads) {
+        const int t = i / q.ldy, c = i % q.ldy;
+        const float pi = q.y[i];
+        float gi = 0.0f;
+        if (c < 3) {
+            for (int k = 0; k < kNSH; ++k) gi = fmaf(q.proj[(long)k * q.T + t], s_dl[k * 3 + c], gi);
+            gi *= pi > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-pi));
+        }
+        q.g[i] = gi;
+        const float mi = fmaf(q.b1, q.adam_m[i], (1.0f - q.b1) * gi);
+        const float vi = fmaf(q.b2, q.adam_v[i], (1.0f - q.b2) * gi * gi);
+        q.adam_m[i] = mi; q.adam_v[i] = vi;
+        q.y[i] = pi * 1.0f - lr_over_bc1 * mi / fmaf(fsqrt(vi), inv_sqrt_bc2, q.eps);
+    }
+    if (threadIdx.x == 0) q.hyper[1] = t_adam;                           // adam_dev_tick_kernel
+    // (the next iteration's softplus + SH projection stays a launch of its own, env_project_kernel: 75 waves side by side -- as the tail
+    // of this one-workgroup kernel it ran 16 waves x 5 scalars in turn and the iteration took 64 us instead of 44)
+}
+
 // torch.optim.Adam (no weight decay, no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ __launch_bounds__(kBlock) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -1494,6 +1580,30 @@ int matpbr_env_phase_step(const float* T, const float* light, const float* gt_sr
     // SaveBest / EarlyStopping decisions (:247,250) and the folded light gradient
     hipLaunchKernelGGL(env_final_kernel, dim3((unsigned)batch), dim3(kEnvFinalThreads), 0, st, (const float*)workspace, stats, d_light, nblk, inv_n3,
                        es_patience, es_min_delta, history, hist_len, batch);
+    return launch_status();
+}
+
+int matpbr_env_texel_phase_step(const float* T, const float* gt_srgb, float* pred, float* d_light, float* stats, float* history, int hist_len,
+                                int es_patience, float es_min_delta, void* workspace, size_t workspace_bytes, int H, int W, float* y, int ldy,
+                                const float* proj, float* env, float* best_env, float* light, float* g, float* adam_m, float* adam_v, float* hyper,
+                                float beta1, float beta2, float eps, int n_texels, int first, void* stream) {
+    if (!T || !gt_srgb || !d_light || !stats || !y || !proj || !env || !best_env || !light || !g || !adam_m || !adam_v || !hyper || H <= 0 || W <= 0 ||
+        n_texels <= 0 || n_texels > 1024 || ldy < 3)
+        return MATPBR_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < matpbr_env_phase_workspace_bytes(H, W, 1)) return MATPBR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = env_blocks(H, W);
+    const long P = (long)H * W;
+    const float inv_n3 = 1.0f / (3.0f * (float)P);
+    hipLaunchKernelGGL(env_prt_kernel, dim3((unsigned)nblk, 1u), dim3(kBlock), 0, st, T, (const float*)light, gt_srgb, pred, (const float*)stats,
+                       (float*)workspace, P, inv_n3);
+    EnvTexelTailArgs q{};
+    q.part = (const float*)workspace; q.stats = stats; q.d_light = d_light; q.y = y; q.g = g; q.adam_m = adam_m; q.adam_v = adam_v; q.proj = proj;
+    q.env = env; q.best_env = best_env; q.light = light; q.hyper = hyper; q.history = history;
+    q.nblk = nblk; q.T = n_texels; q.ldy = ldy; q.first = first; q.es_patience = es_patience; q.hist_len = hist_len;
+    q.inv_n3 = inv_n3; q.es_min_delta = es_min_delta; q.b1 = beta1; q.b2 = beta2; q.eps = eps;
+    hipLaunchKernelGGL(env_texel_tail_kernel, dim3(1), dim3(kEnvFinalThreads), 0, st, q);
+    hipLaunchKernelGGL(env_project_kernel, dim3(kNL), dim3(64), 0, st, (const float*)y, ldy, proj, env, light, n_texels);     // the next iteration's envmap and light
     return launch_status();
 }
 

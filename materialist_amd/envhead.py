@@ -179,6 +179,29 @@ class EnvMlpPhase:
                 graph.replay()
         self.t += 1
 
+    UNROLL_MAX = 32
+
+    def step_many(self, n: int) -> None:
+        """`n` iterations between two polls of the device's EarlyStopping flag, replayed as ONE hipGraph of n unrolled iterations (a replay
+        per iteration leaves ~9 us of host time between two graphs -- a quarter of the texel loop's iteration; measured with
+        tools/env_trace.sh).  The iterations behind a stop are the no-ops they are with `step()`: the stop lives in device memory."""
+        n = int(n)
+        if not self.use_graph or self._graph is None or n < 2 or n > self.UNROLL_MAX:
+            for _ in range(n):
+                self.step()
+            return
+        graphs = self.__dict__.setdefault("_unrolled", {})
+        with torch.cuda.device(self.dev):
+            if n not in graphs:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(n):
+                        self._body()
+                graphs[n] = g
+            graphs[n].replay()
+        self.t += n
+
     def head(self) -> torch.Tensor:
         """The envmap of the last executed iteration, [He, We, 3] (what `envmap_net(start_envmap)` returned in it)."""
         return self.env.view(self.env_size + (3,))
@@ -211,8 +234,9 @@ class EnvTexelPhase:
     """Hot loop A with the `--model_name none` parameterisation of the light -- the 16 x 32 texels themselves through a softplus
     (optimize.py: `env_raw`; inverse_img_w_mi.py:225-254 with the MLP replaced by its output activation) -- launch by launch on the C
     ABI: softplus + SH projection, the pass over the radiance transfer (render, loss, SaveBest / EarlyStopping, d loss / d light), the
-    snapshot of the best envmap, the projection's backward and one Adam launch whose step count and learning rate live in device
-    memory: seven kernels per iteration, captured into a hipGraph.  (`loop.FusedEnvPhase` runs the same iteration with the head, its
+    snapshot of the best envmap, the projection's backward and Adam with its step count and learning rate in device memory: THREE launches
+    per iteration since round 4 (`matpbr_env_texel_phase_step`: the pass over the transfer, one workgroup for everything behind it, the next
+    envmap's projection; seven kernels before, `FUSED_TAIL = False`), captured into a hipGraph.  (`loop.FusedEnvPhase` runs the same iteration with the head, its
     backward and the optimiser as framework ops: a dozen small launches more.)  `raw` ([He, We, 3], a leaf tensor) is updated in place
     when the phase ends (`sync_params()`), as an optimiser over it would have left it."""
 
@@ -253,8 +277,21 @@ class EnvTexelPhase:
             ops.background_into_transfer(self.T, self.H, self.W, scene.bg_basis)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         lib = self.lib
+        self.fused_tail = bool(self.FUSED_TAIL)
+        project = (lib.matpbr_env_project, (P(self.y), 4, P(self.proj), P(self.env), P(self.light), M))
+        if self.fused_tail:
+            # three launches per iteration (matpbr_env_texel_phase_step): the pass over the transfer, one workgroup that does everything behind it,
+            # the NEXT iteration's softplus + SH projection; the first envmap is projected here, once
+            with torch.cuda.device(dev):
+                _lib.check(project[0](*project[1], ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "matpbr_env_project")
+            self._calls = [(lib.matpbr_env_texel_phase_step,
+                            (P(self.T), P(self.gt_srgb), None, P(self.d_light), P(self.stats), P(self.hist), history_len, self.patience, self.min_delta,
+                             P(self.ws_env), self.ws_env.numel() * 4, self.H, self.W, P(self.y), 4, P(self.proj), P(self.env), P(self.best_env_flat),
+                             P(self.light), P(self.g), P(self.adam_m), P(self.adam_v), P(self.hyper), 0.9, 0.999, 1e-8, M, 0))]
+            self._select_at, self._first = -1, True
+            return
         self._calls = [
-            (lib.matpbr_env_project, (P(self.y), 4, P(self.proj), P(self.env), P(self.light), M)),
+            project,
             (lib.matpbr_env_phase_step, (P(self.T), P(self.light), P(self.gt_srgb), None, P(self.d_light), P(self.stats), P(self.hist), history_len,
                                          self.patience, self.min_delta, P(self.ws_env), self.ws_env.numel() * 4, self.H, self.W, 1)),
             (lib.matpbr_select_improved, (P(self.best_env_flat), P(self.env), P(self.stats), 0, M * 3)),
@@ -265,9 +302,21 @@ class EnvTexelPhase:
         ]
         self._select_at, self._first = 2, True
 
+    FUSED_TAIL = True       # False: the seven launches of round 3 (the same bits: tests/test_gpu_parity.py)
+
+    def _body(self) -> None:
+        if not self.fused_tail:
+            return EnvMlpPhase._body(self)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        fn, args = self._calls[0]
+        if self._first:
+            args = args[:-1] + (1,)                             # the first iteration always snapshots (best_env starts undefined)
+        _lib.check(fn(*args, stream), "matpbr_env_texel_phase_step")
+        self._first = False
+
     set_lr = EnvMlpPhase.set_lr
-    _body = EnvMlpPhase._body
     step = EnvMlpPhase.step
+    step_many, UNROLL_MAX = EnvMlpPhase.step_many, EnvMlpPhase.UNROLL_MAX
     poll = EnvMlpPhase.poll
     history = EnvMlpPhase.history
     best_env = EnvMlpPhase.best_env
@@ -275,7 +324,8 @@ class EnvTexelPhase:
     pred = EnvMlpPhase.pred
 
     def head(self) -> torch.Tensor:
-        """The envmap of the last executed iteration, [He, We, 3]."""
+        """The envmap of the CURRENT parameters, [He, We, 3]: with the fused tail what the next iteration will render under (the tail's last
+        act is the next softplus + projection); with the seven launches the envmap of the last executed iteration."""
         return self.env.view(self.env_size + (3,))
 
     def sync_params(self) -> None:

@@ -149,12 +149,19 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         done, stop, lr_now = 0, "num_epochs", lr_of(0)
         while done < max_epochs:
             k = min(sync_every, max_epochs - done)
-            for _ in range(k):
+            while k > 0:
                 if lr_of(done) != lr_now:
                     lr_now = lr_of(done)
                     set_lr(lr_now)
-                ph.step()
-                done += 1
+                run = 1
+                while run < k and lr_of(done + run) == lr_now:               # the iterations up to the next change of the learning rate
+                    run += 1
+                if run > 1 and hasattr(ph, "step_many"):
+                    ph.step_many(run)                                        # one graph of `run` unrolled iterations
+                else:
+                    run = 1
+                    ph.step()
+                done, k = done + run, k - run
             info = ph.poll()
             if frames is not None and gt.ndim == 3 and frames.due("env"):
                 frames.env_frame(loop_num, done - 1, gt, ph.pred, head_now())

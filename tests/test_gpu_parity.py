@@ -704,6 +704,39 @@ def test_env_texel_phase_matches_the_framework_composition():
     assert torch.allclose(tex.stats[:, : ops.STAT_BEST + 1], ref.stats[:, : ops.STAT_BEST + 1], rtol=2e-5, atol=1e-8)
     assert (tex.best_env - ref.best_env).abs().max().item() < 1e-4 and (tex.best_env - ref.best_env).abs().mean().item() < 1e-6   # softplus of the parameters above
     assert tex.poll()["iters"].tolist() == [12]
+    # the fused tail (three launches per iteration: matpbr_env_texel_phase_step) against the seven launches it replaces: the same operations in
+    # the same order -- parameters, Adam moments, statistics, history and the best envmap bit for bit, with EarlyStopping armed and firing --
+    # and the same again with the iterations between two polls replayed as one unrolled graph (step_many, what optimize.env_phase_runner calls)
+    runs = {}
+    for fused, many in ((True, False), (False, False), (True, True)):
+        EnvTexelPhase.FUSED_TAIL = fused
+        try:
+            raw = raw0.clone().requires_grad_(True)
+            ph = EnvTexelPhase(make_scene(), gt, raw, spp=spp, lr=1e-2, patience=3, min_delta=0.2, use_graph=True)
+        finally:
+            EnvTexelPhase.FUSED_TAIL = True
+        assert ph.fused_tail == fused
+        if many:
+            for _ in range(4):
+                ph.step()
+            ph.step_many(5)
+            ph.set_lr(3e-3)
+            ph.step_many(7)
+            ph.step_many(7)
+            ph.step_many(7)
+            assert ph.t == 30 and sorted(ph._unrolled) == [5, 7]
+        else:
+            for it in range(30):
+                if it == 9:
+                    ph.set_lr(3e-3)
+                ph.step()
+        ph.sync_params()
+        runs[fused, many] = (raw.detach().clone(), ph.adam_m.clone(), ph.adam_v.clone(), ph.stats.clone(), ph.history().clone(), ph.best_env.clone(), ph.poll())
+    for other in ((False, False), (True, True)):
+        for a, b in zip(runs[True, False][:6], runs[other][:6]):
+            assert torch.equal(a, b)
+        assert runs[True, False][6]["stopped"].tolist() == [True] and runs[True, False][6]["iters"].tolist() == runs[other][6]["iters"].tolist()
+    assert runs[True, False][6]["iters"].tolist()[0] < 30
 
 
 def test_fused_env_phase_matches_torch_composition():

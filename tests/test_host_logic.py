@@ -27,6 +27,40 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.matpbr_brdf_loss_workspace_bytes(2) > 0
 
 
+def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
+    """`_lib.MatpbrBrdfPhase` (ctypes) and the flag constants of `ops.py` against include/matpbr.h itself: a C program that includes the
+    header prints sizeof / offsetof / the macros (gcc; the header is plain C), the Python side must agree field for field."""
+    import ctypes
+    import json
+    import subprocess
+
+    from materialist_amd import _lib, ops
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [name for name, _ in _lib.MatpbrBrdfPhase._fields_]
+    src = tmp_path / "abi.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "matpbr.h"', 'int main(void) {',
+             '  printf("{\\"sizeof\\": %zu", sizeof(MatpbrBrdfPhase));']
+    lines += [f'  printf(", \\"{f}\\": %zu", offsetof(MatpbrBrdfPhase, {f}));' for f in fields]
+    macros = ["FLAG_CLAMP_PARAMS", "FLAG_ATTACHED_SAMPLING", "FLAG_LAZY_FORCE", "FLAG_JAC16", "FLAG_MODELS_READY", "FLAG_ROTATE_BEST",
+              "FLAG_GENERIC_STEP", "FLAG_JAC32"]
+    lines += [f'  printf(", \\"{m}\\": %u", (unsigned)MATPBR_{m});' for m in macros]
+    lines += ['  printf(", \\"PART_A\\": %u, \\"PART_R\\": %u, \\"PART_M\\": %u, \\"STATS_STRIDE\\": %d}\\n", MATPBR_PART_A, MATPBR_PART_R, MATPBR_PART_M, MATPBR_STATS_STRIDE);',
+              '  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)], check=True)
+    c = json.loads(subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout)
+    assert ctypes.sizeof(_lib.MatpbrBrdfPhase) == c["sizeof"]
+    for f in fields:
+        assert getattr(_lib.MatpbrBrdfPhase, f).offset == c[f], f
+    for m in macros:
+        assert getattr(ops, m) == c[m], m
+    assert c["STATS_STRIDE"] == 16 and ops.STAT_GT_SUM == 15
+    from materialist_amd.loop import FusedBrdfPhase
+    assert FusedBrdfPhase.PARTS == {"a": c["PART_A"], "r": c["PART_R"], "m": c["PART_M"]}
+
+
 def test_argument_validation_without_gpu():
     """Entry points validate before touching the device: errors come back as codes, nothing launches."""
     from materialist_amd import _lib

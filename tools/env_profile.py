@@ -1,5 +1,5 @@
 """Hot loop A alone (envmap PosMLP head + matpbr_env_phase_step, hipGraph replay) for rocprofv3 kernel traces.
-usage: python tools/env_profile.py [steps]"""
+usage: python tools/env_profile.py [steps] [graph|eager] [mlp|texels]"""
 import os
 import sys
 import time
@@ -24,9 +24,15 @@ def main():
     s_gt._set("emitter.data", t(sc.light))
     with torch.no_grad():
         gt = render.render_w_brdf(s_gt, t(sc.albedo), t(sc.roughness), t(sc.metallic), None, 64)
-    enet = posmlp.envmap_net().to(dev)
+    if len(sys.argv) > 3 and sys.argv[3] == "texels":
+        from materialist_amd.envhead import EnvTexelPhase
+        ph = EnvTexelPhase(s_env, gt, torch.zeros(16, 32, 3, device=dev, requires_grad=True), spp=64, lr=1e-3, use_graph=graph)
+        enet = None
+    else:
+        ph = None
+        enet = posmlp.envmap_net().to(dev)
     ones = torch.ones(512, 3, device=dev)
-    ph = loop.FusedEnvPhase(s_env, gt, lambda: enet(ones).reshape(16, 32, 3), loop.capturable_adam(enet.parameters(), 1e-3), spp=64,
+    ph = ph or loop.FusedEnvPhase(s_env, gt, lambda: enet(ones).reshape(16, 32, 3), loop.capturable_adam(enet.parameters(), 1e-3), spp=64,
                             use_graph=graph, keep_pred=False)
     for _ in range(10):
         ph.step()
