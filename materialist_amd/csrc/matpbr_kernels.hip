@@ -309,27 +309,61 @@ __global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const 
     __shared__ float s_dl[kNL];
     __shared__ int s_flag[2];
     float* st = q.stats;
+    // One workgroup, five dependent phases: what this kernel costs is memory round trips (the pass over the transfer has just pushed everything
+    // else out of the L2: ~1.5 us each), so everything that does not depend on the fold is requested BEFORE it and together with its first
+    // rows: the statistics row (thread 0), the step size and count, and each thread's first two parameters with their Adam moments, their
+    // texels of the envmap and their columns of the projection (all of them at 16 x 32 texels)
     const float lr = q.hyper[0], t_adam = q.hyper[1] + 1.0f;            // (read before thread 0 advances the count at the end)
-    if (threadIdx.x == 0) s_flag[0] = stats_enter(st) ? 1 : 0;
+    float loc[kStatsStride];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kStatsStride; ++i) loc[i] = st[i];
+    }
+    constexpr int kEl = 2;
+    const int n_el = q.T * q.ldy;
+    float py[kEl], pm[kEl], pv[kEl], pe[kEl], pp[kEl][kNSH];
+#pragma unroll
+    for (int u = 0; u < kEl; ++u) {
+        const int i = threadIdx.x + u * kEnvFinalThreads, ic = i < n_el ? i : 0, t = ic / q.ldy;
+        py[u] = q.y[ic]; pm[u] = q.adam_m[ic]; pv[u] = q.adam_v[ic];
+        pe[u] = q.env[i < q.T * 3 ? i : 0];
+#pragma unroll
+        for (int k = 0; k < kNSH; ++k) pp[u][k] = q.proj[(long)k * q.T + t];
+    }
+    // ---- env_final_kernel: the partial rows folded 13-way in parallel, fixed order
+    // (a slice's rows go into four running sums in turn, the rows behind its last whole group of four into the first; a thread requests a chunk of
+    // twenty rows before it adds any -- the same adds in the same order as env_final_kernel, one memory latency per 260 rows instead of one per 52)
+    const int col = threadIdx.x % kEnvPart, slice = threadIdx.x / kEnvPart;
+    constexpr int kChunk = 20;
+    const int n_rows = slice < kEnvFinalSlices && slice < q.nblk ? (q.nblk - slice + kEnvFinalSlices - 1) / kEnvFinalSlices : 0, n_whole = n_rows & ~3;
+    const float* __restrict__ p = q.part + col;
+    float x[kChunk];
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) x[j] = p[(long)((n_rows ? slice : 0) + kEnvFinalSlices * (j < n_rows ? j : 0)) * kEnvPart];
+    if (threadIdx.x == 0) s_flag[0] = loc[kStStopped] > 0.5f ? 1 : 0;   // stats_enter
+    // Adam's bias corrections (two powf: some hundred instructions) while all of that is on its way
+    const float bc1 = 1.0f - powf(q.b1, t_adam), bc2 = 1.0f - powf(q.b2, t_adam);
+    const float lr_over_bc1 = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     __syncthreads();
     if (s_flag[0]) {   // a stopped image: no gradient, no update; env / light stay what they are
+        if (threadIdx.x == 0) { st[kStStopped] = 2.0f; st[kStImproved] = 0.0f; }
         if (threadIdx.x < kNL) q.d_light[threadIdx.x] = 0.0f;
         return;
     }
-    // ---- env_final_kernel: the partial rows folded 13-way in parallel, fixed order
-    const int col = threadIdx.x % kEnvPart, slice = threadIdx.x / kEnvPart;
     if (slice < kEnvFinalSlices) {
-        const float* __restrict__ p = q.part + col;
-        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-        int i = slice;
-        for (; i + 3 * kEnvFinalSlices < q.nblk; i += 4 * kEnvFinalSlices) {
-            v0 += p[(long)i * kEnvPart];
-            v1 += p[(long)(i + kEnvFinalSlices) * kEnvPart];
-            v2 += p[(long)(i + 2 * kEnvFinalSlices) * kEnvPart];
-            v3 += p[(long)(i + 3 * kEnvFinalSlices) * kEnvPart];
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int base = 0; base < n_rows; base += kChunk) {
+            if (base > 0) {
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j) x[j] = p[(long)(slice + kEnvFinalSlices * (base + j < n_rows ? base + j : 0)) * kEnvPart];
+            }
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                if (base + j < n_whole) v[j & 3] += x[j];
+                else if (base + j < n_rows) v[0] += x[j];
+            }
         }
-        for (; i < q.nblk; i += kEnvFinalSlices) v0 += p[(long)i * kEnvPart];
-        s_red[slice][col] = (v0 + v1) + (v2 + v3);
+        s_red[slice][col] = (v[0] + v[1]) + (v[2] + v[3]);
     }
     __syncthreads();
     if (threadIdx.x < kEnvPart) {
@@ -340,32 +374,50 @@ __global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const 
         s_red[0][threadIdx.x] = v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        st[kStRatio] = 1.0f;
-        stats_commit(st, s_red[0][kNL] * q.inv_n3, s_red[0][kNL + 1] * q.inv_n3, 1.0f / 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, q.es_patience, q.es_min_delta,
+    if (threadIdx.x == 0) {                                              // the commit on the row held in registers, written back whole
+        loc[kStRatio] = 1.0f;
+        stats_commit(loc, s_red[0][kNL] * q.inv_n3, s_red[0][kNL + 1] * q.inv_n3, 1.0f / 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, q.es_patience, q.es_min_delta,
                      q.history, q.hist_len, 1, 0);
-        s_flag[1] = (q.first || st[kStImproved] > 0.5f) ? 1 : 0;
+        s_flag[1] = (q.first || loc[kStImproved] > 0.5f) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < kStatsStride; ++i) st[i] = loc[i];
     }
     __syncthreads();
     // ---- select_copy_kernel: SaveBest's envmap snapshot (:247): the envmap this iteration was rendered under
-    if (s_flag[1])
-        for (int i = threadIdx.x; i < q.T * 3; i += kEnvFinalThreads) q.best_env[i] = q.env[i];
+    if (s_flag[1]) {
+#pragma unroll
+        for (int u = 0; u < kEl; ++u) {
+            const int i = threadIdx.x + u * kEnvFinalThreads;
+            if (i < q.T * 3) q.best_env[i] = pe[u];
+        }
+        for (int i = threadIdx.x + kEl * kEnvFinalThreads; i < q.T * 3; i += kEnvFinalThreads) q.best_env[i] = q.env[i];
+    }
     // ---- env_project_bwd_kernel + adam_dev_kernel (no weight decay, no snapshot of the parameters)
-    const float bc1 = 1.0f - powf(q.b1, t_adam), bc2 = 1.0f - powf(q.b2, t_adam);
-    const float lr_over_bc1 = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
-    for (int i = threadIdx.x; i < q.T * q.ldy; i += kEnvFinalThreads) {
-        const int t = i / q.ldy, c = i % q.ldy;
-        const float pi = q.y[i];
+    auto element = [&](int i, float pi, float m0, float v0, const float (&pr)[kNSH]) {
+        const int c = i % q.ldy;
         float gi = 0.0f;
         if (c < 3) {
-            for (int k = 0; k < kNSH; ++k) gi = fmaf(q.proj[(long)k * q.T + t], s_dl[k * 3 + c], gi);
+#pragma unroll
+            for (int k = 0; k < kNSH; ++k) gi = fmaf(pr[k], s_dl[k * 3 + c], gi);
             gi *= pi > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-pi));
         }
         q.g[i] = gi;
-        const float mi = fmaf(q.b1, q.adam_m[i], (1.0f - q.b1) * gi);
-        const float vi = fmaf(q.b2, q.adam_v[i], (1.0f - q.b2) * gi * gi);
+        const float mi = fmaf(q.b1, m0, (1.0f - q.b1) * gi);
+        const float vi = fmaf(q.b2, v0, (1.0f - q.b2) * gi * gi);
         q.adam_m[i] = mi; q.adam_v[i] = vi;
         q.y[i] = pi * 1.0f - lr_over_bc1 * mi / fmaf(fsqrt(vi), inv_sqrt_bc2, q.eps);
+    };
+#pragma unroll
+    for (int u = 0; u < kEl; ++u) {
+        const int i = threadIdx.x + u * kEnvFinalThreads;
+        if (i < n_el) element(i, py[u], pm[u], pv[u], pp[u]);
+    }
+    for (int i = threadIdx.x + kEl * kEnvFinalThreads; i < n_el; i += kEnvFinalThreads) {      // more than 16 x 32 texels
+        const int t = i / q.ldy;
+        float pr[kNSH];
+#pragma unroll
+        for (int k = 0; k < kNSH; ++k) pr[k] = q.proj[(long)k * q.T + t];
+        element(i, q.y[i], q.adam_m[i], q.adam_v[i], pr);
     }
     if (threadIdx.x == 0) q.hyper[1] = t_adam;                           // adam_dev_tick_kernel
     // (the next iteration's softplus + SH projection stays a launch of its own, env_project_kernel: 75 waves side by side -- as the tail
@@ -394,11 +446,23 @@ __global__ __launch_bounds__(64) void env_project_kernel(const float* __restrict
                                                          float* __restrict__ env, float* __restrict__ light, int T) {
     const int q = blockIdx.x, k = q / 3, c = q % 3;                // one wave per light scalar, lanes along the texels
     float a = 0.0f;
-    for (int t = threadIdx.x; t < T; t += 64) {
-        const float v = y[t * ldy + c];
-        const float e = v > 20.0f ? v : log1pf(expf(v));          // torch.nn.functional.softplus (beta 1, threshold 20)
-        if (k == 0) env[t * 3 + c] = e;
-        a = fmaf(proj[(long)k * T + t], e, a);
+    for (int t0 = threadIdx.x; t0 < T; t0 += 64 * 8) {              // eight texels of the lane requested together (a chain of dependent loads before)
+        float v[8], pr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + 64 * j, tc = t < T ? t : 0;
+            v[j] = y[tc * ldy + c];
+            pr[j] = proj[(long)k * T + tc];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + 64 * j;
+            if (t < T) {
+                const float e = v[j] > 20.0f ? v[j] : log1pf(expf(v[j]));   // torch.nn.functional.softplus (beta 1, threshold 20)
+                if (k == 0) env[t * 3 + c] = e;
+                a = fmaf(pr[j], e, a);
+            }
+        }
     }
     a = wave_sum_to_lane63(a);
     if (threadIdx.x == 63) light[q] = a;

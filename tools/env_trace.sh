@@ -6,7 +6,7 @@ python - <<'PY'
 import csv, glob
 path = glob.glob("gpurun_out/tr_e/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-k = [i for i, r in enumerate(rows) if "env_prt" in r["Kernel_Name"]]
+k = [i for i, r in enumerate(rows) if "env_prt" in r["Kernel_Name"] or "env_texel_iter" in r["Kernel_Name"]]
 i0 = k[len(k) // 2]
 n = k[len(k) // 2 + 1] - i0
 for r0, r1 in zip(rows[i0 - 1:i0 + n], rows[i0:i0 + n + 1]):
