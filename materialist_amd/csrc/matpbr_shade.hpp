@@ -1087,14 +1087,22 @@ __global__ __launch_bounds__(kBlock) void env_prt_kernel(const float* __restrict
     float acc[kEnvPart];
 #pragma unroll
     for (int k = 0; k < kEnvPart; ++k) acc[k] = 0.0f;
-    for (int it = 0; it < kEnvTilesPerBlock; ++it) {
+    // the workgroup's four tiles, the NEXT tile's 75 coefficients and target requested before the current one is worked on (two sets of
+    // registers, the loop unrolled: no copies) -- a tile was latency + work + issue in turn, 3 us each
+    auto request = [&](float (&t)[kNL], float (&g)[3], int it) {
         const long tile = (long)blockIdx.x * kEnvTilesPerBlock + it;
-        const long p = tile * 256 + threadIdx.x;
-        if (tile >= tiles || p >= P) continue;
-        const float* tp = T + (((long)b * tiles + tile) * kNL) * 256 + threadIdx.x;
-        float t[kNL];
+        const long tc = tile < tiles ? tile : tiles - 1;
+        const long p = tc * 256 + threadIdx.x, pc = p < P ? p : P - 1;
+        const float* tp = T + (((long)b * tiles + tc) * kNL) * 256 + threadIdx.x;
 #pragma unroll
         for (int j = 0; j < kNL; ++j) t[j] = tp[j * 256];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = gt_srgb[((long)b * P + pc) * 3 + c];
+    };
+    auto work = [&](const float (&t)[kNL], const float (&g)[3], int it) {
+        const long tile = (long)blockIdx.x * kEnvTilesPerBlock + it;
+        const long p = tile * 256 + threadIdx.x;
+        if (tile >= tiles || p >= P) return;
         float x[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < kNSH; ++k) {
@@ -1108,7 +1116,7 @@ __global__ __launch_bounds__(kBlock) void env_prt_kernel(const float* __restrict
             if (pred) pred[i * 3 + c] = x[c];
             const float xc = fmaxf(x[c], kLossEps);
             const float xs = pow_inv_gamma(xc);
-            const float d = xs - gt_srgb[i * 3 + c];
+            const float d = xs - g[c];
             const float dxs = x[c] > kLossEps ? xs * rcp(xc) * (1.0f / 2.2f) : 0.0f;
             gq[c] = dxs * fmaf(2.0f, d, fsign(d)) * inv_n3;     // d (MSE + L1) / d pred
             acc[kNL] = fmaf(d, d, acc[kNL]);
@@ -1116,7 +1124,20 @@ __global__ __launch_bounds__(kBlock) void env_prt_kernel(const float* __restrict
         }
 #pragma unroll
         for (int j = 0; j < kNL; ++j) acc[j] = fmaf(t[j], gq[j % 3], acc[j]);
-    }
+    };
+    static_assert(kEnvTilesPerBlock == 4, "the loop below is written out for four tiles");
+    float ta[kNL], tb[kNL], ga[3], gb[3];
+    request(ta, ga, 0);
+    request(tb, gb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    work(ta, ga, 0);
+    request(ta, ga, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    work(tb, gb, 1);
+    request(tb, gb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    work(ta, ga, 2);
+    work(tb, gb, 3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kEnvPart; ++k) {
