@@ -259,8 +259,10 @@ class FusedBrdfPhase:
 
         from . import _lib, ops
 
-        if not scene.use_mesh_normal or "n" in optimize_part:
-            raise NotImplementedError("FusedBrdfPhase optimises a/r/m under the geometric normal; use BrdfPhase for 'n'")
+        # the shading normals are constants of the phase: the geometric normals or, with use_mesh_normal False, the predicted normal map
+        # (`scene.shading_normal()`, :335-340); a part that moves them ('n') is BrdfPhase's
+        if "n" in optimize_part:
+            raise NotImplementedError("FusedBrdfPhase optimises a/r/m under fixed shading normals; use BrdfPhase for 'n'")
         self._ct, self._libmod, self.ops = ctypes, _lib, ops
         self.scene, self.spp, self.scale_delta, self.part = scene, int(spp), float(scale_delta), optimize_part
         self.gt = gt_image.contiguous()

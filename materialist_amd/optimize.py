@@ -310,7 +310,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 return brdf_part_runner_mlp_normal(loop_num, part, patience, min_delta, n_epochs)
         if model_name == "pos_mlp":
             return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
-        if "n" in part or not scene.use_mesh_normal or (mask is not None and gt.ndim != 3):
+        # a part that moves the normal map runs the autograd composition; under a FIXED predicted normal map (use_mesh_normal False, no 'n'
+        # in the part) the fused phases shade with it as they do with the geometric normals
+        if "n" in part or (mask is not None and gt.ndim != 3) or (mask is not None and not scene.use_mesh_normal):
             return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
         phase_kw = dict(optimize_part=part, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
                         best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs, originals=originals)
@@ -344,6 +346,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             if gt.ndim == 4 and env4.ndim == 3:
                 env4 = env4.unsqueeze(0).expand((gt.shape[0],) + tuple(env4.shape))
             keep_best("envmap", env4.contiguous(), improved)
+            if not scene.use_mesh_normal and "normal" in mat:                     # SaveBest keeps the normal map it rendered with (:424-428)
+                keep_best("normal", mat["normal"].detach(), improved)
         say(f"loop {loop_num}: part {part!r} ran {iters} iterations ({stop}), best mse {float(info['best_mse'].min()):.5f}")
         return iters - 1, ph.lr_at(max(iters - 1, 0)), stop
 

@@ -505,6 +505,55 @@ def test_fused_brdf_phase_matches_torch_composition():
     assert fused.poll()["iters"].tolist() == [5]
 
 
+def test_fused_phases_shade_with_a_fixed_predicted_normal_map():
+    """`--opt_order 'rm a n'` makes the whole run shade with the predicted normal map (inverse_img_w_mi.py:335-340,751-756); its parts
+    WITHOUT 'n' leave that map alone, so they run the fused phases (the map is `scene.shading_normal()`): the exact fused step against
+    BrdfPhase under the same map, and the lazy folded step against the exact one."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    H = W = 64
+    spp = 16
+    sc = synthetic.make_scene(6, H, W)
+    depth, light = _t(sc.depth, dev), _t(sc.light, dev)
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    geo = render.load_estimated_mesh(depth, use_mesh_normal=True).shading_normal()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    nmap = torch.nn.functional.normalize(geo + 0.25 * torch.randn(geo.shape, generator=g).to(dev), dim=-1).contiguous()
+    assert float((nmap * geo).sum(-1).min()) < 0.99               # not the geometric normals
+
+    def make_scene():
+        s = render.load_estimated_mesh(depth, use_mesh_normal=False)
+        s._set("emitter.data", light)
+        s._set("shape.bsdf.n", nmap)
+        return s
+
+    assert torch.equal(make_scene().shading_normal(), nmap)
+    with torch.no_grad():
+        gt = render.render_w_brdf(make_scene(), _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), nmap, spp)
+        gt_geo = render.render_w_brdf(render.load_estimated_mesh(depth, use_mesh_normal=True), _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
+    ref = loop.BrdfPhase(make_scene(), gt, *init, nmap, optimize_part="rm", spp=spp)
+    assert ref.opt_keys == ["roughness", "metallic"]
+    fused = loop.FusedBrdfPhase(make_scene(), gt, *init, optimize_part="rm", spp=spp, lazy=False)
+    lazy = loop.FusedBrdfPhase(make_scene(), gt, *init, optimize_part="rm", spp=spp)
+    assert lazy.fold
+    for it in range(5):
+        mse_ref = ref.step()
+        fused.step()
+        lazy.step()
+        st = fused.stats[0].cpu().numpy()
+        assert st[ops.STAT_MSE] == pytest.approx(float(mse_ref), rel=2e-4), f"iteration {it}"
+        assert st[ops.STAT_LOSS] == pytest.approx(float(ref.last["loss"]), rel=2e-4)
+        assert float(lazy.stats[0, ops.STAT_MSE]) == pytest.approx(float(mse_ref), rel=2e-3)
+    for k in ("roughness", "metallic"):
+        assert (fused.p[k] - ref.params[k].detach()).abs().max().item() < 3e-5, k
+        assert (lazy.p[k] - ref.params[k].detach()).abs().max().item() < 3e-4, k     # Adam on a gradient good to ~1 %: a fraction of 5 lr
+    assert torch.equal(fused.p["albedo"], init[0]) and torch.equal(lazy.p["albedo"], init[0])
+    with pytest.raises(NotImplementedError):
+        loop.FusedBrdfPhase(make_scene(), gt, *init, optimize_part="rmn", spp=spp)
+    assert float((gt - gt_geo).abs().max()) > 1e-3                 # the map matters: the phases above did not shade with the geometry's normals
+
+
 def test_fused_phase_parts_and_device_early_stopping():
     """optimize_part masks (only the part's maps move, only its regularisers count) and the on-device EarlyStopping:
     identical stop iteration to the host state machine fed with the recorded losses, nothing changes after the stop."""
@@ -950,6 +999,33 @@ def test_pos_mlp_with_predicted_normals_runs_and_improves(tmp_path):
     cfg = __import__("json").load(open(tmp_path / "case" / "config.json"))
     assert cfg["output_type"] == "armn" and cfg["use_mesh_normal"] is False
     assert res["best_loss"] < 0.2 and np.isfinite(res["psnr"])
+
+
+def test_none_mode_with_n_in_the_order_runs_its_other_parts_fused(tmp_path):
+    """--opt_order 'rm n' under --model_name none: the run shades with the predicted normal map throughout (use_mesh_normal False); the 'rm'
+    part leaves it alone and runs the fused phase, the 'n' part the autograd composition; normal.exr holds unit normals."""
+    from PIL import Image
+
+    from materialist_amd import pipeline
+    from materialist_amd.imageio_exr import read_exr
+
+    _cuda()
+    torch.manual_seed(3)
+    rng = np.random.default_rng(12)
+    src = str(tmp_path / "in.png")
+    Image.fromarray((rng.random((32, 32, 3)) * 255).astype(np.uint8)).save(src)
+    lines = []
+    res = pipeline.inverse_image(src, "case", opt_src="arm", opt_order=["rm", "n"], opt_env_from=0, save_path=str(tmp_path), size=32, spp=8,
+                                 num_epochs=12, sync_every=4, log=lines.append, model_name="none")
+    rm = [ln for ln in lines if "part 'rm'" in ln]
+    nn = [ln for ln in lines if "part 'n'" in ln]
+    assert rm and all("with normals" not in ln for ln in rm), lines
+    assert nn and all("with normals" in ln for ln in nn), lines
+    cfg = __import__("json").load(open(tmp_path / "case" / "config.json"))
+    assert cfg["use_mesh_normal"] is False
+    n = read_exr(str(tmp_path / "case" / "best_results" / "normal.exr"))
+    assert np.abs(np.linalg.norm(n, axis=-1) - 1).max() < 1e-4
+    assert np.isfinite(res["psnr"]) and res["best_loss"] < 0.5
 
 
 def test_pos_mlp_phase_matches_torch_composition():
