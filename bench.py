@@ -277,6 +277,14 @@ def main(argv=None):
                     ph.current_maps = lambda: (lambda m: {"albedo": m["albedo"].detach().clamp(0, 1), "roughness": m["roughness"].detach().clamp(0.07, 1),
                                                           "metallic": m["metallic"].detach().clamp(0, 1)})(ph.maps_from_net()[0])
                 return ph
+            if mode == "fused_n":
+                # a part of --opt_order that moves the normal map ('n' under use_mesh_normal False): loop.NormalBrdfPhase
+                s_n = render.load_estimated_mesh(self.depth, use_mesh_normal=False)
+                s_n._set("emitter.data", self.light)
+                geo = self.scene.shading_normal()
+                gen = torch.Generator(device="cpu").manual_seed(1)
+                n0 = torch.nn.functional.normalize(geo + 0.1 * torch.randn(geo.shape, generator=gen).to(dev), dim=-1).contiguous()
+                return loop.NormalBrdfPhase(s_n, self.gt_image, *self.init, n0, optimize_part="n", spp=args.spp)
             if mode == "env":
                 from materialist_amd import posmlp
                 from materialist_amd.envhead import EnvMlpPhase
@@ -331,7 +339,7 @@ def main(argv=None):
     modes = {mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3, "images_per_gpu": B}}
     wl8 = None
     if not args.no_extras and mode != "torch":
-        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("torch", 300), ("pos_mlp", 100), ("env", 500), ("env_texels", 1000)):
+        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("torch", 300), ("pos_mlp", 100), ("env", 500), ("env_texels", 1000), ("fused_n", 300)):
             if extra == mode or (not extra.startswith("fused") and B > 1):
                 continue
             ph_x = wl.phase(extra)
@@ -374,6 +382,9 @@ def main(argv=None):
                   "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
                   "pos_mlp_exact_f32": "the pos_mlp loop with --mlp-products 0: 256-wide layers on the exact-f32 MFMA kernels, autograd composition "
                                        "(loop.PosMlpBrdfPhase); the default differs from it only in how the f32 products are formed (same error vs fp64)",
+                  "fused_n": "hot loop B, --model_name none, a part that moves the normal map ('n', use_mesh_normal False; loop.NormalBrdfPhase): render, loss "
+                             "statistics with SaveBest / EarlyStopping on the device, d loss / d pred, the backward render into materials and normals "
+                             "(both lobes' directions walked per pixel), regularisers + normalize backward + Adam -- nine launches of libmatpbr.so, no autograd",
                   "env_texels": "hot loop A of --model_name none (envhead.EnvTexelPhase): one pass over the radiance transfer, then ONE workgroup that folds its "
                                 "partial sums, commits SaveBest / EarlyStopping, snapshots the best envmap, back-propagates through the SH projection and the "
                                 "softplus and applies Adam (matpbr_env_texel_phase_step), then the next envmap's projection: three kernels from a hipGraph, seven in round 3",

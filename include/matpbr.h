@@ -73,6 +73,7 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
 #define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
 #define MATPBR_PART_R 4u
 #define MATPBR_PART_M 8u
+#define MATPBR_PART_N 1024u         /* matpbr_brdf_normal_step only: the part moves the normal map ('n' in the part, use_mesh_normal False) */
 /* floats per image in the loss statistics buffer (device memory, caller-owned, persistent across iterations):
  *  0 ratio  1 mse  2 l1  3 l1/mse  4 L1(a)  5 L1(r)  6 L1(m)  7 loss  8 improved(0/1)  9 best_mse (init +inf)
  * 10 early-stopping counter  11 early-stopping best  12 early-stopping has-best
@@ -182,7 +183,8 @@ size_t matpbr_brdf_loss_workspace_bytes(int batch);
 int matpbr_brdf_loss_stats(const float* pred, const float* gt, const float* gt_srgb, const float* pa, const float* pr,
                            const float* pm, const float* a0, const float* r0, const float* m0, float scale_delta,
                            float* stats, void* workspace, size_t workspace_bytes, int H, int W, int batch, uint32_t flags,
-                           void* stream);   /* flags: MATPBR_PART_* of the maps being optimised (none set = all three) */
+                           void* stream);   /* flags: MATPBR_PART_* of the maps being optimised (none set = all three; with MATPBR_PART_N: exactly the
+                                                material maps named beside it) */
 /* matpbr_brdf_loss_stats with the EarlyStopping state machine of matpbr_brdf_phase_step kept in `stats` (es_patience >= 0; myutils/misc.py:37-60)
  * and the per-iteration loss_mse in history[hist_len, B] (nullable): once stats[b][13] is set the image's statistics rest, its `improved` flag stays
  * down (no snapshot in matpbr_brdf_loss_bwd_jac) and matpbr_adamw_step_snapshot_dev(..., stats) rests too, so a caller whose iteration contains
@@ -257,6 +259,35 @@ typedef struct MatpbrBrdfPhase {
                                              derives the folded planes from the generic ones; the generic ones stay current (re-sampled pixels rewrite
                                              both).  Other parts, and MATPBR_FLAG_GENERIC_STEP, run the generic step. */
 } MatpbrBrdfPhase;
+/* A part of --opt_order that moves the normal map ('n', 'armn' under --model_name none with use_mesh_normal False; inverse_img_w_mi.py:356-432),
+ * launch by launch without a framework in the iteration and with SaveBest / EarlyStopping on the device:
+ *     matpbr_shade_fwd(ca, cr, cm, cn, light) -> pred                       the render under the current maps (:384-386)
+ *     matpbr_brdf_loss_stats_es(pred, ..., pa, pr, pm, ...)                 ratio, losses, SaveBest / EarlyStopping decisions (:388-427)
+ *     matpbr_brdf_loss_dpred(pred, gt_srgb, stats) -> d_pred                d loss / d pred from those statistics (:420)
+ *     matpbr_shade_bwd(ca, cr, cm, cn, light, d_pred) -> d_a, d_r, d_m, d_n the backward render
+ *     matpbr_brdf_normal_step(...)                                          regulariser gradients (incl. L1(normal, normal_ori), :410-411),
+ *                                                                           clamp gating, NF.normalize's backward (:379), the snapshot of an
+ *                                                                           improving iteration, Adam on the maps of the part (t = 1-based
+ *                                                                           iteration, lr: StepLR on the host), and the maps of the next render
+ * Images whose EarlyStopping fired in an earlier iteration rest in both entries (the firing iteration still updates, as in the reference).
+ * `ln_part` (nullable, [batch][ceil(H W / 256)]): per-workgroup sums of |n - n0| -- stats' `loss` carries the three material regularisers,
+ * the caller adds scale_delta sum / (3 H W) for the record (the optimisation does not read it). */
+typedef struct MatpbrNormalStep {
+    float *pa, *pr, *pm, *pn;              /* raw parameters [B,H,W,3|1|1|3]; the maps of the part are updated in place */
+    float *ca, *cr, *cm, *cn;              /* what the renders take: clamp(pa,0,1), clamp(pr,.07,1), clamp(pm,0,1), normalize(pn); rewritten for the maps of the part */
+    const float *d_a, *d_r, *d_m, *d_n;    /* matpbr_shade_bwd's gradients with respect to ca, cr, cm, cn (needed for the maps of the part) */
+    const float *a0, *r0, *m0, *n0;        /* regulariser anchors (:189-201) */
+    float *adam_m[4], *adam_v[4];          /* a, r, m, n */
+    float *best_a, *best_r, *best_m, *best_n, *best_img;   /* nullable: SaveBest's snapshot (clamped maps, unit normals, pred ratio ^ (1/2.2)) */
+    const float *pred, *stats;
+    float* ln_part;
+    int H, W, batch;
+    uint32_t part_mask;                    /* MATPBR_PART_A | _R | _M | _N */
+    float scale_delta;
+} MatpbrNormalStep;
+int matpbr_brdf_loss_dpred(const float* pred, const float* gt_srgb, const float* stats, float* d_pred, int H, int W, int batch, void* stream);
+int matpbr_brdf_normal_step(const MatpbrNormalStep* step, int t, float lr, void* stream);
+
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);
 /* MATPBR_FLAG_ROTATE_BEST: after the step with t = t_done, put everything where the copying form leaves it: current parameters in pa / pr / pm,

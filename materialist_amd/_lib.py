@@ -27,6 +27,14 @@ class MatpbrBrdfPhase(ctypes.Structure):
                  ("lazy_tol", ctypes.c_float), ("pred_next", ctypes.c_void_p), ("flags", ctypes.c_uint32), ("lazy_fold", ctypes.c_void_p)])
 
 
+class MatpbrNormalStep(ctypes.Structure):
+    """Mirror of `MatpbrNormalStep` in include/matpbr.h (field order matters)."""
+    _fields_ = ([(k, ctypes.c_void_p) for k in ("pa", "pr", "pm", "pn", "ca", "cr", "cm", "cn", "d_a", "d_r", "d_m", "d_n", "a0", "r0", "m0", "n0")] +
+                [("adam_m", ctypes.c_void_p * 4), ("adam_v", ctypes.c_void_p * 4)] +
+                [(k, ctypes.c_void_p) for k in ("best_a", "best_r", "best_m", "best_n", "best_img", "pred", "stats", "ln_part")] +
+                [("H", ctypes.c_int), ("W", ctypes.c_int), ("batch", ctypes.c_int), ("part_mask", ctypes.c_uint32), ("scale_delta", ctypes.c_float)])
+
+
 class MatpbrError(RuntimeError):
     pass
 
@@ -54,6 +62,8 @@ SIGNATURES = {
     "matpbr_env_texel_phase_step": (ctypes.c_int, [_c_f] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                                    ctypes.c_int, _c_f, ctypes.c_int] + [_c_f] * 8 + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_int,
                                                                                                                           ctypes.c_void_p]),
+    "matpbr_brdf_loss_dpred": (ctypes.c_int, [_c_f] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_brdf_normal_step": (ctypes.c_int, [ctypes.POINTER(MatpbrNormalStep), ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "matpbr_lazy_sums_count": (ctypes.c_int, [ctypes.c_int] * 2),
     "matpbr_shade_fwd_lazy": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(MatpbrCamera), ctypes.c_uint32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),

@@ -1353,6 +1353,7 @@ size_t matpbr_brdf_loss_workspace_bytes(int batch) { return batch > 0 ? (size_t)
 
 static unsigned part_mask_of(uint32_t flags) {
     const unsigned all = MATPBR_PART_A | MATPBR_PART_R | MATPBR_PART_M;
+    if (flags & MATPBR_PART_N) return flags & all;   // a part that moves the normal map names its material maps explicitly ('n' alone: none)
     return (flags & all) ? (flags & all) : all;   // no part bit = all three maps (optimize_part 'arm')
 }
 
@@ -1405,6 +1406,145 @@ int matpbr_brdf_loss_bwd_jac(const float* pa, const float* pr, const float* pm, 
         hipLaunchKernelGGL((jac_bwd_kernel<true, true>), dim3((unsigned)((P + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, q, P);
     else
         hipLaunchKernelGGL((jac_bwd_kernel<true, false>), dim3((unsigned)((P + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, q, P);
+    return launch_status();
+}
+
+// ---- parts of --opt_order that move the normal map ('n', 'armn' under --model_name none; inverse_img_w_mi.py:356-432) without a framework in
+// the iteration: matpbr_shade_fwd, matpbr_brdf_loss_stats_es, then the two entries below around matpbr_shade_bwd
+namespace {
+// d loss / d pred of 3 (l1/mse) mse + l1 on max(pred ratio, eps)^(1/2.2) from the iteration's statistics (jac_bwd_kernel<FUSED>'s expression)
+__global__ __launch_bounds__(kBlock) void loss_dpred_kernel(const float* __restrict__ pred, const float* __restrict__ gt_srgb,
+                                                            const float* __restrict__ stats, float* __restrict__ d_pred, long P, float inv_n3) {
+    const int b = blockIdx.y;
+    if (img_stopped_before(stats, b)) return;
+    const long p = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    const long i = (long)b * P + p;
+    const float ratio = stats[b * kStatsStride + kStRatio], sr = stats[b * kStatsStride + kStSr];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float x = pred[i * 3 + c] * ratio;
+        const float xc = fmaxf(x, kLossEps);
+        const float xs = pow_inv_gamma(xc);
+        const float d = xs - gt_srgb[i * 3 + c];
+        const float dxs = x > kLossEps ? xs * rcp(xc) * (1.0f / 2.2f) : 0.0f;
+        d_pred[i * 3 + c] = ratio * dxs * fmaf(6.0f * sr, d, fsign(d)) * inv_n3;
+    }
+}
+struct NormalStepArgs {
+    MatpbrNormalStep s;
+    float inv_n3, inv_n1, lr_over_bc1, b1, b2, eps, inv_sqrt_bc2;
+};
+__device__ __forceinline__ float adam_one(float p, float gi, float* m, float* v, long i, const NormalStepArgs& q) {
+    const float mi = fmaf(q.b1, m[i], (1.0f - q.b1) * gi);
+    const float vi = fmaf(q.b2, v[i], (1.0f - q.b2) * gi * gi);
+    m[i] = mi; v[i] = vi;
+    return p - q.lr_over_bc1 * mi / fmaf(fsqrt(vi), q.inv_sqrt_bc2, q.eps);
+}
+// per pixel: regulariser gradients (:398-411), torch.clamp's gating, the backward of NF.normalize (:379), SaveBest's snapshot (:421), Adam
+// (:429) on the maps of the part, and the maps the NEXT render takes (clamped parameters, unit normals)
+__global__ __launch_bounds__(kBlock) void normal_step_kernel(const NormalStepArgs q, long P) {
+    __shared__ float s_buf[4];
+    const MatpbrNormalStep& s = q.s;
+    const int b = blockIdx.y;
+    if (img_stopped_before(s.stats, b)) return;
+    const long p = (long)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = p < P;
+    const long i = (long)b * P + (live ? p : P - 1);
+    const bool improved = s.stats[b * kStatsStride + kStImproved] > 0.5f;
+    const float ratio = s.stats[b * kStatsStride + kStRatio];
+    const unsigned part = s.part_mask;
+    float ln = 0.0f;
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float ra = s.pa[i * 3 + c], a = fminf(fmaxf(ra, 0.0f), 1.0f);
+            if (improved && s.best_a) s.best_a[i * 3 + c] = a;
+            if (improved && s.best_img) s.best_img[i * 3 + c] = pow_inv_gamma(fmaxf(s.pred[i * 3 + c] * ratio, kLossEps));
+            if ((part & MATPBR_PART_A) && s.d_a) {
+                float g = s.d_a[i * 3 + c] + s.scale_delta * q.inv_n3 * fsign(a - s.a0[i * 3 + c]);
+                g = (ra >= 0.0f && ra <= 1.0f) ? g : 0.0f;
+                const float pn = adam_one(ra, g, s.adam_m[0], s.adam_v[0], i * 3 + c, q);
+                s.pa[i * 3 + c] = pn;
+                s.ca[i * 3 + c] = fminf(fmaxf(pn, 0.0f), 1.0f);
+            }
+        }
+        const float rr = s.pr[i], r = fminf(fmaxf(rr, 0.07f), 1.0f), rm = s.pm[i], m = fminf(fmaxf(rm, 0.0f), 1.0f);
+        if (improved && s.best_r) s.best_r[i] = r;
+        if (improved && s.best_m) s.best_m[i] = m;
+        if ((part & MATPBR_PART_R) && s.d_r) {
+            float g = s.d_r[i] + s.scale_delta * q.inv_n1 * fsign(r - s.r0[i]);
+            g = (rr >= 0.07f && rr <= 1.0f) ? g : 0.0f;
+            const float pn = adam_one(rr, g, s.adam_m[1], s.adam_v[1], i, q);
+            s.pr[i] = pn;
+            s.cr[i] = fminf(fmaxf(pn, 0.07f), 1.0f);
+        }
+        if ((part & MATPBR_PART_M) && s.d_m) {
+            float g = s.d_m[i] + s.scale_delta * q.inv_n1 * fsign(m - s.m0[i]);
+            g = (rm >= 0.0f && rm <= 1.0f) ? g : 0.0f;
+            const float pn = adam_one(rm, g, s.adam_m[2], s.adam_v[2], i, q);
+            s.pm[i] = pn;
+            s.cm[i] = fminf(fmaxf(pn, 0.0f), 1.0f);
+        }
+        // the normal map: n = v / max(|v|, 1e-12) (NF.normalize); d v = (g - n (n . g)) / |v|
+        float v[3] = {s.pn[i * 3], s.pn[i * 3 + 1], s.pn[i * 3 + 2]};
+        const float len = fsqrt(fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0]))), den = fmaxf(len, 1e-12f);
+        float nh[3] = {v[0] / den, v[1] / den, v[2] / den};
+        if (improved && s.best_n) { s.best_n[i * 3] = nh[0]; s.best_n[i * 3 + 1] = nh[1]; s.best_n[i * 3 + 2] = nh[2]; }
+        if ((part & MATPBR_PART_N) && s.d_n) {
+            float g[3], dot = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float dn = nh[c] - s.n0[i * 3 + c];
+                ln += fabsf(dn);
+                g[c] = s.d_n[i * 3 + c] + s.scale_delta * q.inv_n3 * fsign(dn);
+                dot = fmaf(g[c], nh[c], dot);
+            }
+            float w[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gv = len > 1e-12f ? (g[c] - nh[c] * dot) / den : g[c] / den;
+                w[c] = adam_one(v[c], gv, s.adam_m[3], s.adam_v[3], i * 3 + c, q);
+                s.pn[i * 3 + c] = w[c];
+            }
+            const float den2 = fmaxf(fsqrt(fmaf(w[2], w[2], fmaf(w[1], w[1], w[0] * w[0]))), 1e-12f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s.cn[i * 3 + c] = w[c] / den2;
+        }
+    }
+    if (s.ln_part) {   // sum |n - n0| of this workgroup (the loss's normal regulariser, for the record: loss = stats loss + scale_delta sum / (3 H W))
+        const float tot = block_sum(ln, s_buf);
+        if (threadIdx.x == 0) s.ln_part[(long)b * gridDim.x + blockIdx.x] = tot;
+    }
+}
+}  // namespace
+
+int matpbr_brdf_loss_dpred(const float* pred, const float* gt_srgb, const float* stats, float* d_pred, int H, int W, int batch, void* stream) {
+    if (!pred || !gt_srgb || !stats || !d_pred || H <= 0 || W <= 0 || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+    const long P = (long)H * W;
+    hipLaunchKernelGGL(loss_dpred_kernel, dim3((unsigned)((P + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, pred, gt_srgb,
+                       stats, d_pred, P, 1.0f / (3.0f * (float)P));
+    return launch_status();
+}
+
+int matpbr_brdf_normal_step(const MatpbrNormalStep* ns, int t, float lr, void* stream) {
+    if (!ns || t < 1) return MATPBR_ERR_INVALID_ARG;
+    const MatpbrNormalStep& s = *ns;
+    if (!s.pa || !s.pr || !s.pm || !s.pn || !s.ca || !s.cr || !s.cm || !s.cn || !s.pred || !s.stats || s.H <= 0 || s.W <= 0 || s.batch <= 0)
+        return MATPBR_ERR_INVALID_ARG;
+    if (((s.part_mask & MATPBR_PART_A) && (!s.d_a || !s.a0 || !s.adam_m[0] || !s.adam_v[0])) ||
+        ((s.part_mask & MATPBR_PART_R) && (!s.d_r || !s.r0 || !s.adam_m[1] || !s.adam_v[1])) ||
+        ((s.part_mask & MATPBR_PART_M) && (!s.d_m || !s.m0 || !s.adam_m[2] || !s.adam_v[2])) ||
+        ((s.part_mask & MATPBR_PART_N) && (!s.d_n || !s.n0 || !s.adam_m[3] || !s.adam_v[3])))
+        return MATPBR_ERR_INVALID_ARG;
+    const long P = (long)s.H * s.W;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const double bc1 = 1.0 - std::pow((double)b1, t), bc2 = 1.0 - std::pow((double)b2, t);
+    NormalStepArgs q{};
+    q.s = s;
+    q.inv_n3 = 1.0f / (3.0f * (float)P); q.inv_n1 = 1.0f / (float)P;
+    q.lr_over_bc1 = (float)(lr / bc1); q.b1 = b1; q.b2 = b2; q.eps = eps; q.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+    hipLaunchKernelGGL(normal_step_kernel, dim3((unsigned)((P + kBlock - 1) / kBlock), (unsigned)s.batch), dim3(kBlock), 0, (hipStream_t)stream, q, P);
     return launch_status();
 }
 

@@ -467,6 +467,119 @@ class FusedBrdfPhase:
         return {"albedo": p["albedo"].clamp(0, 1), "roughness": p["roughness"].clamp(0.07, 1), "metallic": p["metallic"].clamp(0, 1)}
 
 
+class NormalBrdfPhase:
+    """Hot loop B in `model_name == 'none'` mode for a part of --opt_order that MOVES THE NORMAL MAP ('n', 'armn', ...; use_mesh_normal False:
+    inverse_img_w_mi.py:356-432), launch by launch on the C ABI: the render under the current maps, the loss statistics with SaveBest /
+    EarlyStopping on the device, d loss / d pred, the backward render (material AND normal gradients: `shade_bwd_nl_kernel` walks both lobes'
+    directions per pixel), and one kernel for the regularisers (L1(normal, normal_ori) among them), the clamp gating, NF.normalize's backward,
+    the snapshot of an improving iteration and Adam (include/matpbr.h `MatpbrNormalStep`): nine launches per iteration, no autograd, no
+    framework losses, no host synchronisation per epoch.  Same arithmetic as `BrdfPhase` (its parity reference: tests/test_gpu_parity.py);
+    same interface as `FusedBrdfPhase` (`run`, `poll`, `history`, `p`, `best`, `best_img`, `lr_at`)."""
+
+    KEYS = ("albedo", "roughness", "metallic", "normal")
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
+                 normal: torch.Tensor, optimize_part: str = "armn", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,
+                 min_delta: float = 0.0, best_mse: Optional[torch.Tensor] = None, history_len: int = 5000,
+                 originals: Optional[Dict[str, torch.Tensor]] = None):
+        import ctypes
+
+        from . import _lib, ops
+
+        if scene.use_mesh_normal or "n" not in optimize_part:
+            raise NotImplementedError("NormalBrdfPhase runs the parts that move the normal map (use_mesh_normal False, 'n' in the part); "
+                                      "FusedBrdfPhase runs the others")
+        self._ct, self._libmod, self.ops = ctypes, _lib, ops
+        self.scene, self.spp, self.scale_delta, self.part = scene, int(ops.check_spp(spp)), float(scale_delta), optimize_part
+        self.gt = gt_image.contiguous()
+        dev = self.gt.device
+        B = self.gt.shape[0] if self.gt.ndim == 4 else 1
+        self.B, self.H, self.W = B, self.gt.shape[-3], self.gt.shape[-2]
+        self.gt_srgb = _loss.linear_to_srgb(self.gt).contiguous()
+        c = lambda t: t.detach().clone().contiguous()
+        self.p = {"albedo": c(albedo), "roughness": c(roughness), "metallic": c(metallic), "normal": c(normal)}
+        self.orig = {k: c(originals[k] if originals is not None and k in originals else v).reshape(v.shape) for k, v in self.p.items()}
+        live = {"albedo": "a" in optimize_part, "roughness": "r" in optimize_part, "metallic": "m" in optimize_part, "normal": True}
+        # what the renders take: the maps of the part clamped / normalised (:372-379; the step kernel rewrites them from the new parameters), the
+        # others as they are
+        lims = {"albedo": (0.0, 1.0), "roughness": (0.07, 1.0), "metallic": (0.0, 1.0)}
+        self.c = {k: (self.p[k].clamp(*lims[k]) if live[k] else self.p[k].clone()) for k in lims}
+        self.c["normal"] = torch.nn.functional.normalize(self.p["normal"], p=2, dim=-1).contiguous()
+        self.g = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.best = {k: c(v) for k, v in self.c.items()}
+        self.best_img = torch.zeros_like(self.gt)
+        self.pred = torch.empty_like(self.gt)
+        self.d_pred = torch.zeros_like(self.gt)
+        self.stats = ops.new_loss_stats(B, dev)
+        if best_mse is not None:   # SaveBest.best_loss is global across phases and never reset (F11)
+            self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
+        lib = self._lib = _lib.load()
+        self.ws = torch.empty(int(lib.matpbr_brdf_loss_workspace_bytes(B)) // 4 + 1, dtype=torch.float32, device=dev)
+        self.hist = torch.zeros((history_len, B), dtype=torch.float32, device=dev)
+        self.ln_part = torch.zeros((B, (self.H * self.W + 255) // 256), dtype=torch.float32, device=dev)
+        light = scene.light.detach()
+        self.light = (light.unsqueeze(0).expand(B, -1, -1) if (B > 1 and light.ndim == 2) else light).contiguous()
+        self.base_lr, self.t = float(lr), 0
+        self.patience, self.min_delta, self.hist_len = int(patience), float(min_delta), int(history_len)
+        self.mask = ops.part_mask(optimize_part)
+        self.cam = ops.MatpbrCamera(float(scene.fov))
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        ns = _lib.MatpbrNormalStep()
+        for i, (k, ch) in enumerate(zip(self.KEYS, "armn")):
+            setattr(ns, "p" + ch, P(self.p[k]))
+            setattr(ns, "c" + ch, P(self.c[k]))
+            setattr(ns, "d_" + ch, P(self.g[k]) if live[k] else None)
+            setattr(ns, ch + "0", P(self.orig[k]))
+            setattr(ns, "best_" + ch, P(self.best[k]) if live[k] else None)      # a map the part leaves alone: its snapshot is the map
+            ns.adam_m[i], ns.adam_v[i] = self.m[k].data_ptr(), self.v[k].data_ptr()
+        ns.best_img, ns.pred, ns.stats, ns.ln_part = P(self.best_img), P(self.pred), P(self.stats), P(self.ln_part)
+        ns.H, ns.W, ns.batch, ns.part_mask, ns.scale_delta = self.H, self.W, B, self.mask, self.scale_delta
+        self._ns, self._live = ns, live
+
+    lr_at = FusedBrdfPhase.lr_at
+
+    def step(self) -> None:
+        ct, lib, o, P = self._ct, self._lib, self.ops, (lambda t: self._ct.c_void_p(t.data_ptr()) if t is not None else None)
+        H, W, B, c, p, g = self.H, self.W, self.B, self.c, self.p, self.g
+        want_mat = any(self._live[k] for k in ("albedo", "roughness", "metallic"))
+        with torch.cuda.device(self.gt.device):
+            st = ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream)
+            chk = self._libmod.check
+            chk(lib.matpbr_shade_fwd(P(c["albedo"]), P(c["roughness"]), P(c["metallic"]), P(c["normal"]), P(self.light), o.LIGHT_SH25, o.NSH,
+                                     P(self.pred), H, W, B, self.spp, ct.byref(self.cam), 0, st), "matpbr_shade_fwd")
+            chk(lib.matpbr_brdf_loss_stats_es(P(self.pred), P(self.gt), P(self.gt_srgb), P(p["albedo"]), P(p["roughness"]), P(p["metallic"]),
+                                              P(self.orig["albedo"]), P(self.orig["roughness"]), P(self.orig["metallic"]), self.scale_delta,
+                                              P(self.stats), P(self.ws), self.ws.numel() * 4, H, W, B, self.mask, self.patience, self.min_delta,
+                                              P(self.hist), self.hist_len, st), "matpbr_brdf_loss_stats_es")
+            chk(lib.matpbr_brdf_loss_dpred(P(self.pred), P(self.gt_srgb), P(self.stats), P(self.d_pred), H, W, B, st), "matpbr_brdf_loss_dpred")
+            chk(lib.matpbr_shade_bwd(P(c["albedo"]), P(c["roughness"]), P(c["metallic"]), P(c["normal"]), P(self.light), o.LIGHT_SH25, o.NSH,
+                                     P(self.d_pred), P(g["albedo"]) if want_mat else None, P(g["roughness"]) if want_mat else None,
+                                     P(g["metallic"]) if want_mat else None, P(g["normal"]), None, None, 0, H, W, B, self.spp, ct.byref(self.cam), 0, st),
+                "matpbr_shade_bwd")
+            chk(lib.matpbr_brdf_normal_step(ct.byref(self._ns), self.t + 1, self.lr_at(self.t), st), "matpbr_brdf_normal_step")
+        self.t += 1
+
+    def run(self, n: int) -> None:
+        for _ in range(n):
+            self.step()
+
+    poll = FusedBrdfPhase.poll
+    history = FusedBrdfPhase.history
+
+    def loss(self) -> torch.Tensor:
+        """The last iteration's loss with the normal regulariser (`stats` carries the three material regularisers): [B]."""
+        return self.stats[:, self.ops.STAT_LOSS] + self.scale_delta * self.ln_part.sum(dim=1) / (3.0 * self.H * self.W)
+
+    def current_maps(self) -> Dict[str, torch.Tensor]:
+        p = self.p
+        lims = {"albedo": (0.0, 1.0), "roughness": (0.07, 1.0), "metallic": (0.0, 1.0)}
+        out = {k: (p[k].clamp(*lims[k]) if self._live[k] else p[k]) for k in lims}
+        out["normal"] = torch.nn.functional.normalize(p["normal"], p=2, dim=-1)
+        return out
+
+
 class MaskedBrdfPhase:
     """Hot loop B, `--model_name none` under `--use_mask` (inverse_img_w_mi.py:347-468 with :379-381), launch by launch on the C ABI.
     Inside the mask the roughness and the metallic the render sees are the masked means of the clamped maps: two image-wide reductions per

@@ -25,7 +25,7 @@ LAZY_NSTATE = 22
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
  STAT_ES_HAS, STAT_STOPPED, STAT_ITERS, STAT_GT_SUM) = range(16)
-PART_A, PART_R, PART_M = 2, 4, 8
+PART_A, PART_R, PART_M, PART_N = 2, 4, 8, 1024
 
 
 class KernelTimer:
@@ -491,7 +491,8 @@ def new_loss_stats(batch: int, device) -> torch.Tensor:
 
 
 def part_mask(optimize_part: str) -> int:
-    return sum({"a": PART_A, "r": PART_R, "m": PART_M}.get(ch, 0) for ch in optimize_part)
+    """MATPBR_PART_* bits of a part of --opt_order ('n': MATPBR_PART_N -- the material maps beside it are then meant literally, 'n' alone = none)."""
+    return sum({"a": PART_A, "r": PART_R, "m": PART_M, "n": PART_N}.get(ch, 0) for ch in optimize_part)
 
 
 def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: float, stats: torch.Tensor,

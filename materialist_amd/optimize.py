@@ -310,13 +310,19 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                 return brdf_part_runner_mlp_normal(loop_num, part, patience, min_delta, n_epochs)
         if model_name == "pos_mlp":
             return brdf_part_runner_mlp(loop_num, part, patience, min_delta, n_epochs)
-        # a part that moves the normal map runs the autograd composition; under a FIXED predicted normal map (use_mesh_normal False, no 'n'
-        # in the part) the fused phases shade with it as they do with the geometric normals
-        if "n" in part or (mask is not None and gt.ndim != 3) or (mask is not None and not scene.use_mesh_normal):
+        # Under a FIXED predicted normal map (use_mesh_normal False, no 'n' in the part) the fused phases shade with it as they do with the
+        # geometric normals; a part that MOVES the normal map runs NormalBrdfPhase (launch by launch on the C ABI, device-side SaveBest /
+        # EarlyStopping); under the geometric normals an 'n' in the part optimises nothing (:356,376); what is left -- masks with predicted
+        # normals or on a batch, a part that is 'n' alone under the geometric normals -- is the autograd composition's
+        eff = part.replace("n", "") if scene.use_mesh_normal else part
+        moves_n = "n" in eff
+        if not eff or (mask is not None and (gt.ndim != 3 or not scene.use_mesh_normal)) or (moves_n and not gt.is_cuda):
             return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
-        phase_kw = dict(optimize_part=part, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
+        phase_kw = dict(optimize_part=eff, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
                         best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs, originals=originals)
-        if mask is not None:      # --use_mask: launch by launch (two image-wide means per iteration), same device-side SaveBest / EarlyStopping
+        if moves_n:
+            ph = _loop.NormalBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mat["normal"], **phase_kw)
+        elif mask is not None:    # --use_mask: launch by launch (two image-wide means per iteration), same device-side SaveBest / EarlyStopping
             ph = _loop.MaskedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mask, **phase_kw)
         else:
             ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], **phase_kw)
@@ -329,7 +335,8 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             if frames is not None and gt.ndim == 3 and frames.due("mat"):
                 shown = ph.pred                                # lazy loop: the render of the current parameters (the next iteration's)
                 frames.mat_frame(loop_num, part, done - 1, gt, _loss.linear_to_srgb((shown * (gt.mean() / shown.mean())).clamp_min(1e-8)),   # its own exposure ratio (:388)
-                                 ph.current_maps(), shading_normal if shading_normal is not None else scene.shading_normal())
+                                 ph.current_maps(), ph.current_maps()["normal"] if moves_n else
+                                 (shading_normal if shading_normal is not None else scene.shading_normal()))
             if bool(info["stopped"].all()):
                 stop = "early_stop"
                 break
@@ -346,9 +353,12 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             if gt.ndim == 4 and env4.ndim == 3:
                 env4 = env4.unsqueeze(0).expand((gt.shape[0],) + tuple(env4.shape))
             keep_best("envmap", env4.contiguous(), improved)
-            if not scene.use_mesh_normal and "normal" in mat:                     # SaveBest keeps the normal map it rendered with (:424-428)
+            if moves_n:                                                          # SaveBest keeps the normal map it rendered with (:421-422)
+                keep_best("normal", ph.best["normal"], improved)
+                mat["normal"] = saver.best["normal"]
+            elif not scene.use_mesh_normal and "normal" in mat:
                 keep_best("normal", mat["normal"].detach(), improved)
-        say(f"loop {loop_num}: part {part!r} ran {iters} iterations ({stop}), best mse {float(info['best_mse'].min()):.5f}")
+        say(f"loop {loop_num}: part {part!r}{' (normal map, on the device)' if moves_n else ''} ran {iters} iterations ({stop}), best mse {float(info['best_mse'].min()):.5f}")
         return iters - 1, ph.lr_at(max(iters - 1, 0)), stop
 
     def on_brdf_part_end(loop_num: int, part: str) -> None:                        # :460-463: every map comes back from the saver

@@ -554,6 +554,67 @@ def test_fused_phases_shade_with_a_fixed_predicted_normal_map():
     assert float((gt - gt_geo).abs().max()) > 1e-3                 # the map matters: the phases above did not shade with the geometry's normals
 
 
+@pytest.mark.parametrize("part", ["n", "armn", "rn"])
+def test_normal_phase_matches_the_torch_composition(part):
+    """NormalBrdfPhase (a part that moves the normal map, launch by launch on the C ABI, SaveBest / EarlyStopping on the device) against
+    BrdfPhase (autograd render, torch losses, torch Adam): the same losses, the same parameters after several Adam steps (Adam normalises
+    the step: five iterations move a parameter by at most 5 lr = 1.5e-3; compared on that scale), the same snapshot."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    H = W = 64
+    spp = 16
+    sc = synthetic.make_scene(7, H, W)
+    depth, light = _t(sc.depth, dev), _t(sc.light, dev)
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    init[0][:4] = 1.2                                               # outside the clamp range: the gating is exercised
+    init[1][4:8] = 0.01
+    geo = render.load_estimated_mesh(depth, use_mesh_normal=True).shading_normal()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n_true = torch.nn.functional.normalize(geo + 0.2 * torch.randn(geo.shape, generator=g).to(dev), dim=-1).contiguous()
+    n_init = (1.7 * torch.nn.functional.normalize(geo + 0.1 * torch.randn(geo.shape, generator=g).to(dev), dim=-1)).contiguous()   # not unit length
+    n_orig = torch.nn.functional.normalize(geo, dim=-1).contiguous()
+
+    def make_scene():
+        s = render.load_estimated_mesh(depth, use_mesh_normal=False)
+        s._set("emitter.data", light)
+        return s
+
+    with torch.no_grad():
+        gt = render.render_w_brdf(make_scene(), _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), n_true, spp)
+    originals = {"albedo": init[0] * 0.9, "roughness": init[1] * 0.9, "metallic": init[2] * 0.9, "normal": n_orig}
+    ref = loop.BrdfPhase(make_scene(), gt, *init, n_init, optimize_part=part, spp=spp, originals=originals)
+    ph = loop.NormalBrdfPhase(make_scene(), gt, *init, n_init, optimize_part=part, spp=spp, originals=originals)
+    for it in range(5):
+        mse_ref = ref.step()
+        ph.step()
+        st = ph.stats[0].cpu().numpy()
+        assert st[ops.STAT_MSE] == pytest.approx(float(mse_ref), rel=5e-4), f"iteration {it}"
+        assert float(ph.loss()[0]) == pytest.approx(float(ref.last["loss"]), rel=5e-4), f"iteration {it}"
+    assert float(ph.stats[0, ops.STAT_BEST]) == pytest.approx(float(ref.saver.best_loss), rel=5e-4)
+    keys = {"a": "albedo", "r": "roughness", "m": "metallic", "n": "normal"}
+    for ch, k in keys.items():
+        if ch in part:
+            diff = (ph.p[k] - ref.params[k].detach().reshape(ph.p[k].shape)).abs().max().item()
+            assert diff < 5e-5, f"{k}: {diff}"
+            assert (ph.p[k] - (n_init if k == "normal" else init["arm".index(ch)]).reshape(ph.p[k].shape)).abs().max().item() > 1e-3   # and it moved
+        else:
+            assert torch.equal(ph.p[k], init["arm".index(ch)].reshape(ph.p[k].shape))
+        assert_close(ph.best[k], ref.saver.best[k].reshape(ph.best[k].shape).cpu().numpy(), rtol=1e-4, what=f"best {k}")
+    assert (ph.best["normal"].norm(dim=-1) - 1).abs().max().item() < 1e-5
+    assert_close(ph.best_img, ref.saver.best["rendered_img"].cpu().numpy(), rtol=1e-3, what="best render")
+    assert ph.history().shape == (5, 1) and ph.poll()["iters"].tolist() == [5]
+    # EarlyStopping on the device: the firing iteration still updates, the ones enqueued behind it change nothing
+    es = loop.NormalBrdfPhase(make_scene(), gt, *init, n_init, optimize_part=part, spp=spp, originals=originals, patience=2, min_delta=0.5)
+    es.run(3)
+    snap = {k: v.clone() for k, v in es.p.items()}
+    assert es.poll()["stopped"].tolist() == [True] and es.poll()["iters"].tolist() == [3]
+    es.run(4)
+    assert es.poll()["iters"].tolist() == [3] and all(torch.equal(es.p[k], snap[k]) for k in snap)
+    with pytest.raises(NotImplementedError):
+        loop.NormalBrdfPhase(make_scene(), gt, *init, n_init, optimize_part="rm", spp=spp)
+
+
 def test_fused_phase_parts_and_device_early_stopping():
     """optimize_part masks (only the part's maps move, only its regularisers count) and the on-device EarlyStopping:
     identical stop iteration to the host state machine fed with the recorded losses, nothing changes after the stop."""
@@ -1003,7 +1064,7 @@ def test_pos_mlp_with_predicted_normals_runs_and_improves(tmp_path):
 
 def test_none_mode_with_n_in_the_order_runs_its_other_parts_fused(tmp_path):
     """--opt_order 'rm n' under --model_name none: the run shades with the predicted normal map throughout (use_mesh_normal False); the 'rm'
-    part leaves it alone and runs the fused phase, the 'n' part the autograd composition; normal.exr holds unit normals."""
+    part leaves it alone and runs the fused phase, the 'n' part NormalBrdfPhase (no autograd in either); normal.exr holds unit normals."""
     from PIL import Image
 
     from materialist_amd import pipeline
@@ -1019,8 +1080,8 @@ def test_none_mode_with_n_in_the_order_runs_its_other_parts_fused(tmp_path):
                                  num_epochs=12, sync_every=4, log=lines.append, model_name="none")
     rm = [ln for ln in lines if "part 'rm'" in ln]
     nn = [ln for ln in lines if "part 'n'" in ln]
-    assert rm and all("with normals" not in ln for ln in rm), lines
-    assert nn and all("with normals" in ln for ln in nn), lines
+    assert rm and all("with normals" not in ln and "normal map" not in ln for ln in rm), lines
+    assert nn and all("normal map, on the device" in ln for ln in nn), lines      # NormalBrdfPhase, not the autograd composition
     cfg = __import__("json").load(open(tmp_path / "case" / "config.json"))
     assert cfg["use_mesh_normal"] is False
     n = read_exr(str(tmp_path / "case" / "best_results" / "normal.exr"))

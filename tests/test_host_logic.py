@@ -42,9 +42,13 @@ def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "matpbr.h"', 'int main(void) {',
              '  printf("{\\"sizeof\\": %zu", sizeof(MatpbrBrdfPhase));']
     lines += [f'  printf(", \\"{f}\\": %zu", offsetof(MatpbrBrdfPhase, {f}));' for f in fields]
+    nfields = [name for name, _ in _lib.MatpbrNormalStep._fields_]
+    lines += ['  printf(", \\"n_sizeof\\": %zu", sizeof(MatpbrNormalStep));']
+    lines += [f'  printf(", \\"n_{f}\\": %zu", offsetof(MatpbrNormalStep, {f}));' for f in nfields]
     macros = ["FLAG_CLAMP_PARAMS", "FLAG_ATTACHED_SAMPLING", "FLAG_LAZY_FORCE", "FLAG_JAC16", "FLAG_MODELS_READY", "FLAG_ROTATE_BEST",
               "FLAG_GENERIC_STEP", "FLAG_JAC32"]
     lines += [f'  printf(", \\"{m}\\": %u", (unsigned)MATPBR_{m});' for m in macros]
+    lines += ['  printf(", \\"PART_N\\": %u", (unsigned)MATPBR_PART_N);']
     lines += ['  printf(", \\"PART_A\\": %u, \\"PART_R\\": %u, \\"PART_M\\": %u, \\"STATS_STRIDE\\": %d}\\n", MATPBR_PART_A, MATPBR_PART_R, MATPBR_PART_M, MATPBR_STATS_STRIDE);',
               '  return 0;', '}']
     src.write_text("\n".join(lines))
@@ -54,8 +58,12 @@ def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
     assert ctypes.sizeof(_lib.MatpbrBrdfPhase) == c["sizeof"]
     for f in fields:
         assert getattr(_lib.MatpbrBrdfPhase, f).offset == c[f], f
+    assert ctypes.sizeof(_lib.MatpbrNormalStep) == c["n_sizeof"]
+    for f in nfields:
+        assert getattr(_lib.MatpbrNormalStep, f).offset == c["n_" + f], f
     for m in macros:
         assert getattr(ops, m) == c[m], m
+    assert ops.PART_N == c["PART_N"] and ops.part_mask("armn") == c["PART_A"] | c["PART_R"] | c["PART_M"] | c["PART_N"]
     assert c["STATS_STRIDE"] == 16 and ops.STAT_GT_SUM == 15
     from materialist_amd.loop import FusedBrdfPhase
     assert FusedBrdfPhase.PARTS == {"a": c["PART_A"], "r": c["PART_R"], "m": c["PART_M"]}
