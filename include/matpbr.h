@@ -326,6 +326,14 @@ int matpbr_env_texel_phase_step(const float* T, const float* gt_srgb, float* pre
                                 int es_patience, float es_min_delta, void* workspace, size_t workspace_bytes, int H, int W, float* y, int ldy,
                                 const float* proj, float* env, float* best_env, float* light, float* g, float* adam_m, float* adam_v, float* hyper,
                                 float beta1, float beta2, float eps, int n_texels, int first, void* stream);
+/* The same two launches for the reference's parameterisation of the light (envhead.EnvMlpPhase: y[T, ldy] is the envmap MLP's output, `env` =
+ * softplus(y) and `light` = proj @ env formed by matpbr_env_project before the call): the pass over the transfer, then one workgroup that folds,
+ * commits SaveBest / EarlyStopping, snapshots the best envmap and back-propagates d_light through the projection and the softplus into d_y[T, ldy]
+ * (rows padded with zeros), from where the caller's backward chain through the MLP starts.  = matpbr_env_phase_step + matpbr_select_improved +
+ * matpbr_env_project_bwd, the same bits; d_y's row stride is ldy. */
+int matpbr_env_mlp_phase_step(const float* T, const float* light, const float* gt_srgb, float* pred, float* d_light, float* stats, float* history,
+                              int hist_len, int es_patience, float es_min_delta, void* workspace, size_t workspace_bytes, int H, int W, const float* y,
+                              int ldy, const float* proj, const float* env, float* best_env, float* d_y, int n_texels, int first, void* stream);
 /* The envmap head of hot loop A without a framework in between (inverse_img_w_mi.py:117-124,238-254): the 16x32 envmap is
  * softplus(envmap_net(start_envmap)) (mymodels/mlps.py:230-232) and the kernels integrate its SH projection.
  *   matpbr_env_project      env[T,3] = softplus(y[T, ldy]), light[25,3] = proj[25,T] env      (T <= 1024 texels)

@@ -304,6 +304,9 @@ struct EnvTexelTailArgs {
     int nblk, T, ldy, first, es_patience, hist_len;
     float inv_n3, es_min_delta, b1, b2, eps;
 };
+// ADAM false: the envmap-MLP parameterisation (envhead.EnvMlpPhase): y is the network's output, its gradient `g` goes back into the MLP's
+// backward chain -- fold, commit, snapshot and the projection's backward only (matpbr_env_mlp_phase_step)
+template <bool ADAM>
 __global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const EnvTexelTailArgs q) {
     __shared__ float s_red[kEnvFinalSlices][kEnvPart];
     __shared__ float s_dl[kNL];
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const 
     // else out of the L2: ~1.5 us each), so everything that does not depend on the fold is requested BEFORE it and together with its first
     // rows: the statistics row (thread 0), the step size and count, and each thread's first two parameters with their Adam moments, their
     // texels of the envmap and their columns of the projection (all of them at 16 x 32 texels)
-    const float lr = q.hyper[0], t_adam = q.hyper[1] + 1.0f;            // (read before thread 0 advances the count at the end)
+    const float lr = ADAM ? q.hyper[0] : 0.0f, t_adam = ADAM ? q.hyper[1] + 1.0f : 1.0f;   // (read before thread 0 advances the count at the end)
     float loc[kStatsStride];
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -325,7 +328,9 @@ __global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const 
 #pragma unroll
     for (int u = 0; u < kEl; ++u) {
         const int i = threadIdx.x + u * kEnvFinalThreads, ic = i < n_el ? i : 0, t = ic / q.ldy;
-        py[u] = q.y[ic]; pm[u] = q.adam_m[ic]; pv[u] = q.adam_v[ic];
+        py[u] = q.y[ic];
+        pm[u] = ADAM ? q.adam_m[ic] : 0.0f;
+        pv[u] = ADAM ? q.adam_v[ic] : 0.0f;
         pe[u] = q.env[i < q.T * 3 ? i : 0];
 #pragma unroll
         for (int k = 0; k < kNSH; ++k) pp[u][k] = q.proj[(long)k * q.T + t];
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const 
     if (s_flag[0]) {   // a stopped image: no gradient, no update; env / light stay what they are
         if (threadIdx.x == 0) { st[kStStopped] = 2.0f; st[kStImproved] = 0.0f; }
         if (threadIdx.x < kNL) q.d_light[threadIdx.x] = 0.0f;
+        for (int i = threadIdx.x; i < n_el; i += kEnvFinalThreads) q.g[i] = 0.0f;      // (what env_project_bwd_kernel makes of a zero d_light)
         return;
     }
     if (slice < kEnvFinalSlices) {
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const 
             gi *= pi > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-pi));
         }
         q.g[i] = gi;
+        if (!ADAM) return;
         const float mi = fmaf(q.b1, m0, (1.0f - q.b1) * gi);
         const float vi = fmaf(q.b2, v0, (1.0f - q.b2) * gi * gi);
         q.adam_m[i] = mi; q.adam_v[i] = vi;
@@ -417,9 +424,9 @@ __global__ __launch_bounds__(kEnvFinalThreads) void env_texel_tail_kernel(const 
         float pr[kNSH];
 #pragma unroll
         for (int k = 0; k < kNSH; ++k) pr[k] = q.proj[(long)k * q.T + t];
-        element(i, q.y[i], q.adam_m[i], q.adam_v[i], pr);
+        element(i, q.y[i], ADAM ? q.adam_m[i] : 0.0f, ADAM ? q.adam_v[i] : 0.0f, pr);
     }
-    if (threadIdx.x == 0) q.hyper[1] = t_adam;                           // adam_dev_tick_kernel
+    if (ADAM && threadIdx.x == 0) q.hyper[1] = t_adam;                   // adam_dev_tick_kernel
     // (the next iteration's softplus + SH projection stays a launch of its own, env_project_kernel: 75 waves side by side -- as the tail
     // of this one-workgroup kernel it ran 16 waves x 5 scalars in turn and the iteration took 64 us instead of 44)
 }
@@ -1806,8 +1813,29 @@ int matpbr_env_texel_phase_step(const float* T, const float* gt_srgb, float* pre
     q.env = env; q.best_env = best_env; q.light = light; q.hyper = hyper; q.history = history;
     q.nblk = nblk; q.T = n_texels; q.ldy = ldy; q.first = first; q.es_patience = es_patience; q.hist_len = hist_len;
     q.inv_n3 = inv_n3; q.es_min_delta = es_min_delta; q.b1 = beta1; q.b2 = beta2; q.eps = eps;
-    hipLaunchKernelGGL(env_texel_tail_kernel, dim3(1), dim3(kEnvFinalThreads), 0, st, q);
+    hipLaunchKernelGGL(env_texel_tail_kernel<true>, dim3(1), dim3(kEnvFinalThreads), 0, st, q);
     hipLaunchKernelGGL(env_project_kernel, dim3(kNL), dim3(64), 0, st, (const float*)y, ldy, proj, env, light, n_texels);     // the next iteration's envmap and light
+    return launch_status();
+}
+
+int matpbr_env_mlp_phase_step(const float* T, const float* light, const float* gt_srgb, float* pred, float* d_light, float* stats, float* history,
+                              int hist_len, int es_patience, float es_min_delta, void* workspace, size_t workspace_bytes, int H, int W, const float* y,
+                              int ldy, const float* proj, const float* env, float* best_env, float* d_y, int n_texels, int first, void* stream) {
+    if (!T || !light || !gt_srgb || !d_light || !stats || !y || !proj || !env || !best_env || !d_y || H <= 0 || W <= 0 || n_texels <= 0 ||
+        n_texels > 1024 || ldy < 3)
+        return MATPBR_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < matpbr_env_phase_workspace_bytes(H, W, 1)) return MATPBR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = env_blocks(H, W);
+    const long P = (long)H * W;
+    const float inv_n3 = 1.0f / (3.0f * (float)P);
+    hipLaunchKernelGGL(env_prt_kernel, dim3((unsigned)nblk, 1u), dim3(kBlock), 0, st, T, light, gt_srgb, pred, (const float*)stats, (float*)workspace, P, inv_n3);
+    EnvTexelTailArgs q{};
+    q.part = (const float*)workspace; q.stats = stats; q.d_light = d_light; q.y = const_cast<float*>(y); q.g = d_y; q.proj = proj;
+    q.env = const_cast<float*>(env); q.best_env = best_env; q.history = history;
+    q.nblk = nblk; q.T = n_texels; q.ldy = ldy; q.first = first; q.es_patience = es_patience; q.hist_len = hist_len;
+    q.inv_n3 = inv_n3; q.es_min_delta = es_min_delta; q.b1 = 0.9f; q.b2 = 0.999f; q.eps = 1e-8f;
+    hipLaunchKernelGGL(env_texel_tail_kernel<false>, dim3(1), dim3(kEnvFinalThreads), 0, st, q);
     return launch_status();
 }
 

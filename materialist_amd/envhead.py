@@ -113,12 +113,22 @@ class EnvMlpPhase:
         wp, bp = self.views[-1]
         calls.append((lib.matpbr_mlp_layer_fwd, (P(inps[-1]), inps[-1].stride(0), P(wp), wp.stride(0), P(bp), P(self.y), None, 4, M, self.n_last, K)))
         calls.append((lib.matpbr_env_project, (P(self.y), 4, P(self.proj), P(self.env), P(self.light), M)))
-        calls.append((lib.matpbr_env_phase_step, (P(self.T), P(self.light), P(self.gt_srgb), None, P(self.d_light), P(self.stats), P(self.hist),
-                                                  history_len, self.patience, self.min_delta, P(self.ws_env), self.ws_env.numel() * 4, self.H,
-                                                  self.W, 1)))
-        self._select_at = len(calls)
-        calls.append((lib.matpbr_select_improved, (P(self.best_env_flat), P(self.env), P(self.stats), 0, M * 3)))
-        calls.append((lib.matpbr_env_project_bwd, (P(self.y), 4, P(self.proj), P(self.d_light), P(self.g_out), 4, M)))
+        if self.FUSED_TAIL:
+            # the pass over the transfer, then ONE workgroup for the fold, the SaveBest / EarlyStopping commit, the snapshot of the best envmap and
+            # the projection's backward (matpbr_env_mlp_phase_step: the same bits as the four kernels below, two launches fewer)
+            self._select_at = len(calls)
+            self._first_arg = 21
+            calls.append((lib.matpbr_env_mlp_phase_step, (P(self.T), P(self.light), P(self.gt_srgb), None, P(self.d_light), P(self.stats), P(self.hist),
+                                                          history_len, self.patience, self.min_delta, P(self.ws_env), self.ws_env.numel() * 4, self.H,
+                                                          self.W, P(self.y), 4, P(self.proj), P(self.env), P(self.best_env_flat), P(self.g_out), M, 0)))
+        else:
+            calls.append((lib.matpbr_env_phase_step, (P(self.T), P(self.light), P(self.gt_srgb), None, P(self.d_light), P(self.stats), P(self.hist),
+                                                      history_len, self.patience, self.min_delta, P(self.ws_env), self.ws_env.numel() * 4, self.H,
+                                                      self.W, 1)))
+            self._select_at = len(calls)
+            self._first_arg = 3
+            calls.append((lib.matpbr_select_improved, (P(self.best_env_flat), P(self.env), P(self.stats), 0, M * 3)))
+            calls.append((lib.matpbr_env_project_bwd, (P(self.y), 4, P(self.proj), P(self.d_light), P(self.g_out), 4, M)))
         # backward chain, one launch per layer (matpbr_mlp_small_bwd_step): with g = dL/d pre of a layer in hand, its weight gradient, the input
         # gradient into the layer below (+ that layer's per-tile column sums) and its own bias gradient (the fold of the column sums the launch
         # before left; for the output layer the column sums of g itself) are independent pieces of work
@@ -147,6 +157,8 @@ class EnvMlpPhase:
         self._calls = calls
         self._first = True
 
+    FUSED_TAIL = True       # False: matpbr_env_phase_step + matpbr_select_improved + matpbr_env_project_bwd (the same bits: tests/test_gpu_parity.py)
+
     # ------------------------------------------------------------------------------------------------------------------------------
     def set_lr(self, lr: float) -> None:
         self.hyper[0:1].fill_(float(lr))
@@ -155,7 +167,8 @@ class EnvMlpPhase:
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         for i, (fn, args) in enumerate(self._calls):
             if i == self._select_at and self._first:
-                args = args[:3] + (1,) + args[4:]               # the first iteration always snapshots (best_env starts undefined)
+                k = getattr(self, "_first_arg", 3)
+                args = args[:k] + (1,) + args[k + 1:]           # the first iteration always snapshots (best_env starts undefined)
             code = fn(*args, stream)
             if code != 0:
                 _lib.check(code, fn.__name__)

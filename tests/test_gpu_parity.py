@@ -2116,6 +2116,27 @@ def test_env_mlp_phase_matches_the_autograd_composition():
     sd = {k: v.clone() for k, v in net_b.state_dict().items()}
     net_b.load_state_dict(sd)
     assert torch.equal(net_b(ones).detach(), before)
+    # the one-workgroup tail behind the pass over the transfer (matpbr_env_mlp_phase_step) against the three launches it replaces: the same bits,
+    # with EarlyStopping armed and firing
+    runs = {}
+    for fused in (True, False):
+        EnvMlpPhase.FUSED_TAIL = fused
+        try:
+            torch.manual_seed(2)
+            net_c = copy.deepcopy(net_a)
+            pc = EnvMlpPhase(make_scene(), gt, net_c, ones, spp=spp, lr=1e-2, patience=3, min_delta=0.3, use_graph=True)
+        finally:
+            EnvMlpPhase.FUSED_TAIL = True
+        assert len(pc._calls) == (13 if fused else 15), len(pc._calls)
+        for _ in range(4):
+            pc.step()
+        pc.step_many(6)
+        pc.step_many(6)
+        runs[fused] = (pc.flat.clone(), pc.adam_m.clone(), pc.stats.clone(), pc.history().clone(), pc.best_env.clone(), pc.g_out.clone(), pc.poll())
+    for a, b in zip(runs[True][:6], runs[False][:6]):
+        assert torch.equal(a, b)
+    assert runs[True][6]["stopped"].tolist() == [True] and runs[True][6]["iters"].tolist() == runs[False][6]["iters"].tolist()
+    assert runs[True][6]["iters"].tolist()[0] < 16
 
 
 def test_sines_that_carry_the_sign_of_their_cosine():
