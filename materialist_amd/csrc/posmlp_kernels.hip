@@ -1142,10 +1142,42 @@ __global__ __launch_bounds__(256) void mlp_small_bwd_step_kernel(const SmallBwdS
     small_tn_body(a.G, a.ldg, a.X, a.ldx, a.dW, a.ldw, a.M, a.N, a.K, b);
     return;
   }
+  if (a.n_bias <= 4 && a.groups_in > 64) {
+    // the output layer: a handful of columns, one row of g per point (512 groups).  One thread per column walked the 512 rows in turn --
+    // a chain of 512 dependent loads, 31 us, the longest kernel of the envmap-MLP iteration; here the rows are spread over the workgroup
+    // (thread t: rows t, t + 256, ... in turn) and the 256 partial sums folded by a fixed tree: deterministic, a few microseconds
+    __shared__ float s_b[256][4];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int g = (int)threadIdx.x; g < a.groups_in; g += 256) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < a.n_bias) v[c] += a.part_in[(long)g * a.part_stride + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s_b[threadIdx.x][c] = v[c];
+    __syncthreads();
+    for (int half = 128; half > 0; half >>= 1) {
+      if ((int)threadIdx.x < half) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_b[threadIdx.x][c] += s_b[threadIdx.x + half][c];
+      }
+      __syncthreads();
+    }
+    if ((int)threadIdx.x < a.n_bias) a.d_bias[threadIdx.x] = s_b[0][threadIdx.x];
+    return;
+  }
   const int c = (b - a.nW) * 256 + (int)threadIdx.x;        // fixed order over the groups: deterministic
   if (c < a.n_bias) {
     float s = 0.f;
-    for (int g = 0; g < a.groups_in; ++g) s += a.part_in[(long)g * a.part_stride + c];
+    int g = 0;
+    for (; g + 8 <= a.groups_in; g += 8) {          // eight groups requested together, added in turn (the same sum, one round trip instead of eight)
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = a.part_in[(long)(g + j) * a.part_stride + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += t[j];
+    }
+    for (; g < a.groups_in; ++g) s += a.part_in[(long)g * a.part_stride + c];
     a.d_bias[c] = s;
   }
 }

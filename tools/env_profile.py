@@ -1,5 +1,7 @@
 """Hot loop A alone (envmap PosMLP head + matpbr_env_phase_step, hipGraph replay) for rocprofv3 kernel traces.
-usage: python tools/env_profile.py [steps] [graph|eager] [mlp|texels]"""
+usage: python tools/env_profile.py [steps] [graph|eager] [mlp|texels|envmlp|normal]
+    mlp: loop.FusedEnvPhase (head, its backward and Adam as framework ops); texels: envhead.EnvTexelPhase; envmlp: envhead.EnvMlpPhase (the
+    reference's parameterisation, every launch on the C ABI); normal: loop.NormalBrdfPhase (hot loop B, a part that moves the normal map)"""
 import os
 import sys
 import time
@@ -24,7 +26,20 @@ def main():
     s_gt._set("emitter.data", t(sc.light))
     with torch.no_grad():
         gt = render.render_w_brdf(s_gt, t(sc.albedo), t(sc.roughness), t(sc.metallic), None, 64)
-    if len(sys.argv) > 3 and sys.argv[3] == "texels":
+    kind = sys.argv[3] if len(sys.argv) > 3 else "mlp"
+    if kind == "normal":
+        s_n = render.load_estimated_mesh(t(sc.depth), use_mesh_normal=False)
+        s_n._set("emitter.data", t(sc.light))
+        geo = render.load_estimated_mesh(t(sc.depth), use_mesh_normal=True).shading_normal()
+        gen = torch.Generator(device="cpu").manual_seed(1)
+        n0 = torch.nn.functional.normalize(geo + 0.1 * torch.randn(geo.shape, generator=gen).to(dev), dim=-1).contiguous()
+        ph = loop.NormalBrdfPhase(s_n, gt, t(sc.init_albedo), t(sc.init_roughness), t(sc.init_metallic), n0, optimize_part="armn", spp=64)
+        enet = None
+    elif kind == "envmlp":
+        from materialist_amd.envhead import EnvMlpPhase
+        ph = EnvMlpPhase(s_env, gt, posmlp.envmap_net().to(dev), torch.ones(512, 3, device=dev), spp=64, lr=1e-3, use_graph=graph)
+        enet = None
+    elif kind == "texels":
         from materialist_amd.envhead import EnvTexelPhase
         ph = EnvTexelPhase(s_env, gt, torch.zeros(16, 32, 3, device=dev, requires_grad=True), spp=64, lr=1e-3, use_graph=graph)
         enet = None

@@ -1,12 +1,15 @@
 #!/bin/bash
-# kernel trace of hot loop A (tools/env_profile.py): per-kernel durations and the gaps between them.  usage: tools/env_trace.sh [mlp|texels]
+# kernel trace of hot loop A (tools/env_profile.py), or of a part that moves the normal map: per-kernel durations of one iteration and the gaps between them.
+#   usage: tools/env_trace.sh [mlp|texels|envmlp|normal]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tr_e -o t -- python3 tools/env_profile.py 300 graph ${1:-texels} 2>&1 | tail -2
-python - <<'PY'
+ENV_TRACE_KIND=${1:-texels} python - <<'PY'
 import csv, glob
 path = glob.glob("gpurun_out/tr_e/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-k = [i for i, r in enumerate(rows) if "env_prt" in r["Kernel_Name"] or "env_texel_iter" in r["Kernel_Name"]]
+import os
+anchor = "shade_kernel" if os.environ.get("ENV_TRACE_KIND") == "normal" else "env_prt"
+k = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 i0 = k[len(k) // 2]
 n = k[len(k) // 2 + 1] - i0
 for r0, r1 in zip(rows[i0 - 1:i0 + n], rows[i0:i0 + n + 1]):

@@ -6,6 +6,8 @@ timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/r04_gpu
 timeout 400 bash tools/trace_pos_mlp.sh r04 > /dev/null 2>&1
 bash tools/pmc_passes_r04.sh > gpurun_out/r04_pmc.log 2>&1
 python tools/pmc_to_traffic.py gpurun_out --write > /dev/null && cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
+for k in texels envmlp normal; do timeout 200 bash tools/env_trace.sh $k > gpurun_out/r04_iteration_$k.txt 2>&1; done
+timeout 200 bash tools/op_face_trace.sh 8 > gpurun_out/r04_trace_operator_face_b8.csv 2>&1
 timeout 600 python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err
 for s in indoor2:none indoor2:pos_mlp jinjya:none; do
   timeout 300 python tools/real_image.py --sample ${s%%:*} --model_name ${s##*:} --out /tmp/real_image > /dev/null 2>&1
