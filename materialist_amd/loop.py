@@ -470,8 +470,8 @@ class FusedBrdfPhase:
 class NormalBrdfPhase:
     """Hot loop B in `model_name == 'none'` mode for a part of --opt_order that MOVES THE NORMAL MAP ('n', 'armn', ...; use_mesh_normal False:
     inverse_img_w_mi.py:356-432), launch by launch on the C ABI: the render under the current maps, the loss statistics with SaveBest /
-    EarlyStopping on the device, d loss / d pred, the backward render (material AND normal gradients: `shade_bwd_nl_kernel` walks both lobes'
-    directions per pixel), and one kernel for the regularisers (L1(normal, normal_ori) among them), the clamp gating, NF.normalize's backward,
+    EarlyStopping on the device, d loss / d pred, the backward render (the normal gradient: `shade_bwd_nl_kernel` walks both lobes' directions per
+    pixel; the material gradients: closed forms of the nine planes the forward render leaves), and one kernel for the regularisers (L1(normal, normal_ori) among them), the clamp gating, NF.normalize's backward,
     the snapshot of an improving iteration and Adam (include/matpbr.h `MatpbrNormalStep`): nine launches per iteration, no autograd, no
     framework losses, no host synchronisation per epoch.  Same arithmetic as `BrdfPhase` (its parity reference: tests/test_gpu_parity.py);
     same interface as `FusedBrdfPhase` (`run`, `poll`, `history`, `p`, `best`, `best_img`, `lr_at`)."""
@@ -512,6 +512,7 @@ class NormalBrdfPhase:
         self.best_img = torch.zeros_like(self.gt)
         self.pred = torch.empty_like(self.gt)
         self.d_pred = torch.zeros_like(self.gt)
+        self.jac = ops.plane9(self.p["albedo"]) if any(live[k] for k in ("albedo", "roughness", "metallic")) else None
         self.stats = ops.new_loss_stats(B, dev)
         if best_mse is not None:   # SaveBest.best_loss is global across phases and never reset (F11)
             self.stats[:, ops.STAT_BEST] = best_mse.to(dev).reshape(-1)
@@ -547,16 +548,20 @@ class NormalBrdfPhase:
         with torch.cuda.device(self.gt.device):
             st = ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream)
             chk = self._libmod.check
-            chk(lib.matpbr_shade_fwd(P(c["albedo"]), P(c["roughness"]), P(c["metallic"]), P(c["normal"]), P(self.light), o.LIGHT_SH25, o.NSH,
-                                     P(self.pred), H, W, B, self.spp, ct.byref(self.cam), 0, st), "matpbr_shade_fwd")
+            # the render; with material maps in the part it also leaves the nine planes their gradients are closed forms of (a second walk of
+            # the samples in the backward pass otherwise: 30 of the iteration's 87 us)
+            chk(lib.matpbr_shade_fwd_ex(P(c["albedo"]), P(c["roughness"]), P(c["metallic"]), P(c["normal"]), P(self.light), o.LIGHT_SH25, o.NSH, None,
+                                        P(self.pred), P(self.jac) if want_mat else None, H, W, B, self.spp, ct.byref(self.cam), 0, st), "matpbr_shade_fwd_ex")
             chk(lib.matpbr_brdf_loss_stats_es(P(self.pred), P(self.gt), P(self.gt_srgb), P(p["albedo"]), P(p["roughness"]), P(p["metallic"]),
                                               P(self.orig["albedo"]), P(self.orig["roughness"]), P(self.orig["metallic"]), self.scale_delta,
                                               P(self.stats), P(self.ws), self.ws.numel() * 4, H, W, B, self.mask, self.patience, self.min_delta,
                                               P(self.hist), self.hist_len, st), "matpbr_brdf_loss_stats_es")
             chk(lib.matpbr_brdf_loss_dpred(P(self.pred), P(self.gt_srgb), P(self.stats), P(self.d_pred), H, W, B, st), "matpbr_brdf_loss_dpred")
+            if want_mat:
+                chk(lib.matpbr_shade_bwd_jac(P(c["albedo"]), P(c["roughness"]), P(c["metallic"]), P(self.jac), P(self.d_pred), P(g["albedo"]),
+                                             P(g["roughness"]), P(g["metallic"]), H, W, B, st), "matpbr_shade_bwd_jac")
             chk(lib.matpbr_shade_bwd(P(c["albedo"]), P(c["roughness"]), P(c["metallic"]), P(c["normal"]), P(self.light), o.LIGHT_SH25, o.NSH,
-                                     P(self.d_pred), P(g["albedo"]) if want_mat else None, P(g["roughness"]) if want_mat else None,
-                                     P(g["metallic"]) if want_mat else None, P(g["normal"]), None, None, 0, H, W, B, self.spp, ct.byref(self.cam), 0, st),
+                                     P(self.d_pred), None, None, None, P(g["normal"]), None, None, 0, H, W, B, self.spp, ct.byref(self.cam), 0, st),
                 "matpbr_shade_bwd")
             chk(lib.matpbr_brdf_normal_step(ct.byref(self._ns), self.t + 1, self.lr_at(self.t), st), "matpbr_brdf_normal_step")
         self.t += 1
