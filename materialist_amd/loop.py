@@ -953,8 +953,10 @@ class PosMlpNormalPhase:
     """Hot loop B in `pos_mlp` mode with output_type 'armn' (inverse_img_w_mi.py:165-172,493-506,516-554): the coordinate MLP
     also predicts the shading normal (`'n'` in --opt_order, predicted normals instead of geometric ones).  Maps from the net
     (clamps of :493-496, `normalize` of :497), the autograd render, the torch-composed loss with the L1 anchor on every live part
-    (:522-537), AdamW + StepLR.  The normal gradient needs the `d n` variant of the backward kernel, so this phase goes through
-    the operator face (`render_w_brdf`) rather than the fused loss kernels."""
+    (:522-537), AdamW + StepLR.  On the GPU (no `--use_mask`) the render, the loss statistics, SaveBest's decision and the gradients of the
+    maps run on the C ABI (`_step_device`: the launches of `NormalBrdfPhase`); autograd only carries those gradients back through the clamps,
+    the normalisation and the MLP (its layers are the HIP kernels of `posmlp._PosMlpHipFn`).  Otherwise: the operator face (`render_w_brdf`)
+    and the torch-composed loss."""
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_armn: torch.Tensor,
                  fixed: Dict[str, torch.Tensor], optimize_part: str = "armn", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1,
@@ -975,6 +977,7 @@ class PosMlpNormalPhase:
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)
         self.saver = saver if saver is not None else DeviceSaveBest()
         self.best_weights = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        self._t = 0
 
     def maps_from_net(self):
         arm = self.net(self.start)                                                       # :493
@@ -992,7 +995,73 @@ class PosMlpNormalPhase:
             maps["metallic"] = masked_mean_fill(maps["metallic"], self.mask)
         return maps, live
 
+    DEVICE_LOSS = True      # False: the autograd render and the torch-composed loss in every case
+
+    def _device_setup(self) -> None:
+        from . import ops
+
+        dev, H, W = self.gt.device, self.H, self.W
+        self.ops = ops
+        self.stats = ops.new_loss_stats(1, dev)
+        self.ws = torch.empty(int(_lib_ws(1)) // 4, dtype=torch.float32, device=dev)
+        self.pred, self.d_pred = torch.empty_like(self.gt), torch.empty_like(self.gt)
+        self.jac = ops.plane9(self.gt)
+        self._light = self.scene.light.detach().contiguous()
+        E = lambda c: torch.empty(H, W, c, device=dev)
+        self.g = {"albedo": E(3), "roughness": E(1), "metallic": E(1)}
+        self.best = {"albedo": E(3), "roughness": E(1), "metallic": E(1), "normal": E(3), "rendered_img": torch.zeros_like(self.gt)}
+        self.saver.best = self.best        # the runner reads the snapshot through the saver
+
+    def _step_device(self) -> torch.Tensor:
+        """The iteration with the render, the loss, SaveBest's decision and the gradients of the maps on the C ABI (no autograd render node,
+        no framework losses): the maps the net produced, detached -> render with its nine planes -> statistics -> material gradients with their
+        regularisers and the snapshot (matpbr_brdf_loss_bwd_jac) -> d loss / d pred -> the normal gradient (matpbr_shade_bwd) + its L1 anchor;
+        autograd carries those gradients back through the clamps, the normalisation and the MLP."""
+        o, sc = getattr(self, "ops", None), self.scene
+        if o is None:
+            self._device_setup()
+            o = self.ops
+        if self.saver.best_loss is not None and self._t == 0:
+            self.stats[:, o.STAT_BEST] = self.saver.best_loss.to(self.gt.device).reshape(-1)   # SaveBest.best_loss is global across phases (F11)
+        maps, live = self.maps_from_net()
+        d = {k: maps[k].detach().contiguous() for k in ("albedo", "roughness", "metallic", "normal")}
+        o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], d["normal"], self._light, self.spp, sc.fov, out=self.pred, jac=self.jac)
+        og = self.orig
+        o.brdf_loss_stats(self.pred, self.gt, self.gt_srgb, d["albedo"], d["roughness"], d["metallic"], og["albedo"].contiguous(),
+                          og["roughness"].contiguous(), og["metallic"].contiguous(), self.scale_delta, self.stats, self.ws, optimize_part=self.part)
+        o.brdf_loss_bwd_jac(d["albedo"], d["roughness"], d["metallic"], self.jac, self.pred, self.gt_srgb, self.stats, og["albedo"].contiguous(),
+                            og["roughness"].contiguous(), og["metallic"].contiguous(), self.scale_delta, self.g["albedo"], self.g["roughness"],
+                            self.g["metallic"], self.best["albedo"], self.best["roughness"], self.best["metallic"], self.best["rendered_img"],
+                            optimize_part=self.part)
+        grads = {k: self.g[k] for k in ("albedo", "roughness", "metallic")}
+        improved = self.stats[0, o.STAT_IMPROVED] > 0.5
+        if "normal" in live:
+            lib = __import__("materialist_amd._lib", fromlist=["load"]).load()
+            with torch.cuda.device(self.gt.device):
+                code = lib.matpbr_brdf_loss_dpred(o._ptr(self.pred), o._ptr(self.gt_srgb), o._ptr(self.stats), o._ptr(self.d_pred), self.H, self.W, 1,
+                                                  o._stream(self.pred))
+            if code != 0:
+                raise RuntimeError(f"matpbr_brdf_loss_dpred: {code}")
+            g_n = o.shade_bwd(d["albedo"], d["roughness"], d["metallic"], d["normal"], self._light, self.d_pred, self.spp, sc.fov, want_mat=False,
+                              want_n=True)[3]
+            g_n.add_(torch.sign(d["normal"] - og["normal"]), alpha=self.scale_delta / (3.0 * self.H * self.W))      # L1(normal, normal_ori), :533-535
+            grads["normal"] = g_n
+        self.best["normal"] = torch.where(improved, d["normal"], self.best["normal"])
+        self.saver.best = self.best
+        torch.autograd.backward([maps[k] for k in live], [grads[k].reshape(maps[k].shape) for k in live])      # :544
+        for k, v in self.net.state_dict().items():                                       # SaveBest keeps the weights too (:546-547)
+            self.best_weights[k] = torch.where(improved, v.detach(), self.best_weights[k])
+        self.saver.best_loss = self.stats[0, o.STAT_BEST].clone()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        if self.opt.param_groups[0]["lr"] > 1.5e-4:                                      # :553-554
+            self.sched.step()
+        self._t += 1
+        return self.stats[0, o.STAT_MSE].clone()
+
     def step(self) -> torch.Tensor:
+        if self.DEVICE_LOSS and self.armn and self.mask is None and self.gt.is_cuda:
+            return self._step_device()
         maps, live = self.maps_from_net()
         pred = _render.render_w_brdf(self.scene, maps["albedo"], maps["roughness"], maps["metallic"], maps["normal"], self.spp)   # :515
         loss, loss_mse, pred_srgb, _ = _loss.brdf_loss(pred, self.gt, {k: maps[k] for k in live}, self.orig, self.scale_delta, self.gt_srgb)

@@ -1089,6 +1089,72 @@ def test_none_mode_with_n_in_the_order_runs_its_other_parts_fused(tmp_path):
     assert np.isfinite(res["psnr"]) and res["best_loss"] < 0.5
 
 
+@pytest.mark.parametrize("part", ["armn", "rmn"])
+def test_pos_mlp_normal_phase_on_the_c_abi_matches_the_autograd_composition(part):
+    """PosMlpNormalPhase (output_type 'armn': the net predicts the normal map too) with the render, the loss statistics, SaveBest's decision and
+    the gradients of the maps on the C ABI against the same phase through the operator face and the torch-composed loss: same losses, same
+    weights after several AdamW steps, same snapshot."""
+    import copy
+
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+
+    dev = _cuda()
+    H = W = 48
+    spp = 8
+    sc = synthetic.make_scene(9, H, W)
+    depth, light = _t(sc.depth, dev), _t(sc.light, dev)
+    geo = render.load_estimated_mesh(depth, use_mesh_normal=True).shading_normal()
+    gen = torch.Generator(device="cpu").manual_seed(6)
+    n_true = torch.nn.functional.normalize(geo + 0.2 * torch.randn(geo.shape, generator=gen).to(dev), dim=-1).contiguous()
+
+    def make_scene():
+        s = render.load_estimated_mesh(depth, use_mesh_normal=False)
+        s._set("emitter.data", light)
+        return s
+
+    with torch.no_grad():
+        gt = render.render_w_brdf(make_scene(), _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), n_true, spp)
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    start = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1), geo.reshape(-1, 3)], dim=-1).contiguous()
+    fixed = {"albedo": init[0], "roughness": init[1], "metallic": init[2], "normal": geo}
+    torch.manual_seed(4)
+    net_a = posmlp.brdf_net("armn").to(dev)
+    net_b = copy.deepcopy(net_a)
+    runs = {}
+    for device_loss, net in ((True, net_a), (False, net_b)):
+        loop.PosMlpNormalPhase.DEVICE_LOSS = device_loss
+        try:
+            ph = loop.PosMlpNormalPhase(make_scene(), gt, net, start, fixed, optimize_part=part, spp=spp, saver=loop.DeviceSaveBest())
+            first_grads, opt_step = [], ph.opt.step
+
+            def capture(*a, **kw):                                   # the gradients of the first iteration, as the optimiser sees them
+                if not first_grads:
+                    first_grads.extend(p_.grad.detach().clone() for p_ in net.parameters())
+                return opt_step(*a, **kw)
+
+            ph.opt.step = capture
+            mses = [float(ph.step()) for _ in range(4)]
+        finally:
+            loop.PosMlpNormalPhase.DEVICE_LOSS = True
+        assert hasattr(ph, "stats") == device_loss                   # which path ran
+        runs[device_loss] = (mses, {k: v.detach().clone() for k, v in net.state_dict().items()}, {k: v.clone() for k, v in ph.saver.best.items()},
+                             float(ph.saver.best_loss), {k: v.clone() for k, v in ph.best_weights.items()}, first_grads)
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert a == pytest.approx(b, rel=5e-4)
+    assert runs[True][3] == pytest.approx(runs[False][3], rel=5e-4)
+    # the same gradients reach the network: every parameter tensor to 1e-3 of its norm
+    for ga, gb, (name, _) in zip(runs[True][5], runs[False][5], net_a.named_parameters()):
+        assert (ga - gb).norm().item() <= 1e-3 * gb.norm().item() + 1e-12, name
+    # ... and the weights after four AdamW steps of 3e-4 agree wherever the gradient is more than rounding (AdamW's first steps are lr * sign(g):
+    # an entry whose gradient is zero to rounding -- the first layer's weights on near-constant inputs -- moves by +- lr in either run)
+    for k, v in runs[True][1].items():
+        diff = (v - runs[False][1][k]).abs()
+        assert diff.median().item() < 2e-6 and (diff > 3e-5).float().mean().item() < 0.15, (k, diff.max().item(), (diff > 3e-5).float().mean().item())
+    for k in ("albedo", "roughness", "metallic", "normal"):
+        assert_close(runs[True][2][k].reshape(-1), runs[False][2][k].reshape(-1).cpu().numpy(), rtol=3e-3, what=f"best {k}")   # (the maps of weights that differ as above)
+    assert_close(runs[True][2]["rendered_img"], runs[False][2]["rendered_img"].cpu().numpy(), rtol=3e-3, what="best render")
+
+
 def test_pos_mlp_phase_matches_torch_composition():
     """f2 in the loop: PosMlpBrdfPhase (maps from the residual MLP, render/loss/backward in libmatpbr.so, gradients handed back
     to torch) against the same iteration composed from torch ops around the autograd render (inverse_img_w_mi.py:493-554)."""
