@@ -123,10 +123,13 @@ struct PxGH {
 };
 struct PStepFlags { bool part_r, part_m, slopes, att; };
 
-__device__ __forceinline__ void pstep_load(PxXY& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags f) {
+// the parameters: the only loads whose address depends on the image's state row (MATPBR_FLAG_ROTATE_BEST: which buffer holds the current values)
+__device__ __forceinline__ void pstep_load_params(PxXY& x, const StepPtrs& sp, unsigned i) {
+    x.r = ldf(sp.r, i * 4u); x.m = ldf(sp.m, i * 4u);
+}
+__device__ __forceinline__ void pstep_load_fixed(PxXY& x, const LazyStepArgs& qs, unsigned i, const PStepFlags f) {
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
-    x.r = ldf(sp.r, o1); x.m = ldf(sp.m, o1);
     x.gt = ld3(q.gt_srgb, o3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { x.X0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c], o1)); x.Y0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c + 1], o1)); }
@@ -150,16 +153,24 @@ __device__ __forceinline__ void pstep_load(PxXY& x, const LazyStepArgs& qs, cons
     if (f.part_r) { x.r0 = ldf(q.r0, o1); if (q.am[1]) { x.mr = ldf(q.am[1], o1); x.vr = ldf(q.av[1], o1); } }
     if (f.part_m) { x.m0 = ldf(q.m0, o1); if (q.am[2]) { x.mm = ldf(q.am[2], o1); x.vm = ldf(q.av[2], o1); } }
 }
-__device__ __forceinline__ void pstep_load(PxGH& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags) {
+__device__ __forceinline__ void pstep_load(PxXY& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags f) {
+    pstep_load_params(x, sp, i);
+    pstep_load_fixed(x, qs, i, f);
+}
+__device__ __forceinline__ void pstep_load_params(PxGH& x, const StepPtrs& sp, unsigned i) { x.a = ld3(sp.a, i * 12u); }
+__device__ __forceinline__ void pstep_load_fixed(PxGH& x, const LazyStepArgs& qs, unsigned i, const PStepFlags) {
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
-    x.a = ld3(sp.a, o3);
     x.gt = ld3(q.gt_srgb, o3);
     x.a0 = ld3(q.a0, o3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { x.G[c] = as_f(ldu(qs.fplane[kFgG + c], o1)); x.H[c] = as_f(ldu(qs.fplane[kFgH + c], o1)); }
     x.ma = F3{0.0f, 0.0f, 0.0f}; x.va = F3{0.0f, 0.0f, 0.0f};
     if (q.am[0]) { x.ma = ld3(q.am[0], o3); x.va = ld3(q.av[0], o3); }
+}
+__device__ __forceinline__ void pstep_load(PxGH& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags f) {
+    pstep_load_params(x, sp, i);
+    pstep_load_fixed(x, qs, i, f);
 }
 
 // torch.optim.Adam on one element (adam_update of matpbr_shade.hpp with the moments in registers)
@@ -309,6 +320,18 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     const int nb = (nblk_img - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
     const int ntile = 2 * nb;
     auto tile_px0 = [&](int t) -> int { return ((int)blockIdx.x + (t >> 1) * (int)gridDim.x) * kLazyBlockPixels + (t & 1) * kTile; };
+    // ---- the first two tiles are requested before anything else: their latency runs under the fold of the statistics.  Models, target,
+    // anchors and moments first -- nothing about their addresses depends on the image's state row, whose load is one more round trip at the
+    // head of every workgroup (and the whole of a one-image launch is a handful of round trips)
+    auto pix = [&](int t) -> int { const int p = tile_px0(t) + (int)threadIdx.x; return p < P ? p : P - 1; };
+    PStepFlags f;
+    f.part_r = (q.part_mask & MATPBR_PART_R) != 0;
+    f.part_m = (q.part_mask & MATPBR_PART_M) != 0;
+    f.slopes = f.part_r || q.d_r != nullptr;
+    f.att = qs.attached != 0;
+    Px A, B;
+    pstep_load_fixed(A, qs, (unsigned)(b * P + pix(0)), f);
+    pstep_load_fixed(B, qs, (unsigned)(b * P + pix(1)), f);
     const float* old = qs.state_old + b * kStateStride;
     if (old[kStStopped] > 0.5f) {                          // EarlyStopping fired in an earlier iteration (uniform): nothing to do
         if (blockIdx.x == 0 && threadIdx.x < kStateStride) {
@@ -320,11 +343,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         }
         return;
     }
-    PStepFlags f;
-    f.part_r = (q.part_mask & MATPBR_PART_R) != 0;
-    f.part_m = (q.part_mask & MATPBR_PART_M) != 0;
-    f.slopes = f.part_r || q.d_r != nullptr;
-    f.att = qs.attached != 0;
     // where this image's iteration reads its parameters and writes the new ones: MATPBR_FLAG_ROTATE_BEST keeps them in two buffers each and
     // the OLD state row says which holds the current values (the new selector is known after the commit below: the writes wait for it)
     const float sel_old = old[kStSel];
@@ -335,11 +353,8 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         if (qs.alt_r) sp.r = rd1 ? qs.alt_r : q.pr;
         if (qs.alt_m) sp.m = rd1 ? qs.alt_m : q.pm;
     }
-    // ---- the first two tiles are requested before anything else: their latency runs under the fold of the statistics
-    auto pix = [&](int t) -> int { const int p = tile_px0(t) + (int)threadIdx.x; return p < P ? p : P - 1; };
-    Px A, B;
-    pstep_load(A, qs, sp, (unsigned)(b * P + pix(0)), f);
-    pstep_load(B, qs, sp, (unsigned)(b * P + pix(1)), f);
+    pstep_load_params(A, sp, (unsigned)(b * P + pix(0)));
+    pstep_load_params(B, sp, (unsigned)(b * P + pix(1)));
     __builtin_amdgcn_sched_barrier(0);
     PS_STAMP(1);
     // ---- the iteration's statistics: every workgroup folds the rows of partial sums of its image (fixed order: the same bits everywhere),
