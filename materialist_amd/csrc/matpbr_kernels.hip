@@ -119,20 +119,26 @@ __global__ __launch_bounds__(kBlock) void loss_sums2_kernel(const float* __restr
     __shared__ float s_buf[4];
     const int b = blockIdx.y;
     float ratio = 1.0f;
-    if (MODE >= 1 && img_stopped(stats, b)) return;
-    // MATPBR_FLAG_ROTATE_BEST: the image's current render is in the buffer its state row names (uniform)
-    if (MODE >= 3 && state != nullptr && state[b * kStateStride + kStSel] > 0.5f) pred = pred_alt;
-    // MODE 4: the first two words of this thread are requested before the fold of the forward sums below (they do not depend on it)
-    const bool vec4 = MODE == 4 && (n3 & 3) == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(gt_srgb)) & 15) == 0;
+    // MODE 4: the first two words of this thread are requested before the fold of the forward sums below (they do not depend on it) -- the
+    // target's before anything else: the render's address waits for the image's state row (MATPBR_FLAG_ROTATE_BEST: which buffer holds it)
+    const bool vec4 = MODE == 4 && (n3 & 3) == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(pred_alt) | reinterpret_cast<uintptr_t>(gt_srgb)) & 15) == 0;
     const long stride4 = (long)gridDim.x * kBlock, first4 = (long)blockIdx.x * kBlock + threadIdx.x;
     float4 pre_p[2], pre_g[2];
     if (vec4) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const long i = first4 + u * stride4;
-            const long ic = i < (n3 >> 2) ? i : 0;
-            pre_p[u] = reinterpret_cast<const float4*>(pred + b * n3)[ic];
-            pre_g[u] = reinterpret_cast<const float4*>(gt_srgb + b * n3)[ic];
+            pre_g[u] = reinterpret_cast<const float4*>(gt_srgb + b * n3)[i < (n3 >> 2) ? i : 0];
+        }
+    }
+    if (MODE >= 1 && img_stopped(stats, b)) return;
+    // MATPBR_FLAG_ROTATE_BEST: the image's current render is in the buffer its state row names (uniform)
+    if (MODE >= 3 && state != nullptr && state[b * kStateStride + kStSel] > 0.5f) pred = pred_alt;
+    if (vec4) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long i = first4 + u * stride4;
+            pre_p[u] = reinterpret_cast<const float4*>(pred + b * n3)[i < (n3 >> 2) ? i : 0];
         }
     }
     float sp_total = 0.0f;

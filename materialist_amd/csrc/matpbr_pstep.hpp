@@ -329,11 +329,12 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     f.part_m = (q.part_mask & MATPBR_PART_M) != 0;
     f.slopes = f.part_r || q.d_r != nullptr;
     f.att = qs.attached != 0;
+    const float* old = qs.state_old + b * kStateStride;
+    const float stopped_old = old[kStStopped], sel_old = old[kStSel];     // (scalar loads, asked for first: they arrive while the ~90 vector loads below issue)
     Px A, B;
     pstep_load_fixed(A, qs, (unsigned)(b * P + pix(0)), f);
     pstep_load_fixed(B, qs, (unsigned)(b * P + pix(1)), f);
-    const float* old = qs.state_old + b * kStateStride;
-    if (old[kStStopped] > 0.5f) {                          // EarlyStopping fired in an earlier iteration (uniform): nothing to do
+    if (stopped_old > 0.5f) {                              // EarlyStopping fired in an earlier iteration (uniform): nothing to do
         if (blockIdx.x == 0 && threadIdx.x < kStateStride) {
             float v = old[threadIdx.x];
             if (threadIdx.x == kStStopped) v = 2.0f;
@@ -345,7 +346,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     }
     // where this image's iteration reads its parameters and writes the new ones: MATPBR_FLAG_ROTATE_BEST keeps them in two buffers each and
     // the OLD state row says which holds the current values (the new selector is known after the commit below: the writes wait for it)
-    const float sel_old = old[kStSel];
     StepPtrs sp{q.a, q.r, q.m, q.pa, q.pr, q.pm, qs.pred_next};
     if (qs.rotate) {
         const bool rd1 = __builtin_amdgcn_readfirstlane((int)(sel_old > 0.5f)) != 0;
