@@ -977,7 +977,7 @@ class PosMlpNormalPhase:
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)
         self.saver = saver if saver is not None else DeviceSaveBest()
         self.best_weights = {k: v.detach().clone() for k, v in net.state_dict().items()}
-        self._t = 0
+        self._t, self.ops = 0, None          # (`ops` and the device buffers: set up by the first `_step_device`)
 
     def maps_from_net(self):
         arm = self.net(self.start)                                                       # :493
@@ -1017,10 +1017,9 @@ class PosMlpNormalPhase:
         no framework losses): the maps the net produced, detached -> render with its nine planes -> statistics -> material gradients with their
         regularisers and the snapshot (matpbr_brdf_loss_bwd_jac) -> d loss / d pred -> the normal gradient (matpbr_shade_bwd) + its L1 anchor;
         autograd carries those gradients back through the clamps, the normalisation and the MLP."""
-        o, sc = getattr(self, "ops", None), self.scene
-        if o is None:
+        if self.ops is None:
             self._device_setup()
-            o = self.ops
+        o, sc = self.ops, self.scene
         if self.saver.best_loss is not None and self._t == 0:
             self.stats[:, o.STAT_BEST] = self.saver.best_loss.to(self.gt.device).reshape(-1)   # SaveBest.best_loss is global across phases (F11)
         maps, live = self.maps_from_net()
@@ -1036,12 +1035,7 @@ class PosMlpNormalPhase:
         grads = {k: self.g[k] for k in ("albedo", "roughness", "metallic")}
         improved = self.stats[0, o.STAT_IMPROVED] > 0.5
         if "normal" in live:
-            lib = __import__("materialist_amd._lib", fromlist=["load"]).load()
-            with torch.cuda.device(self.gt.device):
-                code = lib.matpbr_brdf_loss_dpred(o._ptr(self.pred), o._ptr(self.gt_srgb), o._ptr(self.stats), o._ptr(self.d_pred), self.H, self.W, 1,
-                                                  o._stream(self.pred))
-            if code != 0:
-                raise RuntimeError(f"matpbr_brdf_loss_dpred: {code}")
+            o.brdf_loss_dpred(self.pred, self.gt_srgb, self.stats, self.d_pred)
             g_n = o.shade_bwd(d["albedo"], d["roughness"], d["metallic"], d["normal"], self._light, self.d_pred, self.spp, sc.fov, want_mat=False,
                               want_n=True)[3]
             g_n.add_(torch.sign(d["normal"] - og["normal"]), alpha=self.scale_delta / (3.0 * self.H * self.W))      # L1(normal, normal_ori), :533-535

@@ -515,6 +515,18 @@ def brdf_loss_stats(pred, gt, gt_srgb, pa, pr, pm, a0, r0, m0, scale_delta: floa
     return stats
 
 
+def brdf_loss_dpred(pred, gt_srgb, stats, d_pred) -> torch.Tensor:
+    """d loss / d pred of the BRDF-phase loss from the statistics `brdf_loss_stats` left (include/matpbr.h `matpbr_brdf_loss_dpred`), into `d_pred`."""
+    lib = _lib.load()
+    pred = _dev(pred, "pred", (3,))
+    B, H, W = _bhw(pred)
+    with torch.cuda.device(pred.device):
+        code = lib.matpbr_brdf_loss_dpred(_ptr(pred), _ptr(_dev(gt_srgb, "gt_srgb", (3,))), _ptr(stats), _ptr(_dev(d_pred, "d_pred", (3,))), H, W, B,
+                                          _stream(pred))
+    _lib.check(code, "matpbr_brdf_loss_dpred")
+    return d_pred
+
+
 def brdf_loss_bwd_jac(pa, pr, pm, jac, pred, gt_srgb, stats, a0, r0, m0, scale_delta: float, d_a, d_r, d_m,
                       best_a=None, best_r=None, best_m=None, best_img=None, optimize_part: str = "arm", jac16: bool = False) -> None:
     """Backward of the fused BRDF-phase loss into preallocated d_a/d_r/d_m from the jac planes of the forward pass that rendered

@@ -615,6 +615,70 @@ def test_normal_phase_matches_the_torch_composition(part):
         loop.NormalBrdfPhase(make_scene(), gt, *init, n_init, optimize_part="rm", spp=spp)
 
 
+def test_normal_phase_on_a_batch_and_on_a_ragged_image():
+    """NormalBrdfPhase on a batch of images = the same images alone, bit for bit (per-image statistics, per-image EarlyStopping), and an
+    image whose pixel count is no multiple of the workgroup size (50 x 70) against BrdfPhase."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    spp = 8
+    H, W = 40, 48
+    scs = [synthetic.make_scene(20 + i, H, W) for i in range(2)]
+    st = lambda f: torch.stack([_t(f(s), dev) for s in scs])
+    depth, light = st(lambda s: s.depth), st(lambda s: s.light)
+    init = [st(lambda s: s.init_albedo), st(lambda s: s.init_roughness), st(lambda s: s.init_metallic)]
+    geo = render.load_estimated_mesh(depth, use_mesh_normal=True).shading_normal()
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    n_init = torch.nn.functional.normalize(geo + 0.15 * torch.randn(geo.shape, generator=gen).to(dev), dim=-1).contiguous()
+
+    def make_scene(sel=None):
+        s = render.load_estimated_mesh(depth if sel is None else depth[sel], use_mesh_normal=False)
+        s._set("emitter.data", light if sel is None else light[sel])
+        return s
+
+    with torch.no_grad():
+        gt = render.render_w_brdf(make_scene(), st(lambda s: s.albedo), st(lambda s: s.roughness), st(lambda s: s.metallic), geo, spp)
+    both = loop.NormalBrdfPhase(make_scene(), gt, *init, n_init, optimize_part="rmn", spp=spp, patience=3, min_delta=0.2)
+    both.run(8)
+    info = both.poll()
+    for i in range(2):
+        one = loop.NormalBrdfPhase(make_scene(i), gt[i], *[x[i] for x in init], n_init[i], optimize_part="rmn", spp=spp, patience=3, min_delta=0.2)
+        one.run(8)
+        for k in ("roughness", "metallic", "normal"):
+            assert torch.equal(one.p[k], both.p[k][i]), (i, k)
+            assert torch.equal(one.best[k], both.best[k][i]), (i, k)
+        assert torch.equal(one.history()[:, 0], both.history()[:, i])
+        assert one.poll()["iters"].tolist() == [int(info["iters"][i])]
+    # a ragged image
+    H2, W2 = 50, 70
+    sc = synthetic.make_scene(31, H2, W2)
+    depth2, light2 = _t(sc.depth, dev), _t(sc.light, dev)
+    init2 = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    geo2 = render.load_estimated_mesh(depth2, use_mesh_normal=True).shading_normal()
+    n2 = torch.nn.functional.normalize(geo2 + 0.15 * torch.randn(geo2.shape, generator=gen).to(dev), dim=-1).contiguous()
+
+    def scene2():
+        s = render.load_estimated_mesh(depth2, use_mesh_normal=False)
+        s._set("emitter.data", light2)
+        return s
+
+    with torch.no_grad():
+        gt2 = render.render_w_brdf(scene2(), _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), geo2, spp)
+    # (the anchor of the normal regulariser away from the start map: where normalize(n) equals its anchor up to rounding, sign(n - n0) is the
+    # sign of that rounding -- in the reference too -- and Adam turns it into a step of +- lr)
+    orig2 = {"albedo": init2[0], "roughness": init2[1], "metallic": init2[2], "normal": geo2}
+    ref = loop.BrdfPhase(scene2(), gt2, *init2, n2, optimize_part="an", spp=spp, originals=orig2)
+    ph = loop.NormalBrdfPhase(scene2(), gt2, *init2, n2, optimize_part="an", spp=spp, originals=orig2)
+    for it in range(3):
+        mse_ref = ref.step()
+        ph.step()
+        assert float(ph.stats[0, ops.STAT_MSE]) == pytest.approx(float(mse_ref), rel=5e-4), it
+        assert float(ph.loss()[0]) == pytest.approx(float(ref.last["loss"]), rel=5e-4), it
+    for k in ("albedo", "normal"):
+        assert (ph.p[k] - ref.params[k].detach()).abs().max().item() < 5e-5, k
+        assert torch.isfinite(ph.p[k]).all()
+
+
 def test_fused_phase_parts_and_device_early_stopping():
     """optimize_part masks (only the part's maps move, only its regularisers count) and the on-device EarlyStopping:
     identical stop iteration to the host state machine fed with the recorded losses, nothing changes after the stop."""
