@@ -533,7 +533,8 @@ int matpbr_adamw_step_snapshot_dev(float* p, const float* g, float* m, float* v,
  * The render is linear in the light, R = sum_k light[k] * T[k]:
  *   matpbr_shade_transfer  per-pixel transfer (d render / d light, both lobes) of the current materials into T (matpbr_transfer_bytes(); 300 B/pixel, tiled
  *                          [B][ceil(H*W/256)][75][256]: 75 = 25 coefficients x rgb; opaque to the caller), computed once
- *   matpbr_relight         out[F,H,W,3] for F lights [F,25,3] against one image's T (HBM-bound; 8 lights per pass) */
+ *   matpbr_relight         out[F,H,W,3] for F lights [F,25,3] against one image's T (HBM-bound; up to 24 lights share one pass over T: hand it
+ *                          the frames in batches of 24 -- 300/24 + 12 B/pixel per frame instead of 312) */
 size_t matpbr_transfer_bytes(int H, int W, int batch);
 int matpbr_shade_transfer(const float* a, const float* r, const float* m, const float* n, float* T, int H, int W, int batch,
                           int spp, const MatpbrCamera* cam, uint32_t flags, void* stream);

@@ -1873,8 +1873,13 @@ int matpbr_relight(const float* T, const float* lights, float* out_rgb, int H, i
     hipStream_t st = (hipStream_t)stream;
     for (int f0 = 0; f0 < n_frames; f0 += kRelightFrames) {
         const int nf = n_frames - f0 < kRelightFrames ? n_frames - f0 : kRelightFrames;
-        hipLaunchKernelGGL(relight_kernel, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, T, lights + (long)f0 * kNL,
-                           out_rgb + (long)f0 * P * 3, P, nf);
+        const dim3 grid((unsigned)((P + kBlock - 1) / kBlock));
+        if (nf > 8)
+            hipLaunchKernelGGL(relight_kernel<kRelightFrames>, grid, dim3(kBlock), 0, st, T, lights + (long)f0 * kNL, out_rgb + (long)f0 * P * 3, P, nf);
+        else if (nf > 1)
+            hipLaunchKernelGGL(relight_kernel<8>, grid, dim3(kBlock), 0, st, T, lights + (long)f0 * kNL, out_rgb + (long)f0 * P * 3, P, nf);
+        else    // one light (the best-so-far render of an env phase, a frame of a video): no accumulators for frames that are not there
+            hipLaunchKernelGGL(relight_kernel<1>, grid, dim3(kBlock), 0, st, T, lights + (long)f0 * kNL, out_rgb + (long)f0 * P * 3, P, nf);
     }
     return launch_status();
 }

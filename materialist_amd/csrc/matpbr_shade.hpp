@@ -1039,22 +1039,24 @@ __global__ __launch_bounds__(kBlock, 2) void shade_transfer_kernel(const float* 
     }
 }
 
-// out[f][p][c] = sum_k T[p][k][c] * light[f][k][c] for up to kRelightFrames lights per launch (T read once)
-constexpr int kRelightFrames = 8;
+// out[f][p][c] = sum_k T[p][k][c] * light[f][k][c] for up to NF lights per launch (T read once per launch: 300 B/pixel shared by NF frames of
+// 12 B/pixel each -- sixteen frames per pass move 129 MB per 2048 x 2048 frame, eight 207, one 1.31 GB)
+constexpr int kRelightFrames = 24;
 // the lights are read at wave-uniform addresses: scalar loads, SGPR operands of the FMAs (lights of frames >= n_frames must be readable)
+template <int NF>
 __global__ __launch_bounds__(kBlock) void relight_kernel(const float* __restrict__ T, const float* __restrict__ L, float* __restrict__ out,
                                                          long P, int n_frames) {
     const long p = (long)blockIdx.x * kBlock + threadIdx.x;
     if (p >= P) return;
-    float acc[kRelightFrames][3];
+    float acc[NF][3];
 #pragma unroll
-    for (int f = 0; f < kRelightFrames; ++f) acc[f][0] = acc[f][1] = acc[f][2] = 0.0f;
+    for (int f = 0; f < NF; ++f) acc[f][0] = acc[f][1] = acc[f][2] = 0.0f;
     const float* tp = T + transfer_index(0, p, 0, P);
 #pragma unroll 5
     for (int k = 0; k < kNSH; ++k) {
         const float t0 = tp[(k * 3) * 256], t1 = tp[(k * 3 + 1) * 256], t2 = tp[(k * 3 + 2) * 256];
 #pragma unroll
-        for (int f = 0; f < kRelightFrames; ++f) {
+        for (int f = 0; f < NF; ++f) {
             const int fi = f < n_frames ? f : 0;     // uniform: stays a scalar load
             acc[f][0] = fmaf(t0, L[fi * kNL + k * 3], acc[f][0]);
             acc[f][1] = fmaf(t1, L[fi * kNL + k * 3 + 1], acc[f][1]);
@@ -1062,10 +1064,10 @@ __global__ __launch_bounds__(kBlock) void relight_kernel(const float* __restrict
         }
     }
 #pragma unroll
-    for (int f = 0; f < kRelightFrames; ++f) {
-        if (f < n_frames) {
-            float* o = out + ((long)f * P + p) * 3;
-            o[0] = acc[f][0]; o[1] = acc[f][1]; o[2] = acc[f][2];
+    for (int f = 0; f < NF; ++f) {
+        if (f < n_frames) {                               // one 12-byte store per lane (global_store_dwordx3)
+            struct __attribute__((packed, aligned(4))) Rgb { float x, y, z; };
+            *reinterpret_cast<Rgb*>(out + ((long)f * P + p) * 3) = Rgb{acc[f][0], acc[f][1], acc[f][2]};
         }
     }
 }

@@ -197,8 +197,8 @@ def render_rolling_envmap(save_name: str, env_path: Optional[str], frames: int =
     env_id = os.path.basename(env_path)[:-4]
     paths: List[str] = []
     imgs = []
-    for f0 in range(0, frames, 8):
-        batch = rl.frames(np.stack(lights[f0:f0 + 8]))
+    for f0 in range(0, frames, 24):                                  # matpbr_relight's chunk: the transfer is read once per 24 frames
+        batch = rl.frames(np.stack(lights[f0:f0 + 24]))
         if write_frames:
             srgb = _loss.linear_to_srgb(batch.clamp_min(0)).clamp(0, 1).cpu().numpy()
             for k in range(srgb.shape[0]):

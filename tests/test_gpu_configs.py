@@ -108,13 +108,22 @@ def test_rolling_relight_2048_360_frames():
         direct = ops.shade_fwd(a, r, m, n, L[f].contiguous(), spp)
         assert (out8[f - f0] - direct).abs().max().item() <= 3e-5 * direct.abs().max().item(), f"frame {f}"
         assert torch.isfinite(out8[f - f0]).all()
-    # all 360 frames in 45 passes: finite, and the mean radiance is invariant under rotations about the pole up to the
+    # a frame is the same bits however many share its pass over the transfer (24 per pass since round 4: matpbr_relight's chunk; 8; 1)
+    out24 = torch.empty(24, S, S, 3, device=dev)
+    ops.relight(T, L[:24].contiguous(), S, S, out24)
+    ops.relight(T, L[:8].contiguous(), S, S, out8)
+    assert torch.equal(out24[:8], out8)
+    ops.relight(T, L[16:24].contiguous(), S, S, out8)
+    assert torch.equal(out24[16:], out8)
+    assert torch.equal(ops.relight(T, L[13:14].contiguous(), S, S)[0], out24[13])
+    # all 360 frames in 15 passes: finite, and the mean radiance is invariant under rotations about the pole up to the
     # view-dependence of the image (sanity: within 20 % of frame 0)
     means = []
-    for f0 in range(0, 360, 8):
-        ops.relight(T, L[f0:f0 + 8].contiguous(), S, S, out8)
-        means.append(out8.mean(dim=(1, 2, 3)).cpu())
+    for f0 in range(0, 360, 24):
+        ops.relight(T, L[f0:f0 + 24].contiguous(), S, S, out24)
+        means.append(out24.mean(dim=(1, 2, 3)).cpu())
     means = torch.cat(means)
+    assert means.numel() == 360
     assert torch.isfinite(means).all() and float((means / means[0] - 1).abs().max()) < 0.2
     # rotate_y == column roll of the 16x32 envmap (render_final.py:290-298), whole columns: 360/32 = 11.25 degrees
     rng = np.random.default_rng(2)
