@@ -459,15 +459,15 @@ def main(argv=None):
         def lazy_step_times(w):
             """The ONE launch that is the BRDF fwd+bwd pair of the lazy loop (backward of iteration t + Adam + render of iteration t+1), timed
             IN the loop (iterations 301-500 of a phase, so that the share of pixels re-sampled per launch is the loop's, not the start-up's)
-            with HIP events around it, and the statistics launch back to back."""
+            with HIP events ON it (the kernel's own begin and end: FusedBrdfPhase.step_timed), and the statistics launch back to back."""
             ph = w.phase("fused")
             ph.run(300)
             ev = []
             for _ in range(200):
-                ph.step_timed(ev)             # the real loop, HIP events around the launch in question (on the launch stream)
+                ph.step_timed(ev)             # the real loop, HIP events on the launch in question (on the launch stream)
             torch.cuda.synchronize()
-            t_step = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
-            t_res = sum(e[1].elapsed_time(e[2]) for e in ev) / len(ev)
+            t_step = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)        # the step kernel's own begin -> end (hipExtLaunchKernelGGL events)
+            t_res = sum(e[-1 if len(e) == 4 else 1].elapsed_time(e[2]) for e in ev) / len(ev)
             _, ref = ops.lazy_state_unpack(ph.lazy_state, ph.p["albedo"])
             t_stats = back_to_back(lambda: ph.launch_stage(2))
             return t_step, t_stats, float(ref.float().mean()), t_res
@@ -491,6 +491,9 @@ def main(argv=None):
                                           "constant albedo folded in (64 B/pixel of model); the pixels that left their model's interval are queued and re-sampled "
                                           "(20 GGX samples) by the small launch behind it (resample_launch_ms)",
                 "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / (HBM_PEAK / 1e9), "avg_launch_ms": t_step,
+                "timing": "mean over iterations 301-500 of a phase of the kernel's own begin -> end, two HIP events handed to the launch on the launch "
+                          "stream (hipExtLaunchKernelGGL via matpbr_brdf_phase_stages_timed); events RECORDED around the launch (rounds 2-3) add the "
+                          "stream's dispatch latency on both sides, 2-5 us, and disagreed with the rocprofv3 trace by that much",
                 "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM,
                 "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
                 "resampled_fraction": resampled, "stats_launches_ms": t_stats, "resample_launch_ms": t_res,

@@ -302,6 +302,11 @@ int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* phase, int t_done, void* st
 #define MATPBR_STAGE_RESAMPLE 8u /* pred_next mode: the pixels the backward launch listed (their roughness left their model's interval) are re-sampled,
                                     their models rebuilt and their render written (nothing to launch in the other modes) */
 int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* phase, int t, float lr, uint32_t stages, void* stream);
+/* Measurement only (bench.py's `roofline`): matpbr_brdf_phase_stages whose folded step launch (MATPBR_STAGE_BACKWARD of a phase with `lazy_fold`)
+ * records the kernel's own begin and end into two caller-owned hipEvent_t created with timing enabled (hipExtLaunchKernelGGL) -- events recorded
+ * around a launch include the stream's dispatch latency on both sides, 2-5 us on a 50 us kernel.  MATPBR_ERR_UNSUPPORTED for other phases. */
+int matpbr_brdf_phase_stages_timed(const MatpbrBrdfPhase* phase, int t, float lr, uint32_t stages, void* start_event, void* stop_event,
+                                   void* stream);
 
 /* One evaluation of hot loop A (inverse_img_w_mi.py:238-250) for a candidate light.  Materials and normals are fixed during the
  * phase (:216-220) and the render is linear in the light, so the phase works on the radiance transfer T of

@@ -66,6 +66,8 @@ SIGNATURES = {
     "matpbr_brdf_normal_step": (ctypes.c_int, [ctypes.POINTER(MatpbrNormalStep), ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "matpbr_env_mlp_phase_step": (ctypes.c_int, [_c_f] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                                  ctypes.c_int, _c_f, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_brdf_phase_stages_timed": (ctypes.c_int, [ctypes.POINTER(MatpbrBrdfPhase), ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p,
+                                                      ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_lazy_sums_count": (ctypes.c_int, [ctypes.c_int] * 2),
     "matpbr_shade_fwd_lazy": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(MatpbrCamera), ctypes.c_uint32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),

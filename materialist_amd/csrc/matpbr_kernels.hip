@@ -10,6 +10,7 @@
 //     (scalar loads, no VGPRs);
 //   * every reduction (light gradient, loss statistics) is two-pass with fixed-order partials: no atomics, bit-reproducible.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 #include <algorithm>
@@ -1572,7 +1573,19 @@ int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* str
     return matpbr_brdf_phase_stages(ph, t, lr, MATPBR_STAGE_RENDER | MATPBR_STAGE_STATS | MATPBR_STAGE_BACKWARD | MATPBR_STAGE_RESAMPLE, stream);
 }
 
+static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_t stages, void* stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+
 int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_t stages, void* stream) {
+    return phase_stages_impl(ph, t, lr, stages, stream, nullptr, nullptr);
+}
+
+int matpbr_brdf_phase_stages_timed(const MatpbrBrdfPhase* ph, int t, float lr, uint32_t stages, void* start_event, void* stop_event, void* stream) {
+    if (!start_event || !stop_event) return MATPBR_ERR_INVALID_ARG;
+    if (!ph || !ph->lazy_state || !ph->pred_next || !ph->lazy_fold || (ph->flags & MATPBR_FLAG_GENERIC_STEP)) return MATPBR_ERR_UNSUPPORTED;
+    return phase_stages_impl(ph, t, lr, stages, stream, (hipEvent_t)start_event, (hipEvent_t)stop_event);
+}
+
+static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_t stages, void* stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (!ph || t < 1) return MATPBR_ERR_INVALID_ARG;
     const MatpbrBrdfPhase& q = *ph;
     if (!q.pa || !q.pr || !q.pm || !q.n || !q.light || !q.gt_srgb || !q.a0 || !q.r0 || !q.m0 || !q.pred || !q.jac || !q.stats || q.batch <= 0)
@@ -1722,6 +1735,9 @@ int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             ls.tiles_per_wg = 2 * bpw; ls.n_tiles = 2 * lb.nblk;
             const dim3 pgrid((unsigned)((lb.nblk + bpw - 1) / bpw), (unsigned)q.batch);
             if (!(stages & MATPBR_STAGE_BACKWARD)) {
+            } else if (ev_start) {                            // measurement: the kernel's own begin / end timestamps (matpbr_brdf_phase_stages_timed)
+                if (fold == kFoldXY) hipExtLaunchKernelGGL(lazy_pstep_kernel<kFoldXY>, pgrid, dim3(kBlock), 0, st, ev_start, ev_stop, 0, ls, q.light, g, tab);
+                else hipExtLaunchKernelGGL(lazy_pstep_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, ev_start, ev_stop, 0, ls, q.light, g, tab);
             } else if (fold == kFoldXY) hipLaunchKernelGGL(lazy_pstep_kernel<kFoldXY>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
             else hipLaunchKernelGGL(lazy_pstep_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
             if ((stages & MATPBR_STAGE_RESAMPLE) && pwalk) {     // one wave per chunk of eight listed pixels; 256 waves per image take a queue of any length

@@ -434,17 +434,31 @@ class FusedBrdfPhase:
         self._libmod.check(code, "matpbr_brdf_phase_stages")
 
     def step_timed(self, events: list) -> None:
-        """`step()` with HIP events around its backward launch (the backward pass + Adam, in the lazy mode also the next render) and behind
-        the resampling launch that follows it, appended to `events` as (before, between, after): the in-loop durations for bench.py's roofline."""
+        """`step()` with HIP events on its backward launch (the backward pass + Adam, in the lazy mode also the next render) and behind the
+        resampling launch that follows it, appended to `events` as (begin, end, after the resampling launch[, before it]): the in-loop durations
+        for bench.py's roofline."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.launch_stage(1 | 2)
-        e0.record()
-        self.launch_stage(4)
-        e1.record()
+        if self.fold:
+            # the folded step: the kernel's own begin / end timestamps (matpbr_brdf_phase_stages_timed) -- events recorded around the launch add the
+            # stream's dispatch latency on both sides (2-5 us on a 50 us kernel: the rocprofv3 trace and the events disagreed by that much)
+            ct = self._ct
+            e0.record(); e1.record()         # (creates the underlying hipEvents)
+            with torch.cuda.device(self.gt.device):
+                code = self._lib.matpbr_brdf_phase_stages_timed(ct.byref(self._ph), self.t + 1, self.lr_at(self.t), 4, ct.c_void_p(e0.cuda_event),
+                                                                ct.c_void_p(e1.cuda_event), ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
+            self._libmod.check(code, "matpbr_brdf_phase_stages_timed")
+            ew = torch.cuda.Event(enable_timing=True)
+            ew.record()
+        else:
+            e0.record()
+            self.launch_stage(4)
+            e1.record()
+            ew = e1
         self.launch_stage(8)             # the resampling launch of the lazy mode (nothing otherwise)
         e2 = torch.cuda.Event(enable_timing=True)
         e2.record()
-        events.append((e0, e1, e2))
+        events.append((e0, e1, e2) if ew is e1 else (e0, e1, e2, ew))
         self._advance()
 
     def run(self, n: int) -> None:
