@@ -913,6 +913,52 @@ def test_env_texel_phase_matches_the_framework_composition():
     assert runs[True, False][6]["iters"].tolist()[0] < 30
 
 
+@pytest.mark.parametrize("env_size,hw", [((32, 32), (40, 56)), ((8, 16), (64, 64)), ((16, 32), (96, 128)), ((16, 32), (1024, 1024))])
+def test_env_texel_tail_on_other_envmap_and_image_sizes(env_size, hw):
+    """The one-workgroup tail of hot loop A (matpbr_env_texel_phase_step) beyond the 16 x 32 texels and the image sizes of the other tests: 1024
+    texels (more parameters than its up-front requests cover), 128 texels, few partial rows (a 40 x 56 image: 9 tiles), and 1024 x 1024 (BASELINE
+    configs[3]: 1024 partial rows, four chunks of them per slice of the fold) -- against the seven launches it replaces, bit for bit, with a
+    learning-rate change and EarlyStopping firing."""
+    from materialist_amd import render, synthetic
+    from materialist_amd.envhead import EnvTexelPhase
+
+    dev = _cuda()
+    H, W = hw
+    spp = 8
+    sc = synthetic.make_scene(12, H, W)
+
+    def make_scene():
+        s = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+        p = render.traverse(s)
+        p["shape.bsdf.a"], p["shape.bsdf.r"], p["shape.bsdf.m"] = _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev)
+        return s
+
+    with torch.no_grad():
+        gt = render.render_envmap(make_scene(), _t(sc.light, dev), spp).clone()
+    torch.manual_seed(5)
+    raw0 = torch.randn(*env_size, 3, device=dev) * 0.3
+    runs = {}
+    for fused in (True, False):
+        EnvTexelPhase.FUSED_TAIL = fused
+        try:
+            raw = raw0.clone().requires_grad_(True)
+            ph = EnvTexelPhase(make_scene(), gt, raw, spp=spp, lr=1e-2, patience=3, min_delta=0.2, use_graph=True)
+        finally:
+            EnvTexelPhase.FUSED_TAIL = True
+        for it in range(4):
+            ph.step()
+        ph.set_lr(3e-3)
+        ph.step_many(6)
+        ph.step_many(6)
+        ph.sync_params()
+        runs[fused] = (raw.detach().clone(), ph.adam_m.clone(), ph.adam_v.clone(), ph.stats.clone(), ph.history().clone(), ph.best_env.clone(), ph.g.clone(),
+                       ph.poll())
+    for a, b in zip(runs[True][:7], runs[False][:7]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(runs[True][0]).all() and (runs[True][0] - raw0).abs().max().item() > 1e-3
+    assert runs[True][7]["iters"].tolist() == runs[False][7]["iters"].tolist()
+
+
 def test_fused_env_phase_matches_torch_composition():
     """FusedEnvPhase (one matpbr_env_phase_step per iteration) against EnvPhase (autograd render + torch loss): texel light
     through softplus + SH projection, Adam in torch on both sides."""
