@@ -116,6 +116,8 @@ def test_rolling_relight_2048_360_frames():
     ops.relight(T, L[16:24].contiguous(), S, S, out8)
     assert torch.equal(out24[16:], out8)
     assert torch.equal(ops.relight(T, L[13:14].contiguous(), S, S)[0], out24[13])
+    assert torch.equal(ops.relight(T, L[3:16].contiguous(), S, S), out24[3:16])          # 13 frames: a partly filled pass of the 24-frame kernel
+    assert torch.equal(ops.relight(T, L[:31].contiguous(), S, S)[24:], ops.relight(T, L[24:31].contiguous(), S, S))   # 24 + 7
     # all 360 frames in 15 passes: finite, and the mean radiance is invariant under rotations about the pole up to the
     # view-dependence of the image (sanity: within 20 % of frame 0)
     means = []
