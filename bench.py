@@ -257,7 +257,11 @@ def main(argv=None):
             self.init = tuple(t([getattr(s, k) for s in scenes]) for k in ("init_albedo", "init_roughness", "init_metallic"))
 
         def phase(self, mode):
-            if mode == "fused":
+            if mode in ("fused", "fused_a") and self.B >= 8 and self.B % 2 == 0:
+                # a shard of images, as optimize.optimize_envmap_arm runs it: two groups of images stepping on streams of their own (one group's
+                # walk and statistics launches under the other's streaming step; the same results, bit for bit)
+                return loop.PipelinedBrdfPhase(self.scene, self.gt_image, *self.init, groups=2, optimize_part="rm" if mode == "fused" else "a", spp=args.spp)
+            if mode in ("fused", "fused_one_phase"):        # fused_one_phase: the whole shard as ONE phase (the roofline's kernel timing)
                 return loop.FusedBrdfPhase(self.scene, self.gt_image, *self.init, optimize_part="rm", spp=args.spp)
             if mode == "fused_exact":                       # every pixel's 20 GGX samples walked in every iteration (round 2's loop)
                 return loop.FusedBrdfPhase(self.scene, self.gt_image, *self.init, optimize_part="rm", spp=args.spp, lazy=False)
@@ -367,6 +371,10 @@ def main(argv=None):
             e_el, _ = proto.timed(ph8.step, 0, 500)           # the SAME phase goes on: iterations 311-810 of the part
             modes["fused_b8_steady"] = {"it_per_s": 500 * 8 * world / e_el, "ms_per_step": e_el / 500 * 1e3, "images_per_gpu": 8}
             del ph8
+            ph1 = wl8.phase("fused_one_phase")                # the same shard as ONE phase on one stream (round 3's form of fused_b8)
+            e_el, _ = proto.timed(ph1.step, 10, 300)
+            modes["fused_b8_one_phase"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
+            del ph1
             e_el, _ = proto.timed(wl8.phase("fused_a").step, 10, 300)
             modes["fused_b8_a"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
             e_el, _ = proto.timed(wl8.phase("fused_exact").step, 10, 100)
@@ -377,14 +385,18 @@ def main(argv=None):
                            "render from per-pixel models into which the maps the part leaves alone are folded); the walk of the pixels that left their "
                            "model's interval, eight per wave from a queue (|render - exact sampling| <= 1e-3 on every pixel of every iteration, "
                            "tests/test_gpu_lazy.py)",
+                  "fused_b8": "hot loop B, --model_name none, BASELINE configs[2]'s per-GPU shard (8 x 512x512), part 'rm', the first 310 iterations of the part: the "
+                              "shard as two groups of four images stepping on streams of their own (loop.PipelinedBrdfPhase; an image's iteration does not "
+                              "depend on the images beside it: the same results as one phase over the shard, bit for bit) -- one group's walk and statistics "
+                              "launches, latency-bound, run under the other's streaming step (512 workgroups: MATPBR_FLAG_SHARE_GPU)",
+                  "fused_b8_one_phase": "the shard as ONE FusedBrdfPhase on one stream (what fused_b8 was in rounds 2-3 and earlier in round 4)",
                   "fused_b8_steady": "fused_b8 further into the part (iterations 311-810 of the same phase): a part's first iterations re-sample ten times as many "
                                      "pixels as its steady state (0.26 % per iteration), and the reference's parts run for hundreds to thousands of iterations",
                   "fused_exact": "the same loop walking the 20 GGX samples of every pixel in every iteration (round 2: render+jac, statistics, streaming backward+Adam)",
                   "fused_b8_exact": "the 8-image shard with exact sampling in every iteration (round 2's fused_b8)",
-                  "fused_b8": "the same for BASELINE configs[2]'s per-GPU shard: 8 images in the kernels' batch dimension (image-iterations/s)",
                   "fused_a": "the same two launches in part 'a' of --opt_order 'rm a' (roughness fixed): no pixel ever leaves its model's interval, "
                              "nothing is re-sampled after the part's first render",
-                  "fused_b8_a": "part 'a' on the 8-image shard (image-iterations/s)",
+                  "fused_b8_a": "part 'a' on the 8-image shard, two groups of four images on streams of their own as fused_b8 (image-iterations/s)",
                   "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
                   "pos_mlp_exact_f32": "the pos_mlp loop with --mlp-products 0: 256-wide layers on the exact-f32 MFMA kernels, autograd composition "
                                        "(loop.PosMlpBrdfPhase); the default differs from it only in how the f32 products are formed (same error vs fp64)",
@@ -394,8 +406,9 @@ def main(argv=None):
                   "env_texels": "hot loop A of --model_name none (envhead.EnvTexelPhase): one pass over the radiance transfer, then ONE workgroup that folds its "
                                 "partial sums, commits SaveBest / EarlyStopping, snapshots the best envmap, back-propagates through the SH projection and the "
                                 "softplus and applies Adam (matpbr_env_texel_phase_step), then the next envmap's projection: three kernels from a hipGraph, seven in round 3",
-                  "env": "hot loop A: envmap PosMLP (small-tile MFMA layers) + softplus / SH projection + one pass over the radiance transfer + "
-                         "backward + Adam, 27 launches of libmatpbr.so replayed from a hipGraph",
+                  "env": "hot loop A: envmap PosMLP (small-tile MFMA layers) + softplus / SH projection + one pass over the radiance transfer and one workgroup "
+                         "behind it (fold, SaveBest / EarlyStopping, snapshot, projection backward) + backward chain + Adam: 14 kernels of libmatpbr.so per "
+                         "iteration, ten iterations per hipGraph replay and poll",
                   "torch": "hot loop B as the reference's loop body runs it UNCHANGED on the operator face (loop.BrdfPhase: clamp, render_w_brdf with autograd, "
                            "torch losses, torch.optim.Adam; inverse_img_w_mi.py:371-432): render_w_brdf renders from the scene's cached per-pixel models"}
     modes = {k: dict(v, what=mode_names[k]) for k, v in modes.items()}
@@ -466,7 +479,7 @@ def main(argv=None):
             """The ONE launch that is the BRDF fwd+bwd pair of the lazy loop (backward of iteration t + Adam + render of iteration t+1), timed
             IN the loop (iterations 301-500 of a phase, so that the share of pixels re-sampled per launch is the loop's, not the start-up's)
             with HIP events ON it (the kernel's own begin and end: FusedBrdfPhase.step_timed), and the statistics launch back to back."""
-            ph = w.phase("fused")
+            ph = w.phase("fused_one_phase")
             ph.run(300)
             ev = []
             for _ in range(200):

@@ -69,6 +69,9 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
 #define MATPBR_FLAG_JAC32 512u     /* matpbr_shade_fwd_lazy: `jac16` receives the NINE fp32 planes of matpbr_shade_fwd_ex's `jac` instead (matpbr_plane9_bytes()):
                                         what matpbr_shade_bwd_jac reads -- the operator face (render_w_brdf under autograd, inverse_img_w_mi.py:69-80)
                                         differentiates with full-precision P and S0 - S1 (d out / d m is a difference of the two) */
+#define MATPBR_FLAG_SHARE_GPU 2048u /* MatpbrBrdfPhase.flags: the folded step runs on at most 512 workgroups (two per CU) instead of 1024, leaving wave
+                                       slots and registers on every CU to launches of OTHER streams -- for a batch cut into groups that step on streams
+                                       of their own (loop.PipelinedBrdfPhase): one group's walk and statistics launches then run under another's step */
 #define MATPBR_FLAG_JAC16 32u      /* matpbr_brdf_loss_bwd_jac: `jac` holds the half-precision planes written by matpbr_shade_fwd_lazy */
 #define MATPBR_PART_A 2u            /* which maps a BRDF phase optimises (`optimize_part`, inverse_img_w_mi.py:343-357) */
 #define MATPBR_PART_R 4u

@@ -1726,7 +1726,7 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             ls.walk_queue = ls.walk_cnt + (size_t)q.batch * 2 * kWalkShards;
             ls.walk_par = t & 1;
             // at most 1024 workgroups (four per CU, all resident), each with up to kPstepMaxBlocks consecutive 512-pixel blocks of one image
-            long wg_cap = 1024;
+            long wg_cap = (q.flags & MATPBR_FLAG_SHARE_GPU) ? 512 : 1024;
 #ifdef MATPBR_EXP_TUNE   // measurement builds only (tools/r4_variant.sh)
             if (const char* e = std::getenv("MATPBR_PSTEP_WGS")) wg_cap = std::atol(e) > 0 ? std::atol(e) : wg_cap;
 #endif

@@ -21,6 +21,7 @@ FLAG_MODELS_READY = 64
 FLAG_ROTATE_BEST = 128
 FLAG_GENERIC_STEP = 256
 FLAG_JAC32 = 512
+FLAG_SHARE_GPU = 2048
 LAZY_NSTATE = 22
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,

@@ -324,6 +324,10 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             ph = _loop.NormalBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mat["normal"], **phase_kw)
         elif mask is not None:    # --use_mask: launch by launch (two image-wide means per iteration), same device-side SaveBest / EarlyStopping
             ph = _loop.MaskedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mask, **phase_kw)
+        elif gt.ndim == 4 and gt.shape[0] >= 8 and gt.shape[0] % 2 == 0 and gt.is_cuda:
+            # a shard of images: two groups stepping on streams of their own (the same results, bit for bit; one group's walk and statistics
+            # launches run under the other's streaming step)
+            ph = _loop.PipelinedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], groups=2, **phase_kw)
         else:
             ph = _loop.FusedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], **phase_kw)
         done, stop = 0, "num_epochs"

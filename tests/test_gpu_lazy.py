@@ -582,3 +582,40 @@ def test_a_batch_with_per_image_background_masks_equals_the_images_alone():
         assert float(fe.stats[k, ops.STAT_MSE]) == pytest.approx(float(mse), rel=2e-4)
         assert torch.allclose(fe.pred[k], pred.detach(), rtol=2e-4, atol=1e-6)
         assert (fe.d_light[k] - l0.grad).abs().max().item() <= 2e-4 * float(l0.grad.abs().max())
+
+
+@pytest.mark.parametrize("part", ["rm", "a"])
+def test_a_batch_cut_into_groups_on_streams_of_their_own_is_the_batch(part):
+    """loop.PipelinedBrdfPhase (groups of images stepping on their own streams, the step on 512 workgroups so that another group's walk and
+    statistics launches fit beside it) = one FusedBrdfPhase over the whole batch, bit for bit: parameters, SaveBest's maps and image, history,
+    statistics, the render -- with EarlyStopping armed."""
+    from materialist_amd import loop, render, synthetic
+
+    dev = _cuda()
+    B, H, W, spp = 4, 128, 160, 16
+    scs = [synthetic.make_scene(40 + i, H, W) for i in range(B)]
+    st = lambda f: torch.stack([_t(f(s), dev) for s in scs])
+
+    def make_scene():
+        s = render.load_estimated_mesh(st(lambda s: s.depth), use_mesh_normal=True)
+        s._set("emitter.data", st(lambda s: s.light))
+        return s
+
+    with torch.no_grad():
+        gt = render.render_w_brdf(make_scene(), st(lambda s: s.albedo), st(lambda s: s.roughness), st(lambda s: s.metallic), None, spp)
+    init = [st(lambda s: s.init_albedo), st(lambda s: s.init_roughness), st(lambda s: s.init_metallic)]
+    kw = dict(optimize_part=part, spp=spp, patience=5, min_delta=0.02)
+    one = loop.FusedBrdfPhase(make_scene(), gt, *init, **kw)
+    two = loop.PipelinedBrdfPhase(make_scene(), gt, *init, groups=2, **kw)
+    for n in (1, 7, 40):
+        one.run(n)
+        two.run(n)
+        assert torch.equal(one.stats, two.stats), n
+    for k in ("albedo", "roughness", "metallic"):
+        assert torch.equal(one.p[k], two.p[k]) and torch.equal(one.best[k], two.best[k]), k
+    assert torch.equal(one.best_img, two.best_img) and torch.equal(one.pred, two.pred)
+    assert torch.equal(one.history(), two.history())
+    a, b = one.poll(), two.poll()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert two.t == one.t == 48 and two.lr_at(5) == one.lr_at(5)
+

@@ -26,7 +26,25 @@ def main():
         return loop.FusedBrdfPhase(scene, gt, t(lambda s: s.init_albedo, sel), t(lambda s: s.init_roughness, sel), t(lambda s: s.init_metallic, sel),
                                    optimize_part=part, spp=64)
 
-    for groups in (1, 2, 4):
+    # the product's form of it: loop.PipelinedBrdfPhase (two groups, the step on 512 workgroups: MATPBR_FLAG_SHARE_GPU)
+    sel = range(B)
+    scene = render.load_estimated_mesh(t(lambda s: s.depth, sel), use_mesh_normal=True)
+    scene._set("emitter.data", t(lambda s: s.light, sel))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, t(lambda s: s.albedo, sel), t(lambda s: s.roughness, sel), t(lambda s: s.metallic, sel), None, 64)
+    for g2 in (2, 4):
+        pp = loop.PipelinedBrdfPhase(scene, gt, t(lambda s: s.init_albedo, sel), t(lambda s: s.init_roughness, sel), t(lambda s: s.init_metallic, sel),
+                                     groups=g2, optimize_part=part, spp=64)
+        pp.run(300)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pp.run(500)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print(f"part {part} PipelinedBrdfPhase groups {g2}: {el / 500 * 1e6:.1f} us per iteration of 8 images = {500 * B / el:.0f} image-iterations/s, "
+              f"mse {float(pp.stats[:, 1].mean()):.6f}")
+        del pp
+    for groups in (1, 2):
         per = B // groups
         phs = [phase(range(g * per, (g + 1) * per)) for g in range(groups)]
         streams = [torch.cuda.Stream(dev) for _ in range(groups)]
