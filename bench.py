@@ -41,7 +41,7 @@ def parse(argv=None):
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel; the reference renders with spp=64 (inverse_img_w_mi.py:625)")
     ap.add_argument("--images-per-gpu", type=int, default=1)
-    ap.add_argument("--mode", choices=["fused", "torch", "pos_mlp"], default=None,
+    ap.add_argument("--mode", choices=["fused", "fused_one_phase", "torch", "pos_mlp"], default=None,
                     help="default: pos_mlp (the reference's default mode: maps from the residual PosMLP) for one image per GPU, fused "
                          "(--model_name none, whole iteration in libmatpbr.so) for a batch; torch: the none-mode step composed from torch ops")
     ap.add_argument("--mlp-products", type=int, choices=[0, 6, 9], default=None,
@@ -389,6 +389,7 @@ def main(argv=None):
                               "shard as two groups of four images stepping on streams of their own (loop.PipelinedBrdfPhase; an image's iteration does not "
                               "depend on the images beside it: the same results as one phase over the shard, bit for bit) -- one group's walk and statistics "
                               "launches, latency-bound, run under the other's streaming step (512 workgroups: MATPBR_FLAG_SHARE_GPU)",
+                  "fused_one_phase": "--mode fused_one_phase (tools: traces and counter passes): the images of the shard as ONE FusedBrdfPhase on one stream",
                   "fused_b8_one_phase": "the shard as ONE FusedBrdfPhase on one stream (what fused_b8 was in rounds 2-3 and earlier in round 4)",
                   "fused_b8_steady": "fused_b8 further into the part (iterations 311-810 of the same phase): a part's first iterations re-sample ten times as many "
                                      "pixels as its steady state (0.26 % per iteration), and the reference's parts run for hundreds to thousands of iterations",

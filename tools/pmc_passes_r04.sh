@@ -3,14 +3,18 @@
 #   usage: bash tools/pmc_passes_r04.sh   -> condensed CSVs in gpurun_out/r04_*.csv
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out
-B8="bench.py --images-per-gpu 8 --mode fused --no-extras --no-cpu-baseline"
+B8="bench.py --images-per-gpu 8 --mode fused_one_phase --no-extras --no-cpu-baseline"   # the shard as ONE phase: the 8 x 512x512 launches the canonical bytes are defined on
 B1="bench.py --mode fused --no-extras --no-cpu-baseline"
-# 1. kernel trace of the 8 x 512x512 loop ALONE (the durations the roofline fractions are recomputed from), and of one image
+# 1. kernel trace of the 8 x 512x512 loop ALONE, the shard as ONE phase (the durations the roofline fractions are recomputed from), and of one image;
+#    then the same shard as the product runs it: two groups of four images on two streams (loop.PipelinedBrdfPhase)
 for B in 8 1; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_$B -o t -- python3 bench.py --images-per-gpu $B --mode fused --no-extras --no-cpu-baseline --steps 1000 --warmup 300 > $OUT/r04_trace_b$B.json 2> $OUT/r04_trace_b$B.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_$B -o t -- python3 bench.py --images-per-gpu $B --mode fused_one_phase --no-extras --no-cpu-baseline --steps 1000 --warmup 300 > $OUT/r04_trace_b$B.json 2> $OUT/r04_trace_b$B.err
   python tools/summarize_rocprof.py $OUT/tr_$B > $OUT/r04_trace_b$B.csv
   rm -rf $OUT/tr_$B
 done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_p -o t -- python3 bench.py --images-per-gpu 8 --mode fused --no-extras --no-cpu-baseline --steps 1000 --warmup 300 > $OUT/r04_trace_b8_two_groups.json 2> $OUT/r04_trace_b8_two_groups.err
+python tools/summarize_rocprof.py $OUT/tr_p > $OUT/r04_trace_b8_two_groups.csv
+rm -rf $OUT/tr_p
 pass() {  # name, counters, program...
   local name=$1 ctr=$2; shift 2
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$name -o p -- python3 "$@" > /dev/null 2> $OUT/pmc_$name.err
