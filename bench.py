@@ -656,6 +656,8 @@ def main(argv=None):
     if rank == 0:
         out = {
             "metric": "opt_iterations_per_sec_512x512", "value": value, "unit": "it/s", "n_gpus": world,
+            "device": (lambda pr: {"name": pr.name, "compute_units": pr.multi_processor_count, "memory_gb": round(pr.total_memory / 2 ** 30, 1),
+                                   "gcn_arch": getattr(pr, "gcnArchName", None)})(torch.cuda.get_device_properties(dev)),
             "world_size": dist.get_world_size() if use_dist else 1, "collective_backend": dist.get_backend() if use_dist else None,
             "steps": args.steps, "warmup": args.warmup, "device_warmup": device_warmup, "cold_first_process_it_per_s": cold, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

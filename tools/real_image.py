@@ -151,6 +151,10 @@ def main():
     if args.model_name is None:
         args.model_name = "pos_mlp" if args.sample == "indoor2" else "none"
     out = run(args) if args.sample == "indoor2" else run_jinjya(args)
+    import torch
+
+    pr = torch.cuda.get_device_properties(0)        # (the boxes of the pool are not all alike: which one this was)
+    out["device"] = {"name": pr.name, "compute_units": pr.multi_processor_count, "memory_gb": round(pr.total_memory / 2 ** 30, 1)}
     print(json.dumps(out, indent=1))
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, f"real_image_{args.model_name}.json" if args.sample == "indoor2" else f"real_image_jinjya_{args.model_name}.json"), "w") as fh:

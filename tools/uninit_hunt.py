@@ -50,7 +50,7 @@ for mask in (False, True):
             r = run(part=part, mask=mask, val=val)
             print(f"mask={mask} part={part} poison={val}: {'same' if same(ref, r) else 'DIFFERENT'}", flush=True)
             if not same(ref, r):
-                for c in ("ws", "jac", "_pred", "_best_img", "hist", "dcache"):
+                for c in ("ws", "lazy_fold", "jac", "_pred", "_best_img", "hist", "dcache"):
                     r2 = run(clear=(c,), part=part, mask=mask, val=val)
                     print("   cleared", c, "->", "same" if same(ref, r2) else "different", flush=True)
                 break
