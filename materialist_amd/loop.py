@@ -544,9 +544,18 @@ class PipelinedBrdfPhase:
         for st in self.streams:
             here.wait_stream(st)
 
+    def _release(self) -> None:
+        """The groups' streams wait for the caller's: what the caller's stream has just read of the groups' buffers (they belong to the groups'
+        streams in the allocator's books) is read before those streams touch -- or, after the phase is gone, re-use -- that memory."""
+        here = torch.cuda.current_stream(self.phases[0].gt.device)
+        for st in self.streams:
+            st.wait_stream(here)
+
     def _cat(self, get, dim: int = 0) -> torch.Tensor:
         self._join()
-        return torch.cat([get(ph) for ph in self.phases], dim=dim)
+        out = torch.cat([get(ph) for ph in self.phases], dim=dim)
+        self._release()
+        return out
 
     @property
     def t(self) -> int:
@@ -563,7 +572,9 @@ class PipelinedBrdfPhase:
             with torch.cuda.stream(st):                              # (`p`, `best` may enqueue the resolving launch of the rotating SaveBest)
                 parts.append(getattr(ph, name))
         self._join()
-        return {k: torch.cat([d[k] for d in parts], dim=0) for k in parts[0]}
+        out = {k: torch.cat([d[k] for d in parts], dim=0) for k in parts[0]}
+        self._release()
+        return out
 
     p = property(lambda self: self._dict("p"))
     best = property(lambda self: self._dict("best"))
@@ -575,7 +586,9 @@ class PipelinedBrdfPhase:
             with torch.cuda.stream(st):
                 parts.append(getattr(ph, name))
         self._join()
-        return torch.cat(parts, dim=0)
+        out = torch.cat(parts, dim=0)
+        self._release()
+        return out
 
     best_img = property(lambda self: self._img("best_img"))
     pred = property(lambda self: self._img("pred"))
@@ -585,7 +598,7 @@ class PipelinedBrdfPhase:
 
     def poll(self) -> Dict[str, torch.Tensor]:
         self._join()
-        polls = [ph.poll() for ph in self.phases]
+        polls = [ph.poll() for ph in self.phases]                     # (host copies: a synchronisation each)
         return {k: torch.cat([p_[k] for p_ in polls], dim=0) for k in polls[0]}
 
     def history(self) -> torch.Tensor:
