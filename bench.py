@@ -665,6 +665,8 @@ def main(argv=None):
                                    f"{'--model_name pos_mlp' if mode == 'pos_mlp' else '--model_name none'} "
                                    f"(maps -> render -> gamma-2.2 MSE/L1 loss -> backward -> Adam(W)), spp={args.spp}, geometric normals, SH25 light",
                        "mode": mode, "mode_requested": args.mode, "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25",
+                       "phase": type(phase).__name__ + (" (two groups of images on streams of their own: the same results as one phase, bit for bit)"
+                                                        if type(phase).__name__ == "PipelinedBrdfPhase" else ""),
                        "mlp_products": int(_posmlp._PosMlpHipFn.PRODUCTS),
                        "mlp_arithmetic": ("f32 results: each f32 operand of the 256-wide layers is the exact sum of three bf16 pieces; 6 of the 9 partial "
                                           "products (the dropped ones are below 2^-24 relative) on v_mfma_f32_32x32x16_bf16 with f32 accumulation; error "
