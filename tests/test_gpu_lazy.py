@@ -584,7 +584,7 @@ def test_a_batch_with_per_image_background_masks_equals_the_images_alone():
         assert (fe.d_light[k] - l0.grad).abs().max().item() <= 2e-4 * float(l0.grad.abs().max())
 
 
-@pytest.mark.parametrize("part", ["rm", "a"])
+@pytest.mark.parametrize("part", ["rm", "a", "arm"])
 def test_a_batch_cut_into_groups_on_streams_of_their_own_is_the_batch(part):
     """loop.PipelinedBrdfPhase (groups of images stepping on their own streams, the step on 512 workgroups so that another group's walk and
     statistics launches fit beside it) = one FusedBrdfPhase over the whole batch, bit for bit: parameters, SaveBest's maps and image, history,
