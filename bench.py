@@ -257,6 +257,9 @@ def main(argv=None):
             self.init = tuple(t([getattr(s, k) for s in scenes]) for k in ("init_albedo", "init_roughness", "init_metallic"))
 
         def phase(self, mode):
+            if mode == "fused_arm":                         # all three maps at once (BASELINE configs[0]'s --opt_order arm): the generic step
+                cls = loop.PipelinedBrdfPhase if self.B >= 8 and self.B % 2 == 0 else loop.FusedBrdfPhase
+                return cls(self.scene, self.gt_image, *self.init, optimize_part="arm", spp=args.spp, **({"groups": 2} if cls is loop.PipelinedBrdfPhase else {}))
             if mode in ("fused", "fused_a") and self.B >= 8 and self.B % 2 == 0:
                 # a shard of images, as optimize.optimize_envmap_arm runs it: two groups of images stepping on streams of their own (one group's
                 # walk and statistics launches under the other's streaming step; the same results, bit for bit)
@@ -375,6 +378,8 @@ def main(argv=None):
             e_el, _ = proto.timed(ph1.step, 10, 300)
             modes["fused_b8_one_phase"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
             del ph1
+            e_el, _ = proto.timed(wl8.phase("fused_arm").step, 10, 300)
+            modes["fused_b8_arm"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
             e_el, _ = proto.timed(wl8.phase("fused_a").step, 10, 300)
             modes["fused_b8_a"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
             e_el, _ = proto.timed(wl8.phase("fused_exact").step, 10, 100)
@@ -391,6 +396,8 @@ def main(argv=None):
                               "launches, latency-bound, run under the other's streaming step (512 workgroups: MATPBR_FLAG_SHARE_GPU)",
                   "fused_one_phase": "--mode fused_one_phase (tools: traces and counter passes): the images of the shard as ONE FusedBrdfPhase on one stream",
                   "fused_b8_one_phase": "the shard as ONE FusedBrdfPhase on one stream (what fused_b8 was in rounds 2-3 and earlier in round 4)",
+                  "fused_b8_arm": "the shard in a part that moves all three maps (BASELINE configs[0]'s --opt_order arm): nothing is constant to fold, the generic step "
+                                  "(round 3's kernels: 80 B/pixel of model + the three maps), two groups of four images on streams of their own",
                   "fused_b8_steady": "fused_b8 further into the part (iterations 311-810 of the same phase): a part's first iterations re-sample ten times as many "
                                      "pixels as its steady state (0.26 % per iteration), and the reference's parts run for hundreds to thousands of iterations",
                   "fused_exact": "the same loop walking the 20 GGX samples of every pixel in every iteration (round 2: render+jac, statistics, streaming backward+Adam)",
