@@ -464,7 +464,7 @@ int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, co
 /* ONE float per sine activation.  sin and cos of a pre-activation lie on the unit circle: the forward pass can store the sine with the SIGN of
  * the cosine in its last mantissa bit (the stored value moves by at most one ulp) and no cosines at all (a third of a 256-wide layer's
  * traffic); the backward pass rebuilds cos = sign * sqrt(1 - sin^2) where it multiplies by it.  The products stay f32-accurate; the cosine
- * factor of the backward pass carries |error| ~ 1.2e-7 / |cos| (rms relative error of a layer ~ 1e-5).
+ * factor of the backward pass carries |error| ~ 2e-7 / |cos| (rms relative error of a layer ~ 1e-5).
  *   matpbr_mlp_layer_fwd_bx / _bx_tail / _bx_head with c_out == NULL   write such sines
  *   matpbr_mlp_layer_fwd_sgn          the same for the thin first layer (K <= 16, image size), as matpbr_mlp_layer_fwd_tail
  *   matpbr_mlp_layer_bwd_input_bx_sgn / matpbr_mlp_layer_bwd_input_sgn   as matpbr_mlp_layer_bwd_input_bx / _bwd_input (n_red <= 16, image size) with
@@ -497,8 +497,19 @@ int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int 
  *                                the first layer's, stored transposed (ld_j = 1, ld_c = row stride of d_w).
  *   matpbr_adamw_step_dev        matpbr_adam_step_dev with torch.optim.AdamW's decoupled weight decay (:470) */
 int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wsplit, void* stream);
-/* up to 8 splits in one launch (host arrays of n_jobs entries; transposed[j] != 0 selects the _t variant for job j): the weights of
- * every layer change together, once per optimiser step */
+/* The FORWARD sine layers on two f16 pieces per operand (round 5; nprod = 3 of matpbr_mlp_layer_fwd_bx[_tail|_head]; mymodels/mlps.py:102-103,
+ * :216-224).  Two round-to-nearest f16 pieces carry an f32 number to 2^-24 of its size (a rounded piece leaves a signed remainder), so three
+ * f16 products p1 q1 + p1 q2 + p2 q1 with f32 accumulation are an f32-accurate product at half the matrix time of nprod = 6.  f16 has no
+ * exponent range to spare: the weights are cut as 256 w (|w| < 255; the kernel scales the sums back) and the rows x must satisfy |x| <= 65504
+ * (sines, coordinates and colours here); numbers below 2^-14 are carried to an absolute 3e-8.  The input-gradient and weight-gradient
+ * products (loss gradients of any magnitude) stay on three bf16 pieces.
+ *   matpbr_mlp_split_weights_fmt   matpbr_mlp_split_weights with flags = MATPBR_WSPLIT_TRANSPOSED | MATPBR_WSPLIT_F16X2; an F16X2 image is
+ *                                  the operand of nprod = 3 ONLY (and a bf16 image of nprod 6 / 9 only); same buffer size */
+#define MATPBR_WSPLIT_TRANSPOSED 1
+#define MATPBR_WSPLIT_F16X2 2
+int matpbr_mlp_split_weights_fmt(const float* w, int ldw, int N, int K, int flags, void* wsplit, void* stream);
+/* up to 8 splits in one launch (host arrays of n_jobs entries; transposed[j] = the flags of matpbr_mlp_split_weights_fmt for job j:
+ * 0 / 1 as before, + MATPBR_WSPLIT_F16X2 for the f16 form): the weights of every layer change together, once per optimiser step */
 int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const int* N, const int* K, const int* transposed,
                                    void* const* wsplit, int n_jobs, void* stream);
 int matpbr_mlp_skinny_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, long M, int J, int K,

@@ -118,6 +118,7 @@ SIGNATURES = {
     "matpbr_mlp_layer_bwd_weight_bx": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                      ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_split_weights_t": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "matpbr_mlp_split_weights_fmt": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_skinny_fwd": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p]),
     "matpbr_mlp_arm_head_fwd": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, _c_f, _c_f, _c_f, ctypes.c_long,
@@ -177,7 +178,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return _build.LIB_PATH
+    """The product library, or the file MATPBR_LIB names (an instrumented / experimental build beside it: tools/ never overwrite the product)."""
+    return os.environ.get("MATPBR_LIB") or _build.LIB_PATH
 
 
 def load(build_if_missing: bool = False) -> ctypes.CDLL:

@@ -67,6 +67,8 @@ class ArmMlpPhase:
     PACKED = True     # one float per sine activation (class switch: the tests run both)
     FUSED_OUT_BWD = True   # the output layer's backward pass in one launch over the last sine layer's activations (class switch)
     FUSED_FIRST_BWD = True # the first layer's weight / bias gradient from the epilogue of the input-gradient kernel above it (class switch)
+    FWD_PRODUCTS = 3       # forward sine layers on two f16 pieces per operand, three products (include/matpbr.h `matpbr_mlp_split_weights_fmt`);
+                           # 0: as the backward products (`_PosMlpHipFn.PRODUCTS`, three bf16 pieces).  Class switch: the tests run both
 
     @staticmethod
     def supported(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> bool:
@@ -106,6 +108,7 @@ class ArmMlpPhase:
                      "roughness": self.start_arm[:, 3:4].reshape(H, W, 1).contiguous(),
                      "metallic": self.start_arm[:, 4:5].reshape(H, W, 1).contiguous()}
         self.products = int(_PosMlpHipFn.PRODUCTS)
+        self.fwd_products = int(self.FWD_PRODUCTS) or self.products
         # ---- network state --------------------------------------------------------------------------------------------------------
         st = flat_state(net, dev)
         self.flat, self.views, self._spans = st["flat"], st["views"], st["spans"]
@@ -150,7 +153,8 @@ class ArmMlpPhase:
         jobs = []
         for l in range(1, self.L - 1):
             wp, _ = self.views[l]
-            jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l], 256, 0, self.wsplit_f[l].data_ptr()))              # W_l [n_l, 256]
+            jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l], 256, ops.WSPLIT_F16X2 if self.fwd_products == 3 else 0,
+                         self.wsplit_f[l].data_ptr()))                                                             # W_l [n_l, 256]
             jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l - 1], self.ns[l], 1, self.wsplit_b[l].data_ptr()))    # (W_l[:, :n_{l-1}])^T
         if len(jobs) > 8:
             raise NotImplementedError("ArmMlpPhase: at most four 256-wide layers after the first")
@@ -201,7 +205,7 @@ class ArmMlpPhase:
 
     def forward(self) -> Dict[str, torch.Tensor]:
         """brdf_net(start_arm) and the maps of :493-504 (maps that the part does not optimise keep their fixed values)."""
-        o, P = ops, self.products
+        o, P = ops, self.fwd_products
         with torch.cuda.device(self.dev):
             _lib.check(_lib.load().matpbr_mlp_split_weights_multi(*self._split_args, o._stream(self.flat)), "matpbr_mlp_split_weights_multi")
         wp, bp = self.views[0]

@@ -179,6 +179,30 @@ struct NtArgs {
 __device__ __forceinline__ float pack_cos_sign(float s, float c) {
   return __uint_as_float((__float_as_uint(s) & ~1u) | (__float_as_uint(c) >> 31));
 }
+// The packed sine in one go (round 5): a forward that keeps no cosines needs sin(x) and the SIGN of cos(x) only.  Reduction by whole
+// multiples of pi to r in [-pi/2, pi/2] (k = rint(x / pi) by the magic-number add: the integer sits in the low mantissa bits of t):
+// sin(x) = (-1)^k sin(r), sign(cos(x)) = (-1)^k -- one odd polynomial (degree 9, |error| 4.7e-9 on the interval), no quadrant select,
+// no second polynomial.  14 VALU instructions against 22 + 3 for sincos_cw + pack_cos_sign; |sin error| <= 1.2e-7 for |x| < 1e5.
+// k is the rounding of an f32 product: at |x| of a few hundred radians an argument within ~|x| 1e-7 of an odd multiple of pi/2 can be
+// reduced to |r| slightly beyond pi/2, where cos(r) < 0 -- ROBUST (the first layer, whose arguments are pixel coordinates times
+// weights) fixes the sign there with a compare and an add-with-carry; in the 256-wide layers (|x| of order 10) the affected |cos| is
+// below 2e-6, inside the error of the rebuilt cosine (cos_from_packed_sin).
+template <bool ROBUST = false>
+__device__ __forceinline__ float sin_packed(float x) {
+  const float t = __builtin_fmaf(x, 0.3183098861837907f, 12582912.0f);
+  const float kf = t - 12582912.0f;
+  float r = __builtin_fmaf(kf, -3.1415927410125732f, x);
+  r = __builtin_fmaf(kf, 8.742277657347586e-08f, r);
+  const float r2 = r * r;
+  float p = __builtin_fmaf(2.5997510419983882e-06f, r2, -0.0001980647793971002f);
+  p = __builtin_fmaf(p, r2, 0.008333015255630016f);
+  p = __builtin_fmaf(p, r2, -0.16666656732559204f);
+  const float s = __builtin_fmaf(r * r2, p, r);
+  unsigned kb = __float_as_uint(t);
+  const unsigned sb = __float_as_uint(s) ^ (kb << 31);
+  if (ROBUST) kb += __builtin_fabsf(r) > 1.5707963705062866f ? 1u : 0u;
+  return __uint_as_float((sb & ~1u) | (kb & 1u));
+}
 __device__ __forceinline__ float cos_from_packed_sin(float sp) {
   const float c = __builtin_amdgcn_sqrtf(__builtin_fmaxf(__builtin_fmaf(-sp, sp, 1.0f), 0.0f));
   return __uint_as_float(__float_as_uint(c) | (__float_as_uint(sp) << 31));
@@ -1222,46 +1246,40 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigne
   p3 = cvt_pk_bf16(s0, s1);
 }
 
+// Two f16 pieces per f32 (round 5, the FORWARD layers: NPROD == 3).  f16 keeps 11 significant bits, and a rounded piece leaves a SIGNED
+// remainder of at most half its last place: x - p1 is below 2^-12 |x|, its own rounding below 2^-24 |x| -- two f16 pieces carry an f32
+// operand to the size of its own rounding, where bf16 (8 bits) needs three.  Three products (p1 q1 + p1 q2 + p2 q1; the dropped p2 q2
+// is 2^-24 of the product) then do the work of six: half the matrix time, two thirds of the weight bytes, 6 instead of 11 split
+// instructions per pair.  What f16 lacks is exponent range (normal down to 6.1e-5, subnormal spacing 6e-8): the operands must be of
+// order one.  Activations are sines and the x0 tail (coordinates, colours): |x| <= 65504 is the documented limit, and below 2^-14 a
+// second piece is subnormal, i.e. carried to an ABSOLUTE 3e-8 -- the size of an f32 rounding at 0.5.  Weights (~ +-1/16) are cut as
+// 256 w (exact) and the accumulator is scaled back by 2^-8 in the epilogue (one fma with the bias): |w| < 255.  Measured against fp64
+// (tests/test_gpu_parity.py::test_two_piece_f16_forward_layers_are_f32_accurate): representation + dropped term 2e-8 rms at K = 256
+// against 1.2e-7 rms of the f32 accumulation every f32 kernel carries -- the error of the layer is that of the exact-f32 kernels.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+constexpr float kF16WScale = 256.0f, kF16WUnscale = 0.00390625f;
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {     // round-to-nearest-even (v_cvt_pk_f16_f32 / two v_cvt_f16_f32)
+  const f32x2v v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
+}
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& p1, unsigned& p2) {
+  p1 = cvt_pk_f16(x0, x1);
+  const f16x2v h = __builtin_bit_cast(f16x2v, p1);
+  p2 = cvt_pk_f16(x0 - (float)h.x, x1 - (float)h.y);
+}
+
 // wsplit layout: [K/32 super-steps][2 steps][3 pieces][2 lane halves g][256 rows n] x uint4 (8 bf16: k = 32 ks + 16 g + 8 s + j).
+// f16 form (MATPBR_WSPLIT_F16X2): [K/32][2 steps][2 pieces][2 g][256 n] x uint4 of 8 f16, the values scaled by 256 (16 KB per half step).
 // One super-step (3072 uint4 = 48 KB) is also the LDS image of the weights for that super-step: a wave's read of one operand is
 // two contiguous 512-byte runs (conflict-free), the global -> LDS copy is a straight copy.
 constexpr int kBxStage = 2 * 3 * 2 * 256;   // uint4 per super-step
 __host__ __device__ inline size_t wsplit_index(int ks, int s, int piece, int n, int g) {
   return ((((size_t)ks * 2 + s) * 3 + piece) * 2 + g) * 256 + n;
 }
-// TRANSPOSED: element (n, k) of the operand is B[k * ldb + n] (the forward weight serving as the backward product's operand)
-template <bool TRANSPOSED>
-__global__ __launch_bounds__(256) void mlp_split_weights_kernel(const float* __restrict__ B, int ldb, int N, int K, uint4* __restrict__ out) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;          // over (ks, s, n, g)
-  const int nks = (K + 31) / 32;
-  if (idx >= nks * 2 * 256 * 2) return;
-  const int g = idx & 1, n = (idx >> 1) & 255, s = (idx >> 9) & 1, ks = idx >> 10;
-  float v[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = 32 * ks + 16 * g + 8 * s + j;
-    v[j] = (n < N && k < K) ? (TRANSPOSED ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k]) : 0.f;
-  }
-  unsigned p[3][4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) split3(v[2 * q], v[2 * q + 1], p[0][q], p[1][q], p[2][q]);
-#pragma unroll
-  for (int piece = 0; piece < 3; ++piece) out[wsplit_index(ks, s, piece, n, g)] = make_uint4(p[piece][0], p[piece][1], p[piece][2], p[piece][3]);
-}
-
-// Several operands in one launch (the weights of every layer change together, once per optimiser step): blockIdx.y = job
-struct SplitJobs {
-  const float* w[8];
-  uint4* out[8];
-  int ldw[8], N[8], K[8], transposed[8];
-};
-__global__ __launch_bounds__(256) void mlp_split_weights_multi_kernel(const SplitJobs jobs) {
-  const int j = blockIdx.y;
-  const float* __restrict__ B = jobs.w[j];
-  uint4* __restrict__ out = jobs.out[j];
-  const int ldb = jobs.ldw[j], N = jobs.N[j], K = jobs.K[j];
-  const bool tr = jobs.transposed[j] != 0;
-  const int idx = blockIdx.x * 256 + threadIdx.x;          // over (ks, s, n, g)
+// One thread = the 8 consecutive k of (super-step ks, step s, row n, lane half g).  tr: element (n, k) of the operand is B[k * ldb + n]
+// (the forward weight serving as the backward product's operand); f16: the two-piece f16 form
+__device__ __forceinline__ void split_weights_item(const float* __restrict__ B, int ldb, int N, int K, bool tr, bool f16, uint4* __restrict__ out, int idx) {
   const int nks = (K + 31) / 32;
   if (idx >= nks * 2 * 256 * 2) return;
   const int g = idx & 1, n = (idx >> 1) & 255, s = (idx >> 9) & 1, ks = idx >> 10;
@@ -1271,11 +1289,35 @@ __global__ __launch_bounds__(256) void mlp_split_weights_multi_kernel(const Spli
     const int k = 32 * ks + 16 * g + 8 * s + q;
     v[q] = (n < N && k < K) ? (tr ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k]) : 0.f;
   }
+  if (f16) {
+    unsigned p[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split2h(v[2 * q] * kF16WScale, v[2 * q + 1] * kF16WScale, p[0][q], p[1][q]);
+#pragma unroll
+    for (int piece = 0; piece < 2; ++piece)
+      out[((((size_t)ks * 2 + s) * 2 + piece) * 2 + g) * 256 + n] = make_uint4(p[piece][0], p[piece][1], p[piece][2], p[piece][3]);
+    return;
+  }
   unsigned p[3][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) split3(v[2 * q], v[2 * q + 1], p[0][q], p[1][q], p[2][q]);
 #pragma unroll
   for (int piece = 0; piece < 3; ++piece) out[wsplit_index(ks, s, piece, n, g)] = make_uint4(p[piece][0], p[piece][1], p[piece][2], p[piece][3]);
+}
+__global__ __launch_bounds__(256) void mlp_split_weights_kernel(const float* __restrict__ B, int ldb, int N, int K, int flags, uint4* __restrict__ out) {
+  split_weights_item(B, ldb, N, K, (flags & 1) != 0, (flags & 2) != 0, out, blockIdx.x * 256 + threadIdx.x);
+}
+
+// Several operands in one launch (the weights of every layer change together, once per optimiser step): blockIdx.y = job
+struct SplitJobs {
+  const float* w[8];
+  uint4* out[8];
+  int ldw[8], N[8], K[8], transposed[8];   // transposed: bit 0 = transposed operand, bit 1 = the f16 form
+};
+__global__ __launch_bounds__(256) void mlp_split_weights_multi_kernel(const SplitJobs jobs) {
+  const int j = blockIdx.y;
+  split_weights_item(jobs.w[j], jobs.ldw[j], jobs.N[j], jobs.K[j], (jobs.transposed[j] & 1) != 0, (jobs.transposed[j] & 2) != 0, jobs.out[j],
+                     blockIdx.x * 256 + threadIdx.x);
 }
 
 // Eight waves per workgroup (4 row groups of 32 x 2 column halves of 128; 128 x 256 outputs per workgroup, one workgroup per
@@ -1326,6 +1368,12 @@ __device__ __forceinline__ void glds16_x3(const void* sbase, unsigned voff, unsi
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds16_x4(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void glds16_x4v(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_dst) {   // v_j: the lane's offset of piece j MINUS 1024 j
@@ -1564,8 +1612,8 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
         for (int r = 0; r < 16; ++r) {
           float v = acc[ni][r];
           if (EPI == EPI_SINCOS) {
-            sincos_cw(v + bn[ni], v, second[r]);
-            if (p.out1 == nullptr) v = pack_cos_sign(v, second[r]);      // uniform: the sines carry the sign of their cosine
+            if (p.out1 == nullptr) v = sin_packed(v + bn[ni]);          // uniform: the sines carry the sign of their cosine
+            else sincos_cw(v + bn[ni], v, second[r]);
           } else if (EPI == EPI_BIAS) {
             v += bn[ni];
           }
@@ -1684,6 +1732,12 @@ constexpr size_t kGxSmem = 2 * kGxW + 2 * kGlRows;                       // 80 K
 template <int EPI, int NPROD, bool HEAD, bool PK, bool W0 = false>   // PK: the sines carry the sign of their cosine, no cosines are stored (out1 == nullptr); W0: as mlp_nt_bx
 __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const uint4* __restrict__ wsplit, const HeadArgs hd) {
   extern __shared__ __align__(16) unsigned char gx_smem[];
+  // NPROD == 3: two f16 pieces per operand (split2h), three products; the weight image of a half step is 16 KB ([2 pieces][2 g][256 n] x 16 B),
+  // slice (piece, g) = wave w's four DMA pieces, kept at the 6144-byte slice pitch of the bf16 form (the epilogue's scratch needs 4608)
+  constexpr bool F16 = NPROD == 3;
+  static_assert(!F16 || (EPI == EPI_SINCOS && !W0), "the two-piece f16 form serves the forward layers only");
+  constexpr int kSlicePitch = F16 ? 384 : 256;                            // uint4 between (piece, g) slices in LDS
+  constexpr size_t kStepBytes = F16 ? 16384 : (size_t)kGxW;               // one half step of the global image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int ng = (p.K + 31) / 32;                                        // granules per tile (a ragged last one: columns at and beyond K are scratch)
@@ -1691,7 +1745,7 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = lds_byte_address(gx_smem);
   const unsigned w_dst = lds0 + (unsigned)wave_u * 6144u, a_dst = lds0 + 2u * kGxW + (unsigned)wave_u * 4096u;
-  const unsigned w_voff = (unsigned)(384 * wave + lane) * 16u;
+  const unsigned w_voff = (unsigned)((F16 ? 256 : 384) * wave + lane) * 16u;
   unsigned a_voff[4], a_rd[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1714,11 +1768,15 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc0[ni][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
   }
-  const int b_lane = lh * 256 + wn * 128 + li;
+  const int b_lane = lh * kSlicePitch + wn * 128 + li;
   auto issue_w = [&](int step_w, int wb) {                                // step_w: half super-step index within the reduction
-    const char* src = reinterpret_cast<const char*>(wsplit) + (size_t)step_w * kGxW;
-    glds16_x3(src, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW);
-    glds16_x3(src + 3072, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW + 3072u);
+    const char* src = reinterpret_cast<const char*>(wsplit) + (size_t)step_w * kStepBytes;
+    if (F16) {
+      glds16_x4(src, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW);
+    } else {
+      glds16_x3(src, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW);
+      glds16_x3(src + 3072, w_voff, w_dst + (unsigned)wb * (unsigned)kGxW + 3072u);
+    }
   };
   auto issue_a = [&](int tile_a, int g_a, int ab) {
     const float* src = p.A + (size_t)tile_a * kBM * p.lda + 32 * g_a;
@@ -1758,20 +1816,37 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
             u.x = k < p.K ? u.x : 0.f; u.y = k + 1 < p.K ? u.y : 0.f; u.z = k + 2 < p.K ? u.z : 0.f; u.w = k + 3 < p.K ? u.w : 0.f;
             v.x = k + 4 < p.K ? v.x : 0.f; v.y = k + 5 < p.K ? v.y : 0.f; v.z = k + 6 < p.K ? v.z : 0.f; v.w = k + 7 < p.K ? v.w : 0.f;
           }
-          split3(u.x, u.y, aq[mi][0].x, aq[mi][1].x, aq[mi][2].x);
-          split3(u.z, u.w, aq[mi][0].y, aq[mi][1].y, aq[mi][2].y);
-          split3(v.x, v.y, aq[mi][0].z, aq[mi][1].z, aq[mi][2].z);
-          split3(v.z, v.w, aq[mi][0].w, aq[mi][1].w, aq[mi][2].w);
+          if (F16) {
+            split2h(u.x, u.y, aq[mi][0].x, aq[mi][1].x);
+            split2h(u.z, u.w, aq[mi][0].y, aq[mi][1].y);
+            split2h(v.x, v.y, aq[mi][0].z, aq[mi][1].z);
+            split2h(v.z, v.w, aq[mi][0].w, aq[mi][1].w);
+          } else {
+            split3(u.x, u.y, aq[mi][0].x, aq[mi][1].x, aq[mi][2].x);
+            split3(u.z, u.w, aq[mi][0].y, aq[mi][1].y, aq[mi][2].y);
+            split3(v.x, v.y, aq[mi][0].z, aq[mi][1].z, aq[mi][2].z);
+            split3(v.z, v.w, aq[mi][0].w, aq[mi][1].w, aq[mi][2].w);
+          }
         }
         const uint4* sb = reinterpret_cast<const uint4*>(gx_smem + wb * kGxW) + b_lane;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           uint4 bq[3];
 #pragma unroll
-          for (int piece = 0; piece < 3; ++piece) bq[piece] = sb[(piece * 2) * 256 + ni * 32];
+          for (int piece = 0; piece < (F16 ? 2 : 3); ++piece) bq[piece] = sb[(piece * 2) * kSlicePitch + ni * 32];
+          if constexpr (F16) {                                 // p2 q1, p1 q2, p1 q1: the small terms first
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              constexpr int ia[3] = {1, 0, 0}, ib[3] = {0, 1, 0};
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[mi][ia[t]]), __builtin_bit_cast(f16x8, bq[ib[t]]),
+                                                                     acc[mi][ni], 0, 0, 0);
+            }
+          }
           // products from the smallest terms up, as mlp_nt_bx
 #pragma unroll
-          for (int t = 0; t < 9; ++t) {
+          for (int t = 0; t < (F16 ? 0 : 9); ++t) {
             constexpr int ia[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, ib[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
             if (NPROD == 6 && t < 3) continue;
 #pragma unroll
@@ -1831,10 +1906,9 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
       for (int r = 0; r < 16; ++r) {
         float v = acc[mi][ni][r];
         if (EPI == EPI_SINCOS) {
-          float c;
-          sincos_cw(v + bn[ni], v, c);
-          if (PK) v = pack_cos_sign(v, c);
-          else second[r] = c;
+          const float pre = F16 ? __builtin_fmaf(v, kF16WUnscale, bn[ni]) : v + bn[ni];
+          if (PK) v = sin_packed(pre);
+          else sincos_cw(pre, v, second[r]);
         }
         scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
       }
@@ -2164,6 +2238,15 @@ inline bool gx_ok(const NtArgs& p) { return g_nt_gl.load(std::memory_order_relax
 template <int EPI>
 int launch_nt_bx(NtArgs p, const uint4* wsplit, int nprod, hipStream_t stream) {   // p.M a multiple of 128; returns the grid, -1 when the launch could not be set up
   const int tiles = p.M / kBM;
+  if (nprod == 3) {                                                       // the two-piece f16 form: forward layers on mlp_nt_gx only
+    if constexpr (EPI == EPI_SINCOS) {
+      if (p.K > 32 && (long)kBM * p.lda * 4 < (1l << 31) && (p.N >= 256 || p.tail != nullptr)) {
+        const unsigned grid2 = (unsigned)(tiles < 512 ? tiles : 512);
+        return launch_nt_gx<EPI, 3, false>(p, wsplit, HeadArgs{}, grid2, stream) ? (int)grid2 : -1;
+      }
+    }
+    return -1;
+  }
   if constexpr (EPI != EPI_BIAS) {
     if (gx_ok(p) && (p.N >= 256 || EPI == EPI_MULC || p.tail != nullptr)) {
       const unsigned grid2 = (unsigned)(tiles < 512 ? tiles : 512);
@@ -2295,8 +2378,8 @@ __global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int til
       for (int r = 0; r < 16; ++r) {
         float v = acc[r];
         if (EPI == EPI_SINCOS) {
-          sincos_cw(v + bn[ni], v, second[r]);
-          if (p.out1 == nullptr) v = pack_cos_sign(v, second[r]);
+          if (p.out1 == nullptr) v = sin_packed<true>(v + bn[ni]);
+          else sincos_cw(v + bn[ni], v, second[r]);
         } else if (EPI == EPI_BIAS) v += bn[ni];
         scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * kLd + li] = v;
       }
@@ -2743,11 +2826,16 @@ int matpbr_mlp_small_bwd_step(const float* g, int ldg, const float* w, int ldw, 
 
 size_t matpbr_mlp_wsplit_bytes(int K) { return K > 0 ? (size_t)((K + 31) / 32) * 2 * 3 * 256 * 2 * sizeof(uint4) : 0; }
 
-int matpbr_mlp_split_weights(const float* w, int ldw, int N, int K, void* wsplit, void* stream) {
-  if (!w || !wsplit || N <= 0 || N > 256 || K <= 0 || K > 256 || ldw < K) return MATPBR_ERR_INVALID_ARG;
+static int split_weights_one(const float* w, int ldw, int N, int K, int flags, void* wsplit, void* stream) {
+  if (!w || !wsplit || N <= 0 || N > 256 || K <= 0 || K > 256 || ldw < ((flags & 1) ? N : K)) return MATPBR_ERR_INVALID_ARG;
   const int n = ((K + 31) / 32) * 2 * 256 * 2;
-  hipLaunchKernelGGL(mlp_split_weights_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, (uint4*)wsplit);
+  hipLaunchKernelGGL(mlp_split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, flags, (uint4*)wsplit);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+int matpbr_mlp_split_weights(const float* w, int ldw, int N, int K, void* wsplit, void* stream) { return split_weights_one(w, ldw, N, K, 0, wsplit, stream); }
+int matpbr_mlp_split_weights_fmt(const float* w, int ldw, int N, int K, int flags, void* wsplit, void* stream) {
+  if (flags & ~(MATPBR_WSPLIT_TRANSPOSED | MATPBR_WSPLIT_F16X2)) return MATPBR_ERR_INVALID_ARG;
+  return split_weights_one(w, ldw, N, K, flags, wsplit, stream);
 }
 
 int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const int* N, const int* K, const int* transposed, void* const* wsplit,
@@ -2756,7 +2844,7 @@ int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const 
   SplitJobs jobs{};
   int kmax = 0;
   for (int j = 0; j < n_jobs; ++j) {
-    if (!w[j] || !wsplit[j] || N[j] <= 0 || N[j] > 256 || K[j] <= 0 || K[j] > 256 || ldw[j] < (transposed[j] ? N[j] : K[j])) return MATPBR_ERR_INVALID_ARG;
+    if (!w[j] || !wsplit[j] || N[j] <= 0 || N[j] > 256 || K[j] <= 0 || K[j] > 256 || (transposed[j] & ~3) || ldw[j] < ((transposed[j] & 1) ? N[j] : K[j])) return MATPBR_ERR_INVALID_ARG;
     jobs.w[j] = w[j]; jobs.out[j] = (uint4*)wsplit[j]; jobs.ldw[j] = ldw[j]; jobs.N[j] = N[j]; jobs.K[j] = K[j]; jobs.transposed[j] = transposed[j];
     kmax = K[j] > kmax ? K[j] : kmax;
   }
@@ -2765,25 +2853,21 @@ int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const 
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
-int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wsplit, void* stream) {
-  if (!w || !wsplit || N <= 0 || N > 256 || K <= 0 || K > 256 || ldw < N) return MATPBR_ERR_INVALID_ARG;
-  const int n = ((K + 31) / 32) * 2 * 256 * 2;
-  hipLaunchKernelGGL(mlp_split_weights_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, (uint4*)wsplit);
-  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
-}
+int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wsplit, void* stream) { return split_weights_one(w, ldw, N, K, 1, wsplit, stream); }
 
 int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
                                  const float* tail, int ldt, long M, int N, int K, int nprod, void* stream) {
   // c_out == NULL: the sines carry the sign of their cosine in their last mantissa bit and no cosines are written (matpbr_mlp_layer_fwd_bx_sgn)
   if (!x || !wsplit || !bias || !s_out || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
-  if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
+  if ((nprod != 3 && nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
       !aligned16(s_out) || (c_out && !aligned16(c_out)))
     return MATPBR_ERR_UNSUPPORTED;
+  if (nprod == 3 && (K <= 32 || (N < 256 && !tail))) return MATPBR_ERR_UNSUPPORTED;   // mlp_nt_gx: whole 16-byte stores over a skip layer's tail
   if (tail && ldt < 256 - N) return MATPBR_ERR_INVALID_ARG;
   NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, N, K, ldx, 0, ldo};
   p.tail = tail; p.ldt = ldt;
   if (launch_nt_bx<EPI_SINCOS>(p, (const uint4*)wsplit, nprod, (hipStream_t)stream) < 0) return MATPBR_ERR_LAUNCH;
-  if (tail && N < 256 && !(gx_ok(p) && N > 224))     // mlp_nt_gx writes the tail in its epilogue (it sits in the last 32-column block)
+  if (tail && N < 256 && !((nprod == 3 || gx_ok(p)) && N > 224))     // mlp_nt_gx writes the tail in its epilogue (it sits in the last 32-column block)
     hipLaunchKernelGGL(mlp_tail_copy_kernel, dim3((unsigned)((M * (256 - N) + 255) / 256 < 2048 ? (M * (256 - N) + 255) / 256 : 2048)), dim3(256), 0,
                        (hipStream_t)stream, s_out, ldo, tail, ldt, M, N);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
@@ -2794,13 +2878,19 @@ int matpbr_mlp_layer_fwd_bx_head(const float* x, int ldx, const void* wsplit, co
                                  float* map_r, float* map_m, long M, int K, int nprod, void* stream) {
   if (!x || !wsplit || !bias || !s_out || !w_out || !bias_out || !start || !th || M <= 0 || K <= 0 || K > 256 || lds < 5 || ldw_out < 256)
     return MATPBR_ERR_INVALID_ARG;
-  if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
+  if ((nprod != 3 && nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldx & 3) || ldx < ((K + 31) & ~31) || !aligned16(x) ||
       !aligned16(s_out) || (c_out && !aligned16(c_out)))
     return MATPBR_ERR_UNSUPPORTED;
   NtArgs p{x, nullptr, bias, nullptr, s_out, c_out, nullptr, (int)M, 256, K, ldx, 0, ldo};
   const HeadArgs hd{w_out, ldw_out, bias_out, ArmHead{start, lds, th, map_a, map_r, map_m}};
   const int tiles = (int)(M / kBM);
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+  if (nprod == 3) {                          // two f16 pieces: the packed-sine form of mlp_nt_gx
+    if (c_out != nullptr || K <= 32 || (long)kBM * ldx * 4 >= (1l << 31)) return MATPBR_ERR_UNSUPPORTED;
+    const unsigned grid2 = (unsigned)(tiles < 512 ? tiles : 512);
+    const bool ok3 = launch_nt_gx<EPI_SINCOS, 3, true>(p, (const uint4*)wsplit, hd, grid2, (hipStream_t)stream);
+    return ok3 && hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+  }
   if (gx_ok(p) && c_out == nullptr) {        // with stored cosines the two-workgroup form spills: the 512-thread kernel
     const unsigned grid2 = (unsigned)(tiles < 512 ? tiles : 512);
     const bool ok2 = nprod == 9 ? launch_nt_gx<EPI_SINCOS, 9, true>(p, (const uint4*)wsplit, hd, grid2, (hipStream_t)stream)

@@ -673,26 +673,31 @@ def mlp_layer_bwd_input(g: torch.Tensor, wt: torch.Tensor, c_prev: torch.Tensor,
     _lib.check(code, "matpbr_mlp_layer_bwd_input")
 
 
-def mlp_split_weights(w: torch.Tensor, N: int, K: int, out: Optional[torch.Tensor] = None, transposed: bool = False) -> torch.Tensor:
+WSPLIT_TRANSPOSED, WSPLIT_F16X2 = 1, 2
+
+
+def mlp_split_weights(w: torch.Tensor, N: int, K: int, out: Optional[torch.Tensor] = None, transposed: bool = False, f16: bool = False) -> torch.Tensor:
     """w[:N, :K] (row-major, unit column stride) split into three bf16 pieces in the operand order of the bx kernels (opaque bytes).
-    transposed: the operand is w[:K, :N]^T (the forward weight serving the backward product)."""
+    transposed: the operand is w[:K, :N]^T (the forward weight serving the backward product).  f16: two f16 pieces of 256 w, the operand of
+    the forward layers with nprod = 3 (include/matpbr.h `matpbr_mlp_split_weights_fmt`)."""
     lib = _lib.load()
     if not (w.is_cuda and w.dtype == torch.float32 and w.ndim == 2 and w.stride(1) == 1):
         raise ValueError("mlp_split_weights: expected a [rows, cols] fp32 CUDA matrix with unit column stride")
     need = int(lib.matpbr_mlp_wsplit_bytes(K))
     if out is None or out.numel() < need:
         out = torch.empty(need, dtype=torch.uint8, device=w.device)
-    fn = lib.matpbr_mlp_split_weights_t if transposed else lib.matpbr_mlp_split_weights
+    flags = (WSPLIT_TRANSPOSED if transposed else 0) | (WSPLIT_F16X2 if f16 else 0)
     with torch.cuda.device(w.device):
-        code = fn(_ptr(w), w.stride(0), N, K, _ptr(out), _stream(w))
+        code = lib.matpbr_mlp_split_weights_fmt(_ptr(w), w.stride(0), N, K, flags, _ptr(out), _stream(w))
     _lib.check(code, "matpbr_mlp_split_weights")
     return out
 
 
 def mlp_layer_fwd_bx(x: torch.Tensor, wsplit: torch.Tensor, bias: torch.Tensor, s_out: torch.Tensor, c_out: Optional[torch.Tensor], N: int, K: int,
                      nprod: int = 6, tail: Optional[torch.Tensor] = None) -> None:
-    """mlp_layer_fwd on the bf16 matrix pipe with split operands (nprod 6 or 9 partial products per f32 product).  c_out None: the sines
-    carry the sign of their cosine in the last mantissa bit and no cosines are written."""
+    """mlp_layer_fwd on the bf16 matrix pipe with split operands (nprod 6 or 9 partial products per f32 product; nprod 3: two f16 pieces,
+    `wsplit` from mlp_split_weights(..., f16=True)).  c_out None: the sines carry the sign of their cosine in the last mantissa bit and no
+    cosines are written."""
     lib = _lib.load()
     x, s_out = _mat2(x, "x"), _mat2(s_out, "s_out")
     if c_out is not None and _mat2(c_out, "c_out").stride(0) != s_out.stride(0):
