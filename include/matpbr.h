@@ -508,6 +508,31 @@ int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wspl
 #define MATPBR_WSPLIT_TRANSPOSED 1
 #define MATPBR_WSPLIT_F16X2 2
 int matpbr_mlp_split_weights_fmt(const float* w, int ldw, int N, int K, int flags, void* wsplit, void* stream);
+/* The BACKWARD products of the 256-wide layers on two f16 pieces (round 5; the autograd backward of mymodels/mlps.py:102-103, :216-224 as
+ * driven by inverse_img_w_mi.py:493-547).  A loss gradient has no natural size, so the rows g travel in blocks: every 128-row tile (128
+ * consecutive pixels) has ONE power-of-two exponent that brings its largest |g| to [2^13, 2^14), taken from `g_tile_max` -- [M / 128] f32
+ * bit patterns of the tiles' largest |g|, which the kernel that PRODUCED g filled by atomic max into an array the caller zeroed (bit patterns
+ * of magnitudes order as values: the result does not depend on the order of the adds).  Within a tile, elements down to 2^-16 of the largest
+ * keep the 2^-24 relative accuracy of two pieces, smaller ones are carried to an absolute 2^-39 of it; against fp64 the products' error is
+ * that of the three-bf16-piece form and of the exact-f32 kernels (tests/test_gpu_parity.py::test_block_scaled_f16_backward_products).
+ * The weight operand is an MATPBR_WSPLIT_F16X2 image (of the transposed forward weight for the input gradient).
+ *   matpbr_mlp_out_layer_bwd_tmax    matpbr_mlp_out_layer_bwd that also fills g_tile_max for the g_prev it writes
+ *   matpbr_mlp_layer_bwd_input_blk   matpbr_mlp_layer_bwd_input_bx_sgn (sign-carrying sines below) on these pieces; out_tile_max (nullable):
+ *                                    the tile maxima of the g_prev it writes, for the next product
+ *   matpbr_mlp_first_layer_bwd_blk   matpbr_mlp_first_layer_bwd_bx likewise (sgn = 1)
+ *   matpbr_mlp_layer_bwd_weight_blk  matpbr_mlp_layer_bwd_weight_bx likewise: x (sines, |x| <= 65504) as it is, g under one exponent per slab of
+ *                                    rows (the largest of its tiles' maxima); M a multiple of 128 */
+int matpbr_mlp_out_layer_bwd_tmax(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
+                                  int ldg, void* g_tile_max, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace,
+                                  size_t workspace_bytes, long M, int J, int n_prev, void* stream);
+int matpbr_mlp_layer_bwd_input_blk(const float* g, int ldg, const void* g_tile_max, const void* wtsplit, const float* s_prev, float* g_prev, int ldo,
+                                   void* out_tile_max, float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
+                                   void* stream);
+int matpbr_mlp_first_layer_bwd_blk(const float* g, int ldg, const void* g_tile_max, const void* wtsplit, const float* s_prev, int lds, const float* x0,
+                                   int ldx0, float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes,
+                                   void* workspace2, size_t workspace2_bytes, long M, int n0, int n_red, void* stream);
+int matpbr_mlp_layer_bwd_weight_blk(const float* g, int ldg, const void* g_tile_max, const float* x, int ldx, float* d_w, int ldw, void* workspace,
+                                    size_t workspace_bytes, long M, int N, int K, void* stream);
 /* up to 8 splits in one launch (host arrays of n_jobs entries; transposed[j] = the flags of matpbr_mlp_split_weights_fmt for job j:
  * 0 / 1 as before, + MATPBR_WSPLIT_F16X2 for the f16 form): the weights of every layer change together, once per optimiser step */
 int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const int* N, const int* K, const int* transposed,

@@ -118,6 +118,16 @@ SIGNATURES = {
     "matpbr_mlp_layer_bwd_weight_bx": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                      ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_split_weights_t": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "matpbr_mlp_out_layer_bwd_tmax": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, _c_f,
+                                                     ctypes.c_long, ctypes.c_long, _c_f, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_bwd_input_blk": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_f, _c_f, ctypes.c_int, ctypes.c_void_p, _c_f,
+                                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_first_layer_bwd_blk": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f,
+                                                      ctypes.c_long, ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                      ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "matpbr_mlp_layer_bwd_weight_blk": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p,
+                                                       ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_split_weights_fmt": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_skinny_fwd": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p]),

@@ -67,6 +67,8 @@ class ArmMlpPhase:
     PACKED = True     # one float per sine activation (class switch: the tests run both)
     FUSED_OUT_BWD = True   # the output layer's backward pass in one launch over the last sine layer's activations (class switch)
     FUSED_FIRST_BWD = True # the first layer's weight / bias gradient from the epilogue of the input-gradient kernel above it (class switch)
+    BWD_F16 = True         # the backward products of the 256-wide layers on two f16 pieces under one exponent per 128-row tile
+                           # (include/matpbr.h `matpbr_mlp_layer_bwd_input_blk`); needs PACKED, FUSED_OUT_BWD, FUSED_FIRST_BWD.  Class switch
     FWD_PRODUCTS = 3       # forward sine layers on two f16 pieces per operand, three products (include/matpbr.h `matpbr_mlp_split_weights_fmt`);
                            # 0: as the backward products (`_PosMlpHipFn.PRODUCTS`, three bf16 pieces).  Class switch: the tests run both
 
@@ -109,6 +111,7 @@ class ArmMlpPhase:
                      "metallic": self.start_arm[:, 4:5].reshape(H, W, 1).contiguous()}
         self.products = int(_PosMlpHipFn.PRODUCTS)
         self.fwd_products = int(self.FWD_PRODUCTS) or self.products
+        self.bwd_f16 = bool(self.BWD_F16 and self.PACKED and self.FUSED_OUT_BWD and self.FUSED_FIRST_BWD)
         # ---- network state --------------------------------------------------------------------------------------------------------
         st = flat_state(net, dev)
         self.flat, self.views, self._spans = st["flat"], st["views"], st["spans"]
@@ -155,7 +158,8 @@ class ArmMlpPhase:
             wp, _ = self.views[l]
             jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l], 256, ops.WSPLIT_F16X2 if self.fwd_products == 3 else 0,
                          self.wsplit_f[l].data_ptr()))                                                             # W_l [n_l, 256]
-            jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l - 1], self.ns[l], 1, self.wsplit_b[l].data_ptr()))    # (W_l[:, :n_{l-1}])^T
+            jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l - 1], self.ns[l], 1 | (ops.WSPLIT_F16X2 if self.bwd_f16 else 0),
+                         self.wsplit_b[l].data_ptr()))                                                             # (W_l[:, :n_{l-1}])^T
         if len(jobs) > 8:
             raise NotImplementedError("ArmMlpPhase: at most four 256-wide layers after the first")
         import ctypes as _ct
@@ -163,6 +167,8 @@ class ArmMlpPhase:
         nj = len(jobs)
         self._split_args = ((_ct.c_void_p * nj)(*[j[0] for j in jobs]), (_ct.c_int * nj)(*[j[1] for j in jobs]), (_ct.c_int * nj)(*[j[2] for j in jobs]),
                             (_ct.c_int * nj)(*[j[3] for j in jobs]), (_ct.c_int * nj)(*[j[4] for j in jobs]), (_ct.c_void_p * nj)(*[j[5] for j in jobs]), nj)
+        # block exponents of the gradient matrices (one row of tile maxima per sine layer's dL/d pre), zeroed once per iteration
+        self.tmax = torch.zeros(max(self.L - 1, 1), M // 128, dtype=torch.int32, device=dev) if self.bwd_f16 else None
         self.maps = {"albedo": E(H, W, 3), "roughness": E(H, W, 1), "metallic": E(H, W, 1)}
         keys = {"a": "albedo", "r": "roughness", "m": "metallic"}
         self.live = [keys[c] for c in self.part if c in keys]
@@ -241,7 +247,11 @@ class ArmMlpPhase:
         _, gb_prev = self.gviews[self.L - 2]
         # the output layer in ONE pass over the last sine layer's activations: its weight / bias gradient, dL/d pre of that sine layer and its
         # bias gradient (separately: a second 268 MB read of the sines, a transposing copy of the output weight, two reduce launches)
-        if self.FUSED_OUT_BWD:
+        f16 = self.bwd_f16
+        if f16:
+            self.tmax.zero_()
+            o.mlp_out_layer_bwd_tmax(self.d_x, self.bufs[-1], wp, g_prev, self.tmax[self.L - 2], gw, gb, gb_prev, 5, self.ns[-1])
+        elif self.FUSED_OUT_BWD:
             o.mlp_out_layer_bwd(self.d_x, self.bufs[-1], None if self.packed else self.cbufs[-1], wp, g_prev, gw, gb, gb_prev, 5, self.ns[-1])
         else:
             o.mlp_skinny_bwd_weight(self.d_x, self.bufs[-1], gw, 5, 256, d_bias=gb)
@@ -252,10 +262,21 @@ class ArmMlpPhase:
         for l in range(self.L - 2, 0, -1):                       # g = dL/d pre of layer l: its weight gradient, then dL/d pre of layer l-1
             wp, _ = self.views[l]
             gw, _ = self.gviews[l]
-            o.mlp_layer_bwd_weight_bx(g, self.bufs[l - 1], n_red, 256, P, out=gw)
+            if f16:
+                o.mlp_layer_bwd_weight_blk(g, self.tmax[l], self.bufs[l - 1], n_red, 256, out=gw)
+            else:
+                o.mlp_layer_bwd_weight_bx(g, self.bufs[l - 1], n_red, 256, P, out=gw)
             n_prev = self.ns[l - 1]
             _, gb = self.gviews[l - 1]
             c_prev = self.bufs[l - 1] if self.packed else self.cbufs[l - 1]
+            if f16:
+                if l == 1:
+                    o.mlp_first_layer_bwd_blk(g, self.tmax[l], self.wsplit_b[l], c_prev, self.x0p, self.gviews[0][0], self.d0, n_prev, n_red, gb)
+                    return
+                g_prev = self.gbufs[0] if g is self.gbufs[1] else self.gbufs[1]
+                o.mlp_layer_bwd_input_blk(g, self.tmax[l], self.wsplit_b[l], c_prev, g_prev, n_prev, n_red, gb, self.tmax[l - 1])
+                g, n_red = g_prev, n_prev
+                continue
             if l == 1 and self.FUSED_FIRST_BWD:
                 # into the first layer: its pre-activation gradient is not stored, the same launch forms its weight and bias gradient
                 o.mlp_first_layer_bwd_bx(g, self.wsplit_b[l], c_prev, self.x0p, self.gviews[0][0], self.d0, n_prev, n_red, gb, P, packed=self.packed)

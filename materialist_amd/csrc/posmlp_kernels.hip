@@ -167,7 +167,33 @@ struct NtArgs {
   const float* x0;     // mlp_nt_bx<.., W0>: [M, ldx0 >= 16] the network's input rows (columns beyond d0 zero)
   int ldx0;
   float* w0_part;      // mlp_nt_bx<.., W0>: [4 gridDim.x][16][256] partial first-layer weight gradients (the layout of the skinny kernels)
+  const unsigned* a_tmax;   // mlp_nt_gx<EPI_MULC, 3>: [M / 128] max |A| of every 128-row tile (f32 bit patterns): the tile's block exponent
+  unsigned* o_tmax;         // nullable: the same of the rows written (atomic max into a zeroed array: the next product's a_tmax)
 };
+
+// Gradients on two f16 pieces (round 5).  A loss gradient has no natural size, so a 128-row tile of G travels as 2^-e (p1 + p2) with ONE
+// exponent e per tile -- the tile's largest |g| is brought to [2^13, 2^14) (f16 overflows at 2^16) -- taken from `tile_max`, which the
+// kernel that produced G filled (an atomic max over bit patterns: order-free).  Elements within 2^-16 of their tile's largest keep the
+// 2^-24 relative accuracy of two pieces; smaller ones are carried to an absolute 2^-39 of it.  Rows of one tile are 128 consecutive pixels.
+__device__ __forceinline__ void block_scale(unsigned max_bits, float& scale, float& unscale) {
+  const float mx = __uint_as_float(max_bits);
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) (void)__builtin_frexpf(mx, &e);        // mx = m 2^e, m in [0.5, 1)
+  else e = 14;                                                       // no gradient at all (or not finite: it propagates as it is)
+  scale = __builtin_ldexpf(1.0f, 14 - e);
+  unscale = __builtin_ldexpf(1.0f, e - 14);
+}
+__device__ __forceinline__ float wave_max_lane63(float v) {
+#define MATPBR_DPP_MAX(ctrl, rowmask) v = __builtin_fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rowmask, 0xf, true)))
+  MATPBR_DPP_MAX(0x111, 0xf);     // row_shr:1 ... (zeros shifted in: the operands are magnitudes)
+  MATPBR_DPP_MAX(0x112, 0xf);
+  MATPBR_DPP_MAX(0x114, 0xf);
+  MATPBR_DPP_MAX(0x118, 0xf);
+  MATPBR_DPP_MAX(0x142, 0xa);     // row_bcast:15 into rows 1, 3
+  MATPBR_DPP_MAX(0x143, 0xc);     // row_bcast:31 into rows 2, 3
+#undef MATPBR_DPP_MAX
+  return v;
+}
 
 // One float per sine activation instead of two.  The backward pass needs cos(pre) of every hidden unit; sin and cos lie on the unit circle,
 // so |cos| = sqrt(1 - sin^2) and only its sign is missing: the forward epilogue writes it into the LAST MANTISSA BIT of the sine it
@@ -1735,7 +1761,8 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
   // NPROD == 3: two f16 pieces per operand (split2h), three products; the weight image of a half step is 16 KB ([2 pieces][2 g][256 n] x 16 B),
   // slice (piece, g) = wave w's four DMA pieces, kept at the 6144-byte slice pitch of the bf16 form (the epilogue's scratch needs 4608)
   constexpr bool F16 = NPROD == 3;
-  static_assert(!F16 || (EPI == EPI_SINCOS && !W0), "the two-piece f16 form serves the forward layers only");
+  constexpr bool BLK = F16 && EPI == EPI_MULC;                            // the rows are loss gradients: one exponent per 128-row tile (block_scale)
+  static_assert(!F16 || EPI != EPI_BIAS, "the two-piece f16 form: sine layers forward (sines in, unit scale) and input gradients (block-scaled rows)");
   constexpr int kSlicePitch = F16 ? 384 : 256;                            // uint4 between (piece, g) slices in LDS
   constexpr size_t kStepBytes = F16 ? 16384 : (size_t)kGxW;               // one half step of the global image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1789,6 +1816,11 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
 
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int row0 = tile * kBM;
+    float a_scale = 1.0f, a_unscale = kF16WUnscale, omax = 0.f;
+    if (BLK) {
+      block_scale(p.a_tmax[tile], a_scale, a_unscale);
+      a_unscale *= kF16WUnscale;
+    }
     f32x16 acc[2][4];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -1815,6 +1847,10 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
             const int k = 32 * g + 16 * lh + 8 * s;
             u.x = k < p.K ? u.x : 0.f; u.y = k + 1 < p.K ? u.y : 0.f; u.z = k + 2 < p.K ? u.z : 0.f; u.w = k + 3 < p.K ? u.w : 0.f;
             v.x = k + 4 < p.K ? v.x : 0.f; v.y = k + 5 < p.K ? v.y : 0.f; v.z = k + 6 < p.K ? v.z : 0.f; v.w = k + 7 < p.K ? v.w : 0.f;
+          }
+          if (BLK) {
+            u.x *= a_scale; u.y *= a_scale; u.z *= a_scale; u.w *= a_scale;
+            v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
           }
           if (F16) {
             split2h(u.x, u.y, aq[mi][0].x, aq[mi][1].x);
@@ -1905,6 +1941,7 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[mi][ni][r];
+        if (BLK) v *= a_unscale;
         if (EPI == EPI_SINCOS) {
           const float pre = F16 ? __builtin_fmaf(v, kF16WUnscale, bn[ni]) : v + bn[ni];
           if (PK) v = sin_packed(pre);
@@ -1921,6 +1958,8 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
           if (p.cmul_sin) c4 = cos_from_packed_sin(c4);
           v.x *= c4.x; v.y *= c4.y; v.z *= c4.z; v.w *= c4.w;
           csum4[ni].x += v.x; csum4[ni].y += v.y; csum4[ni].z += v.z; csum4[ni].w += v.w;
+          if (BLK && !W0) omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))),
+                                                   __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
         }
         if (EPI == EPI_SINCOS && !HEAD && ni == 3 && p.tail != nullptr && wn == 1) {
             // a skip layer's buffer: the columns at and beyond N hold x0 (mymodels/mlps.py:214-217), written here instead of by a copy launch
@@ -1982,6 +2021,10 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
       }
       __syncthreads();                                        // the granule is the next DMA target
     }
+    if (BLK && !W0 && p.o_tmax != nullptr) {                    // this wave's share of the tile's largest |G'|: the next product's block exponent
+      const float wmx = wave_max_lane63(omax);
+      if (lane == 63) atomicMax(p.o_tmax + tile, __float_as_uint(wmx));
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the scratch slice is this wave's next DMA target
 #ifdef MATPBR_BX_STAMPS
     if (blockIdx.x == 0 && wave < 2 && lane == 0 && tile == (int)gridDim.x) g_epi_stamp[wave] = __builtin_amdgcn_s_memtime();
@@ -2034,12 +2077,22 @@ __device__ __forceinline__ int wg_perm(int i) { return (i & 16) + 2 * (i & 7) + 
 // every step; with opposite orders one of them splits and stores while the other one multiplies.
 template <int NPROD, bool EARLY>
 __device__ __forceinline__ void wgrad_bx_body(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
-                                              float* __restrict__ partial, long M, long rows_per_slab, uint4* sW) {
+                                              float* __restrict__ partial, long M, long rows_per_slab, uint4* sW, const unsigned* __restrict__ g_tmax) {
+  // NPROD == 3: two f16 pieces per operand.  X (sines, the x0 tail) as it is; G under ONE exponent per slab, from the largest of the
+  // tile maxima of the slab's rows (block_scale); the partial sums are scaled back when they are stored
+  constexpr bool F16 = NPROD == 3;
+  constexpr int NP = F16 ? 2 : 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nq = wave >> 1, kq = wave & 1, li = lane & 31, lh = lane >> 5;
   const long m_begin = (long)blockIdx.x * rows_per_slab;
   const long m_end = (m_begin + rows_per_slab < M) ? m_begin + rows_per_slab : M;
   const int steps = m_begin < m_end ? (int)((m_end - m_begin) / 16) : 0;
+  float g_scale = 1.0f, g_unscale = 1.0f;
+  if (F16 && steps > 0) {
+    unsigned mb = 0;
+    for (long t = m_begin / kBM; t <= (m_end - 1) / kBM; ++t) mb = g_tmax[t] > mb ? g_tmax[t] : mb;      // magnitudes: bit patterns order as values
+    block_scale(mb, g_scale, g_unscale);
+  }
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -2053,7 +2106,8 @@ __device__ __forceinline__ void wgrad_bx_body(const float* __restrict__ G, int l
   const int cp = tid & 255, sh = tid >> 8;
   const float* src = (cp >> 7) ? X + (m_begin + 8 * sh) * ldx + 2 * (cp & 127) : G + (m_begin + 8 * sh) * ldg + 2 * (cp & 127);
   const long ld = (cp >> 7) ? ldx : ldg;
-  uint4* sdst = sW + (((cp >> 7) * 3) * 2 + sh) * 256 + ((cp & 127) >> 3) * 16 + (cp & 7);   // + buf * kWgStage + (piece * 2) * 256 + 8 * column
+  const float my_scale = (F16 && !(cp >> 7)) ? g_scale : 1.0f;
+  uint4* sdst = sW + (((cp >> 7) * NP) * 2 + sh) * 256 + ((cp & 127) >> 3) * 16 + (cp & 7);   // + buf * kWgStage + (piece * 2) * 256 + 8 * column
   float2 raw[kWgDepth][8];
   auto load_stage = [&](int slot, int step) {
 #pragma unroll
@@ -2065,13 +2119,20 @@ __device__ __forceinline__ void wgrad_bx_body(const float* __restrict__ G, int l
       uint4 pc[3];
       const float2* r = raw[slot];
 #define MATPBR_COMP(v) (c == 0 ? (v).x : (v).y)
-      split3(MATPBR_COMP(r[0]), MATPBR_COMP(r[1]), pc[0].x, pc[1].x, pc[2].x);
-      split3(MATPBR_COMP(r[2]), MATPBR_COMP(r[3]), pc[0].y, pc[1].y, pc[2].y);
-      split3(MATPBR_COMP(r[4]), MATPBR_COMP(r[5]), pc[0].z, pc[1].z, pc[2].z);
-      split3(MATPBR_COMP(r[6]), MATPBR_COMP(r[7]), pc[0].w, pc[1].w, pc[2].w);
+      if (F16) {
+        split2h(MATPBR_COMP(r[0]) * my_scale, MATPBR_COMP(r[1]) * my_scale, pc[0].x, pc[1].x);
+        split2h(MATPBR_COMP(r[2]) * my_scale, MATPBR_COMP(r[3]) * my_scale, pc[0].y, pc[1].y);
+        split2h(MATPBR_COMP(r[4]) * my_scale, MATPBR_COMP(r[5]) * my_scale, pc[0].z, pc[1].z);
+        split2h(MATPBR_COMP(r[6]) * my_scale, MATPBR_COMP(r[7]) * my_scale, pc[0].w, pc[1].w);
+      } else {
+        split3(MATPBR_COMP(r[0]), MATPBR_COMP(r[1]), pc[0].x, pc[1].x, pc[2].x);
+        split3(MATPBR_COMP(r[2]), MATPBR_COMP(r[3]), pc[0].y, pc[1].y, pc[2].y);
+        split3(MATPBR_COMP(r[4]), MATPBR_COMP(r[5]), pc[0].z, pc[1].z, pc[2].z);
+        split3(MATPBR_COMP(r[6]), MATPBR_COMP(r[7]), pc[0].w, pc[1].w, pc[2].w);
+      }
 #undef MATPBR_COMP
 #pragma unroll
-      for (int piece = 0; piece < 3; ++piece) sdst[buf * kWgStage + (piece * 2) * 256 + 8 * c] = pc[piece];
+      for (int piece = 0; piece < NP; ++piece) sdst[buf * kWgStage + (piece * 2) * 256 + 8 * c] = pc[piece];
     }
   };
   // unconditional (the last steps re-stage the last rows, which nobody reads): loads under a branch could not be counted.
@@ -2104,21 +2165,33 @@ __device__ __forceinline__ void wgrad_bx_body(const float* __restrict__ G, int l
         const int cur = st & 1;
         if (EARLY) stage((u + 1) % kWgDepth, cur ^ 1, st + 1 + kWgDepth);
         const uint4* sa = sW + cur * kWgStage + lh * 256 + nq * 64 + li;             // + (piece * 2) * 256 + ni * 32
-        const uint4* sb = sW + cur * kWgStage + (3 * 2 + lh) * 256 + kq * 128 + li;  // + (piece * 2) * 256 + ki * 32
+        const uint4* sb = sW + cur * kWgStage + (NP * 2 + lh) * 256 + kq * 128 + li;  // + (piece * 2) * 256 + ki * 32
         uint4 a[3][2];
 #pragma unroll
-        for (int piece = 0; piece < 3; ++piece)
+        for (int piece = 0; piece < NP; ++piece)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) a[piece][ni] = sa[(piece * 2) * 256 + ni * 32];
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
           uint4 b[3][2];
 #pragma unroll
-          for (int piece = 0; piece < 3; ++piece)
+          for (int piece = 0; piece < NP; ++piece)
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) b[piece][k2] = sb[(piece * 2) * 256 + (kh * 2 + k2) * 32];
+          if constexpr (F16) {
 #pragma unroll
-          for (int t = 0; t < 9; ++t) {
+            for (int t = 0; t < 3; ++t) {
+              constexpr int ia[3] = {1, 0, 0}, ib[3] = {0, 1, 0};
+#pragma unroll
+              for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                  acc[ni][kh * 2 + k2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ia[t]][ni]),
+                                                                               __builtin_bit_cast(f16x8, b[ib[t]][k2]), acc[ni][kh * 2 + k2], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < (F16 ? 0 : 9); ++t) {
             constexpr int ia[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, ib[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
             if (NPROD == 6 && t < 3) continue;
 #pragma unroll
@@ -2143,19 +2216,19 @@ __device__ __forceinline__ void wgrad_bx_body(const float* __restrict__ G, int l
       for (int r = 0; r < 16; ++r) {
         const int n = nq * 64 + ni * 32 + wg_perm((r & 3) + 8 * (r >> 2) + 4 * lh);
         const int k = kq * 128 + ki * 32 + wg_perm(li);
-        out[n * 256 + k] = acc[ni][ki][r];
+        out[n * 256 + k] = F16 ? acc[ni][ki][r] * g_unscale : acc[ni][ki][r];
       }
 }
 
 template <int NPROD>
 __global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_bx(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
-                                                              float* __restrict__ partial, long M, long rows_per_slab) {
+                                                              float* __restrict__ partial, long M, long rows_per_slab, const unsigned* __restrict__ g_tmax) {
   extern __shared__ __align__(16) unsigned char wg_smem[];
   uint4* sW = reinterpret_cast<uint4*>(wg_smem);
   if (threadIdx.x >> 8)
-    wgrad_bx_body<NPROD, true>(G, ldg, X, ldx, partial, M, rows_per_slab, sW);
+    wgrad_bx_body<NPROD, true>(G, ldg, X, ldx, partial, M, rows_per_slab, sW, g_tmax);
   else
-    wgrad_bx_body<NPROD, false>(G, ldg, X, ldx, partial, M, rows_per_slab, sW);
+    wgrad_bx_body<NPROD, false>(G, ldg, X, ldx, partial, M, rows_per_slab, sW, g_tmax);
 }
 
 constexpr size_t kBxSmem = 2 * kBxStage * sizeof(uint4) + 8 * 32 * kLd * sizeof(float);   // 96 KB of weights + 36 KB of epilogue scratch
@@ -2238,9 +2311,9 @@ inline bool gx_ok(const NtArgs& p) { return g_nt_gl.load(std::memory_order_relax
 template <int EPI>
 int launch_nt_bx(NtArgs p, const uint4* wsplit, int nprod, hipStream_t stream) {   // p.M a multiple of 128; returns the grid, -1 when the launch could not be set up
   const int tiles = p.M / kBM;
-  if (nprod == 3) {                                                       // the two-piece f16 form: forward layers on mlp_nt_gx only
-    if constexpr (EPI == EPI_SINCOS) {
-      if (p.K > 32 && (long)kBM * p.lda * 4 < (1l << 31) && (p.N >= 256 || p.tail != nullptr)) {
+  if (nprod == 3) {                                                       // the two-piece f16 forms run on mlp_nt_gx only
+    if constexpr (EPI != EPI_BIAS) {
+      if (p.K > 32 && (long)kBM * p.lda * 4 < (1l << 31) && (p.N >= 256 || EPI == EPI_MULC || p.tail != nullptr) && (EPI != EPI_MULC || p.a_tmax != nullptr)) {
         const unsigned grid2 = (unsigned)(tiles < 512 ? tiles : 512);
         return launch_nt_gx<EPI, 3, false>(p, wsplit, HeadArgs{}, grid2, stream) ? (int)grid2 : -1;
       }
@@ -2538,6 +2611,7 @@ struct SkinnyDgrad {          // the input-gradient half of mlp_skinny_tn_kernel
   float* G;                   // [M][ldg]
   int ldg;
   float* gsum_part;           // [slabs][256]
+  unsigned* tmax;             // nullable [M / 128]: atomic max of |G| per 128-row tile (zeroed by the caller): the block exponents of the f16 products
 };
 template <int J, bool DGRAD = false>
 __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restrict__ S, int lds, const float* __restrict__ B, int ldb,
@@ -2561,6 +2635,15 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
     for (int j = 0; j < kOutJ; ++j) wv[j] = j < dg.Jv ? *reinterpret_cast<const float4*>(dg.W + (size_t)j * dg.ldw + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   constexpr int U = 4;
+  float tmx = 0.f;                                          // largest |G| of the rows since the last tile boundary (this wave's rows)
+  long tmx_tile = m_begin / kBM;
+  auto tmx_flush = [&]() {
+    if (DGRAD && dg.tmax != nullptr) {
+      const float wmx = wave_max_lane63(tmx);
+      if (cq == 63) atomicMax(dg.tmax + tmx_tile, __float_as_uint(wmx));
+    }
+    tmx = 0.f;
+  };
   for (long m0 = m_begin + rs; m0 < m_end; m0 += 4 * U) {
     float4 b[U];
 #pragma unroll
@@ -2591,9 +2674,15 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
         const float4 gv = make_float4(dot.x * c.x, dot.y * c.y, dot.z * c.z, dot.w * c.w);
         *reinterpret_cast<float4*>(dg.G + m * dg.ldg + 4 * cq) = gv;
         gsum.x += gv.x; gsum.y += gv.y; gsum.z += gv.z; gsum.w += gv.w;
+        if (m / kBM != tmx_tile) {                            // uniform over the wave (m is): a new tile begins
+          tmx_flush();
+          tmx_tile = m / kBM;
+        }
+        tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fmaxf(__builtin_fabsf(gv.x), __builtin_fabsf(gv.y))), __builtin_fmaxf(__builtin_fabsf(gv.z), __builtin_fabsf(gv.w)));
       }
     }
   }
+  if (DGRAD) tmx_flush();
   if (DGRAD) {                                             // column sums of G over the slab: the four row-waves in fixed order
     if (rs > 0) *reinterpret_cast<float4*>(&red[rs - 1][0][4 * cq]) = gsum;
     __syncthreads();
@@ -2908,14 +2997,17 @@ int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const f
 }
 
 static int mlp_layer_bwd_input_bx_impl(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,
-                                       void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, int sgn, void* stream) {
+                                       void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, int sgn, void* stream,
+                                       const unsigned* g_tile_max = nullptr, unsigned* out_tile_max = nullptr) {
   if (!g || !wtsplit || !c_prev || !g_prev || M <= 0 || n_prev <= 0 || n_prev > 256 || n_red <= 0 || n_red > 256) return MATPBR_ERR_INVALID_ARG;
-  if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || !aligned16(g) ||
+  if (nprod == 3 && (!g_tile_max || n_red <= 32)) return MATPBR_ERR_INVALID_ARG;
+  if ((nprod != 3 && nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || !aligned16(g) ||
       !aligned16(g_prev) || !aligned16(c_prev))
     return MATPBR_ERR_UNSUPPORTED;
   if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
   NtArgs p{g, nullptr, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, (int)M, n_prev, n_red, ldg, 0, ldo};
   p.cmul_sin = sgn;
+  p.a_tmax = g_tile_max; p.o_tmax = out_tile_max;
   const int groups = launch_nt_bx<EPI_MULC>(p, (const uint4*)wtsplit, nprod, (hipStream_t)stream);
   if (groups < 0) return MATPBR_ERR_LAUNCH;
   if (d_bias_prev)
@@ -2923,11 +3015,12 @@ static int mlp_layer_bwd_input_bx_impl(const float* g, int ldg, const void* wtsp
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
-int matpbr_mlp_first_layer_bwd_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, int ldc, int sgn, const float* x0, int ldx0,
-                                  float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes, void* workspace2,
-                                  size_t workspace2_bytes, long M, int n0, int n_red, int nprod, void* stream) {
+static int mlp_first_layer_bwd_impl(const float* g, int ldg, const void* wtsplit, const float* c_prev, int ldc, int sgn, const float* x0, int ldx0,
+                                    float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes, void* workspace2,
+                                    size_t workspace2_bytes, long M, int n0, int n_red, int nprod, const unsigned* g_tile_max, void* stream) {
   if (!g || !wtsplit || !c_prev || !x0 || !d_w0 || M <= 0 || n0 <= 0 || n0 > 256 || n_red <= 0 || n_red > 256 || d0 <= 0 || d0 > 16) return MATPBR_ERR_INVALID_ARG;
-  if ((nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldc < 256 || (ldc & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || ldx0 < 16 || (ldx0 & 3) ||
+  if (nprod == 3 && (!g_tile_max || n_red <= 32)) return MATPBR_ERR_INVALID_ARG;
+  if ((nprod != 3 && nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldc < 256 || (ldc & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || ldx0 < 16 || (ldx0 & 3) ||
       !aligned16(g) || !aligned16(c_prev) || !aligned16(x0))
     return MATPBR_ERR_UNSUPPORTED;
   if (d_bias0 && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
@@ -2935,11 +3028,18 @@ int matpbr_mlp_first_layer_bwd_bx(const float* g, int ldg, const void* wtsplit, 
   NtArgs p{g, nullptr, nullptr, c_prev, nullptr, nullptr, d_bias0 ? (float*)workspace : nullptr, (int)M, n0, n_red, ldg, 0, ldc};
   p.cmul_sin = sgn;
   p.x0 = x0; p.ldx0 = ldx0; p.w0_part = (float*)workspace2;
+  p.a_tmax = g_tile_max;
   const int tiles = (int)(M / kBM);
   unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
   int slabs = (int)grid * 4;
   bool ok;
-  if (gx_ok(p) && g_nt_w0_gx.load(std::memory_order_relaxed) != 0) {
+  if (nprod == 3) {                                        // block-scaled f16 pieces: the two-workgroup form (fewer operand registers: no spills)
+    if ((long)kBM * ldg * 4 >= (1l << 31)) return MATPBR_ERR_UNSUPPORTED;
+    grid = (unsigned)(tiles < 512 ? tiles : 512);
+    slabs = (int)grid * 2;
+    ok = lds_opt_in<&mlp_nt_gx<EPI_MULC, 3, false, false, true>>(kGxSmem);
+    if (ok) hipLaunchKernelGGL((mlp_nt_gx<EPI_MULC, 3, false, false, true>), dim3(grid), dim3(kGxThreads), kGxSmem, (hipStream_t)stream, p, (const uint4*)wtsplit, HeadArgs{});
+  } else if (gx_ok(p) && g_nt_w0_gx.load(std::memory_order_relaxed) != 0) {
     grid = (unsigned)(tiles < 512 ? tiles : 512);
     slabs = (int)grid * 2;
     if (nprod == 9) {
@@ -2959,12 +3059,33 @@ int matpbr_mlp_first_layer_bwd_bx(const float* g, int ldg, const void* wtsplit, 
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
+int matpbr_mlp_first_layer_bwd_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, int ldc, int sgn, const float* x0, int ldx0,
+                                  float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes, void* workspace2,
+                                  size_t workspace2_bytes, long M, int n0, int n_red, int nprod, void* stream) {
+  if (nprod == 3) return MATPBR_ERR_INVALID_ARG;           // the f16 form needs the tile maxima: matpbr_mlp_first_layer_bwd_blk
+  return mlp_first_layer_bwd_impl(g, ldg, wtsplit, c_prev, ldc, sgn, x0, ldx0, d_w0, ld_j, ld_c, d0, d_bias0, workspace, workspace_bytes, workspace2,
+                                  workspace2_bytes, M, n0, n_red, nprod, nullptr, stream);
+}
+int matpbr_mlp_first_layer_bwd_blk(const float* g, int ldg, const void* g_tile_max, const void* wtsplit, const float* s_prev, int lds, const float* x0, int ldx0,
+                                   float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes, void* workspace2,
+                                   size_t workspace2_bytes, long M, int n0, int n_red, void* stream) {
+  return mlp_first_layer_bwd_impl(g, ldg, wtsplit, s_prev, lds, 1, x0, ldx0, d_w0, ld_j, ld_c, d0, d_bias0, workspace, workspace_bytes, workspace2,
+                                  workspace2_bytes, M, n0, n_red, 3, (const unsigned*)g_tile_max, stream);
+}
+int matpbr_mlp_layer_bwd_input_blk(const float* g, int ldg, const void* g_tile_max, const void* wtsplit, const float* s_prev, float* g_prev, int ldo,
+                                   void* out_tile_max, float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
+  return mlp_layer_bwd_input_bx_impl(g, ldg, wtsplit, s_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, 3, 1, stream,
+                                     (const unsigned*)g_tile_max, (unsigned*)out_tile_max);
+}
+
 int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,
                                   void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, void* stream) {
+  if (nprod == 3) return MATPBR_ERR_INVALID_ARG;
   return mlp_layer_bwd_input_bx_impl(g, ldg, wtsplit, c_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, nprod, 0, stream);
 }
 int matpbr_mlp_layer_bwd_input_bx_sgn(const float* g, int ldg, const void* wtsplit, const float* s_prev, float* g_prev, int ldo, float* d_bias_prev,
                                       void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, void* stream) {
+  if (nprod == 3) return MATPBR_ERR_INVALID_ARG;
   return mlp_layer_bwd_input_bx_impl(g, ldg, wtsplit, s_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, nprod, 1, stream);
 }
 
@@ -2995,24 +3116,37 @@ int matpbr_mlp_layer_bwd_weight(const float* g, int ldg, const float* x, int ldx
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
-int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
-                                   size_t workspace_bytes, long M, int N, int K, int nprod, void* stream) {
+static int mlp_layer_bwd_weight_bx_impl(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
+                                        size_t workspace_bytes, long M, int N, int K, int nprod, const unsigned* g_tile_max, void* stream) {
   if (!g || !x || !d_w || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
-  if ((nprod != 6 && nprod != 9) || (M & 15) || ldg < 256 || ldx < 256 || (ldg & 3) || (ldx & 3) || ldw < K || !aligned16(g) || !aligned16(x))
+  if (nprod == 3 && (!g_tile_max || (M % kBM))) return MATPBR_ERR_INVALID_ARG;
+  if ((nprod != 3 && nprod != 6 && nprod != 9) || (M & 15) || ldg < 256 || ldx < 256 || (ldg & 3) || (ldx & 3) || ldw < K || !aligned16(g) || !aligned16(x))
     return MATPBR_ERR_UNSUPPORTED;   // all 256 columns of both are read
   if (!workspace || workspace_bytes < matpbr_mlp_bwd_weight_workspace_bytes(M)) return MATPBR_ERR_WORKSPACE;
   int slabs = wgrad_slabs(M);
   long rows = ((M + slabs - 1) / slabs + 15) / 16 * 16;
   slabs = (int)((M + rows - 1) / rows);
-  if (nprod == 6) {
+  if (nprod == 3) {
+    if (!lds_opt_in<&mlp_wgrad_bx<3>>(kWgSmem)) return MATPBR_ERR_LAUNCH;
+    hipLaunchKernelGGL(mlp_wgrad_bx<3>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, g_tile_max);
+  } else if (nprod == 6) {
     if (!lds_opt_in<&mlp_wgrad_bx<6>>(kWgSmem)) return MATPBR_ERR_LAUNCH;
-    hipLaunchKernelGGL(mlp_wgrad_bx<6>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows);
+    hipLaunchKernelGGL(mlp_wgrad_bx<6>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, (const unsigned*)nullptr);
   } else {
     if (!lds_opt_in<&mlp_wgrad_bx<9>>(kWgSmem)) return MATPBR_ERR_LAUNCH;
-    hipLaunchKernelGGL(mlp_wgrad_bx<9>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows);
+    hipLaunchKernelGGL(mlp_wgrad_bx<9>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, (const unsigned*)nullptr);
   }
   hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
+                                   size_t workspace_bytes, long M, int N, int K, int nprod, void* stream) {
+  if (nprod == 3) return MATPBR_ERR_INVALID_ARG;           // matpbr_mlp_layer_bwd_weight_blk
+  return mlp_layer_bwd_weight_bx_impl(g, ldg, x, ldx, d_w, ldw, workspace, workspace_bytes, M, N, K, nprod, nullptr, stream);
+}
+int matpbr_mlp_layer_bwd_weight_blk(const float* g, int ldg, const void* g_tile_max, const float* x, int ldx, float* d_w, int ldw, void* workspace,
+                                    size_t workspace_bytes, long M, int N, int K, void* stream) {
+  return mlp_layer_bwd_weight_bx_impl(g, ldg, x, ldx, d_w, ldw, workspace, workspace_bytes, M, N, K, 3, (const unsigned*)g_tile_max, stream);
 }
 
 int matpbr_mlp_sincos(const float* pre, long ldp, float* s_out, long lds, float* c_out, long ldc, long M, int n, void* stream) {
@@ -3080,9 +3214,9 @@ int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ld
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
-int matpbr_mlp_out_layer_bwd(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
-                             int ldg, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace, size_t workspace_bytes,
-                             long M, int J, int n_prev, void* stream) {
+static int mlp_out_layer_bwd_impl(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
+                                  int ldg, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace, size_t workspace_bytes,
+                                  long M, int J, int n_prev, unsigned* g_tile_max, void* stream) {
   if (!d_x || !s_prev || !w_out || !g_prev || !d_w || M <= 0 || J <= 0 || J > kOutJ || n_prev <= 0 || n_prev > 256) return MATPBR_ERR_INVALID_ARG;
   if (ldd < 8 || lds < 256 || (lds & 3) || ldg < 256 || (ldg & 3) || ldw < 256 || (ldw & 3) || !aligned16(s_prev) || !aligned16(g_prev) || !aligned16(w_out) ||
       (c_prev && !aligned16(c_prev)))
@@ -3094,11 +3228,25 @@ int matpbr_mlp_out_layer_bwd(const float* d_x, int ldd, const float* s_prev, con
   float* partial = (float*)workspace;
   float* bpart = partial + (size_t)kSkinnySlabs * 8 * 256;
   float* gsum_part = bpart + (size_t)kSkinnySlabs * 8;
-  SkinnyDgrad dg{w_out, ldw, J, c_prev, g_prev, ldg, gsum_part};
+  SkinnyDgrad dg{w_out, ldw, J, c_prev, g_prev, ldg, gsum_part, g_tile_max};
   hipLaunchKernelGGL((mlp_skinny_tn_kernel<8, true>), dim3(slabs), dim3(256), 0, (hipStream_t)stream, d_x, ldd, s_prev, lds, partial, bpart, M, rows, dg);
   hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(8 * 4 + (d_bias_prev ? 4 : 0)), dim3(1024), 0, (hipStream_t)stream, (const float*)partial, (const float*)bpart, slabs, 8,
                      J, 256, d_w, ld_j, ld_c, d_bias, (const float*)gsum_part, n_prev, d_bias_prev);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
+}
+
+int matpbr_mlp_out_layer_bwd(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
+                             int ldg, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace, size_t workspace_bytes,
+                             long M, int J, int n_prev, void* stream) {
+  return mlp_out_layer_bwd_impl(d_x, ldd, s_prev, c_prev, lds, w_out, ldw, g_prev, ldg, d_w, ld_j, ld_c, d_bias, d_bias_prev, workspace, workspace_bytes, M, J,
+                                n_prev, nullptr, stream);
+}
+int matpbr_mlp_out_layer_bwd_tmax(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
+                                  int ldg, void* g_tile_max, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace,
+                                  size_t workspace_bytes, long M, int J, int n_prev, void* stream) {
+  if (!g_tile_max) return MATPBR_ERR_INVALID_ARG;
+  return mlp_out_layer_bwd_impl(d_x, ldd, s_prev, c_prev, lds, w_out, ldw, g_prev, ldg, d_w, ld_j, ld_c, d_bias, d_bias_prev, workspace, workspace_bytes, M, J,
+                                n_prev, (unsigned*)g_tile_max, stream);
 }
 
 }  // extern "C"

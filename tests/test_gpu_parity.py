@@ -2084,6 +2084,77 @@ def test_two_piece_f16_forward_layers_are_f32_accurate(N, K):
         ops.mlp_layer_fwd_bx(x, ws, b, s1, torch.empty_like(s1), 200, K, 3)            # N < 256 without a tail
 
 
+@pytest.mark.parametrize("n_prev,n_red", [(256, 256), (241, 256), (256, 241)])
+def test_block_scaled_f16_backward_products(n_prev, n_red):
+    """f2 (round 5): the backward products of the 256-wide layers on two f16 pieces with one exponent per 128-row tile
+    (`matpbr_mlp_layer_bwd_input_blk`, `matpbr_mlp_layer_bwd_weight_blk`, `matpbr_mlp_out_layer_bwd_tmax`; the autograd backward of
+    mymodels/mlps.py:102-103).  Gradients of the size a mean loss over 512 x 512 pixels produces (1e-6), tiles whose magnitudes differ by
+    1e4 (each tile has its own exponent), a few elements far below their tile's largest: against fp64 the error is that of the three-bf16-piece
+    form and within 1.5 x the exact-f32 kernels' (the f32 accumulation dominates), ROW by row inside a tile as well; the tile maxima the
+    kernels write are the maxima; the bias gradient is the column sum; a zero tile stays zero."""
+    from materialist_amd import ops
+
+    dev = _cuda()
+    torch.manual_seed(23)
+    M = 128 * 520                                         # more tiles than workgroups
+    T = M // 128
+    tile_mag = torch.exp(torch.randn(T, device=dev) * 2.0).clamp(1e-2, 1e2).repeat_interleave(128)[:, None]
+    g = torch.randn(M, 256, device=dev) * 1e-6 * tile_mag
+    g[:, ::7] *= 1e-3                                     # elements far below their tile's largest
+    g[128 * 5:128 * 6] = 0.0                              # a tile without any gradient
+    g[:, n_red:] = float("nan")                           # scratch columns of a ragged reduction
+    w = (torch.rand(n_red, 256, device=dev) * 2 - 1) / 16          # forward weight W[n_red, n_prev]: the operand is its transpose
+    x_prev = torch.randn(M, 256, device=dev)
+    wb = torch.randn(n_prev, 256, device=dev) / 16
+    s_prev = torch.empty(M, 256, device=dev)
+    ops.mlp_layer_fwd_bx(x_prev, ops.mlp_split_weights(wb, n_prev, 256, f16=True), torch.zeros(n_prev, device=dev), s_prev, None, n_prev, 256, 3,
+                         tail=torch.zeros(M, 16, device=dev) if n_prev < 256 else None)
+    tmax = g[:, :n_red].abs().view(T, 128, n_red).amax((1, 2)).contiguous().view(torch.int32)
+    cosv = torch.cos(x_prev.double() @ wb[:, :256].double().t())
+    ref = (g[:, :n_red].double() @ w[:, :n_prev].double()) * cosv
+    outs = {}
+    for mode in ("bf16", "f16"):
+        gp, db = torch.full((M, 256), float("nan"), device=dev), torch.empty(n_prev, device=dev)
+        if mode == "bf16":
+            ops.mlp_layer_bwd_input_bx(g, ops.mlp_split_weights(w, n_prev, n_red, transposed=True), s_prev, gp, n_prev, n_red, db, 6, packed=True)
+            tm_out = None
+        else:
+            tm_out = ops.mlp_tile_max(M, dev)
+            ops.mlp_layer_bwd_input_blk(g, tmax, ops.mlp_split_weights(w, n_prev, n_red, transposed=True, f16=True), s_prev, gp, n_prev, n_red, db, tm_out)
+        outs[mode] = (gp, db, tm_out)
+    torch.cuda.synchronize()
+    # the rebuilt cosine (|error| ~ 2e-7 / |cos|) is common to both forms: compare on the product before the cosine where it matters
+    row_scale = ref.abs().amax(1, keepdim=True).view(T, 128, 1).amax(1, keepdim=True).expand(T, 128, 1).reshape(M, 1) + 1e-30   # per TILE
+    e = {k: (v[0][:, :n_prev].double() - ref).abs() / row_scale for k, v in outs.items()}
+    assert torch.isfinite(outs["f16"][0][:, :n_prev]).all()
+    assert e["f16"].max().item() <= max(1.5 * e["bf16"].max().item(), 2e-5), (e["f16"].max().item(), e["bf16"].max().item())
+    rms = {k: v.pow(2).mean().sqrt().item() for k, v in e.items()}
+    assert rms["f16"] <= 1.25 * rms["bf16"] + 1e-9, rms
+    assert (outs["f16"][0][:, :n_prev] - outs["bf16"][0][:, :n_prev]).abs().div(row_scale).max().item() <= 4e-6
+    assert outs["f16"][0][128 * 5:128 * 6, :n_prev].abs().max().item() == 0.0
+    gp16, db16, tm_out = outs["f16"]
+    want = gp16[:, :n_prev].abs().view(T, 128, n_prev).amax((1, 2))
+    assert torch.equal(tm_out.view(torch.float32), want)
+    col = gp16[:, :n_prev].double().sum(0)
+    assert (db16.double() - col).abs().max().item() <= 1e-5 * (col.abs().max().item() + 1e-30)
+    # weight gradient g^T x: x the sign-carrying sines (and a coordinate column), g as above
+    xin = s_prev.clone()
+    xin[:, 255] = torch.randint(0, 512, (M,), device=dev).float()
+    gg = g.clone()
+    gg[:, n_red:] = float("inf")
+    ref_w = torch.zeros(n_red, 256, dtype=torch.float64, device=dev)
+    for c in range(0, M, 16640):
+        ref_w += gg[c:c + 16640, :n_red].double().t() @ xin[c:c + 16640].double()
+    dw6 = ops.mlp_layer_bwd_weight_bx(gg, xin, n_red, 256, 6)
+    dw3 = ops.mlp_layer_bwd_weight_blk(gg, tmax, xin, n_red, 256)
+    dw0 = ops.mlp_layer_bwd_weight(g.nan_to_num(0.0), xin, n_red, 256)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw3).all()
+    sw = ref_w.abs().max().item()
+    e0, e6, e3 = ((d.double() - ref_w).abs().max().item() / sw for d in (dw0, dw6, dw3))
+    assert e3 <= max(1.5 * e0, 1.5 * e6, 2e-6), (e3, e6, e0)
+
+
 @pytest.mark.parametrize("M", [16, 16 * 3, 16 * 1001, 16 * 4099])
 def test_split_operand_weight_gradient_ragged_slabs(M):
     """The slab partition of the split-operand weight gradient for row counts that leave a short (odd number of 16-row steps)
