@@ -1151,7 +1151,12 @@ class PosMlpNormalPhase:
         self._light = self.scene.light.detach().contiguous()
         E = lambda c: torch.empty(H, W, c, device=dev)
         self.g = {"albedo": E(3), "roughness": E(1), "metallic": E(1)}
-        self.best = {"albedo": E(3), "roughness": E(1), "metallic": E(1), "normal": E(3), "rendered_img": torch.zeros_like(self.gt)}
+        # the snapshot buffers start as the incoming fixed maps (what a reader of `saver.best` sees until an iteration improves on the carried-over
+        # best loss: never uninitialised memory)
+        start = {"albedo": self.fixed["albedo"], "roughness": self.fixed["roughness"], "metallic": self.fixed["metallic"],
+                 "normal": self.fixed.get("normal", self.scene.shading_normal())}
+        self.best = {k: v.detach().to(dev, torch.float32).reshape(H, W, -1).clone() for k, v in start.items()}
+        self.best["rendered_img"] = torch.zeros_like(self.gt)
         self.saver.best = self.best        # the runner reads the snapshot through the saver
 
     def _step_device(self) -> torch.Tensor:

@@ -153,8 +153,8 @@ class Scene:
         self.light[..., 0, :] = float(np.sqrt(4 * np.pi))  # unit white radiance until the caller sets emitter.data
         self.emitter_data = self.light
         self._ws = {"ws": None}
-        self._cache: Optional[dict] = None               # OPERATOR_CACHE: what was computed for (light, normals) of `_cache["key"]`
-        self._seen_key = None
+        self._cache: Optional[dict] = None               # OPERATOR_CACHE: what was computed for the (light, normals) objects of `_cache["src"]`
+        self._seen: Optional[dict] = None                # the pair seen by the last call that found no cache (built when it comes back)
         self.cache_builds = 0                            # how many times it was (re)built (tests, profiling)
         self.bg_mask: Optional[torch.Tensor] = None      # [H,W] bool: pixels without geometry (mesh_mask.png)
         self.bg_basis: Optional[torch.Tensor] = None     # [H*W,25]: Y_k(camera ray) on those pixels, 0 elsewhere
@@ -195,9 +195,13 @@ class Scene:
         if key == "shape.bsdf.use_mesh_normal":
             self.use_mesh_normal = bool(value)
         elif key == "emitter.data":
-            self.emitter_data = value
-            self.light = self.light_from_emitter(value)
+            light = self.light_from_emitter(value)           # texels: a fresh projection every time (they may have been stepped in place)
+            if light is not self.light:                      # another light: what was kept for the old one goes (also when no render came in between)
+                self.invalidate_cache()
+            self.emitter_data, self.light = value, light
         else:
+            if key == "shape.bsdf.n" and value is not self.n and not self.use_mesh_normal:
+                self.invalidate_cache()
             setattr(self, key.rsplit(".", 1)[1], value)
 
     # -- lighting ------------------------------------------------------------------------------------
@@ -222,26 +226,37 @@ class Scene:
         # use_mesh_normal=True shades with the geometric normal, not the n map (F10; mi_plugin.py:1386-1389)
         return self.geo_normal if self.use_mesh_normal else self.n
 
-    def _cached(self, light: torch.Tensor, nrm: torch.Tensor, spp: int) -> Optional[dict]:
-        """The per-(light, normals) cache, rebuilt when either changed (identity or in-place version) or `spp` did.  None when the light or
-        the normals take part in autograd (they are not constants of the call) or caching is off."""
+    def invalidate_cache(self) -> None:
+        """Forget what the operator face keeps per (light, normals).  For callers that write the light or the normal map through raw pointers
+        (this library's own kernels, `.data`), which no version counter sees."""
+        self._cache = None
+        self._seen = None
+
+    def _cached(self, light_src: torch.Tensor, light: torch.Tensor, nrm: torch.Tensor, spp: int) -> Optional[dict]:
+        """The per-(light, normals) cache, rebuilt when either changed or `spp` did.  "Changed" is decided on the tensor OBJECTS the scene holds
+        (`light_src`: `self.light` before any broadcast; `nrm`) -- the cache keeps strong references to them, so their storage cannot be freed
+        and handed to another tensor at the same address -- plus their autograd version counters (an in-place optimiser step).  None when the
+        light or the normals take part in autograd (they are not constants of the call) or caching is off."""
         if OPERATOR_CACHE == "none" or ATTACHED_SAMPLING or light.requires_grad or nrm.requires_grad or not light.is_cuda:
             return None
-        key = (light.data_ptr(), light._version, tuple(light.shape), nrm.data_ptr(), nrm._version, int(spp), self.fov)
-        if self._cache is not None and self._cache["key"] == key:
+        tag = (light_src._version, tuple(light.shape), nrm._version, int(spp), self.fov)
+
+        def same(entry):
+            return entry is not None and entry["src"][0] is light_src and entry["src"][1] is nrm and entry["tag"] == tag
+
+        if same(self._cache):
             return self._cache
-        if key != self._seen_key:          # a light used once (an env-phase iteration, a relit frame) is not worth nine planes per pixel:
-            self._seen_key = key           # the cache is built when the same (light, normals) come back
+        if not same(self._seen):           # a light used once (an env-phase iteration, a relit frame) is not worth nine planes per pixel:
+            self._seen = {"src": (light_src, nrm), "tag": tag}      # the cache is built when the same (light, normals) come back
             self._cache = None
             return None
-        if True:
-            lc, nc = light.detach().contiguous(), nrm.detach().contiguous()
-            stats = ops.new_loss_stats(self.B, self.device)
-            stats[:, ops.STAT_RATIO] = 1.0
-            stats[:, ops.STAT_GT_SUM] = 1e-6          # first (forced) build: every interval against the render itself (a conservative floor)
-            self._cache = {"key": key, "light": lc, "n": nc, "dcache": ops.diffuse_cache(nc, lc, int(spp), self.fov), "state": None,
-                           "stats": stats, "fresh": True}
-            self.cache_builds += 1
+        lc, nc = light.detach().contiguous(), nrm.detach().contiguous()
+        stats = ops.new_loss_stats(self.B, self.device)
+        stats[:, ops.STAT_RATIO] = 1.0
+        stats[:, ops.STAT_GT_SUM] = 1e-6          # first (forced) build: every interval against the render itself (a conservative floor)
+        self._cache = {"src": (light_src, nrm), "tag": tag, "light": lc, "n": nc, "dcache": ops.diffuse_cache(nc, lc, int(spp), self.fov),
+                       "state": None, "stats": stats, "fresh": True}
+        self.cache_builds += 1
         return self._cache
 
     def render(self, spp: int) -> torch.Tensor:
@@ -252,7 +267,7 @@ class Scene:
         r = self.r.reshape(shp + (1,))
         m = self.m.reshape(shp + (1,))
         nrm = self.shading_normal()
-        cache = self._cached(light, nrm, spp)
+        cache = self._cached(self.light, light, nrm, spp)
         want_mat = torch.is_grad_enabled() and any(t.requires_grad for t in (self.a, r, m))
         if cache is not None and want_mat and OPERATOR_CACHE == "lazy":
             if cache["state"] is None:

@@ -399,6 +399,52 @@ def test_operator_face_keeps_its_models_between_calls_and_rebuilds_them_when_the
     assert float(((img - exact).abs() / torch.maximum(exact.abs(), exact.abs().mean())).max()) < 2e-5
 
 
+def test_operator_face_cache_is_keyed_on_tensor_objects_not_addresses():
+    """a batch with ONE shared [25,3] light is rendered through an expanded (copied) light, so the cache cannot be keyed on the copy's
+    address.  Two `_set("emitter.data", ...)` without a render in between, lights that are freed and re-allocated (the caching allocator hands
+    the same address to the next one), a light written through its raw storage + `invalidate_cache()`: every render is the render of the
+    light that is set."""
+    import gc
+
+    from materialist_amd import ops, render
+
+    dev = _cuda()
+    B, H, W, spp = 2, 32, 64, 16
+    scs = [_scene_arrays(H, W, image_id=i)[0] for i in (3, 4)]
+    depth = torch.stack([_t(s.depth, dev) for s in scs])
+    scene = render.load_estimated_mesh(depth, use_mesh_normal=True)
+    nrm = scene.shading_normal()
+    a0, r0, m0 = (torch.stack([_t(getattr(s, k), dev) for s in scs]) for k in ("albedo", "roughness", "metallic"))
+    base = _t(scs[0].light, dev)
+
+    def check(light):
+        a, r, m = (x.clone().requires_grad_(True) for x in (a0, r0, m0))
+        img = render.render_w_brdf(scene, a, r, m, None, spp)
+        img.sum().backward()
+        exact = ops.shade_fwd(a0, r0, m0, nrm, light.unsqueeze(0).expand(B, -1, -1).contiguous(), spp)
+        assert float(((img.detach() - exact).abs() / torch.maximum(exact.abs(), exact.abs().mean())).max()) < 1e-3
+
+    for k in range(6):                                   # each light lives for three renders (build on the second), then is dropped
+        light = (base * (0.5 + 0.3 * k)).contiguous()
+        scene._set("emitter.data", light)
+        for _ in range(3):
+            check(light)
+        del light
+        gc.collect()
+    builds = scene.cache_builds
+    assert builds == 6
+    l1, l2 = (base * 0.4).contiguous(), (base * 1.7).contiguous()
+    scene._set("emitter.data", l1)
+    scene._set("emitter.data", l2)                       # no render in between
+    for _ in range(3):
+        check(l2)
+    # a write through the raw storage (what this library's kernels do): no version counter moves, the caller says so
+    l2.data.mul_(0.5)
+    scene.invalidate_cache()
+    for _ in range(3):
+        check(l2)
+
+
 # ------------------------------------------------------------------------- size-independent properties @ 512^2
 def test_full_size_properties():
     from materialist_amd import ops, synthetic

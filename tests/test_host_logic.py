@@ -46,7 +46,7 @@ def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
     lines += ['  printf(", \\"n_sizeof\\": %zu", sizeof(MatpbrNormalStep));']
     lines += [f'  printf(", \\"n_{f}\\": %zu", offsetof(MatpbrNormalStep, {f}));' for f in nfields]
     macros = ["FLAG_CLAMP_PARAMS", "FLAG_ATTACHED_SAMPLING", "FLAG_LAZY_FORCE", "FLAG_JAC16", "FLAG_MODELS_READY", "FLAG_ROTATE_BEST",
-              "FLAG_GENERIC_STEP", "FLAG_JAC32"]
+              "FLAG_GENERIC_STEP", "FLAG_JAC32", "FLAG_SHARE_GPU"]
     lines += [f'  printf(", \\"{m}\\": %u", (unsigned)MATPBR_{m});' for m in macros]
     lines += ['  printf(", \\"PART_N\\": %u", (unsigned)MATPBR_PART_N);']
     lines += ['  printf(", \\"PART_A\\": %u, \\"PART_R\\": %u, \\"PART_M\\": %u, \\"STATS_STRIDE\\": %d}\\n", MATPBR_PART_A, MATPBR_PART_R, MATPBR_PART_M, MATPBR_STATS_STRIDE);',
@@ -63,6 +63,10 @@ def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
         assert getattr(_lib.MatpbrNormalStep, f).offset == c["n_" + f], f
     for m in macros:
         assert getattr(ops, m) == c[m], m
+    # one word carries flags AND part bits (MatpbrBrdfPhase.flags beside part_mask; the `flags` argument of the brdf_loss_* entry points):
+    # every value a single bit, all of them distinct
+    bits = [c[m] for m in macros] + [c["PART_A"], c["PART_R"], c["PART_M"], c["PART_N"]]
+    assert all(v and not (v & (v - 1)) for v in bits) and len(set(bits)) == len(bits), bits
     assert ops.PART_N == c["PART_N"] and ops.part_mask("armn") == c["PART_A"] | c["PART_R"] | c["PART_M"] | c["PART_N"]
     assert c["STATS_STRIDE"] == 16 and ops.STAT_GT_SUM == 15
     from materialist_amd.loop import FusedBrdfPhase
