@@ -508,6 +508,21 @@ int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wspl
 #define MATPBR_WSPLIT_TRANSPOSED 1
 #define MATPBR_WSPLIT_F16X2 2
 int matpbr_mlp_split_weights_fmt(const float* w, int ldw, int N, int K, int flags, void* wsplit, void* stream);
+/* The whole forward pass of the 'arm' coordinate MLP in ONE launch (round 5; csrc/posmlp_chain.hip; mymodels/mlps.py:211-236 with the skip
+ * concatenations of :214-217 and the tanh head of :232-234, the maps of inverse_img_w_mi.py:493-496).  The products are formed transposed
+ * (weights = A operand, rows = B operand), so a lane's sines of one layer are its share of the next layer's operand: between two layers the
+ * activations stay in registers; every layer's sign-carrying sines are still WRITTEN once (the backward pass reads them), none is read.
+ * Arithmetic as matpbr_mlp_layer_fwd_bx with nprod = 3 (two f16 pieces of 256 w and of the sines, three products, f32 accumulation), the
+ * first layer (K = d0 <= 16) on the exact-f32 matrix instruction; = the layer-by-layer kernels to f32 rounding (the k order differs).
+ *   matpbr_mlp_chain_images_bytes  size of the `images` buffer
+ *   matpbr_mlp_chain_prep          once per weight state: w[0] [n[0], ldw >= d0], w[1..3] [n[l], ldw >= 256], w[4] [n[4] <= 8, ldw >= 256] and the
+ *                                  five bias vectors -> images.  n[l] of a sine layer is 256, or 241 = 256 - 15 for a layer whose buffer ends in x0
+ *   matpbr_mlp_chain_fwd           x0 [M, ldx0 >= 16] (zero beyond d0) -> s_out[0..3] [M, ldo >= 256] (columns n[l].. of a 241-wide layer = x0,
+ *                                  written here), th [M, 8], the maps (each nullable) as matpbr_mlp_arm_head_fwd.  M a multiple of 128 */
+size_t matpbr_mlp_chain_images_bytes(void);
+int matpbr_mlp_chain_prep(const float* const* w, const int* ldw, const int* n, const float* const* bias, int d0, void* images, void* stream);
+int matpbr_mlp_chain_fwd(const float* x0, int ldx0, const void* images, float* const* s_out, int ldo, const int* n, const float* start, int lds, float* th,
+                         float* map_a, float* map_r, float* map_m, int n_head, long M, void* stream);
 /* The BACKWARD products of the 256-wide layers on two f16 pieces (round 5; the autograd backward of mymodels/mlps.py:102-103, :216-224 as
  * driven by inverse_img_w_mi.py:493-547).  A loss gradient has no natural size, so the rows g travel in blocks: every 128-row tile (128
  * consecutive pixels) has ONE power-of-two exponent that brings its largest |g| to [2^13, 2^14), taken from `g_tile_max` -- [M / 128] f32

@@ -69,6 +69,8 @@ class ArmMlpPhase:
     FUSED_FIRST_BWD = True # the first layer's weight / bias gradient from the epilogue of the input-gradient kernel above it (class switch)
     BWD_F16 = True         # the backward products of the 256-wide layers on two f16 pieces under one exponent per 128-row tile
                            # (include/matpbr.h `matpbr_mlp_layer_bwd_input_blk`); needs PACKED, FUSED_OUT_BWD, FUSED_FIRST_BWD.  Class switch
+    FWD_CHAIN = True       # the whole forward pass as one launch with the activations in registers between the layers
+                           # (include/matpbr.h `matpbr_mlp_chain_fwd`; needs PACKED, FWD_PRODUCTS 3 and the reference's 15-241-256-241-256-5 shape)
     FWD_PRODUCTS = 3       # forward sine layers on two f16 pieces per operand, three products (include/matpbr.h `matpbr_mlp_split_weights_fmt`);
                            # 0: as the backward products (`_PosMlpHipFn.PRODUCTS`, three bf16 pieces).  Class switch: the tests run both
 
@@ -164,6 +166,18 @@ class ArmMlpPhase:
             raise NotImplementedError("ArmMlpPhase: at most four 256-wide layers after the first")
         import ctypes as _ct
 
+        self.chain = bool(self.FWD_CHAIN and self.packed and self.fwd_products == 3 and self.L == 5 and all(n in (241, 256) for n in self.ns)
+                          and self.views[-1][0].shape[0] <= 8 and self.d0 <= 15 and all((n == 241) == ((l + 1) in net.skip) for l, n in enumerate(self.ns)))
+        if self.chain:
+            jobs = [jb for jb in jobs if jb[4] & 1]                # the forward images are the chain's own (matpbr_mlp_chain_prep)
+            lib = _lib.load()
+            self._chain_images = torch.empty(int(lib.matpbr_mlp_chain_images_bytes()), dtype=torch.uint8, device=dev)
+            P_ = _ct.c_void_p
+            ws_, bs_ = [v[0] for v in self.views], [v[1] for v in self.views]
+            self._chain_prep = ((P_ * 5)(*[w_.data_ptr() for w_ in ws_]), (_ct.c_int * 5)(*[w_.stride(0) for w_ in ws_]), (_ct.c_int * 5)(*[w_.shape[0] for w_ in ws_]),
+                                (P_ * 5)(*[b_.data_ptr() for b_ in bs_]), int(self.d0), P_(self._chain_images.data_ptr()))
+            self._chain_out = (P_ * 4)(*[b_.data_ptr() for b_ in self.bufs])
+            self._chain_n = (_ct.c_int * 4)(*self.ns)
         nj = len(jobs)
         self._split_args = ((_ct.c_void_p * nj)(*[j[0] for j in jobs]), (_ct.c_int * nj)(*[j[1] for j in jobs]), (_ct.c_int * nj)(*[j[2] for j in jobs]),
                             (_ct.c_int * nj)(*[j[3] for j in jobs]), (_ct.c_int * nj)(*[j[4] for j in jobs]), (_ct.c_void_p * nj)(*[j[5] for j in jobs]), nj)
@@ -214,6 +228,16 @@ class ArmMlpPhase:
         o, P = ops, self.fwd_products
         with torch.cuda.device(self.dev):
             _lib.check(_lib.load().matpbr_mlp_split_weights_multi(*self._split_args, o._stream(self.flat)), "matpbr_mlp_split_weights_multi")
+        if self.chain:
+            live = self.live
+            lib, st = _lib.load(), o._stream(self.flat)
+            mp = [o._ptr(self.maps[k]) if k in live else None for k in ("albedo", "roughness", "metallic")]
+            with torch.cuda.device(self.dev):
+                _lib.check(lib.matpbr_mlp_chain_prep(*self._chain_prep, st), "matpbr_mlp_chain_prep")
+                _lib.check(lib.matpbr_mlp_chain_fwd(o._ptr(self.x0p), self.x0p.stride(0), o._ptr(self._chain_images), self._chain_out, 256, self._chain_n,
+                                                    o._ptr(self.start_arm), self.start_arm.stride(0), o._ptr(self.th), *mp, self.views[-1][0].shape[0], self.M, st),
+                           "matpbr_mlp_chain_fwd")
+            return {k: (self.maps[k] if k in live else self.fixed[k]) for k in self.maps}
         wp, bp = self.views[0]
         # skip layers on the split-operand kernel: whole 16-byte stores over the x0 tail, rewritten by a small launch (-20 us per layer
         # against guarding the straddling word of every row in the epilogue); the first layer's kernel keeps its guard (no gain there)

@@ -2130,6 +2130,66 @@ def test_two_piece_f16_forward_layers_are_f32_accurate(N, K):
         ops.mlp_layer_fwd_bx(x, ws, b, s1, torch.empty_like(s1), 200, K, 3)            # N < 256 without a tail
 
 
+@pytest.mark.parametrize("size", [(128, 128), (192, 192)])
+def test_forward_chain_is_the_layer_by_layer_forward(size):
+    """f2 (round 5): `matpbr_mlp_chain_fwd` -- the whole 'arm' network (15 -> 241 -> 256 -> 241 -> 256 -> 5, skip concatenations, tanh head,
+    mymodels/mlps.py:211-236) in one launch with the activations in registers between the layers -- against the layer-by-layer launches of
+    ArmMlpPhase (same arithmetic, another order of the k index) and against the reference module in fp64: every layer's sign-carrying sines
+    (x0 tails included), tanh(x), the three maps.  128 tiles (one per workgroup) and 288 tiles (workgroups that stream a second tile)."""
+    import copy
+
+    from materialist_amd import loop, ops, posmlp, render, synthetic
+    from materialist_amd.armhead import ArmMlpPhase
+
+    dev = _cuda()
+    H, W = size
+    sc = synthetic.make_scene(4, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    gt = torch.rand(H, W, 3, device=dev)
+    a0, r0, m0 = (_t(v, dev).clamp(0, 1) for v in (sc.init_albedo, sc.init_roughness, sc.init_metallic))
+    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).contiguous()
+    torch.manual_seed(5)
+    net = posmlp.brdf_net("arm").to(dev)
+    net.lin4.weight.data.normal_(0, 0.05)
+    net.lin4.bias.data.normal_(0, 0.05)
+    fixed = {"albedo": a0, "roughness": r0, "metallic": m0}
+    outs = {}
+    for chain in (False, True):
+        ArmMlpPhase.FWD_CHAIN = chain
+        try:
+            ph = ArmMlpPhase(scene, gt, copy.deepcopy(net), start_arm, fixed, optimize_part="arm", spp=8)
+            assert ph.chain == chain
+            for l_, b_ in enumerate(ph.bufs):                            # (the layer-by-layer path wrote the x0 tails once, at construction)
+                if chain:
+                    b_.fill_(float("nan"))
+                else:
+                    b_[:, :ph.ns[l_]] = float("nan")
+            maps = ph.forward()
+            torch.cuda.synchronize()
+            outs[chain] = ([b_.clone() for b_ in ph.bufs], ph.th.clone(), {k: v.clone() for k, v in maps.items()})
+        finally:
+            ArmMlpPhase.FWD_CHAIN = True
+    (b0, th0, m0_), (b1, th1, m1_) = outs[False], outs[True]
+    for l, (x, y) in enumerate(zip(b0, b1)):
+        assert torch.isfinite(y).all(), l
+        n = ph.ns[l]
+        assert torch.equal(x[:, n:], y[:, n:]), l                                       # the x0 tail of a skip layer's buffer
+        # the first layer's arguments are pixel coordinates times weights (|pre| of order 100: one f32 ulp is 8e-6, and the two paths add the
+        # 15 terms in different orders); deeper layers amplify the rounding below them.  Measured: 6e-6 (192 x 192), 3.5e-6 (128 x 128)
+        assert (x[:, :n] - y[:, :n]).abs().max().item() <= 2e-5, (l, (x[:, :n] - y[:, :n]).abs().max().item())
+        sx, sy = x[:, :n].view(torch.int32) & 1, y[:, :n].view(torch.int32) & 1        # the sign of the cosine, away from cos = 0
+        big = (1 - x[:, :n].double() ** 2).clamp_min(0).sqrt() > 1e-3
+        assert torch.equal(sx[big], sy[big]), l
+    assert (th0[:, :5] - th1[:, :5]).abs().max().item() <= 2e-5 and float(th1[:, 5:].abs().max()) == 0.0
+    for k in m0_:
+        assert (m0_[k] - m1_[k]).abs().max().item() <= 2.6e-5, k
+    # the reference module in fp64 (mymodels/mlps.py:211-236 restated in posmlp.PosMLP)
+    ref = copy.deepcopy(net).double()(start_arm.double())
+    got = torch.cat([m1_["albedo"].reshape(-1, 3), ((m1_["roughness"].reshape(-1, 1) - 0.07) / 0.93), m1_["metallic"].reshape(-1, 1)], -1)
+    assert (got.double() - ref).abs().max().item() <= 4e-5
+
+
 @pytest.mark.parametrize("n_prev,n_red", [(256, 256), (241, 256), (256, 241)])
 def test_block_scaled_f16_backward_products(n_prev, n_red):
     """f2 (round 5): the backward products of the 256-wide layers on two f16 pieces with one exponent per 128-row tile
