@@ -27,6 +27,7 @@
 
 namespace {
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int kChStage = 32768;                         // bytes of a weight stage: [2 k-steps][2 pieces][2 lane halves][256 features] x 16 B
 constexpr int kChLayer = 8 * kChStage;                  // a layer's image: 8 stages
 constexpr int kChW0 = 8 * 2 * 32 * 8 * 4;               // [8 blocks][2 g][32 i][8 s] f32: W0[32 fb + i][2 s + g]
@@ -191,7 +192,11 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainArgs p
       const float unscale = FIRST ? 1.0f : kF16WUnscale;
       // (selects, not indexed kernel arguments: an indexed read would put the argument block into scratch memory)
       const bool tail = (L == 1 ? p.tail[0] : L == 2 ? p.tail[1] : L == 3 ? p.tail[2] : p.tail[3]) != 0;
+#ifdef MATPBR_CHAIN_STORE_L2     // measurement: every tile stores over the same 128 rows (the stores' issue cost without their HBM traffic)
+      float* const outp = (L == 1 ? p.out[0] : L == 2 ? p.out[1] : L == 3 ? p.out[2] : p.out[3]) + (row & 127) * p.ldo + 4 * h;
+#else
       float* const outp = (L == 1 ? p.out[0] : L == 2 ? p.out[1] : L == 3 ? p.out[2] : p.out[3]) + row * p.ldo + 4 * h;
+#endif
       const float* const bias = sBias + (L - 1) * 256 + 4 * h;
       f32x16 accN[8];
 #pragma unroll
@@ -205,7 +210,11 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainArgs p
         if (t >= 1 && !HEAD) {
           // the weights of stage P (requested two stages ago): everything but the youngest request (8 pieces) and the stores behind it (4)
           // the weights of stage P: its last piece went out with chunk 7 two slots ago; behind it one store, then last slot's 8 pieces and 4 stores
+#ifdef MATPBR_CHAIN_LOOSE_WAIT       // measurement only (WRONG results): how much of a slot is the wait for older stores' acknowledgements
+          asm volatile("s_waitcnt vmcnt(45) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
           asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         }
         // A fragments (weights) of block c, stage t - 1: [k-step][piece]; requested one chunk ahead of their products
         uint4 af[2][2][2];
@@ -262,7 +271,12 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainArgs p
             split2h(v0, v1, p_hi, p_lo);
             set_comp(bp[t & 1][q >> 1][0], 2 * (q & 1) + (c & 1), p_hi);
             set_comp(bp[t & 1][q >> 1][1], 2 * (q & 1) + (c & 1), p_lo);
-#ifndef MATPBR_CHAIN_NO_STORE
+#ifdef MATPBR_CHAIN_STORE_LINEAR     // measurement: the same bytes as whole 1 KB runs per instruction (a scrambled layout: what coalesced stores would cost)
+            if (c & 1) *reinterpret_cast<float4*>((L == 1 ? p.out[0] : L == 2 ? p.out[1] : L == 3 ? p.out[2] : p.out[3]) + ((size_t)(tile * 4 + wave) * 8 + t) * 1024 + q * 256 + lane * 4) =
+                make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
+#elif defined(MATPBR_CHAIN_STORE_NT)
+            if (c & 1) __builtin_nontemporal_store(f32x4v{vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]}, reinterpret_cast<f32x4v*>(outp + 32 * t + 8 * q));
+#elif !defined(MATPBR_CHAIN_NO_STORE)
             if (c & 1) *reinterpret_cast<float4*>(outp + 32 * t + 8 * q) = make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
 #endif
           }

@@ -24,7 +24,8 @@ ROUGHNESS_SHIFT, METALLIC_SHIFT = 0.7, 0.05   # :183-184
 def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], optimize_order: Sequence[str] = ("arm",), spp: int = 64,
                          opt_env_from: int = 0, opt_src: str = "arm", scale_delta: float = 0.1, num_epochs: int = 5000,
                          sync_every: int = 25, env_size=(16, 32), log=None, frames=None, results_dir: Optional[str] = None,
-                         shading_normal: Optional[torch.Tensor] = None, model_name: str = "none", use_mask: bool = False) -> Dict[str, object]:
+                         shading_normal: Optional[torch.Tensor] = None, model_name: str = "none", use_mask: bool = False,
+                         digests: Optional[list] = None) -> Dict[str, object]:
     """mat: albedo [H,W,3], roughness [H,W,1], metallic [H,W,1], normal [H,W,3], gt_image [H,W,3] (optionally gt_envmap).
     Returns the best maps / envmap / render, the final PSNR and the schedule trace.  `frames` (pipeline.FrameWriter) and
     `results_dir` switch on the reference's file outputs: a frame at every host poll (the reference: every 10 epochs,
@@ -32,6 +33,15 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
     dev = mat["gt_image"].device
     gt = mat["gt_image"].contiguous()
     mat = dict(mat)
+
+    def stage_digest(stage: str, *tensors) -> None:
+        # `digests` (a list the caller hands in): (stage, SHA-256 of the stage's tensors) at the schedule's boundaries -- what a run that came out
+        # different is compared on to find the FIRST stage that differs (tools/pipeline_hashes.py, tests/golden/indoor2_digests.json).  A stage
+        # boundary already synchronises with the host (the pollers have returned), so the copies cost nothing the loops would notice
+        if digests is not None:
+            digests.append((stage, _loss.tensors_digest(*tensors)))
+
+    stage_digest("inputs", gt, mat["albedo"], mat["roughness"], mat["metallic"], scene.shading_normal())
     if "r" not in opt_src:                                                         # :185-188
         mat["roughness"] = torch.full_like(mat["roughness"], ROUGHNESS_SHIFT)
     if "m" not in opt_src:
@@ -198,6 +208,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
                              state["final_envmap"], final=True)                     # opt_env_img.png (:298)
         if save:
             _save_results()                                                         # :302-303
+        stage_digest(f"loop {loop_num} env", state["final_envmap"])
         say(f"loop {loop_num}: env phase done, mse {state['last_mse']:.5f}")
 
     def on_brdf_phase_begin(loop_num: int, which: str) -> None:                    # :317-342
@@ -373,6 +384,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
             mat["normal"] = saver.best["normal"].detach().clone()
             params["shape.bsdf.n"] = mat["normal"]
         _save_results()                                                             # :465,590
+        stage_digest(f"loop {loop_num} brdf {part}", mat["albedo"], mat["roughness"], mat["metallic"])
 
     trace: List[TraceEvent] = run_schedule(list(optimize_order), None, None, opt_src=opt_src, opt_env_from=opt_env_from,
                                            num_epochs=num_epochs, on_env_phase_end=on_env_phase_end,
@@ -385,6 +397,7 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         red = (-3, -2, -1) if gt.ndim == 4 else None                                # per image for a batch
         ratio = gt.mean(dim=red, keepdim=True) / final.mean(dim=red, keepdim=True) if red else gt.mean() / final.mean()
         psnr_each = _loss.psnr(final * ratio, gt).reshape(-1)
+    stage_digest("final", saver.best["albedo"], saver.best["roughness"], saver.best["metallic"], saver.best["envmap"], final)
     return {"albedo": saver.best["albedo"], "roughness": saver.best["roughness"], "metallic": saver.best["metallic"], "normal": mat.get("normal"),
             "envmap": saver.best["envmap"], "rendered_img": saver.best["rendered_img"], "final_render": final,
             "psnr": float(psnr_each.mean()), "psnr_per_image": psnr_each.tolist(), "best_loss": float(saver.best_loss.min()),

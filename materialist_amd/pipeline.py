@@ -373,7 +373,8 @@ def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], 
 def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", opt_order: Sequence[str] = ("arm",), use_mask: bool = False,
                   opt_env_from: int = 0, save_path: Optional[str] = None, model_name: str = "pos_mlp", size: int = 512, spp: int = 64,
                   num_epochs: int = 5000, pred_dir: Optional[str] = None, device: str = "cuda", sync_every: int = 10,
-                  log=print, matnet_weights: Optional[str] = None, frame_interval: float = 0.2, matnet=None, geometry: str = "mesh") -> Dict[str, object]:
+                  log=print, matnet_weights: Optional[str] = None, frame_interval: float = 0.2, matnet=None, geometry: str = "mesh",
+                  digests: Optional[list] = None) -> Dict[str, object]:
     """inverse_img_w_mi.py:623-770 (resolution-generic: `size`; `model_name` is honoured, F4).  `matnet`: an already loaded MaterialNet
     (run_batch.py loads the weights once on rank 0 and broadcasts them)."""
     from . import optimize, render
@@ -460,12 +461,14 @@ def inverse_image(img_inverse_path: str, save_name: str, opt_src: str = "arm", o
         rm = _mesh.reference_mesh(d_mesh, render.DEFAULT_FOV)                                    # :726-727, minAngle 6, gap closing included
         _mesh.write_ply(mesh_path, rm["vertices"], rm["triangles"])
     scene = render.load_estimated_mesh(t(depth), use_mesh_normal=use_mesh_normal, device=device, mesh_mask=mesh_mask, geometry=geometry)
+    if digests is not None:
+        digests.append(("prep", _loss.tensors_digest(t(img), t(depth), scene.geo_normal)))       # the image as read, the depth as flipped, the mesher's normals
     frames = FrameWriter(output_dir, min_interval=frame_interval)
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
                                         num_epochs=num_epochs, sync_every=sync_every, log=log, frames=frames,
                                         results_dir=os.path.join(output_dir, "best_results"),
                                         shading_normal=scene.geo_normal if use_mesh_normal else None,
-                                        model_name=model_name, use_mask=use_mask and "mask" in mat)
+                                        model_name=model_name, use_mask=use_mask and "mask" in mat, digests=digests)
     frames.close()
     create_video_from_frames(frames.env_frames, os.path.join(output_dir, "env_optimization.mp4"))        # :593-599
     create_video_from_frames(frames.mat_frames, os.path.join(output_dir, "mat_optimization.mp4"))

@@ -409,9 +409,25 @@ def test_the_pipeline_is_reproducible(model_name, epochs, tmp_path):
         assert res.returncode == 0, res.stderr[-2000:]
         runs += json.loads([l for l in res.stdout.splitlines() if l.startswith("[")][-1])
     assert len(runs) == 3 and len(runs[0]["hashes"]) >= 6
+
+    def first_difference(x, y):
+        for (sx, dx), (sy, dy) in zip(x, y):
+            if (sx, dx) != (sy, dy):
+                return f"first stage that differs: {sx!r} ({dx} against {dy})"
+        return "stage digests agree" if len(x) == len(y) else f"{len(x)} against {len(y)} stages"
+
     for r in runs[1:]:
-        assert r["hashes"] == runs[0]["hashes"], (runs[0]["psnr"], r["psnr"])
+        assert r["hashes"] == runs[0]["hashes"], (runs[0]["psnr"], r["psnr"], first_difference(runs[0]["stage_digests"], r["stage_digests"]))
         assert r["log"][1:] == runs[0]["log"][1:]            # the same losses, iteration counts and stop reasons, line by line
+    # across runs, processes AND boxes: the digests committed for this arithmetic (regenerate with tools/pipeline_hashes.py --write-golden after a
+    # change that is meant to move the numbers; a difference found here names the first stage of the schedule at which a run went its own way)
+    gpath = os.path.join(root, "tests", "golden", f"indoor2_digests_{model_name}.json")
+    assert os.path.exists(gpath), "commit the stage digests: python tools/pipeline_hashes.py --model_name ... --write-golden " + gpath
+    gold = json.load(open(gpath))
+    assert gold["num_epochs"] == epochs and gold["seed"] == 11
+    got = runs[0]["stage_digests"]
+    assert [list(d) for d in got] == gold["stage_digests"], (first_difference(gold["stage_digests"], got), gold["psnr"], runs[0]["psnr"])
+    assert runs[0]["hashes"] == gold["hashes"]
 
 
 def test_run_batch_takes_predictions_and_runs_a_shard_of_photographs_as_one_batch(golden_dir, tmp_path):

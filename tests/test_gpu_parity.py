@@ -399,6 +399,43 @@ def test_operator_face_keeps_its_models_between_calls_and_rebuilds_them_when_the
     assert float(((img - exact).abs() / torch.maximum(exact.abs(), exact.abs().mean())).max()) < 2e-5
 
 
+@pytest.mark.parametrize("B,part", [(1, "rm"), (1, "arm"), (3, "a"), (3, "rm")])
+def test_fused_brdf_loss_node_is_the_torch_composition(B, part):
+    """a11 on the drop-in face (round 5): `loss.brdf_loss` of CUDA tensors is ONE autograd node over matpbr_brdf_loss_stats and
+    matpbr_brdf_loss_dpred; against the torch composition of inverse_img_w_mi.py:388-418 (the same function with `loss.FUSED = False`): the
+    loss, loss_mse, the ratio, pred_srgb, and the gradients with respect to the render and to every regularised map, single image and batch."""
+    from materialist_amd import loss as L
+
+    dev = _cuda()
+    torch.manual_seed(31)
+    H, W = 48, 80
+    shp = (H, W) if B == 1 else (B, H, W)
+    gt = torch.rand(shp + (3,), device=dev) * 0.8 + 0.05
+    pred0 = (gt * (0.6 + 0.5 * torch.rand(shp + (3,), device=dev))).contiguous()
+    keys = {"a": ("albedo", 3), "r": ("roughness", 1), "m": ("metallic", 1)}
+    raw = {keys[c][0]: torch.rand(shp + (keys[c][1],), device=dev) for c in part}
+    orig = {k: (v + 0.1 * torch.randn_like(v)).clamp(0, 1) for k, v in raw.items()}
+    res = {}
+    for fused in (False, True):
+        L.FUSED = fused
+        try:
+            pred = pred0.clone().requires_grad_(True)
+            ps = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+            parts = {k: (v.clamp(0.07, 1) if k == "roughness" else v.clamp(0, 1)) for k, v in ps.items()}
+            loss, mse, pred_srgb, ratio = L.brdf_loss(pred * 1.0, gt, parts, orig, 0.1)
+            (loss * 1.7).backward()
+            res[fused] = (loss.detach(), mse.detach(), pred_srgb.detach(), ratio.detach() if torch.is_tensor(ratio) else ratio, pred.grad, {k: v.grad for k, v in ps.items()})
+        finally:
+            L.FUSED = True
+    (l0, m0, s0, r0, g0, gp0), (l1, m1, s1, r1, g1, gp1) = res[False], res[True]
+    assert float(l1) == pytest.approx(float(l0), rel=2e-5)
+    assert torch.allclose(m1.reshape(-1), m0.reshape(-1), rtol=2e-5) and torch.allclose(torch.as_tensor(r1).reshape(-1), torch.as_tensor(r0).reshape(-1).to(dev), rtol=1e-5)
+    assert (s1 - s0).abs().max().item() <= 2e-6
+    assert (g1 - g0).abs().max().item() <= 2e-4 * g0.abs().max().item()
+    for k in gp0:
+        assert (gp1[k] - gp0[k]).abs().max().item() <= 1e-6 * max(gp0[k].abs().max().item(), 1e-30) + 1e-12, k
+
+
 def test_operator_face_cache_is_keyed_on_tensor_objects_not_addresses():
     """a batch with ONE shared [25,3] light is rendered through an expanded (copied) light, so the cache cannot be keyed on the copy's
     address.  Two `_set("emitter.data", ...)` without a render in between, lights that are freed and re-allocated (the caching allocator hands

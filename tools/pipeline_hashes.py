@@ -29,7 +29,8 @@ def one(model_name: str, out_dir: str, num_epochs: int, seed: int):
     args = ri.parse(["--sample", "indoor2", "--model_name", model_name, "--out", out_dir, "--num_epochs", str(num_epochs)])
     args.out = os.path.abspath(out_dir)
     res = ri.run(args)
-    return {"psnr": res["psnr_vs_photo"]["this_build_final_render"], "hashes": hashes(args.out), "log": [l.split("] ")[-1] for l in res["log"]]}
+    return {"psnr": res["psnr_vs_photo"]["this_build_final_render"], "hashes": hashes(args.out), "log": [l.split("] ")[-1] for l in res["log"]],
+            "stage_digests": [list(d) for d in res["stage_digests"]]}
 
 
 if __name__ == "__main__":
@@ -39,6 +40,13 @@ if __name__ == "__main__":
     ap.add_argument("--num_epochs", type=int, default=5000)
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--write-golden", default=None, help="write run 0's stage digests, file hashes and PSNR to this JSON (tests/golden/indoor2_digests_<mode>.json)")
     a = ap.parse_args()
     runs = [one(a.model_name, os.path.join(a.out, f"run{k}"), a.num_epochs, a.seed) for k in range(a.repeat)]
+    if a.write_golden:
+        import torch
+
+        with open(a.write_golden, "w") as f:
+            json.dump({"model_name": a.model_name, "num_epochs": a.num_epochs, "seed": a.seed, "device": torch.cuda.get_device_properties(0).gcnArchName,
+                       "psnr": runs[0]["psnr"], "stage_digests": runs[0]["stage_digests"], "hashes": runs[0]["hashes"]}, f, indent=1)
     print(json.dumps(runs))

@@ -106,11 +106,11 @@ def run(args):
     tmp = tempfile.mkdtemp(prefix="indoor2_")
     z = unpack_fixture(tmp)
     gt = _loss.srgb_to_linear(torch.from_numpy(z["image_srgb_u8"].astype(np.float32) / 255)).numpy()
-    lines = []
+    lines, digests = [], []
     t0 = time.time()
     res = inverse_image(os.path.join(tmp, "indoor2.png"), "indoor2", opt_src="a", opt_order=args.opt_order, opt_env_from=args.opt_env_from,
                         save_path=args.out, model_name=args.model_name, size=512, spp=64, num_epochs=args.num_epochs, pred_dir=tmp,
-                        log=lambda s: lines.append(s))
+                        log=lambda s: lines.append(s), digests=digests)
     torch.cuda.synchronize()
     wall = time.time() - t0
     mine = res["final_render"].detach().cpu().numpy()
@@ -131,6 +131,7 @@ def run(args):
                                     for k in ("albedo", "roughness", "metallic")},
     }
     out["log"] = lines
+    out["stage_digests"] = digests        # (stage, SHA-256 of the stage's tensors): compare with tests/golden/indoor2_digests.json to localise a run that differs
     return out
 
 
