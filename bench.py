@@ -209,6 +209,9 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from materialist_amd.dist import pin_rank_cores
+
+    pinned = pin_rank_cores()          # the ranks of a node on disjoint core sets (before any thread pool starts)
     # the CPU baseline runs BEFORE the GPU legs (rank 0, N = 1 only): the GPU work then sits at the end of the run
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -241,11 +244,11 @@ def main(argv=None):
     class Workload:
         """B independent synthetic images of this rank's shard, resident in HBM, and the phases that iterate on them."""
 
-        def __init__(self, B):
+        def __init__(self, B, size=None):
             self.B = B
             lo, hi = shard_range(world * B, world, rank)     # contiguous shard of independent images (SURVEY.md 8e)
             self.lo = lo
-            scenes = [synthetic.make_scene(i, H, W) for i in range(lo, hi)]
+            scenes = [synthetic.make_scene(i, size or H, size or W) for i in range(lo, hi)]
             t = lambda xs: torch.from_numpy(np.stack(xs) if B > 1 else xs[0]).to(dev)
             self.depth = t([s.depth for s in scenes])
             self.gt = tuple(t([getattr(s, k) for s in scenes]) for k in ("albedo", "roughness", "metallic"))
@@ -366,6 +369,15 @@ def main(argv=None):
             finally:
                 _posmlp._PosMlpHipFn.PRODUCTS = keep
             modes["pos_mlp_exact_f32"] = {"it_per_s": 100 * B * world / e_el, "ms_per_step": e_el / 100 * 1e3, "images_per_gpu": B}
+            # ... and on three bf16 pieces per operand, six products, layer by layer (round 4's form of every product of the iteration)
+            from materialist_amd.armhead import ArmMlpPhase as _Arm
+            keep_sw = (_Arm.FWD_PRODUCTS, _Arm.FWD_CHAIN, _Arm.BWD_F16)
+            _Arm.FWD_PRODUCTS, _Arm.FWD_CHAIN, _Arm.BWD_F16 = 0, False, False
+            try:
+                e_el, _ = proto.timed(stepper(wl.phase("pos_mlp")), 10, 100)
+            finally:
+                _Arm.FWD_PRODUCTS, _Arm.FWD_CHAIN, _Arm.BWD_F16 = keep_sw
+            modes["pos_mlp_bf16x3"] = {"it_per_s": 100 * B * world / e_el, "ms_per_step": e_el / 100 * 1e3, "images_per_gpu": B}
         if B != 8 and H * W <= 512 * 512:
             wl8 = Workload(8)                 # BASELINE configs[2]: 64 images, 8 per GPU; this is one GPU's shard (every rank runs its own)
             ph8 = wl8.phase("fused")
@@ -384,6 +396,34 @@ def main(argv=None):
             modes["fused_b8_a"] = {"it_per_s": 300 * 8 * world / e_el, "ms_per_step": e_el / 300 * 1e3, "images_per_gpu": 8}
             e_el, _ = proto.timed(wl8.phase("fused_exact").step, 10, 100)
             modes["fused_b8_exact"] = {"it_per_s": 100 * 8 * world / e_el, "ms_per_step": e_el / 100 * 1e3, "images_per_gpu": 8}
+    # 8-GPU readiness that one GPU can show: what an iteration costs the HOST (Python + ctypes + launch calls), next to what it costs the GPU.
+    # Measured as the wall time per step() of the same phase classes on images so small that the GPU side is far shorter than the host side
+    # (64 x 64 / 128 x 128: the launches and their arguments are the same); eight ranks on one node need that many microseconds of a core each
+    host_enqueue = None
+    if not args.no_extras and mode != "torch":
+        host_enqueue = {}
+        for name, hb, hsize, hmode in (("PipelinedBrdfPhase_b8_rm", 8, 64, "fused"), ("FusedBrdfPhase_b1_rm", 1, 64, "fused"), ("ArmMlpPhase_rm", 1, 128, "pos_mlp")):
+            try:
+                wl_s = Workload(hb, hsize)
+                ph_s = wl_s.phase(hmode)
+                for _ in range(20):
+                    ph_s.step()
+                torch.cuda.synchronize()
+                t_h = time.perf_counter()
+                for _ in range(200):
+                    ph_s.step()
+                host_us = (time.perf_counter() - t_h) / 200 * 1e6       # enqueue only: no synchronisation inside
+                torch.cuda.synchronize()
+                full = {"PipelinedBrdfPhase_b8_rm": "fused_b8", "FusedBrdfPhase_b1_rm": "fused", "ArmMlpPhase_rm": "pos_mlp"}[name]
+                host_enqueue[name] = {"host_enqueue_us_per_iteration": host_us, "gpu_us_per_iteration_at_512": (modes[full]["ms_per_step"] * 1e3) if full in modes else None,
+                                      "measured_on": f"{hb} x {hsize}x{hsize} (same launches; the GPU side is shorter than the host side there)"}
+                del ph_s, wl_s
+            except Exception as e:
+                host_enqueue[name] = {"error": repr(e)}
+        host_enqueue["cores"] = len(os.sched_getaffinity(0))
+        host_enqueue["note"] = ("a rank's iteration is enqueued by ONE Python thread; with the ranks of a node pinned to disjoint core sets (bench.py launch_ranks, "
+                                "run_batch.py) each needs one core that is not shared: where host_enqueue approaches the GPU time (the 8-image none-mode shard) a "
+                                "shared or oversubscribed core is what would cost the 8-GPU scaling, not the fabric")
     mode_names = {"fused": "hot loop B, --model_name none, whole iteration in libmatpbr.so, THREE launches in a part that moves the roughness, two otherwise: the "
                            "partial sums of the loss statistics; the folded, persistent step (csrc/matpbr_pstep.hpp: at most 1024 workgroups stream the image "
                            "from two register sets, fold the statistics, commit SaveBest / EarlyStopping, run the backward pass, Adam and the next iteration's "
@@ -405,7 +445,12 @@ def main(argv=None):
                   "fused_a": "the same two launches in part 'a' of --opt_order 'rm a' (roughness fixed): no pixel ever leaves its model's interval, "
                              "nothing is re-sampled after the part's first render",
                   "fused_b8_a": "part 'a' on the 8-image shard, two groups of four images on streams of their own as fused_b8 (image-iterations/s)",
-                  "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase: split-operand sine layers, tanh head, render, loss, backward, AdamW on a flat buffer; no BLAS, no autograd)",
+                  "pos_mlp": "hot loop B, --model_name pos_mlp: every launch of the iteration a kernel of libmatpbr.so (armhead.ArmMlpPhase): the network's forward pass "
+                             "as ONE launch (transposed products chain the layers through registers: csrc/posmlp_chain.hip), render, loss, the backward products "
+                             "(input gradients with cos and bias-gradient epilogues, weight gradients) on two f16 pieces under one exponent per 128-row tile, "
+                             "AdamW on a flat buffer; no BLAS, no autograd",
+                  "pos_mlp_bf16x3": "the pos_mlp loop as round 4 ran it: every 256-wide product on three bf16 pieces per operand and six matrix products, layer "
+                                    "by layer (ArmMlpPhase with FWD_PRODUCTS 0, FWD_CHAIN False, BWD_F16 False); the default differs in how the f32 products are formed",
                   "pos_mlp_exact_f32": "the pos_mlp loop with --mlp-products 0: 256-wide layers on the exact-f32 MFMA kernels, autograd composition "
                                        "(loop.PosMlpBrdfPhase); the default differs from it only in how the f32 products are formed (same error vs fp64)",
                   "fused_n": "hot loop B, --model_name none, a part that moves the normal map ('n', use_mesh_normal False; loop.NormalBrdfPhase): render, loss "
@@ -499,6 +544,27 @@ def main(argv=None):
             t_stats = back_to_back(lambda: ph.launch_stage(2))
             return t_step, t_stats, float(ref.float().mean()), t_res
 
+        def lazy_gradient_error(w):
+            """What the timed kernel's gradients are worth: the loss gradients the lazy step forms from its per-pixel models at iteration
+            400 of a part against the streaming backward pass on the EXACT jac planes of the same parameters (every sample of every pixel walked:
+            tests/test_gpu_lazy.py measures the same every 50th iteration of 2000)."""
+            ph = loop.FusedBrdfPhase(w.scene, w.gt_image, *w.init, optimize_part="rm", spp=args.spp, keep_grads=True)
+            ph.run(400)
+            p_at = [ph.p[k].clone() for k in ("albedo", "roughness", "metallic")]
+            ph.step()
+            exact, jac_e = torch.empty_like(w.gt_image), ops.plane9(w.gt_image)
+            g_ref = {k: torch.empty_like(v) for k, v in ph.g.items()}
+            ops.shade_fwd(*p_at, ph.n, ph.light, args.spp, clamp_params=True, out=exact, dcache=ph.dcache, jac=jac_e)
+            ops.brdf_loss_bwd_jac(*p_at, jac_e, exact, ph.gt_srgb, ph.stats, ph.orig["albedo"], ph.orig["roughness"], ph.orig["metallic"], 0.1,
+                                  g_ref["albedo"], g_ref["roughness"], g_ref["metallic"], optimize_part="rm")
+            res = {}
+            for k in ("roughness", "metallic"):
+                e = ((ph.g[k] - g_ref[k]).abs() / torch.maximum(g_ref[k].abs(), g_ref[k].abs().mean())).reshape(-1)
+                res[k] = {"rel_l2": float((ph.g[k] - g_ref[k]).norm() / g_ref[k].norm()), "worst_pixel": float(e.max()),
+                          "p999_pixel": float(torch.quantile(e[:: max(1, e.numel() // 2_000_000)].float(), 0.999)), "median_pixel": float(e.median()),
+                          "cosine": float((ph.g[k] * g_ref[k]).sum() / (ph.g[k].norm() * g_ref[k].norm()))}
+            return res
+
         wr = wl8 if wl8 is not None else wl
         tk = kernel_times(wr)
         px = H * W * wr.B
@@ -509,6 +575,11 @@ def main(argv=None):
                 pmc = json.load(open(tpath))
             except Exception:
                 pmc = {}
+        from materialist_amd.build import sources_digest
+        if pmc.get("csrc_sha16") != sources_digest():
+            # the counter passes were collected on other kernels than the ones this run executes: no traffic figure rather than a stale one
+            pmc = {"stale": f"profiles/pmc_traffic.json was collected on csrc {pmc.get('csrc_sha16')}, this build is {sources_digest()}: "
+                            "re-run tools/pmc_passes_r05.sh + tools/pmc_to_traffic.py --write"}
         key = f"{H}x{W}_b{wr.B}_spp{args.spp}"
         t_step, t_stats, resampled, t_res = lazy_step_times(wr)
         ach = (BYTES_FWD + BYTES_BWD_ARM) * px / (t_step * 1e-3) / 1e9
@@ -524,7 +595,10 @@ def main(argv=None):
                 "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM,
                 "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
                 "resampled_fraction": resampled, "stats_launches_ms": t_stats, "resample_launch_ms": t_res,
-                "traffic": traffic, "traffic_source": pmc.get("source_r04") if traffic else None,
+                "gradient_error_of_this_kernel": dict(lazy_gradient_error(wr), note="d loss / d roughness, d loss / d metallic at iteration 401 of the part, every pixel, "
+                                                      "against the backward pass on exact sampling of the same parameters (pixel errors relative to max(|g|, mean|g|)); "
+                                                      "the RENDER of the same kernel is within 1e-3 of exact sampling on every pixel (tests/test_gpu_lazy.py)"),
+                "traffic": traffic, "traffic_source": pmc.get("source_r04") if traffic else pmc.get("stale"),
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "
                         "really moves per launch (PMC; by construction 144 B/pixel in an 'rm' part: r, m read and written 16, the folded models 64, target 12, the "
@@ -610,18 +684,46 @@ def main(argv=None):
                 "bwd_input_mulcos_colsum": {"avg_launch_ms": ms_din, "achieved": tf(ms_din)},
                 "bwd_weight": {"avg_launch_ms": ms_dw, "achieved": tf(ms_dw)}}
         if bx:
-            # the kernels the iteration runs issue P bf16 MFMA products per f32 product: their roofline is the bf16 matrix pipe
-            gemm = {"bound": "mfma", "unit": "TFLOP/s", "peak": 2500.0, "achieved": P * bx["achieved"],
-                    "peak_note": f"dense bf16 MFMA peak; `achieved` = the bf16 matrix-pipe flop the split-operand kernels issue ({P} partial products per f32 "
-                                 "product, v_mfma_f32_32x32x16_bf16, f32 accumulate) per second, epilogues included.  In f32-EQUIVALENT terms (2 M N K per "
-                                 f"product) that is `f32_equivalent.achieved`; its ceiling is 2500 / {P} TFLOP/s, not the 157.3 of the f32 pipe",
-                    "kernel": "mlp_nt_gx<sincos> / <mul cos> / mlp_wgrad_bx: [H*W,256]x[256,256], operands split into three bf16 pieces, f32 accumulate",
-                    "f32_equivalent": {"achieved": bx["achieved"], "ceiling_of_the_scheme": 2500.0 / P, "f32_mfma_peak_for_reference": 157.3},
-                    "split_operand": bx, "exact_f32": f32k,
-                    "stand_alone_vs_in_loop": "these legs run each kernel 20 times back to back on N(0,1) data: 255-270 us per forward layer, against 200-215 us "
-                                              "for the same launch inside the traced iteration.  Measured (tools/layer_gap.py): the same kernel on zeros 205 us, on "
-                                              "sin(.) inputs 255 us, on N(0,1) 269 us (the chip holds a lower clock under sustained matrix work on wide-range data); "
-                                              "two chained layers (the second reads what the first wrote: Infinity Cache) 224 us each",
+            # what the iteration runs since round 5: two f16 pieces per operand, three products (half the matrix work of the bf16 form) -- the layers are
+            # then bound by their HBM traffic, and that is what they are priced against; the share of the f16 matrix pipe is reported beside it
+            B4 = Mg * 256 * 4.0
+            f16 = None
+            try:
+                wsp3, wsp3t = ops.mlp_split_weights(wg, 256, 256, f16=True), ops.mlp_split_weights(wg, 256, 256, transposed=True, f16=True)
+                xs_ = torch.sin(xg)                                   # the rows of a forward layer are sines
+                ops.mlp_layer_fwd_bx(xs_, wsp3, bg, sg, None, 256, 256, 3)
+                g_small = gg * 1e-6                                   # loss gradients of a mean over 512 x 512 pixels
+                tmx = g_small.abs().view(Mg // 128, -1).amax(1).contiguous().view(torch.int32)
+                tmo = ops.mlp_tile_max(Mg, dev)
+                ms3_f = back_to_back(lambda: ops.mlp_layer_fwd_bx(xs_, wsp3, bg, sg, None, 256, 256, 3), 20)
+                ms3_i = back_to_back(lambda: ops.mlp_layer_bwd_input_blk(g_small, tmx, wsp3t, sg, gp, 256, 256, dbg, tmo), 20)
+                ms3_w = back_to_back(lambda: ops.mlp_layer_bwd_weight_blk(g_small, tmx, sg, 256, 256, out=dwg), 20)
+                leg = lambda ms, nb: {"avg_launch_ms": ms, "bytes": nb, "achieved": nb / (ms * 1e-3) / 1e9, "frac": nb / (ms * 1e-3) / HBM_PEAK,
+                                      "f16_matrix_pipe_frac": 3 * flop / (ms * 1e-3) / 2.5e15}
+                f16 = {"products": 3, "forward_sin": leg(ms3_f, 2 * B4), "bwd_input_mulcos_colsum": leg(ms3_i, 3 * B4), "bwd_weight": leg(ms3_w, 2 * B4),
+                       "bytes_note": "algorithmic: forward reads the rows and writes the sign-carrying sines (2 x M x 256 x 4 B); the input gradient reads g and the "
+                                     "sines below and writes g' (3 x); the weight gradient reads g and the rows (2 x)"}
+                ph_c = wl.phase("pos_mlp")
+                if getattr(ph_c, "chain", False):
+                    ms_c = back_to_back(lambda: ph_c.forward(), 20)
+                    nb_c = 4 * B4 + Mg * (16 + 8 + 5) * 4.0
+                    f16["forward_chain"] = dict(leg(ms_c, nb_c), what="matpbr_mlp_chain_fwd (+ its image preparation): the whole network forward in one launch; writes "
+                                                "the four layers' sines once, reads none of them (layer by layer: 91 us first layer + three 256-wide layers)",
+                                                f16_matrix_pipe_frac=3 * 3 * flop / (ms_c * 1e-3) / 2.5e15)
+                del ph_c
+            except Exception as e:                                     # (a library without the round-5 entry points)
+                f16 = {"error": repr(e)}
+            tot_ms = (f16["forward_sin"]["avg_launch_ms"] + f16["bwd_input_mulcos_colsum"]["avg_launch_ms"] + f16["bwd_weight"]["avg_launch_ms"]) if "forward_sin" in f16 else None
+            gemm = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
+                    "achieved": (7 * B4 / (tot_ms * 1e-3) / 1e9) if tot_ms else 0.0,
+                    "kernel": "the three 256-wide products of a layer as the pos_mlp iteration runs them: mlp_nt_gx<sin, 3> / mlp_nt_gx<mul cos, 3> / mlp_wgrad_bx<3> "
+                              "([H*W,256]x[256,256], two f16 pieces per operand, three products, f32 accumulate; epilogues included), back to back",
+                    "two_piece_f16": f16,
+                    "three_piece_bf16": dict(bx, note=f"round 4's form ({P} bf16 products per f32 product): TFLOP/s in f32-equivalent terms (2 M N K per product); "
+                                                      f"its matrix-pipe share is {P} x that / 2500"),
+                    "exact_f32": f32k,
+                    "stand_alone_vs_in_loop": "these legs run each kernel 20 times back to back (the chip holds a lower clock under sustained matrix work than inside "
+                                              "the iteration, where the same launches are 5-15 % shorter: profiles/r05_pos_mlp_sequence.txt)",
                     "blas_product_same_shape": {"avg_launch_ms": ms_g, "achieved": tf(ms_g), "kernel": "hipBLASLt f32 (PyTorch-ROCm), no epilogue"}}
         else:
             gemm = {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "peak_note": "dense f32 MFMA peak (exact-f32 kernels)", "kernel": f32k["kernel"],
@@ -675,15 +777,22 @@ def main(argv=None):
                        "phase": type(phase).__name__ + (" (two groups of images on streams of their own: the same results as one phase, bit for bit)"
                                                         if type(phase).__name__ == "PipelinedBrdfPhase" else ""),
                        "mlp_products": int(_posmlp._PosMlpHipFn.PRODUCTS),
-                       "mlp_arithmetic": ("f32 results: each f32 operand of the 256-wide layers is the exact sum of three bf16 pieces; 6 of the 9 partial "
-                                          "products (the dropped ones are below 2^-24 relative) on v_mfma_f32_32x32x16_bf16 with f32 accumulation; error "
-                                          "against an fp64 product equals that of the exact-f32 MFMA kernels (tests/test_gpu_parity.py::"
-                                          "test_split_operand_sine_layers_match_fp64_and_the_f32_kernels); --mlp-products 0 runs the exact-f32 kernels"
+                       "mlp_arithmetic": ("f32 results.  Each f32 operand of a 256-wide product is carried as TWO round-to-nearest f16 pieces (a rounded piece leaves a "
+                                          "signed remainder: two pieces reach 2^-24 of the operand, where bf16 needs three) and three products p1 q1 + p1 q2 + p2 q1 are formed "
+                                          "on v_mfma_f32_32x32x16_f16 with f32 accumulation; the weights are cut as 256 w, the loss gradients of the backward products under "
+                                          "one power-of-two exponent per 128-row tile; the first layer (K = 15) on v_mfma_f32_32x32x2_f32.  Against fp64 the error of every "
+                                          "product is that of the exact-f32 MFMA kernels and of round 4's three-bf16-piece form (the f32 accumulation dominates all three): "
+                                          "tests/test_gpu_parity.py::test_two_piece_f16_forward_layers_are_f32_accurate, ::test_block_scaled_f16_backward_products, "
+                                          "::test_forward_chain_is_the_layer_by_layer_forward; modes.pos_mlp_bf16x3 and modes.pos_mlp_exact_f32 run the other two forms"
                                           if _posmlp._PosMlpHipFn.PRODUCTS else "exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32)")},
             "ranks": [{"rank": r, "it_per_s": args.steps * B / t} for r, t in enumerate(per_rank)],
             "modes": modes,
             "psnr_db": {"initial_guess": psnr0, "after_timed_steps": psnr1, "vs": "own HIP render of the synthetic ground truth (Mitsuba cannot run, SURVEY F3)"},
         }
+        if pinned is not None:
+            out["rank_core_pinning"] = pinned
+        if host_enqueue is not None:
+            out["host_enqueue"] = host_enqueue
         if roof is not None:
             roof["posmlp_gemm"], roof["relight"] = gemm, relight
             out["roofline"] = roof

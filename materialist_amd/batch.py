@@ -21,6 +21,10 @@ def init_distributed(backend: str | None = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        from .dist import pin_rank_cores
+
+        pin_rank_cores()                                               # the ranks of a node on disjoint core sets (dist.pin_rank_cores)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:

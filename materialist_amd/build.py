@@ -20,6 +20,17 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libmatpbr.so can only be built with the ROCm toolchain")
 
 
+def sources_digest() -> str:
+    """SHA-256 (16 hex digits) of every kernel source and header: what profiles/pmc_traffic.json is tied to (bench.py `roofline.traffic`)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.normpath(os.path.join(CSRC, name)), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

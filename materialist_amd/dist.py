@@ -3,7 +3,7 @@ GPU, no collective inside an optimisation iteration; one broadcast of the run co
 gather of per-image results at the end (RCCL when the backend is "nccl", gloo on CPU for tests)."""
 from __future__ import annotations
 
-from typing import Any, List, Tuple
+from typing import Optional, Any, List, Tuple
 
 import torch
 import torch.distributed as dist
@@ -82,3 +82,22 @@ def broadcast_state_dict(state_dict, device, src: int = 0):
             out[k] = flat[off:off + n].view(shape).to(td)
             off += n
     return {k: out[k] for k, _, _ in layout}
+
+
+def pin_rank_cores() -> Optional[dict]:
+    """One process per GPU: the ranks of a node take DISJOINT sets of host cores (LOCAL_RANK-th slice of the cores this process may
+    run on).  A rank's iterations are enqueued by one Python thread -- ~30 launches (pos_mlp) or 6 (none mode) per iteration -- and where that
+    takes about as long as the GPU needs for them (bench.py `host_enqueue`: the 8-image none-mode shard), two ranks sharing a core is what an
+    8-GPU run loses on, not the fabric.  Returns what was done (None: a single local rank, or no affinity API)."""
+    import os
+
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // local_world)
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+    os.sched_setaffinity(0, mine)
+    os.environ["OMP_NUM_THREADS"] = str(min(len(mine), int(os.environ.get("OMP_NUM_THREADS", "4"))))
+    return {"cores_of_this_rank": len(mine), "first": mine[0], "last": mine[-1], "local_world_size": local_world}

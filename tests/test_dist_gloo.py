@@ -189,3 +189,27 @@ def test_network_weights_leave_rank_0_once_as_a_flat_buffer(tmp_path):
         assert p.exitcode == 0
     want = {k: (tuple(v.shape), str(v.dtype), float(v.double().sum())) for k, v in sd.items()}
     assert res[0] == want and res[1] == want
+
+
+def test_ranks_of_a_node_take_disjoint_core_sets():
+    """`dist.pin_rank_cores` gives the LOCAL_RANK-th slice of the cores a process may run on; the slices of a node's ranks
+    are disjoint and cover no core twice (each rank's iterations are enqueued by one Python thread)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_all = len(os.sched_getaffinity(0))
+    if n_all < 2:
+        pytest.skip("one core")
+    seen = []
+    for lr in range(2):
+        env = dict(os.environ, LOCAL_WORLD_SIZE="2", LOCAL_RANK=str(lr), WORLD_SIZE="2", PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", "import os, json; from materialist_amd.dist import pin_rank_cores; r = pin_rank_cores(); "
+                              "print(json.dumps([r, sorted(os.sched_getaffinity(0))]))"], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-1000:]
+        info, cores = json.loads(out.stdout.strip().splitlines()[-1])
+        assert info["cores_of_this_rank"] == len(cores) == n_all // 2
+        seen.append(set(cores))
+    assert not (seen[0] & seen[1])

@@ -65,8 +65,10 @@ def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
         assert getattr(ops, m) == c[m], m
     # one word carries flags AND part bits (MatpbrBrdfPhase.flags beside part_mask; the `flags` argument of the brdf_loss_* entry points):
     # every value a single bit, all of them distinct
-    bits = [c[m] for m in macros] + [c["PART_A"], c["PART_R"], c["PART_M"], c["PART_N"]]
-    assert all(v and not (v & (v - 1)) for v in bits) and len(set(bits)) == len(bits), bits
+    # (ATTACHED_SAMPLING = 2 = PART_A on purpose never meet: the first is a flag of matpbr_shade_bwd / MatpbrBrdfPhase.flags, whose part bits
+    # travel in `part_mask`; the brdf_loss_* entry points OR the part bits with JAC16 only)
+    for word in ([c[m] for m in macros if m != "FLAG_JAC16"], [c["PART_A"], c["PART_R"], c["PART_M"], c["PART_N"], c["FLAG_JAC16"]]):
+        assert all(v and not (v & (v - 1)) for v in word) and len(set(word)) == len(word), word
     assert ops.PART_N == c["PART_N"] and ops.part_mask("armn") == c["PART_A"] | c["PART_R"] | c["PART_M"] | c["PART_N"]
     assert c["STATS_STRIDE"] == 16 and ops.STAT_GT_SUM == 15
     from materialist_amd.loop import FusedBrdfPhase

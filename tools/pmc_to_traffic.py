@@ -30,17 +30,23 @@ def bytes_of(tag, kernel, rnd="r03"):
 
 tj_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+sys.path.insert(0, ROOT)
+from materialist_amd.build import sources_digest  # noqa: E402
+
+# the kernels these bytes were counted on: bench.py reports `traffic` only while csrc/ still hashes to this
+tj["csrc_sha16"] = sources_digest()
 # round 4: the folded, persistent step (lazy_pstep_kernel), the walk launch behind it, the statistics pass
+RND = os.environ.get("PMC_ROUND", "r05")
 for tag, b in (("b8", 8), ("b1", 1)):
     for name, kern in (("lazy_pstep", "matpbr::lazy_pstep_kernel"), ("lazy_pwalk", "matpbr::lazy_pwalk_kernel"), ("loss_sums2_r04", "loss_sums2_kernel<")):
-        v = bytes_of(tag, kern, "r04")
+        v = bytes_of(tag, kern, RND)
         if v is not None:
             tj[f"{name}_512x512_b{b}_spp64"] = v
-if os.path.exists(os.path.join(d, "r04_pmc_b8_FETCH_SIZE.csv")):
-    tj["source_r04"] = ("profiles/r04_pmc_{b1,b8}_{FETCH_SIZE,WRITE_SIZE}.csv (rocprofv3 --kernel-trace --pmc, separate passes, tools/pmc_passes_r04.sh); "
+if os.path.exists(os.path.join(d, f"{RND}_pmc_b8_FETCH_SIZE.csv")):
+    tj["source_r04"] = (f"profiles/{RND}_pmc_{{b1,b8}}_{{FETCH_SIZE,WRITE_SIZE}}.csv (rocprofv3 --kernel-trace --pmc, separate passes, tools/pmc_passes_{RND}.sh); "
                         "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB), the gfx950 correction of MI355X_MICROARCH.md as calibrated in round 2")
-sq4 = counters(os.path.join(d, "r04_pmc_b8_sq.csv"), "matpbr::lazy_pstep_kernel")
-gr4 = counters(os.path.join(d, "r04_pmc_b8_grbm.csv"), "matpbr::lazy_pstep_kernel")
+sq4 = counters(os.path.join(d, f"{RND}_pmc_b8_sq.csv"), "matpbr::lazy_pstep_kernel")
+gr4 = counters(os.path.join(d, f"{RND}_pmc_b8_grbm.csv"), "matpbr::lazy_pstep_kernel")
 if "SQ_ACTIVE_INST_VALU" in sq4 and "GRBM_GUI_ACTIVE" in gr4:
     tj["lazy_pstep_valu_active_frac"] = sq4["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * gr4["GRBM_GUI_ACTIVE"] / 8.0)
 for tag, b in (("b8", 8), ("b1", 1)):
