@@ -14,9 +14,8 @@
  *     theta = acos(y), phi = atan2(x,-z) (myutils/envmap_utils.py:29-36).
  *   - `stream` is the caller's hipStream_t (NULL = default stream).  Entry points only enqueue work:
  *     no allocation, no synchronisation, no global mutable state -> usable under hipGraph capture
- *     and re-entrant per stream.  The ONE exception is declared as such: matpbr_mlp_set_lds_dma, a process-wide
- *     measurement switch between three main loops of the 256-wide layer kernels that produce the same bits (two
- *     relaxed atomics read at launch time; no result depends on it, nothing else in the library is global).
+ *     and re-entrant per stream.  (The ONE process-wide switch the library has is a measurement aid and lives in
+ *     matpbr_experimental.h: matpbr_mlp_set_lds_dma, between main loops of the bf16 layer kernels that produce the same bits.)
  *   - Return value: 0 = MATPBR_OK, negative = error (matpbr_strerror); nothing throws.
  *   - `spp` (even, 2..MATPBR_MAX_SPP) is the reference's samples-per-pixel argument
  *     (inverse_img_w_mi.py:59,69,625): here it sizes the deterministic quadrature rules of the two BRDF lobes
@@ -305,11 +304,6 @@ int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* phase, int t_done, void* st
 #define MATPBR_STAGE_RESAMPLE 8u /* pred_next mode: the pixels the backward launch listed (their roughness left their model's interval) are re-sampled,
                                     their models rebuilt and their render written (nothing to launch in the other modes) */
 int matpbr_brdf_phase_stages(const MatpbrBrdfPhase* phase, int t, float lr, uint32_t stages, void* stream);
-/* Measurement only (bench.py's `roofline`): matpbr_brdf_phase_stages whose folded step launch (MATPBR_STAGE_BACKWARD of a phase with `lazy_fold`)
- * records the kernel's own begin and end into two caller-owned hipEvent_t created with timing enabled (hipExtLaunchKernelGGL) -- events recorded
- * around a launch include the stream's dispatch latency on both sides, 2-5 us on a 50 us kernel.  MATPBR_ERR_UNSUPPORTED for other phases. */
-int matpbr_brdf_phase_stages_timed(const MatpbrBrdfPhase* phase, int t, float lr, uint32_t stages, void* start_event, void* stop_event,
-                                   void* stream);
 
 /* One evaluation of hot loop A (inverse_img_w_mi.py:238-250) for a candidate light.  Materials and normals are fixed during the
  * phase (:216-220) and the render is linear in the light, so the phase works on the radiance transfer T of
@@ -558,16 +552,6 @@ int matpbr_mlp_arm_head_fwd(const float* x, int ldx, const float* w, int ldw, co
                             float* map_a, float* map_r, float* map_m, long M, int K, void* stream);
 int matpbr_mlp_arm_head_bwd(const float* g_a, const float* g_r, const float* g_m, const float* th, float* d_x, long M, void* stream);
 size_t matpbr_mlp_skinny_workspace_bytes(int J);
-/* The main loop of the split-operand layer kernels (matpbr_mlp_layer_fwd_bx[_tail|_head], matpbr_mlp_layer_bwd_input_bx[_sgn],
- * matpbr_mlp_first_layer_bwd_bx) with 256 output columns and a reduction that is a multiple of 32:
- *   2 (default)  operands by LDS-DMA (global_load_lds_dwordx4), two 256-thread workgroups per CU with 64 x 128 wave tiles
- *                (mlp_nt_gx; the first-layer form and the head form with stored cosines run as mode 1)
- *   1            operands by LDS-DMA, one 512-thread workgroup per CU (mlp_nt_bx<.., GL>)
- *   0            register-staged operands (mlp_nt_bx)
- *   3            as 2 with the first-layer form on mlp_nt_gx as well (23 spilled registers; measured +0.2 %: not the default)
- * The three form the same products in the same order: outputs are the same bits (the bias-gradient column sums are grouped per
- * workgroup and agree to rounding).  A measurement switch, process-wide; returns the previous setting. */
-int matpbr_mlp_set_lds_dma(int mode);
 /* The backward pass of the 'arm' network's OUTPUT layer (mymodels/mlps.py:233-236 under autograd) in one pass over the sines of the last
  * sine layer, given d_x[M, ldd >= 8] = dL/d(output pre-activations) (J <= 5 valid columns, matpbr_mlp_arm_head_bwd):
  *   d_w[j * ld_j + c * ld_c] = sum_m d_x[m][j] s_prev[m][c],  d_bias[j] = sum_m d_x[m][j]                  (the layer's own gradients)

@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "../../include/matpbr.h"
+#include "../../include/matpbr_experimental.h"
 #include "matpbr_device.hpp"
 #include "matpbr_shade.hpp"
 #include "matpbr_lazy.hpp"

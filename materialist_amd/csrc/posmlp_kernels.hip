@@ -46,6 +46,7 @@
 #include <type_traits>
 
 #include "../../include/matpbr.h"
+#include "../../include/matpbr_experimental.h"
 #include "posmlp_device.hpp"
 
 namespace {
