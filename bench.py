@@ -551,18 +551,21 @@ def main(argv=None):
             ph = loop.FusedBrdfPhase(w.scene, w.gt_image, *w.init, optimize_part="rm", spp=args.spp, keep_grads=True)
             ph.run(400)
             p_at = [ph.p[k].clone() for k in ("albedo", "roughness", "metallic")]
+            pred_at = ph.pred.clone()                                   # the lazy loop's own render of these parameters
             ph.step()
             exact, jac_e = torch.empty_like(w.gt_image), ops.plane9(w.gt_image)
             g_ref = {k: torch.empty_like(v) for k, v in ph.g.items()}
             ops.shade_fwd(*p_at, ph.n, ph.light, args.spp, clamp_params=True, out=exact, dcache=ph.dcache, jac=jac_e)
-            ops.brdf_loss_bwd_jac(*p_at, jac_e, exact, ph.gt_srgb, ph.stats, ph.orig["albedo"], ph.orig["roughness"], ph.orig["metallic"], 0.1,
-                                  g_ref["albedo"], g_ref["roughness"], g_ref["metallic"], optimize_part="rm")
             res = {}
-            for k in ("roughness", "metallic"):
-                e = ((ph.g[k] - g_ref[k]).abs() / torch.maximum(g_ref[k].abs(), g_ref[k].abs().mean())).reshape(-1)
-                res[k] = {"rel_l2": float((ph.g[k] - g_ref[k]).norm() / g_ref[k].norm()), "worst_pixel": float(e.max()),
-                          "p999_pixel": float(torch.quantile(e[:: max(1, e.numel() // 2_000_000)].float(), 0.999)), "median_pixel": float(e.median()),
-                          "cosine": float((ph.g[k] * g_ref[k]).sum() / (ph.g[k].norm() * g_ref[k].norm()))}
+            for tag, pred_for_loss in (("derivatives_of_the_models", pred_at), ("whole_loss_gradient", exact)):
+                ops.brdf_loss_bwd_jac(*p_at, jac_e, pred_for_loss, ph.gt_srgb, ph.stats, ph.orig["albedo"], ph.orig["roughness"], ph.orig["metallic"], 0.1,
+                                      g_ref["albedo"], g_ref["roughness"], g_ref["metallic"], optimize_part="rm")
+                res[tag] = {}
+                for k in ("roughness", "metallic"):
+                    e = ((ph.g[k] - g_ref[k]).abs() / torch.maximum(g_ref[k].abs(), g_ref[k].abs().mean())).reshape(-1)
+                    res[tag][k] = {"rel_l2": float((ph.g[k] - g_ref[k]).norm() / g_ref[k].norm()), "worst_pixel": float(e.max()),
+                                   "p999_pixel": float(torch.quantile(e[:: max(1, e.numel() // 2_000_000)].float(), 0.999)), "median_pixel": float(e.median()),
+                                   "cosine": float((ph.g[k] * g_ref[k]).sum() / (ph.g[k].norm() * g_ref[k].norm()))}
             return res
 
         wr = wl8 if wl8 is not None else wl
@@ -596,8 +599,11 @@ def main(argv=None):
                 "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
                 "resampled_fraction": resampled, "stats_launches_ms": t_stats, "resample_launch_ms": t_res,
                 "gradient_error_of_this_kernel": dict(lazy_gradient_error(wr), note="d loss / d roughness, d loss / d metallic at iteration 401 of the part, every pixel, "
-                                                      "against the backward pass on exact sampling of the same parameters (pixel errors relative to max(|g|, mean|g|)); "
-                                                      "the RENDER of the same kernel is within 1e-3 of exact sampling on every pixel (tests/test_gpu_lazy.py)"),
+                                                      "against the backward pass on exact sampling of the same parameters (pixel errors relative to max(|g|, mean|g|)).  "
+                                                      "derivatives_of_the_models: d loss / d pred formed on the lazy loop's own render for both sides -- the error of d out / d r "
+                                                      "(first order in r - r_ref since round 5) and d out / d m alone; whole_loss_gradient: on the exact render -- adds the pixels "
+                                                      "whose sign(pred - gt) of the L1 term differs between two renders that agree to 1e-3 (converged pixels; grows as the part "
+                                                      "converges).  The RENDER of the same kernel is within 1e-3 of exact sampling on every pixel (tests/test_gpu_lazy.py)"),
                 "traffic": traffic, "traffic_source": pmc.get("source_r04") if traffic else pmc.get("stale"),
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "

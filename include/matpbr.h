@@ -154,7 +154,7 @@ int matpbr_lazy_sums_count(int H, int W);
 int matpbr_shade_fwd_lazy(const float* a, const float* r, const float* m, const float* n, const float* light, int light_kind, int n_light,
                           const float* dcache, void* lazy_state, float* out_rgb, void* jac16, const float* stats, float* sums, int H, int W,
                           int batch, int spp, const MatpbrCamera* cam, uint32_t flags, float floor, float tol, void* stream);
-int matpbr_lazy_state_unpack(const void* lazy_state, float* state22, int* refreshed, int H, int W, int batch, void* stream);
+int matpbr_lazy_state_unpack(const void* lazy_state, float* state28, int* refreshed, int H, int W, int batch, void* stream);
 int matpbr_jac16_unpack(const void* jac16, float* jac, int H, int W, int batch, void* stream);
 
 /* Backward render.  Replaces the AD pass that `loss.backward()` drives through dr.wrap_ad / mi.render

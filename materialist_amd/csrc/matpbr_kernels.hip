@@ -1343,14 +1343,14 @@ int matpbr_shade_fwd_lazy(const float* a, const float* r, const float* m, const 
                         (flags & MATPBR_FLAG_LAZY_FORCE) ? 1 : 0, floor_, tol, (hipStream_t)stream, (flags & MATPBR_FLAG_JAC32) ? 1 : 0);
 }
 
-int matpbr_lazy_state_unpack(const void* lazy_state, float* state22, int* refreshed, int H, int W, int batch, void* stream) {
-    if (!lazy_state || (!state22 && !refreshed) || H <= 0 || W <= 0 || batch <= 0) return MATPBR_ERR_INVALID_ARG;
+int matpbr_lazy_state_unpack(const void* lazy_state, float* state28, int* refreshed, int H, int W, int batch, void* stream) {
+    if (!lazy_state || (!state28 && !refreshed) || H <= 0 || W <= 0 || batch <= 0) return MATPBR_ERR_INVALID_ARG;
     const long P = (long)H * W, BP = P * batch;
     const uint32_t* counts = (const uint32_t*)((const char*)lazy_state + lazy_planes_bytes(P, batch));
     const uint16_t* lists = (const uint16_t*)((const char*)counts + lazy_counts_bytes(P, batch));
-    if (state22)
+    if (state28)
         hipLaunchKernelGGL(lazy_unpack_kernel, dim3((unsigned)((BP + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                           (const uint32_t*)lazy_state, state22, BP);
+                           (const uint32_t*)lazy_state, state28, BP);
     if (refreshed)
         hipLaunchKernelGGL(lazy_refreshed_kernel, dim3((unsigned)lazy_fwd_blocks(P), (unsigned)batch), dim3(kBlock), 0, (hipStream_t)stream, counts, lists,
                            refreshed, (int)P, lazy_fwd_blocks(P));

@@ -3,8 +3,9 @@
 // In the parts of --opt_order that move the roughness (inverse_img_w_mi.py:371-386 / 493-515) light and shading normals are fixed
 // (:317-342), so the specular sums S0, S1 of a pixel are functions of its roughness alone -- and Adam moves r by 1e-4 .. 3e-4 per
 // step.  Each pixel keeps a LOCAL MODEL around the roughness r_ref its 20 samples were last walked at:
-//     P, SD = S0 - S1, S1 at r_ref (fp32);  their slopes P', gSD, gS1 and A2 (P is a quadratic in r), and the detached r-derivatives
-//     dSD, dS1 of the backward convention (fp16: they only multiply dr = r - r_ref <= 0.03);  a validity interval [r_ref - lo, r_ref + hi].
+//     P, SD = S0 - S1, S1 at r_ref (fp32);  their slopes P', gSD, gS1 and A2 (P is a quadratic in r), the detached r-derivatives
+//     dSD, dS1 of the backward convention AND THEIR slopes eSD, eS1 (the same one-sided difference: the samples at r + h are walked anyway),
+//     so that d out / d r is first order in dr = r - r_ref like the render (fp16);  a validity interval [r_ref - lo, r_ref + hi].
 // lazy_fwd_kernel renders out = a (1-m) P(r) + C0 SD(r) + S1(r) from the model -- a streaming kernel -- writes the half-precision
 // jac planes of the backward pass, and lists the pixels that have left their interval; lazy_refresh_kernel walks the samples of the
 // listed pixels only (1-2 % of the image per iteration on recorded runs), rebuilds their models and patches their render.
@@ -22,7 +23,8 @@ constexpr float kLzKinkSafety = 0.8f, kLzMoved = 1e-4f;
 
 // ---- state: 32-bit planes of B*P entries (a lane's two pixels are an 8-byte access, a wave's access is 512 contiguous bytes) ----
 enum { kLzRref = 0, kLzLoHi = 1 /* half2 (lo, hi) */, kLzRho = 2, kLzP = 3, kLzSD = 6, kLzS1 = 9,
-       kLzPk = 12 /* half2 (P', A2) */, kLzSk = 15 /* half2 (gSD, gS1) */, kLzDk = 18 /* half2 (dSD, dS1) */, kLzPlanes = 21 };
+       kLzPk = 12 /* half2 (P', A2) */, kLzSk = 15 /* half2 (gSD, gS1) */, kLzDk = 18 /* half2 (dSD, dS1) */,
+       kLzEk = 21 /* half2 (eSD, eS1): the slopes of dSD, dS1 in r (round 5: d out / d r to first order in r - r_ref) */, kLzPlanes = 24 };
 // jac16: 5 planes, half2 (P_c, SD_c) for c = 0..2, half2 (JR_0, JR_1), half2 (JR_2, 0)
 constexpr int kJac16Planes = 5;
 constexpr int kLazyBlockPixels = 2 * kBlock;
@@ -42,17 +44,33 @@ __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(ui
 //       X_c(dr) = X0 + X1 dr + X2 dr^2,  Y_c(dr) = Y0 + Y1 dr - X2 dr^2  (X2 = a_c A2_c: P is an exact quadratic in r),
 //       d out_c / d m = Y_c(dr);  d out_c / d r = JX_c + m JY_c with JX = JX0 + 2 X2 dr, JY = JY0 - 2 X2 dr: the stop-gradient convention
 //       (JX0 = a dP + 0.04 dSD + dS1, JY0 = (a - 0.04) dSD - a dP); with attached sampling the models' slopes X1, Y1 take their place.
-//       16 planes = 64 B/pixel (the generic model: 80 B/pixel + the 12 B/pixel of the albedo it is combined with).
+//       17 planes = 68 B/pixel (the generic model: 92 B/pixel + the 12 B/pixel of the albedo it is combined with).
 //   kFoldGH (part 'a': roughness and metallic are constants of the part)   out_c = a_c G_c + H_c,   d out_c / d a_c = G_c,
 //       G_c = (1 - m) P_c(dr) + m SD_c(dr),   H_c = 0.04 (1 - m) SD_c(dr) + S1_c(dr):  6 planes = 24 B/pixel, never re-sampled.
 // The generic planes stay the specification (oracle/matpbr_oracle.c); the folded ones are derived from them by lazy_fold_kernel at the
 // start of a part and rewritten together with them for every re-sampled pixel.
 enum { kFoldNone = 0, kFoldXY = 1, kFoldGH = 2 };
 enum { kFxRref = 0, kFxLoHi = 1, kFxX0 = 2 /* X0_c at 2 + 2c, Y0_c at 3 + 2c */, kFxS = 8 /* half2 (X1_c, Y1_c) */, kFxJ = 11 /* half2 (JX0_c, JY0_c) */,
-       kFxQ = 14 /* half2 (X2_0, X2_1), half2 (X2_2, 0) */, kFxPlanes = 16 };
+       kFxQ = 14 /* half2 (X2_0, X2_1); half (X2_2) | two bf8 (JX1_0, JY1_0) */, kFxE = 16 /* four bf8: JX1_1, JY1_1, JX1_2, JY1_2 */, kFxPlanes = 17 };
+// JX1, JY1: the slopes of the folded detached derivative (JX = JX0 + (2 X2 + JX1) dr, JY = JY0 + (JY1 - 2 X2) dr).  They multiply dr <= 0.03 and
+// correct d out / d r by a few per cent: eight bits (e5m2) carry them -- the six of them are 6 of the 8 spare bytes of one more plane + kFxQ's spare half
 enum { kFgG = 0, kFgH = 3, kFgPlanes = 6 };
-struct FoldXY { float X0, Y0, X1, Y1, JX0, JY0, X2; };
-__device__ __forceinline__ void fold_xy(float a, float P, float SD, float S1, float dP, float A2, float gSD, float gS1, float dSD, float dS1, FoldXY& f) {
+// The slopes eSD, eS1 of the detached derivatives come from a one-sided difference over kLzH; a sample that crosses the horizon inside that
+// stencil makes the difference a jump / h, not a slope.  Whatever they are, they may correct the derivative by at most half its size
+// at the far end of the pixel's interval (|e| <= 0.5 (|dSD| + |dS1|) / max(lo, hi)): the specification's LAZY_E_CAP.
+__device__ __forceinline__ float lazy_e_cap(float e, float dSD, float dS1, float lo, float hi) {
+    const float lim = 0.5f * (fabsf(dSD) + fabsf(dS1)) / fmaxf(fmaxf(lo, hi), 1e-4f);
+    return fminf(fmaxf(e, -lim), lim);
+}
+struct FoldXY { float X0, Y0, X1, Y1, JX0, JY0, X2, JX1, JY1; };
+template <bool UPPER>
+__device__ __forceinline__ uint32_t pack_bf8x2(float lo, float hi, uint32_t old) {     // two e5m2 bytes into a half of `old` (magnitudes clamped: no infinities)
+    const float c = 49152.0f;
+    return (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(lo, -c), c), fminf(fmaxf(hi, -c), c), (int)old, UPPER);
+}
+template <int BYTE> __device__ __forceinline__ float bf8_at(uint32_t w) { return __builtin_amdgcn_cvt_f32_bf8((int)w, BYTE); }
+__device__ __forceinline__ void fold_xy(float a, float P, float SD, float S1, float dP, float A2, float gSD, float gS1, float dSD, float dS1, float eSD, float eS1,
+                                        FoldXY& f) {
     const float am = a - 0.04f, naP = -(a * P), nadP = -(a * dP);
     f.X0 = fmaf(a, P, fmaf(0.04f, SD, S1));
     f.Y0 = fmaf(am, SD, naP);
@@ -61,6 +79,8 @@ __device__ __forceinline__ void fold_xy(float a, float P, float SD, float S1, fl
     f.JX0 = fmaf(a, dP, fmaf(0.04f, dSD, dS1));
     f.JY0 = fmaf(am, dSD, nadP);
     f.X2 = a * A2;
+    f.JX1 = fmaf(0.04f, eSD, eS1);
+    f.JY1 = am * eSD;
 }
 constexpr int kTile = kBlock;          // pixels of a tile of lazy_pstep_kernel: one per thread
 constexpr int kMaxTilesPerWg = 8;      // tiles a workgroup of lazy_pstep_kernel streams at most (its LDS lists are sized for them)
@@ -145,6 +165,7 @@ __global__ __launch_bounds__(kBlock) void lazy_fwd_kernel(const LazyFwdArgs q, i
             const uint32_t pk0 = S[(kLzPk + c) * BP + i0], pk1 = S[(kLzPk + c) * BP + i1];
             const uint32_t sk0 = S[(kLzSk + c) * BP + i0], sk1 = S[(kLzSk + c) * BP + i1];
             const uint32_t dk0 = S[(kLzDk + c) * BP + i0], dk1 = S[(kLzDk + c) * BP + i1];
+            const uint32_t ek0 = S[(kLzEk + c) * BP + i0], ek1 = S[(kLzEk + c) * BP + i1];
             const f2 dP0 = f2{h2_lo(pk0), h2_lo(pk1)}, A2 = f2{h2_hi(pk0), h2_hi(pk1)};
             const f2 Pc = vfma(vfma(A2, dr, dP0), dr, Pv);                        // P(r) = P + P' dr + A2 dr^2 (exact quadratic)
             const f2 dP = vfma(2.0f * A2, dr, dP0);
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void lazy_fwd_kernel(const LazyFwdArgs q, i
             const f2 S1 = vfma(f2{h2_hi(sk0), h2_hi(sk1)}, dr, S1v);
             const f2 C0 = vfma(m, a[c], omm * 0.04f);                                // :1412
             const f2 rgb = vfma(a[c] * omm, Pc, vfma(C0, SD, S1));
-            JR[c] = vfma(a[c] * omm, dP, vfma(C0, f2{h2_lo(dk0), h2_lo(dk1)}, f2{h2_hi(dk0), h2_hi(dk1)}));
+            JR[c] = vfma(a[c] * omm, dP, vfma(C0, vfma(f2{h2_lo(ek0), h2_lo(ek1)}, dr, f2{h2_lo(dk0), h2_lo(dk1)}), vfma(f2{h2_hi(ek0), h2_hi(ek1)}, dr, f2{h2_hi(dk0), h2_hi(dk1)})));
             if (act0 && !need0) { q.out[i0 * 3 + c] = rgb.x; tot += rgb.x; }
             if (two && !need1) { q.out[i1 * 3 + c] = rgb.y; tot += rgb.y; }
             if (q.jac32) {
@@ -282,7 +303,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 struct LazyRecord { float a[3], r, m, dr; };
 constexpr int kResampleWaves = 256;    // waves (64-thread workgroups) of lazy_resample_kernel per image at most, eight listed pixels each per pass
 constexpr int kRecStride = 7;         // floats per record: pixel, a (clamped, updated), r, m, r - r_ref (odd stride: conflict-free)
-constexpr int kWalkVals = 20;         // per-sample contributions: S0, S1, dS0, dS1 at r (12), S0, S1 at r + dir h (6), interval lo / hi
+constexpr int kWalkVals = 26;         // per-sample contributions: S0, S1, dS0, dS1 at r (12), S0, S1 at r + dir h (6), interval lo / hi
 
 // Loads / stores at (wave-uniform base pointer) + (32-bit per-lane byte offset): the form the hardware addresses directly
 // (global_load ... v_off, s[base]); indexing 21 planes through 64-bit per-lane arithmetic costs more VALU issue slots than the
@@ -310,18 +331,21 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const St
     const float rref = as_f(ldu(qs.plane[kLzRref], o1));
     const uint32_t lohi = ldu(qs.plane[kLzLoHi], o1);
     float Pv[3], SDv[3], S1v[3];
-    uint32_t pk[3], sk[3], dk[3];
-    // a part that leaves the roughness alone never moves away from r_ref: the nine planes of slopes (36 of the 80 B/pixel of a model)
+    uint32_t pk[3], sk[3], dk[3], ek[3];
+    // a part that leaves the roughness alone never moves away from r_ref: the twelve planes of slopes (48 of the 92 B/pixel of a model)
     // multiply r - r_ref = 0 and are not read (uniform branch)
     const bool slopes = (q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         Pv[c] = as_f(ldu(qs.plane[kLzP + c], o1)); SDv[c] = as_f(ldu(qs.plane[kLzSD + c], o1)); S1v[c] = as_f(ldu(qs.plane[kLzS1 + c], o1));
-        pk[c] = sk[c] = dk[c] = 0u;
+        pk[c] = sk[c] = dk[c] = ek[c] = 0u;
     }
     if (slopes) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { pk[c] = ldu(qs.plane[kLzPk + c], o1); sk[c] = ldu(qs.plane[kLzSk + c], o1); dk[c] = ldu(qs.plane[kLzDk + c], o1); }
+        for (int c = 0; c < 3; ++c) {
+            pk[c] = ldu(qs.plane[kLzPk + c], o1); sk[c] = ldu(qs.plane[kLzSk + c], o1); dk[c] = ldu(qs.plane[kLzDk + c], o1);
+            if (!qs.attached) ek[c] = ldu(qs.plane[kLzEk + c], o1);
+        }
     }
     float a[3];
     const float r = fminf(fmaxf(rr, 0.07f), 1.0f), m = fminf(fmaxf(rm, 0.0f), 1.0f);
@@ -348,7 +372,8 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const St
         xs_keep[c] = xs;
         // d out / d r: the stop-gradient convention (dSD, dS1) by default; with `attached` the derivative of the rendered value through
         // the sample directions, which is what the models' slopes are (the live reference's convention, mi_plugin.py:227-230,1335-1341)
-        const float JR = fmaf(a[c] * omm, dPc, qs.attached ? fmaf(C0, h2_lo(sk[c]), h2_hi(sk[c])) : fmaf(C0, h2_lo(dk[c]), h2_hi(dk[c])));
+        const float JR = fmaf(a[c] * omm, dPc, qs.attached ? fmaf(C0, h2_lo(sk[c]), h2_hi(sk[c]))
+                                                            : fmaf(C0, fmaf(h2_lo(ek[c]), dr, h2_lo(dk[c])), fmaf(h2_hi(ek[c]), dr, h2_hi(dk[c]))));
         da[c] = go * fmaf(m, SD, omm * Pc);
         dm = fmaf(go, fmaf(a[c] - 0.04f, SD, -(a[c] * Pc)), dm);
         drr = fmaf(go, JR, drr);
@@ -700,10 +725,12 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
     for (int c = 0; c < 3; ++c) {   // the sums at r + dir h, from the lanes four further up
         fv[12 + c] = __shfl_down(fv[c], 4);
         fv[15 + c] = __shfl_down(fv[3 + c], 4);
+        fv[20 + c] = __shfl_down(fv[6 + c], 4);      // dS0, dS1 at r + dir h: the slopes of the detached derivatives
+        fv[23 + c] = __shfl_down(fv[9 + c], 4);
     }
     if (item_ok && sub == 0) {
         const float ih = dir * (1.0f / kLzH);
-        float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3], x2h[3] = {0.0f, 0.0f, 0.0f};
+        float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3], eSD[3], eS1[3], x2h[3] = {0.0f, 0.0f, 0.0f}, jx1[3] = {0.0f, 0.0f, 0.0f}, jy1[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             vSD[c] = fv[c] - fv[3 + c];
@@ -712,6 +739,8 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             gS1[c] = (fv[15 + c] - fv[3 + c]) * ih;
             dSD[c] = fv[6 + c] - fv[9 + c];
             dS1v[c] = fv[9 + c];
+            eSD[c] = ((fv[20 + c] - fv[23 + c]) - dSD[c]) * ih;
+            eS1[c] = (fv[23 + c] - fv[9 + c]) * ih;
         }
         float rho = rho_old;
         if (fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
@@ -722,6 +751,12 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             rho = fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
         }
         rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float es = lazy_e_cap(eSD[c], dSD[c], dS1v[c], fminf(fv[18], rho), fminf(fv[19], rho));
+            eS1[c] = lazy_e_cap(eS1[c], dSD[c], dS1v[c], fminf(fv[18], rho), fminf(fv[19], rho));
+            eSD[c] = es;
+        }
         *(uint32_t*)((char*)qs.plane[kLzRref] + o1) = as_u(rc_r);
         *(uint32_t*)((char*)qs.plane[kLzLoHi] + o1) = pack_h2(0.998f * fminf(fv[18], rho), 0.998f * fminf(fv[19], rho));
         *(uint32_t*)((char*)qs.plane[kLzRho] + o1) = as_u(rho);
@@ -733,11 +768,12 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             *(uint32_t*)((char*)qs.plane[kLzPk + c] + o1) = pack_h2(dP[c], A2[c]);
             *(uint32_t*)((char*)qs.plane[kLzSk + c] + o1) = pack_h2(gSD[c], gS1[c]);
             *(uint32_t*)((char*)qs.plane[kLzDk + c] + o1) = pack_h2(dSD[c], dS1v[c]);
+            *(uint32_t*)((char*)qs.plane[kLzEk + c] + o1) = pack_h2(eSD[c], eS1[c]);
             float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
             if (FOLD) {      // the folded planes of lazy_pstep_kernel<kFoldXY> (fold_xy_*: one definition for the fold kernel and this one)
                 FoldXY f;
-                fold_xy(rc[1 + c], Pc[c], vSD[c], vS1[c], dP[c], A2[c], gSD[c], gS1[c], dSD[c], dS1v[c], f);
-                x2h[c] = f.X2;
+                fold_xy(rc[1 + c], Pc[c], vSD[c], vS1[c], dP[c], A2[c], gSD[c], gS1[c], dSD[c], dS1v[c], eSD[c], eS1[c], f);
+                x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1;
                 *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c] + o1) = as_u(f.X0);
                 *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c + 1] + o1) = as_u(f.Y0);
                 *(uint32_t*)((char*)qs.fplane[kFxS + c] + o1) = pack_h2(f.X1, f.Y1);
@@ -751,7 +787,8 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             *(uint32_t*)((char*)qs.fplane[kFxRref] + o1) = as_u(rc_r);
             *(uint32_t*)((char*)qs.fplane[kFxLoHi] + o1) = pack_h2(0.998f * fminf(fv[18], rho), 0.998f * fminf(fv[19], rho));
             *(uint32_t*)((char*)qs.fplane[kFxQ] + o1) = pack_h2(x2h[0], x2h[1]);
-            *(uint32_t*)((char*)qs.fplane[kFxQ + 1] + o1) = pack_h2(x2h[2], 0.0f);
+            *(uint32_t*)((char*)qs.fplane[kFxQ + 1] + o1) = pack_bf8x2<true>(jx1[0], jy1[0], pack_h2(x2h[2], 0.0f));
+            *(uint32_t*)((char*)qs.fplane[kFxE] + o1) = pack_bf8x2<true>(jx1[2], jy1[2], pack_bf8x2<false>(jx1[1], jy1[1], 0u));
         }
     }
 }
@@ -1034,19 +1071,22 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
             }
             klo = lane_group_min<LPI>(klo);
             khi = lane_group_min<LPI>(khi);
-            float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3];
+            float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3], eSD[3], eS1[3];
             const float ih = dir * (1.0f / kLzH);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float s0x = lane_group_sum<LPI>(S0[c].x), s0y = lane_group_sum<LPI>(S0[c].y);
                 const float s1x = lane_group_sum<LPI>(S1[c].x), s1y = lane_group_sum<LPI>(S1[c].y);
                 const float d0 = lane_group_sum<LPI>(dS0[c].x), d1 = lane_group_sum<LPI>(dS1[c].x);
+                const float d0y = lane_group_sum<LPI>(dS0[c].y), d1y = lane_group_sum<LPI>(dS1[c].y);
                 vSD[c] = s0x - s1x;
                 vS1[c] = s1x;
                 gSD[c] = ((s0y - s1y) - vSD[c]) * ih;
                 gS1[c] = (s1y - s1x) * ih;
                 dSD[c] = d0 - d1;
                 dS1v[c] = d1;
+                eSD[c] = ((d0y - d1y) - dSD[c]) * ih;
+                eS1[c] = (d1y - d1) * ih;
             }
             if (active && sub == 0) {
                 if (has_old && fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
@@ -1057,6 +1097,12 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     rho = fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
                 }
                 rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float es = lazy_e_cap(eSD[c], dSD[c], dS1v[c], fminf(klo, rho), fminf(khi, rho));
+                    eS1[c] = lazy_e_cap(eS1[c], dSD[c], dS1v[c], fminf(klo, rho), fminf(khi, rho));
+                    eSD[c] = es;
+                }
                 uint32_t* S = q.state;
                 S[kLzRref * BP + i] = as_u(rc);
                 S[kLzLoHi * BP + i] = pack_h2(0.998f * fminf(klo, rho), 0.998f * fminf(khi, rho));   // fp16 rounding must not widen the interval
@@ -1070,6 +1116,7 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     S[(kLzPk + c) * BP + i] = pack_h2(dP[c], A2[c]);
                     S[(kLzSk + c) * BP + i] = pack_h2(gSD[c], gS1[c]);
                     S[(kLzDk + c) * BP + i] = pack_h2(dSD[c], dS1v[c]);
+                    S[(kLzEk + c) * BP + i] = pack_h2(eSD[c], eS1[c]);
                     const float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
                     q.out[i * 3 + c] = rgb;
                     tot += rgb;
@@ -1093,17 +1140,18 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
 }
 
 // ---- test / inspection helpers -------------------------------------------------------------------
-// state -> the oracle's layout [B*P][22]: r_ref, lo, hi, rho, SD, S1, gSD, gS1, dSD, dS1; refreshed[B*P] (nullable) = 1 for the pixels
+// state -> the oracle's layout [B*P][28]: r_ref, lo, hi, rho, SD, S1, gSD, gS1, dSD, dS1, eSD, eS1; refreshed[B*P] (nullable) = 1 for the pixels
 // of the last call's work lists
 __global__ __launch_bounds__(kBlock) void lazy_unpack_kernel(const uint32_t* __restrict__ S, float* __restrict__ st, long BP) {
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= BP) return;
-    float* o = st + i * 22;
+    float* o = st + i * 28;
     const uint32_t lh = S[kLzLoHi * BP + i];
     o[0] = as_f(S[kLzRref * BP + i]); o[1] = h2_lo(lh); o[2] = h2_hi(lh); o[3] = as_f(S[kLzRho * BP + i]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const uint32_t sk = S[(kLzSk + c) * BP + i], dk = S[(kLzDk + c) * BP + i];
+        const uint32_t sk = S[(kLzSk + c) * BP + i], dk = S[(kLzDk + c) * BP + i], ek = S[(kLzEk + c) * BP + i];
+        o[22 + c] = h2_lo(ek); o[25 + c] = h2_hi(ek);
         o[4 + c] = as_f(S[(kLzSD + c) * BP + i]); o[7 + c] = as_f(S[(kLzS1 + c) * BP + i]);
         o[10 + c] = h2_lo(sk); o[13 + c] = h2_hi(sk); o[16 + c] = h2_lo(dk); o[19 + c] = h2_hi(dk);
     }

@@ -5,7 +5,7 @@
 // Adam moments: 172.6 B/pixel in an 'rm' part against the 108 B/pixel of the canonical forward + backward pair.  Two things are wrong with that:
 //   * bytes: a part moves SOME of the maps (--opt_order 'rm a', :343-357); what it leaves alone is a constant that folds into the model
 //     (kFoldXY: the albedo, 64 B/pixel of model and no albedo read; kFoldGH: roughness and metallic, 24 B/pixel of model and neither map read).
-//     'rm': r 4 + m 4 read, 8 written, model 64, target 12, render 12, anchors 8, Adam moments 32 = 144 B/pixel (was 172);
+//     'rm': r 4 + m 4 read, 8 written, model 68 (64 + the slopes of the detached derivatives, round 5), target 12, render 12, anchors 8, Adam moments 32 = 148 B/pixel (was 172);
 //     'a' : a 12 read, 12 written, model 24, target 12, render 12, anchors 12, Adam moments 48 = 132 B/pixel (was 160);
 //   * shape: 4096 workgroups of 512 pixels each fold the iteration's statistics before their first load, and the few pixels that leave their
 //     model's interval are a launch of their own (a 20 us latency chain at 8 x 512^2).  Here a workgroup takes up to four consecutive 512-pixel
@@ -64,16 +64,17 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
         const float r = fminf(fmaxf(ldf(q.r, o1), 0.07f), 1.0f), m = fminf(fmaxf(ldf(q.m, o1), 0.0f), 1.0f), omm = 1.0f - m;
         const float rref = as_f(ldu(q.plane[kLzRref], o1));
         const float dr = r - rref;
-        float rgb[3], x2h[3];
+        float rgb[3], x2h[3], jx1[3] = {0.0f, 0.0f, 0.0f}, jy1[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float Pv = as_f(ldu(q.plane[kLzP + c], o1)), SDv = as_f(ldu(q.plane[kLzSD + c], o1)), S1v = as_f(ldu(q.plane[kLzS1 + c], o1));
             const uint32_t pk = ldu(q.plane[kLzPk + c], o1), sk = ldu(q.plane[kLzSk + c], o1), dk = ldu(q.plane[kLzDk + c], o1);
             if (MODE == kFoldXY) {
                 FoldXY f;
-                fold_xy(a[c], Pv, SDv, S1v, h2_lo(pk), h2_hi(pk), h2_lo(sk), h2_hi(sk), h2_lo(dk), h2_hi(dk), f);
+                const uint32_t ek = ldu(q.plane[kLzEk + c], o1);
+                fold_xy(a[c], Pv, SDv, S1v, h2_lo(pk), h2_hi(pk), h2_lo(sk), h2_hi(sk), h2_lo(dk), h2_hi(dk), h2_lo(ek), h2_hi(ek), f);
                 const uint32_t s = pack_h2(f.X1, f.Y1);
-                x2h[c] = f.X2;
+                x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1;
                 stu(q.fplane[kFxX0 + 2 * c], o1, as_u(f.X0));
                 stu(q.fplane[kFxX0 + 2 * c + 1], o1, as_u(f.Y0));
                 stu(q.fplane[kFxS + c], o1, s);
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
             stu(q.fplane[kFxRref], o1, as_u(rref));
             stu(q.fplane[kFxLoHi], o1, ldu(q.plane[kLzLoHi], o1));
             stu(q.fplane[kFxQ], o1, pack_h2(x2h[0], x2h[1]));
-            stu(q.fplane[kFxQ + 1], o1, pack_h2(x2h[2], 0.0f));
+            stu(q.fplane[kFxQ + 1], o1, pack_bf8x2<true>(jx1[0], jy1[0], pack_h2(x2h[2], 0.0f)));
+            stu(q.fplane[kFxE], o1, pack_bf8x2<true>(jx1[2], jy1[2], pack_bf8x2<false>(jx1[1], jy1[1], 0u)));
         }
         st3(q.out, o3, rgb[0], rgb[1], rgb[2]);
     }
@@ -113,7 +115,7 @@ struct PxXY {
     float r, m, rref;
     uint32_t lohi;
     float X0[3], Y0[3];
-    uint32_t s[3], j[3], q0, q1;
+    uint32_t s[3], j[3], q0, q1, e;
     F3 gt;
     float r0, m0, mr, vr, mm, vm;
 };
@@ -133,7 +135,7 @@ __device__ __forceinline__ void pstep_load_fixed(PxXY& x, const LazyStepArgs& qs
     x.gt = ld3(q.gt_srgb, o3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { x.X0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c], o1)); x.Y0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c + 1], o1)); }
-    x.rref = 0.0f; x.lohi = 0u; x.q0 = x.q1 = 0u;
+    x.rref = 0.0f; x.lohi = 0u; x.q0 = x.q1 = x.e = 0u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) x.s[c] = x.j[c] = 0u;
     if (f.slopes) {           // a part that leaves the roughness alone never moves away from r_ref (uniform branch)
@@ -144,9 +146,11 @@ __device__ __forceinline__ void pstep_load_fixed(PxXY& x, const LazyStepArgs& qs
         if (f.att) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) x.j[c] = x.s[c];
+            x.q1 &= 0xffffu;                                   // the models' own slopes are the derivative: no first-order correction on top
         } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) x.j[c] = ldu(qs.fplane[kFxJ + c], o1);
+            x.e = ldu(qs.fplane[kFxE], o1);
         }
     }
     x.r0 = x.m0 = x.mr = x.vr = x.mm = x.vm = 0.0f;
@@ -207,7 +211,10 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
         float X, Y;
         xy_eval(x.X0[c], x.Y0[c], x.s[c], x2, dr, X, Y);
         const float go = loss_go(fmaf(m, Y, X), gt[c], ratio, sr, q.inv_n3, xs_keep[c]);
-        const float JX = fmaf(2.0f * x2, dr, h2_lo(x.j[c])), JY = fmaf(-2.0f * x2, dr, h2_hi(x.j[c]));
+        // d out / d r to first order in dr: the curvature of the diffuse lobe (2 X2, exact) and the slopes of the detached specular derivatives
+        const float jx1 = c == 0 ? bf8_at<2>(x.q1) : (c == 1 ? bf8_at<0>(x.e) : bf8_at<2>(x.e));
+        const float jy1 = c == 0 ? bf8_at<3>(x.q1) : (c == 1 ? bf8_at<1>(x.e) : bf8_at<3>(x.e));
+        const float JX = fmaf(fmaf(2.0f, x2, jx1), dr, h2_lo(x.j[c])), JY = fmaf(fmaf(-2.0f, x2, jy1), dr, h2_hi(x.j[c]));
         drr = fmaf(go, fmaf(m, JY, JX), drr);
         dm = fmaf(go, Y, dm);
     }

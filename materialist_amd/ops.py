@@ -22,7 +22,8 @@ FLAG_ROTATE_BEST = 128
 FLAG_GENERIC_STEP = 256
 FLAG_JAC32 = 512
 FLAG_SHARE_GPU = 2048
-LAZY_NSTATE = 22
+LAZY_NSTATE = 28
+LAZY_PLANES = 24          # 32-bit planes of a lazy model (csrc/matpbr_lazy.hpp kLzPlanes)
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
  STAT_ES_HAS, STAT_STOPPED, STAT_ITERS, STAT_GT_SUM) = range(16)
@@ -226,7 +227,7 @@ def shade_fwd_lazy(a, r, m, n, light, spp: int, dcache: torch.Tensor, state: tor
 
 
 def lazy_state_unpack(state: torch.Tensor, a: torch.Tensor):
-    """(models [B,H,W,22]: r_ref, lo, hi, rho, SD, S1, gSD, gS1, dSD, dS1 (rgb each), refreshed [B,H,W] int32: the pixels the last `shade_fwd_lazy` re-sampled)."""
+    """(models [B,H,W,28]: r_ref, lo, hi, rho, SD, S1, gSD, gS1, dSD, dS1, eSD, eS1 (rgb each), refreshed [B,H,W] int32: the pixels the last `shade_fwd_lazy` re-sampled)."""
     B, H, W = _bhw(a)
     st = torch.empty((B, H, W, LAZY_NSTATE), dtype=torch.float32, device=a.device)
     ref = torch.empty((B, H, W), dtype=torch.int32, device=a.device)
@@ -259,7 +260,7 @@ def background_into_lazy_state(state: torch.Tensor, a: torch.Tensor, bg_mask: to
     """Constant models for the masked pixels ([(B,)H,W] mask): P = SD = 0, S1 = bg_rgb, no slopes, an interval no roughness can leave."""
     B, H, W = _bhw(a)
     P = B * H * W
-    planes = state[: 21 * 4 * P].view(torch.int32).view(21, P)
+    planes = state[: LAZY_PLANES * 4 * P].view(torch.int32).view(LAZY_PLANES, P)
     idx = bg_mask.reshape(-1).nonzero().reshape(-1)
     bits = lambda t: t.contiguous().view(torch.int32)
     planes[0, idx] = bits(r.reshape(-1)[idx].clamp(0.07, 1.0).float())
@@ -269,7 +270,7 @@ def background_into_lazy_state(state: torch.Tensor, a: torch.Tensor, bg_mask: to
     planes[3:9, idx] = 0
     for c in range(3):
         planes[9 + c, idx] = bits(bg_rgb.reshape(-1, 3)[idx, c].float())
-    planes[12:21, idx] = 0
+    planes[12:LAZY_PLANES, idx] = 0
 
 
 def background_index(bg_mask: torch.Tensor) -> torch.Tensor:

