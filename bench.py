@@ -41,7 +41,7 @@ def parse(argv=None):
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel; the reference renders with spp=64 (inverse_img_w_mi.py:625)")
     ap.add_argument("--images-per-gpu", type=int, default=1)
-    ap.add_argument("--mode", choices=["fused", "fused_one_phase", "torch", "torch_graph", "pos_mlp"], default=None,
+    ap.add_argument("--mode", choices=["fused", "fused_one_phase", "torch", "pos_mlp"], default=None,
                     help="default: pos_mlp (the reference's default mode: maps from the residual PosMLP) for one image per GPU, fused "
                          "(--model_name none, whole iteration in libmatpbr.so) for a batch; torch: the none-mode step composed from torch ops")
     ap.add_argument("--mlp-products", type=int, choices=[0, 6, 9], default=None,
@@ -312,7 +312,7 @@ def main(argv=None):
                 pr["shape.bsdf.a"], pr["shape.bsdf.r"], pr["shape.bsdf.m"] = self.gt
                 raw = torch.zeros(16, 32, 3, device=dev, requires_grad=True)
                 return EnvTexelPhase(s_env, self.gt_image, raw, spp=args.spp, lr=1e-3, use_graph=True)
-            return loop.BrdfPhase(self.scene, self.gt_image, *self.init, None, optimize_part="rm", spp=args.spp, graph=(mode == "torch_graph"))
+            return loop.BrdfPhase(self.scene, self.gt_image, *self.init, None, optimize_part="rm", spp=args.spp)
 
     wl = Workload(args.images_per_gpu)
     B = wl.B
@@ -349,7 +349,7 @@ def main(argv=None):
     modes = {mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3, "images_per_gpu": B}}
     wl8 = None
     if not args.no_extras and mode != "torch":
-        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("torch", 300), ("torch_graph", 300), ("pos_mlp", 100), ("env", 500), ("env_texels", 1000), ("fused_n", 300)):
+        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("torch", 300), ("pos_mlp", 100), ("env", 500), ("env_texels", 1000), ("fused_n", 300)):
             if extra == mode or (not extra.startswith("fused") and B > 1):
                 continue
             ph_x = wl.phase(extra)
@@ -462,8 +462,6 @@ def main(argv=None):
                   "env": "hot loop A: envmap PosMLP (small-tile MFMA layers) + softplus / SH projection + one pass over the radiance transfer and one workgroup "
                          "behind it (fold, SaveBest / EarlyStopping, snapshot, projection backward) + backward chain + Adam: 14 kernels of libmatpbr.so per "
                          "iteration, ten iterations per hipGraph replay and poll",
-                  "torch_graph": "the same loop body captured into a hipGraph after three eager iterations and replayed (loop.BrdfPhase(graph=True): the same launches in the "
-                                 "same order, one host call per iteration; the learning rate in a device tensor)",
                   "torch": "hot loop B as the reference's loop body runs it UNCHANGED on the operator face (loop.BrdfPhase: clamp, render_w_brdf with autograd, "
                            "torch losses, torch.optim.Adam; inverse_img_w_mi.py:371-432): render_w_brdf renders from the scene's cached per-pixel models"}
     modes = {k: dict(v, what=mode_names[k]) for k, v in modes.items()}

@@ -89,14 +89,14 @@ class DeviceSaveBest:
         if self.best_loss is None:
             self.best_loss = torch.full_like(loss, float("inf"))
         better = loss < self.best_loss
-        torch.where(better, loss, self.best_loss, out=self.best_loss)       # in place: the state keeps its addresses (a captured step replays onto them)
+        self.best_loss = torch.where(better, loss, self.best_loss)
         for k, v in maps.items():
             v = v.detach()
             sel = better.reshape(better.shape + (1,) * (v.ndim - better.ndim)) if better.ndim else better
             if k not in self.best:
                 self.best[k] = v.clone()
             else:
-                torch.where(sel, v, self.best[k], out=self.best[k])
+                self.best[k] = torch.where(sel, v, self.best[k])
 
 
 def _make_adam(params, lr):
@@ -129,12 +129,9 @@ class BrdfPhase:
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
                  normal: Optional[torch.Tensor] = None, optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4,
                  scale_delta: float = 0.1, saver: Optional[DeviceSaveBest] = None, mask: Optional[torch.Tensor] = None,
-                 originals: Optional[Dict[str, torch.Tensor]] = None, graph: bool = False):
+                 originals: Optional[Dict[str, torch.Tensor]] = None):
         """`originals`: the regulariser anchors albedo_ori / roughness_ori / metallic_ori / normal_ori, captured once before the
-        loops (inverse_img_w_mi.py:189-201); default: this phase's start maps.
-        `graph`: after three eager iterations the loop body (:371-427: clamps, render_w_brdf, loss, backward, SaveBest, Adam) is captured into a
-        hipGraph and replayed -- the same launches in the same order, issued by one host call instead of some forty (the StepLR rule of
-        :431-432 is applied between replays: the learning rate lives in a device tensor)."""
+        loops (inverse_img_w_mi.py:189-201); default: this phase's start maps."""
         self.scene, self.gt, self.spp, self.scale_delta = scene, gt_image, spp, scale_delta
         self.mask = mask
         self.part = optimize_part
@@ -145,15 +142,8 @@ class BrdfPhase:
         keys = {"a": "albedo", "r": "roughness", "m": "metallic", "n": "normal"}
         self.opt_keys = [keys[c] for c in optimize_part if c in keys and not (c == "n" and scene.use_mesh_normal)]
         self.params = {k: torch.nn.Parameter(self.maps[k].detach().clone()) for k in self.opt_keys}
-        self.graph = bool(graph) and gt_image.is_cuda
-        self._graph, self._calls, self._lr, self._sched_epoch = None, 0, float(lr), 0
-        if self.graph:
-            self._lr_t = torch.tensor(float(lr), dtype=torch.float32, device=gt_image.device)
-            self.opt = torch.optim.Adam(list(self.params.values()), lr=self._lr_t, capturable=True, foreach=True)
-            self.sched = None
-        else:
-            self.opt = _make_adam(list(self.params.values()), lr)
-            self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)   # :363-365
+        self.opt = _make_adam(list(self.params.values()), lr)
+        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)   # :363-365
         self.saver = saver if saver is not None else DeviceSaveBest()
         self.last = {}
 
@@ -173,7 +163,7 @@ class BrdfPhase:
             m["metallic"] = masked_mean_fill(m["metallic"], self.mask)
         return m
 
-    def _body(self):
+    def step(self) -> torch.Tensor:
         m = self.current_maps()
         normal = None if self.scene.use_mesh_normal else m["normal"]
         pred = _render.render_w_brdf(self.scene, m["albedo"], m["roughness"], m["metallic"], normal, self.spp)   # :384-386
@@ -184,35 +174,10 @@ class BrdfPhase:
         self.saver.update(loss_mse, albedo=m["albedo"], roughness=m["roughness"], metallic=m["metallic"], rendered_img=pred_srgb, **extra)
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
-        return loss.detach(), loss_mse.detach()
-
-    def step(self) -> torch.Tensor:
-        if self.graph:
-            if self._graph is None and self._calls >= 3:
-                # three eager iterations have run (the scene's cache is built, every kernel has had its first launch): capture the body once
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (the backward pass runs on autograd's worker thread)
-                    self._static = self._body()
-                self._graph = g
-            elif self._graph is not None:
-                self._graph.replay()
-            else:
-                self._static = self._body()
-            self._calls += 1
-            if self._lr > 1.5e-4:                                                                                # :431-432, on the host copy of the rate
-                self._sched_epoch += 1
-                if self._sched_epoch % 100 == 0:
-                    self._lr *= 0.8
-                    self._lr_t.fill_(self._lr)
-            loss, loss_mse = self._static
-            self.last = {"loss": loss, "loss_mse": loss_mse}
-            return loss_mse
-        loss, loss_mse = self._body()
         if self.opt.param_groups[0]["lr"] > 1.5e-4:                                                              # :431-432
             self.sched.step()
-        self.last = {"loss": loss, "loss_mse": loss_mse}
-        return loss_mse
+        self.last = {"loss": loss.detach(), "loss_mse": loss_mse.detach()}
+        return loss_mse.detach()
 
 
 class EnvPhase:

@@ -436,36 +436,6 @@ def test_fused_brdf_loss_node_is_the_torch_composition(B, part):
         assert (gp1[k] - gp0[k]).abs().max().item() <= 1e-6 * max(gp0[k].abs().max().item(), 1e-30) + 1e-12, k
 
 
-def test_drop_in_loop_body_captured_into_a_graph_is_the_eager_loop():
-    """`loop.BrdfPhase(graph=True)` replays the reference's loop body (inverse_img_w_mi.py:371-432 on the operator face: clamps,
-    render_w_brdf with autograd, the loss node, SaveBest, Adam, StepLR) from a hipGraph captured after three eager iterations -- the same launches
-    in the same order: losses, parameters and SaveBest's snapshot equal the eager loop's after 130 iterations (one StepLR decay inside)."""
-    from materialist_amd import loop, render, synthetic
-
-    dev = _cuda()
-    H, W, spp = 64, 64, 64
-    sc = synthetic.make_scene(2, H, W)
-
-    def run(graph):
-        scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
-        scene._set("emitter.data", _t(sc.light, dev))
-        with torch.no_grad():
-            gt = render.render_w_brdf(scene, _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp).clone()
-        init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
-        ph = loop.BrdfPhase(scene, gt, *init, None, optimize_part="rm", spp=spp, graph=graph)
-        hist = [float(ph.step()) for _ in range(130)]
-        return hist, {k: v.detach().clone() for k, v in ph.params.items()}, {k: v.clone() for k, v in ph.saver.best.items()}, float(ph.saver.best_loss)
-
-    h0, p0, b0, l0 = run(False)
-    h1, p1, b1, l1 = run(True)
-    assert h1[:3] == h0[:3]                                   # the eager iterations before the capture
-    assert np.allclose(h1, h0, rtol=2e-5) and l1 == pytest.approx(l0, rel=2e-5)
-    for k in p0:
-        assert (p1[k] - p0[k]).abs().max().item() <= 2e-6, k  # (foreach Adam with a tensor rate against the fused one: rounding)
-    for k in b0:
-        assert (b1[k] - b0[k]).abs().max().item() <= 2e-5, k
-
-
 def test_operator_face_cache_is_keyed_on_tensor_objects_not_addresses():
     """a batch with ONE shared [25,3] light is rendered through an expanded (copied) light, so the cache cannot be keyed on the copy's
     address.  Two `_set("emitter.data", ...)` without a render in between, lights that are freed and re-allocated (the caching allocator hands
