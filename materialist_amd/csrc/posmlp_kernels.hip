@@ -1877,7 +1877,10 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
 // Columns at or beyond N (K) are computed and dropped by mlp_wgrad_reduce: dW[n][k] depends on column n of G and k of X only.
 constexpr int kWgStage = 2 * 3 * 2 * 256;                  // uint4 per buffer: [G|X][piece][row half][column slot]
 constexpr size_t kWgSmem = 2 * kWgStage * sizeof(uint4);
-constexpr int kWgDepth = 2;
+#ifndef MATPBR_WG_DEPTH
+#define MATPBR_WG_DEPTH 2
+#endif
+constexpr int kWgDepth = MATPBR_WG_DEPTH;      // (measurement builds: tools/wg_ab.sh)
 constexpr int kWgThreads = 512;
 __device__ __forceinline__ int wg_perm(int i) { return (i & 16) + 2 * (i & 7) + ((i >> 3) & 1); }   // fragment lane -> column within a tile of 32
 // EARLY: stage before the products of a step instead of after them.  The two waves of a SIMD (w and w + 4) meet at the barrier of
