@@ -1966,12 +1966,11 @@ __device__ __forceinline__ void wgrad_bx_body(const float* __restrict__ G, int l
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    // step st multiplies from buffer st & 1 and stages step st + 1 (registers (st + 1) % depth) into the other one
-    for (int st0 = 0; st0 < steps; st0 += kWgDepth) {
-#pragma unroll
-      for (int u = 0; u < kWgDepth; ++u) {
-        const int st = st0 + u;
-        if (st >= steps) break;
+    // step st multiplies from buffer st & 1 and stages step st + 1 (registers (st + 1) % depth) into the other one.  Whole groups of kWgDepth
+    // steps in the loop, the rest behind it: an exit from the middle of the unrolled body shares the loop's latch, and the waits the compiler
+    // derives at the loop header are then the merge of both orders of the loads in flight -- vmcnt(0) at every group's first step
+    auto step = [&](auto u_tag, int st) {
+        constexpr int u = decltype(u_tag)::value;
         const int cur = st & 1;
         if (EARLY) stage((u + 1) % kWgDepth, cur ^ 1, st + 1 + kWgDepth);
         const uint4* sa = sW + cur * kWgStage + lh * 256 + nq * 64 + li;             // + (piece * 2) * 256 + ni * 32
@@ -2014,8 +2013,17 @@ __device__ __forceinline__ void wgrad_bx_body(const float* __restrict__ G, int l
         }
         if (!EARLY) stage((u + 1) % kWgDepth, cur ^ 1, st + 1 + kWgDepth);
         __syncthreads();
-      }
+    };
+    int st0 = 0;
+    for (; st0 + kWgDepth <= steps; st0 += kWgDepth) {
+      step(std::integral_constant<int, 0>{}, st0);
+      if constexpr (kWgDepth > 1) step(std::integral_constant<int, 1>{}, st0 + 1);
+      if constexpr (kWgDepth > 2) step(std::integral_constant<int, 2>{}, st0 + 2);
+      if constexpr (kWgDepth > 3) step(std::integral_constant<int, 3>{}, st0 + 3);
     }
+    if (st0 < steps) step(std::integral_constant<int, 0>{}, st0);
+    if constexpr (kWgDepth > 2) if (st0 + 1 < steps) step(std::integral_constant<int, 1>{}, st0 + 1);
+    if constexpr (kWgDepth > 3) if (st0 + 2 < steps) step(std::integral_constant<int, 2>{}, st0 + 2);
   }
   float* out = partial + (long)blockIdx.x * 256 * 256;
 #pragma unroll

@@ -109,9 +109,13 @@ def _make_adam(params, lr):
 def masked_mean_fill(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """`x[mask] = x[mask].mean()` of `--use_mask` (inverse_img_w_mi.py:379-381,509-511), out of place and without boolean
     indexing (no host synchronisation): every masked entry becomes the masked mean, so its gradient is the mean of the masked
-    gradients, as autograd gives for the reference's in-place form.  x [H,W,C], mask [H,W] bool."""
+    gradients, as autograd gives for the reference's in-place form.  x [H,W,C], mask [H,W] bool; a batch x [B,H,W,C] with its masks
+    [B,H,W] is its images alone: one mean per image."""
     w = mask.to(x.dtype).reshape(mask.shape + (1,) * (x.ndim - mask.ndim))
-    mean = (x * w).sum() / (w.sum() * (x.numel() // w.numel())).clamp_min(1.0)
+    if x.ndim == 4:
+        mean = (x * w).sum(dim=(1, 2, 3), keepdim=True) / (w.sum(dim=(1, 2, 3), keepdim=True) * (x.shape[-1] // w.shape[-1])).clamp_min(1.0)
+    else:
+        mean = (x * w).sum() / (w.sum() * (x.numel() // w.numel())).clamp_min(1.0)
     return x * (1.0 - w) + mean * w
 
 
@@ -503,6 +507,39 @@ class _SceneGroup:
         return (self._bg_basis @ light).reshape(self.bg_mask.shape + (3,))
 
 
+class _SceneImage(_SceneGroup):
+    """One image of a batched Scene, as the single-image phases read a Scene."""
+
+    def __init__(self, scene: _render.Scene, i: int):
+        self.use_mesh_normal, self.fov = scene.use_mesh_normal, scene.fov
+        self._n = scene.shading_normal()[i]
+        light = scene.light
+        self.light = light if light.ndim == 2 else light[i]
+        self.bg_mask = None if scene.bg_mask is None else scene.bg_mask[i]
+        self._bg_basis = None if scene.bg_mask is None else scene.bg_basis[i]
+
+    def background_radiance(self, light: torch.Tensor) -> torch.Tensor:
+        return (self._bg_basis @ light).reshape(self.bg_mask.shape + (3,))
+
+
+class _BatchOfOne:
+    """A single-image phase seen as a batch of one image: what PipelinedBrdfPhase concatenates."""
+
+    def __init__(self, ph):
+        self._ph = ph
+
+    def __getattr__(self, name):
+        return getattr(self._ph, name)
+
+    p = property(lambda self: {k: v.unsqueeze(0) for k, v in self._ph.p.items()})
+    best = property(lambda self: {k: v.unsqueeze(0) for k, v in self._ph.best.items()})
+    best_img = property(lambda self: self._ph.best_img.unsqueeze(0))
+    pred = property(lambda self: self._ph.pred.unsqueeze(0))
+
+    def current_maps(self) -> Dict[str, torch.Tensor]:
+        return {k: v.unsqueeze(0) for k, v in self._ph.current_maps().items()}
+
+
 class PipelinedBrdfPhase:
     """A batch of images as GROUPS of images, each a `FusedBrdfPhase` stepping on a stream of its own.  An image's iteration does not depend on the
     images beside it (a batch is its images alone, bit for bit: tests/test_gpu_lazy.py), so the groups are independent -- and the walk and
@@ -511,8 +548,9 @@ class PipelinedBrdfPhase:
     FusedBrdfPhase over the whole batch, bit for bit; same interface.  8 x 512 x 512, part 'rm': 80.6 -> 75 us per iteration of the batch."""
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
-                 groups: int = 2, best_mse: Optional[torch.Tensor] = None, originals: Optional[Dict[str, torch.Tensor]] = None, **kw):
-        if gt_image.ndim != 4 or gt_image.shape[0] % groups or groups < 2:
+                 groups: int = 2, best_mse: Optional[torch.Tensor] = None, originals: Optional[Dict[str, torch.Tensor]] = None, make_phase=None,
+                 **kw):
+        if gt_image.ndim != 4 or gt_image.shape[0] % groups or (groups < 2 and make_phase is None):
             raise ValueError("PipelinedBrdfPhase: a batch [B,H,W,3] whose size the number of groups divides")
         B, dev = gt_image.shape[0], gt_image.device
         per = B // groups
@@ -524,10 +562,13 @@ class PipelinedBrdfPhase:
             sl = slice(gi * per, (gi + 1) * per)
             st.wait_stream(here)                                     # the caller's tensors are ready on the caller's stream
             with torch.cuda.stream(st):                              # the group's buffers and its set-up launches belong to its stream
-                self.phases.append(FusedBrdfPhase(_SceneGroup(scene, sl), gt_image[sl], albedo[sl], roughness[sl], metallic[sl],
-                                                  best_mse=None if best_mse is None else best_mse.reshape(-1)[sl],
-                                                  originals=None if originals is None else {k: v[sl] for k, v in originals.items()},
-                                                  share_gpu=True, **kw))
+                group_kw = dict(best_mse=None if best_mse is None else best_mse.reshape(-1)[sl],
+                                originals=None if originals is None else {k: v[sl] for k, v in originals.items()}, **kw)
+                if make_phase is not None:
+                    self.phases.append(make_phase(sl, group_kw))
+                else:
+                    self.phases.append(FusedBrdfPhase(_SceneGroup(scene, sl), gt_image[sl], albedo[sl], roughness[sl], metallic[sl], share_gpu=True,
+                                                      **group_kw))
         self.ops = self.phases[0].ops
 
     def step(self) -> None:
@@ -852,6 +893,38 @@ class MaskedBrdfPhase:
     def current_maps(self) -> Dict[str, torch.Tensor]:
         d = self._fed_maps()
         return {"albedo": d["albedo"].clamp(0, 1), "roughness": d["roughness"].clamp(0.07, 1), "metallic": d["metallic"].clamp(0, 1)}
+
+
+class MaskedBatchPhase(PipelinedBrdfPhase):
+    """`--use_mask` on a batch of images: a batch is its images alone, so it is one `MaskedBrdfPhase` per image (the masked means, SaveBest and
+    EarlyStopping are per image), each stepping on a stream of its own -- an image's launches are small next to the chip, and the means between
+    them are chains of round trips that run under the other images' renders.  Same interface as `PipelinedBrdfPhase`; same results as the
+    images run alone, bit for bit (tests/test_gpu_parity.py)."""
+
+    def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, albedo: torch.Tensor, roughness: torch.Tensor, metallic: torch.Tensor,
+                 mask: torch.Tensor, **kw):
+        if gt_image.ndim != 4 or mask.shape != gt_image.shape[:3]:
+            raise ValueError("MaskedBatchPhase: images [B,H,W,3] with their masks [B,H,W]")
+
+        def make(sl: slice, group_kw: dict):
+            i = sl.start
+            one = dict(group_kw)
+            if one.get("originals") is not None:
+                one["originals"] = {k: v[0] for k, v in one["originals"].items()}
+            return _BatchOfOne(MaskedBrdfPhase(_SceneImage(scene, i), gt_image[i], albedo[i], roughness[i], metallic[i], mask[i], **one))
+
+        super().__init__(scene, gt_image, albedo, roughness, metallic, groups=gt_image.shape[0], make_phase=make, **kw)
+
+    def current_maps(self) -> Dict[str, torch.Tensor]:
+        self._join()
+        parts = []
+        for ph, st in zip(self.phases, self.streams):
+            with torch.cuda.stream(st):
+                parts.append(ph.current_maps())
+        self._join()
+        out = {k: torch.cat([d[k] for d in parts], dim=0) for k in parts[0]}
+        self._release()
+        return out
 
 
 class FusedEnvPhase:

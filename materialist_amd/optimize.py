@@ -324,15 +324,17 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         # Under a FIXED predicted normal map (use_mesh_normal False, no 'n' in the part) the fused phases shade with it as they do with the
         # geometric normals; a part that MOVES the normal map runs NormalBrdfPhase (launch by launch on the C ABI, device-side SaveBest /
         # EarlyStopping); under the geometric normals an 'n' in the part optimises nothing (:356,376); what is left -- masks with predicted
-        # normals or on a batch, a part that is 'n' alone under the geometric normals -- is the autograd composition's
+        # normals, a part that is 'n' alone under the geometric normals -- is the autograd composition's
         eff = part.replace("n", "") if scene.use_mesh_normal else part
         moves_n = "n" in eff
-        if not eff or (mask is not None and (gt.ndim != 3 or not scene.use_mesh_normal)) or (moves_n and not gt.is_cuda):
+        if not eff or (mask is not None and not scene.use_mesh_normal) or (moves_n and not gt.is_cuda):
             return brdf_part_runner_normal(loop_num, part, patience, min_delta, n_epochs)
         phase_kw = dict(optimize_part=eff, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
                         best_mse=saver.best_loss if saver.best_loss is not None else None, history_len=n_epochs, originals=originals)
         if moves_n:
             ph = _loop.NormalBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mat["normal"], **phase_kw)
+        elif mask is not None and gt.ndim == 4:    # a batch under --use_mask: its images alone, each on a stream of its own
+            ph = _loop.MaskedBatchPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mask, **phase_kw)
         elif mask is not None:    # --use_mask: launch by launch (two image-wide means per iteration), same device-side SaveBest / EarlyStopping
             ph = _loop.MaskedBrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], mask, **phase_kw)
         elif gt.ndim == 4 and gt.shape[0] >= 8 and gt.shape[0] % 2 == 0 and gt.is_cuda:

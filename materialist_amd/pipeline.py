@@ -299,22 +299,38 @@ def initial_prediction(img: np.ndarray, size: int, device, matnet=None, matnet_w
 
 def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], opt_src: str = "arm", opt_order: Sequence[str] = ("arm",),
                            opt_env_from: int = 0, save_path: Optional[str] = None, size: int = 512, spp: int = 64, num_epochs: int = 5000,
-                           pred_dirs: Optional[Sequence[Optional[str]]] = None, device: str = "cuda", matnet=None, log=print) -> Dict[str, object]:
+                           pred_dirs: Optional[Sequence[Optional[str]]] = None, device: str = "cuda", matnet=None, log=print,
+                           use_mask: bool = False) -> Dict[str, object]:
     """`--model_name none` on several photographs at once: the images of a rank's shard as ONE batch in the kernels' batch dimension
     (per-image light, SaveBest and EarlyStopping on the device), each with the reference's output directory (inverse_img_w_mi.py:623-770
     per image; the reference runs them one after another, run_inverse_pipeline.sh:16-28).  `mesh_mask.png` and pixels the mesher
-    leaves without a triangle are per-image background masks of the batch; `--use_mask` and parts with 'n' stay with `inverse_image`
-    (they need per-image operator calls)."""
+    leaves without a triangle are per-image background masks of the batch; `--use_mask` reads every image's `best_results/mask.png`
+    (:702-711; an image without one runs unmasked) and its masked means are per image (loop.MaskedBatchPhase); parts with 'n' stay with
+    `inverse_image`."""
     from . import optimize, render
     from . import mesh as _mesh
 
     if "n" in str(list(opt_order)):
         raise ValueError("inverse_images_batched optimises a / r / m under the geometric normal")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
-    mats, depths, normals, out_dirs, holes = [], [], [], [], []
+    mats, depths, normals, out_dirs, holes, masks = [], [], [], [], [], []
     for k, (path, name) in enumerate(zip(img_paths, save_names)):
         output_dir = get_output_dir(name, save_path)
         os.makedirs(os.path.join(output_dir, "best_results"), exist_ok=True)
+        if use_mask:                                         # :702-711
+            from PIL import Image
+
+            mp = os.path.join(output_dir, "best_results", "mask.png")
+            if os.path.exists(mp):
+                mk = np.asarray(Image.open(mp))
+                mk = np.ascontiguousarray((mk[..., 0] if mk.ndim == 3 else mk) > 0)
+                if mk.shape != (size, size):
+                    raise ValueError(f"{mp}: mask is {mk.shape}, the run is {size}x{size}")
+                log(f"Applied mask from {mp}")
+            else:
+                warnings.warn(f"No mask found for {name}, continuing without mask", UserWarning)
+                mk = np.zeros((size, size), dtype=bool)
+            masks.append(torch.from_numpy(mk))
         mm_path, mesh_mask = os.path.join(output_dir, "mesh_mask.png"), np.zeros((size, size), dtype=bool)
         if os.path.exists(mm_path):                          # :713-724: pixels without geometry
             from PIL import Image
@@ -337,7 +353,7 @@ def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], 
         write_exr(os.path.join(output_dir, "gt_image.exr"), img)
         write_png(os.path.join(output_dir, "gt_image.png"), img, linear=True)
         with open(os.path.join(output_dir, "config.json"), "w") as f:
-            json.dump({"img_path": path, "save_name": name, "opt_src": opt_src, "opt_order": list(opt_order), "use_mask": False,
+            json.dump({"img_path": path, "save_name": name, "opt_src": opt_src, "opt_order": list(opt_order), "use_mask": bool(use_mask),
                        "opt_env_from": opt_env_from, "model_name": "none", "timestamp": time.strftime("%Y-%m-%d %H:%M:%S"),
                        "image_size": list(img.shape[:2]), "spp": spp, "output_type": "arm", "use_mesh_normal": True}, f, indent=4)
         depth = np.array(2 * pred["depth"].max() - pred["depth"], dtype=np.float32)
@@ -357,8 +373,11 @@ def inverse_images_batched(img_paths: Sequence[str], save_names: Sequence[str], 
     scene = render.load_estimated_mesh(torch.stack(depths), use_mesh_normal=True, device=device)
     scene.geo_normal = torch.stack(normals).contiguous()                   # the reference mesher's per-pixel normals (gap closing included)
     scene.set_mesh_mask(torch.stack(holes))                                # vertices without a triangle: no geometry along that camera ray
+    use_mask = bool(use_mask) and any(bool(m.any()) for m in masks)
+    if use_mask:
+        mat["mask"] = torch.stack(masks).to(device)
     res = optimize.optimize_envmap_ARMN(scene, mat, optimize_order=list(opt_order), spp=spp, opt_env_from=opt_env_from, opt_src=opt_src,
-                                        num_epochs=num_epochs, log=log, model_name="none")
+                                        num_epochs=num_epochs, log=log, model_name="none", use_mask=use_mask)
     nrm = scene.geo_normal
     for b, output_dir in enumerate(out_dirs):
         best = {k: res[k][b] for k in ("albedo", "roughness", "metallic", "rendered_img")}

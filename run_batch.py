@@ -23,6 +23,8 @@ def main(argv=None):
     ap.add_argument("--model_name", type=str, default="pos_mlp", choices=["none", "pos_mlp"],
                     help="pos_mlp: the reference's behaviour (inverse_img_w_mi.py:782 always runs it); none: optimise the maps directly "
                          "(a rank's synthetic shard then runs as ONE batch in the kernels' batch dimension)")
+    ap.add_argument("--use_mask", action="store_true",
+                    help="inverse_img_w_mi.py:779: every photograph's <output dir>/best_results/mask.png (:702-711); per-image masked means")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--num_epochs", type=int, default=5000)
@@ -70,7 +72,7 @@ def main(argv=None):
                                                 opt_src=cfg["opt_src"], num_epochs=cfg["num_epochs"], model_name=cfg["model_name"])
         else:
             name = os.path.splitext(os.path.basename(path))[0]
-            res = pipeline.inverse_image(path, name, cfg["opt_src"], cfg["opt_order"], False, cfg["opt_env_from"], cfg["save_path"], cfg["model_name"],
+            res = pipeline.inverse_image(path, name, cfg["opt_src"], cfg["opt_order"], cfg["use_mask"], cfg["opt_env_from"], cfg["save_path"], cfg["model_name"],
                                          size=cfg["size"], spp=cfg["spp"], num_epochs=cfg["num_epochs"], device=str(dev), log=lambda *_: None,
                                          matnet=matnet, pred_dir=pred_dir_of(path))
         return [res["best_loss"], res["psnr"], float(sum(max(t.epoch, 0) + 1 for t in res["trace"] if t.phase != "end"))]
@@ -82,7 +84,8 @@ def main(argv=None):
             names = [os.path.splitext(os.path.basename(p))[0] for p in shard_paths]
             res = pipeline.inverse_images_batched(shard_paths, names, cfg["opt_src"], cfg["opt_order"], cfg["opt_env_from"], cfg["save_path"],
                                                   size=cfg["size"], spp=cfg["spp"], num_epochs=cfg["num_epochs"],
-                                                  pred_dirs=[pred_dir_of(p) for p in shard_paths], device=str(dev), matnet=matnet, log=lambda *_: None)
+                                                  pred_dirs=[pred_dir_of(p) for p in shard_paths], device=str(dev), matnet=matnet, log=lambda *_: None,
+                                                  use_mask=cfg["use_mask"])
             its = float(sum(max(t.epoch, 0) + 1 for t in res["trace"] if t.phase != "end"))
             return [[bl, ps, its] for bl, ps in zip(res["best_loss_per_image"], res["psnr_per_image"])]
         scs = [synthetic.make_scene(int(p.split(":")[1]), cfg["size"], cfg["size"]) for p in shard_paths]
@@ -100,7 +103,7 @@ def main(argv=None):
         return [[bl, ps, its] for bl, ps in zip(res["best_loss_per_image"], res["psnr_per_image"])]
 
     cfg = {"save_path": a.save_path, "opt_src": a.opt_src, "opt_order": a.opt_order, "opt_env_from": a.opt_env_from, "model_name": a.model_name,
-           "size": a.size, "spp": a.spp, "num_epochs": a.num_epochs}
+           "size": a.size, "spp": a.spp, "num_epochs": a.num_epochs, "use_mask": bool(a.use_mask)}
     # a rank's shard runs as one batch in --model_name none mode (synthetic scenes, or photographs; a photograph's mesh_mask.png and
     # the pixels its mesh leaves uncovered are per-image masks of the batch)
     batched = a.model_name == "none" and bool(paths) and "n" not in str(a.opt_order) and (

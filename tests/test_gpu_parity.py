@@ -1582,6 +1582,49 @@ def test_use_mask_none_mode_phase_matches_the_torch_composition(part):
     assert int(ph.poll()["iters"][0]) == 6
 
 
+@pytest.mark.gpu
+def test_use_mask_on_a_batch_is_its_images_alone():
+    """`--use_mask` on a batch (`loop.MaskedBatchPhase`: one MaskedBrdfPhase per image on a stream of its own, per-image masked means, SaveBest and
+    EarlyStopping): the same bits as the images run alone, and the route `optimize_envmap_ARMN` takes for a batch with masks."""
+    from materialist_amd import loop, ops, optimize, render, synthetic
+
+    dev = _cuda()
+    H, W, spp, B = 64, 96, 16, 3
+    scs = [synthetic.make_scene(20 + b, H, W) for b in range(B)]
+    st = lambda k: torch.from_numpy(np.stack([np.ascontiguousarray(getattr(s_, k), dtype=np.float32) for s_ in scs])).to(dev)
+    scene = render.load_estimated_mesh(st("depth"), use_mesh_normal=True)
+    scene._set("emitter.data", st("light"))
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene, st("albedo"), st("roughness"), st("metallic"), None, spp).clone()
+    init = [st("init_albedo"), st("init_roughness"), st("init_metallic")]
+    mask = torch.zeros(B, H, W, dtype=torch.bool, device=dev)
+    mask[0, 8:40, 10:70] = True
+    mask[1, 30:60, 0:50] = True                              # (image 2: no masked pixel at all)
+    ph = loop.MaskedBatchPhase(scene, gt, *init, mask, optimize_part="rm", spp=spp, history_len=8)
+    ph.run(5)
+    cur, best, st_b = ph.current_maps(), ph.best, ph.stats
+    for b in range(B):
+        sc1 = render.load_estimated_mesh(st("depth")[b], use_mesh_normal=True)
+        sc1._set("emitter.data", st("light")[b])
+        one = loop.MaskedBrdfPhase(sc1, gt[b], *(x[b] for x in init), mask[b], optimize_part="rm", spp=spp, history_len=8)
+        one.run(5)
+        assert torch.equal(st_b[b], one.stats[0]), b
+        for k in ("albedo", "roughness", "metallic"):
+            assert torch.equal(cur[k][b], one.current_maps()[k]) and torch.equal(best[k][b], one.best[k]), (b, k)
+        assert torch.equal(ph.pred[b], one.pred) and torch.equal(ph.history()[:, b], one.history()[:, 0])
+    inside = cur["roughness"][0].reshape(H, W)[mask[0]]
+    assert float(inside.max() - inside.min()) == 0.0 and int(ph.poll()["iters"].min()) == 5
+    # the whole optimisation on the batch takes this route and keeps the maps uniform inside every image's mask
+    mat = {"albedo": init[0], "roughness": init[1], "metallic": init[2], "gt_image": gt, "mask": mask}
+    scene2 = render.load_estimated_mesh(st("depth"), use_mesh_normal=True)
+    res = optimize.optimize_envmap_ARMN(scene2, mat, optimize_order=["rm"], spp=spp, num_epochs=12, model_name="none", use_mask=True, log=lambda *_: None)
+    for b in range(2):
+        for k in ("roughness", "metallic"):
+            v = res[k][b].reshape(H, W)[mask[b]]
+            assert float(v.max() - v.min()) == 0.0, (b, k)
+    assert len(res["psnr_per_image"]) == B
+
+
 @pytest.mark.parametrize("packed", [True, False])
 def test_output_layer_backward_in_one_pass_equals_the_separate_kernels(packed):
     """matpbr_mlp_out_layer_bwd (weight / bias gradient of the 5-output layer, dL/d pre of the last sine layer and its bias gradient in one

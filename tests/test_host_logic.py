@@ -387,3 +387,20 @@ def test_masked_mean_fill_is_the_reference_in_place_form():
     (y * w).sum().backward()
     assert torch.allclose(x, y, atol=1e-14) and torch.allclose(p_ref.grad, p_new.grad, atol=1e-14)
     assert torch.equal(masked_mean_fill(p_new.detach(), torch.zeros(9, 7, dtype=torch.bool)), p_new.detach())
+
+
+def test_masked_mean_fill_of_a_batch_is_its_images_alone():
+    """A batch under --use_mask: one masked mean PER IMAGE (a batch's images are independent runs of the reference), an image without masked pixels
+    unchanged."""
+    import torch
+
+    from materialist_amd.loop import masked_mean_fill
+
+    torch.manual_seed(1)
+    x = torch.rand(3, 9, 7, 1, dtype=torch.float64)
+    mask = torch.rand(3, 9, 7) > 0.5
+    mask[2] = False
+    y = masked_mean_fill(x, mask)
+    for b in range(3):
+        assert torch.allclose(y[b], masked_mean_fill(x[b], mask[b]), atol=1e-15)
+    assert torch.equal(y[2], x[2])
