@@ -568,7 +568,9 @@ int matpbr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, 
                           float weight_decay, void* stream);
 /* the same with SaveBest's weight snapshot in the same pass: best[i] = p[i] (the weights that produced this iteration's render)
  * when stats[8] (improved) is set, before p is updated (best nullable; best needs stats).  With `stats`, an image whose EarlyStopping
- * fired in an earlier iteration (stats[13] >= 2) rests: no update, no step count (the reference's loop has left by then, :250-254,548-555) */
+ * fired in an earlier iteration (stats[13] >= 2) rests: no update, no step count (the reference's loop has left by then, :250-254,548-555);
+ * and the 1-based step of the bias corrections is the row's iteration counter stats[14] -- the caller's iteration commits its statistics
+ * (matpbr_brdf_loss_stats / the phase steps) ONCE before this call and starts its optimiser with its statistics row -- hyper[1] is kept in step. */
 int matpbr_adamw_step_snapshot_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2,
                                    float eps, float weight_decay, float* best, const float* stats, void* stream);
 

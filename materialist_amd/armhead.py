@@ -75,21 +75,33 @@ class ArmMlpPhase:
                            # 0: as the backward products (`_PosMlpHipFn.PRODUCTS`, three bf16 pieces).  Class switch: the tests run both
 
     @staticmethod
-    def supported(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> bool:
-        if gt_image.ndim != 3 or not gt_image.is_cuda or not scene.use_mesh_normal or "n" in optimize_part:
-            return False
+    def why_not(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> Optional[str]:
+        """None when the launch-by-launch phase takes this part; otherwise what sends it to the autograd composition (several times slower:
+        bench.py modes.pos_mlp_exact_f32 is that class of loop) -- optimize.py says so in the run's log."""
+        if gt_image.ndim != 3:
+            return "a batch of images (the network optimises one image per process, as the reference does)"
+        if not gt_image.is_cuda:
+            return "the image is not on a GPU"
+        if not scene.use_mesh_normal or "n" in optimize_part:
+            return "predicted normals / a part that moves the normal map (the eight-output 'armn' network: its first layer reads 18 inputs, the fused layer kernels 16)"
         if getattr(net, "output_type", None) != "arm" or not _PosMlpHipFn.PRODUCTS:
-            return False
+            return "not the five-output 'arm' network on the split-operand kernels"
         M = gt_image.shape[0] * gt_image.shape[1]
         if M % 128 or M < _PosMlpHipFn.MIN_ROWS:
-            return False
+            return f"{M} pixels: the layer kernels take whole 128-row tiles of at least {_PosMlpHipFn.MIN_ROWS} rows"
         L = net.n_layers
         d0 = getattr(net, "lin0").linear.weight.shape[1]
         for l in range(L - 1):
             n = getattr(net, f"lin{l}").linear.weight.shape[0]
             if (n + d0 if (l + 1) in net.skip else n) != 256:
-                return False
-        return getattr(net, f"lin{L - 1}").weight.shape == (5, 256) and d0 <= 16
+                return "hidden layers that are not 256 wide"
+        if getattr(net, f"lin{L - 1}").weight.shape != (5, 256) or d0 > 16:
+            return "an output layer that is not 256 -> 5, or more than 16 inputs"
+        return None
+
+    @staticmethod
+    def supported(scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, optimize_part: str, mask) -> bool:
+        return ArmMlpPhase.why_not(scene, gt_image, net, optimize_part, mask) is None
 
     def __init__(self, scene: _render.Scene, gt_image: torch.Tensor, net: torch.nn.Module, start_arm: torch.Tensor, fixed: Dict[str, torch.Tensor],
                  optimize_part: str = "arm", spp: int = 64, lr: float = 3e-4, scale_delta: float = 0.1, patience: int = 0,

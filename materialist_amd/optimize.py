@@ -221,6 +221,11 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
 
     # ------------------------------------------------------------------ hot loop B (:347-468), device-resident
     def brdf_part_runner_mlp(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
+        from .armhead import ArmMlpPhase
+
+        why = ArmMlpPhase.why_not(scene, gt, brdf_net, part, mask)
+        if why is not None:           # not silently: the composition is several times slower than the launch-by-launch phase
+            say(f"loop {loop_num}: part {part!r} (pos_mlp) runs the autograd composition, not the launch-by-launch phase: {why}")
         ph = _loop.pos_mlp_brdf_phase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in ("albedo", "roughness", "metallic")},
                                       optimize_part=part, spp=spp, scale_delta=scale_delta, patience=patience, min_delta=min_delta,
                                       best_mse=saver.best_loss, history_len=n_epochs, mask=mask)
@@ -256,7 +261,9 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
 
     def brdf_part_runner_normal(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
         """Parts that optimise the normal map (output_type 'armn', use_mesh_normal False; :335-340,378-379,406-409), and `--use_mask` on
-        a batch: the autograd render with the torch-composed loss (BrdfPhase) and the reference's per-epoch host EarlyStopping."""
+        predicted normals: the autograd render with the torch-composed loss (BrdfPhase) and the reference's per-epoch host EarlyStopping."""
+        say(f"loop {loop_num}: part {part!r} runs the autograd composition on the operator face (a mask under predicted normals, or 'n' alone under "
+            "the geometric normals): several times slower than the fused phases")
         ph = _loop.BrdfPhase(scene, gt, mat["albedo"], mat["roughness"], mat["metallic"], None if scene.use_mesh_normal else mat["normal"],
                              optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask,
                              originals=originals)
@@ -284,6 +291,10 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
 
     def brdf_part_runner_mlp_normal(loop_num: int, part: str, patience: int, min_delta: float, n_epochs: int):
         """pos_mlp with output_type 'armn' (:165-172,493-506): the net predicts the normal map as well."""
+        from .armhead import ArmMlpPhase
+
+        say(f"loop {loop_num}: part {part!r} (pos_mlp) runs PosMlpNormalPhase (render, losses and layer products on the C ABI, chained by autograd), "
+            f"not the launch-by-launch phase: {ArmMlpPhase.why_not(scene, gt, brdf_net, part, mask)}")
         fixed_keys = ("albedo", "roughness", "metallic") + (() if scene.use_mesh_normal else ("normal",))
         ph = _loop.PosMlpNormalPhase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in fixed_keys},
                                      optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask)
