@@ -30,7 +30,17 @@ def assert_close(got, ref, rtol=RTOL, what=""):
     scale = np.abs(ref).mean()
     err = np.abs(got - ref) / np.maximum(np.abs(ref), scale + 1e-30)
     assert np.isfinite(got).all(), f"{what}: non-finite values"
+    _report(what, err.max(), rtol)
     assert err.max() <= rtol, f"{what}: max scaled rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def _report(what, measured, bound):
+    """MATPBR_TOLERANCE_REPORT=<file>: one line per comparison, the measured maximum beside its bound (how the bounds in this file were set:
+    DESIGN.md section 5)."""
+    path = os.environ.get("MATPBR_TOLERANCE_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{what}\t{float(measured):.3e}\t{float(bound):.1e}\n")
 
 
 def _scene_arrays(H, W, image_id=0, unit_random_normals=True):
@@ -86,11 +96,14 @@ def test_brdf_terms_match_reference_grids(golden_dir):
     g = np.load(os.path.join(golden_dir, "brdf_scalar_grids.npz"))
     R, C = np.meshgrid(g["r"], g["c"], indexing="ij")
     out = ops.brdf_terms(_t(C.reshape(-1), dev), _t(np.full(C.size, 0.5), dev), _t(R.reshape(-1), dev), _t(np.full(C.size, 0.04), dev)).cpu().numpy()
-    # D_GGX near cos = 1 at small r is the ill-conditioned literal form (condition number 1/alpha^2): 1e-3 away from the peak, 2e-2 on it
+    # D_GGX near cos = 1 at small r is the ill-conditioned literal form (condition number 1/alpha^2): measured 8.5e-4 on the peak (round 5;
+    # bound 2e-2 until then), an order below it elsewhere -- 1e-3 everywhere
     D = g["D"].reshape(-1)
     peak = (R.reshape(-1) < 0.15) & (C.reshape(-1) > 0.95)
     errD = np.abs(out[:, 0] - D) / np.maximum(np.abs(D), 1e-12)
-    assert errD[~peak].max() < 1e-3 and errD[peak].max() < 2e-2
+    _report("D_GGX away from the peak", errD[~peak].max(), 1e-3)
+    _report("D_GGX on the peak (r < 0.15, cos > 0.95)", errD[peak].max(), 1e-3)
+    assert errD[~peak].max() < 1e-3 and errD[peak].max() < 1e-3, (errD[~peak].max(), errD[peak].max())
     np.testing.assert_allclose(out[:, 1], g["G1"].reshape(-1), rtol=1e-5)
     np.testing.assert_allclose(out[:, 2], g["Gs"][2].reshape(-1), rtol=1e-5)       # Gs_nol[2] = 0.5
     fr = ops.brdf_terms(_t(g["c"], dev), _t(g["c"], dev), _t(np.full(33, 0.5), dev), _t(np.full(33, 0.5), dev)).cpu().numpy()
@@ -106,8 +119,8 @@ def test_sample_brdf_matches_reference_golden(golden_dir):
     wi, pdf, w = ops.sample_brdf(_t(g["sample1"], dev), _t(g["sample2"].T, dev), _t(g["wo"].T, dev), _t(g["n"].T, dev),
                                  _t(g["a"].T, dev), _t(g["r"], dev), _t(g["m"], dev))
     assert np.abs(wi.cpu().numpy() - g["wi"].T).max() < 2e-5
-    assert_close(w, g["weight"].T, rtol=2e-3, what="MC weight")
-    assert_close(pdf, g["pdf"], rtol=5e-3, what="pdf")
+    assert_close(w, g["weight"].T, rtol=1e-4, what="MC weight")            # measured 6.2e-6
+    assert_close(pdf, g["pdf"], rtol=1e-3, what="pdf")                     # measured 6.1e-5
 
 
 def test_attached_sampling_derivative_matches_the_reference_autograd(golden_dir):
@@ -131,7 +144,8 @@ def test_attached_sampling_derivative_matches_the_reference_autograd(golden_dir)
     for got, ref, nm in ((d_pdf, ref_pdf, "d pdf / d r"), (d_w, ref_w, "d weight / d r")):
         scale = np.abs(ref[ok]).mean()
         err = np.abs(got[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), scale)
-        assert err.max() <= 2e-3, f"{nm}: {err.max():.3e}"
+        _report(nm, err.max(), 1e-3)
+        assert err.max() <= 1e-3, f"{nm}: {err.max():.3e}"               # measured: d pdf / d r 8.0e-4 (fp32 forward mode against the reference's fp32 autograd), d weight / d r 5.0e-5
     # and it is not the detached derivative: on GGX lanes the two differ visibly
     assert np.abs(ref_wi[ok & ~diffuse]).max() > 0.1
 
@@ -213,7 +227,7 @@ def test_shade_bwd_matches_oracle(oracle64, spp):
     names = ("d_a", "d_r", "d_m", "d_n", "d_light")
     got_all = ops.shade_bwd(*args, spp, want_mat=True, want_n=True, want_light=True)
     for nm, got, rf in zip(names, got_all, ref):
-        assert_close(got, rf, rtol=2e-3 if nm in ("d_r", "d_n") else RTOL, what=f"{nm} spp{spp}")
+        assert_close(got, rf, rtol=RTOL, what=f"{nm} spp{spp}")              # d_r, d_n measured <= 3.9e-5 (2e-3 until round 5)
     # every flag combination runs its own kernel instantiation: same numbers as the all-on variant
     for want_mat, want_n, want_light in [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1)]:
         got = ops.shade_bwd(*args, spp, want_mat=bool(want_mat), want_n=bool(want_n), want_light=bool(want_light))
@@ -248,7 +262,9 @@ def test_attached_sampling_flag_gives_the_exact_r_derivative_of_the_render(oracl
     d_a0, d_r0, d_m0, _, _ = ops.shade_bwd(*args, spp)
     d_a1, d_r1, d_m1, _, _ = ops.shade_bwd(*args, spp, attached=True)
     assert torch.equal(d_a0, d_a1) and torch.equal(d_m0, d_m1)
-    assert_close(d_r1, ref, rtol=3e-3, what=f"attached d_r spp{spp}")
+    # measured 1.37e-3 at either sample count: one pixel whose GGX sample sits next to the pdf > 1e-6 mask of :1338, where the fp32 forward-mode
+    # derivative and the fp64 oracle's differ in which side a sample falls; the 99.9th percentile is below 1e-4
+    assert_close(d_r1, ref, rtol=2e-3, what=f"attached d_r spp{spp}")
     a_, d_ = d_r1.double().flatten(), d_r0.double().flatten()
     cos = float((a_ * d_).sum() / (a_.norm() * d_.norm()))
     print(f"attached vs detached d_r at spp {spp}: cosine {cos:.4f}, norm ratio {float(a_.norm() / d_.norm()):.4f}")
@@ -267,7 +283,7 @@ def test_attached_sampling_flag_gives_the_exact_r_derivative_of_the_render(oracl
         out.backward(_t(d_out, dev))
     finally:
         render.ATTACHED_SAMPLING = False
-    assert_close(r_t.grad, ref, rtol=3e-3, what="attached d_r through render_w_brdf")
+    assert_close(r_t.grad, ref, rtol=2e-3, what="attached d_r through render_w_brdf")       # (the same pixel: 1.37e-3)
 
 
 def test_extreme_materials_and_back_facing_normals(oracle64):
@@ -294,7 +310,7 @@ def test_extreme_materials_and_back_facing_normals(oracle64):
     assert_close(ops.shade_fwd(*args, spp), ref_f, what="fwd, extreme maps")
     got = ops.shade_bwd(*args, _t(d_out, dev), spp, want_mat=True, want_n=True, want_light=True)
     for nm, g_, rf in zip(("d_a", "d_r", "d_m", "d_n", "d_light"), got, ref_b):
-        assert_close(g_, rf, rtol=3e-3 if nm in ("d_r", "d_n") else RTOL, what=f"{nm}, extreme maps")
+        assert_close(g_, rf, rtol=RTOL, what=f"{nm}, extreme maps")          # measured: d_r 2.0e-5, d_n 2.9e-4 (3e-3 until round 5)
 
 
 def test_non_unit_normal_map_is_normalised(oracle64):
@@ -310,7 +326,7 @@ def test_non_unit_normal_map_is_normalised(oracle64):
     args = [_t(x, dev) for x in (sc.albedo, sc.roughness, sc.metallic, n * scale, sc.light)]
     assert_close(ops.shade_fwd(*args, spp), ref_f, what="fwd")
     got = ops.shade_bwd(*args, _t(d_out, dev), spp, want_mat=True, want_n=True, want_light=False)
-    assert_close(got[3], ref_b[3], rtol=2e-3, what="d_n through normalisation")
+    assert_close(got[3], ref_b[3], rtol=RTOL, what="d_n through normalisation")
 
 
 def test_autograd_operator_face(oracle64):
@@ -333,9 +349,9 @@ def test_autograd_operator_face(oracle64):
     assert_close(img, ref_img, what="render_w_brdf")
     d_a, d_r, d_m, d_n, d_l = oracle64.shade_bwd(sc.albedo, sc.roughness, sc.metallic, n, coef, g_out.cpu().numpy(), spp)
     assert_close(a.grad, d_a, what="a.grad")
-    assert_close(r.grad, d_r, rtol=2e-3, what="r.grad")
+    assert_close(r.grad, d_r, rtol=RTOL, what="r.grad")
     assert_close(m.grad, d_m, what="m.grad")
-    assert_close(nn.grad, d_n, rtol=2e-3, what="n.grad")
+    assert_close(nn.grad, d_n, rtol=RTOL, what="n.grad")
     d_env = (sh.envmap_to_sh_matrix(16, 32).T @ d_l).reshape(16, 32, 3)
     assert_close(env.grad, d_env, what="envmap.grad")
     # use_mesh_normal=True shades with the geometric normal, not the n map (F10)
@@ -349,7 +365,7 @@ def test_autograd_operator_face(oracle64):
 def test_operator_face_keeps_its_models_between_calls_and_rebuilds_them_when_the_light_changes():
     """render_w_brdf called again and again under one light (the reference's BRDF loop, inverse_img_w_mi.py:384-386): from the second call
     with the same (light, normals) on, the scene renders from cached per-pixel models and differentiates through their jac planes -- within
-    1e-3 of the exact render, 3e-3 of the exact d_a / d_m and 3e-2 of the exact d_r (worst pixel); a new light (another tensor, or the same tensor modified in place)
+    1e-3 of the exact render and of the exact d_a / d_m, 3e-3 of the exact d_r (worst pixel); a new light (another tensor, or the same tensor modified in place)
     invalidates the cache, and the renders follow the new light."""
     from materialist_amd import ops, render
 
@@ -374,23 +390,27 @@ def test_operator_face_keeps_its_models_between_calls_and_rebuilds_them_when_the
         d_a, d_r, d_m = ops.shade_bwd_jac(a.detach(), r.detach(), m.detach(), jac, g_out)
         e_img = float(((img.detach() - exact).abs() / torch.maximum(exact.abs(), exact.abs().mean())).max())
         err = lambda got, ref: float(((got - ref.reshape(got.shape)).abs() / torch.maximum(ref.abs(), ref.abs().mean()).reshape(got.shape)).max())
-        # d out / d r of a model is the detached derivative AT ITS REFERENCE ROUGHNESS (half precision, zeroth order in r - r_ref, as in the
-        # fused loops): a few 1e-3 a step away from r_ref where the specular sums bend fastest; d_a and d_m come from fp32 P and S0 - S1
-        return e_img, max(err(a.grad, d_a), err(m.grad, d_m), err(r.grad, d_r) / 10.0)
+        # d out / d r of a model is the detached derivative to FIRST order in r - r_ref (round 5; half-precision value, e5m2 slope, as in the
+        # fused loops): measured 1.1e-3 on the worst pixel (3e-2 was the bound of the zeroth-order models), bound 3e-3; d_a and d_m come from
+        # fp32 P and S0 - S1: measured 1.3e-4, bound 1e-3
+        _report("operator-face cache: render", e_img, 1e-3)
+        _report("operator-face cache: d_a, d_m", max(err(a.grad, d_a), err(m.grad, d_m)), 1e-3)
+        _report("operator-face cache: d_r (worst pixel)", err(r.grad, d_r), 3e-3)
+        return e_img, max(err(a.grad, d_a), err(m.grad, d_m), err(r.grad, d_r) / 3.0)
 
     for step in range(4):                       # call 0: a light seen for the first time (direct); call 1 builds the cache; 2, 3 render from it
         e_img, e_g = call(L1, step)
-        assert e_img < 1e-3 and e_g < 3e-3, (step, e_img, e_g)
+        assert e_img < 1e-3 and e_g < 1e-3, (step, e_img, e_g)
     assert scene.cache_builds == 1
     scene._set("emitter.data", L2)              # another light: the models of L1 must not be used
     for step in range(3):
         e_img, e_g = call(L2, step)
-        assert e_img < 1e-3 and e_g < 3e-3, ("L2", step, e_img, e_g)
+        assert e_img < 1e-3 and e_g < 1e-3, ("L2", step, e_img, e_g)
     assert scene.cache_builds == 2
     L2.mul_(1.25)                               # the same tensor, modified in place (an optimiser step): a new version
     for step in range(3):
         e_img, e_g = call(L2, step)
-        assert e_img < 1e-3 and e_g < 3e-3, ("L2 in place", step, e_img, e_g)
+        assert e_img < 1e-3 and e_g < 1e-3, ("L2 in place", step, e_img, e_g)
     assert scene.cache_builds == 3
     # a call without gradients under a cached light: the exact render (GGX samples + cached diffuse coefficients)
     with torch.no_grad():
@@ -1108,7 +1128,7 @@ def test_fused_env_phase_matches_torch_composition():
     assert gph.poll()["iters"].tolist() == [8]
     assert (raw_c - raw_d).abs().max().item() < 1e-6
     assert torch.allclose(gph.history(), eag.history(), rtol=1e-5)
-    assert_close(fused.pred, pred.detach().cpu().numpy(), rtol=5e-3, what="last render")
+    assert_close(fused.pred, pred.detach().cpu().numpy(), rtol=1e-3, what="last render")
 
 
 def test_inverse_image_writes_the_reference_output_layout(tmp_path):
@@ -1353,8 +1373,8 @@ def test_pos_mlp_normal_phase_on_the_c_abi_matches_the_autograd_composition(part
         diff = (v - runs[False][1][k]).abs()
         assert diff.median().item() < 2e-6 and (diff > 3e-5).float().mean().item() < 0.15, (k, diff.max().item(), (diff > 3e-5).float().mean().item())
     for k in ("albedo", "roughness", "metallic", "normal"):
-        assert_close(runs[True][2][k].reshape(-1), runs[False][2][k].reshape(-1).cpu().numpy(), rtol=3e-3, what=f"best {k}")   # (the maps of weights that differ as above)
-    assert_close(runs[True][2]["rendered_img"], runs[False][2]["rendered_img"].cpu().numpy(), rtol=3e-3, what="best render")
+        assert_close(runs[True][2][k].reshape(-1), runs[False][2][k].reshape(-1).cpu().numpy(), rtol=1e-3, what=f"best {k}")   # (the maps of weights that differ as above)
+    assert_close(runs[True][2]["rendered_img"], runs[False][2]["rendered_img"].cpu().numpy(), rtol=1e-3, what="best render")
 
 
 def test_pos_mlp_phase_matches_torch_composition():
@@ -2607,7 +2627,7 @@ def test_env_mlp_phase_matches_the_autograd_composition():
     assert ph._graph is not None and ph.poll()["iters"].tolist() == [7]
     for (ka, va), (kb, vb) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
         assert ka == kb and (va - vb).abs().max().item() < 2e-5, ka       # 7 Adam steps of <= 1e-3
-    assert_close(ph.head(), env.detach().cpu().numpy(), rtol=2e-3, what="envmap of the last iteration")
+    assert_close(ph.head(), env.detach().cpu().numpy(), rtol=1e-3, what="envmap of the last iteration")
     assert ph.best_env.shape == (16, 32, 3) and ph.best_img.shape == (H, W, 3)
     # the module keeps working as a module (parameters are views of the flat buffer): state_dict round trip
     before = net_b(ones).detach().clone()
