@@ -1880,7 +1880,7 @@ constexpr size_t kWgSmem = 2 * kWgStage * sizeof(uint4);
 #ifndef MATPBR_WG_DEPTH
 #define MATPBR_WG_DEPTH 2
 #endif
-constexpr int kWgDepth = MATPBR_WG_DEPTH;      // (measurement builds: tools/wg_ab.sh)
+constexpr int kWgDepth = MATPBR_WG_DEPTH;      // (measurement builds: tools/ab.sh)
 constexpr int kWgThreads = 512;
 __device__ __forceinline__ int wg_perm(int i) { return (i & 16) + 2 * (i & 7) + ((i >> 3) & 1); }   // fragment lane -> column within a tile of 32
 // EARLY: stage before the products of a step instead of after them.  The two waves of a SIMD (w and w + 4) meet at the barrier of
@@ -2475,8 +2475,9 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
       const float* srow = S + m * lds;
       const bool live = m0 + 4 * u < m_end;
       float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+      constexpr int JA = DGRAD ? kOutJ : J;                  // DGRAD: at most kOutJ columns of S are valid (the others are padding: their sums stay zero)
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
+      for (int j = 0; j < JA; ++j) {
         const float sv = srow[j];
         acc[j].x = fmaf(sv, b[u].x, acc[j].x);
         acc[j].y = fmaf(sv, b[u].y, acc[j].y);

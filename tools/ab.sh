@@ -1,12 +1,14 @@
 #!/bin/bash
-# measurement builds of posmlp_kernels.hip BESIDE the product library (MATPBR_LIB): usage: bash tools/wg_ab.sh "<-D flags 1>" "<-D flags 2>" ...
+# measurement builds of posmlp_kernels.hip BESIDE the product library (MATPBR_LIB).  usage: bash tools/ab.sh <timing script> "<-D flags 1>" ...
+# (the product library is what build.py built from the tree; "== product" runs it first)
 cd "$GRAFT_REPO_ROOT" || exit 1
 B=materialist_amd/_build
-echo "== product"; python tools/wg_time.py 2>&1 | tail -1
+T=$1; shift
+echo "== product"; python $T 2>&1 | tail -1
 i=0
 for FL in "$@"; do
   i=$((i+1))
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-gpu-rdc $FL -c materialist_amd/csrc/posmlp_kernels.hip -o /tmp/pk_v$i.o || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc -o /tmp/libmatpbr_w$i.so $B/matpbr_kernels.o /tmp/pk_v$i.o $B/posmlp_chain.o $B/mesh_host.o || exit 1
-  echo "== $FL"; MATPBR_LIB=/tmp/libmatpbr_w$i.so python tools/wg_time.py 2>&1 | tail -1
+  echo "== $FL"; MATPBR_LIB=/tmp/libmatpbr_w$i.so python $T 2>&1 | tail -1
 done
