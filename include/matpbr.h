@@ -530,18 +530,36 @@ int matpbr_mlp_chain_fwd(const float* x0, int ldx0, const void* images, float* c
  *                                    the tile maxima of the g_prev it writes, for the next product
  *   matpbr_mlp_first_layer_bwd_blk   matpbr_mlp_first_layer_bwd_bx likewise (sgn = 1)
  *   matpbr_mlp_layer_bwd_weight_blk  matpbr_mlp_layer_bwd_weight_bx likewise: x (sines, |x| <= 65504) as it is, g under one exponent per slab of
- *                                    rows (the largest of its tiles' maxima); M a multiple of 128 */
+ *                                    rows (the largest of its tiles' maxima); M a multiple of 128
+ * Every one of these ends in a small launch that folds per-workgroup partial sums (a weight gradient's 256 slabs, the column sums behind a bias
+ * gradient) -- nine latency-bound launches per iteration whose results nothing but the optimiser reads.  `defer` (nullable: fold now) receives the
+ * fold as a record instead (matpbr_mlp_first_layer_bwd_blk: two records; kind MATPBR_REDUCE_NONE where there is nothing to fold); the caller keeps
+ * the workspaces of the deferred calls apart and untouched, and runs all records in ONE launch before its optimiser step:
+ *   matpbr_mlp_reduce_jobs           at most 16 records; the same sums in the same order as the launches they replace (the same bits) */
+#define MATPBR_REDUCE_NONE (-1)
+#define MATPBR_REDUCE_WGRAD 0   /* src [groups][256 x 256] -> dst[n * n2 + k], n < n0, k < n1 */
+#define MATPBR_REDUCE_COLSUM 1  /* src [groups][256] -> dst[c], c < n0 */
+#define MATPBR_REDUCE_SKINNY 2  /* matpbr_mlp_skinny_bwd_weight's fold: src [groups][n0][256] -> dst[j ld_j + c ld_c] (j < n1, c < n2), src_b [groups][n0] -> dst_b[j],
+                                   src_g [groups][256] -> dst_g[c] (c < n3; nullable) */
+typedef struct MatpbrReduceJob {
+    int kind, groups;
+    const float *src, *src_b, *src_g;
+    float *dst, *dst_b, *dst_g;
+    int n0, n1, n2, n3;
+    long ld_j, ld_c;
+} MatpbrReduceJob;
+int matpbr_mlp_reduce_jobs(const MatpbrReduceJob* jobs, int n_jobs, void* stream);
 int matpbr_mlp_out_layer_bwd_tmax(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
                                   int ldg, void* g_tile_max, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace,
-                                  size_t workspace_bytes, long M, int J, int n_prev, void* stream);
+                                  size_t workspace_bytes, long M, int J, int n_prev, MatpbrReduceJob* defer, void* stream);
 int matpbr_mlp_layer_bwd_input_blk(const float* g, int ldg, const void* g_tile_max, const void* wtsplit, const float* s_prev, float* g_prev, int ldo,
                                    void* out_tile_max, float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
-                                   void* stream);
+                                   MatpbrReduceJob* defer, void* stream);
 int matpbr_mlp_first_layer_bwd_blk(const float* g, int ldg, const void* g_tile_max, const void* wtsplit, const float* s_prev, int lds, const float* x0,
                                    int ldx0, float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes,
-                                   void* workspace2, size_t workspace2_bytes, long M, int n0, int n_red, void* stream);
+                                   void* workspace2, size_t workspace2_bytes, long M, int n0, int n_red, MatpbrReduceJob* defer2, void* stream);
 int matpbr_mlp_layer_bwd_weight_blk(const float* g, int ldg, const void* g_tile_max, const float* x, int ldx, float* d_w, int ldw, void* workspace,
-                                    size_t workspace_bytes, long M, int N, int K, void* stream);
+                                    size_t workspace_bytes, long M, int N, int K, MatpbrReduceJob* defer, void* stream);
 /* up to 8 splits in one launch (host arrays of n_jobs entries; transposed[j] = the flags of matpbr_mlp_split_weights_fmt for job j:
  * 0 / 1 as before, + MATPBR_WSPLIT_F16X2 for the f16 form): the weights of every layer change together, once per optimiser step */
 int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const int* N, const int* K, const int* transposed,

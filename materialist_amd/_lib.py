@@ -40,6 +40,13 @@ class MatpbrError(RuntimeError):
 
 
 # name -> (restype, argtypes); must list every symbol include/matpbr.h declares
+class ReduceJob(ctypes.Structure):
+    """include/matpbr.h `MatpbrReduceJob`: a deferred fold of per-workgroup partial sums (matpbr_mlp_reduce_jobs)."""
+    _fields_ = [("kind", ctypes.c_int), ("groups", ctypes.c_int), ("src", ctypes.c_void_p), ("src_b", ctypes.c_void_p), ("src_g", ctypes.c_void_p),
+                ("dst", ctypes.c_void_p), ("dst_b", ctypes.c_void_p), ("dst_g", ctypes.c_void_p), ("n0", ctypes.c_int), ("n1", ctypes.c_int),
+                ("n2", ctypes.c_int), ("n3", ctypes.c_int), ("ld_j", ctypes.c_long), ("ld_c", ctypes.c_long)]
+
+
 SIGNATURES = {
     "matpbr_version": (ctypes.c_int, []),
     "matpbr_strerror": (ctypes.c_char_p, [ctypes.c_int]),
@@ -120,14 +127,15 @@ SIGNATURES = {
     "matpbr_mlp_split_weights_t": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_out_layer_bwd_tmax": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, _c_f,
                                                      ctypes.c_long, ctypes.c_long, _c_f, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_int,
-                                                     ctypes.c_int, ctypes.c_void_p]),
+                                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "matpbr_mlp_reduce_jobs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_layer_bwd_input_blk": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_f, _c_f, ctypes.c_int, ctypes.c_void_p, _c_f,
-                                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+                                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_first_layer_bwd_blk": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f,
                                                       ctypes.c_long, ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
-                                                      ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+                                                      ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_layer_bwd_weight_blk": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p,
-                                                       ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+                                                       ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_chain_images_bytes": (ctypes.c_size_t, []),
     "matpbr_mlp_chain_prep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_chain_fwd": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, _c_f, ctypes.c_int, _c_f, _c_f, _c_f,

@@ -71,6 +71,9 @@ class ArmMlpPhase:
                            # (include/matpbr.h `matpbr_mlp_layer_bwd_input_blk`); needs PACKED, FUSED_OUT_BWD, FUSED_FIRST_BWD.  Class switch
     FWD_CHAIN = True       # the whole forward pass as one launch with the activations in registers between the layers
                            # (include/matpbr.h `matpbr_mlp_chain_fwd`; needs PACKED, FWD_PRODUCTS 3 and the reference's 15-241-256-241-256-5 shape)
+    DEFER_REDUCE = True    # the folds of the backward pass's partial sums (weight gradients' slabs, column sums behind the bias gradients) in ONE
+                           # launch before the optimiser step instead of one behind every product (include/matpbr.h `matpbr_mlp_reduce_jobs`); needs
+                           # BWD_F16.  Class switch: the same bits either way (tests/test_gpu_parity.py)
     FWD_PRODUCTS = 3       # forward sine layers on two f16 pieces per operand, three products (include/matpbr.h `matpbr_mlp_split_weights_fmt`);
                            # 0: as the backward products (`_PosMlpHipFn.PRODUCTS`, three bf16 pieces).  Class switch: the tests run both
 
@@ -195,6 +198,7 @@ class ArmMlpPhase:
                             (_ct.c_int * nj)(*[j[3] for j in jobs]), (_ct.c_int * nj)(*[j[4] for j in jobs]), (_ct.c_void_p * nj)(*[j[5] for j in jobs]), nj)
         # block exponents of the gradient matrices (one row of tile maxima per sine layer's dL/d pre), zeroed once per iteration
         self.tmax = torch.zeros(max(self.L - 1, 1), M // 128, dtype=torch.int32, device=dev) if self.bwd_f16 else None
+        self._jobs = (_lib.ReduceJob * 16)()                     # the backward pass's deferred folds (DEFER_REDUCE)
         self.maps = {"albedo": E(H, W, 3), "roughness": E(H, W, 1), "metallic": E(H, W, 1)}
         keys = {"a": "albedo", "r": "roughness", "m": "metallic"}
         self.live = [keys[c] for c in self.part if c in keys]
@@ -284,9 +288,14 @@ class ArmMlpPhase:
         # the output layer in ONE pass over the last sine layer's activations: its weight / bias gradient, dL/d pre of that sine layer and its
         # bias gradient (separately: a second 268 MB read of the sines, a transposing copy of the output weight, two reduce launches)
         f16 = self.bwd_f16
+        import ctypes as _ct
+
+        jobs, nj = (self._jobs, 0) if (f16 and self.DEFER_REDUCE) else (None, 0)
+        slot = (lambda k: (_ct.cast(_ct.byref(jobs, k * _ct.sizeof(_lib.ReduceJob)), _ct.c_void_p), f"_d{k}")) if jobs is not None else (lambda k: None)
         if f16:
             self.tmax.zero_()
-            o.mlp_out_layer_bwd_tmax(self.d_x, self.bufs[-1], wp, g_prev, self.tmax[self.L - 2], gw, gb, gb_prev, 5, self.ns[-1])
+            o.mlp_out_layer_bwd_tmax(self.d_x, self.bufs[-1], wp, g_prev, self.tmax[self.L - 2], gw, gb, gb_prev, 5, self.ns[-1], defer=slot(nj))
+            nj += 1
         elif self.FUSED_OUT_BWD:
             o.mlp_out_layer_bwd(self.d_x, self.bufs[-1], None if self.packed else self.cbufs[-1], wp, g_prev, gw, gb, gb_prev, 5, self.ns[-1])
         else:
@@ -299,7 +308,8 @@ class ArmMlpPhase:
             wp, _ = self.views[l]
             gw, _ = self.gviews[l]
             if f16:
-                o.mlp_layer_bwd_weight_blk(g, self.tmax[l], self.bufs[l - 1], n_red, 256, out=gw)
+                o.mlp_layer_bwd_weight_blk(g, self.tmax[l], self.bufs[l - 1], n_red, 256, out=gw, defer=slot(nj))
+                nj += 1
             else:
                 o.mlp_layer_bwd_weight_bx(g, self.bufs[l - 1], n_red, 256, P, out=gw)
             n_prev = self.ns[l - 1]
@@ -307,10 +317,14 @@ class ArmMlpPhase:
             c_prev = self.bufs[l - 1] if self.packed else self.cbufs[l - 1]
             if f16:
                 if l == 1:
-                    o.mlp_first_layer_bwd_blk(g, self.tmax[l], self.wsplit_b[l], c_prev, self.x0p, self.gviews[0][0], self.d0, n_prev, n_red, gb)
+                    o.mlp_first_layer_bwd_blk(g, self.tmax[l], self.wsplit_b[l], c_prev, self.x0p, self.gviews[0][0], self.d0, n_prev, n_red, gb, defer=slot(nj))
+                    nj += 2
+                    if jobs is not None:
+                        o.mlp_reduce_jobs(jobs, nj, self.flat)
                     return
                 g_prev = self.gbufs[0] if g is self.gbufs[1] else self.gbufs[1]
-                o.mlp_layer_bwd_input_blk(g, self.tmax[l], self.wsplit_b[l], c_prev, g_prev, n_prev, n_red, gb, self.tmax[l - 1])
+                o.mlp_layer_bwd_input_blk(g, self.tmax[l], self.wsplit_b[l], c_prev, g_prev, n_prev, n_red, gb, self.tmax[l - 1], defer=slot(nj))
+                nj += 1
                 g, n_red = g_prev, n_prev
                 continue
             if l == 1 and self.FUSED_FIRST_BWD:

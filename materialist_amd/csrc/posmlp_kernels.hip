@@ -820,12 +820,14 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad_tn(const float* __restrict__
       }
 }
 
-__global__ __launch_bounds__(1024) void mlp_wgrad_reduce(const float* __restrict__ partial, int slabs, float* __restrict__ dW, int N, int K,
-                                                         int ldw) {
+// The folds of the per-workgroup partial sums the gradient kernels leave behind, as device functions over a workgroup of 1024 threads and 1024
+// floats of LDS: launched one by one behind their producers (the entry points without a `defer` record), or all of an iteration's together in
+// mlp_reduce_jobs_kernel (matpbr_mlp_reduce_jobs: nothing but the optimiser reads a weight or bias gradient) -- the same sums in the same order.
+__device__ __forceinline__ void wgrad_reduce_body(float* red, const float* __restrict__ partial, int slabs, float* __restrict__ dW, int N, int K, int ldw,
+                                                  int block) {
   // 256 outputs per workgroup x 4 slices of the slabs (a chain of slabs / 16 dependent rounds instead of slabs / 4), LDS fold
-  __shared__ float red[4][256];
   const int t = threadIdx.x & 255, sl = threadIdx.x >> 8;
-  const int idx = blockIdx.x * 256 + t;   // over 256 x 256
+  const int idx = block * 256 + t;   // over 256 x 256
   const int per = (slabs + 3) / 4, c0 = sl * per, c1 = c0 + per < slabs ? c0 + per : slabs;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int c = c0;
@@ -836,19 +838,25 @@ __global__ __launch_bounds__(1024) void mlp_wgrad_reduce(const float* __restrict
     s3 += partial[(long)(c + 3) * 65536 + idx];
   }
   for (; c < c1; ++c) s0 += partial[(long)c * 65536 + idx];
-  red[sl][t] = (s0 + s1) + (s2 + s3);
+  red[sl * 256 + t] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   const int n = idx >> 8, k = idx & 255;
-  if (sl == 0 && n < N && k < K) dW[(long)n * ldw + k] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  if (sl == 0 && n < N && k < K) dW[(long)n * ldw + k] = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+}
+__global__ __launch_bounds__(1024) void mlp_wgrad_reduce(const float* __restrict__ partial, int slabs, float* __restrict__ dW, int N, int K,
+                                                         int ldw) {
+  __shared__ float red[1024];
+  wgrad_reduce_body(red, partial, slabs, dW, N, K, ldw, (int)blockIdx.x);
 }
 
-// column sums of the per-workgroup partials [groups, 256] -> out[n]: one workgroup per column, fixed-order tree
-__global__ __launch_bounds__(256) void mlp_colsum_reduce(const float* __restrict__ part, int groups, float* __restrict__ out) {
-  __shared__ float red[256];
-  const int col = blockIdx.x;
+// column sums of the per-workgroup partials [groups, 256] -> out[n]: one workgroup per column (its first 256 threads), fixed-order tree
+__device__ __forceinline__ void colsum_reduce_body(float* red, const float* __restrict__ part, int groups, float* __restrict__ out, int col) {
+  const bool act = threadIdx.x < 256;
   float s = 0.f;
-  for (int g = threadIdx.x; g < groups; g += 256) s += part[(long)g * 256 + col];
-  red[threadIdx.x] = s;
+  if (act) {
+    for (int g = threadIdx.x; g < groups; g += 256) s += part[(long)g * 256 + col];
+    red[threadIdx.x] = s;
+  }
   __syncthreads();
 #pragma unroll
   for (int w = 128; w > 0; w >>= 1) {
@@ -856,6 +864,10 @@ __global__ __launch_bounds__(256) void mlp_colsum_reduce(const float* __restrict
     __syncthreads();
   }
   if (threadIdx.x == 0) out[col] = red[0];
+}
+__global__ __launch_bounds__(256) void mlp_colsum_reduce(const float* __restrict__ part, int groups, float* __restrict__ out) {
+  __shared__ float red[256];
+  colsum_reduce_body(red, part, groups, out, (int)blockIdx.x);
 }
 
 // S = sin(pre), C = cos(pre) over [M, n] with independent row strides (the first layer, whose K = 15 product stays in the BLAS)
@@ -2546,12 +2558,12 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
 
 // out[j * ld_j + c * ld_c] = sum over slabs of partial[slab][j][c] (j < Jv, c < C); d_b[j] = sum of bpart[slab][j].  One
 // workgroup per (j, 64 columns): 16 slab slices x 64 columns, fixed order.
-__global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __restrict__ partial, const float* __restrict__ bpart, int slabs, int J, int Jv,
+__device__ __forceinline__ void skinny_reduce_body(float* red_, int block, const float* __restrict__ partial, const float* __restrict__ bpart, int slabs, int J, int Jv,
                                                              int C, float* __restrict__ out, long ld_j, long ld_c, float* __restrict__ d_b,
                                                              const float* __restrict__ gsum_part, int C2, float* __restrict__ d_b2) {
-  __shared__ float red[16][64];
-  int j = blockIdx.x >> 2;
-  const int cl = threadIdx.x & 63, c = (blockIdx.x & 3) * 64 + cl, sl = threadIdx.x >> 6;
+  float (*red)[64] = reinterpret_cast<float (*)[64]>(red_);
+  int j = block >> 2;
+  const int cl = threadIdx.x & 63, c = (block & 3) * 64 + cl, sl = threadIdx.x >> 6;
   if (j == J) {                                              // the extra workgroups: column sums of the fused input gradient -> its bias gradient
     partial = gsum_part; J = 1; j = 0; Jv = 1; C = C2; out = d_b2; ld_j = 0; ld_c = 1; d_b = nullptr;
   }
@@ -2573,7 +2585,7 @@ __global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __rest
     for (int u = 0; u < 16; ++u) t += red[u][cl];
     out[j * ld_j + c * ld_c] = t;
   }
-  if (d_b != nullptr && bpart != nullptr && (blockIdx.x & 3) == 0) {   // the bias gradient: 1024 threads over the slabs, LDS tree
+  if (d_b != nullptr && bpart != nullptr && (block & 3) == 0) {   // the bias gradient: 1024 threads over the slabs, LDS tree
     __syncthreads();
     float t = 0.f;
     for (int q2 = threadIdx.x; q2 < slabs; q2 += 1024) t += bpart[(size_t)q2 * J + j];
@@ -2592,6 +2604,46 @@ __global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __rest
       d_b[j] = u;
     }
   }
+}
+__global__ __launch_bounds__(1024) void mlp_skinny_tn_reduce(const float* __restrict__ partial, const float* __restrict__ bpart, int slabs, int J, int Jv,
+                                                             int C, float* __restrict__ out, long ld_j, long ld_c, float* __restrict__ d_b,
+                                                             const float* __restrict__ gsum_part, int C2, float* __restrict__ d_b2) {
+  __shared__ float red[1024];
+  skinny_reduce_body(red, (int)blockIdx.x, partial, bpart, slabs, J, Jv, C, out, ld_j, ld_c, d_b, gsum_part, C2, d_b2);
+}
+
+// Every fold of an iteration's backward pass in ONE launch (matpbr_mlp_reduce_jobs): workgroup -> job by the running count of workgroups
+constexpr int kMaxReduceJobs = 16;
+struct ReduceJobs {
+  MatpbrReduceJob j[kMaxReduceJobs];
+  int first[kMaxReduceJobs + 1];
+  int n;
+};
+__global__ __launch_bounds__(1024) void mlp_reduce_jobs_kernel(const ReduceJobs js) {
+  __shared__ float red[1024];
+  int k = 0;
+  while (k + 1 < js.n && (int)blockIdx.x >= js.first[k + 1]) ++k;          // (uniform)
+  const MatpbrReduceJob& q = js.j[k];
+  const int block = (int)blockIdx.x - js.first[k];
+  if (q.kind == MATPBR_REDUCE_WGRAD) wgrad_reduce_body(red, q.src, q.groups, q.dst, q.n0, q.n1, q.n2, block);
+  else if (q.kind == MATPBR_REDUCE_COLSUM) colsum_reduce_body(red, q.src, q.groups, q.dst, block);
+  else skinny_reduce_body(red, block, q.src, q.src_b, q.groups, q.n0, q.n1, q.n2, q.dst, q.ld_j, q.ld_c, q.dst_b, q.src_g, q.n3, q.dst_g);
+}
+inline int reduce_job_blocks(const MatpbrReduceJob& q) {
+  if (q.kind == MATPBR_REDUCE_WGRAD) return 256;
+  if (q.kind == MATPBR_REDUCE_COLSUM) return q.n0;
+  return q.n0 * 4 + (q.dst_g ? 4 : 0);
+}
+inline void launch_reduce_job(const MatpbrReduceJob& q, hipStream_t st) {          // the job by itself, behind its producer
+  if (q.kind == MATPBR_REDUCE_WGRAD) hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(1024), 0, st, q.src, q.groups, q.dst, q.n0, q.n1, q.n2);
+  else if (q.kind == MATPBR_REDUCE_COLSUM) hipLaunchKernelGGL(mlp_colsum_reduce, dim3(q.n0), dim3(256), 0, st, q.src, q.groups, q.dst);
+  else hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(reduce_job_blocks(q)), dim3(1024), 0, st, q.src, q.src_b, q.groups, q.n0, q.n1, q.n2, q.dst, q.ld_j, q.ld_c,
+                          q.dst_b, q.src_g, q.n3, q.dst_g);
+}
+// reduce now, or leave the record to the caller (matpbr_mlp_reduce_jobs)
+inline void reduce_or_defer(const MatpbrReduceJob& q, MatpbrReduceJob* defer, hipStream_t st) {
+  if (defer) *defer = q;
+  else launch_reduce_job(q, st);
 }
 
 }  // namespace
@@ -2817,7 +2869,7 @@ int matpbr_mlp_layer_fwd_bx(const float* x, int ldx, const void* wsplit, const f
 
 static int mlp_layer_bwd_input_bx_impl(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,
                                        void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, int nprod, int sgn, void* stream,
-                                       const unsigned* g_tile_max = nullptr, unsigned* out_tile_max = nullptr) {
+                                       const unsigned* g_tile_max = nullptr, unsigned* out_tile_max = nullptr, MatpbrReduceJob* defer = nullptr) {
   if (!g || !wtsplit || !c_prev || !g_prev || M <= 0 || n_prev <= 0 || n_prev > 256 || n_red <= 0 || n_red > 256) return MATPBR_ERR_INVALID_ARG;
   if (nprod == 3 && (!g_tile_max || n_red <= 32)) return MATPBR_ERR_INVALID_ARG;
   if ((nprod != 3 && nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldo < 256 || (ldo & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || !aligned16(g) ||
@@ -2829,14 +2881,19 @@ static int mlp_layer_bwd_input_bx_impl(const float* g, int ldg, const void* wtsp
   p.a_tmax = g_tile_max; p.o_tmax = out_tile_max;
   const int groups = launch_nt_bx<EPI_MULC>(p, (const uint4*)wtsplit, nprod, (hipStream_t)stream);
   if (groups < 0) return MATPBR_ERR_LAUNCH;
-  if (d_bias_prev)
-    hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
+  if (defer) defer->kind = MATPBR_REDUCE_NONE;
+  if (d_bias_prev) {
+    MatpbrReduceJob q{};
+    q.kind = MATPBR_REDUCE_COLSUM; q.groups = groups; q.src = (const float*)workspace; q.dst = d_bias_prev; q.n0 = n_prev;
+    reduce_or_defer(q, defer, (hipStream_t)stream);
+  }
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
 static int mlp_first_layer_bwd_impl(const float* g, int ldg, const void* wtsplit, const float* c_prev, int ldc, int sgn, const float* x0, int ldx0,
                                     float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes, void* workspace2,
-                                    size_t workspace2_bytes, long M, int n0, int n_red, int nprod, const unsigned* g_tile_max, void* stream) {
+                                    size_t workspace2_bytes, long M, int n0, int n_red, int nprod, const unsigned* g_tile_max, void* stream,
+                                    MatpbrReduceJob* defer = nullptr) {
   if (!g || !wtsplit || !c_prev || !x0 || !d_w0 || M <= 0 || n0 <= 0 || n0 > 256 || n_red <= 0 || n_red > 256 || d0 <= 0 || d0 > 16) return MATPBR_ERR_INVALID_ARG;
   if (nprod == 3 && (!g_tile_max || n_red <= 32)) return MATPBR_ERR_INVALID_ARG;
   if ((nprod != 3 && nprod != 6 && nprod != 9) || (M % kBM) || M > 0x7fffff00L || ldc < 256 || (ldc & 3) || (ldg & 3) || ldg < ((n_red + 31) & ~31) || ldx0 < 16 || (ldx0 & 3) ||
@@ -2872,9 +2929,15 @@ static int mlp_first_layer_bwd_impl(const float* g, int ldg, const void* wtsplit
     ok = nprod == 9 ? launch_nt_bx_w0<9>(p, (const uint4*)wtsplit, grid, (hipStream_t)stream) : launch_nt_bx_w0<6>(p, (const uint4*)wtsplit, grid, (hipStream_t)stream);
   }
   if (!ok) return MATPBR_ERR_LAUNCH;
-  if (d_bias0) hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n0), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid, d_bias0);
-  hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(16 * 4), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace2, (const float*)nullptr, slabs, 16, d0, n0,
-                     d_w0, ld_j, ld_c, (float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
+  if (defer) defer[0].kind = MATPBR_REDUCE_NONE;
+  if (d_bias0) {
+    MatpbrReduceJob q{};
+    q.kind = MATPBR_REDUCE_COLSUM; q.groups = (int)grid; q.src = (const float*)workspace; q.dst = d_bias0; q.n0 = n0;
+    reduce_or_defer(q, defer, (hipStream_t)stream);
+  }
+  MatpbrReduceJob q2{};
+  q2.kind = MATPBR_REDUCE_SKINNY; q2.groups = slabs; q2.src = (const float*)workspace2; q2.dst = d_w0; q2.n0 = 16; q2.n1 = d0; q2.n2 = n0; q2.ld_j = ld_j; q2.ld_c = ld_c;
+  reduce_or_defer(q2, defer ? defer + 1 : nullptr, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
@@ -2887,14 +2950,15 @@ int matpbr_mlp_first_layer_bwd_bx(const float* g, int ldg, const void* wtsplit, 
 }
 int matpbr_mlp_first_layer_bwd_blk(const float* g, int ldg, const void* g_tile_max, const void* wtsplit, const float* s_prev, int lds, const float* x0, int ldx0,
                                    float* d_w0, long ld_j, long ld_c, int d0, float* d_bias0, void* workspace, size_t workspace_bytes, void* workspace2,
-                                   size_t workspace2_bytes, long M, int n0, int n_red, void* stream) {
+                                   size_t workspace2_bytes, long M, int n0, int n_red, MatpbrReduceJob* defer2, void* stream) {
   return mlp_first_layer_bwd_impl(g, ldg, wtsplit, s_prev, lds, 1, x0, ldx0, d_w0, ld_j, ld_c, d0, d_bias0, workspace, workspace_bytes, workspace2,
-                                  workspace2_bytes, M, n0, n_red, 3, (const unsigned*)g_tile_max, stream);
+                                  workspace2_bytes, M, n0, n_red, 3, (const unsigned*)g_tile_max, stream, defer2);
 }
 int matpbr_mlp_layer_bwd_input_blk(const float* g, int ldg, const void* g_tile_max, const void* wtsplit, const float* s_prev, float* g_prev, int ldo,
-                                   void* out_tile_max, float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
+                                   void* out_tile_max, float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red,
+                                   MatpbrReduceJob* defer, void* stream) {
   return mlp_layer_bwd_input_bx_impl(g, ldg, wtsplit, s_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, 3, 1, stream,
-                                     (const unsigned*)g_tile_max, (unsigned*)out_tile_max);
+                                     (const unsigned*)g_tile_max, (unsigned*)out_tile_max, defer);
 }
 
 int matpbr_mlp_layer_bwd_input_bx(const float* g, int ldg, const void* wtsplit, const float* c_prev, float* g_prev, int ldo, float* d_bias_prev,
@@ -2936,7 +3000,8 @@ int matpbr_mlp_layer_bwd_weight(const float* g, int ldg, const float* x, int ldx
 }
 
 static int mlp_layer_bwd_weight_bx_impl(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
-                                        size_t workspace_bytes, long M, int N, int K, int nprod, const unsigned* g_tile_max, void* stream) {
+                                        size_t workspace_bytes, long M, int N, int K, int nprod, const unsigned* g_tile_max, void* stream,
+                                        MatpbrReduceJob* defer = nullptr) {
   if (!g || !x || !d_w || M <= 0 || N <= 0 || N > 256 || K <= 0 || K > 256) return MATPBR_ERR_INVALID_ARG;
   if (nprod == 3 && (!g_tile_max || (M % kBM))) return MATPBR_ERR_INVALID_ARG;
   if ((nprod != 3 && nprod != 6 && nprod != 9) || (M & 15) || ldg < 256 || ldx < 256 || (ldg & 3) || (ldx & 3) || ldw < K || !aligned16(g) || !aligned16(x))
@@ -2955,7 +3020,9 @@ static int mlp_layer_bwd_weight_bx_impl(const float* g, int ldg, const float* x,
     if (!lds_opt_in<&mlp_wgrad_bx<9>>(kWgSmem)) return MATPBR_ERR_LAUNCH;
     hipLaunchKernelGGL(mlp_wgrad_bx<9>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, (const unsigned*)nullptr);
   }
-  hipLaunchKernelGGL(mlp_wgrad_reduce, dim3(256), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, slabs, d_w, N, K, ldw);
+  MatpbrReduceJob q{};
+  q.kind = MATPBR_REDUCE_WGRAD; q.groups = slabs; q.src = (const float*)workspace; q.dst = d_w; q.n0 = N; q.n1 = K; q.n2 = ldw;
+  reduce_or_defer(q, defer, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int ldx, float* d_w, int ldw, void* workspace,
@@ -2964,8 +3031,8 @@ int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int 
   return mlp_layer_bwd_weight_bx_impl(g, ldg, x, ldx, d_w, ldw, workspace, workspace_bytes, M, N, K, nprod, nullptr, stream);
 }
 int matpbr_mlp_layer_bwd_weight_blk(const float* g, int ldg, const void* g_tile_max, const float* x, int ldx, float* d_w, int ldw, void* workspace,
-                                    size_t workspace_bytes, long M, int N, int K, void* stream) {
-  return mlp_layer_bwd_weight_bx_impl(g, ldg, x, ldx, d_w, ldw, workspace, workspace_bytes, M, N, K, 3, (const unsigned*)g_tile_max, stream);
+                                    size_t workspace_bytes, long M, int N, int K, MatpbrReduceJob* defer, void* stream) {
+  return mlp_layer_bwd_weight_bx_impl(g, ldg, x, ldx, d_w, ldw, workspace, workspace_bytes, M, N, K, 3, (const unsigned*)g_tile_max, stream, defer);
 }
 
 int matpbr_mlp_sincos(const float* pre, long ldp, float* s_out, long lds, float* c_out, long ldc, long M, int n, void* stream) {
@@ -3035,7 +3102,7 @@ int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ld
 
 static int mlp_out_layer_bwd_impl(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
                                   int ldg, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace, size_t workspace_bytes,
-                                  long M, int J, int n_prev, unsigned* g_tile_max, void* stream) {
+                                  long M, int J, int n_prev, unsigned* g_tile_max, void* stream, MatpbrReduceJob* defer = nullptr) {
   if (!d_x || !s_prev || !w_out || !g_prev || !d_w || M <= 0 || J <= 0 || J > kOutJ || n_prev <= 0 || n_prev > 256) return MATPBR_ERR_INVALID_ARG;
   if (ldd < 8 || lds < 256 || (lds & 3) || ldg < 256 || (ldg & 3) || ldw < 256 || (ldw & 3) || !aligned16(s_prev) || !aligned16(g_prev) || !aligned16(w_out) ||
       (c_prev && !aligned16(c_prev)))
@@ -3049,8 +3116,10 @@ static int mlp_out_layer_bwd_impl(const float* d_x, int ldd, const float* s_prev
   float* gsum_part = bpart + (size_t)kSkinnySlabs * 8;
   SkinnyDgrad dg{w_out, ldw, J, c_prev, g_prev, ldg, gsum_part, g_tile_max};
   hipLaunchKernelGGL((mlp_skinny_tn_kernel<8, true>), dim3(slabs), dim3(256), 0, (hipStream_t)stream, d_x, ldd, s_prev, lds, partial, bpart, M, rows, dg);
-  hipLaunchKernelGGL(mlp_skinny_tn_reduce, dim3(8 * 4 + (d_bias_prev ? 4 : 0)), dim3(1024), 0, (hipStream_t)stream, (const float*)partial, (const float*)bpart, slabs, 8,
-                     J, 256, d_w, ld_j, ld_c, d_bias, (const float*)gsum_part, n_prev, d_bias_prev);
+  MatpbrReduceJob q{};
+  q.kind = MATPBR_REDUCE_SKINNY; q.groups = slabs; q.src = partial; q.src_b = bpart; q.src_g = gsum_part; q.dst = d_w; q.dst_b = d_bias; q.dst_g = d_bias_prev;
+  q.n0 = 8; q.n1 = J; q.n2 = 256; q.n3 = n_prev; q.ld_j = ld_j; q.ld_c = ld_c;
+  reduce_or_defer(q, defer, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
@@ -3062,10 +3131,30 @@ int matpbr_mlp_out_layer_bwd(const float* d_x, int ldd, const float* s_prev, con
 }
 int matpbr_mlp_out_layer_bwd_tmax(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
                                   int ldg, void* g_tile_max, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace,
-                                  size_t workspace_bytes, long M, int J, int n_prev, void* stream) {
+                                  size_t workspace_bytes, long M, int J, int n_prev, MatpbrReduceJob* defer, void* stream) {
   if (!g_tile_max) return MATPBR_ERR_INVALID_ARG;
   return mlp_out_layer_bwd_impl(d_x, ldd, s_prev, c_prev, lds, w_out, ldw, g_prev, ldg, d_w, ld_j, ld_c, d_bias, d_bias_prev, workspace, workspace_bytes, M, J,
-                                n_prev, (unsigned*)g_tile_max, stream);
+                                n_prev, (unsigned*)g_tile_max, stream, defer);
+}
+
+int matpbr_mlp_reduce_jobs(const MatpbrReduceJob* jobs, int n_jobs, void* stream) {
+  if (!jobs || n_jobs <= 0 || n_jobs > kMaxReduceJobs) return MATPBR_ERR_INVALID_ARG;
+  ReduceJobs js{};
+  int blocks = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const MatpbrReduceJob& q = jobs[i];
+    if (q.kind == MATPBR_REDUCE_NONE) continue;
+    if ((q.kind != MATPBR_REDUCE_WGRAD && q.kind != MATPBR_REDUCE_COLSUM && q.kind != MATPBR_REDUCE_SKINNY) || !q.src || !q.dst || q.groups <= 0 || q.n0 <= 0)
+      return MATPBR_ERR_INVALID_ARG;
+    js.j[js.n] = q;
+    js.first[js.n] = blocks;
+    blocks += reduce_job_blocks(q);
+    ++js.n;
+  }
+  if (js.n == 0) return MATPBR_OK;
+  js.first[js.n] = blocks;
+  hipLaunchKernelGGL(mlp_reduce_jobs_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, js);
+  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
 }  // extern "C"

@@ -861,63 +861,75 @@ def mlp_tile_max(M: int, device) -> torch.Tensor:
 
 
 def mlp_out_layer_bwd_tmax(d_x: torch.Tensor, s_prev: torch.Tensor, w_out: torch.Tensor, g_prev: torch.Tensor, g_tile_max: torch.Tensor,
-                           d_w: torch.Tensor, d_bias: Optional[torch.Tensor], d_bias_prev: Optional[torch.Tensor], J: int, n_prev: int) -> None:
-    """mlp_out_layer_bwd on sign-carrying sines that also fills `g_tile_max` (zeroed by the caller) for the g_prev it writes."""
+                           d_w: torch.Tensor, d_bias: Optional[torch.Tensor], d_bias_prev: Optional[torch.Tensor], J: int, n_prev: int, defer=None) -> None:
+    """mlp_out_layer_bwd on sign-carrying sines that also fills `g_tile_max` (zeroed by the caller) for the g_prev it writes.
+    defer: (slot of a `_lib.ReduceJob` array, workspace tag) -- the fold is left as a record for `mlp_reduce_jobs`, the partial sums in a workspace
+    of that tag."""
     lib = _lib.load()
     s_prev, g_prev = _mat2(s_prev, "s_prev"), _mat2(g_prev, "g_prev")
     M = s_prev.shape[0]
-    ws = _mlp_workspace("skinny%d" % ((J + 7) // 8), 0, s_prev.device, lib.matpbr_mlp_skinny_workspace_bytes(J))
+    ws = _mlp_workspace("skinny%d%s" % ((J + 7) // 8, defer[1] if defer else ""), 0, s_prev.device, lib.matpbr_mlp_skinny_workspace_bytes(J))
     with torch.cuda.device(s_prev.device):
         code = lib.matpbr_mlp_out_layer_bwd_tmax(_ptr(d_x), d_x.stride(0), _ptr(s_prev), None, s_prev.stride(0), _ptr(w_out), w_out.stride(0),
                                                  _ptr(g_prev), g_prev.stride(0), _ptr(g_tile_max), _ptr(d_w), d_w.stride(0), 1, _ptr(d_bias),
-                                                 _ptr(d_bias_prev), _ptr(ws), ws.numel() * 4, M, int(J), int(n_prev), _stream(s_prev))
+                                                 _ptr(d_bias_prev), _ptr(ws), ws.numel() * 4, M, int(J), int(n_prev), defer[0] if defer else None, _stream(s_prev))
     _lib.check(code, "matpbr_mlp_out_layer_bwd_tmax")
 
 
 def mlp_layer_bwd_input_blk(g: torch.Tensor, g_tile_max: torch.Tensor, wtsplit: torch.Tensor, s_prev: torch.Tensor, g_prev: torch.Tensor, n_prev: int,
-                            n_red: int, d_bias_prev: Optional[torch.Tensor], out_tile_max: Optional[torch.Tensor]) -> None:
-    """mlp_layer_bwd_input_bx(packed=True) on two f16 pieces: `wtsplit` from mlp_split_weights(..., transposed=True, f16=True)."""
+                            n_red: int, d_bias_prev: Optional[torch.Tensor], out_tile_max: Optional[torch.Tensor], defer=None) -> None:
+    """mlp_layer_bwd_input_bx(packed=True) on two f16 pieces: `wtsplit` from mlp_split_weights(..., transposed=True, f16=True).  defer: as
+    mlp_out_layer_bwd_tmax."""
     lib = _lib.load()
     g = _mat2(g, "g")
     M = g.shape[0]
     if s_prev.stride(0) != g_prev.stride(0):
         raise ValueError("s_prev and g_prev must share their row stride")
-    ws = _mlp_workspace("bwd_input", M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
+    ws = _mlp_workspace("bwd_input" + (defer[1] if defer else ""), M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
     with torch.cuda.device(g.device):
         code = lib.matpbr_mlp_layer_bwd_input_blk(_ptr(g), g.stride(0), _ptr(g_tile_max), _ptr(wtsplit), _ptr(s_prev), _ptr(g_prev), g_prev.stride(0),
                                                   _ptr(out_tile_max) if out_tile_max is not None else None,
                                                   _ptr(d_bias_prev) if d_bias_prev is not None else None, _ptr(ws), ws.numel() * 4, M, n_prev, n_red,
-                                                  _stream(g))
+                                                  defer[0] if defer else None, _stream(g))
     _lib.check(code, "matpbr_mlp_layer_bwd_input_blk")
 
 
 def mlp_first_layer_bwd_blk(g: torch.Tensor, g_tile_max: torch.Tensor, wtsplit: torch.Tensor, s_prev: torch.Tensor, x0: torch.Tensor, d_w0: torch.Tensor,
-                            d0: int, n0: int, n_red: int, d_bias0: Optional[torch.Tensor]) -> None:
-    """mlp_first_layer_bwd_bx(packed=True) on two f16 pieces."""
+                            d0: int, n0: int, n_red: int, d_bias0: Optional[torch.Tensor], defer=None) -> None:
+    """mlp_first_layer_bwd_bx(packed=True) on two f16 pieces.  defer: as mlp_out_layer_bwd_tmax, the slot being the first of TWO records."""
     lib = _lib.load()
     g, s_prev, x0 = _mat2(g, "g"), _mat2(s_prev, "s_prev"), _mat2(x0, "x0")
     M = g.shape[0]
-    ws = _mlp_workspace("bwd_input", M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
-    ws2 = _mlp_workspace("skinny2", 0, g.device, lib.matpbr_mlp_skinny_workspace_bytes(16))
+    ws = _mlp_workspace("bwd_input" + (defer[1] if defer else ""), M, g.device, lib.matpbr_mlp_bwd_input_workspace_bytes(M))
+    ws2 = _mlp_workspace("skinny2" + (defer[1] if defer else ""), 0, g.device, lib.matpbr_mlp_skinny_workspace_bytes(16))
     with torch.cuda.device(g.device):
         code = lib.matpbr_mlp_first_layer_bwd_blk(_ptr(g), g.stride(0), _ptr(g_tile_max), _ptr(wtsplit), _ptr(s_prev), s_prev.stride(0), _ptr(x0), x0.stride(0),
                                                   _ptr(d_w0), 1, d_w0.stride(0), int(d0), _ptr(d_bias0), _ptr(ws), ws.numel() * 4, _ptr(ws2), ws2.numel() * 4,
-                                                  M, int(n0), int(n_red), _stream(g))
+                                                  M, int(n0), int(n_red), defer[0] if defer else None, _stream(g))
     _lib.check(code, "matpbr_mlp_first_layer_bwd_blk")
 
 
-def mlp_layer_bwd_weight_blk(g: torch.Tensor, g_tile_max: torch.Tensor, x: torch.Tensor, N: int, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """mlp_layer_bwd_weight_bx on two f16 pieces (x as it is, g under one exponent per slab of rows)."""
+def mlp_layer_bwd_weight_blk(g: torch.Tensor, g_tile_max: torch.Tensor, x: torch.Tensor, N: int, K: int, out: Optional[torch.Tensor] = None,
+                             defer=None) -> torch.Tensor:
+    """mlp_layer_bwd_weight_bx on two f16 pieces (x as it is, g under one exponent per slab of rows).  defer: as mlp_out_layer_bwd_tmax (the 256
+    slabs of partial sums stay in a workspace of their own: 67 MB per deferred layer at 512 x 512)."""
     lib = _lib.load()
     g, x = _mat2(g, "g"), _mat2(x, "x")
     M = g.shape[0]
-    ws = _mlp_workspace("bwd_weight", M, g.device, lib.matpbr_mlp_bwd_weight_workspace_bytes(M))
+    ws = _mlp_workspace("bwd_weight" + (defer[1] if defer else ""), M, g.device, lib.matpbr_mlp_bwd_weight_workspace_bytes(M))
     d_w = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
         code = lib.matpbr_mlp_layer_bwd_weight_blk(_ptr(g), g.stride(0), _ptr(g_tile_max), _ptr(x), x.stride(0), _ptr(d_w), d_w.stride(0), _ptr(ws),
-                                                   ws.numel() * 4, M, N, K, _stream(g))
+                                                   ws.numel() * 4, M, N, K, defer[0] if defer else None, _stream(g))
     _lib.check(code, "matpbr_mlp_layer_bwd_weight_blk")
     return d_w
+
+
+def mlp_reduce_jobs(jobs, n: int, like: torch.Tensor) -> None:
+    """Every deferred fold of an iteration's backward pass in one launch (include/matpbr.h `matpbr_mlp_reduce_jobs`); jobs: a `_lib.ReduceJob` array."""
+    with torch.cuda.device(like.device):
+        code = _lib.load().matpbr_mlp_reduce_jobs(ctypes.byref(jobs), int(n), _stream(like))
+    _lib.check(code, "matpbr_mlp_reduce_jobs")
 
 
 LIGHT_SH9, LIGHT_ENV_TEXELS = 1, 2

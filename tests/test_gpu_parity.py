@@ -2299,6 +2299,44 @@ def test_forward_chain_is_the_layer_by_layer_forward(size):
     assert (got.double() - ref).abs().max().item() <= 4e-5
 
 
+def test_deferred_folds_of_the_backward_pass_are_the_same_bits():
+    """`matpbr_mlp_reduce_jobs`: the folds of the backward pass's partial sums (three weight gradients' 256 slabs, the column sums behind four bias
+    gradients, the output layer's and the first layer's skinny products) in ONE launch before the optimiser step, against one launch behind every
+    product (ArmMlpPhase.DEFER_REDUCE False): the same gradient buffer and the same weights after three AdamW steps, bit for bit."""
+    import copy
+
+    from materialist_amd import posmlp, render, synthetic
+    from materialist_amd.armhead import ArmMlpPhase
+
+    dev = _cuda()
+    H = W = 128
+    sc = synthetic.make_scene(6, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    gt = torch.rand(H, W, 3, device=dev)
+    a0, r0, m0 = (_t(v, dev).clamp(0, 1) for v in (sc.init_albedo, sc.init_roughness, sc.init_metallic))
+    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).contiguous()
+    torch.manual_seed(9)
+    net = posmlp.brdf_net("arm").to(dev)
+    net.lin4.weight.data.normal_(0, 0.05)
+    fixed = {"albedo": a0, "roughness": r0, "metallic": m0}
+    runs = {}
+    for defer in (False, True):
+        ArmMlpPhase.DEFER_REDUCE = defer
+        try:
+            ph = ArmMlpPhase(scene, gt, copy.deepcopy(net), start_arm, fixed, optimize_part="arm", spp=8)
+            assert ph.bwd_f16
+            for _ in range(3):
+                ph.step()
+            torch.cuda.synchronize()
+            runs[defer] = (ph.gflat.clone(), ph.flat.clone(), ph.stats.clone())
+        finally:
+            ArmMlpPhase.DEFER_REDUCE = True
+    assert float(runs[True][0].abs().max()) > 0.0
+    for a, b in zip(runs[True], runs[False]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("n_prev,n_red", [(256, 256), (241, 256), (256, 241)])
 def test_block_scaled_f16_backward_products(n_prev, n_red):
     """f2 (round 5): the backward products of the 256-wide layers on two f16 pieces with one exponent per 128-row tile
