@@ -510,11 +510,16 @@ int matpbr_mlp_split_weights_fmt(const float* w, int ldw, int N, int K, int flag
  * first layer (K = d0 <= 16) on the exact-f32 matrix instruction; = the layer-by-layer kernels to f32 rounding (the k order differs).
  *   matpbr_mlp_chain_images_bytes  size of the `images` buffer
  *   matpbr_mlp_chain_prep          once per weight state: w[0] [n[0], ldw >= d0], w[1..3] [n[l], ldw >= 256], w[4] [n[4] <= 8, ldw >= 256] and the
- *                                  five bias vectors -> images.  n[l] of a sine layer is 256, or 241 = 256 - 15 for a layer whose buffer ends in x0
+ *                                  five bias vectors -> images.  n[l] of a sine layer is 256, or 241 = 256 - 15 for a layer whose buffer ends in x0.
+ *                                  In the same launch, what else an iteration prepares once per optimiser step (both nullable): bwd_images[0..2] =
+ *                                  the MATPBR_WSPLIT_F16X2 | MATPBR_WSPLIT_TRANSPOSED images of (w[l][:, :n[l-1]])^T, l = 1..3, the operands of
+ *                                  matpbr_mlp_layer_bwd_input_blk (= matpbr_mlp_split_weights_fmt, the same bits), and `zero_words` 32-bit zeros
+ *                                  at `zero` (the gradient tiles' maxima, which their producers fill by atomic max)
  *   matpbr_mlp_chain_fwd           x0 [M, ldx0 >= 16] (zero beyond d0) -> s_out[0..3] [M, ldo >= 256] (columns n[l].. of a 241-wide layer = x0,
  *                                  written here), th [M, 8], the maps (each nullable) as matpbr_mlp_arm_head_fwd.  M a multiple of 128 */
 size_t matpbr_mlp_chain_images_bytes(void);
-int matpbr_mlp_chain_prep(const float* const* w, const int* ldw, const int* n, const float* const* bias, int d0, void* images, void* stream);
+int matpbr_mlp_chain_prep(const float* const* w, const int* ldw, const int* n, const float* const* bias, int d0, void* images, void* const* bwd_images,
+                          void* zero, long zero_words, void* stream);
 int matpbr_mlp_chain_fwd(const float* x0, int ldx0, const void* images, float* const* s_out, int ldo, const int* n, const float* start, int lds, float* th,
                          float* map_a, float* map_r, float* map_m, int n_head, long M, void* stream);
 /* The BACKWARD products of the 256-wide layers on two f16 pieces (round 5; the autograd backward of mymodels/mlps.py:102-103, :216-224 as

@@ -137,7 +137,8 @@ SIGNATURES = {
     "matpbr_mlp_layer_bwd_weight_blk": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p,
                                                        ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_chain_images_bytes": (ctypes.c_size_t, []),
-    "matpbr_mlp_chain_prep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "matpbr_mlp_chain_prep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]),
     "matpbr_mlp_chain_fwd": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, _c_f, ctypes.c_int, _c_f, _c_f, _c_f,
                                             _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_void_p]),
     "matpbr_mlp_split_weights_fmt": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),

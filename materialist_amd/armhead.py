@@ -183,14 +183,19 @@ class ArmMlpPhase:
 
         self.chain = bool(self.FWD_CHAIN and self.packed and self.fwd_products == 3 and self.L == 5 and all(n in (241, 256) for n in self.ns)
                           and self.views[-1][0].shape[0] <= 8 and self.d0 <= 15 and all((n == 241) == ((l + 1) in net.skip) for l, n in enumerate(self.ns)))
+        # one preparation launch per iteration (matpbr_mlp_chain_prep): the chain's forward images, the backward products' f16 images, the reset of
+        # the gradient tiles' maxima
+        self.prep_all = bool(self.chain and self.bwd_f16 and self.L == 5)
         if self.chain:
-            jobs = [jb for jb in jobs if jb[4] & 1]                # the forward images are the chain's own (matpbr_mlp_chain_prep)
+            jobs = [] if self.prep_all else [jb for jb in jobs if jb[4] & 1]   # the forward images are the chain's own
             lib = _lib.load()
             self._chain_images = torch.empty(int(lib.matpbr_mlp_chain_images_bytes()), dtype=torch.uint8, device=dev)
             P_ = _ct.c_void_p
             ws_, bs_ = [v[0] for v in self.views], [v[1] for v in self.views]
-            self._chain_prep = ((P_ * 5)(*[w_.data_ptr() for w_ in ws_]), (_ct.c_int * 5)(*[w_.stride(0) for w_ in ws_]), (_ct.c_int * 5)(*[w_.shape[0] for w_ in ws_]),
-                                (P_ * 5)(*[b_.data_ptr() for b_ in bs_]), int(self.d0), P_(self._chain_images.data_ptr()))
+            self._chain_prep = [(P_ * 5)(*[w_.data_ptr() for w_ in ws_]), (_ct.c_int * 5)(*[w_.stride(0) for w_ in ws_]), (_ct.c_int * 5)(*[w_.shape[0] for w_ in ws_]),
+                                (P_ * 5)(*[b_.data_ptr() for b_ in bs_]), int(self.d0), P_(self._chain_images.data_ptr()), None, None, 0]
+            if self.prep_all:
+                self._chain_prep[6] = (P_ * 3)(*[self.wsplit_b[l].data_ptr() for l in (1, 2, 3)])
             self._chain_out = (P_ * 4)(*[b_.data_ptr() for b_ in self.bufs])
             self._chain_n = (_ct.c_int * 4)(*self.ns)
         nj = len(jobs)
@@ -198,6 +203,8 @@ class ArmMlpPhase:
                             (_ct.c_int * nj)(*[j[3] for j in jobs]), (_ct.c_int * nj)(*[j[4] for j in jobs]), (_ct.c_void_p * nj)(*[j[5] for j in jobs]), nj)
         # block exponents of the gradient matrices (one row of tile maxima per sine layer's dL/d pre), zeroed once per iteration
         self.tmax = torch.zeros(max(self.L - 1, 1), M // 128, dtype=torch.int32, device=dev) if self.bwd_f16 else None
+        if self.prep_all:
+            self._chain_prep[7], self._chain_prep[8] = _ct.c_void_p(self.tmax.data_ptr()), self.tmax.numel()
         self._jobs = (_lib.ReduceJob * 16)()                     # the backward pass's deferred folds (DEFER_REDUCE)
         self.maps = {"albedo": E(H, W, 3), "roughness": E(H, W, 1), "metallic": E(H, W, 1)}
         keys = {"a": "albedo", "r": "roughness", "m": "metallic"}
@@ -242,8 +249,9 @@ class ArmMlpPhase:
     def forward(self) -> Dict[str, torch.Tensor]:
         """brdf_net(start_arm) and the maps of :493-504 (maps that the part does not optimise keep their fixed values)."""
         o, P = ops, self.fwd_products
-        with torch.cuda.device(self.dev):
-            _lib.check(_lib.load().matpbr_mlp_split_weights_multi(*self._split_args, o._stream(self.flat)), "matpbr_mlp_split_weights_multi")
+        if self._split_args[-1] > 0:
+            with torch.cuda.device(self.dev):
+                _lib.check(_lib.load().matpbr_mlp_split_weights_multi(*self._split_args, o._stream(self.flat)), "matpbr_mlp_split_weights_multi")
         if self.chain:
             live = self.live
             lib, st = _lib.load(), o._stream(self.flat)
@@ -293,7 +301,8 @@ class ArmMlpPhase:
         jobs, nj = (self._jobs, 0) if (f16 and self.DEFER_REDUCE) else (None, 0)
         slot = (lambda k: (_ct.cast(_ct.byref(jobs, k * _ct.sizeof(_lib.ReduceJob)), _ct.c_void_p), f"_d{k}")) if jobs is not None else (lambda k: None)
         if f16:
-            self.tmax.zero_()
+            if not self.prep_all:                                # (otherwise zeroed by the iteration's preparation launch)
+                self.tmax.zero_()
             o.mlp_out_layer_bwd_tmax(self.d_x, self.bufs[-1], wp, g_prev, self.tmax[self.L - 2], gw, gb, gb_prev, 5, self.ns[-1], defer=slot(nj))
             nj += 1
         elif self.FUSED_OUT_BWD:

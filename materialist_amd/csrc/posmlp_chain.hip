@@ -42,11 +42,44 @@ struct ChainPrep {
   const float* b[5];
   int ldw[5], n[5], d0;
   unsigned char* images;
+  // what else changes once per optimiser step, in the same launch (jobs 6..): the input-gradient products' operands -- MATPBR_WSPLIT_F16X2 |
+  // MATPBR_WSPLIT_TRANSPOSED images of W1..W3 (element (n, k) = W[k][n], n < bn, k < bk: mlp_split_weights_kernel's item, the same bits) --
+  // and the reset of the gradient tiles' maxima
+  uint4* bwd[3];
+  int bn[3], bk[3], n_bwd;
+  unsigned* zero;
+  int zero_words;
 };
 
-// blockIdx.y: 0..2 the chain images of layers 1..3, 3 the f32 image of the first layer, 4 the output layer's image, 5 the biases
+// blockIdx.y: 0..2 the chain images of layers 1..3, 3 the f32 image of the first layer, 4 the output layer's image, 5 the biases,
+// 6.. the backward images, then the zeros
 __global__ __launch_bounds__(256) void mlp_chain_prep_kernel(const ChainPrep a) {
   const int job = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+  if (job >= 6) {
+    const int jb = job - 6;
+    if (jb < a.n_bwd) {
+      const int N = a.bn[jb], K = a.bk[jb], nks = (K + 31) / 32;
+      if (idx >= nks * 2 * 256 * 2) return;
+      const int g = idx & 1, n = (idx >> 1) & 255, s2 = (idx >> 9) & 1, ks = idx >> 10;
+      const float* B = a.w[1 + jb];
+      const int ldb = a.ldw[1 + jb];
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 32 * ks + 16 * g + 8 * s2 + q;
+        v[q] = (n < N && k < K) ? B[(size_t)k * ldb + n] : 0.f;
+      }
+      unsigned p[2][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split2h(v[2 * q] * kF16WScale, v[2 * q + 1] * kF16WScale, p[0][q], p[1][q]);
+#pragma unroll
+      for (int piece = 0; piece < 2; ++piece)
+        a.bwd[jb][((((size_t)ks * 2 + s2) * 2 + piece) * 2 + g) * 256 + n] = make_uint4(p[piece][0], p[piece][1], p[piece][2], p[piece][3]);
+    } else {
+      for (int i = idx; i < a.zero_words; i += 32 * 256) a.zero[i] = 0u;
+    }
+    return;
+  }
   if (job < 3) {                                               // thread = (stage ks, k-step s, feature n, lane half g): 8 slots of one k-step
     if (idx >= 8 * 2 * 256 * 2) return;
     const int g = idx & 1, n = (idx >> 1) & 255, s = (idx >> 9) & 1, ks = idx >> 10;
@@ -343,8 +376,10 @@ extern "C" {
 
 size_t matpbr_mlp_chain_images_bytes(void) { return kChImages; }
 
-int matpbr_mlp_chain_prep(const float* const* w, const int* ldw, const int* n, const float* const* bias, int d0, void* images, void* stream) {
-  if (!w || !ldw || !n || !bias || !images || d0 <= 0 || d0 > 16) return MATPBR_ERR_INVALID_ARG;
+int matpbr_mlp_chain_prep(const float* const* w, const int* ldw, const int* n, const float* const* bias, int d0, void* images, void* const* bwd_images,
+                          void* zero, long zero_words, void* stream) {
+  if (!w || !ldw || !n || !bias || !images || d0 <= 0 || d0 > 16 || zero_words < 0 || zero_words > 0x7fffffffL || (zero_words > 0 && !zero))
+    return MATPBR_ERR_INVALID_ARG;
   ChainPrep a{};
   for (int l = 0; l < 5; ++l) {
     if (!w[l] || !bias[l] || n[l] <= 0 || n[l] > 256 || ldw[l] < (l == 0 ? d0 : 256)) return MATPBR_ERR_INVALID_ARG;
@@ -353,7 +388,18 @@ int matpbr_mlp_chain_prep(const float* const* w, const int* ldw, const int* n, c
   if (n[4] > 8) return MATPBR_ERR_INVALID_ARG;
   a.d0 = d0;
   a.images = (unsigned char*)images;
-  hipLaunchKernelGGL(mlp_chain_prep_kernel, dim3(32, 6), dim3(256), 0, (hipStream_t)stream, a);
+  if (bwd_images) {                                         // (W_l[:, :n_{l-1}])^T for l = 1..3: n_{l-1} outputs over n_l reduction columns
+    for (int l = 1; l <= 3; ++l) {
+      if (!bwd_images[l - 1]) return MATPBR_ERR_INVALID_ARG;
+      a.bwd[l - 1] = (uint4*)bwd_images[l - 1];
+      a.bn[l - 1] = n[l - 1]; a.bk[l - 1] = n[l];
+    }
+    a.n_bwd = 3;
+  }
+  a.zero = (unsigned*)zero;
+  a.zero_words = (int)zero_words;
+  const unsigned jobs = 6u + (unsigned)a.n_bwd + (zero_words > 0 ? 1u : 0u);
+  hipLaunchKernelGGL(mlp_chain_prep_kernel, dim3(32, jobs), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
