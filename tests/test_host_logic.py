@@ -49,6 +49,9 @@ def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
     nfields = [name for name, _ in _lib.MatpbrNormalStep._fields_]
     lines += ['  printf(", \\"n_sizeof\\": %zu", sizeof(MatpbrNormalStep));']
     lines += [f'  printf(", \\"n_{f}\\": %zu", offsetof(MatpbrNormalStep, {f}));' for f in nfields]
+    rfields = [name for name, _ in _lib.ReduceJob._fields_]
+    lines += ['  printf(", \\"r_sizeof\\": %zu", sizeof(MatpbrReduceJob));']
+    lines += [f'  printf(", \\"r_{f}\\": %zu", offsetof(MatpbrReduceJob, {f}));' for f in rfields]
     macros = ["FLAG_CLAMP_PARAMS", "FLAG_ATTACHED_SAMPLING", "FLAG_LAZY_FORCE", "FLAG_JAC16", "FLAG_MODELS_READY", "FLAG_ROTATE_BEST",
               "FLAG_GENERIC_STEP", "FLAG_JAC32", "FLAG_SHARE_GPU"]
     lines += [f'  printf(", \\"{m}\\": %u", (unsigned)MATPBR_{m});' for m in macros]
@@ -65,6 +68,9 @@ def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
     assert ctypes.sizeof(_lib.MatpbrNormalStep) == c["n_sizeof"]
     for f in nfields:
         assert getattr(_lib.MatpbrNormalStep, f).offset == c["n_" + f], f
+    assert ctypes.sizeof(_lib.ReduceJob) == c["r_sizeof"]
+    for f in rfields:
+        assert getattr(_lib.ReduceJob, f).offset == c["r_" + f], f
     for m in macros:
         assert getattr(ops, m) == c[m], m
     # one word carries flags AND part bits (MatpbrBrdfPhase.flags beside part_mask; the `flags` argument of the brdf_loss_* entry points):
