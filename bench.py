@@ -722,7 +722,7 @@ def main(argv=None):
             tot_ms = (f16["forward_sin"]["avg_launch_ms"] + f16["bwd_input_mulcos_colsum"]["avg_launch_ms"] + f16["bwd_weight"]["avg_launch_ms"]) if "forward_sin" in f16 else None
             gemm = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
                     "achieved": (7 * B4 / (tot_ms * 1e-3) / 1e9) if tot_ms else 0.0,
-                    "kernel": "the three 256-wide products of a layer as the pos_mlp iteration runs them: mlp_nt_gx<sin, 3> / mlp_nt_gx<mul cos, 3> / mlp_wgrad_bx<3> "
+                    "kernel": "the three 256-wide products of a layer as the pos_mlp iteration runs them: mlp_nt_gx<sin, 3> / mlp_nt_gx<mul cos, 3> / mlp_wgrad_hx "
                               "([H*W,256]x[256,256], two f16 pieces per operand, three products, f32 accumulate; epilogues included), back to back",
                     "two_piece_f16": f16,
                     "three_piece_bf16": dict(bx, note=f"round 4's form ({P} bf16 products per f32 product): TFLOP/s in f32-equivalent terms (2 M N K per product); "

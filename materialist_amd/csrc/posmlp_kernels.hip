@@ -2061,6 +2061,143 @@ __global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_bx(const float* __res
     wgrad_bx_body<NPROD, false>(G, ldg, X, ldx, partial, M, rows_per_slab, sW, g_tmax);
 }
 
+// mlp_wgrad_hx: the two-piece f16 weight gradient with its rows brought in by LDS-DMA and cut ONCE (see EXPERIMENTS.md, "where the weight
+// gradient's time goes").  A wave that ISSUES memory instructions while the memory pipeline is full waits at the issue -- and does not
+// multiply meanwhile: with every wave issuing its share after the same barrier, rows that arrive in 65-85 us by themselves and products that
+// take 71 us by themselves took their SUM (131-145 us, stamps).  Here only waves 0..3 (one per SIMD) issue the DMA of a step, first thing after
+// the barrier, while their partners on the same SIMDs (waves 4..7) have the matrix pipe; then they multiply: loop 120 us, the pair with its
+// fold 150-153 us against 158-161 of mlp_wgrad_bx<3> on the same boxes (tools/ab.sh tools/wg_time.py "-DMATPBR_WG_HX=0").
+//   * rows: f32 as they are, 16 rows x [G | X] = 32 KB a stage, 32 one-KB pieces (eight per issuing wave, scalar bases), ring of three stages;
+//   * every thread cuts ITS 2 columns x 8 rows of the NEXT step out of the landed stage (what mlp_wgrad_bx cuts) into mlp_wgrad_bx's fragment
+//     image (one 32 KB buffer), behind the products of the CURRENT step, whose fragments are already in registers;
+//   * two barriers a step: A -- the pieces of this step are written and the rows of the next have landed; B -- everybody holds its
+//     fragments and its rows, the piece buffer and the oldest raw stage may be rewritten.
+// Same pieces, same products in the same order as mlp_wgrad_bx<3>: the same bits.
+#ifndef MATPBR_WG_HX
+#define MATPBR_WG_HX 1                         // (measurement builds: 0 = the register-staged mlp_wgrad_bx<3>)
+#endif
+constexpr int kHxRaw = 16 * 2 * 1024;                      // bytes of a raw stage: [G rows 0..15][X rows 0..15], 1 KB each
+constexpr int kHxPieces = 2 * 2 * 2 * 256;                 // uint4 of the piece buffer: [G|X][piece][row half][column slot]
+constexpr size_t kHxSmem = 3 * kHxRaw + kHxPieces * sizeof(uint4);     // 128 KB
+__global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_hx(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                              float* __restrict__ partial, long M, long rows_per_slab, const unsigned* __restrict__ g_tmax) {
+  extern __shared__ __align__(16) unsigned char hx_smem[];
+  uint4* sP = reinterpret_cast<uint4*>(hx_smem + 3 * kHxRaw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nq = wave >> 1, kq = wave & 1, li = lane & 31, lh = lane >> 5;
+  const long m_begin = (long)blockIdx.x * rows_per_slab;
+  const long m_end = (m_begin + rows_per_slab < M) ? m_begin + rows_per_slab : M;
+  const int steps = m_begin < m_end ? (int)((m_end - m_begin) / 16) : 0;
+  float g_scale = 1.0f, g_unscale = 1.0f;
+  if (steps > 0) {
+    unsigned mb = 0;
+    for (long t = m_begin / kBM; t <= (m_end - 1) / kBM; ++t) mb = g_tmax[t] > mb ? g_tmax[t] : mb;      // magnitudes: bit patterns order as values
+    block_scale(mb, g_scale, g_unscale);
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][ki][r] = 0.f;
+  if (steps > 0) {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool loader = wave_u < 4;                               // (uniform per wave)
+    const unsigned lds0 = lds_byte_address(hx_smem);
+    unsigned vg[4], vx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vg[j] = (unsigned)(j * ldg) * 4u + (unsigned)lane * 16u - 1024u * j;
+      vx[j] = (unsigned)(j * ldx) * 4u + (unsigned)lane * 16u - 1024u * j;
+    }
+    auto issue = [&](int step, int buf) {                         // a loader wave's rows 4 w .. 4 w + 3 of the step, of G and of X
+      const int sc = step < steps ? step : steps - 1;              // (beyond the slab: the last rows again, into a buffer nobody reads)
+      const long row = m_begin + 16L * sc + 4 * wave_u;
+      const unsigned dst = lds0 + (unsigned)buf * (unsigned)kHxRaw + (unsigned)wave_u * 4096u;
+      glds16_x4v(G + row * ldg, vg[0], vg[1], vg[2], vg[3], dst);
+      glds16_x4v(X + row * ldx, vx[0], vx[1], vx[2], vx[3], dst + 16u * 1024u);
+    };
+    // the cut: this thread's 2 columns (pair cp of the 256 pairs of G | X) and row half sh, as mlp_wgrad_bx stages them
+    const int cp = tid & 255, sh = tid >> 8;
+    const float my_scale = (cp >> 7) ? 1.0f : g_scale;
+    const unsigned raw_off = (unsigned)((cp >> 7) * 16 * 1024 + (8 * sh) * 1024 + (cp & 127) * 8);          // + buf * kHxRaw + j * 1024
+    uint4* sdst = sP + (((cp >> 7) * 2) * 2 + sh) * 256 + ((cp & 127) >> 3) * 16 + (cp & 7);                  // + (piece * 2) * 256 + 8 * column
+    float2 raw[8];
+    auto read_raw = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const float2*>(hx_smem + buf * kHxRaw + raw_off + j * 1024);
+    };
+    auto cut_store = [&]() {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        uint4 pc[2];
+#define MATPBR_COMP(v) (c == 0 ? (v).x : (v).y)
+        split2h(MATPBR_COMP(raw[0]) * my_scale, MATPBR_COMP(raw[1]) * my_scale, pc[0].x, pc[1].x);
+        split2h(MATPBR_COMP(raw[2]) * my_scale, MATPBR_COMP(raw[3]) * my_scale, pc[0].y, pc[1].y);
+        split2h(MATPBR_COMP(raw[4]) * my_scale, MATPBR_COMP(raw[5]) * my_scale, pc[0].z, pc[1].z);
+        split2h(MATPBR_COMP(raw[6]) * my_scale, MATPBR_COMP(raw[7]) * my_scale, pc[0].w, pc[1].w);
+#undef MATPBR_COMP
+#pragma unroll
+        for (int piece = 0; piece < 2; ++piece) sdst[(piece * 2) * 256 + 8 * c] = pc[piece];
+      }
+    };
+    auto products = [&](const uint4 (&a)[2][2], const uint4 (&b)[2][4]) {
+#pragma unroll
+      for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {                                    // p2 q1, p1 q2, p1 q1: the small terms first
+          constexpr int ia[3] = {1, 0, 0}, ib[3] = {0, 1, 0};
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[ni][ki] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ia[t]][ni]), __builtin_bit_cast(f16x8, b[ib[t]][ki]), acc[ni][ki], 0, 0, 0);
+        }
+    };
+    if (loader) { issue(0, 0); issue(1, 1); }
+    if (loader) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");                              // the rows of step 0 have landed
+    read_raw(0);
+    cut_store();
+    if (loader) issue(2, 2);
+    const uint4* sa = sP + lh * 256 + nq * 64 + li;                      // + (piece * 2) * 256 + ni * 32
+    const uint4* sb = sP + (2 * 2 + lh) * 256 + kq * 128 + li;           // + (piece * 2) * 256 + ki * 32
+    int nxt = 1;                                                         // the raw buffer of step st + 1
+    for (int st = 0; st < steps; ++st) {
+      if (loader) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the rows of st + 1 have landed (st + 2 in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // A: pieces of st written by everybody
+      uint4 a[2][2], b[2][4];
+#pragma unroll
+      for (int piece = 0; piece < 2; ++piece) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) a[piece][ni] = sa[(piece * 2) * 256 + ni * 32];
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) b[piece][ki] = sb[(piece * 2) * 256 + ki * 32];
+      }
+      read_raw(nxt);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // B: everybody holds its fragments and its rows of st + 1
+      if (loader) {
+        issue(st + 3, nxt == 0 ? 2 : nxt - 1);                            // into the buffer of step st (cut during step st - 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      products(a, b);
+      cut_store();                                                       // the pieces of step st + 1 (beyond the slab: of its last rows, unused)
+      nxt = nxt == 2 ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the look-ahead pieces: nothing may land after the workgroup has ended
+  }
+  float* out = partial + (long)blockIdx.x * 256 * 256;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nq * 64 + ni * 32 + wg_perm((r & 3) + 8 * (r >> 2) + 4 * lh);
+        const int k = kq * 128 + ki * 32 + wg_perm(li);
+        out[n * 256 + k] = acc[ni][ki][r] * g_unscale;
+      }
+}
+
 constexpr size_t kBxSmem = 2 * kBxStage * sizeof(uint4) + 8 * 32 * kLd * sizeof(float);   // 96 KB of weights + 36 KB of epilogue scratch
 constexpr size_t kBxSmemHead = kBxSmem + (5 * 256 + 128 * 2 * 8) * sizeof(float);           // + output-layer weights and the row exchange
 // More than 64 KB of dynamic LDS needs an opt-in attribute, which HIP keeps per device: one bit per (kernel, device), set under the
@@ -3010,7 +3147,10 @@ static int mlp_layer_bwd_weight_bx_impl(const float* g, int ldg, const float* x,
   int slabs = wgrad_slabs(M);
   long rows = ((M + slabs - 1) / slabs + 15) / 16 * 16;
   slabs = (int)((M + rows - 1) / rows);
-  if (nprod == 3) {
+  if (nprod == 3 && MATPBR_WG_HX && (long)ldg * 4 >= 1024 && (long)ldx * 4 >= 1024 && (long)3 * ldg * 4 + 1024 < (1l << 31) && (long)3 * ldx * 4 + 1024 < (1l << 31)) {
+    if (!lds_opt_in<&mlp_wgrad_hx>(kHxSmem)) return MATPBR_ERR_LAUNCH;
+    hipLaunchKernelGGL(mlp_wgrad_hx, dim3(slabs), dim3(kWgThreads), kHxSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, g_tile_max);
+  } else if (nprod == 3) {
     if (!lds_opt_in<&mlp_wgrad_bx<3>>(kWgSmem)) return MATPBR_ERR_LAUNCH;
     hipLaunchKernelGGL(mlp_wgrad_bx<3>, dim3(slabs), dim3(kWgThreads), kWgSmem, (hipStream_t)stream, g, ldg, x, ldx, (float*)workspace, M, rows, g_tile_max);
   } else if (nprod == 6) {

@@ -32,7 +32,7 @@ ph = ArmMlpPhase(scene, torch.rand(H, W, 3, device=dev), posmlp.brdf_net("arm").
 for _ in range(4):
     ops.mlp_layer_fwd_bx(x, ws3, b, s, None, N, K, 3)                            # mlp_nt_gx<sin, 3>
     ops.mlp_layer_bwd_input_blk(g, tmx, ws3t, s, gp, N, K, db, tmo)              # mlp_nt_gx<mul cos, 3>
-    ops.mlp_layer_bwd_weight_blk(g, tmx, s, N, K)                                # mlp_wgrad_bx<3>
+    ops.mlp_layer_bwd_weight_blk(g, tmx, s, N, K)                                # mlp_wgrad_hx
     ph.forward()                                                                 # mlp_chain_fwd_kernel
     ops.mlp_layer_fwd_bx(x, ws6, b, s, None, N, K, 6)                            # round 4's forms
     ops.mlp_layer_bwd_input_bx(g, ws6, s, gp, N, K, db, 6, packed=True)
