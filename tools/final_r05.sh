@@ -20,7 +20,7 @@ d = json.load(open("gpurun_out/r05_bench.json"))
 r = d["roofline"]
 print(d["value"], d["ms_per_step"], r["frac"], r["avg_launch_ms"], r["traffic"], r["own_traffic_frac"], d["cpu_baseline"]["value"])
 # the perf gate (thresholds live here, not in pytest: the boxes of the pool are not all alike)
-assert d["value"] >= 580, d["value"]
+assert d["value"] >= 600, d["value"]
 assert r["frac"] >= 0.45, r["frac"]
 print({k: round(v["it_per_s"]) for k, v in d["modes"].items()})
 PY
