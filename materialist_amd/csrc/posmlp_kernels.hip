@@ -2085,13 +2085,19 @@ __global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_hx(const float* __res
   uint4* sP = reinterpret_cast<uint4*>(hx_smem + 3 * kHxRaw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nq = wave >> 1, kq = wave & 1, li = lane & 31, lh = lane >> 5;
-  const long m_begin = (long)blockIdx.x * rows_per_slab;
-  const long m_end = (m_begin + rows_per_slab < M) ? m_begin + rows_per_slab : M;
-  const int steps = m_begin < m_end ? (int)((m_end - m_begin) / 16) : 0;
+  // this workgroup's rows: the 128-row tiles T - 1 - b, T - 1 - b - grid, ... of the T tiles, each from its last rows to its first.  Interleaved,
+  // so that at any moment the launch reads ONE region of G and of X; DESCENDING, because the kernels on either side of it (the input
+  // gradients: tiles in ascending order) end at the last rows and start at the first -- what one kernel touched last is what the next
+  // touches first, and the 256 MB Infinity Cache still holds it (tools/ab.sh tools/wg_time.py "-DMATPBR_WG_ASCENDING")
+  (void)rows_per_slab;
+  const int tiles = (int)(M / kBM);
+  const int t_first = tiles - 1 - (int)blockIdx.x;
+  const int my_tiles = t_first >= 0 ? t_first / (int)gridDim.x + 1 : 0;
+  const int steps = my_tiles * (kBM / 16);
   float g_scale = 1.0f, g_unscale = 1.0f;
   if (steps > 0) {
     unsigned mb = 0;
-    for (long t = m_begin / kBM; t <= (m_end - 1) / kBM; ++t) mb = g_tmax[t] > mb ? g_tmax[t] : mb;      // magnitudes: bit patterns order as values
+    for (int t = t_first; t >= 0; t -= (int)gridDim.x) mb = g_tmax[t] > mb ? g_tmax[t] : mb;      // magnitudes: bit patterns order as values
     block_scale(mb, g_scale, g_unscale);
   }
   f32x16 acc[2][4];
@@ -2113,7 +2119,13 @@ __global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_hx(const float* __res
     }
     auto issue = [&](int step, int buf) {                         // a loader wave's rows 4 w .. 4 w + 3 of the step, of G and of X
       const int sc = step < steps ? step : steps - 1;              // (beyond the slab: the last rows again, into a buffer nobody reads)
-      const long row = m_begin + 16L * sc + 4 * wave_u;
+#if defined(MATPBR_WG_SLABS)
+      const long row = (long)blockIdx.x * (my_tiles * kBM) + 16L * sc + 4 * wave_u;      // (measurement: one contiguous slab per workgroup; tiles a multiple of the grid)
+#elif defined(MATPBR_WG_ASCENDING)
+      const long row = ((long)(tiles - 1 - t_first) + (long)(sc >> 3) * gridDim.x) * kBM + 16 * (sc & 7) + 4 * wave_u;
+#else
+      const long row = ((long)t_first - (long)(sc >> 3) * gridDim.x) * kBM + 16 * (7 - (sc & 7)) + 4 * wave_u;
+#endif
       const unsigned dst = lds0 + (unsigned)buf * (unsigned)kHxRaw + (unsigned)wave_u * 4096u;
       glds16_x4v(G + row * ldg, vg[0], vg[1], vg[2], vg[3], dst);
       glds16_x4v(X + row * ldx, vx[0], vx[1], vx[2], vx[3], dst + 16u * 1024u);
