@@ -29,6 +29,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"spp" in lib.matpbr_strerror(-2)
     assert lib.matpbr_shade_bwd_workspace_bytes(512, 512, 1, 25) == 512 * 75 * 4
     assert lib.matpbr_brdf_loss_workspace_bytes(2) > 0
+    # argument checks that return before anything touches a device: the deferred-fold entry point (at most 16 records, kinds it knows)
+    assert lib.matpbr_mlp_reduce_jobs(None, 0, None) != 0
+    jobs = (_lib.ReduceJob * 17)()
+    import ctypes
+    assert lib.matpbr_mlp_reduce_jobs(ctypes.cast(jobs, ctypes.c_void_p), 17, None) != 0
+    jobs[0].kind = 7
+    assert lib.matpbr_mlp_reduce_jobs(ctypes.cast(jobs, ctypes.c_void_p), 1, None) != 0
+    for k in range(3):
+        jobs[k].kind = -1                                   # MATPBR_REDUCE_NONE: nothing to fold, nothing launched
+    assert lib.matpbr_mlp_reduce_jobs(ctypes.cast(jobs, ctypes.c_void_p), 3, None) == 0
 
 
 def test_python_mirror_of_the_abi_struct_and_flags_matches_the_header(tmp_path):
