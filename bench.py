@@ -324,6 +324,11 @@ def main(argv=None):
     # Device warm-up, outside the protocol's W + K steps: a throw-away phase of the same mode runs for ~0.5 s.  The first GPU work of a fresh
     # process on an idle MI355X runs below its sustained clocks for some tens of milliseconds (measured: --steps 20 --warmup 5 as the box's
     # first process 256-284 it/s, the same command right after it 407-420); W = 5 iterations (12 ms) do not cover that.  Reported in the line.
+    # The phase that is timed is BUILT first (its 1.8 GB of buffers, its diffuse cache) and the warm-up runs right before its W + K steps:
+    # built after the warm-up (rounds 2-4), the allocations left the GPU idle for ~0.1 s and the protocol's first iterations ran on clocks that
+    # had dropped again (--steps 20 --warmup 5 read 3 % below --steps 300 on the same box).
+    phase = wl.phase(mode)
+    psnr0 = float(loop._loss.psnr(render.render_w_brdf(wl.scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), wl.gt_image).mean())
     t_w = time.perf_counter()
     warm = wl.phase(mode)
     wstep = getattr(warm, "bench_step", warm.step)
@@ -334,11 +339,8 @@ def main(argv=None):
         torch.cuda.synchronize()
         n_warm += 10
     device_warmup = {"seconds": round(time.perf_counter() - t_w, 3), "iterations_of_a_throwaway_phase": n_warm}
-    del warm, wstep
-    torch.cuda.empty_cache()
-    phase = wl.phase(mode)
-    psnr0 = float(loop._loss.psnr(render.render_w_brdf(wl.scene, *[phase.current_maps()[k].detach() for k in ("albedo", "roughness", "metallic")], None, args.spp), wl.gt_image).mean())
     elapsed, per_rank = proto.timed(stepper(phase), args.warmup, args.steps)
+    del warm, wstep
     value = args.steps * B * world / elapsed
     m = phase.current_maps()
     with torch.no_grad():
