@@ -311,6 +311,10 @@ constexpr int kWalkVals = 26;         // per-sample contributions: S0, S1, dS0, 
 __device__ __forceinline__ uint32_t ldu(const void* base, unsigned off) { return *(const uint32_t*)((const char*)base + off); }
 __device__ __forceinline__ float ldf(const void* base, unsigned off) { return *(const float*)((const char*)base + off); }
 __device__ __forceinline__ void stf(void* base, unsigned off, float v) { *(float*)((char*)base + off) = v; }
+// 12 bytes per lane of an HWC map: global_load_dwordx3 / global_store_dwordx3 at (uniform base) + (32-bit lane offset)
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3(const void* base, unsigned off) { return *(const F3*)((const char*)base + off); }
+__device__ __forceinline__ void st3(void* base, unsigned off, float x, float y, float z) { *(F3*)((char*)base + off) = F3{x, y, z}; }
 
 // one pixel of lazy_step_kernel; returns whether the pixel's new roughness has left its model's interval, adds its render to `tot`
 struct StepPtrs {             // where this image's iteration reads its parameters and writes the new ones and the next render (uniform)
@@ -325,8 +329,12 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const St
     if (qs.rotate) improved = false;      // no snapshot stores: the buffer just read IS the snapshot
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
-    const float ra[3] = {ldf(sp.a, o3), ldf(sp.a, o3 + 4), ldf(sp.a, o3 + 8)}, rr = ldf(sp.r, o1), rm = ldf(sp.m, o1);
-    const float gt[3] = {ldf(q.gt_srgb, o3), ldf(q.gt_srgb, o3 + 4), ldf(q.gt_srgb, o3 + 8)};
+    // HWC maps as ONE 12-byte access per lane (as the folded step): a third of the memory instructions of the albedo's streams, and Adam's
+    // moments of the albedo in registers between their load and their store -- the 'arm' part of the 8 x 512^2 shard 140 -> 123 us per
+    // iteration on one box (tools/arm_trace.py), the same bits
+    const F3 ra3 = ld3(sp.a, o3), gt3 = ld3(q.gt_srgb, o3);
+    const float ra[3] = {ra3.x, ra3.y, ra3.z}, rr = ldf(sp.r, o1), rm = ldf(sp.m, o1);
+    const float gt[3] = {gt3.x, gt3.y, gt3.z};
     // the pixel's model
     const float rref = as_f(ldu(qs.plane[kLzRref], o1));
     const uint32_t lohi = ldu(qs.plane[kLzLoHi], o1);
@@ -380,24 +388,38 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const St
     }
     float na[3] = {ra[0], ra[1], ra[2]}, nr = rr, nm = rm;     // the raw parameters after the step
     if (q.part_mask & MATPBR_PART_A) {
+        const F3 a03 = ld3(q.a0, o3);
+        const float a0v[3] = {a03.x, a03.y, a03.z};
+        float mo[3] = {0.0f, 0.0f, 0.0f}, vo[3] = {0.0f, 0.0f, 0.0f}, gs[3];
+        if (q.am[0]) {
+            const F3 m3 = ld3(q.am[0], o3), v3 = ld3(q.av[0], o3);
+            mo[0] = m3.x; mo[1] = m3.y; mo[2] = m3.z; vo[0] = v3.x; vo[1] = v3.y; vo[2] = v3.z;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float a0c = ldf(q.a0, o3 + 4 * c);
+            const float a0c = a0v[c];
             float gsum = da[c] + q.scale_delta * q.inv_n3 * fsign(a[c] - a0c);                                                   // :398,418
             gsum = (ra[c] >= 0.0f && ra[c] <= 1.0f) ? gsum : 0.0f;                                                               // clamp backward
-            if (q.d_a) stf(q.d_a, o3 + 4 * c, gsum);
-            if (improved && q.best_a) stf(q.best_a, o3 + 4 * c, a[c]);
-            if (q.am[0]) { na[c] = adam_update(ra[c], gsum, q.am[0], q.av[0], (long)i * 3 + c, q); stf(sp.pa, o3 + 4 * c, na[c]); }
+            gs[c] = gsum;
+            if (q.am[0]) {                                     // adam_update on registers: the same operations
+                const float mi = fmaf(q.b1, mo[c], (1.0f - q.b1) * gsum);
+                const float vi = fmaf(q.b2, vo[c], (1.0f - q.b2) * gsum * gsum);
+                mo[c] = mi; vo[c] = vi;
+                na[c] = ra[c] - q.lr_over_bc1 * mi / fmaf(fsqrt(vi), q.inv_sqrt_bc2, q.eps);
+            }
             reg[0] += fabsf(fminf(fmaxf(na[c], 0.0f), 1.0f) - a0c);
         }
+        if (q.d_a) st3(q.d_a, o3, gs[0], gs[1], gs[2]);
+        if (improved && q.best_a) st3(q.best_a, o3, a[0], a[1], a[2]);
+        if (q.am[0]) {
+            st3(q.am[0], o3, mo[0], mo[1], mo[2]);
+            st3(q.av[0], o3, vo[0], vo[1], vo[2]);
+            st3(sp.pa, o3, na[0], na[1], na[2]);
+        }
     } else if (q.d_a) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) stf(q.d_a, o3 + 4 * c, (ra[c] >= 0.0f && ra[c] <= 1.0f) ? da[c] : 0.0f);
+        st3(q.d_a, o3, (ra[0] >= 0.0f && ra[0] <= 1.0f) ? da[0] : 0.0f, (ra[1] >= 0.0f && ra[1] <= 1.0f) ? da[1] : 0.0f, (ra[2] >= 0.0f && ra[2] <= 1.0f) ? da[2] : 0.0f);
     }
-    if (improved && q.best_img) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) stf(q.best_img, o3 + 4 * c, xs_keep[c]);
-    }
+    if (improved && q.best_img) st3(q.best_img, o3, xs_keep[0], xs_keep[1], xs_keep[2]);
     const float r0v = (q.part_mask & MATPBR_PART_R) ? ldf(q.r0, o1) : 0.0f, m0v = (q.part_mask & MATPBR_PART_M) ? ldf(q.m0, o1) : 0.0f;
     float gr = drr + ((q.part_mask & MATPBR_PART_R) ? q.scale_delta * q.inv_n1 * fsign(r - r0v) : 0.0f);
     float gm = dm + ((q.part_mask & MATPBR_PART_M) ? q.scale_delta * q.inv_n1 * fsign(m - m0v) : 0.0f);
@@ -421,6 +443,7 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const St
     const bool need = !(dr1 >= -h2_lo(lohi) && dr1 <= h2_hi(lohi));
 #endif
     rec.r = r1; rec.m = m1; rec.dr = dr1;
+    float rgb3[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float a1 = fminf(fmaxf(na[c], 0.0f), 1.0f);
@@ -429,11 +452,10 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const St
         const float C0 = fmaf(m1, a1, omm1 * 0.04f);
         const float rgb = fmaf(a1 * omm1, Pc, fmaf(C0, SD, S1));
         rec.a[c] = a1;
-        if (!need) {
-            stf(sp.pred_next, o3 + 4 * c, rgb);
-            tot += rgb;
-        }
+        rgb3[c] = rgb;
+        if (!need) tot += rgb;
     }
+    if (!need) st3(sp.pred_next, o3, rgb3[0], rgb3[1], rgb3[2]);
     return need;
 }
 

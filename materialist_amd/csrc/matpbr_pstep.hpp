@@ -22,10 +22,6 @@
 
 namespace matpbr {
 
-// 12 bytes per lane of an HWC map: global_load_dwordx3 / global_store_dwordx3 at (uniform base) + (32-bit lane offset)
-struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
-__device__ __forceinline__ F3 ld3(const void* base, unsigned off) { return *(const F3*)((const char*)base + off); }
-__device__ __forceinline__ void st3(void* base, unsigned off, float x, float y, float z) { *(F3*)((char*)base + off) = F3{x, y, z}; }
 __device__ __forceinline__ void stu(void* base, unsigned off, uint32_t v) { *(uint32_t*)((char*)base + off) = v; }
 
 __device__ __forceinline__ float xy_x2(uint32_t q0, uint32_t q1, int c) { return c == 0 ? h2_lo(q0) : (c == 1 ? h2_hi(q0) : h2_lo(q1)); }
