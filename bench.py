@@ -589,6 +589,7 @@ def main(argv=None):
         t_step, t_stats, resampled, t_res = lazy_step_times(wr)
         ach = (BYTES_FWD + BYTES_BWD_ARM) * px / (t_step * 1e-3) / 1e9
         traffic = pmc.get(f"lazy_pstep_{key}")
+        ge = lazy_gradient_error(wr)
         roof = {"bound": "hbm", "kernel": "lazy_pstep_kernel<kFoldXY>: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, "
                                           "SaveBest by buffer rotation, Adam) + render of iteration t+1 from per-pixel local models in the roughness with the part's "
                                           "constant albedo folded in (68 B/pixel of model); the pixels that left their model's interval are queued and re-sampled "
@@ -600,12 +601,13 @@ def main(argv=None):
                 "bytes_per_pixel": BYTES_FWD + BYTES_BWD_ARM,
                 "workload": f"{wr.B} x {H}x{W} (BASELINE configs[2] per-GPU shard)" if wr.B == 8 else f"{wr.B} x {H}x{W}",
                 "resampled_fraction": resampled, "stats_launches_ms": t_stats, "resample_launch_ms": t_res,
-                "gradient_error_of_this_kernel": dict(lazy_gradient_error(wr), note="d loss / d roughness, d loss / d metallic at iteration 401 of the part, every pixel, "
+                "gradient_error_of_this_kernel": dict(ge, note="d loss / d roughness, d loss / d metallic at iteration 401 of the part, every pixel, "
                                                       "against the backward pass on exact sampling of the same parameters (pixel errors relative to max(|g|, mean|g|)).  "
                                                       "derivatives_of_the_models: d loss / d pred formed on the lazy loop's own render for both sides -- the error of d out / d r "
                                                       "(first order in r - r_ref since round 5) and d out / d m alone; whole_loss_gradient: on the exact render -- adds the pixels "
                                                       "whose sign(pred - gt) of the L1 term differs between two renders that agree to 1e-3 (converged pixels; grows as the part "
                                                       "converges).  The RENDER of the same kernel is within 1e-3 of exact sampling on every pixel (tests/test_gpu_lazy.py)"),
+                "grad_rel_l2": ge["derivatives_of_the_models"]["roughness"]["rel_l2"], "grad_worst_pixel": ge["derivatives_of_the_models"]["roughness"]["worst_pixel"],
                 "traffic": traffic, "traffic_source": pmc.get("source_r04") if traffic else pmc.get("stale"),
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "
