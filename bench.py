@@ -32,6 +32,55 @@ BYTES_FWD = 44             # read a 12 + r 4 + m 4 + n 12, write r
 BYTES_BWD_ARM = 64         # read a,r,m,n 32 + d_rgb 12, write d_a 12 + d_r 4 + d_m 4
 BYTES_ENV = 312            # hot loop A on the transfer: read T 300 + gt 12 per pixel (pred not written)
 
+LINE_LIMIT = 4096          # the driver parses the LAST stdout line; round 5's 20 KB line did not parse
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "world_size", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+_CONFIG_KEYS = ("workload", "mode", "height", "width", "spp", "images_per_gpu", "light", "parallelism")
+_ROOF_KEYS = ("bound", "kernel", "workload", "achieved", "peak", "unit", "frac", "avg_launch_ms", "bytes_per_pixel", "traffic", "own_traffic_frac",
+              "grad_rel_l2", "grad_worst_pixel", "iteration_frac")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+
+
+def _short(v, n=120):
+    if isinstance(v, str):
+        return v if len(v) <= n else v[: n - 3] + "..."
+    if isinstance(v, float):
+        return float(f"{v:.6g}")
+    return v
+
+
+def compact_line(out: dict) -> str:
+    """The ONE line the driver parses: the contract's keys, numbers and short names only (<= LINE_LIMIT bytes).  Everything else of `out`
+    (modes, per-kernel legs, notes, host_enqueue ...) goes to bench_detail.json (write_detail)."""
+    line = {k: _short(out[k]) for k in _TOP_KEYS if k in out}
+    line["config"] = {k: _short(out["config"][k]) for k in _CONFIG_KEYS if k in out.get("config", {})}
+    if out.get("roofline"):
+        line["roofline"] = {k: _short(out["roofline"][k], 100) for k in _ROOF_KEYS if k in out["roofline"]}
+    if out.get("cpu_baseline"):
+        line["cpu_baseline"] = {k: _short(out["cpu_baseline"][k], 160) for k in _CPU_KEYS if k in out["cpu_baseline"]}
+    if out.get("modes"):
+        line["modes_it_per_s"] = {k: _short(float(v["it_per_s"])) for k, v in out["modes"].items()}
+    if out.get("psnr_db"):
+        line["psnr_db"] = {k: _short(v) for k, v in out["psnr_db"].items() if not isinstance(v, str)}
+    line["detail"] = "bench_detail.json"
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:                      # never print a line the driver cannot parse: drop the optional blocks first
+        for k in ("modes_it_per_s", "psnr_db"):
+            line.pop(k, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(out: dict) -> None:
+    """Everything the run measured, for people: bench_detail.json beside bench.py (and under gpurun_out/ when that exists, so that it travels back)."""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError:
+                pass
+
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
@@ -590,7 +639,8 @@ def main(argv=None):
         ach = (BYTES_FWD + BYTES_BWD_ARM) * px / (t_step * 1e-3) / 1e9
         traffic = pmc.get(f"lazy_pstep_{key}")
         ge = lazy_gradient_error(wr)
-        roof = {"bound": "hbm", "kernel": "lazy_pstep_kernel<kFoldXY>: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, "
+        roof = {"bound": "hbm", "kernel": "lazy_pstep_kernel (BRDF bwd of iteration t + Adam + fwd of t+1, one launch)",
+                "kernel_detail": "lazy_pstep_kernel<kFoldXY>: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, "
                                           "SaveBest by buffer rotation, Adam) + render of iteration t+1 from per-pixel local models in the roughness with the part's "
                                           "constant albedo folded in (68 B/pixel of model); the pixels that left their model's interval are queued and re-sampled "
                                           "(20 GGX samples) by the small launch behind it (resample_launch_ms)",
@@ -780,9 +830,11 @@ def main(argv=None):
             "world_size": dist.get_world_size() if use_dist else 1, "collective_backend": dist.get_backend() if use_dist else None,
             "steps": args.steps, "warmup": args.warmup, "device_warmup": device_warmup, "cold_first_process_it_per_s": cold, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2-synthetic (BASELINE configs[1]): {H}x{W}, one epoch of hot loop B, part 'rm' of --opt_order 'rm a', "
+            "config": {"workload": f"BASELINE configs[1] synthetic: {B}x{H}x{W}/GPU, --model_name {'pos_mlp' if mode == 'pos_mlp' else 'none'} --opt_order 'rm a' part rm, spp {args.spp}",
+                       "workload_detail": f"C2-synthetic (BASELINE configs[1]): {H}x{W}, one epoch of hot loop B, part 'rm' of --opt_order 'rm a', "
                                    f"{'--model_name pos_mlp' if mode == 'pos_mlp' else '--model_name none'} "
                                    f"(maps -> render -> gamma-2.2 MSE/L1 loss -> backward -> Adam(W)), spp={args.spp}, geometric normals, SH25 light",
+                       "parallelism": f"dp{world} (independent images, no data-path collective)",
                        "mode": mode, "mode_requested": args.mode, "height": H, "width": W, "spp": args.spp, "images_per_gpu": B, "light": "SH25",
                        "phase": type(phase).__name__ + (" (two groups of images on streams of their own: the same results as one phase, bit for bit)"
                                                         if type(phase).__name__ == "PipelinedBrdfPhase" else ""),
@@ -808,7 +860,8 @@ def main(argv=None):
             out["roofline"] = roof
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        write_detail(out)
+        print(compact_line(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

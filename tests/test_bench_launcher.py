@@ -30,3 +30,27 @@ def test_bench_single_process_does_not_launch():
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and len(out["ranks"]) == 1
+
+
+def test_bench_line_is_compact_and_carries_the_contract_keys():
+    """The driver parses the LAST stdout line: round 5's 20 KB line came back `parsed: null`.  The line is assembled by bench.compact_line from the
+    full record (which goes to bench_detail.json); it must stay under 4 KB whatever the record holds, and keep the contract's keys."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))           # a real (20 KB) record of the same shape
+    full["roofline"]["note"] = "x" * 50_000                                            # prose of any length never reaches the line
+    full["config"]["workload"] = "w" * 5_000
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT == 4096 and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(("workload", "mode", "height", "width", "spp", "images_per_gpu")) <= set(line["config"]) and len(line["config"]["workload"]) <= 120
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "bytes_per_pixel")) <= set(line["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert line["value"] == float(f"{full['value']:.6g}") and line["roofline"]["frac"] == float(f"{full['roofline']['frac']:.6g}")
+    # a record with hundreds of modes still yields a parseable line (the optional blocks are dropped first)
+    full["modes"] = {f"mode_{i}": {"it_per_s": 1.0 + i} for i in range(600)}
+    assert len(bench.compact_line(full)) < 4096
