@@ -367,8 +367,11 @@ def test_rccl_path_of_the_bench_at_world_size_one():
            "--steps", "300", "--warmup", "10"]           # the default line's `fused_b8` protocol (a phase's first iterations re-sample the most)
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)      # a child process: never an exec from a GPU-initialised one
     assert res.returncode == 0, res.stderr[-2000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    line = res.stdout.splitlines()[-1]                   # the driver parses the LAST stdout line: compact, contract keys only
+    assert len(line) < 4096
+    brief = json.loads(line)
+    out = json.load(open(os.path.join(root, brief["detail"])))          # the full record of the same run
+    assert brief["value"] == pytest.approx(out["value"], rel=1e-5) and brief["config"]["images_per_gpu"] == 8 and brief["world_size"] == 1
     assert out["world_size"] == 1 and out["n_gpus"] == 1 and out["collective_backend"] == "nccl"
     assert out["config"]["images_per_gpu"] == 8 and out["config"]["mode"] == "fused"
     assert out["value"] == pytest.approx(300 * 8 / (out["ms_per_step"] * 300 * 1e-3), rel=1e-6)     # image-iterations/s over all ranks
@@ -378,7 +381,10 @@ def test_rccl_path_of_the_bench_at_world_size_one():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-relight", "--steps", "5", "--warmup", "2"], env=env,
                          capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
-    default = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    brief = json.loads(res.stdout.splitlines()[-1])
+    assert len(res.stdout.splitlines()[-1]) < 4096 and 0 < brief["roofline"]["frac"] < 1 and brief["modes_it_per_s"]["fused_b8"] > 0
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"} <= set(brief["roofline"])
+    default = json.load(open(os.path.join(root, brief["detail"])))
     b8 = default["modes"]["fused_b8"]
     # structure and consistency only: throughput and roofline thresholds are the perf gate's business (tools/final_r05.sh), not a test's --
     # the boxes of the pool are not all alike
