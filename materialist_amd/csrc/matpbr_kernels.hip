@@ -1624,7 +1624,11 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     const int nfwd = fold != kFoldNone ? grid_blocks(q.H, q.W)
                                        : grid_blocks(q.H, q.W) + ((lazy_fused && t > 1) ? (resample ? nres : 0) : (lazy ? lazy_groups((long)q.H * q.W) : 0));
     float* fwd_sums = (float*)q.workspace;
-    float* part = fwd_sums + (size_t)q.batch * nfwd;
+    // the statistics rows at a FIXED place behind the forward sums' capacity.  (Rounds 3-5 put them right behind the nfwd sums in use; at t = 1 of a
+    // generic step nfwd = blocks + refresh groups is smaller than the blocks + resampling waves per image the step kernel of the same iteration
+    // strides its block sums by, so a workgroup of image b >= 1 that finished early stored its block sum INTO rows other workgroups of the launch
+    // were still folding: a race of a phase's first iteration, seen as a regulariser term of a few per cent in one run of many.)
+    float* part = fwd_sums + (size_t)q.batch * fwd_sums_cap(q.H, q.W);
     const long n1 = (long)q.H * q.W, n3 = n1 * 3;
     dim3 grid((unsigned)grid_blocks(q.H, q.W), (unsigned)q.batch);
     // 1. render with the clamped parameters (:371-386): specular samples only when the diffuse coefficients are cached;

@@ -20,11 +20,23 @@ namespace matpbr {
 // ---- constants of the specification (oracle/matpbr_oracle.c LAZY_*) --------------------------------------------------------
 constexpr float kLzH = 1e-3f, kLzRhoInit = 2e-3f, kLzRhoMin = 2.5e-4f, kLzRhoMax = 3e-2f, kLzTolS = 2.5e-4f, kLzTolK = 1.5e-4f;
 constexpr float kLzKinkSafety = 0.8f, kLzMoved = 1e-4f;
+// round 6: the radius also answers to the DERIVATIVE the model hands the backward pass.  At a refresh the old model's prediction of the detached
+// derivative d out_c / d r at the new roughness (dSD + eSD dr, dS1 + eS1 dr) is compared with the walked one, relative to
+// max(|d out_c / d r|, kLzJFloor x the parity floor), tolerance kLzTolJ -- the same controller, on the larger of the two normalised errors
+constexpr float kLzTolJ = 2.5e-4f, kLzJFloor = 0.25f;
+__device__ __forceinline__ float lazy_rho_next(float rho, float adr, float e_s, float e_j, float tol_s, float tol_j) {
+    const float ec = fmaxf(e_s * (1.0f / tol_s), e_j * (1.0f / tol_j));
+    const float want = 0.9f * adr * rsq(fmaxf(ec, 1e-9f));
+    return fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
+}
 
 // ---- state: 32-bit planes of B*P entries (a lane's two pixels are an 8-byte access, a wave's access is 512 contiguous bytes) ----
 enum { kLzRref = 0, kLzLoHi = 1 /* half2 (lo, hi) */, kLzRho = 2, kLzP = 3, kLzSD = 6, kLzS1 = 9,
        kLzPk = 12 /* half2 (P', A2) */, kLzSk = 15 /* half2 (gSD, gS1) */, kLzDk = 18 /* half2 (dSD, dS1) */,
-       kLzEk = 21 /* half2 (eSD, eS1): the slopes of dSD, dS1 in r (round 5: d out / d r to first order in r - r_ref) */, kLzPlanes = 24 };
+       kLzEk = 21 /* half2 (eSD, eS1): the slopes of dSD, dS1 in r (round 5: d out / d r to first order in r - r_ref) */,
+       kLzD32 = 24 /* dSD_c at 24 + c, dS1_c at 27 + c in fp32: read by the NEXT refresh of the pixel only (the radius control compares the old model's
+                      prediction of the derivative with the walked one: half-precision rounding of dSD, dS1 would drown the tolerance) -- no streaming kernel reads them */,
+       kLzPlanes = 30 };
 // jac16: 5 planes, half2 (P_c, SD_c) for c = 0..2, half2 (JR_0, JR_1), half2 (JR_2, 0)
 constexpr int kJac16Planes = 5;
 constexpr int kLazyBlockPixels = 2 * kBlock;
@@ -44,16 +56,28 @@ __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(ui
 //       X_c(dr) = X0 + X1 dr + X2 dr^2,  Y_c(dr) = Y0 + Y1 dr - X2 dr^2  (X2 = a_c A2_c: P is an exact quadratic in r),
 //       d out_c / d m = Y_c(dr);  d out_c / d r = JX_c + m JY_c with JX = JX0 + 2 X2 dr, JY = JY0 - 2 X2 dr: the stop-gradient convention
 //       (JX0 = a dP + 0.04 dSD + dS1, JY0 = (a - 0.04) dSD - a dP); with attached sampling the models' slopes X1, Y1 take their place.
-//       17 planes = 68 B/pixel (the generic model: 92 B/pixel + the 12 B/pixel of the albedo it is combined with).
+//       18 planes = 72 B/pixel (the generic model: 96 B/pixel + the 12 B/pixel of the albedo it is combined with).
 //   kFoldGH (part 'a': roughness and metallic are constants of the part)   out_c = a_c G_c + H_c,   d out_c / d a_c = G_c,
 //       G_c = (1 - m) P_c(dr) + m SD_c(dr),   H_c = 0.04 (1 - m) SD_c(dr) + S1_c(dr):  6 planes = 24 B/pixel, never re-sampled.
 // The generic planes stay the specification (oracle/matpbr_oracle.c); the folded ones are derived from them by lazy_fold_kernel at the
 // start of a part and rewritten together with them for every re-sampled pixel.
 enum { kFoldNone = 0, kFoldXY = 1, kFoldGH = 2 };
-enum { kFxRref = 0, kFxLoHi = 1, kFxX0 = 2 /* X0_c at 2 + 2c, Y0_c at 3 + 2c */, kFxS = 8 /* half2 (X1_c, Y1_c) */, kFxJ = 11 /* half2 (JX0_c, JY0_c) */,
-       kFxQ = 14 /* half2 (X2_0, X2_1); half (X2_2) | two bf8 (JX1_0, JY1_0) */, kFxE = 16 /* four bf8: JX1_1, JY1_1, JX1_2, JY1_2 */, kFxPlanes = 17 };
-// JX1, JY1: the slopes of the folded detached derivative (JX = JX0 + (2 X2 + JX1) dr, JY = JY0 + (JY1 - 2 X2) dr).  They multiply dr <= 0.03 and
-// correct d out / d r by a few per cent: eight bits (e5m2) carry them -- the six of them are 6 of the 8 spare bytes of one more plane + kFxQ's spare half
+enum { kFxRref = 0, kFxLoHi = 1 /* byte lo | byte hi (iv_pack) | half X2_0 */, kFxX0 = 2 /* X0_c at 2 + 2c, Y0_c at 3 + 2c */, kFxS = 8 /* half2 (X1_c, Y1_c) */,
+       kFxJ = 11 /* half2 (JX0_c, JY0_c) */, kFxQ = 14 /* half2 (X2_1, X2_2) */, kFxE = 15 /* half2 (JX1_c, JY1_c) at 15 + c */, kFxPlanes = 18 };
+// JX1, JY1: the slopes of the folded detached derivative (JX = JX0 + (2 X2 + JX1) dr, JY = JY0 + (JY1 - 2 X2) dr).  Round 5 carried them in eight
+// bits (e5m2): a first-order term of 5 % of the derivative at the far end of an interval then comes with an error of up to 6e-3 of the derivative
+// (tools/lazy_grad_diag.py), above the 1e-3 the gradients are held to -- half precision since round 6.  The interval's two lengths pay for four of
+// the six bytes: eight bits each (iv_pack: four exponent and four mantissa bits, rounded DOWN -- an interval never widens; 3 % shorter on average).
+constexpr int kIvBias = (127 - 21) << 4;        // code 0 = 2^-21 (4.8e-7: 1/200 of an Adam step; shorter intervals are carried as that), code 255 = 3.03e-2 >= kLzRhoMax
+__device__ __forceinline__ uint32_t iv_pack(float x) {
+    const int q = (int)(__builtin_bit_cast(uint32_t, x) >> 19) - kIvBias;
+    return (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
+__device__ __forceinline__ float iv_unpack(uint32_t code) { return __builtin_bit_cast(float, (code + (uint32_t)kIvBias) << 19); }
+__device__ __forceinline__ float iv_round(float x) { return iv_unpack(iv_pack(x)); }      // the specification's interval lengths ARE these 256 values
+__device__ __forceinline__ uint32_t pack_lohi_x2(float lo, float hi, float x2_0) {
+    return iv_pack(lo) | (iv_pack(hi) << 8) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)x2_0) << 16);
+}
 enum { kFgG = 0, kFgH = 3, kFgPlanes = 6 };
 // The slopes eSD, eS1 of the detached derivatives come from a one-sided difference over kLzH; a sample that crosses the horizon inside that
 // stencil makes the difference a jump / h, not a slope.  Whatever they are, they may correct the derivative by at most half its size
@@ -62,22 +86,23 @@ __device__ __forceinline__ float lazy_e_cap(float e, float dSD, float dS1, float
     const float lim = 0.5f * (fabsf(dSD) + fabsf(dS1)) / fmaxf(fmaxf(lo, hi), 1e-4f);
     return fminf(fmaxf(e, -lim), lim);
 }
-struct FoldXY { float X0, Y0, X1, Y1, JX0, JY0, X2, JX1, JY1; };
-template <bool UPPER>
-__device__ __forceinline__ uint32_t pack_bf8x2(float lo, float hi, uint32_t old) {     // two e5m2 bytes into a half of `old` (magnitudes clamped: no infinities)
-    const float c = 49152.0f;
-    return (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(lo, -c), c), fminf(fmaxf(hi, -c), c), (int)old, UPPER);
-}
-template <int BYTE> __device__ __forceinline__ float bf8_at(uint32_t w) { return __builtin_amdgcn_cvt_f32_bf8((int)w, BYTE); }
+// kFxJ carries (JA0_c, JY0_c) with JA0 = JX0 + m_ref JY0, m_ref = the pixel's metallic when its model was built, in eight bits (code / 255: the low
+// byte of the word that holds Y0 of the blue channel, whose mantissa keeps 15 bits): d out_c / d r = JA0 + (m - m_ref) JY0 + ..., so that the
+// half-precision rounding of the two words is relative to the derivative itself, not to two terms that may cancel in JX0 + m JY0 (round 6).
+struct FoldXY { float X0, Y0, X1, Y1, JX0 /* JA0 */, JY0, X2, JX1, JY1; uint32_t Y0w; };
+__device__ __forceinline__ uint32_t mref_code(float m) { return (uint32_t)__builtin_rintf(fminf(fmaxf(m, 0.0f), 1.0f) * 255.0f); }
+__device__ __forceinline__ float mref_of(uint32_t word) { return (float)(word & 0xffu) * (1.0f / 255.0f); }
 __device__ __forceinline__ void fold_xy(float a, float P, float SD, float S1, float dP, float A2, float gSD, float gS1, float dSD, float dS1, float eSD, float eS1,
-                                        FoldXY& f) {
+                                        uint32_t mcode, bool carries_code, FoldXY& f) {
     const float am = a - 0.04f, naP = -(a * P), nadP = -(a * dP);
     f.X0 = fmaf(a, P, fmaf(0.04f, SD, S1));
     f.Y0 = fmaf(am, SD, naP);
+    f.Y0w = as_u(f.Y0);
+    if (carries_code) { f.Y0w = (f.Y0w & 0xffffff00u) | mcode; f.Y0 = as_f(f.Y0w & 0xffffff00u); }
     f.X1 = fmaf(a, dP, fmaf(0.04f, gSD, gS1));
     f.Y1 = fmaf(am, gSD, nadP);
-    f.JX0 = fmaf(a, dP, fmaf(0.04f, dSD, dS1));
     f.JY0 = fmaf(am, dSD, nadP);
+    f.JX0 = fmaf(mref_of(mcode), f.JY0, fmaf(a, dP, fmaf(0.04f, dSD, dS1)));
     f.X2 = a * A2;
     f.JX1 = fmaf(0.04f, eSD, eS1);
     f.JY1 = am * eSD;
@@ -661,7 +686,7 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
     }
     float dir = dr < 0.0f ? -1.0f : 1.0f;
     if (rc_r + dir * kLzH > 1.0f || rc_r + dir * kLzH < 0.07f) dir = -dir;
-    float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3], pSD[3], pS1[3];
+    float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3], pSD[3], pS1[3], pdSD[3], pdS1[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float A0 = ldf(qs.dcache + c * BPl, o1), A1 = ldf(qs.dcache + (3 + c) * BPl, o1);
@@ -669,6 +694,9 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
         const uint32_t sk = ldu(qs.plane[kLzSk + c], o1);      // what the old model predicts at the new roughness
         pSD[c] = fmaf(h2_lo(sk), dr, as_f(ldu(qs.plane[kLzSD + c], o1)));
         pS1[c] = fmaf(h2_hi(sk), dr, as_f(ldu(qs.plane[kLzS1 + c], o1)));
+        const uint32_t ek = ldu(qs.plane[kLzEk + c], o1);      // ... and of the detached derivatives
+        pdSD[c] = fmaf(h2_lo(ek), dr, as_f(ldu(qs.plane[kLzD32 + c], o1)));
+        pdS1[c] = fmaf(h2_hi(ek), dr, as_f(ldu(qs.plane[kLzD32 + 3 + c], o1)));
         Pc[c] = fmaf(fmaf(A2[c], rc_r, A1), rc_r, A0);
         dP[c] = fmaf(2.0f * rc_r, A2[c], A1);
         kd[c] = rc[1 + c] * (1.0f - mv);
@@ -765,12 +793,15 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             eS1[c] = (fv[23 + c] - fv[9 + c]) * ih;
         }
         float rho = rho_old;
-        if (fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
-            float e = 0.0f;
+        if (fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error of the render and of d out / d r
+            float e = 0.0f, ej = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) e = fmaxf(e, fabsf(fmaf(C0[c], pSD[c] - vSD[c], pS1[c] - vS1[c])) * iscale[c]);
-            const float want = 0.9f * fabsf(dr) * fsqrt(tol_s / fmaxf(e, 1e-12f));
-            rho = fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
+            for (int c = 0; c < 3; ++c) {
+                e = fmaxf(e, fabsf(fmaf(C0[c], pSD[c] - vSD[c], pS1[c] - vS1[c])) * iscale[c]);
+                const float jc = fmaf(kd[c], dP[c], fmaf(C0[c], dSD[c], dS1v[c]));
+                ej = fmaxf(ej, fabsf(fmaf(C0[c], pdSD[c] - dSD[c], pdS1[c] - dS1v[c])) / fmaxf(fabsf(jc), kLzJFloor * floor_));
+            }
+            rho = lazy_rho_next(rho, fabsf(dr), e, ej, tol_s, tol_s * (kLzTolJ / kLzTolS));
         }
         rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
 #pragma unroll
@@ -780,7 +811,7 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             eSD[c] = es;
         }
         *(uint32_t*)((char*)qs.plane[kLzRref] + o1) = as_u(rc_r);
-        *(uint32_t*)((char*)qs.plane[kLzLoHi] + o1) = pack_h2(0.998f * fminf(fv[18], rho), 0.998f * fminf(fv[19], rho));
+        *(uint32_t*)((char*)qs.plane[kLzLoHi] + o1) = pack_h2(iv_round(fminf(fv[18], rho)), iv_round(fminf(fv[19], rho)));
         *(uint32_t*)((char*)qs.plane[kLzRho] + o1) = as_u(rho);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -791,13 +822,15 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             *(uint32_t*)((char*)qs.plane[kLzSk + c] + o1) = pack_h2(gSD[c], gS1[c]);
             *(uint32_t*)((char*)qs.plane[kLzDk + c] + o1) = pack_h2(dSD[c], dS1v[c]);
             *(uint32_t*)((char*)qs.plane[kLzEk + c] + o1) = pack_h2(eSD[c], eS1[c]);
+            *(uint32_t*)((char*)qs.plane[kLzD32 + c] + o1) = as_u(dSD[c]);
+            *(uint32_t*)((char*)qs.plane[kLzD32 + 3 + c] + o1) = as_u(dS1v[c]);
             float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
             if (FOLD) {      // the folded planes of lazy_pstep_kernel<kFoldXY> (fold_xy_*: one definition for the fold kernel and this one)
                 FoldXY f;
-                fold_xy(rc[1 + c], Pc[c], vSD[c], vS1[c], dP[c], A2[c], gSD[c], gS1[c], dSD[c], dS1v[c], eSD[c], eS1[c], f);
+                fold_xy(rc[1 + c], Pc[c], vSD[c], vS1[c], dP[c], A2[c], gSD[c], gS1[c], dSD[c], dS1v[c], eSD[c], eS1[c], mref_code(mv), c == 2, f);
                 x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1;
                 *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c] + o1) = as_u(f.X0);
-                *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c + 1] + o1) = as_u(f.Y0);
+                *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c + 1] + o1) = f.Y0w;
                 *(uint32_t*)((char*)qs.fplane[kFxS + c] + o1) = pack_h2(f.X1, f.Y1);
                 *(uint32_t*)((char*)qs.fplane[kFxJ + c] + o1) = pack_h2(f.JX0, f.JY0);
                 rgb = fmaf(mv, f.Y0, f.X0);
@@ -807,10 +840,12 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
         }
         if (FOLD) {
             *(uint32_t*)((char*)qs.fplane[kFxRref] + o1) = as_u(rc_r);
-            *(uint32_t*)((char*)qs.fplane[kFxLoHi] + o1) = pack_h2(0.998f * fminf(fv[18], rho), 0.998f * fminf(fv[19], rho));
-            *(uint32_t*)((char*)qs.fplane[kFxQ] + o1) = pack_h2(x2h[0], x2h[1]);
-            *(uint32_t*)((char*)qs.fplane[kFxQ + 1] + o1) = pack_bf8x2<true>(jx1[0], jy1[0], pack_h2(x2h[2], 0.0f));
-            *(uint32_t*)((char*)qs.fplane[kFxE] + o1) = pack_bf8x2<true>(jx1[2], jy1[2], pack_bf8x2<false>(jx1[1], jy1[1], 0u));
+            // the interval as the generic plane holds it (its half-precision words): both forms list a pixel in the same iteration, up to iv_pack's rounding
+            const uint32_t lh = pack_h2(iv_round(fminf(fv[18], rho)), iv_round(fminf(fv[19], rho)));
+            *(uint32_t*)((char*)qs.fplane[kFxLoHi] + o1) = pack_lohi_x2(h2_lo(lh), h2_hi(lh), x2h[0]);
+            *(uint32_t*)((char*)qs.fplane[kFxQ] + o1) = pack_h2(x2h[1], x2h[2]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *(uint32_t*)((char*)qs.fplane[kFxE + c] + o1) = pack_h2(jx1[c], jy1[c]);
         }
     }
 }
@@ -1018,7 +1053,7 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
             const float rc = px.r.x, mv = px.m.x;
             // what the old model predicts at the new roughness: the parity scale of this refresh, and the measured extrapolation error
             const bool has_old = !q.force;
-            float rho = kLzRhoInit, dr = 0.0f, pSD[3] = {0, 0, 0}, pS1[3] = {0, 0, 0};
+            float rho = kLzRhoInit, dr = 0.0f, pSD[3] = {0, 0, 0}, pS1[3] = {0, 0, 0}, pdSD[3] = {0, 0, 0}, pdS1[3] = {0, 0, 0};
             if (has_old) {
                 dr = rc - as_f(q.state[kLzRref * BP + i]);
                 rho = as_f(q.state[kLzRho * BP + i]);
@@ -1027,6 +1062,9 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     const uint32_t sk = q.state[(kLzSk + c) * BP + i];
                     pSD[c] = fmaf(h2_lo(sk), dr, as_f(q.state[(kLzSD + c) * BP + i]));
                     pS1[c] = fmaf(h2_hi(sk), dr, as_f(q.state[(kLzS1 + c) * BP + i]));
+                    const uint32_t ek = q.state[(kLzEk + c) * BP + i];
+                    pdSD[c] = fmaf(h2_lo(ek), dr, as_f(q.state[(kLzD32 + c) * BP + i]));
+                    pdS1[c] = fmaf(h2_hi(ek), dr, as_f(q.state[(kLzD32 + 3 + c) * BP + i]));
                 }
             }
             float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3];
@@ -1111,12 +1149,15 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                 eS1[c] = (d1y - d1) * ih;
             }
             if (active && sub == 0) {
-                if (has_old && fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error
-                    float e = 0.0f;
+                if (has_old && fabsf(dr) > kLzMoved) {   // step-size control on the measured extrapolation error of the render and of d out / d r
+                    float e = 0.0f, ej = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) e = fmaxf(e, fabsf(fmaf(C0[c], pSD[c] - vSD[c], pS1[c] - vS1[c])) * iscale[c]);
-                    const float want = 0.9f * fabsf(dr) * fsqrt(tol_s / fmaxf(e, 1e-12f));
-                    rho = fminf(fmaxf(want, 0.5f * rho), 2.0f * rho);
+                    for (int c = 0; c < 3; ++c) {
+                        e = fmaxf(e, fabsf(fmaf(C0[c], pSD[c] - vSD[c], pS1[c] - vS1[c])) * iscale[c]);
+                        const float jc = fmaf(kd[c], dP[c], fmaf(C0[c], dSD[c], dS1v[c]));
+                        ej = fmaxf(ej, fabsf(fmaf(C0[c], pdSD[c] - dSD[c], pdS1[c] - dS1v[c])) / fmaxf(fabsf(jc), kLzJFloor * floor_));
+                    }
+                    rho = lazy_rho_next(rho, fabsf(dr), e, ej, tol_s, tol_s * (kLzTolJ / kLzTolS));
                 }
                 rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
 #pragma unroll
@@ -1127,7 +1168,7 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                 }
                 uint32_t* S = q.state;
                 S[kLzRref * BP + i] = as_u(rc);
-                S[kLzLoHi * BP + i] = pack_h2(0.998f * fminf(klo, rho), 0.998f * fminf(khi, rho));   // fp16 rounding must not widen the interval
+                S[kLzLoHi * BP + i] = pack_h2(iv_round(fminf(klo, rho)), iv_round(fminf(khi, rho)));   // rounded DOWN to the 256 lengths of iv_pack (exact in half precision)
                 S[kLzRho * BP + i] = as_u(rho);
                 float jr[3];
 #pragma unroll
@@ -1138,6 +1179,8 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     S[(kLzPk + c) * BP + i] = pack_h2(dP[c], A2[c]);
                     S[(kLzSk + c) * BP + i] = pack_h2(gSD[c], gS1[c]);
                     S[(kLzDk + c) * BP + i] = pack_h2(dSD[c], dS1v[c]);
+                    S[(kLzD32 + c) * BP + i] = as_u(dSD[c]);
+                    S[(kLzD32 + 3 + c) * BP + i] = as_u(dS1v[c]);
                     S[(kLzEk + c) * BP + i] = pack_h2(eSD[c], eS1[c]);
                     const float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
                     q.out[i * 3 + c] = rgb;

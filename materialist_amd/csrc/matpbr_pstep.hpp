@@ -5,7 +5,7 @@
 // Adam moments: 172.6 B/pixel in an 'rm' part against the 108 B/pixel of the canonical forward + backward pair.  Two things are wrong with that:
 //   * bytes: a part moves SOME of the maps (--opt_order 'rm a', :343-357); what it leaves alone is a constant that folds into the model
 //     (kFoldXY: the albedo, 64 B/pixel of model and no albedo read; kFoldGH: roughness and metallic, 24 B/pixel of model and neither map read).
-//     'rm': r 4 + m 4 read, 8 written, model 68 (64 + the slopes of the detached derivatives, round 5), target 12, render 12, anchors 8, Adam moments 32 = 148 B/pixel (was 172);
+//     'rm': r 4 + m 4 read, 8 written, model 72 (64 + the slopes of the detached derivatives: e5m2 in round 5, half precision since round 6), target 12, render 12, anchors 8, Adam moments 32 = 152 B/pixel (was 172);
 //     'a' : a 12 read, 12 written, model 24, target 12, render 12, anchors 12, Adam moments 48 = 132 B/pixel (was 160);
 //   * shape: 4096 workgroups of 512 pixels each fold the iteration's statistics before their first load, and the few pixels that leave their
 //     model's interval are a launch of their own (a 20 us latency chain at 8 x 512^2).  Here a workgroup takes up to four consecutive 512-pixel
@@ -24,7 +24,8 @@ namespace matpbr {
 
 __device__ __forceinline__ void stu(void* base, unsigned off, uint32_t v) { *(uint32_t*)((char*)base + off) = v; }
 
-__device__ __forceinline__ float xy_x2(uint32_t q0, uint32_t q1, int c) { return c == 0 ? h2_lo(q0) : (c == 1 ? h2_hi(q0) : h2_lo(q1)); }
+// X2_c from the words that hold it: `lohi` (kFxLoHi: interval bytes | half X2_0) and `q` (kFxQ: half2 (X2_1, X2_2))
+__device__ __forceinline__ float xy_x2(uint32_t lohi, uint32_t q, int c) { return c == 0 ? h2_hi(lohi) : (c == 1 ? h2_lo(q) : h2_hi(q)); }
 // X_c(dr), Y_c(dr) of a kFoldXY model from its stored words (s = half2 (X1, Y1))
 __device__ __forceinline__ void xy_eval(float X0, float Y0, uint32_t s, float x2, float dr, float& X, float& Y) {
     X = fmaf(fmaf(x2, dr, h2_lo(s)), dr, X0);
@@ -68,11 +69,11 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
             if (MODE == kFoldXY) {
                 FoldXY f;
                 const uint32_t ek = ldu(q.plane[kLzEk + c], o1);
-                fold_xy(a[c], Pv, SDv, S1v, h2_lo(pk), h2_hi(pk), h2_lo(sk), h2_hi(sk), h2_lo(dk), h2_hi(dk), h2_lo(ek), h2_hi(ek), f);
+                fold_xy(a[c], Pv, SDv, S1v, h2_lo(pk), h2_hi(pk), h2_lo(sk), h2_hi(sk), h2_lo(dk), h2_hi(dk), h2_lo(ek), h2_hi(ek), mref_code(m), c == 2, f);
                 const uint32_t s = pack_h2(f.X1, f.Y1);
                 x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1;
                 stu(q.fplane[kFxX0 + 2 * c], o1, as_u(f.X0));
-                stu(q.fplane[kFxX0 + 2 * c + 1], o1, as_u(f.Y0));
+                stu(q.fplane[kFxX0 + 2 * c + 1], o1, f.Y0w);
                 stu(q.fplane[kFxS + c], o1, s);
                 stu(q.fplane[kFxJ + c], o1, pack_h2(f.JX0, f.JY0));
                 float X, Y;
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
         }
         if (MODE == kFoldXY) {
             stu(q.fplane[kFxRref], o1, as_u(rref));
-            stu(q.fplane[kFxLoHi], o1, ldu(q.plane[kLzLoHi], o1));
-            stu(q.fplane[kFxQ], o1, pack_h2(x2h[0], x2h[1]));
-            stu(q.fplane[kFxQ + 1], o1, pack_bf8x2<true>(jx1[0], jy1[0], pack_h2(x2h[2], 0.0f)));
-            stu(q.fplane[kFxE], o1, pack_bf8x2<true>(jx1[2], jy1[2], pack_bf8x2<false>(jx1[1], jy1[1], 0u)));
+            const uint32_t lh = ldu(q.plane[kLzLoHi], o1);
+            stu(q.fplane[kFxLoHi], o1, pack_lohi_x2(h2_lo(lh), h2_hi(lh), x2h[0]));
+            stu(q.fplane[kFxQ], o1, pack_h2(x2h[1], x2h[2]));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) stu(q.fplane[kFxE + c], o1, pack_h2(jx1[c], jy1[c]));
         }
         st3(q.out, o3, rgb[0], rgb[1], rgb[2]);
     }
@@ -111,7 +113,7 @@ struct PxXY {
     float r, m, rref;
     uint32_t lohi;
     float X0[3], Y0[3];
-    uint32_t s[3], j[3], q0, q1, e;
+    uint32_t s[3], j[3], e[3], q;
     F3 gt;
     float r0, m0, mr, vr, mm, vm;
 };
@@ -131,22 +133,20 @@ __device__ __forceinline__ void pstep_load_fixed(PxXY& x, const LazyStepArgs& qs
     x.gt = ld3(q.gt_srgb, o3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { x.X0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c], o1)); x.Y0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c + 1], o1)); }
-    x.rref = 0.0f; x.lohi = 0u; x.q0 = x.q1 = x.e = 0u;
+    x.rref = 0.0f; x.lohi = 0u; x.q = 0u;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) x.s[c] = x.j[c] = 0u;
+    for (int c = 0; c < 3; ++c) x.s[c] = x.j[c] = x.e[c] = 0u;
     if (f.slopes) {           // a part that leaves the roughness alone never moves away from r_ref (uniform branch)
         x.rref = as_f(ldu(qs.fplane[kFxRref], o1)); x.lohi = ldu(qs.fplane[kFxLoHi], o1);
-        x.q0 = ldu(qs.fplane[kFxQ], o1); x.q1 = ldu(qs.fplane[kFxQ + 1], o1);
+        x.q = ldu(qs.fplane[kFxQ], o1);
 #pragma unroll
         for (int c = 0; c < 3; ++c) x.s[c] = ldu(qs.fplane[kFxS + c], o1);
         if (f.att) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x.j[c] = x.s[c];
-            x.q1 &= 0xffffu;                                   // the models' own slopes are the derivative: no first-order correction on top
+            for (int c = 0; c < 3; ++c) x.j[c] = x.s[c];       // the models' own slopes are the derivative: no first-order correction on top (e = 0)
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x.j[c] = ldu(qs.fplane[kFxJ + c], o1);
-            x.e = ldu(qs.fplane[kFxE], o1);
+            for (int c = 0; c < 3; ++c) { x.j[c] = ldu(qs.fplane[kFxJ + c], o1); x.e[c] = ldu(qs.fplane[kFxE + c], o1); }
         }
     }
     x.r0 = x.m0 = x.mr = x.vr = x.mm = x.vm = 0.0f;
@@ -198,20 +198,23 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
     const float r = fminf(fmaxf(x.r, 0.07f), 1.0f), m = fminf(fmaxf(x.m, 0.0f), 1.0f);
     const float dr = r - x.rref;
     const float gt[3] = {x.gt.x, x.gt.y, x.gt.z};
+    // the low byte of the blue channel's Y0 word is m_ref (kFxJ: JA0 = JX0 + m_ref JY0); with the models' own slopes as the derivative there is none
+    const float Y0[3] = {x.Y0[0], x.Y0[1], as_f(as_u(x.Y0[2]) & 0xffffff00u)};
+    const float dmr = m - (f.att ? 0.0f : mref_of(as_u(x.Y0[2])));
     float drr = 0.0f, dm = 0.0f, xs_keep[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         // the render of iteration t is not read back: it IS the model at the current parameters (the expression that wrote pred -- the step
         // before, the walk at dr = 0, or lazy_fold_kernel -- on the same operands: the same bits)
-        const float x2 = xy_x2(x.q0, x.q1, c);
+        const float x2 = xy_x2(x.lohi, x.q, c);
         float X, Y;
-        xy_eval(x.X0[c], x.Y0[c], x.s[c], x2, dr, X, Y);
+        xy_eval(x.X0[c], Y0[c], x.s[c], x2, dr, X, Y);
         const float go = loss_go(fmaf(m, Y, X), gt[c], ratio, sr, q.inv_n3, xs_keep[c]);
         // d out / d r to first order in dr: the curvature of the diffuse lobe (2 X2, exact) and the slopes of the detached specular derivatives
-        const float jx1 = c == 0 ? bf8_at<2>(x.q1) : (c == 1 ? bf8_at<0>(x.e) : bf8_at<2>(x.e));
-        const float jy1 = c == 0 ? bf8_at<3>(x.q1) : (c == 1 ? bf8_at<1>(x.e) : bf8_at<3>(x.e));
-        const float JX = fmaf(fmaf(2.0f, x2, jx1), dr, h2_lo(x.j[c])), JY = fmaf(fmaf(-2.0f, x2, jy1), dr, h2_hi(x.j[c]));
-        drr = fmaf(go, fmaf(m, JY, JX), drr);
+        const float jx1 = h2_lo(x.e[c]), jy1 = h2_hi(x.e[c]);
+        // = JX + m JY with JX = JX0 + (2 X2 + JX1) dr, JY = JY0 + (JY1 - 2 X2) dr, JX0 = JA0 - m_ref JY0
+        const float J0 = fmaf(dmr, h2_hi(x.j[c]), h2_lo(x.j[c])), J1 = fmaf(m, fmaf(-2.0f, x2, jy1), fmaf(2.0f, x2, jx1));
+        drr = fmaf(go, fmaf(J1, dr, J0), drr);
         dm = fmaf(go, Y, dm);
     }
     if (improved && q.best_img) st3(q.best_img, o3, xs_keep[0], xs_keep[1], xs_keep[2]);
@@ -238,13 +241,15 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
     const float r1 = fminf(fmaxf(nr, 0.07f), 1.0f), m1 = fminf(fmaxf(nm, 0.0f), 1.0f), dr1 = r1 - x.rref;
     if (f.part_r) reg[1] += fabsf(r1 - x.r0);
     if (f.part_m) reg[2] += fabsf(m1 - x.m0);
-    const bool need = f.slopes && !(dr1 >= -h2_lo(x.lohi) && dr1 <= h2_hi(x.lohi));
+    // (both codes 255: a constant model -- a pixel without geometry, ops.background_into_lazy_state -- that no roughness leaves; a walked interval is
+    // at most kLzRhoMax, code 254)
+    const bool need = f.slopes && !(dr1 >= -iv_unpack(x.lohi & 0xffu) && dr1 <= iv_unpack((x.lohi >> 8) & 0xffu)) && (x.lohi & 0xffffu) != 0xffffu;
     if (!need) {
         float rgb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float X, Y;
-            xy_eval(x.X0[c], x.Y0[c], x.s[c], xy_x2(x.q0, x.q1, c), dr1, X, Y);
+            xy_eval(x.X0[c], Y0[c], x.s[c], xy_x2(x.lohi, x.q, c), dr1, X, Y);
             rgb[c] = fmaf(m1, Y, X);
             tot += rgb[c];
         }

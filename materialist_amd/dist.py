@@ -84,20 +84,40 @@ def broadcast_state_dict(state_dict, device, src: int = 0):
     return {k: out[k] for k, _, _ in layout}
 
 
+_PINNED: Optional[dict] = None          # what pin_rank_cores did in this process (it acts once)
+
+
 def pin_rank_cores() -> Optional[dict]:
     """One process per GPU: the ranks of a node take DISJOINT sets of host cores (LOCAL_RANK-th slice of the cores this process may
     run on).  A rank's iterations are enqueued by one Python thread -- ~30 launches (pos_mlp) or 6 (none mode) per iteration -- and where that
     takes about as long as the GPU needs for them (bench.py `host_enqueue`: the 8-image none-mode shard), two ranks sharing a core is what an
-    8-GPU run loses on, not the fabric.  Returns what was done (None: a single local rank, or no affinity API)."""
+    8-GPU run loses on, not the fabric.  Returns what was done (None: nothing -- a single local rank, no affinity API, MATPBR_NO_PIN set,
+    LOCAL_WORLD_SIZE unknown, or a launcher that has bound this rank already).
+
+    Acts ONCE per process (a second call returns the first call's record: slicing the slice again would leave a rank on 1 / local_world of
+    its cores).  A process whose mask is already a strict subset of the node's cores was bound by its launcher (slurm --cpu-bind, numactl per
+    rank): its mask is left alone.  torch's intra-op pool is sized to the slice (`torch.set_num_threads`: OMP_NUM_THREADS set here would come
+    after torch and OpenMP were loaded)."""
     import os
 
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+    global _PINNED
+    if _PINNED is not None:
+        return _PINNED
+    if os.environ.get("MATPBR_NO_PIN") or not hasattr(os, "sched_setaffinity") or "LOCAL_WORLD_SIZE" not in os.environ:
+        return None          # LOCAL_WORLD_SIZE is required (torch.distributed.run sets it): WORLD_SIZE over-counts the ranks of a node on multi-node jobs
+    local_world, local_rank = int(os.environ["LOCAL_WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world <= 1:
         return None
     cores = sorted(os.sched_getaffinity(0))
+    node = os.cpu_count() or len(cores)
+    if len(cores) < node and len(cores) * local_world <= node:
+        # the launcher has given this rank a share of the node already: leave it (and size the thread pool to it)
+        torch.set_num_threads(max(1, min(len(cores), torch.get_num_threads())))
+        _PINNED = {"cores_of_this_rank": len(cores), "first": cores[0], "last": cores[-1], "local_world_size": local_world, "bound_by": "launcher"}
+        return _PINNED
     per = max(1, len(cores) // local_world)
     mine = cores[local_rank * per:(local_rank + 1) * per] or cores
     os.sched_setaffinity(0, mine)
-    os.environ["OMP_NUM_THREADS"] = str(min(len(mine), int(os.environ.get("OMP_NUM_THREADS", "4"))))
-    return {"cores_of_this_rank": len(mine), "first": mine[0], "last": mine[-1], "local_world_size": local_world}
+    torch.set_num_threads(max(1, min(len(mine), int(os.environ.get("OMP_NUM_THREADS", "4")))))
+    _PINNED = {"cores_of_this_rank": len(mine), "first": mine[0], "last": mine[-1], "local_world_size": local_world, "bound_by": "pin_rank_cores"}
+    return _PINNED

@@ -10,6 +10,7 @@ round trip is needed per iteration (the reference syncs three times per epoch, :
 """
 from __future__ import annotations
 
+import os
 import copy
 from typing import Dict, Optional
 
@@ -368,6 +369,10 @@ class FusedBrdfPhase:
         if self.rotate:
             ph.flags |= ops.FLAG_ROTATE_BEST
         self._ph, self._lib = ph, lib
+        if os.environ.get("MATPBR_POISON"):      # debugging aid: every buffer the kernels are expected to WRITE before they read it starts as garbage
+            for buf in (self.ws, self.jac, self._pred, self._pred_bufs[1] if self.lazy else None):
+                if buf is not None:
+                    buf.fill_(float(os.environ["MATPBR_POISON"]))
 
     def lr_at(self, t0: int) -> float:
         """Learning rate of the iteration with 0-based index t0: StepLR(100, 0.8) stepped only while lr > 1.5e-4 (:363-365,431-432)."""
@@ -558,6 +563,8 @@ class PipelinedBrdfPhase:
         self.streams = [torch.cuda.Stream(dev) for _ in range(groups)]
         self.phases = []
         here = torch.cuda.current_stream(dev)
+        if make_phase is None:
+            scene.shading_normal()                                   # computed (and cached) on the CALLER's stream: every group's stream waits for it below
         for gi, st in enumerate(self.streams):
             sl = slice(gi * per, (gi + 1) * per)
             st.wait_stream(here)                                     # the caller's tensors are ready on the caller's stream

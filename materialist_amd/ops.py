@@ -23,7 +23,7 @@ FLAG_GENERIC_STEP = 256
 FLAG_JAC32 = 512
 FLAG_SHARE_GPU = 2048
 LAZY_NSTATE = 28
-LAZY_PLANES = 24          # 32-bit planes of a lazy model (csrc/matpbr_lazy.hpp kLzPlanes)
+LAZY_PLANES = 30          # 32-bit planes of a lazy model (csrc/matpbr_lazy.hpp kLzPlanes)
 STATS_STRIDE = 16
 (STAT_RATIO, STAT_MSE, STAT_L1, STAT_SR, STAT_LA, STAT_LR, STAT_LM, STAT_LOSS, STAT_IMPROVED, STAT_BEST, STAT_ES_COUNTER, STAT_ES_BEST,
  STAT_ES_HAS, STAT_STOPPED, STAT_ITERS, STAT_GT_SUM) = range(16)

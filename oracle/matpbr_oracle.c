@@ -884,6 +884,10 @@ enum { LZ_RREF = 0, LZ_LO, LZ_HI, LZ_RHO, LZ_SD = 4, LZ_S1 = 7, LZ_GSD = 10, LZ_
 #define LAZY_TOL_K R(1.5e-4)
 #define LAZY_KINK_SAFETY R(0.8)
 #define LAZY_MOVED R(1e-4)
+/* round 6: the radius also answers to the derivative handed to the backward pass: the old state's prediction of d out_c / d r at the new roughness
+ * (dSD + eSD dr, dS1 + eS1 dr) against the walked one, relative to max(|d out_c / d r|, LAZY_JFLOOR x the parity floor), tolerance LAZY_TOL_J */
+#define LAZY_TOL_J R(2.5e-4)
+#define LAZY_JFLOOR R(0.25)
 int oracle_lazy_nstate(void) { return LAZY_NSTATE; }
 
 typedef struct LazySums { real S0[3], S1[3], dS0[3], dS1[3]; } LazySums;
@@ -949,6 +953,19 @@ static void lazy_sums(const real wo[3], const real n[3], real r, const real* coe
     }
 }
 static real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* round 6: an interval's two lengths are carried in eight bits each (four exponent, four mantissa bits: (16 + m) 2^(e - 25), 4.8e-7 .. 3.03e-2),
+ * rounded DOWN -- an interval never widens (csrc/matpbr_lazy.hpp iv_pack / iv_unpack; lengths below 2^-21 are carried as 2^-21) */
+static real iv_round_down(real x) {
+    float f = (float)x;
+    uint32_t u;
+    if ((real)f > x) f = nextafterf(f, 0.0f);
+    memcpy(&u, &f, 4);
+    int q = (int)(u >> 19) - ((127 - 21) << 4);
+    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+    u = (uint32_t)(q + ((127 - 21) << 4)) << 19;
+    memcpy(&f, &u, 4);
+    return (real)f;
+}
 /* refresh of one pixel at (clamped) roughness r: new state `st`, the exact render `out`.  The parity scale that weighs kinks and
  * the measured extrapolation error is taken from what is known BEFORE the samples are walked (so that one walk suffices): the old
  * state's prediction of the render at r, or the floor alone on a forced (first) refresh, whose intervals are <= rho_init anyway. */
@@ -987,19 +1004,27 @@ static void lazy_refresh_pixel(const real wo[3], const real n[3], const real a[3
     if (old) {
         rho = old[LZ_RHO];
         if (fabs(dr) > LAZY_MOVED) {
-            real e = R(0);
-            for (int c = 0; c < 3; ++c)
+            real e = R(0), ej = R(0);
+            for (int c = 0; c < 3; ++c) {
                 e = rmax(e, fabs(C0[c] * (pSD[c] - st[LZ_SD + c]) + (pS1[c] - st[LZ_S1 + c])) / scale[c]);
-            const real want = R(0.9) * fabs(dr) * sqrt(tol * LAZY_TOL_S / rmax(e, R(1e-12)));
+                const real pdSD = old[LZ_DSD + c] + old[LZ_ESD + c] * dr, pdS1 = old[LZ_DS1 + c] + old[LZ_ES1 + c] * dr;
+                const real dP = A[3 + c] + R(2) * r * A[6 + c];
+                const real jc = a[c] * (R(1) - m) * dP + C0[c] * st[LZ_DSD + c] + st[LZ_DS1 + c];
+                ej = rmax(ej, fabs(C0[c] * (pdSD - st[LZ_DSD + c]) + (pdS1 - st[LZ_DS1 + c])) / rmax(fabs(jc), LAZY_JFLOOR * floor_));
+            }
+            const real ec = rmax(e / (tol * LAZY_TOL_S), ej / (tol * LAZY_TOL_J));
+            const real want = R(0.9) * fabs(dr) / sqrt(rmax(ec, R(1e-9)));
             rho = clampr(want, R(0.5) * rho, R(2) * rho);
         }
     }
     rho = clampr(rho, LAZY_RHO_MIN, LAZY_RHO_MAX);
     st[LZ_RREF] = r; st[LZ_LO] = k.lo < rho ? k.lo : rho; st[LZ_HI] = k.hi < rho ? k.hi : rho; st[LZ_RHO] = rho;
+    const real lo_cap = st[LZ_LO], hi_cap = st[LZ_HI];      /* LAZY_E_CAP below is stated on the lengths before rounding */
+    st[LZ_LO] = iv_round_down(st[LZ_LO]); st[LZ_HI] = iv_round_down(st[LZ_HI]);
     /* LAZY_E_CAP: a sample that crosses the horizon inside the stencil makes the one-sided difference of a detached derivative a jump / h, not
      * a slope; whatever eSD, eS1 are, they correct the derivative by at most half its size at the far end of the interval */
     for (int c = 0; c < 3; ++c) {
-        const real lim = R(0.5) * (fabs(st[LZ_DSD + c]) + fabs(st[LZ_DS1 + c])) / rmax(rmax(st[LZ_LO], st[LZ_HI]), R(1e-4));
+        const real lim = R(0.5) * (fabs(st[LZ_DSD + c]) + fabs(st[LZ_DS1 + c])) / rmax(rmax(lo_cap, hi_cap), R(1e-4));
         st[LZ_ESD + c] = clampr(st[LZ_ESD + c], -lim, lim);
         st[LZ_ES1 + c] = clampr(st[LZ_ES1 + c], -lim, lim);
     }

@@ -371,7 +371,7 @@ def test_folded_persistent_step_is_the_generic_step(part):
         if it in (0, 1, 10, iters - 1):      # the render of the current parameters (what the next iteration judges); Adam normalises the
             # gradient, so where it is nearly zero rounding decides a step's sign and single pixels part ways over 150 steps
             worst = (fo.pred - ge.pred).abs() / ge.pred.abs().mean()
-            assert float(worst.max()) < {0: 2e-6, 1: 2e-4, 10: 1e-3}.get(it, 3e-2) and float(worst.mean()) < 2e-4, (it, float(worst.max()), float(worst.mean()))
+            assert float(worst.max()) < {0: 6e-6, 1: 2e-4, 10: 1e-3}.get(it, 3e-2) and float(worst.mean()) < 2e-4, (it, float(worst.max()), float(worst.mean()))      # (it 0: 2.7e-6 -- the blue channel's Y0 keeps 15 mantissa bits: its low byte is m_ref)
     h_f, h_g = fo.history()[:, 0].cpu().numpy(), ge.history()[:, 0].cpu().numpy()
     assert np.abs(h_f - h_g).max() <= 5e-4 * h_g.max()
     assert abs(n_f - n_g) <= 0.01 * n_g + 2 and (n_g > 0) == ("r" in part)
