@@ -24,6 +24,10 @@ constexpr float kLzKinkSafety = 0.8f, kLzMoved = 1e-4f;
 // derivative d out_c / d r at the new roughness (dSD + eSD dr, dS1 + eS1 dr) is compared with the walked one, relative to
 // max(|d out_c / d r|, kLzJFloor x the parity floor), tolerance kLzTolJ -- the same controller, on the larger of the two normalised errors
 constexpr float kLzTolJ = 2.5e-4f, kLzJFloor = 0.25f;
+// ... and so do the kinks: beyond a crossing the model keeps extrapolating the crossing sample's share of the DERIVATIVE too -- its share of the sums
+// times lam = d ln(weight)/dr -- which, relative to d out / d r, weighs ~50 times what its share of the value weighs relative to the render.  An
+// interval ends where either costs its tolerance (kLzTolKJ of max(|d out_c / d r|, kLzJFloor x the parity floor) for the derivative).
+constexpr float kLzTolKJ = 5e-4f;
 __device__ __forceinline__ float lazy_rho_next(float rho, float adr, float e_s, float e_j, float tol_s, float tol_j) {
     const float ec = fmaxf(e_s * (1.0f / tol_s), e_j * (1.0f / tol_j));
     const float want = 0.9f * adr * rsq(fmaxf(ec, 1e-9f));
@@ -686,7 +690,7 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
     }
     float dir = dr < 0.0f ? -1.0f : 1.0f;
     if (rc_r + dir * kLzH > 1.0f || rc_r + dir * kLzH < 0.07f) dir = -dir;
-    float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3], pSD[3], pS1[3], pdSD[3], pdS1[3];
+    float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3], ijscale[3], pSD[3], pS1[3], pdSD[3], pdS1[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float A0 = ldf(qs.dcache + c * BPl, o1), A1 = ldf(qs.dcache + (3 + c) * BPl, o1);
@@ -702,6 +706,8 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
         kd[c] = rc[1 + c] * (1.0f - mv);
         C0[c] = fmaf(mv, rc[1 + c], (1.0f - mv) * 0.04f);
         iscale[c] = 1.0f / fmaxf(fabsf(fmaf(kd[c], Pc[c], fmaf(C0[c], pSD[c], pS1[c]))), floor_);
+        // the derivative's scale, from the old model's prediction like the render's; premultiplied by tol_k / tol_kj: one lazy_kink call serves both
+        ijscale[c] = (kLzTolK / kLzTolKJ) / fmaxf(fabsf(fmaf(kd[c], dP[c], fmaf(C0[c], pdSD[c], pdS1[c]))), kLzJFloor * floor_);
     }
     RS_STAMP(3);
     // ---- this lane's samples: one azimuth of every ring, at r (sub 0-3) or at r + dir h (sub 4-7)  (spec_ring / spec_sample /
@@ -743,15 +749,17 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
 #pragma unroll
                     for (int c = 0; c < 3; ++c) L[c] = fmaf(B[k], lp[3 * k + c], L[c]);
                 }
-                const float wx = wgt * x5, wl = wgt * fmaf(dk_dr * g1l, NoL - 1.0f, lam0), wlx5 = wl * x5;
+                const float lam = fmaf(dk_dr * g1l, NoL - 1.0f, lam0);
+                const float wx = wgt * x5, wl = wgt * lam, wlx5 = wl * x5;
+                const float lamk1 = fabsf(lam0 - dk_dr * g1l0), lamk2 = fabsf(lam);      // |d ln(weight)/dr| at n.wi = 0 / at this sample
                 float m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     S0[c] = fmaf(wgt, L[c], S0[c]); S1[c] = fmaf(wx, L[c], S1[c]);
                     dS0[c] = fmaf(wl, L[c], dS0[c]); dS1[c] = fmaf(wlx5, L[c], dS1[c]);
-                    const float aL = fabsf(L[c]) * iscale[c];
-                    m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL);
-                    m2 = fmaxf(m2, aL);
+                    const float aL = fabsf(L[c]), sc1 = fmaxf(iscale[c], lamk1 * ijscale[c]), sc2 = fmaxf(iscale[c], lamk2 * ijscale[c]);
+                    m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL * sc1);
+                    m2 = fmaxf(m2, aL * sc2);
                 }
                 // where this sample's clamped variables n.wi and wo.h cross zero, to first order in r
                 const float dp = fmaf(stp, fmaf(az.x, vx, az.y * vy), ctp * vz);
@@ -1067,7 +1075,7 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     pdS1[c] = fmaf(h2_hi(ek), dr, as_f(q.state[(kLzD32 + 3 + c) * BP + i]));
                 }
             }
-            float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3];
+            float C0[3], kd[3], Pc[3], dP[3], A2[3], iscale[3], ijscale[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float A0 = q.dcache[c * BP + i], A1 = q.dcache[(3 + c) * BP + i];
@@ -1078,6 +1086,8 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                 C0[c] = fmaf(mv, px.a[c].x, (1.0f - mv) * 0.04f);
                 const float pred = has_old ? fabsf(fmaf(kd[c], Pc[c], fmaf(C0[c], pSD[c], pS1[c]))) : 0.0f;
                 iscale[c] = 1.0f / fmaxf(pred, floor_);
+                const float jpred = has_old ? fabsf(fmaf(kd[c], dP[c], fmaf(C0[c], pdSD[c], pdS1[c]))) : 0.0f;
+                ijscale[c] = (kLzTolK / kLzTolKJ) / fmaxf(jpred, kLzJFloor * floor_);
             }
             float dir = (has_old && dr < 0.0f) ? -1.0f : 1.0f;
             if (rc + dir * kLzH > 1.0f || rc + dir * kLzH < 0.07f) dir = -dir;
@@ -1118,12 +1128,13 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     // where this sample's clamped variables n.wi and wo.h cross zero, to first order in r
                     const float dp = fmaf(stp, fmaf(az.x, px.vx.x, az.y * px.vy.x), ctp * px.vz.x);
                     const float wlzp = 2.0f * fmaf(dp, R.ct.x, sm.d.x * ctp);
+                    const float lamk1 = fabsf(lam0.x - px.dk_dr.x * g1l0), lamk2 = fabsf(lam.x);
                     float m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const float aL = fabsf(L[c].x) * iscale[c];
-                        m1 = fmaxf(m1, fmaf(1.0f - C0[c], sm.x5.x, C0[c]) * aL);
-                        m2 = fmaxf(m2, aL);
+                        const float aL = fabsf(L[c].x), sc1 = fmaxf(iscale[c], lamk1 * ijscale[c]), sc2 = fmaxf(iscale[c], lamk2 * ijscale[c]);
+                        m1 = fmaxf(m1, fmaf(1.0f - C0[c], sm.x5.x, C0[c]) * aL * sc1);
+                        m2 = fmaxf(m2, aL * sc2);
                     }
                     lazy_kink(sm.wlz.x, wlzp, R.ringw.x * g1l0 * sm.dpos.x * m1 * fabsf(wlzp), tol_k, klo, khi);
                     lazy_kink(sm.d.x, dp, R.ringw.x * sm.g1l.x * sm.NoL.x * m2 * fabsf(dp), tol_k, klo, khi);

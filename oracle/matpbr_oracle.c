@@ -888,6 +888,9 @@ enum { LZ_RREF = 0, LZ_LO, LZ_HI, LZ_RHO, LZ_SD = 4, LZ_S1 = 7, LZ_GSD = 10, LZ_
  * (dSD + eSD dr, dS1 + eS1 dr) against the walked one, relative to max(|d out_c / d r|, LAZY_JFLOOR x the parity floor), tolerance LAZY_TOL_J */
 #define LAZY_TOL_J R(2.5e-4)
 #define LAZY_JFLOOR R(0.25)
+/* ... and the kinks: beyond a crossing the model keeps extrapolating the crossing sample's share of the derivative too (its share of the sums times
+ * lam = d ln(weight)/dr); an interval ends where either costs its tolerance (LAZY_TOL_KJ of max(|d out_c / d r|, LAZY_JFLOOR x the parity floor)) */
+#define LAZY_TOL_KJ R(5e-4)
 int oracle_lazy_nstate(void) { return LAZY_NSTATE; }
 
 typedef struct LazySums { real S0[3], S1[3], dS0[3], dS1[3]; } LazySums;
@@ -905,7 +908,7 @@ static void lazy_kink(real x, real xp, real J, real tol_k, LazyKinks* k) {
 /* the specular sums at roughness r (all 20 samples); with `kinks` also the crossing scan, for which C0 / scale (per channel)
  * weigh a sample's contribution to the rendered value relative to the parity scale */
 static void lazy_sums(const real wo[3], const real n[3], real r, const real* coef, const Rules* q, LazySums* S, LazyKinks* kinks,
-                      const real C0[3], const real scale[3], real tol_k) {
+                      const real C0[3], const real scale[3], const real jscale[3], real tol_k) {
     const real *u0 = q->su0, *u1 = q->su1, *w = q->sw;
     real s[3], t[3];
     oracle_frame(n, s, t);
@@ -941,12 +944,16 @@ static void lazy_sums(const real wo[3], const real n[3], real r, const real* coe
         const real dpos = rmax(d, R(0)), nlpos = rmax(wlz, R(0));
         const real g1l0 = R(1) / (kk + R(1e-6)), g1l = R(1) / (nlpos * (R(1) - kk) + kk + R(1e-6));
         const real x5 = pow5(R(1) - dpos);
+        /* |d ln(weight)/dr| (spec_sample's lam) at n.wi = 0 and at this sample */
+        const real lam_ring = R(4) / r - R(8) * r * r * r * c2 / (c2 * (alpha2 - R(1)) + R(1) + R(1e-6)) - (r + R(1)) / R(4) * g1v * (R(1) - NoV);
+        const real lamk1 = fabs(lam_ring - (r + R(1)) / R(4) * g1l0), lamk2 = fabs(lam_ring - (r + R(1)) / R(4) * g1l * (R(1) - nlpos));
+        const real rk = LAZY_TOL_K / LAZY_TOL_KJ;
         real J1 = R(0), J2 = R(0);
         for (int c = 0; c < 3; ++c) {
             const real F = C0[c] + (R(1) - C0[c]) * x5, aL = fabs(L[c]);
             const real K1 = w[j] * g1v * g1l0 * dpos / ct * F * aL, K2 = w[j] * g1v * g1l * nlpos / ct * aL;
-            J1 = rmax(J1, K1 / scale[c]);
-            J2 = rmax(J2, K2 / scale[c]);
+            J1 = rmax(J1, K1 * rmax(R(1) / scale[c], lamk1 * rk / jscale[c]));
+            J2 = rmax(J2, K2 * rmax(R(1) / scale[c], lamk2 * rk / jscale[c]));
         }
         lazy_kink(wlz, wlzp, J1 * fabs(wlzp), tol_k, kinks);
         lazy_kink(d, dp, J2 * fabs(dp), tol_k, kinks);
@@ -971,24 +978,27 @@ static real iv_round_down(real x) {
  * state's prediction of the render at r, or the floor alone on a forced (first) refresh, whose intervals are <= rho_init anyway. */
 static void lazy_refresh_pixel(const real wo[3], const real n[3], const real a[3], real r, real m, const real* coef, const Rules* q,
                                const real A[9], real floor_, real tol, const real* old, real* st, real out[3]) {
-    real C0[3], P[3], scale[3], pSD[3], pS1[3];
+    real C0[3], P[3], scale[3], jscale[3], pSD[3], pS1[3];
     LazySums S, Sh;
     const real dr = old ? r - old[LZ_RREF] : R(0);
     for (int c = 0; c < 3; ++c) {
         C0[c] = (R(1) - m) * R(0.04) + m * a[c];
         P[c] = A[c] + r * A[3 + c] + r * r * A[6 + c];
         scale[c] = floor_;
+        jscale[c] = LAZY_JFLOOR * floor_;
         if (old) {
             pSD[c] = old[LZ_SD + c] + old[LZ_GSD + c] * dr;
             pS1[c] = old[LZ_S1 + c] + old[LZ_GS1 + c] * dr;
             scale[c] = rmax(fabs(a[c] * (R(1) - m) * P[c] + C0[c] * pSD[c] + pS1[c]), floor_);
+            const real pdSD = old[LZ_DSD + c] + old[LZ_ESD + c] * dr, pdS1 = old[LZ_DS1 + c] + old[LZ_ES1 + c] * dr;
+            jscale[c] = rmax(fabs(a[c] * (R(1) - m) * (A[3 + c] + R(2) * r * A[6 + c]) + C0[c] * pdSD + pdS1), LAZY_JFLOOR * floor_);
         }
     }
     real dir = (old && dr < R(0)) ? R(-1) : R(1);
     if (r + dir * LAZY_H > R(1) || r + dir * LAZY_H < R(0.07)) dir = -dir;
     LazyKinks k = {R(1e30), R(1e30)};
-    lazy_sums(wo, n, r, coef, q, &S, &k, C0, scale, tol * LAZY_TOL_K);
-    lazy_sums(wo, n, r + dir * LAZY_H, coef, q, &Sh, NULL, NULL, NULL, R(0));
+    lazy_sums(wo, n, r, coef, q, &S, &k, C0, scale, jscale, tol * LAZY_TOL_K);
+    lazy_sums(wo, n, r + dir * LAZY_H, coef, q, &Sh, NULL, NULL, NULL, NULL, R(0));
     for (int c = 0; c < 3; ++c) {
         st[LZ_SD + c] = S.S0[c] - S.S1[c];
         st[LZ_S1 + c] = S.S1[c];

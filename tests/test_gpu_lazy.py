@@ -239,14 +239,18 @@ def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_
     print("lazy gate: per check d_r JACOBIAN ONLY 99.9th-percentile pixel: " + " ".join(f"{v:.4f}" for v in per_check["roughness"]["jp999"]))
     print("lazy gate: per check d_r JACOBIAN ONLY worst pixel: " + " ".join(f"{v:.3f}" for v in per_check["roughness"]["jmax"]))
     print("lazy gate: per check d_m JACOBIAN ONLY rel. L2: " + " ".join(f"{v:.5f}" for v in per_check["metallic"]["jl2"]))
-    assert float(worst) <= 1e-3
+    assert float(worst) <= 1e-3                    # (measured 5.9e-4; round 5: 8.1e-4)
     assert float(worst_dr) <= 2e-3
-    # VERDICT r4 item 4 (d_r relative L2 <= 1 %, 99.9th-percentile pixel <= 2e-2): met by the DERIVATIVES of the models on every check since
-    # d out / d r is first order in r - r_ref (round 5: the slopes eSD, eS1 of the detached derivatives; measured L2 <= 7e-4, p999 <= 7.8e-3,
-    # worst pixel 3.1e-2; round 4, zeroth order: 2.2e-2, 0.10, 0.24)
+    # The DERIVATIVES of the models (d loss / d pred formed on the lazy loop's own render for both sides), every pixel, 39 checks.  Round 5: L2 7e-4,
+    # 99.9th-percentile pixel 7.8e-3, worst pixel 3.1e-2 -- the tail was pixels just beyond a sample's horizon crossing (the interval's kink
+    # allowance was stated on the VALUE; the crossing sample's share of the derivative weighs ~50 x more relative to d out / d r) and pixels at the
+    # far end of intervals whose radius answered to the value's extrapolation error only; the folded slopes travelled in e5m2.  Round 6 (radius and
+    # kink allowance also on the derivative, half-precision slopes, JA0 = JX0 + m_ref JY0): L2 <= 3e-4, 99.9th percentile <= 1.7e-3, worst pixel
+    # <= 4e-3.  What is left is the half-precision storage of the derivative words (2^-11 each, several per pixel) where the channels' terms of
+    # d loss / d r cancel: tighter tolerances (1.5e-4 / 3e-4: 27 % more pixels walked) leave the same tail (tools/lazy_grad_diag.py).
     jr, jm = per_check["roughness"], per_check["metallic"]
-    assert max(jr["jl2"]) <= 2e-3 and max(jr["jp999"]) <= 2e-2 and max(jr["jmax"]) <= 6e-2, (max(jr["jl2"]), max(jr["jp999"]), max(jr["jmax"]))
-    assert max(jm["jl2"]) <= 2e-3 and max(jm["jp999"]) <= 6e-3, (max(jm["jl2"]), max(jm["jp999"]))      # (measured 6.8e-4, 2.8e-3)
+    assert max(jr["jl2"]) <= 6e-4 and max(jr["jp999"]) <= 2.5e-3 and max(jr["jmax"]) <= 6e-3, (max(jr["jl2"]), max(jr["jp999"]), max(jr["jmax"]))
+    assert max(jm["jl2"]) <= 5e-4 and max(jm["jp999"]) <= 2e-3, (max(jm["jl2"]), max(jm["jp999"]))      # (measured 2.2e-4)
     # The LOSS gradient of the lazy loop against the loss gradient on the exact render (below) differs by more, and by more the further the
     # part has converged (rel. L2 2e-4 at the first check, 4 % at iteration 1950): d loss / d pred carries sign(pred - gt) from the L1 term, and
     # where a pixel has converged the two renders (within 1e-3 of each other by the gate above) disagree on that sign -- the pixel's whole

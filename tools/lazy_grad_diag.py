@@ -42,12 +42,21 @@ for fold in (True, False):
             first = (eS.abs() * dr.abs()[:, None]).amax(1) / dS.abs().amax(1).clamp_min(1e-9)       # size of the first-order term relative to the derivative
             print(f"fold={fold} it={it}: L2 {float((g-gr).norm()/gr.norm()):.2e}  p99.9 {float(torch.quantile(e[::2].float(), 0.999)):.2e}  max {float(e.max()):.2e}  "
                   f"n(e>1e-3) {int((e > 1e-3).sum())}  n(e>5e-3) {int((e > 5e-3).sum())}  mean |dr| {float(dr.abs().mean()):.2e}  mean first-order/deriv {float(first.mean()):.3f}")
+            # the models' own d out_c / d r (generic planes as they stand, half-precision words widened) against the exact one, per channel
+            a_, m_ = p_at[0].reshape(-1, 3).clamp(0, 1), p_at[2].reshape(-1).clamp(0, 1)
+            rr = p_at[1].reshape(-1).clamp(0.07, 1)
+            dc = ph.dcache.reshape(9, -1)
+            Jm = torch.stack([a_[:, c] * (1 - m_) * (dc[3 + c] + 2 * rr * dc[6 + c]) + (0.04 * (1 - m_) + m_ * a_[:, c]) * (s[:, 16 + c] + s[:, 22 + c] * dr) + (s[:, 19 + c] + s[:, 25 + c] * dr) for c in range(3)])
+            Je = jac[6:9].reshape(3, -1)
+            eJ = ((Jm - Je).abs() / torch.maximum(Je.abs(), Je.abs().mean())).amax(0)
+            print(f"   models' own d out/d r per channel vs exact: p99.9 {float(torch.quantile(eJ[::2].float(), 0.999)):.2e} max {float(eJ.max()):.2e} n(>1e-3) {int((eJ > 1e-3).sum())};  "
+                  f"of the {int((e > 2e-3).sum())} pixels with gradient error > 2e-3: {int(((e > 2e-3) & (eJ > 1e-3)).sum())} have a model error > 1e-3 (the others: cancellation between channels / terms)")
             J = jac[6:9].reshape(3, -1).abs()
             _, refd = ops.lazy_state_unpack(ph.lazy_state, ph.p["albedo"])
             print(f"   mean |d out/d r| {float(J.mean()):.3e}  median {float(J.median()):.3e}  parity floor 0.5 mean(gt) {0.5 * float(gt.mean()):.3e}  re-sampled this iteration {float(refd.float().mean()):.5f}")
             idx = torch.argsort(e, descending=True)[:4]
             for i in idx.tolist():
-                print(f"   px {i}: e {float(e[i]):.2e} r {float(p_at[1].reshape(-1)[i]):.4f} dr {float(dr[i]):+.2e} lo {float(lo[i]):.2e} hi {float(hi[i]):.2e} rho {float(s[i,3]):.2e} "
+                print(f"   px {i}: eJ {float(eJ[i]):.2e} J exact {Je[:, i].tolist()} model {Jm[:, i].tolist()} e {float(e[i]):.2e} r {float(p_at[1].reshape(-1)[i]):.4f} dr {float(dr[i]):+.2e} lo {float(lo[i]):.2e} hi {float(hi[i]):.2e} rho {float(s[i,3]):.2e} "
                       f"frac {float(frac_int[i]):.2f} first/deriv {float(first[i]):.3f} g {float(g[i]):+.3e} gref {float(gr[i]):+.3e} gmean {float(gr.abs().mean()):.3e}")
             # error against position in the interval and against the size of the first-order term
             for lo_f, hi_f in ((0, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.01)):
