@@ -23,11 +23,11 @@ constexpr float kLzKinkSafety = 0.8f, kLzMoved = 1e-4f;
 // round 6: the radius also answers to the DERIVATIVE the model hands the backward pass.  At a refresh the old model's prediction of the detached
 // derivative d out_c / d r at the new roughness (dSD + eSD dr, dS1 + eS1 dr) is compared with the walked one, relative to
 // max(|d out_c / d r|, kLzJFloor x the parity floor), tolerance kLzTolJ -- the same controller, on the larger of the two normalised errors
-constexpr float kLzTolJ = 2.5e-4f, kLzJFloor = 0.25f;
+constexpr float kLzTolJ = 5e-4f, kLzJFloor = 0.25f;
 // ... and so do the kinks: beyond a crossing the model keeps extrapolating the crossing sample's share of the DERIVATIVE too -- its share of the sums
 // times lam = d ln(weight)/dr -- which, relative to d out / d r, weighs ~50 times what its share of the value weighs relative to the render.  An
 // interval ends where either costs its tolerance (kLzTolKJ of max(|d out_c / d r|, kLzJFloor x the parity floor) for the derivative).
-constexpr float kLzTolKJ = 5e-4f;
+constexpr float kLzTolKJ = 1e-3f;
 __device__ __forceinline__ float lazy_rho_next(float rho, float adr, float e_s, float e_j, float tol_s, float tol_j) {
     const float ec = fmaxf(e_s * (1.0f / tol_s), e_j * (1.0f / tol_j));
     const float want = 0.9f * adr * rsq(fmaxf(ec, 1e-9f));
@@ -698,9 +698,13 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
         const uint32_t sk = ldu(qs.plane[kLzSk + c], o1);      // what the old model predicts at the new roughness
         pSD[c] = fmaf(h2_lo(sk), dr, as_f(ldu(qs.plane[kLzSD + c], o1)));
         pS1[c] = fmaf(h2_hi(sk), dr, as_f(ldu(qs.plane[kLzS1 + c], o1)));
+#ifdef MATPBR_AB_NOD32
+        pdSD[c] = pdS1[c] = 0.0f;
+#else
         const uint32_t ek = ldu(qs.plane[kLzEk + c], o1);      // ... and of the detached derivatives
         pdSD[c] = fmaf(h2_lo(ek), dr, as_f(ldu(qs.plane[kLzD32 + c], o1)));
         pdS1[c] = fmaf(h2_hi(ek), dr, as_f(ldu(qs.plane[kLzD32 + 3 + c], o1)));
+#endif
         Pc[c] = fmaf(fmaf(A2[c], rc_r, A1), rc_r, A0);
         dP[c] = fmaf(2.0f * rc_r, A2[c], A1);
         kd[c] = rc[1 + c] * (1.0f - mv);
@@ -757,9 +761,15 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
                 for (int c = 0; c < 3; ++c) {
                     S0[c] = fmaf(wgt, L[c], S0[c]); S1[c] = fmaf(wx, L[c], S1[c]);
                     dS0[c] = fmaf(wl, L[c], dS0[c]); dS1[c] = fmaf(wlx5, L[c], dS1[c]);
+#ifdef MATPBR_AB_NOKJ
+                    const float aL = fabsf(L[c]) * iscale[c];
+                    m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL);
+                    m2 = fmaxf(m2, aL);
+#else
                     const float aL = fabsf(L[c]), sc1 = fmaxf(iscale[c], lamk1 * ijscale[c]), sc2 = fmaxf(iscale[c], lamk2 * ijscale[c]);
                     m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL * sc1);
                     m2 = fmaxf(m2, aL * sc2);
+#endif
                 }
                 // where this sample's clamped variables n.wi and wo.h cross zero, to first order in r
                 const float dp = fmaf(stp, fmaf(az.x, vx, az.y * vy), ctp * vz);
@@ -809,6 +819,9 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
                 const float jc = fmaf(kd[c], dP[c], fmaf(C0[c], dSD[c], dS1v[c]));
                 ej = fmaxf(ej, fabsf(fmaf(C0[c], pdSD[c] - dSD[c], pdS1[c] - dS1v[c])) / fmaxf(fabsf(jc), kLzJFloor * floor_));
             }
+#ifdef MATPBR_AB_NOEJ
+            ej = 0.0f;
+#endif
             rho = lazy_rho_next(rho, fabsf(dr), e, ej, tol_s, tol_s * (kLzTolJ / kLzTolS));
         }
         rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
@@ -830,8 +843,10 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             *(uint32_t*)((char*)qs.plane[kLzSk + c] + o1) = pack_h2(gSD[c], gS1[c]);
             *(uint32_t*)((char*)qs.plane[kLzDk + c] + o1) = pack_h2(dSD[c], dS1v[c]);
             *(uint32_t*)((char*)qs.plane[kLzEk + c] + o1) = pack_h2(eSD[c], eS1[c]);
+#ifndef MATPBR_AB_NOD32
             *(uint32_t*)((char*)qs.plane[kLzD32 + c] + o1) = as_u(dSD[c]);
             *(uint32_t*)((char*)qs.plane[kLzD32 + 3 + c] + o1) = as_u(dS1v[c]);
+#endif
             float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
             if (FOLD) {      // the folded planes of lazy_pstep_kernel<kFoldXY> (fold_xy_*: one definition for the fold kernel and this one)
                 FoldXY f;

@@ -886,11 +886,11 @@ enum { LZ_RREF = 0, LZ_LO, LZ_HI, LZ_RHO, LZ_SD = 4, LZ_S1 = 7, LZ_GSD = 10, LZ_
 #define LAZY_MOVED R(1e-4)
 /* round 6: the radius also answers to the derivative handed to the backward pass: the old state's prediction of d out_c / d r at the new roughness
  * (dSD + eSD dr, dS1 + eS1 dr) against the walked one, relative to max(|d out_c / d r|, LAZY_JFLOOR x the parity floor), tolerance LAZY_TOL_J */
-#define LAZY_TOL_J R(2.5e-4)
+#define LAZY_TOL_J R(5e-4)
 #define LAZY_JFLOOR R(0.25)
 /* ... and the kinks: beyond a crossing the model keeps extrapolating the crossing sample's share of the derivative too (its share of the sums times
  * lam = d ln(weight)/dr); an interval ends where either costs its tolerance (LAZY_TOL_KJ of max(|d out_c / d r|, LAZY_JFLOOR x the parity floor)) */
-#define LAZY_TOL_KJ R(5e-4)
+#define LAZY_TOL_KJ R(1e-3)
 int oracle_lazy_nstate(void) { return LAZY_NSTATE; }
 
 typedef struct LazySums { real S0[3], S1[3], dS0[3], dS1[3]; } LazySums;

@@ -345,6 +345,66 @@ def test_split_operand_and_exact_f32_loops_reach_the_same_loss_at_512():
     assert np.abs(curves[6] - curves[0]).max() <= 1e-3 * np.abs(curves[0]).max(), (curves[6], curves[0])
 
 
+# ---------------------------------------------------------------------------------------------- configs[1] as BASELINE.json writes it
+def test_config1_as_written_indoor1_pos_mlp_rm_a_opt_env_from_2(golden_dir, tmp_path):
+    """BASELINE configs[1]: `examples/indoor1.png 512x512, --model_name=pos_mlp --opt_order='rm a' --opt_env_from=2`.  The photograph is
+    427 x 423 RGBA: centre crop to 423 x 423, alpha dropped, bilinear to 512 x 512 (myutils/misc.py:10-34), sRGB -> linear (:643-646).  The
+    reference ships no MaterialNet prediction and no result for this photograph (the every-other real-image test uses indoor2, which has
+    both), so the run starts from the flat prior and the test checks the RUN: the schedule (loop 1: one-epoch env phase because
+    opt_env_from = 2 > 1, part 'rm', 'a' skipped; loop 2: env phase, 'rm', 'a'), a loss that goes down, and the reference's output layout."""
+    import json
+    import warnings
+
+    from PIL import Image
+
+    from materialist_amd import pipeline
+    from materialist_amd.imageio_exr import read_exr
+
+    _cuda()
+    path = os.path.join(golden_dir, "indoor1.npz")
+    if not os.path.exists(path):
+        pytest.skip("indoor1 fixture missing")
+    rgba = np.load(path)["image_rgba_u8"]
+    assert rgba.shape == (423, 427, 4)
+    src = str(tmp_path / "indoor1.png")
+    Image.fromarray(rgba, "RGBA").save(src)
+    lines = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = pipeline.inverse_image(src, "indoor1", opt_src="arm", opt_order=["rm", "a"], opt_env_from=2, save_path=str(tmp_path), size=512, spp=64,
+                                     num_epochs=60, sync_every=10, log=lines.append, frame_interval=1e9, model_name="pos_mlp")
+    out = res["output_dir"]
+    cfg = json.load(open(os.path.join(out, "config.json")))
+    assert cfg["image_size"] == [512, 512]
+    assert cfg["model_name"] == "pos_mlp" and cfg["opt_order"] == ["rm", "a"] and cfg["opt_env_from"] == 2 and cfg["spp"] == 64
+    # the crop: 423 rows kept, columns 2..424 of 427 (centre), resized with align_corners=True -- the corners of the target are the crop's corners
+    gt = read_exr(os.path.join(out, "gt_image.exr"))
+    assert gt.shape == (512, 512, 3)
+    srgb = lambda u: np.where(u <= 0.04045, u / 12.92, ((u + 0.055) / 1.055) ** 2.4)
+    crop = rgba[:, 2:425, :3].astype(np.float64) / 255.0
+    for (i, j), (ci, cj) in (((0, 0), (0, 0)), ((511, 511), (422, 422)), ((0, 511), (0, 422))):
+        assert np.allclose(gt[i, j], srgb(crop[ci, cj]), atol=2e-3), (i, j, gt[i, j], srgb(crop[ci, cj]))
+    # the schedule of --opt_env_from 2 (inverse_img_w_mi.py:211-235,343-345)
+    tr = res["trace"]
+    shown = [(t.loop, t.phase, t.part, t.epoch, t.stop) for t in tr]
+    assert [(t.loop, t.phase, t.part) for t in tr if t.phase != "end"][:6] == [(1, "env", ""), (1, "brdf", "rm"), (1, "brdf", "a"), (2, "env", ""), (2, "brdf", "rm"), (2, "brdf", "a")], shown
+    assert tr[0].epoch == 0, shown                                   # loop 1 < opt_env_from: a single env epoch
+    assert tr[2].stop == "skip 'a' in loop 1", shown
+    assert [t.epoch for t in tr if t.phase == "brdf" and t.loop == 1 and t.part == "rm"] == [59], shown      # 60 epochs, no early stop from the flat prior
+    assert np.isfinite(res["best_loss"]) and res["psnr"] > 15.0
+    # the loss went down: the gamma-space MSE the single env epoch of loop 1 saw (flat prior, uniform light) against SaveBest's at the end
+    import re
+
+    first = [float(re.search(r"mse ([0-9.eE+-]+)", l).group(1)) for l in lines if isinstance(l, str) and "loop 1: env phase done" in l]
+    assert first and res["best_loss"] < 0.6 * first[0], (first, res["best_loss"])
+    for name in ("albedoPred.exr", "normalPred.exr", "roughnessPred.png", "metallicPred.png", "depthPred.exr", "gt_image.exr", "gt_image.png", "config.json",
+                 "env.png", "final_envmap.hdr", "opt_env_img.png", "indoor1.ply"):
+        assert os.path.exists(os.path.join(out, name)), name
+    assert sorted(os.listdir(os.path.join(out, "best_results"))) == ["albedo.exr", "envmap.hdr", "metallic.exr", "normal.exr", "rendered_img.exr", "roughness.exr"]
+    best = read_exr(os.path.join(out, "best_results", "rendered_img.exr"))
+    assert best.shape == (512, 512, 3) and np.isfinite(best).all()
+
+
 # ---------------------------------------------------------------------------------------------- configs[2], what N ranks do, on one GPU
 def test_rccl_path_of_the_bench_at_world_size_one():
     """`bench.py` launched exactly as the driver launches its N-rank runs (`python -m torch.distributed.run --nproc-per-node ...`), with one

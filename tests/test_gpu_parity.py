@@ -34,13 +34,16 @@ def assert_close(got, ref, rtol=RTOL, what=""):
     assert err.max() <= rtol, f"{what}: max scaled rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
-def _report(what, measured, bound):
-    """MATPBR_TOLERANCE_REPORT=<file>: one line per comparison, the measured maximum beside its bound (how the bounds in this file were set:
-    DESIGN.md section 5)."""
+def _report(what, measured, bound, floor=False):
+    """MATPBR_TOLERANCE_REPORT=<file>: one line per comparison -- the test that made it (pytest's own id: the same wording in two tests can no
+    longer collide), what was compared, the measured value beside its bound ("<=" a maximum, ">=" a floor) and whether it held (how the bounds
+    in this file were set: DESIGN.md section 5)."""
     path = os.environ.get("MATPBR_TOLERANCE_REPORT")
     if path:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
+        ok = float(measured) >= float(bound) if floor else float(measured) <= float(bound)
         with open(path, "a") as f:
-            f.write(f"{what}\t{float(measured):.3e}\t{float(bound):.1e}\n")
+            f.write(f"{test}\t{what}\t{float(measured):.3e}\t{'>=' if floor else '<='}\t{float(bound):.1e}\t{'ok' if ok else 'EXCEEDED'}\n")
 
 
 def _scene_arrays(H, W, image_id=0, unit_random_normals=True):
@@ -2086,6 +2089,43 @@ def test_real_image_run_lands_where_the_reference_run_did(tmp_path):
         assert os.path.exists(os.path.join(str(tmp_path), "indoor2", name)), name
 
 
+def test_hip_render_of_the_references_final_maps_against_mitsubas_render_of_them(golden_dir):
+    """The image-level pin against Mitsuba, on the GPU (the CPU twin with the full-precision files is
+    tests/test_reference_outputs.py).  The reference shipped, for its sample photograph, the maps its run ended at (best_results/{albedo,roughness,
+    metallic}.exr), the 16 x 32 envmap, MaterialNet's depth and Mitsuba's render of exactly those (best_results/rendered_img.exr: `path`,
+    max_depth 4, spp 64: inverse_img_w_mi.py:49-52).  The HIP render of the same maps under the same light and geometry is the depth-1,
+    un-shadowed term of that estimator: what separates the two images is occlusion, inter-reflection and Monte-Carlo
+    noise, not a convention.  The floors below are what that residual measures today (21-25 dB); a convention regression (camera, normals
+    from depth, envmap -> SH, gamma) lands far below them.  Only `indoor` has such a pair: jinjya's rendered_img.exr is not the render of
+    its maps (19.8 dB against its own panel, tests/test_reference_outputs.py)."""
+    from materialist_amd import render, sh
+
+    dev = _cuda()
+    z = np.load(os.path.join(golden_dir, "indoor2.npz"))
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+    a = t(z["ref_albedo_u8"].astype(np.float32) / 255.0)
+    r = t(z["ref_roughness_u8"].astype(np.float32)[..., None] / 255.0).clamp(0.07, 1.0)
+    m = t(z["ref_metallic_u8"].astype(np.float32)[..., None] / 255.0)
+    ref = z["ref_render_f16"].astype(np.float64)
+    depth = z["depth_pred_f32"]
+    depth = 2 * depth.max() - depth                                                  # inverse_img_w_mi.py:722
+    scene = render.load_estimated_mesh(t(depth), use_mesh_normal=True)
+    scene._set("emitter.data", t(z["ref_envmap_f32"]))                               # 16 x 32 texels -> SH25 by the fixed projection
+    with torch.no_grad():
+        img = render.render_w_brdf(scene, a, r, m, None, 64).cpu().numpy().astype(np.float64)
+    g = lambda x: np.clip(x, 0, 1) ** (1 / 2.2)
+    psnr = lambda x, y: -10 * np.log10(np.mean((g(x) - g(y)) ** 2))
+    raw, matched = psnr(img, ref), psnr(img * (ref.mean() / img.mean()), ref)        # the BRDF loss is scale-free (:388-391)
+    _report("HIP render vs Mitsuba render of the reference's final maps (indoor), dB raw", raw, 20.5, floor=True)
+    _report("HIP render vs Mitsuba render of the reference's final maps (indoor), dB mean-matched", matched, 24.5, floor=True)
+    assert raw > 20.5 and matched > 24.5, (raw, matched)
+    # the two renders agree on WHERE the light is: the correlation of their luminance gradients along x and y
+    lum = lambda x: g(x).mean(-1)
+    gx = lambda x: np.diff(x, axis=1)[8:-8, 8:-8].reshape(-1)
+    c = np.corrcoef(gx(lum(img)), gx(lum(ref)))[0, 1]
+    assert c > 0.5, c
+
+
 @pytest.mark.parametrize("M,hidden,skip,d0,n_out", [(4096, (256, 256, 256, 256), (1, 3), 15, 5), (1000, (64, 128, 64), (2,), 12, 3),
                                                    (2 * 128 + 7, (256, 256), (), 10, 8), (1024 + 40, (256, 128, 256), (), 12, 4)])
 def test_posmlp_mfma_kernels_match_the_torch_composition(M, hidden, skip, d0, n_out):
@@ -2335,6 +2375,49 @@ def test_deferred_folds_of_the_backward_pass_are_the_same_bits():
     assert float(runs[True][0].abs().max()) > 0.0
     for a, b in zip(runs[True], runs[False]):
         assert torch.equal(a, b)
+
+
+def test_weight_gradients_on_a_second_stream_are_the_same_bits():
+    """ArmMlpPhase.OVERLAP_WGRAD (round 6): the three weight-gradient products of the backward pass run on a second HIP stream beside the
+    input-gradient product of their layer (one dL/d pre matrix per layer instead of two ping-pong ones; events order the two streams; the folds
+    wait for both).  Against the single-stream order: the same gradient buffer, weights and statistics after five AdamW steps, bit for bit --
+    and again when the phase's own stream is not the default one."""
+    import copy
+
+    from materialist_amd import posmlp, render, synthetic
+    from materialist_amd.armhead import ArmMlpPhase
+
+    dev = _cuda()
+    H = W = 128
+    sc = synthetic.make_scene(6, H, W)
+    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
+    scene._set("emitter.data", _t(sc.light, dev))
+    gt = torch.rand(H, W, 3, device=dev)
+    a0, r0, m0 = (_t(v, dev).clamp(0, 1) for v in (sc.init_albedo, sc.init_roughness, sc.init_metallic))
+    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).contiguous()
+    torch.manual_seed(9)
+    net = posmlp.brdf_net("arm").to(dev)
+    net.lin4.weight.data.normal_(0, 0.05)
+    fixed = {"albedo": a0, "roughness": r0, "metallic": m0}
+    runs = {}
+    for tag, overlap, own_stream in (("one", False, False), ("two", True, False), ("two_side", True, True)):
+        ArmMlpPhase.OVERLAP_WGRAD = overlap
+        try:
+            st = torch.cuda.Stream(dev) if own_stream else torch.cuda.current_stream(dev)
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                ph = ArmMlpPhase(scene, gt, copy.deepcopy(net), start_arm, fixed, optimize_part="rm", spp=8)
+                assert ph.bwd_f16 and ph.overlap == overlap and len(ph.gbufs) == (3 if overlap else 2)
+                for _ in range(5):
+                    ph.step()
+            torch.cuda.synchronize()
+            runs[tag] = (ph.gflat.clone(), ph.flat.clone(), ph.stats.clone())
+        finally:
+            ArmMlpPhase.OVERLAP_WGRAD = True
+    assert float(runs["two"][0].abs().max()) > 0.0
+    for tag in ("two", "two_side"):
+        for a, b in zip(runs[tag], runs["one"]):
+            assert torch.equal(a, b), tag
 
 
 @pytest.mark.parametrize("n_prev,n_red", [(256, 256), (241, 256), (256, 241)])
