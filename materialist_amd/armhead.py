@@ -74,9 +74,6 @@ class ArmMlpPhase:
     DEFER_REDUCE = True    # the folds of the backward pass's partial sums (weight gradients' slabs, column sums behind the bias gradients) in ONE
                            # launch before the optimiser step instead of one behind every product (include/matpbr.h `matpbr_mlp_reduce_jobs`); needs
                            # BWD_F16.  Class switch: the same bits either way (tests/test_gpu_parity.py)
-    OVERLAP_WGRAD = True   # the backward pass's weight-gradient products on a second HIP stream, beside the input-gradient product of the same layer
-                           # (they read the same dL/d pre and depend on nothing of each other; each alone reaches 0.5-0.65 of the HBM rate).  Needs
-                           # BWD_F16 + DEFER_REDUCE (the folds wait for both streams).  Class switch: the same bits either way
     FWD_PRODUCTS = 3       # forward sine layers on two f16 pieces per operand, three products (include/matpbr.h `matpbr_mlp_split_weights_fmt`);
                            # 0: as the backward products (`_PosMlpHipFn.PRODUCTS`, three bf16 pieces).  Class switch: the tests run both
 
@@ -165,11 +162,7 @@ class ArmMlpPhase:
         # (include/matpbr.h `matpbr_mlp_layer_fwd_sgn`): no cosine matrices, a third less traffic per forward layer
         self.packed = bool(self.PACKED)
         self.cbufs = [None if self.packed else torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(self.L - 1)]
-        self.overlap = bool(self.OVERLAP_WGRAD and self.bwd_f16 and self.DEFER_REDUCE)
-        # dL/d pre matrices: two ping-pong, or one per 256-wide layer when the weight gradients run beside the input gradients (a matrix is then
-        # still being read on the second stream while the main stream writes the one after next)
-        self.gbufs = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(max(2, self.L - 2) if self.overlap else 2)]
-        self._side = torch.cuda.Stream(dev) if self.overlap else None
+        self.gbufs = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(2)]
         self.th, self.d_x = E(M, 8), E(M, 8)
         self.w_out_t = E(256, 8)                                 # the output weight transposed (operand of the input-gradient kernel)
         # split-operand images of the 256-wide layers' weights, forward and (transposed) backward operand: written by ONE launch
@@ -320,18 +313,10 @@ class ArmMlpPhase:
             o.mlp_layer_bwd_input(self.d_x, self.w_out_t, self.bufs[-1] if self.packed else self.cbufs[-1], g_prev, self.ns[-1], 5, gb_prev,
                                   packed=self.packed)
         g, n_red = g_prev, self.ns[-1]
-        overlap = self.overlap and jobs is not None
-        main = torch.cuda.current_stream(self.dev) if overlap else None
-        gi = 0                                                   # index of the buffer that holds g
         for l in range(self.L - 2, 0, -1):                       # g = dL/d pre of layer l: its weight gradient, then dL/d pre of layer l-1
             wp, _ = self.views[l]
             gw, _ = self.gviews[l]
-            if f16 and overlap:
-                self._side.wait_event(main.record_event())       # g (and its tile maxima) are complete on the main stream
-                with torch.cuda.stream(self._side):
-                    o.mlp_layer_bwd_weight_blk(g, self.tmax[l], self.bufs[l - 1], n_red, 256, out=gw, defer=slot(nj))
-                nj += 1
-            elif f16:
+            if f16:
                 o.mlp_layer_bwd_weight_blk(g, self.tmax[l], self.bufs[l - 1], n_red, 256, out=gw, defer=slot(nj))
                 nj += 1
             else:
@@ -343,13 +328,10 @@ class ArmMlpPhase:
                 if l == 1:
                     o.mlp_first_layer_bwd_blk(g, self.tmax[l], self.wsplit_b[l], c_prev, self.x0p, self.gviews[0][0], self.d0, n_prev, n_red, gb, defer=slot(nj))
                     nj += 2
-                    if overlap:
-                        main.wait_event(self._side.record_event())   # every weight-gradient product has left its partial sums
                     if jobs is not None:
                         o.mlp_reduce_jobs(jobs, nj, self.flat)
                     return
-                gi = (gi + 1) % len(self.gbufs)
-                g_prev = self.gbufs[gi]
+                g_prev = self.gbufs[0] if g is self.gbufs[1] else self.gbufs[1]
                 o.mlp_layer_bwd_input_blk(g, self.tmax[l], self.wsplit_b[l], c_prev, g_prev, n_prev, n_red, gb, self.tmax[l - 1], defer=slot(nj))
                 nj += 1
                 g, n_red = g_prev, n_prev

@@ -2377,49 +2377,6 @@ def test_deferred_folds_of_the_backward_pass_are_the_same_bits():
         assert torch.equal(a, b)
 
 
-def test_weight_gradients_on_a_second_stream_are_the_same_bits():
-    """ArmMlpPhase.OVERLAP_WGRAD (round 6): the three weight-gradient products of the backward pass run on a second HIP stream beside the
-    input-gradient product of their layer (one dL/d pre matrix per layer instead of two ping-pong ones; events order the two streams; the folds
-    wait for both).  Against the single-stream order: the same gradient buffer, weights and statistics after five AdamW steps, bit for bit --
-    and again when the phase's own stream is not the default one."""
-    import copy
-
-    from materialist_amd import posmlp, render, synthetic
-    from materialist_amd.armhead import ArmMlpPhase
-
-    dev = _cuda()
-    H = W = 128
-    sc = synthetic.make_scene(6, H, W)
-    scene = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True)
-    scene._set("emitter.data", _t(sc.light, dev))
-    gt = torch.rand(H, W, 3, device=dev)
-    a0, r0, m0 = (_t(v, dev).clamp(0, 1) for v in (sc.init_albedo, sc.init_roughness, sc.init_metallic))
-    start_arm = torch.cat([a0.reshape(-1, 3), r0.reshape(-1, 1), m0.reshape(-1, 1)], -1).contiguous()
-    torch.manual_seed(9)
-    net = posmlp.brdf_net("arm").to(dev)
-    net.lin4.weight.data.normal_(0, 0.05)
-    fixed = {"albedo": a0, "roughness": r0, "metallic": m0}
-    runs = {}
-    for tag, overlap, own_stream in (("one", False, False), ("two", True, False), ("two_side", True, True)):
-        ArmMlpPhase.OVERLAP_WGRAD = overlap
-        try:
-            st = torch.cuda.Stream(dev) if own_stream else torch.cuda.current_stream(dev)
-            st.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(st):
-                ph = ArmMlpPhase(scene, gt, copy.deepcopy(net), start_arm, fixed, optimize_part="rm", spp=8)
-                assert ph.bwd_f16 and ph.overlap == overlap and len(ph.gbufs) == (3 if overlap else 2)
-                for _ in range(5):
-                    ph.step()
-            torch.cuda.synchronize()
-            runs[tag] = (ph.gflat.clone(), ph.flat.clone(), ph.stats.clone())
-        finally:
-            ArmMlpPhase.OVERLAP_WGRAD = True
-    assert float(runs["two"][0].abs().max()) > 0.0
-    for tag in ("two", "two_side"):
-        for a, b in zip(runs[tag], runs["one"]):
-            assert torch.equal(a, b), tag
-
-
 @pytest.mark.parametrize("n_prev,n_red", [(256, 256), (241, 256), (256, 241)])
 def test_block_scaled_f16_backward_products(n_prev, n_red):
     """f2 (round 5): the backward products of the 256-wide layers on two f16 pieces with one exponent per 128-row tile
