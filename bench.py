@@ -633,7 +633,7 @@ def main(argv=None):
         if pmc.get("csrc_sha16") != sources_digest():
             # the counter passes were collected on other kernels than the ones this run executes: no traffic figure rather than a stale one
             pmc = {"stale": f"profiles/pmc_traffic.json was collected on csrc {pmc.get('csrc_sha16')}, this build is {sources_digest()}: "
-                            "re-run tools/pmc_passes_r05.sh + tools/pmc_to_traffic.py --write"}
+                            "re-run tools/pmc_passes_r06.sh + tools/pmc_to_traffic.py --write"}
         key = f"{H}x{W}_b{wr.B}_spp{args.spp}"
         t_step, t_stats, resampled, t_res = lazy_step_times(wr)
         ach = (BYTES_FWD + BYTES_BWD_ARM) * px / (t_step * 1e-3) / 1e9

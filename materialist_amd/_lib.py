@@ -98,9 +98,6 @@ SIGNATURES = {
     "matpbr_env_project": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_env_project_bwd": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_select_improved": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_void_p]),
-    "matpbr_adam_step_dev": (ctypes.c_int, [_c_f] * 4 + [ctypes.c_long, _c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
-    "matpbr_mlp_layer_bwd_input_w": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_void_p,
-                                                   ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_wsplit_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_mlp_split_weights": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_void_p]),
     "matpbr_mlp_layer_fwd_bx": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, _c_f, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
@@ -124,7 +121,6 @@ SIGNATURES = {
                                                         ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_mlp_layer_bwd_weight_bx": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                      ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "matpbr_mlp_split_weights_t": (ctypes.c_int, [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "matpbr_mlp_out_layer_bwd_tmax": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_void_p, _c_f,
                                                      ctypes.c_long, ctypes.c_long, _c_f, _c_f, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_int,
                                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
@@ -165,8 +161,6 @@ SIGNATURES = {
     "matpbr_sample_brdf_dr": (ctypes.c_int, [_c_f] * 10 + [ctypes.c_long, ctypes.c_void_p]),
     "matpbr_mlp_layer_fwd_bx_head": (ctypes.c_int, [_c_f, ctypes.c_int, _c_f, _c_f, _c_f, _c_f, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_int,
                                                    _c_f, _c_f, _c_f, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "matpbr_mlp_sincos": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
-    "matpbr_mlp_mul": (ctypes.c_int, [_c_f, ctypes.c_long, _c_f, ctypes.c_long, _c_f, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
     "matpbr_column_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "matpbr_column_sum": (ctypes.c_int, [_c_f, _c_f, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "matpbr_shade_transfer": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MatpbrCamera),

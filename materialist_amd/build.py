@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmatpbr.so")
 SOURCES = ["matpbr_kernels.hip", "posmlp_kernels.hip", "posmlp_chain.hip", "mesh_host.cpp"]
-HEADERS = [os.path.join("..", "..", "include", "matpbr_experimental.h"), "posmlp_device.hpp", "matpbr_device.hpp", "matpbr_shade.hpp", "matpbr_lazy.hpp", "matpbr_pstep.hpp", os.path.join("..", "..", "include", "matpbr.h")]
+HEADERS = [os.path.join("..", "..", "include", "matpbr_experimental.h"), "posmlp_device.hpp", "matpbr_device.hpp", "matpbr_shade.hpp", "matpbr_lazy.hpp", "matpbr_pstep.hpp", os.path.join("..", "..", "include", "matpbr.h"), os.path.join("..", "..", "include", "matpbr_mlp.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -1736,9 +1736,6 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             ls.walk_par = t & 1;
             // at most 1024 workgroups (four per CU, all resident), each with up to kPstepMaxBlocks consecutive 512-pixel blocks of one image
             long wg_cap = (q.flags & MATPBR_FLAG_SHARE_GPU) ? 512 : 1024;
-#ifdef MATPBR_EXP_TUNE   // measurement builds only (tools/r4_variant.sh)
-            if (const char* e = std::getenv("MATPBR_PSTEP_WGS")) wg_cap = std::atol(e) > 0 ? std::atol(e) : wg_cap;
-#endif
             int bpw = (int)(((long)lb.nblk * q.batch + wg_cap - 1) / wg_cap);
             bpw = bpw < 1 ? 1 : (bpw > kPstepMaxBlocks ? kPstepMaxBlocks : bpw);
             ls.tiles_per_wg = 2 * bpw; ls.n_tiles = 2 * lb.nblk;
@@ -1752,9 +1749,6 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             if ((stages & MATPBR_STAGE_RESAMPLE) && pwalk) {     // one wave per chunk of eight listed pixels; 256 waves per image take a queue of any length
                 // waves per image: a multiple of the shards, 2048 in all at most (a long queue -- the first iterations of a part -- is walked in passes)
                 int walk_cap = 2048;
-#ifdef MATPBR_EXP_TUNE   // measurement builds only (tools/r4_tune.sh)
-                if (const char* e = std::getenv("MATPBR_PWALK_WGS")) walk_cap = std::atoi(e) > 0 ? std::atoi(e) : walk_cap;
-#endif
                 int nw = walk_cap / q.batch / kWalkShards * kWalkShards;
                 const int most = (int)((walk_shard_cap(n1) + 7) / 8) * kWalkShards;
                 nw = nw < kWalkShards ? kWalkShards : (nw > 1024 ? 1024 : nw);
@@ -1772,12 +1766,6 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     return launch_status();
 }
 
-#ifdef MATPBR_PS_STAMPS
-int matpbr_debug_ps_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_stamps), sizeof(g_ps_stamps)) == hipSuccess ? 0 : 1; }
-#endif
-#ifdef MATPBR_RS_STAMPS
-int matpbr_debug_rs_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_stamps), sizeof(g_rs_stamps)) == hipSuccess ? 0 : 1; }
-#endif
 int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* ph, int t_done, void* stream) {
     if (!ph || t_done < 0) return MATPBR_ERR_INVALID_ARG;
     const MatpbrBrdfPhase& q = *ph;
@@ -1963,10 +1951,6 @@ int matpbr_adamw_step_snapshot_dev(float* p, const float* g, float* m, float* v,
 int matpbr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps,
                           float weight_decay, void* stream) {
     return matpbr_adamw_step_snapshot_dev(p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay, nullptr, nullptr, stream);
-}
-
-int matpbr_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float* hyper, float beta1, float beta2, float eps, void* stream) {
-    return matpbr_adamw_step_dev(p, g, m, v, n, hyper, beta1, beta2, eps, 0.0f, stream);
 }
 
 int matpbr_sin_bwd(const float* d_y, long ld_d, const float* pre, long ld_p, float* out, long M, int n, void* stream) {

@@ -352,9 +352,6 @@ struct StepPtrs {             // where this image's iteration reads its paramete
 };
 __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, float ratio, float sr, bool improved, float& tot,
                                                 float (&reg)[3], LazyRecord& rec) {
-#ifdef MATPBR_NO_SNAPSHOT   // measurement only (tools/no_snapshot_ab.sh)
-    improved = false;
-#endif
     if (qs.rotate) improved = false;      // no snapshot stores: the buffer just read IS the snapshot
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
@@ -464,13 +461,7 @@ __device__ __forceinline__ bool lazy_step_pixel(const LazyStepArgs& qs, const St
     const float r1 = fminf(fmaxf(nr, 0.07f), 1.0f), m1 = fminf(fmaxf(nm, 0.0f), 1.0f), dr1 = r1 - rref, omm1 = 1.0f - m1;
     if (q.part_mask & MATPBR_PART_R) reg[1] += fabsf(r1 - r0v);
     if (q.part_mask & MATPBR_PART_M) reg[2] += fabsf(m1 - m0v);
-#if defined(MATPBR_EXP_NORESAMPLE)   // measurement only (tools/step_parts_ab.sh): the walk compiled out / never taken at run time
-    const bool need = false;
-#elif defined(MATPBR_EXP_NORESAMPLE_RT)
-    const bool need = !(dr1 >= -h2_lo(lohi) && dr1 <= h2_hi(lohi)) && qs.n_sums < 0;
-#else
     const bool need = !(dr1 >= -h2_lo(lohi) && dr1 <= h2_hi(lohi));
-#endif
     rec.r = r1; rec.m = m1; rec.dr = dr1;
     float rgb3[3];
 #pragma unroll
@@ -530,14 +521,10 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
         // fold: thread i takes row i (fold_rows <= kBlock), waves by a fixed DPP tree, the four wave totals in fixed order
         const float* rows = qs.fold_part + (long)b * step_part_stride(qs.fold_rows);
         float v[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#ifndef MATPBR_EXP_NOFOLD   // measurement only (tools/step_parts_ab.sh)
         for (int i = threadIdx.x; i < qs.fold_rows; i += kBlock) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] += rows[(long)i * 5 + k];
         }
-#else
-        v[0] = 1.0f; v[1] = 1.0f;
-#endif
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const float w = wave_sum_to_lane63(v[k]);
@@ -644,15 +631,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
 // quarters of the workgroups list a pixel or two, and a workgroup that walks holds its registers and LDS through two more memory round
 // trips while nothing of it streams; here the walkers are a launch of their own and the step kernel is a pure streaming pass (80
 // registers, no spills).
-#ifdef MATPBR_RS_STAMPS   // cycle stamps of one wave of the resampling launch (tools/rs_stamps.sh); never in the product build
-__device__ unsigned long long g_rs_stamps[8];
-#ifndef MATPBR_RS_BLOCK
-#define MATPBR_RS_BLOCK 3
-#endif
-#define RS_STAMP(k) do { if (blockIdx.x == MATPBR_RS_BLOCK && blockIdx.y == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); g_rs_stamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define RS_STAMP(k) do { } while (0)
-#endif
 // One listed pixel re-sampled by the eight lanes `sub` = 0..7 of its group (four azimuths x (r, r + dir h: the one-sided difference that gives
 // the slopes), each lane walking the rings of its azimuth, contributions folded by a fixed butterfly): rebuilds the pixel's model, writes its
 // render into sp.pred_next and adds it to `tot` (lane sub == 0 of an item that exists; the other lanes return without side effects).
@@ -698,13 +676,9 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
         const uint32_t sk = ldu(qs.plane[kLzSk + c], o1);      // what the old model predicts at the new roughness
         pSD[c] = fmaf(h2_lo(sk), dr, as_f(ldu(qs.plane[kLzSD + c], o1)));
         pS1[c] = fmaf(h2_hi(sk), dr, as_f(ldu(qs.plane[kLzS1 + c], o1)));
-#ifdef MATPBR_AB_NOD32
-        pdSD[c] = pdS1[c] = 0.0f;
-#else
         const uint32_t ek = ldu(qs.plane[kLzEk + c], o1);      // ... and of the detached derivatives
         pdSD[c] = fmaf(h2_lo(ek), dr, as_f(ldu(qs.plane[kLzD32 + c], o1)));
         pdS1[c] = fmaf(h2_hi(ek), dr, as_f(ldu(qs.plane[kLzD32 + 3 + c], o1)));
-#endif
         Pc[c] = fmaf(fmaf(A2[c], rc_r, A1), rc_r, A0);
         dP[c] = fmaf(2.0f * rc_r, A2[c], A1);
         kd[c] = rc[1 + c] * (1.0f - mv);
@@ -713,7 +687,6 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
         // the derivative's scale, from the old model's prediction like the render's; premultiplied by tol_k / tol_kj: one lazy_kink call serves both
         ijscale[c] = (kLzTolK / kLzTolKJ) / fmaxf(fabsf(fmaf(kd[c], dP[c], fmaf(C0[c], pdSD[c], pdS1[c]))), kLzJFloor * floor_);
     }
-    RS_STAMP(3);
     // ---- this lane's samples: one azimuth of every ring, at r (sub 0-3) or at r + dir h (sub 4-7)  (spec_ring / spec_sample /
     // spec_accumulate of matpbr_shade.hpp, one value per lane)
     float S0[3] = {0, 0, 0}, S1[3] = {0, 0, 0}, dS0[3] = {0, 0, 0}, dS1[3] = {0, 0, 0}, klo = 1e30f, khi = 1e30f;
@@ -761,15 +734,9 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
                 for (int c = 0; c < 3; ++c) {
                     S0[c] = fmaf(wgt, L[c], S0[c]); S1[c] = fmaf(wx, L[c], S1[c]);
                     dS0[c] = fmaf(wl, L[c], dS0[c]); dS1[c] = fmaf(wlx5, L[c], dS1[c]);
-#ifdef MATPBR_AB_NOKJ
-                    const float aL = fabsf(L[c]) * iscale[c];
-                    m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL);
-                    m2 = fmaxf(m2, aL);
-#else
                     const float aL = fabsf(L[c]), sc1 = fmaxf(iscale[c], lamk1 * ijscale[c]), sc2 = fmaxf(iscale[c], lamk2 * ijscale[c]);
                     m1 = fmaxf(m1, fmaf(1.0f - C0[c], x5, C0[c]) * aL * sc1);
                     m2 = fmaxf(m2, aL * sc2);
-#endif
                 }
                 // where this sample's clamped variables n.wi and wo.h cross zero, to first order in r
                 const float dp = fmaf(stp, fmaf(az.x, vx, az.y * vy), ctp * vz);
@@ -779,7 +746,6 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             }
         }
     }
-    RS_STAMP(4);
     // fold over the four azimuth lanes with a fixed butterfly (the same tree for every pixel: reproducible)
     float fv[kWalkVals];
 #pragma unroll
@@ -819,9 +785,6 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
                 const float jc = fmaf(kd[c], dP[c], fmaf(C0[c], dSD[c], dS1v[c]));
                 ej = fmaxf(ej, fabsf(fmaf(C0[c], pdSD[c] - dSD[c], pdS1[c] - dS1v[c])) / fmaxf(fabsf(jc), kLzJFloor * floor_));
             }
-#ifdef MATPBR_AB_NOEJ
-            ej = 0.0f;
-#endif
             rho = lazy_rho_next(rho, fabsf(dr), e, ej, tol_s, tol_s * (kLzTolJ / kLzTolS));
         }
         rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
@@ -843,10 +806,8 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             *(uint32_t*)((char*)qs.plane[kLzSk + c] + o1) = pack_h2(gSD[c], gS1[c]);
             *(uint32_t*)((char*)qs.plane[kLzDk + c] + o1) = pack_h2(dSD[c], dS1v[c]);
             *(uint32_t*)((char*)qs.plane[kLzEk + c] + o1) = pack_h2(eSD[c], eS1[c]);
-#ifndef MATPBR_AB_NOD32
             *(uint32_t*)((char*)qs.plane[kLzD32 + c] + o1) = as_u(dSD[c]);
             *(uint32_t*)((char*)qs.plane[kLzD32 + 3 + c] + o1) = as_u(dS1v[c]);
-#endif
             float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
             if (FOLD) {      // the folded planes of lazy_pstep_kernel<kFoldXY> (fold_xy_*: one definition for the fold kernel and this one)
                 FoldXY f;
@@ -880,7 +841,6 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
     const JacBwdArgs& q = qs.j;
     const int b = blockIdx.y;
     const int P = g.H * g.W;
-    RS_STAMP(0);
     // one round trip for everything that depends on nothing: the stop flag, the counts, the committed state, the tables
     extern __shared__ int s_pref[];                                        // [nblk + 1]
     const int nblk = qs.n_sums - (int)gridDim.x;
@@ -923,7 +883,6 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
         if ((int)threadIdx.x >= d) incl += v;
     }
     const int T = __shfl(incl, 63);                                        // all the image's items (uniform)
-    RS_STAMP(1);
     if (T == 0 || (long)blockIdx.x * 8 >= T) {
         if (threadIdx.x == 0) qs.block_sums[(long)b * qs.n_sums + nblk + blockIdx.x] = 0.0f;
         return;
@@ -980,11 +939,9 @@ __global__ __launch_bounds__(64) void lazy_resample_kernel(const LazyStepArgs qs
                 rel -= cj; ++lo_b;
             }
             const int p = lo_b * kLazyBlockPixels + (int)lists[(long)lo_b * kLazyBlockPixels + rel];
-            RS_STAMP(2);
             resample_walk_pixel<false>(qs, sp, s_light, s_ring, s_saz, g, tab, b, P, BPl, p, item_ok, sub, floor_, tol_k, tol_s, tot);
         }
     }
-    RS_STAMP(5);
     tot = wave_sum_to_lane63(tot);
     if (lane == 63) qs.block_sums[(long)b * qs.n_sums + nblk + blockIdx.x] = tot;
 }

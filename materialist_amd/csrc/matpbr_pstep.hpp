@@ -296,14 +296,7 @@ template <int MODE> struct PStepPx;
 template <> struct PStepPx<kFoldXY> { typedef PxXY type; };
 template <> struct PStepPx<kFoldGH> { typedef PxGH type; };
 
-#ifdef MATPBR_PS_STAMPS   // cycle stamps of one workgroup of the persistent step (tools/ps_stamps.sh); never in the product build
-__device__ unsigned long long g_ps_stamps[16];
-#define PS_STAMP(k) do { if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); g_ps_stamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define PS_NOTE(k, v) do { if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) g_ps_stamps[k] = (unsigned long long)(v); } while (0)
-#else
-#define PS_STAMP(k) do { } while (0)
 #define PS_NOTE(k, v) do { } while (0)
-#endif
 constexpr int kPstepListCap = kMaxTilesPerWg * 64;     // entries of a wave's list: every pixel it owns in the workgroup's tiles
 constexpr int kPstepMaxBlocks = kMaxTilesPerWg / 2;
 
@@ -320,7 +313,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     const int b = blockIdx.y;
     const int P = g.H * g.W;
     const int nblk_img = lazy_fwd_blocks(P);
-    PS_STAMP(0);
     PS_NOTE(12, __builtin_amdgcn_s_memrealtime());
     // this workgroup's blocks: blockIdx.x, blockIdx.x + gridDim.x, ... (>= 1 by the launch geometry).  Interleaved, not consecutive: the
     // workgroups that run side by side stream neighbouring blocks, and the pixels that leave their intervals together (a neighbourhood of
@@ -364,7 +356,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     pstep_load_params(A, sp, (unsigned)(b * P + pix(0)));
     pstep_load_params(B, sp, (unsigned)(b * P + pix(1)));
     __builtin_amdgcn_sched_barrier(0);
-    PS_STAMP(1);
     // ---- the iteration's statistics: every workgroup folds the rows of partial sums of its image (fixed order: the same bits everywhere),
     // forms the scalars from the OLD SaveBest / EarlyStopping state; workgroup 0 of the image writes the NEW state and the caller's row
     float ratio, sr;
@@ -419,7 +410,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         sr = s_state[kStSr];
         improved = s_state[kStImproved] > 0.5f;
     }
-    PS_STAMP(2);
     if (qs.rotate) {                                           // uniform per image: scalar selects of the base pointers
         const bool wr1 = __builtin_amdgcn_readfirstlane((int)(s_state[kStSel] > 0.5f)) != 0;
         if (qs.alt_a) sp.pa = wr1 ? qs.alt_a : q.pa;
@@ -479,7 +469,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         }
         PS_NOTE(15, cntw);
     }
-    PS_STAMP(3);
     __syncthreads();
     // ---- per-block results: the sum of the render of the streamed pixels (the four waves in order) and the regulariser sums; the listed
     // pixels of a block, compacted in a fixed order (wave, tile, lane: whatever the batch size and the blocks per workgroup), go to the block's
@@ -510,7 +499,6 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         const int bl = threadIdx.x / 3, k = threadIdx.x - 3 * bl;
         qs.reg_sums[((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * 3 + k] = (s_breg[bl][0][k] + s_breg[bl][1][k]) + (s_breg[bl][2][k] + s_breg[bl][3][k]);
     }
-    PS_STAMP(8);
     PS_NOTE(13, __builtin_amdgcn_s_memrealtime());
 }
 
@@ -540,7 +528,6 @@ __global__ __launch_bounds__(64) void lazy_pwalk_kernel(const LazyStepArgs qs, c
     const int nblk = lazy_fwd_blocks(P);
     const int lane = threadIdx.x;
     const int shard = wv % kWalkShards, k0 = wv / kWalkShards, kstep = nwv / kWalkShards;
-    RS_STAMP(0);
     // one round trip for everything that depends on nothing: the stop flag, the list's length, this wave's first entries, the state, the tables
     const float stopped = qs.state_old[b * kStateStride + kStStopped];
     const int n = (int)qs.walk_cnt[(b * 2 + qs.walk_par) * kWalkShards + shard];
@@ -552,7 +539,6 @@ __global__ __launch_bounds__(64) void lazy_pwalk_kernel(const LazyStepArgs qs, c
     const float2 saz_v = (&tab.saz[0][0])[lane];
     const float4 ring_v = tab.sring[lane < kMaxRings ? lane : 0];
     if (stopped > 0.5f || 8 * k0 >= n) return;                             // the step kernel skipped the image / nothing for this wave (uniform)
-    RS_STAMP(1);
     s_light[lane] = lt0 * kShNorm[lane / 3];
     if (lane + 64 < kNL) s_light[lane + 64] = lt1 * kShNorm[(lane + 64) / 3];
     s_saz[lane] = saz_v;
@@ -575,14 +561,11 @@ __global__ __launch_bounds__(64) void lazy_pwalk_kernel(const LazyStepArgs qs, c
         const bool ok = 8 * k + (lane >> 3) < n;
         const int first = __shfl((int)pix, 0);                             // entry 8 k exists; (unconditionally: a shuffle inside the select below
         const int p = ok ? (int)pix : first;                               //  would read lane 0 while it is masked off)
-        RS_STAMP(2);
         float rs = 0.0f;
         resample_walk_pixel<true>(qs, sp, s_light, s_ring, s_saz, g, tab, b, P, BPl, p, ok, sub, floor_, tol_k, tol_s, rs);
-        RS_STAMP(5);
         if (ok && sub == 0)
             atomicAdd((unsigned long long*)(qs.walk_fix + (long)b * nblk + p / kLazyBlockPixels), (unsigned long long)(long long)__double2ll_rn((double)rs * kWalkFix));
     }
-    RS_STAMP(6);
 }
 
 }  // namespace matpbr

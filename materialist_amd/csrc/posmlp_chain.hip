@@ -225,11 +225,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainArgs p
       const float unscale = FIRST ? 1.0f : kF16WUnscale;
       // (selects, not indexed kernel arguments: an indexed read would put the argument block into scratch memory)
       const bool tail = (L == 1 ? p.tail[0] : L == 2 ? p.tail[1] : L == 3 ? p.tail[2] : p.tail[3]) != 0;
-#ifdef MATPBR_CHAIN_STORE_L2     // measurement: every tile stores over the same 128 rows (the stores' issue cost without their HBM traffic)
-      float* const outp = (L == 1 ? p.out[0] : L == 2 ? p.out[1] : L == 3 ? p.out[2] : p.out[3]) + (row & 127) * p.ldo + 4 * h;
-#else
       float* const outp = (L == 1 ? p.out[0] : L == 2 ? p.out[1] : L == 3 ? p.out[2] : p.out[3]) + row * p.ldo + 4 * h;
-#endif
       const float* const bias = sBias + (L - 1) * 256 + 4 * h;
       f32x16 accN[8];
 #pragma unroll
@@ -243,11 +239,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainArgs p
         if (t >= 1 && !HEAD) {
           // the weights of stage P (requested two stages ago): everything but the youngest request (8 pieces) and the stores behind it (4)
           // the weights of stage P: its last piece went out with chunk 7 two slots ago; behind it one store, then last slot's 8 pieces and 4 stores
-#ifdef MATPBR_CHAIN_LOOSE_WAIT       // measurement only (WRONG results): how much of a slot is the wait for older stores' acknowledgements
-          asm volatile("s_waitcnt vmcnt(45) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
           asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
         }
         // A fragments (weights) of block c, stage t - 1: [k-step][piece]; requested one chunk ahead of their products
         uint4 af[2][2][2];
@@ -271,11 +263,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainArgs p
           const bool mm = t >= 1 && (!HEAD || c == 0);          // the products block t - 1 released: 32 features (block c) x this stage's two k-steps
           if (t >= 1 && !HEAD) issue_piece(P + 2, c);           // one 1 KB piece of the stage after next per chunk: its issue rides in a product's shadow
           if (t >= 1 && !HEAD && c + 1 < 8) read_frags(c + 1, af[(c + 1) & 1]);
-#ifdef MATPBR_CHAIN_NO_MFMA       // measurement builds only (tools/chain_ab.sh): what the slot costs without its products / without its epilogue
-          if (false) {
-#else
           if (mm) {
-#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
               const uint4 a_hi = af[c & 1][ks][0], a_lo = af[c & 1][ks][1];
@@ -288,12 +276,8 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainArgs p
           if (t < 8) {                                         // the epilogue of block t of the finished layer: outputs 2 c, 2 c + 1 (features 32 t + 8 q + 4 h + t0, + 1)
             const int q = c >> 1, t0 = 2 * (c & 1);
             const float b0 = t0 ? bq[q].z : bq[q].x, b1 = t0 ? bq[q].w : bq[q].y;
-#ifdef MATPBR_CHAIN_NO_EPI
-            float v0 = acc[t][2 * c] + b0, v1 = acc[t][2 * c + 1] * unscale + b1;
-#else
             float v0 = sin_packed<FIRST>(__builtin_fmaf(acc[t][2 * c], unscale, b0));
             float v1 = sin_packed<FIRST>(__builtin_fmaf(acc[t][2 * c + 1], unscale, b1));
-#endif
             if (t == 7 && tail) {                              // uniform: a 241-wide layer's last block ends in x0 (mymodels/mlps.py:214-217)
               v0 = tail_pick<true>(v0, xr, h, q, t0);
               v1 = tail_pick<true>(v1, xr, h, q, t0 + 1);
@@ -304,14 +288,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainArgs p
             split2h(v0, v1, p_hi, p_lo);
             set_comp(bp[t & 1][q >> 1][0], 2 * (q & 1) + (c & 1), p_hi);
             set_comp(bp[t & 1][q >> 1][1], 2 * (q & 1) + (c & 1), p_lo);
-#ifdef MATPBR_CHAIN_STORE_LINEAR     // measurement: the same bytes as whole 1 KB runs per instruction (a scrambled layout: what coalesced stores would cost)
-            if (c & 1) *reinterpret_cast<float4*>((L == 1 ? p.out[0] : L == 2 ? p.out[1] : L == 3 ? p.out[2] : p.out[3]) + ((size_t)(tile * 4 + wave) * 8 + t) * 1024 + q * 256 + lane * 4) =
-                make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
-#elif defined(MATPBR_CHAIN_STORE_NT)
-            if (c & 1) __builtin_nontemporal_store(f32x4v{vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]}, reinterpret_cast<f32x4v*>(outp + 32 * t + 8 * q));
-#elif !defined(MATPBR_CHAIN_NO_STORE)
             if (c & 1) *reinterpret_cast<float4*>(outp + 32 * t + 8 * q) = make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
-#endif
           }
           // one chunk = one scheduling pattern: the next chunk's four fragment reads first, then each product followed by its share of
           // the epilogue's vector instructions (an in-order wave issues them in the product's shadow only if they FOLLOW it in the stream)

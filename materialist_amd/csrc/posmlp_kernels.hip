@@ -870,30 +870,6 @@ __global__ __launch_bounds__(256) void mlp_colsum_reduce(const float* __restrict
   colsum_reduce_body(red, part, groups, out, (int)blockIdx.x);
 }
 
-// S = sin(pre), C = cos(pre) over [M, n] with independent row strides (the first layer, whose K = 15 product stays in the BLAS)
-__global__ __launch_bounds__(256) void mlp_sincos_kernel(const float* __restrict__ pre, long ldp, float* __restrict__ S, long lds,
-                                                         float* __restrict__ C, long ldc, long M, int n) {
-  const long total = M * n;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long m = i / n;
-    const int j = (int)(i - m * n);
-    float s, c;
-    sincos_cw(pre[m * ldp + j], s, c);
-    S[m * lds + j] = s;
-    C[m * ldc + j] = c;
-  }
-}
-
-// out = a * b over [M, n] with row strides (G = d_inp * C for the layer fed by the BLAS product)
-__global__ __launch_bounds__(256) void mlp_mul_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
-                                                      float* __restrict__ out, long ldo, long M, int n) {
-  const long total = M * n;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long m = i / n;
-    const int j = (int)(i - m * n);
-    out[m * ldo + j] = a[m * lda + j] * b[m * ldb + j];
-  }
-}
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1205,20 +1181,6 @@ constexpr int kBxThreads = 512;
 // v_mfma_f32_16x16x4f32 per block fold them into 8 x 4 accumulator registers per wave.  Saves the 268 MB store, the 268 MB read of the
 // skinny weight-gradient pass and its launch.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-#ifdef MATPBR_BX_STAMPS   // in-kernel cycle stamps of workgroup 0, waves 0 and 4 (one SIMD), second tile (tools/bx_stamps.py); never in the product build
-__device__ unsigned long long g_bx_stamps[2][8][8];
-__device__ unsigned long long g_epi_stamp[2];
-#define BX_STAMP(slot)                                                                                         \
-  do {                                                                                                         \
-    if (GL && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && tile == (int)gridDim.x) {                      \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-      g_bx_stamps[wave >> 2][ks_stamp][slot] = __builtin_amdgcn_s_memtime();                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-    }                                                                                                          \
-  } while (0)
-#else
-#define BX_STAMP(slot) do { } while (0)
-#endif
 // GL: both operands of the main loop arrive by LDS-DMA (global_load_lds_dwordx4: no register round trip, no ds_write, full 128-byte
 // lines of the rows, the rows read once per workgroup instead of once per column half).  Weights: two 48 KB buffers, one super-step
 // ahead; rows: a ring of three 16 KB buffers [128 rows][8 x 16 B] (chunk c of row r at slot c ^ (r >> 1 & 7): the fragment reads of
@@ -1340,7 +1302,6 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
       const int ksn = ks + 1 < nks ? ks + 1 : 0;                           // next super-step of the stream (wraps into the next tile)
       float4 cur[4];
       const int ks_stamp = ks & 7; (void)ks_stamp;
-      BX_STAMP(0);
       if (GL) {
         // the weights of the next super-step and the rows of the one after it (beyond this workgroup's last tile: its rows again, unused)
         int t2 = tile, k2 = ks + 2;
@@ -1350,7 +1311,6 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
           gl_issue_w(ksn, buf ^ 1);
           gl_issue_a(t2, k2, a_slot >= 1 ? a_slot - 1 : 2);                // (a_slot + 2) % 3
         }
-        BX_STAMP(1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const float4*>(bx_smem + gl_rd[q] + a_slot * kGlRows);
       } else {
@@ -1402,14 +1362,12 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
                                                               acc[ni], 0, 0, 0);
         }
       }
-      BX_STAMP(2);
       if (GL) {
         // everything but the four youngest pieces (the rows of step + 2) has landed; the barrier publishes it
         // (lgkmcnt: this wave's fragment reads of the buffers that the next step's DMA overwrites are complete, not merely issued)
         if (issuer) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         a_slot = a_slot == 2 ? 0 : a_slot + 1;
-        BX_STAMP(3);
       } else {
       // the other buffer was last read in the previous super-step, and every wave has passed that step's barrier
       uint4* sdst = sB + (buf ^ 1) * kBxStage + tid;
@@ -1522,7 +1480,6 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
       // sComb is written again at the end of the next tile, eight barriers from here
     }
     if (GL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the scratch slices are the next LDS-DMA targets (of waves 0-3)
-    { const int ks_stamp = 0; (void)ks_stamp; BX_STAMP(4); }
   }
   if (GL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the unused look-ahead pieces: nothing may land after the workgroup ends
   if (W0) {                                                   // lane holds dW0[n = .. + 4 (lane >> 4) + r][k = lane & 15]
@@ -1559,18 +1516,6 @@ __global__ __launch_bounds__(kBxThreads, 1) void mlp_nt_bx(const NtArgs p, const
 // (inline asm, counted by hand: vmcnt(4) after the first half of a granule, vmcnt(0) after the second).  Wave w fills slice w of every
 // buffer; slice w of the weight buffer it fills next is its transposition scratch in the epilogue.  HEAD: the output-layer weights and
 // the row exchange live in the row granule that is free during the epilogue (re-read per tile, two more barriers per tile).
-#ifdef MATPBR_BX_STAMPS
-#define GX_STAMP(ksidx, slot)                                                                                  \
-  do {                                                                                                         \
-    if (blockIdx.x == 0 && wave < 2 && lane == 0 && tile == (int)gridDim.x) {                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-      g_bx_stamps[wave][(ksidx) & 7][slot] = __builtin_amdgcn_s_memtime();                                     \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-    }                                                                                                          \
-  } while (0)
-#else
-#define GX_STAMP(ksidx, slot) do { } while (0)
-#endif
 constexpr int kGxThreads = 256;
 constexpr int kGxW = kBxStage / 2 * 16;                                  // bytes of one weight buffer (24 KB)
 constexpr size_t kGxSmem = 2 * kGxW + 2 * kGlRows;                       // 80 KB
@@ -1653,10 +1598,8 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int step_n = s == 0 ? 2 * g + 1 : (g + 1 < ng ? 2 * g + 2 : 0);
-        GX_STAMP(g, 4 * s + 0);
         issue_w(step_n, wb ^ 1);
         if (s == 0) issue_a(t2, g2, ab ^ 1);
-        GX_STAMP(g, 4 * s + 1);
         uint4 aq[2][3];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -1710,10 +1653,8 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
                                                                     acc[mi][ni], 0, 0, 0);
           }
         }
-        GX_STAMP(g, 4 * s + 2);
         if (s == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        GX_STAMP(g, 4 * s + 3);
         wb ^= 1;
       }
       ab ^= 1;
@@ -1845,9 +1786,6 @@ __global__ __launch_bounds__(kGxThreads, 2) void mlp_nt_gx(const NtArgs p, const
       if (lane == 63) atomicMax(p.o_tmax + tile, __float_as_uint(wmx));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the scratch slice is this wave's next DMA target
-#ifdef MATPBR_BX_STAMPS
-    if (blockIdx.x == 0 && wave < 2 && lane == 0 && tile == (int)gridDim.x) g_epi_stamp[wave] = __builtin_amdgcn_s_memtime();
-#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the unused look-ahead pieces: nothing may land after the workgroup ends
   if (W0) {                                                     // lane holds dW0[n = .. + 4 (lane >> 4) + r][k = lane & 15]
@@ -2119,13 +2057,7 @@ __global__ __launch_bounds__(kWgThreads, 1) void mlp_wgrad_hx(const float* __res
     }
     auto issue = [&](int step, int buf) {                         // a loader wave's rows 4 w .. 4 w + 3 of the step, of G and of X
       const int sc = step < steps ? step : steps - 1;              // (beyond the slab: the last rows again, into a buffer nobody reads)
-#if defined(MATPBR_WG_SLABS)
-      const long row = (long)blockIdx.x * (my_tiles * kBM) + 16L * sc + 4 * wave_u;      // (measurement: one contiguous slab per workgroup; tiles a multiple of the grid)
-#elif defined(MATPBR_WG_ASCENDING)
-      const long row = ((long)(tiles - 1 - t_first) + (long)(sc >> 3) * gridDim.x) * kBM + 16 * (sc & 7) + 4 * wave_u;
-#else
       const long row = ((long)t_first - (long)(sc >> 3) * gridDim.x) * kBM + 16 * (7 - (sc & 7)) + 4 * wave_u;
-#endif
       const unsigned dst = lds0 + (unsigned)buf * (unsigned)kHxRaw + (unsigned)wave_u * 4096u;
       glds16_x4v(G + row * ldg, vg[0], vg[1], vg[2], vg[3], dst);
       glds16_x4v(X + row * ldx, vx[0], vx[1], vx[2], vx[3], dst + 16u * 1024u);
@@ -2799,12 +2731,6 @@ inline void reduce_or_defer(const MatpbrReduceJob& q, MatpbrReduceJob* defer, hi
 
 extern "C" {
 
-#ifdef MATPBR_BX_STAMPS
-int matpbr_debug_bx_stamps(unsigned long long* out) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bx_stamps), sizeof(g_bx_stamps)) != hipSuccess) return 1;
-  return hipMemcpyFromSymbol(out + 128, HIP_SYMBOL(g_epi_stamp), sizeof(g_epi_stamp)) == hipSuccess ? 0 : 1;
-}
-#endif
 int matpbr_mlp_set_lds_dma(int mode) {
   g_nt_w0_gx.store(mode == 3 ? 1 : 0, std::memory_order_relaxed);
   const int was = g_nt_gl.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
@@ -2897,19 +2823,6 @@ int matpbr_mlp_layer_bwd_input_sgn(const float* g, int ldg, const float* wt, int
   return mlp_layer_bwd_input_impl(g, ldg, wt, ldwt, s_prev, g_prev, ldo, d_bias_prev, workspace, workspace_bytes, M, n_prev, n_red, 1, stream);
 }
 
-int matpbr_mlp_layer_bwd_input_w(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo,
-                                 float* d_bias_prev, void* workspace, size_t workspace_bytes, long M, int n_prev, int n_red, void* stream) {
-  if (!g || !w || !c_prev || !g_prev || M <= 0 || n_prev <= 0 || n_prev > 256 || n_red <= 0 || n_red > 256) return MATPBR_ERR_INVALID_ARG;
-  if (M > kSmallM) return MATPBR_ERR_UNSUPPORTED;   // large point sets use matpbr_mlp_layer_bwd_input with the transposed weight
-  if ((ldg & 3) || ldg < ((n_red + 3) & ~3) || ldw < n_prev || ldo < n_prev || !aligned16(g)) return MATPBR_ERR_INVALID_ARG;
-  if (d_bias_prev && (!workspace || workspace_bytes < matpbr_mlp_bwd_input_workspace_bytes(M))) return MATPBR_ERR_WORKSPACE;
-  NtArgs p{g, w, nullptr, c_prev, g_prev, nullptr, d_bias_prev ? (float*)workspace : nullptr, 0, n_prev, n_red, ldg, ldw, ldo};
-  const int groups = launch_small_nt<EPI_MULC, true>(p, M, (hipStream_t)stream);
-  if (d_bias_prev)
-    hipLaunchKernelGGL(mlp_colsum_reduce, dim3(n_prev), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, groups, d_bias_prev);
-  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
-}
-
 int matpbr_mlp_small_bwd_step(const float* g, int ldg, const float* w, int ldw, const float* c_prev, float* g_prev, int ldo, float* colsum_out,
                               int n_prev, const float* x, int ldx, float* d_w, int ldw_out, int K, const float* colsum_in, int colsum_stride,
                               int groups_in, float* d_bias, long M, int n_red, void* stream) {
@@ -2961,8 +2874,6 @@ int matpbr_mlp_split_weights_multi(const float* const* w, const int* ldw, const 
   hipLaunchKernelGGL(mlp_split_weights_multi_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
   return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
-
-int matpbr_mlp_split_weights_t(const float* w, int ldw, int N, int K, void* wsplit, void* stream) { return split_weights_one(w, ldw, N, K, 1, wsplit, stream); }
 
 int matpbr_mlp_layer_fwd_bx_tail(const float* x, int ldx, const void* wsplit, const float* bias, float* s_out, float* c_out, int ldo,
                                  const float* tail, int ldt, long M, int N, int K, int nprod, void* stream) {
@@ -3185,22 +3096,6 @@ int matpbr_mlp_layer_bwd_weight_bx(const float* g, int ldg, const float* x, int 
 int matpbr_mlp_layer_bwd_weight_blk(const float* g, int ldg, const void* g_tile_max, const float* x, int ldx, float* d_w, int ldw, void* workspace,
                                     size_t workspace_bytes, long M, int N, int K, MatpbrReduceJob* defer, void* stream) {
   return mlp_layer_bwd_weight_bx_impl(g, ldg, x, ldx, d_w, ldw, workspace, workspace_bytes, M, N, K, 3, (const unsigned*)g_tile_max, stream, defer);
-}
-
-int matpbr_mlp_sincos(const float* pre, long ldp, float* s_out, long lds, float* c_out, long ldc, long M, int n, void* stream) {
-  if (!pre || !s_out || !c_out || M <= 0 || n <= 0) return MATPBR_ERR_INVALID_ARG;
-  long blocks = (M * n + 255) / 256;
-  if (blocks > 256L * 32) blocks = 256L * 32;
-  hipLaunchKernelGGL(mlp_sincos_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pre, ldp, s_out, lds, c_out, ldc, M, n);
-  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
-}
-
-int matpbr_mlp_mul(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long M, int n, void* stream) {
-  if (!a || !b || !out || M <= 0 || n <= 0) return MATPBR_ERR_INVALID_ARG;
-  long blocks = (M * n + 255) / 256;
-  if (blocks > 256L * 32) blocks = 256L * 32;
-  hipLaunchKernelGGL(mlp_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, M, n);
-  return hipGetLastError() == hipSuccess ? MATPBR_OK : MATPBR_ERR_LAUNCH;
 }
 
 int matpbr_mlp_skinny_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, long M, int J, int K,

@@ -446,7 +446,7 @@ def test_rccl_path_of_the_bench_at_world_size_one():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"} <= set(brief["roofline"])
     default = json.load(open(os.path.join(root, brief["detail"])))
     b8 = default["modes"]["fused_b8"]
-    # structure and consistency only: throughput and roofline thresholds are the perf gate's business (tools/final_r05.sh), not a test's --
+    # structure and consistency only: throughput and roofline thresholds are the perf gate's business (tools/final_r06.sh), not a test's --
     # the boxes of the pool are not all alike
     assert b8["images_per_gpu"] == 8 and b8["it_per_s"] > 0 and b8["it_per_s"] == pytest.approx(8e3 / b8["ms_per_step"], rel=1e-3)
     assert 0 < default["roofline"]["frac"] < 1 and default["cold_first_process_it_per_s"] > 0

@@ -15,9 +15,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     from materialist_amd import _lib
 
     lib = _lib.load()
-    header = open(os.path.join(ROOT, "include", "matpbr.h")).read()
+    header = open(os.path.join(ROOT, "include", "matpbr.h")).read()                        # the shading hot path (b)
+    mlp = open(os.path.join(ROOT, "include", "matpbr_mlp.h")).read()                        # row f2: the coordinate MLP's entry points (included by matpbr.h)
     experimental = open(os.path.join(ROOT, "include", "matpbr_experimental.h")).read()      # measurement / A-B entry points: exported, not the boundary
-    core = set(re.findall(r"\b(matpbr_\w+)\s*\(", header))
+    hot = set(re.findall(r"\b(matpbr_\w+)\s*\(", header))
+    net = set(re.findall(r"\b(matpbr_\w+)\s*\(", mlp))
+    assert len(hot) <= 60 and not (hot & net) and '#include "matpbr_mlp.h"' in header, (len(hot), hot & net)
+    core = hot | net
     extra = set(re.findall(r"^int (matpbr_\w+)\s*\(", experimental, re.M))
     assert extra == {"matpbr_brdf_phase_stages_timed", "matpbr_mlp_set_lds_dma"} and not (core & extra)
     declared = core | extra

@@ -1,5 +1,5 @@
 """A few launches of every 256-wide layer kernel of the pos_mlp iteration (round 5: two f16 pieces, three products; the bf16 and exact-f32
-forms beside them) and of the forward chain, for rocprofv3 counter passes (tools/pmc_passes_r05.sh)."""
+forms beside them) and of the forward chain, for rocprofv3 counter passes (tools/pmc_passes_r06.sh)."""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 """hipEvent timing of the forward pass of the pos_mlp iteration alone (ArmMlpPhase.forward at 512 x 512): chain against layer by layer.
-usage: chain_time.py [reps]   (MATPBR_LIB selects the library: measurement builds of tools/chain_ab.sh)"""
+usage: chain_time.py [reps]   (MATPBR_LIB selects the library)"""
 import os
 import sys
 
