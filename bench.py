@@ -642,7 +642,7 @@ def main(argv=None):
         roof = {"bound": "hbm", "kernel": "lazy_pstep_kernel (BRDF bwd of iteration t + Adam + fwd of t+1, one launch)",
                 "kernel_detail": "lazy_pstep_kernel<kFoldXY>: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, "
                                           "SaveBest by buffer rotation, Adam) + render of iteration t+1 from per-pixel local models in the roughness with the part's "
-                                          "constant albedo folded in (72 B/pixel of model); the pixels that left their model's interval are queued and re-sampled "
+                                          "constant albedo folded in (68 B/pixel of model); the pixels that left their model's interval are queued and re-sampled "
                                           "(20 GGX samples) by the small launch behind it (resample_launch_ms)",
                 "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / (HBM_PEAK / 1e9), "avg_launch_ms": t_step,
                 "timing": "mean over iterations 301-500 of a phase of the kernel's own begin -> end, two HIP events handed to the launch on the launch "
@@ -661,7 +661,7 @@ def main(argv=None):
                 "traffic": traffic, "traffic_source": pmc.get("source_r04") if traffic else pmc.get("stale"),
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "
-                        "really moves per launch (PMC; by construction 152 B/pixel in an 'rm' part: r, m read and written 16, the folded models 72, target 12, the "
+                        "really moves per launch (PMC; by construction 148 B/pixel in an 'rm' part: r, m read and written 16, the folded models 68, target 12, the "
                         "next render 12, anchors 8, Adam moments 32), "
                         "own_traffic_frac = traffic / duration / peak: how close the launch is to the HBM limit on its OWN bytes"}
         ex = entry(px, tk["fwd_loop"], tk["bwd_loop"],

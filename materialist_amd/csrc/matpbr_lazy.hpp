@@ -60,14 +60,31 @@ __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(ui
 //       X_c(dr) = X0 + X1 dr + X2 dr^2,  Y_c(dr) = Y0 + Y1 dr - X2 dr^2  (X2 = a_c A2_c: P is an exact quadratic in r),
 //       d out_c / d m = Y_c(dr);  d out_c / d r = JX_c + m JY_c with JX = JX0 + 2 X2 dr, JY = JY0 - 2 X2 dr: the stop-gradient convention
 //       (JX0 = a dP + 0.04 dSD + dS1, JY0 = (a - 0.04) dSD - a dP); with attached sampling the models' slopes X1, Y1 take their place.
-//       18 planes = 72 B/pixel (the generic model: 96 B/pixel + the 12 B/pixel of the albedo it is combined with).
+//       17 planes = 68 B/pixel (the generic model: 96 B/pixel + the 12 B/pixel of the albedo it is combined with).
 //   kFoldGH (part 'a': roughness and metallic are constants of the part)   out_c = a_c G_c + H_c,   d out_c / d a_c = G_c,
 //       G_c = (1 - m) P_c(dr) + m SD_c(dr),   H_c = 0.04 (1 - m) SD_c(dr) + S1_c(dr):  6 planes = 24 B/pixel, never re-sampled.
 // The generic planes stay the specification (oracle/matpbr_oracle.c); the folded ones are derived from them by lazy_fold_kernel at the
 // start of a part and rewritten together with them for every re-sampled pixel.
 enum { kFoldNone = 0, kFoldXY = 1, kFoldGH = 2 };
-enum { kFxRref = 0, kFxLoHi = 1 /* byte lo | byte hi (iv_pack) | half X2_0 */, kFxX0 = 2 /* X0_c at 2 + 2c, Y0_c at 3 + 2c */, kFxS = 8 /* half2 (X1_c, Y1_c) */,
-       kFxJ = 11 /* half2 (JX0_c, JY0_c) */, kFxQ = 14 /* half2 (X2_1, X2_2) */, kFxE = 15 /* half2 (JX1_c, JY1_c) at 15 + c */, kFxPlanes = 18 };
+enum { kFxRref = 0, kFxLoHi = 1 /* byte lo | byte hi (iv_pack) | half X2_0 */, kFxXY = 2 /* five words: xy_pack */, kFxS = 7 /* half2 (X1_c, Y1_c) */,
+       kFxJ = 10 /* half2 (JA0_c, JY0_c) */, kFxQ = 13 /* half2 (X2_1, X2_2) */, kFxE = 14 /* half2 (JX1_c, JY1_c) at 14 + c */, kFxPlanes = 17 };
+// X0_c, Y0_c: 24 bits each (sign, exponent, 15 mantissa bits, rounded to nearest: 1.5e-5 of a render that is held to 1e-3), six of them in five
+// words -- the top 24 bits of word k hold X0_0, Y0_0, X0_1, Y0_1, X0_2 in turn, the low bytes of words 0..2 the three bytes of Y0_2, the low byte
+// of word 3 m_ref (see FoldXY), the low byte of word 4 is spare.  68 B/pixel with half-precision slopes of the derivative (round 5: 68 with e5m2).
+__device__ __forceinline__ float xy_round(float x) { return as_f((as_u(x) + 0x80u) & 0xffffff00u); }
+__device__ __forceinline__ void xy_pack(const float (&X0)[3], const float (&Y0)[3], uint32_t mcode, uint32_t (&w)[5]) {      // X0, Y0: xy_round'ed already
+    const uint32_t y2 = as_u(Y0[2]);
+    w[0] = as_u(X0[0]) | (y2 >> 24);
+    w[1] = as_u(Y0[0]) | ((y2 >> 16) & 0xffu);
+    w[2] = as_u(X0[1]) | ((y2 >> 8) & 0xffu);
+    w[3] = as_u(Y0[1]) | (mcode & 0xffu);
+    w[4] = as_u(X0[2]);
+}
+__device__ __forceinline__ void xy_unpack(const uint32_t (&w)[5], float (&X0)[3], float (&Y0)[3]) {
+    X0[0] = as_f(w[0] & 0xffffff00u); Y0[0] = as_f(w[1] & 0xffffff00u); X0[1] = as_f(w[2] & 0xffffff00u); Y0[1] = as_f(w[3] & 0xffffff00u);
+    X0[2] = as_f(w[4] & 0xffffff00u);
+    Y0[2] = as_f((w[0] << 24) | ((w[1] & 0xffu) << 16) | ((w[2] & 0xffu) << 8));
+}
 // JX1, JY1: the slopes of the folded detached derivative (JX = JX0 + (2 X2 + JX1) dr, JY = JY0 + (JY1 - 2 X2) dr).  Round 5 carried them in eight
 // bits (e5m2): a first-order term of 5 % of the derivative at the far end of an interval then comes with an error of up to 6e-3 of the derivative
 // (tools/lazy_grad_diag.py), above the 1e-3 the gradients are held to -- half precision since round 6.  The interval's two lengths pay for four of
@@ -91,18 +108,16 @@ __device__ __forceinline__ float lazy_e_cap(float e, float dSD, float dS1, float
     return fminf(fmaxf(e, -lim), lim);
 }
 // kFxJ carries (JA0_c, JY0_c) with JA0 = JX0 + m_ref JY0, m_ref = the pixel's metallic when its model was built, in eight bits (code / 255: the low
-// byte of the word that holds Y0 of the blue channel, whose mantissa keeps 15 bits): d out_c / d r = JA0 + (m - m_ref) JY0 + ..., so that the
+// byte of xy_pack's fourth word): d out_c / d r = JA0 + (m - m_ref) JY0 + ..., so that the
 // half-precision rounding of the two words is relative to the derivative itself, not to two terms that may cancel in JX0 + m JY0 (round 6).
-struct FoldXY { float X0, Y0, X1, Y1, JX0 /* JA0 */, JY0, X2, JX1, JY1; uint32_t Y0w; };
+struct FoldXY { float X0, Y0, X1, Y1, JX0 /* JA0 */, JY0, X2, JX1, JY1; };
 __device__ __forceinline__ uint32_t mref_code(float m) { return (uint32_t)__builtin_rintf(fminf(fmaxf(m, 0.0f), 1.0f) * 255.0f); }
 __device__ __forceinline__ float mref_of(uint32_t word) { return (float)(word & 0xffu) * (1.0f / 255.0f); }
 __device__ __forceinline__ void fold_xy(float a, float P, float SD, float S1, float dP, float A2, float gSD, float gS1, float dSD, float dS1, float eSD, float eS1,
-                                        uint32_t mcode, bool carries_code, FoldXY& f) {
+                                        uint32_t mcode, FoldXY& f) {
     const float am = a - 0.04f, naP = -(a * P), nadP = -(a * dP);
-    f.X0 = fmaf(a, P, fmaf(0.04f, SD, S1));
-    f.Y0 = fmaf(am, SD, naP);
-    f.Y0w = as_u(f.Y0);
-    if (carries_code) { f.Y0w = (f.Y0w & 0xffffff00u) | mcode; f.Y0 = as_f(f.Y0w & 0xffffff00u); }
+    f.X0 = xy_round(fmaf(a, P, fmaf(0.04f, SD, S1)));            // as the planes carry them (xy_pack): every writer renders from the stored values
+    f.Y0 = xy_round(fmaf(am, SD, naP));
     f.X1 = fmaf(a, dP, fmaf(0.04f, gSD, gS1));
     f.Y1 = fmaf(am, gSD, nadP);
     f.JY0 = fmaf(am, dSD, nadP);
@@ -765,6 +780,7 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
     if (item_ok && sub == 0) {
         const float ih = dir * (1.0f / kLzH);
         float vSD[3], vS1[3], gSD[3], gS1[3], dSD[3], dS1v[3], eSD[3], eS1[3], x2h[3] = {0.0f, 0.0f, 0.0f}, jx1[3] = {0.0f, 0.0f, 0.0f}, jy1[3] = {0.0f, 0.0f, 0.0f};
+        float fx0[3] = {0.0f, 0.0f, 0.0f}, fy0[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             vSD[c] = fv[c] - fv[3 + c];
@@ -811,10 +827,8 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             float rgb = fmaf(kd[c], Pc[c], fmaf(C0[c], vSD[c], vS1[c]));
             if (FOLD) {      // the folded planes of lazy_pstep_kernel<kFoldXY> (fold_xy_*: one definition for the fold kernel and this one)
                 FoldXY f;
-                fold_xy(rc[1 + c], Pc[c], vSD[c], vS1[c], dP[c], A2[c], gSD[c], gS1[c], dSD[c], dS1v[c], eSD[c], eS1[c], mref_code(mv), c == 2, f);
-                x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1;
-                *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c] + o1) = as_u(f.X0);
-                *(uint32_t*)((char*)qs.fplane[kFxX0 + 2 * c + 1] + o1) = f.Y0w;
+                fold_xy(rc[1 + c], Pc[c], vSD[c], vS1[c], dP[c], A2[c], gSD[c], gS1[c], dSD[c], dS1v[c], eSD[c], eS1[c], mref_code(mv), f);
+                x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1; fx0[c] = f.X0; fy0[c] = f.Y0;
                 *(uint32_t*)((char*)qs.fplane[kFxS + c] + o1) = pack_h2(f.X1, f.Y1);
                 *(uint32_t*)((char*)qs.fplane[kFxJ + c] + o1) = pack_h2(f.JX0, f.JY0);
                 rgb = fmaf(mv, f.Y0, f.X0);
@@ -823,6 +837,10 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             tot += rgb;
         }
         if (FOLD) {
+            uint32_t xw[5];
+            xy_pack(fx0, fy0, mref_code(mv), xw);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) *(uint32_t*)((char*)qs.fplane[kFxXY + k] + o1) = xw[k];
             *(uint32_t*)((char*)qs.fplane[kFxRref] + o1) = as_u(rc_r);
             // the interval as the generic plane holds it (its half-precision words): both forms list a pixel in the same iteration, up to iv_pack's rounding
             const uint32_t lh = pack_h2(iv_round(fminf(fv[18], rho)), iv_round(fminf(fv[19], rho)));

@@ -5,7 +5,7 @@
 // Adam moments: 172.6 B/pixel in an 'rm' part against the 108 B/pixel of the canonical forward + backward pair.  Two things are wrong with that:
 //   * bytes: a part moves SOME of the maps (--opt_order 'rm a', :343-357); what it leaves alone is a constant that folds into the model
 //     (kFoldXY: the albedo, 64 B/pixel of model and no albedo read; kFoldGH: roughness and metallic, 24 B/pixel of model and neither map read).
-//     'rm': r 4 + m 4 read, 8 written, model 72 (64 + the slopes of the detached derivatives: e5m2 in round 5, half precision since round 6), target 12, render 12, anchors 8, Adam moments 32 = 152 B/pixel (was 172);
+//     'rm': r 4 + m 4 read, 8 written, model 68 (X0 / Y0 in 24 bits each, half-precision slopes of the detached derivatives: round 6), target 12, render 12, anchors 8, Adam moments 32 = 148 B/pixel (was 172);
 //     'a' : a 12 read, 12 written, model 24, target 12, render 12, anchors 12, Adam moments 48 = 132 B/pixel (was 160);
 //   * shape: 4096 workgroups of 512 pixels each fold the iteration's statistics before their first load, and the few pixels that leave their
 //     model's interval are a launch of their own (a 20 us latency chain at 8 x 512^2).  Here a workgroup takes up to four consecutive 512-pixel
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
         const float r = fminf(fmaxf(ldf(q.r, o1), 0.07f), 1.0f), m = fminf(fmaxf(ldf(q.m, o1), 0.0f), 1.0f), omm = 1.0f - m;
         const float rref = as_f(ldu(q.plane[kLzRref], o1));
         const float dr = r - rref;
-        float rgb[3], x2h[3], jx1[3] = {0.0f, 0.0f, 0.0f}, jy1[3] = {0.0f, 0.0f, 0.0f};
+        float rgb[3], x2h[3], jx1[3] = {0.0f, 0.0f, 0.0f}, jy1[3] = {0.0f, 0.0f, 0.0f}, fx0[3] = {0.0f, 0.0f, 0.0f}, fy0[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float Pv = as_f(ldu(q.plane[kLzP + c], o1)), SDv = as_f(ldu(q.plane[kLzSD + c], o1)), S1v = as_f(ldu(q.plane[kLzS1 + c], o1));
@@ -69,11 +69,9 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
             if (MODE == kFoldXY) {
                 FoldXY f;
                 const uint32_t ek = ldu(q.plane[kLzEk + c], o1);
-                fold_xy(a[c], Pv, SDv, S1v, h2_lo(pk), h2_hi(pk), h2_lo(sk), h2_hi(sk), h2_lo(dk), h2_hi(dk), h2_lo(ek), h2_hi(ek), mref_code(m), c == 2, f);
+                fold_xy(a[c], Pv, SDv, S1v, h2_lo(pk), h2_hi(pk), h2_lo(sk), h2_hi(sk), h2_lo(dk), h2_hi(dk), h2_lo(ek), h2_hi(ek), mref_code(m), f);
                 const uint32_t s = pack_h2(f.X1, f.Y1);
-                x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1;
-                stu(q.fplane[kFxX0 + 2 * c], o1, as_u(f.X0));
-                stu(q.fplane[kFxX0 + 2 * c + 1], o1, f.Y0w);
+                x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1; fx0[c] = f.X0; fy0[c] = f.Y0;
                 stu(q.fplane[kFxS + c], o1, s);
                 stu(q.fplane[kFxJ + c], o1, pack_h2(f.JX0, f.JY0));
                 float X, Y;
@@ -90,6 +88,10 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
             tot += rgb[c];
         }
         if (MODE == kFoldXY) {
+            uint32_t xw[5];
+            xy_pack(fx0, fy0, mref_code(m), xw);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) stu(q.fplane[kFxXY + k], o1, xw[k]);
             stu(q.fplane[kFxRref], o1, as_u(rref));
             const uint32_t lh = ldu(q.plane[kLzLoHi], o1);
             stu(q.fplane[kFxLoHi], o1, pack_lohi_x2(h2_lo(lh), h2_hi(lh), x2h[0]));
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
 struct PxXY {
     float r, m, rref;
     uint32_t lohi;
-    float X0[3], Y0[3];
+    uint32_t xy[5];                   // X0_c, Y0_c and m_ref as the planes carry them (xy_pack)
     uint32_t s[3], j[3], e[3], q;
     F3 gt;
     float r0, m0, mr, vr, mm, vm;
@@ -132,7 +134,7 @@ __device__ __forceinline__ void pstep_load_fixed(PxXY& x, const LazyStepArgs& qs
     const unsigned o1 = i * 4u, o3 = i * 12u;
     x.gt = ld3(q.gt_srgb, o3);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { x.X0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c], o1)); x.Y0[c] = as_f(ldu(qs.fplane[kFxX0 + 2 * c + 1], o1)); }
+    for (int k = 0; k < 5; ++k) x.xy[k] = ldu(qs.fplane[kFxXY + k], o1);
     x.rref = 0.0f; x.lohi = 0u; x.q = 0u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) x.s[c] = x.j[c] = x.e[c] = 0u;
@@ -198,9 +200,10 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
     const float r = fminf(fmaxf(x.r, 0.07f), 1.0f), m = fminf(fmaxf(x.m, 0.0f), 1.0f);
     const float dr = r - x.rref;
     const float gt[3] = {x.gt.x, x.gt.y, x.gt.z};
-    // the low byte of the blue channel's Y0 word is m_ref (kFxJ: JA0 = JX0 + m_ref JY0); with the models' own slopes as the derivative there is none
-    const float Y0[3] = {x.Y0[0], x.Y0[1], as_f(as_u(x.Y0[2]) & 0xffffff00u)};
-    const float dmr = m - (f.att ? 0.0f : mref_of(as_u(x.Y0[2])));
+    // (m_ref rides in xy_pack's fourth word: kFxJ holds JA0 = JX0 + m_ref JY0; with the models' own slopes as the derivative there is none)
+    float X0[3], Y0[3];
+    xy_unpack(x.xy, X0, Y0);
+    const float dmr = m - (f.att ? 0.0f : mref_of(x.xy[3]));
     float drr = 0.0f, dm = 0.0f, xs_keep[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -208,7 +211,7 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
         // before, the walk at dr = 0, or lazy_fold_kernel -- on the same operands: the same bits)
         const float x2 = xy_x2(x.lohi, x.q, c);
         float X, Y;
-        xy_eval(x.X0[c], Y0[c], x.s[c], x2, dr, X, Y);
+        xy_eval(X0[c], Y0[c], x.s[c], x2, dr, X, Y);
         const float go = loss_go(fmaf(m, Y, X), gt[c], ratio, sr, q.inv_n3, xs_keep[c]);
         // d out / d r to first order in dr: the curvature of the diffuse lobe (2 X2, exact) and the slopes of the detached specular derivatives
         const float jx1 = h2_lo(x.e[c]), jy1 = h2_hi(x.e[c]);
@@ -249,7 +252,7 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float X, Y;
-            xy_eval(x.X0[c], Y0[c], x.s[c], xy_x2(x.lohi, x.q, c), dr1, X, Y);
+            xy_eval(X0[c], Y0[c], x.s[c], xy_x2(x.lohi, x.q, c), dr1, X, Y);
             rgb[c] = fmaf(m1, Y, X);
             tot += rgb[c];
         }
