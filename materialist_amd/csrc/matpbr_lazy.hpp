@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(ui
 enum { kFoldNone = 0, kFoldXY = 1, kFoldGH = 2 };
 enum { kFxRref = 0, kFxLoHi = 1 /* byte lo | byte hi (iv_pack) | half X2_0 */, kFxXY = 2 /* five words: xy_pack */, kFxS = 7 /* half2 (X1_c, Y1_c) */,
        kFxJ = 10 /* half2 (JA0_c, JY0_c) */, kFxQ = 13 /* half2 (X2_1, X2_2) */, kFxE = 14 /* half2 (JX1_c, JY1_c) at 14 + c */, kFxPlanes = 17 };
-// X0_c, Y0_c: 24 bits each (sign, exponent, 15 mantissa bits, rounded to nearest: 1.5e-5 of a render that is held to 1e-3), six of them in five
+// X0_c, Y0_c: 24 bits each (sign, exponent, 15 mantissa bits, rounded to nearest: 2^-16 = 1.5e-5 of a render that is held to 1e-3), six of them in five
 // words -- the top 24 bits of word k hold X0_0, Y0_0, X0_1, Y0_1, X0_2 in turn, the low bytes of words 0..2 the three bytes of Y0_2, the low byte
 // of word 3 m_ref (see FoldXY), the low byte of word 4 is spare.  68 B/pixel with half-precision slopes of the derivative (round 5: 68 with e5m2).
 __device__ __forceinline__ float xy_round(float x) { return as_f((as_u(x) + 0x80u) & 0xffffff00u); }

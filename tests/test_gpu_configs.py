@@ -380,7 +380,7 @@ def test_config1_as_written_indoor1_pos_mlp_rm_a_opt_env_from_2(golden_dir, tmp_
     # the crop: 423 rows kept, columns 2..424 of 427 (centre), resized with align_corners=True -- the corners of the target are the crop's corners
     gt = read_exr(os.path.join(out, "gt_image.exr"))
     assert gt.shape == (512, 512, 3)
-    srgb = lambda u: np.where(u <= 0.04045, u / 12.92, ((u + 0.055) / 1.055) ** 2.4)
+    srgb = lambda u: u ** 2.2                                          # the reference's srgb_to_linear (myutils/misc.py:163-166)
     crop = rgba[:, 2:425, :3].astype(np.float64) / 255.0
     for (i, j), (ci, cj) in (((0, 0), (0, 0)), ((511, 511), (422, 422)), ((0, 511), (0, 422))):
         assert np.allclose(gt[i, j], srgb(crop[ci, cj]), atol=2e-3), (i, j, gt[i, j], srgb(crop[ci, cj]))

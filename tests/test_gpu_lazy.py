@@ -377,7 +377,7 @@ def test_folded_persistent_step_is_the_generic_step(part):
         if it in (0, 1, 10, iters - 1):      # the render of the current parameters (what the next iteration judges); Adam normalises the
             # gradient, so where it is nearly zero rounding decides a step's sign and single pixels part ways over 150 steps
             worst = (fo.pred - ge.pred).abs() / ge.pred.abs().mean()
-            assert float(worst.max()) < {0: 4e-5, 1: 2e-4, 10: 1e-3}.get(it, 3e-2) and float(worst.mean()) < 2e-4, (it, float(worst.max()), float(worst.mean()))      # (it 0: the folded X0 / Y0 keep 15 mantissa bits, 2^-17 of terms that partly cancel)
+            assert float(worst.max()) < {0: 4e-5, 1: 2e-4, 10: 1e-3}.get(it, 3e-2) and float(worst.mean()) < 2e-4, (it, float(worst.max()), float(worst.mean()))      # (it 0: the folded X0 / Y0 keep 15 mantissa bits, 2^-16 of terms that partly cancel)
     h_f, h_g = fo.history()[:, 0].cpu().numpy(), ge.history()[:, 0].cpu().numpy()
     assert np.abs(h_f - h_g).max() <= 5e-4 * h_g.max()
     assert abs(n_f - n_g) <= 0.01 * n_g + 2 and (n_g > 0) == ("r" in part)
@@ -515,7 +515,7 @@ def test_pixels_without_geometry_run_in_the_fused_loops():
             fused.step()
             assert float(fused.stats[0, ops.STAT_MSE]) == pytest.approx(float(mse_ref), rel=5e-4), (part, it)
             assert float(fused.stats[0, ops.STAT_LOSS]) == pytest.approx(float(ref.last["loss"]), rel=5e-4), (part, it)
-            assert torch.allclose(fused.pred[m], bg[m], rtol=1e-5, atol=1e-7)      # (the folded models carry X0 = the background in 24 bits: 2^-17)
+            assert torch.allclose(fused.pred[m], bg[m], rtol=2e-5, atol=1e-7)      # (the folded models carry X0 = the background in 24 bits: 15 mantissa bits, rounded to nearest: 2^-16)
         for k, j in (("albedo", 0), ("roughness", 1), ("metallic", 2)):
             assert torch.equal(fused.p[k][m], init[j][m]), (part, k)                    # no gradient, no drift behind the mask
             if k in ref.params:
