@@ -433,3 +433,154 @@ class ArmMlpPhase:
 
     def history(self) -> torch.Tensor:
         return self.hist[: self.t]
+
+
+class MlpEngine:
+    """The coordinate MLP alone, launch by launch on the C ABI, for networks `ArmMlpPhase` does not take whole: any first-layer width up to 24
+    inputs and up to 8 raw outputs (the eight-output 'armn' network of `'n'` parts: 18 inputs, hidden layers 238 / 256 / 238 / 256,
+    mymodels/mlps.py:236-244, inverse_img_w_mi.py:167-172).  `forward_raw()` -> the last linear layer's output [M, 8]; `backward_raw(d_x)` ->
+    every parameter's gradient into the flat gradient buffer; `adamw_step(stats)` -> AdamW on the flat buffer with SaveBest's weight snapshot.
+    The head (tanh, residual, clamps, `normalize`) and its backward are the caller's: a few element-wise passes over [M, 8].
+
+    First layer on the thin-K f32 MFMA kernel (packed sines), 256-wide layers forward on two f16 pieces, backward products on two f16 pieces
+    under one exponent per 128-row tile, folds deferred to one launch (the kernels of `ArmMlpPhase`'s layer-by-layer path); the first layer's
+    weight gradient on the general f32 kernel (its fused form takes at most 16 inputs)."""
+
+    @staticmethod
+    def why_not(net: torch.nn.Module, M: int, device) -> Optional[str]:
+        if torch.device(device).type != "cuda":
+            return "not on a GPU"
+        if M % 128 or M < _PosMlpHipFn.MIN_ROWS:
+            return f"{M} points: the layer kernels take whole 128-row tiles of at least {_PosMlpHipFn.MIN_ROWS} rows"
+        L = net.n_layers
+        d0 = getattr(net, "lin0").linear.weight.shape[1]
+        if d0 > 24 or L < 3 or L > 6:
+            return "more than 24 inputs, or fewer than two / more than five sine layers"
+        for l in range(L - 1):
+            n = getattr(net, f"lin{l}").linear.weight.shape[0]
+            if (n + d0 if (l + 1) in net.skip else n) != 256:
+                return "hidden layers that are not 256 wide"
+        wo = getattr(net, f"lin{L - 1}").weight
+        if wo.shape[1] != 256 or wo.shape[0] not in (3, 5, 8):
+            return "an output layer that is not 256 -> 3 / 5 / 8"
+        return None
+
+    def __init__(self, net: torch.nn.Module, points_in: torch.Tensor, lr: float = 3e-4, weight_decay: float = 0.01):
+        import ctypes as _ct
+
+        dev = points_in.device
+        why = MlpEngine.why_not(net, points_in.shape[0], dev)
+        if why is not None:
+            raise NotImplementedError("MlpEngine: " + why)
+        self.net, self.dev = net, dev
+        M = self.M = points_in.shape[0]
+        st = flat_state(net, dev)
+        self.flat, self.views, self._spans = st["flat"], st["views"], st["spans"]
+        self.L = L = net.n_layers
+        self.gflat = torch.zeros_like(self.flat)
+        self.adam_m, self.adam_v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.hyper = torch.tensor([float(lr), 0.0], dtype=torch.float32, device=dev)
+        self.weight_decay, self._lr = float(weight_decay), float(lr)
+        self.gviews, off = [], 0
+        for wp, bp in self.views:
+            gw = self.gflat[off:off + wp.numel()].view_as(wp)
+            off += wp.numel()
+            gb = self.gflat[off:off + _al4(bp.numel())]
+            off += _al4(bp.numel())
+            self.gviews.append((gw, gb))
+        self._best_flat = self.flat.clone()
+        E = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        x0 = net._points(points_in.detach().to(dev, torch.float32))
+        self.d0 = d0 = x0.shape[1]
+        self.x0p = E(M, 8 if d0 <= 8 else (16 if d0 <= 16 else 24))
+        self.x0p[:, :d0] = x0
+        self.ns = [self.views[l][0].shape[0] for l in range(L - 1)]
+        self.n_out = self.views[-1][0].shape[0]
+        self.bufs = [E(M, 256) for _ in range(L - 1)]
+        for l, n in enumerate(self.ns):
+            if n != 256:
+                self.bufs[l][:, n:] = x0                        # cat(x, x0) of the skip layers: written once
+        self.gbufs = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.xout = E(M, 8)
+        nbytes = int(_lib.load().matpbr_mlp_wsplit_bytes(256))
+        self.wsplit_f = {l: torch.empty(nbytes, dtype=torch.uint8, device=dev) for l in range(1, L - 1)}
+        self.wsplit_b = {l: torch.empty(nbytes, dtype=torch.uint8, device=dev) for l in range(1, L - 1)}
+        jobs = []
+        for l in range(1, L - 1):
+            wp, _ = self.views[l]
+            jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l], 256, ops.WSPLIT_F16X2, self.wsplit_f[l].data_ptr()))                 # W_l [n_l, 256]
+            jobs.append((wp.data_ptr(), wp.stride(0), self.ns[l - 1], self.ns[l], 1 | ops.WSPLIT_F16X2, self.wsplit_b[l].data_ptr()))   # (W_l[:, :n_{l-1}])^T
+        nj = len(jobs)
+        self._split_args = ((_ct.c_void_p * nj)(*[j[0] for j in jobs]), (_ct.c_int * nj)(*[j[1] for j in jobs]), (_ct.c_int * nj)(*[j[2] for j in jobs]),
+                            (_ct.c_int * nj)(*[j[3] for j in jobs]), (_ct.c_int * nj)(*[j[4] for j in jobs]), (_ct.c_void_p * nj)(*[j[5] for j in jobs]), nj)
+        self.tmax = torch.zeros(L - 1, M // 128, dtype=torch.int32, device=dev)
+        self._jobs = (_lib.ReduceJob * 16)()
+
+    def set_lr(self, lr: float) -> None:
+        self._lr = float(lr)
+        self.hyper[0:1].fill_(self._lr)
+
+    def forward_raw(self) -> torch.Tensor:
+        o = ops
+        with torch.cuda.device(self.dev):
+            _lib.check(_lib.load().matpbr_mlp_split_weights_multi(*self._split_args, o._stream(self.flat)), "matpbr_mlp_split_weights_multi")
+        wp, bp = self.views[0]
+        o.mlp_layer_fwd(self.x0p, wp, bp, self.bufs[0], None, self.d0, packed=True)
+        for l in range(1, self.L - 1):
+            _, bp = self.views[l]
+            o.mlp_layer_fwd_bx(self.bufs[l - 1], self.wsplit_f[l], bp, self.bufs[l], None, self.ns[l], 256, 3, tail=self.x0p if self.ns[l] != 256 else None)
+        wo, bo = self.views[-1]
+        o.mlp_skinny_fwd(self.bufs[-1], wo, bo, self.xout, 256)
+        return self.xout
+
+    def backward_raw(self, d_x: torch.Tensor) -> None:
+        """d loss / d (the raw outputs) [M, 8] (columns beyond the network's outputs zero) -> the flat gradient buffer."""
+        import ctypes as _ct
+
+        o, jobs = ops, self._jobs
+        slot = lambda k: (_ct.cast(_ct.byref(jobs, k * _ct.sizeof(_lib.ReduceJob)), _ct.c_void_p), f"_e{k}")
+        nj = 0
+        self.tmax.zero_()
+        wo, _ = self.views[-1]
+        gw, gb = self.gviews[-1]
+        _, gb_prev = self.gviews[self.L - 2]
+        g = self.gbufs[0]
+        o.mlp_out_layer_bwd_tmax(d_x, self.bufs[-1], wo, g, self.tmax[self.L - 2], gw, gb, gb_prev, self.n_out, self.ns[-1], defer=slot(nj))
+        nj += 1
+        n_red = self.ns[-1]
+        for l in range(self.L - 2, 0, -1):                       # g = dL/d pre of layer l: its weight gradient, then dL/d pre of layer l - 1
+            gw, _ = self.gviews[l]
+            o.mlp_layer_bwd_weight_blk(g, self.tmax[l], self.bufs[l - 1], n_red, 256, out=gw, defer=slot(nj))
+            nj += 1
+            n_prev = self.ns[l - 1]
+            _, gb = self.gviews[l - 1]
+            g_prev = self.gbufs[1] if g is self.gbufs[0] else self.gbufs[0]
+            o.mlp_layer_bwd_input_blk(g, self.tmax[l], self.wsplit_b[l], self.bufs[l - 1], g_prev, n_prev, n_red, gb, self.tmax[l - 1], defer=slot(nj))
+            nj += 1
+            g, n_red = g_prev, n_prev
+        gw0, _ = self.gviews[0]
+        gw0[:, :self.d0].copy_(o.mlp_layer_bwd_weight(g, self.x0p, n_red, self.d0))      # the first layer's weight gradient (general f32 kernel)
+        o.mlp_reduce_jobs(jobs, nj, self.flat)
+
+    def adamw_step(self, stats: torch.Tensor) -> None:
+        """AdamW on the flat buffer; `stats` (one statistics row): SaveBest's weight snapshot in the same pass when the row says "improved", no
+        update for an image whose EarlyStopping has fired, Adam's step count = the row's iteration counter (include/matpbr_mlp.h)."""
+        o = ops
+        with torch.cuda.device(self.dev):
+            _lib.check(_lib.load().matpbr_adamw_step_snapshot_dev(o._ptr(self.flat), o._ptr(self.gflat), o._ptr(self.adam_m), o._ptr(self.adam_v),
+                                                                  self.flat.numel(), o._ptr(self.hyper), 0.9, 0.999, 1e-8, self.weight_decay,
+                                                                  o._ptr(self._best_flat), o._ptr(stats), o._stream(self.flat)),
+                       "matpbr_adamw_step_snapshot_dev")
+
+    @property
+    def best_weights(self) -> Dict[str, torch.Tensor]:
+        out, off, order = {}, 0, []
+        for wp, bp in self.views:
+            order += [(off, wp), (off + wp.numel(), bp)]
+            off += wp.numel() + _al4(bp.numel())
+        by_ptr = {t.data_ptr(): o_ for o_, t in order}
+        for name, (view, k) in self._spans.items():
+            o_ = by_ptr[view.data_ptr()]
+            best = self._best_flat[o_:o_ + view.numel()].view_as(view)
+            out[name] = (best[:, :k] if k is not None else best).clone()
+        return out

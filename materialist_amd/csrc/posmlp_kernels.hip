@@ -2300,7 +2300,7 @@ int launch_nt(NtArgs p, long M, hipStream_t stream) {
 // all 8 column tiles sit in registers, A comes straight from the rows (64 bytes each), the tile goes through the wave's own LDS
 // slice for 16-byte stores, no barrier anywhere; many independent waves per CU keep the stores flowing.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int EPI, int KP>   // KP: K padded to 8 or 16 (the row stride of A and B covers it; padding columns hold zeros)
+template <int EPI, int KP>   // KP: K padded to 8, 16 or 24 (the row stride of A and B covers it; padding columns hold zeros)
 __global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int tiles) {
   __shared__ __align__(16) float scr_all[4][32 * kLd];
   __shared__ __align__(16) float sWt[256 * KP];                // the weights [n][k], zero beyond N / K: 16 KB, read per column tile
@@ -2405,12 +2405,14 @@ __global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int til
   }
 }
 constexpr int kThinBlocks = 1024;                            // workgroups of the thin-K kernels (4 per CU)
+inline int thin_pad(int K) { return K <= 8 ? 8 : (K <= 16 ? 16 : 24); }      // the floats of a row of x the thin-K kernel reads (the weights are read element by element: ldw >= K)
 template <int EPI>
 int launch_thin_k(const NtArgs& p, hipStream_t stream) {     // returns the number of workgroups (rows of the colsum partials)
   const int tiles = (p.M + 31) / 32;
   const int grid = (tiles + 3) / 4 < kThinBlocks ? (tiles + 3) / 4 : kThinBlocks;
   if (p.K <= 8) hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 8>), dim3(grid), dim3(256), 0, stream, p, tiles);
-  else hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 16>), dim3(grid), dim3(256), 0, stream, p, tiles);
+  else if (p.K <= 16) hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 16>), dim3(grid), dim3(256), 0, stream, p, tiles);
+  else hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 24>), dim3(grid), dim3(256), 0, stream, p, tiles);      // the 18 inputs of the 'armn' network (round 6)
   return grid;
 }
 
@@ -2745,7 +2747,7 @@ int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, 
   if (tail && (ldo < 256 || ldt < 256 - N || !c_out)) return MATPBR_ERR_INVALID_ARG;   // the tail fills columns N..255 of a 256-wide sine layer
   NtArgs p{x, w, bias, nullptr, s_out, c_out, nullptr, 0, N, K, ldx, ldw, ldo};
   p.tail = tail; p.ldt = ldt;
-  const bool thin = M > kSmallM && K <= 16 && ldx >= (K <= 8 ? 8 : 16) && ldw >= (K <= 8 ? 8 : 16) && ldo >= 256 && !(ldo & 3) && aligned16(s_out) &&
+  const bool thin = M > kSmallM && K <= 24 && ldx >= thin_pad(K) && ldw >= ((K + 3) & ~3) && ldo >= 256 && !(ldo & 3) && aligned16(s_out) &&
                     (!c_out || aligned16(c_out));
   if (M <= kSmallM) {
     if (c_out) launch_small_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
@@ -2766,9 +2768,9 @@ int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, 
 
 int matpbr_mlp_layer_fwd_sgn(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, int ldo, const float* tail, int ldt,
                              long M, int N, int K, void* stream) {
-  if (!x || !w || !bias || !s_out || M <= 0 || M > 0x7fffff00L || N <= 0 || N > 256 || K <= 0 || K > 16) return MATPBR_ERR_INVALID_ARG;
-  // the thin-K kernel only (the first layer of the coordinate MLP at image size): every other shape keeps its cosines
-  if (M <= kSmallM || (ldx & 3) || (ldw & 3) || ldx < (K <= 8 ? 8 : 16) || ldw < (K <= 8 ? 8 : 16) || ldo < 256 || (ldo & 3) || !aligned16(x) || !aligned16(w) ||
+  if (!x || !w || !bias || !s_out || M <= 0 || M > 0x7fffff00L || N <= 0 || N > 256 || K <= 0 || K > 24) return MATPBR_ERR_INVALID_ARG;
+  // the thin-K kernel only (the first layer of the coordinate MLP at image size: 15 inputs, 18 for 'armn'): every other shape keeps its cosines
+  if (M <= kSmallM || (ldx & 3) || (ldw & 3) || ldx < thin_pad(K) || ldw < ((K + 3) & ~3) || ldo < 256 || (ldo & 3) || !aligned16(x) || !aligned16(w) ||
       !aligned16(s_out))
     return MATPBR_ERR_UNSUPPORTED;
   if (tail && ldt < 256 - N) return MATPBR_ERR_INVALID_ARG;

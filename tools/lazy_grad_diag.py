@@ -10,7 +10,7 @@ from materialist_amd import loop, ops, render, synthetic
 dev = torch.device("cuda:0")
 H = W = 512
 spp = 64
-sc = synthetic.make_scene(0, H, W)
+sc = synthetic.make_scene(int(os.environ.get('DIAG_IMAGE', '0')), H, W)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
 scene = render.load_estimated_mesh(t(sc.depth), use_mesh_normal=True)
 scene._set("emitter.data", t(sc.light))
@@ -18,7 +18,7 @@ with torch.no_grad():
     gt = render.render_w_brdf(scene, t(sc.albedo), t(sc.roughness), t(sc.metallic), None, spp)
 init = [t(x) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
 checks = [int(x) for x in (sys.argv[1:] or [50, 200, 400, 800, 1200])]
-for fold in (True, False):
+for fold in ((True,) if os.environ.get('DIAG_FOLD_ONLY') else (True, False)):
     ph = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp, lazy=True, keep_grads=True, fold=fold)
     exact, jac = torch.empty_like(gt), ops.plane9(gt)
     g_ref = {k: torch.empty_like(v) for k, v in ph.g.items()}
