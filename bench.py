@@ -336,6 +336,22 @@ def main(argv=None):
                     ph.current_maps = lambda: (lambda m: {"albedo": m["albedo"].detach().clamp(0, 1), "roughness": m["roughness"].detach().clamp(0.07, 1),
                                                           "metallic": m["metallic"].detach().clamp(0, 1)})(ph.maps_from_net()[0])
                 return ph
+            if mode == "pos_mlp_n":
+                # --model_name pos_mlp with 'n' in --opt_order: the eight-output 'armn' network (inverse_img_w_mi.py:167-172,493-506) predicts the normal
+                # map too; loop.PosMlpNormalPhase with armhead.MlpEngine (launch by launch on the C ABI since round 6)
+                from materialist_amd import posmlp
+
+                s_n = render.load_estimated_mesh(self.depth, use_mesh_normal=False)
+                s_n._set("emitter.data", self.light)
+                geo = self.scene.shading_normal()
+                init = self.init
+                start_armn = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1), geo.reshape(-1, 3)], -1).clamp(-1, 1).contiguous()
+                ph = loop.PosMlpNormalPhase(s_n, self.gt_image, posmlp.brdf_net("armn").to(dev), start_armn,
+                                            {"albedo": init[0], "roughness": init[1], "metallic": init[2], "normal": geo}, optimize_part="armn", spp=args.spp,
+                                            saver=loop.DeviceSaveBest())
+                ph.bench_step = ph._step_device                 # (ph.step() returns the MSE as a host float: the reference's per-epoch poll; not timed here)
+                ph.current_maps = lambda: {k: v for k, v in zip(("albedo", "roughness", "metallic"), init)}
+                return ph
             if mode == "fused_n":
                 # a part of --opt_order that moves the normal map ('n' under use_mesh_normal False): loop.NormalBrdfPhase
                 s_n = render.load_estimated_mesh(self.depth, use_mesh_normal=False)
@@ -400,7 +416,7 @@ def main(argv=None):
     modes = {mode: {"it_per_s": value, "ms_per_step": elapsed / args.steps * 1e3, "images_per_gpu": B}}
     wl8 = None
     if not args.no_extras and mode != "torch":
-        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("torch", 300), ("pos_mlp", 100), ("env", 500), ("env_texels", 1000), ("fused_n", 300)):
+        for extra, steps in (("fused", 2000), ("fused_a", 2000), ("fused_exact", 500), ("torch", 300), ("pos_mlp", 100), ("env", 500), ("env_texels", 1000), ("fused_n", 300), ("pos_mlp_n", 100)):
             if extra == mode or (not extra.startswith("fused") and B > 1):
                 continue
             ph_x = wl.phase(extra)
@@ -411,6 +427,15 @@ def main(argv=None):
             else:
                 e_el, _ = proto.timed(stepper(ph_x), 10, steps)
             modes[extra] = {"it_per_s": steps * B * world / e_el, "ms_per_step": e_el / steps * 1e3, "images_per_gpu": B}
+        if "pos_mlp_n" in modes:
+            # ... and as rounds 4-5 ran it: the network under autograd (posmlp._PosMlpHipFn: three bf16 pieces, layer by layer) with torch.optim.AdamW
+            keep_e = loop.PosMlpNormalPhase.ENGINE
+            loop.PosMlpNormalPhase.ENGINE = False
+            try:
+                e_el, _ = proto.timed(stepper(wl.phase("pos_mlp_n")), 5, 50)
+            finally:
+                loop.PosMlpNormalPhase.ENGINE = keep_e
+            modes["pos_mlp_n_autograd"] = {"it_per_s": 50 * B * world / e_el, "ms_per_step": e_el / 50 * 1e3, "images_per_gpu": B}
         if mode == "pos_mlp" and _posmlp._PosMlpHipFn.PRODUCTS:
             # the same loop with the 256-wide layers on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), for the record
             keep = _posmlp._PosMlpHipFn.PRODUCTS
@@ -507,6 +532,11 @@ def main(argv=None):
                   "fused_n": "hot loop B, --model_name none, a part that moves the normal map ('n', use_mesh_normal False; loop.NormalBrdfPhase): render, loss "
                              "statistics with SaveBest / EarlyStopping on the device, d loss / d pred, the backward render into materials and normals "
                              "(both lobes' directions walked per pixel), regularisers + normalize backward + Adam -- nine launches of libmatpbr.so, no autograd",
+                  "pos_mlp_n": "hot loop B, --model_name pos_mlp with 'n' in --opt_order (part 'armn'): the eight-output network launch by launch on the C ABI "
+                               "(armhead.MlpEngine: thin-K first layer, 256-wide layers on two f16 pieces forward and backward, 8-column output layer, AdamW on "
+                               "the flat buffer), render under the predicted normal map, loss statistics, material and normal gradients (loop.PosMlpNormalPhase)",
+                  "pos_mlp_n_autograd": "pos_mlp_n as rounds 4-5 ran it (PosMlpNormalPhase.ENGINE False): the network under autograd on the bf16 x 3 layer kernels, "
+                                        "torch.optim.AdamW",
                   "env_texels": "hot loop A of --model_name none (envhead.EnvTexelPhase): one pass over the radiance transfer, then ONE workgroup that folds its "
                                 "partial sums, commits SaveBest / EarlyStopping, snapshots the best envmap, back-propagates through the SH projection and the "
                                 "softplus and applies Adam (matpbr_env_texel_phase_step), then the next envmap's projection: three kernels from a hipGraph, seven in round 3",

@@ -86,7 +86,7 @@ class ArmMlpPhase:
         if not gt_image.is_cuda:
             return "the image is not on a GPU"
         if not scene.use_mesh_normal or "n" in optimize_part:
-            return "predicted normals / a part that moves the normal map (the eight-output 'armn' network: its first layer reads 18 inputs, the fused layer kernels 16)"
+            return "predicted normals / a part that moves the normal map (the eight-output 'armn' network and the render under a normal map: loop.PosMlpNormalPhase with armhead.MlpEngine)"
         if getattr(net, "output_type", None) != "arm" or not _PosMlpHipFn.PRODUCTS:
             return "not the five-output 'arm' network on the split-operand kernels"
         M = gt_image.shape[0] * gt_image.shape[1]
@@ -436,15 +436,15 @@ class ArmMlpPhase:
 
 
 class MlpEngine:
-    """The coordinate MLP alone, launch by launch on the C ABI, for networks `ArmMlpPhase` does not take whole: any first-layer width up to 24
-    inputs and up to 8 raw outputs (the eight-output 'armn' network of `'n'` parts: 18 inputs, hidden layers 238 / 256 / 238 / 256,
+    """The coordinate MLP alone, launch by launch on the C ABI, for networks `ArmMlpPhase` does not take whole: any first-layer width up to 16
+    inputs and up to 8 raw outputs (the eight-output 'armn' network of `'n'` parts: 10 inputs -- raw pixel coordinates + 8 channels --, hidden layers 246 / 256 / 246 / 256,
     mymodels/mlps.py:236-244, inverse_img_w_mi.py:167-172).  `forward_raw()` -> the last linear layer's output [M, 8]; `backward_raw(d_x)` ->
     every parameter's gradient into the flat gradient buffer; `adamw_step(stats)` -> AdamW on the flat buffer with SaveBest's weight snapshot.
     The head (tanh, residual, clamps, `normalize`) and its backward are the caller's: a few element-wise passes over [M, 8].
 
     First layer on the thin-K f32 MFMA kernel (packed sines), 256-wide layers forward on two f16 pieces, backward products on two f16 pieces
     under one exponent per 128-row tile, folds deferred to one launch (the kernels of `ArmMlpPhase`'s layer-by-layer path); the first layer's
-    weight gradient on the general f32 kernel (its fused form takes at most 16 inputs)."""
+    weight gradient on the general f32 kernel."""
 
     @staticmethod
     def why_not(net: torch.nn.Module, M: int, device) -> Optional[str]:
@@ -454,8 +454,8 @@ class MlpEngine:
             return f"{M} points: the layer kernels take whole 128-row tiles of at least {_PosMlpHipFn.MIN_ROWS} rows"
         L = net.n_layers
         d0 = getattr(net, "lin0").linear.weight.shape[1]
-        if d0 > 24 or L < 3 or L > 6:
-            return "more than 24 inputs, or fewer than two / more than five sine layers"
+        if d0 > 16 or L < 3 or L > 6:
+            return "more than 16 inputs, or fewer than two / more than five sine layers"
         for l in range(L - 1):
             n = getattr(net, f"lin{l}").linear.weight.shape[0]
             if (n + d0 if (l + 1) in net.skip else n) != 256:
@@ -492,7 +492,7 @@ class MlpEngine:
         E = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
         x0 = net._points(points_in.detach().to(dev, torch.float32))
         self.d0 = d0 = x0.shape[1]
-        self.x0p = E(M, 8 if d0 <= 8 else (16 if d0 <= 16 else 24))
+        self.x0p = E(M, 8 if d0 <= 8 else 16)
         self.x0p[:, :d0] = x0
         self.ns = [self.views[l][0].shape[0] for l in range(L - 1)]
         self.n_out = self.views[-1][0].shape[0]

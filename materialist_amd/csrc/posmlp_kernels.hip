@@ -2300,7 +2300,7 @@ int launch_nt(NtArgs p, long M, hipStream_t stream) {
 // all 8 column tiles sit in registers, A comes straight from the rows (64 bytes each), the tile goes through the wave's own LDS
 // slice for 16-byte stores, no barrier anywhere; many independent waves per CU keep the stores flowing.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int EPI, int KP>   // KP: K padded to 8, 16 or 24 (the row stride of A and B covers it; padding columns hold zeros)
+template <int EPI, int KP>   // KP: K padded to 8 or 16 (the row stride of A and B covers it; padding columns hold zeros)
 __global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int tiles) {
   __shared__ __align__(16) float scr_all[4][32 * kLd];
   __shared__ __align__(16) float sWt[256 * KP];                // the weights [n][k], zero beyond N / K: 16 KB, read per column tile
@@ -2405,14 +2405,13 @@ __global__ __launch_bounds__(256) void mlp_thin_k_kernel(const NtArgs p, int til
   }
 }
 constexpr int kThinBlocks = 1024;                            // workgroups of the thin-K kernels (4 per CU)
-inline int thin_pad(int K) { return K <= 8 ? 8 : (K <= 16 ? 16 : 24); }      // the floats of a row of x the thin-K kernel reads (the weights are read element by element: ldw >= K)
+inline int thin_pad(int K) { return K <= 8 ? 8 : 16; }      // the floats of a row of x the thin-K kernel reads (the weights are read element by element: ldw >= K)
 template <int EPI>
 int launch_thin_k(const NtArgs& p, hipStream_t stream) {     // returns the number of workgroups (rows of the colsum partials)
   const int tiles = (p.M + 31) / 32;
   const int grid = (tiles + 3) / 4 < kThinBlocks ? (tiles + 3) / 4 : kThinBlocks;
   if (p.K <= 8) hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 8>), dim3(grid), dim3(256), 0, stream, p, tiles);
-  else if (p.K <= 16) hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 16>), dim3(grid), dim3(256), 0, stream, p, tiles);
-  else hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 24>), dim3(grid), dim3(256), 0, stream, p, tiles);      // the 18 inputs of the 'armn' network (round 6)
+  else hipLaunchKernelGGL((mlp_thin_k_kernel<EPI, 16>), dim3(grid), dim3(256), 0, stream, p, tiles);
   return grid;
 }
 
@@ -2526,7 +2525,7 @@ struct SkinnyDgrad {          // the input-gradient half of mlp_skinny_tn_kernel
   float* gsum_part;           // [slabs][256]
   unsigned* tmax;             // nullable [M / 128]: atomic max of |G| per 128-row tile (zeroed by the caller): the block exponents of the f16 products
 };
-template <int J, bool DGRAD = false>
+template <int J, bool DGRAD = false, int JV = kOutJ>      // JV (DGRAD): the valid columns of S -- 5 ('arm'), 8 ('armn': round 6)
 __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restrict__ S, int lds, const float* __restrict__ B, int ldb,
                                                             float* __restrict__ partial, float* __restrict__ bpart, long M, long rows_per_slab,
                                                             const SkinnyDgrad dg) {
@@ -2542,10 +2541,10 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
   // DGRAD (the output layer of the 'arm' network, J = 8, 5 valid): the same pass over the wide matrix B = sines of the last sine layer also
   // forms that layer's pre-activation gradient G[m][n] = (sum_j S[m][j] W[j][n]) cos(pre[m][n]) and its column sums -- a K = 5 product
   // is five FMAs per element, and the separate input-gradient pass read the 268 MB of sines a second time
-  float4 wv[DGRAD ? kOutJ : 1], gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 wv[DGRAD ? JV : 1], gsum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (DGRAD) {
 #pragma unroll
-    for (int j = 0; j < kOutJ; ++j) wv[j] = j < dg.Jv ? *reinterpret_cast<const float4*>(dg.W + (size_t)j * dg.ldw + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < JV; ++j) wv[j] = j < dg.Jv ? *reinterpret_cast<const float4*>(dg.W + (size_t)j * dg.ldw + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   constexpr int U = 4;
   float tmx = 0.f;                                          // largest |G| of the rows since the last tile boundary (this wave's rows)
@@ -2570,7 +2569,7 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
       const float* srow = S + m * lds;
       const bool live = m0 + 4 * u < m_end;
       float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
-      constexpr int JA = DGRAD ? kOutJ : J;                  // DGRAD: at most kOutJ columns of S are valid (the others are padding: their sums stay zero)
+      constexpr int JA = DGRAD ? JV : J;                     // DGRAD: at most JV columns of S are valid (the others are padding: their sums stay zero)
 #pragma unroll
       for (int j = 0; j < JA; ++j) {
         const float sv = srow[j];
@@ -2579,7 +2578,7 @@ __global__ __launch_bounds__(256) void mlp_skinny_tn_kernel(const float* __restr
         acc[j].z = fmaf(sv, b[u].z, acc[j].z);
         acc[j].w = fmaf(sv, b[u].w, acc[j].w);
         bs[j] += live ? sv : 0.f;
-        if (DGRAD && j < kOutJ) {
+        if (DGRAD && j < JV) {
           dot.x = fmaf(sv, wv[j].x, dot.x); dot.y = fmaf(sv, wv[j].y, dot.y); dot.z = fmaf(sv, wv[j].z, dot.z); dot.w = fmaf(sv, wv[j].w, dot.w);
         }
       }
@@ -2747,7 +2746,7 @@ int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, 
   if (tail && (ldo < 256 || ldt < 256 - N || !c_out)) return MATPBR_ERR_INVALID_ARG;   // the tail fills columns N..255 of a 256-wide sine layer
   NtArgs p{x, w, bias, nullptr, s_out, c_out, nullptr, 0, N, K, ldx, ldw, ldo};
   p.tail = tail; p.ldt = ldt;
-  const bool thin = M > kSmallM && K <= 24 && ldx >= thin_pad(K) && ldw >= ((K + 3) & ~3) && ldo >= 256 && !(ldo & 3) && aligned16(s_out) &&
+  const bool thin = M > kSmallM && K <= 16 && ldx >= thin_pad(K) && ldw >= ((K + 3) & ~3) && ldo >= 256 && !(ldo & 3) && aligned16(s_out) &&
                     (!c_out || aligned16(c_out));
   if (M <= kSmallM) {
     if (c_out) launch_small_nt<EPI_SINCOS>(p, M, (hipStream_t)stream);
@@ -2768,8 +2767,8 @@ int matpbr_mlp_layer_fwd_tail(const float* x, int ldx, const float* w, int ldw, 
 
 int matpbr_mlp_layer_fwd_sgn(const float* x, int ldx, const float* w, int ldw, const float* bias, float* s_out, int ldo, const float* tail, int ldt,
                              long M, int N, int K, void* stream) {
-  if (!x || !w || !bias || !s_out || M <= 0 || M > 0x7fffff00L || N <= 0 || N > 256 || K <= 0 || K > 24) return MATPBR_ERR_INVALID_ARG;
-  // the thin-K kernel only (the first layer of the coordinate MLP at image size: 15 inputs, 18 for 'armn'): every other shape keeps its cosines
+  if (!x || !w || !bias || !s_out || M <= 0 || M > 0x7fffff00L || N <= 0 || N > 256 || K <= 0 || K > 16) return MATPBR_ERR_INVALID_ARG;
+  // the thin-K kernel only (the first layer of the coordinate MLP at image size: 15 inputs, 10 for 'armn'): every other shape keeps its cosines
   if (M <= kSmallM || (ldx & 3) || (ldw & 3) || ldx < thin_pad(K) || ldw < ((K + 3) & ~3) || ldo < 256 || (ldo & 3) || !aligned16(x) || !aligned16(w) ||
       !aligned16(s_out))
     return MATPBR_ERR_UNSUPPORTED;
@@ -3152,7 +3151,7 @@ int matpbr_mlp_skinny_bwd_weight(const float* s, int lds, const float* b, int ld
 static int mlp_out_layer_bwd_impl(const float* d_x, int ldd, const float* s_prev, const float* c_prev, int lds, const float* w_out, int ldw, float* g_prev,
                                   int ldg, float* d_w, long ld_j, long ld_c, float* d_bias, float* d_bias_prev, void* workspace, size_t workspace_bytes,
                                   long M, int J, int n_prev, unsigned* g_tile_max, void* stream, MatpbrReduceJob* defer = nullptr) {
-  if (!d_x || !s_prev || !w_out || !g_prev || !d_w || M <= 0 || J <= 0 || J > kOutJ || n_prev <= 0 || n_prev > 256) return MATPBR_ERR_INVALID_ARG;
+  if (!d_x || !s_prev || !w_out || !g_prev || !d_w || M <= 0 || J <= 0 || J > 8 || n_prev <= 0 || n_prev > 256) return MATPBR_ERR_INVALID_ARG;
   if (ldd < 8 || lds < 256 || (lds & 3) || ldg < 256 || (ldg & 3) || ldw < 256 || (ldw & 3) || !aligned16(s_prev) || !aligned16(g_prev) || !aligned16(w_out) ||
       (c_prev && !aligned16(c_prev)))
     return MATPBR_ERR_INVALID_ARG;
@@ -3164,7 +3163,8 @@ static int mlp_out_layer_bwd_impl(const float* d_x, int ldd, const float* s_prev
   float* bpart = partial + (size_t)kSkinnySlabs * 8 * 256;
   float* gsum_part = bpart + (size_t)kSkinnySlabs * 8;
   SkinnyDgrad dg{w_out, ldw, J, c_prev, g_prev, ldg, gsum_part, g_tile_max};
-  hipLaunchKernelGGL((mlp_skinny_tn_kernel<8, true>), dim3(slabs), dim3(256), 0, (hipStream_t)stream, d_x, ldd, s_prev, lds, partial, bpart, M, rows, dg);
+  if (J <= kOutJ) hipLaunchKernelGGL((mlp_skinny_tn_kernel<8, true>), dim3(slabs), dim3(256), 0, (hipStream_t)stream, d_x, ldd, s_prev, lds, partial, bpart, M, rows, dg);
+  else hipLaunchKernelGGL((mlp_skinny_tn_kernel<8, true, 8>), dim3(slabs), dim3(256), 0, (hipStream_t)stream, d_x, ldd, s_prev, lds, partial, bpart, M, rows, dg);
   MatpbrReduceJob q{};
   q.kind = MATPBR_REDUCE_SKINNY; q.groups = slabs; q.src = partial; q.src_b = bpart; q.src_g = gsum_part; q.dst = d_w; q.dst_b = d_bias; q.dst_g = d_bias_prev;
   q.n0 = 8; q.n1 = J; q.n2 = 256; q.n3 = n_prev; q.ld_j = ld_j; q.ld_c = ld_c;

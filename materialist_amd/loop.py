@@ -1195,11 +1195,32 @@ class PosMlpNormalPhase:
                      "metallic": self.start[:, 4:5].reshape(H, W, 1)}
         if self.armn:
             self.orig["normal"] = self.start[:, 5:8].reshape(H, W, 3)
-        self.opt = _make_adamw(net.parameters(), lr)
-        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)
         self.saver = saver if saver is not None else DeviceSaveBest()
-        self.best_weights = {k: v.detach().clone() for k, v in net.state_dict().items()}
         self._t, self.ops = 0, None          # (`ops` and the device buffers: set up by the first `_step_device`)
+        # round 6: the network launch by launch on the C ABI (armhead.MlpEngine: forward, backward products, AdamW with SaveBest's weight snapshot --
+        # no autograd graph, no framework optimiser); the head (tanh / residual / clamps / normalize) and its backward are element-wise passes here
+        self.engine = None
+        if self.ENGINE and self.DEVICE_LOSS and self.armn and mask is None and gt_image.is_cuda:
+            from .armhead import MlpEngine
+
+            if MlpEngine.why_not(net, self.start.shape[0], gt_image.device) is None:
+                self.engine = MlpEngine(net, self.start, lr=lr)
+        if self.engine is not None:
+            import types
+
+            self.opt, self.sched = types.SimpleNamespace(param_groups=[{"lr": float(lr)}]), None      # what the callers read back
+            self._sched_epoch, self._bw = 0, None
+        else:
+            self.opt = _make_adamw(net.parameters(), lr)
+            self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=100, gamma=0.8)
+            self._bw = {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    ENGINE = True           # False: the network through autograd (`posmlp._PosMlpHipFn`) and torch.optim.AdamW
+
+    @property
+    def best_weights(self) -> Dict[str, torch.Tensor]:
+        """SaveBest's copy of the network's weights (:546-547)."""
+        return self.engine.best_weights if self.engine is not None else self._bw
 
     def maps_from_net(self):
         arm = self.net(self.start)                                                       # :493
@@ -1216,6 +1237,50 @@ class PosMlpNormalPhase:
             maps["roughness"] = masked_mean_fill(maps["roughness"], self.mask)
             maps["metallic"] = masked_mean_fill(maps["metallic"], self.mask)
         return maps, live
+
+    def _maps_from_engine(self):
+        """`maps_from_net` without autograd: the raw outputs of armhead.MlpEngine through the 'armn' head (mymodels/mlps.py:236-244) and the clamps /
+        normalisation of inverse_img_w_mi.py:493-497, the same expressions in the same order; what the head's backward needs is kept."""
+        H, W = self.H, self.W
+        with torch.no_grad():
+            x = self.engine.forward_raw()
+            t5 = torch.tanh(x[:, 0:5])
+            u = 1.3 * t5 + self.start[:, 0:5]
+            arm = (u.clamp(0, 1) + u) - u                                                  # x.clamp(0, 1).detach() + x - x.detach()
+            nraw = torch.tanh(x[:, 5:8] + self.start[:, 5:8])
+            nlen = nraw.norm(dim=1, keepdim=True).clamp_min(1e-12)                         # torch.nn.functional.normalize's eps
+            r_pre = arm[:, 3:4] * 0.93 + 0.07
+            raw = {"albedo": arm[:, 0:3].clamp(0, 1).reshape(H, W, 3), "roughness": r_pre.clamp(0, 1).reshape(H, W, 1),
+                   "metallic": arm[:, 4:5].clamp(0, 1).reshape(H, W, 1), "normal": (nraw / nlen).reshape(H, W, 3)}
+            # the clamps of :493-496 pass a gradient where their ARGUMENT lies inside [0, 1] (bounds included): the straight-through value
+            # (clamp(u) + u) - u of a saturated u is 1 to rounding -- a hair above it for about half of them, and those entries get none
+            gate = torch.cat([(arm[:, 0:3] >= 0) & (arm[:, 0:3] <= 1), (r_pre >= 0) & (r_pre <= 1), (arm[:, 4:5] >= 0) & (arm[:, 4:5] <= 1)], dim=1)
+        keys = {"a": "albedo", "r": "roughness", "m": "metallic", "n": "normal"}
+        live = [keys[c] for c in self.part if c in keys]
+        maps = {k: (raw[k] if k in live else self.fixed[k]) for k in raw}
+        self._head = (t5, nraw, nlen, gate)
+        return maps, live
+
+    def _engine_backward(self, grads: Dict[str, torch.Tensor], live) -> None:
+        """The head's backward (the clamps' gates as recorded by the forward; `normalize`; tanh) -> d loss / d (raw
+        outputs) -> the network's backward products (armhead.MlpEngine.backward_raw)."""
+        t5, nraw, nlen, gate = self._head
+        M = t5.shape[0]
+        with torch.no_grad():
+            d_arm = torch.zeros(M, 5, device=t5.device)
+            if "albedo" in live:
+                d_arm[:, 0:3] = grads["albedo"].reshape(M, 3)
+            if "roughness" in live:
+                d_arm[:, 3:4] = grads["roughness"].reshape(M, 1) * 0.93
+            if "metallic" in live:
+                d_arm[:, 4:5] = grads["metallic"].reshape(M, 1)
+            d_x = torch.zeros(M, 8, device=t5.device)
+            d_x[:, 0:5] = torch.where(gate, d_arm, torch.zeros_like(d_arm)) * (1.3 * (1.0 - t5 * t5))
+            if "normal" in live:
+                g = grads["normal"].reshape(M, 3)
+                y = nraw / nlen
+                d_x[:, 5:8] = ((g - y * (y * g).sum(dim=1, keepdim=True)) / nlen) * (1.0 - nraw * nraw)
+        self.engine.backward_raw(d_x)
 
     DEVICE_LOSS = True      # False: the autograd render and the torch-composed loss in every case
 
@@ -1249,7 +1314,7 @@ class PosMlpNormalPhase:
         o, sc = self.ops, self.scene
         if self.saver.best_loss is not None and self._t == 0:
             self.stats[:, o.STAT_BEST] = self.saver.best_loss.to(self.gt.device).reshape(-1)   # SaveBest.best_loss is global across phases (F11)
-        maps, live = self.maps_from_net()
+        maps, live = self._maps_from_engine() if self.engine is not None else self.maps_from_net()
         d = {k: maps[k].detach().contiguous() for k in ("albedo", "roughness", "metallic", "normal")}
         o.shade_fwd(d["albedo"], d["roughness"], d["metallic"], d["normal"], self._light, self.spp, sc.fov, out=self.pred, jac=self.jac)
         og = self.orig
@@ -1269,9 +1334,21 @@ class PosMlpNormalPhase:
             grads["normal"] = g_n
         self.best["normal"] = torch.where(improved, d["normal"], self.best["normal"])
         self.saver.best = self.best
+        if self.engine is not None:
+            self._engine_backward(grads, live)                                           # :544
+            self.saver.best_loss = self.stats[0, o.STAT_BEST].clone()
+            self.engine.adamw_step(self.stats)                                           # AdamW + SaveBest's copy of the weights (:546-547) in one launch
+            lr_now = self.opt.param_groups[0]["lr"]
+            if lr_now > 1.5e-4:                                                          # StepLR(100, 0.8), stepped while lr > 1.5e-4 (:553-554)
+                self._sched_epoch += 1
+                if self._sched_epoch % 100 == 0:
+                    self.engine.set_lr(lr_now * 0.8)
+                    self.opt.param_groups[0]["lr"] = lr_now * 0.8
+            self._t += 1
+            return self.stats[0, o.STAT_MSE].clone()
         torch.autograd.backward([maps[k] for k in live], [grads[k].reshape(maps[k].shape) for k in live])      # :544
         for k, v in self.net.state_dict().items():                                       # SaveBest keeps the weights too (:546-547)
-            self.best_weights[k] = torch.where(improved, v.detach(), self.best_weights[k])
+            self._bw[k] = torch.where(improved, v.detach(), self._bw[k])
         self.saver.best_loss = self.stats[0, o.STAT_BEST].clone()
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
@@ -1292,7 +1369,7 @@ class PosMlpNormalPhase:
         self.saver.update(loss_mse, albedo=maps["albedo"], roughness=maps["roughness"], metallic=maps["metallic"], rendered_img=pred_srgb, **extra)
         flag = (self.saver.best_loss < before).reshape(())
         for k, v in self.net.state_dict().items():                                       # SaveBest keeps the weights too (:546-547)
-            self.best_weights[k] = torch.where(flag, v.detach(), self.best_weights[k])
+            self._bw[k] = torch.where(flag, v.detach(), self._bw[k])
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         if self.opt.param_groups[0]["lr"] > 1.5e-4:                                      # :553-554

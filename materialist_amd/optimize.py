@@ -293,11 +293,15 @@ def optimize_envmap_ARMN(scene: _render.Scene, mat: Dict[str, torch.Tensor], opt
         """pos_mlp with output_type 'armn' (:165-172,493-506): the net predicts the normal map as well."""
         from .armhead import ArmMlpPhase
 
-        say(f"loop {loop_num}: part {part!r} (pos_mlp) runs PosMlpNormalPhase (render, losses and layer products on the C ABI, chained by autograd), "
-            f"not the launch-by-launch phase: {ArmMlpPhase.why_not(scene, gt, brdf_net, part, mask)}")
         fixed_keys = ("albedo", "roughness", "metallic") + (() if scene.use_mesh_normal else ("normal",))
         ph = _loop.PosMlpNormalPhase(scene, gt, brdf_net, start_arm, {k: mat[k] for k in fixed_keys},
                                      optimize_part=part, spp=spp, scale_delta=scale_delta, saver=_loop.DeviceSaveBest(), mask=mask)
+        if ph.engine is not None:
+            say(f"loop {loop_num}: part {part!r} (pos_mlp, armn) runs launch by launch on the C ABI (PosMlpNormalPhase with armhead.MlpEngine: render, losses, "
+                "the network's layer products and AdamW; no autograd)")
+        else:
+            say(f"loop {loop_num}: part {part!r} (pos_mlp) runs PosMlpNormalPhase with the network under autograd (render, losses and layer products on the C "
+                f"ABI), not a launch-by-launch phase: {ArmMlpPhase.why_not(scene, gt, brdf_net, part, mask)}")
         if saver.best_loss is not None:
             ph.saver.best_loss = saver.best_loss.clone().reshape(())
         es = _loop.EarlyStopping(patience, min_delta)

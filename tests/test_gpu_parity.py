@@ -1182,6 +1182,92 @@ def test_inverse_image_writes_the_reference_output_layout(tmp_path):
     assert os.path.exists(roll["mp4"]) and os.path.basename(roll["mp4"]) == "rolling_envmap_case_envmap.mp4"      # render_final.py:405-409
 
 
+@pytest.mark.parametrize("part", ["armn", "rmn"])
+def test_armn_network_launch_by_launch_is_the_autograd_phase(part):
+    """the eight-output 'armn' network (10 inputs: raw coordinates + 8 channels, hidden layers 246 / 256 / 246 / 256; mymodels/mlps.py:236-244,
+    inverse_img_w_mi.py:167-172) launch by launch on the C ABI -- `armhead.MlpEngine` inside `loop.PosMlpNormalPhase`: the first layer on the thin-K
+    kernel, the 256-wide layers on two f16 pieces forward and backward, the 8-column output layer, AdamW with SaveBest's weight
+    snapshot on the flat buffer; the head (tanh, residual, straight-through clamps, normalize) and its backward as element-wise passes -- against
+    the same phase with the network under autograd and torch.optim.AdamW (`ENGINE = False`): the gradients that reach every parameter in the
+    first iteration, the losses of five iterations, the weights after them and SaveBest's copy."""
+    import copy
+
+    from materialist_amd import loop, posmlp, render, synthetic
+
+    dev = _cuda()
+    H = W = 96                                                       # 9216 points: whole 128-row tiles, above the layer kernels' minimum
+    spp = 8
+    sc = synthetic.make_scene(9, H, W)
+    depth, light = _t(sc.depth, dev), _t(sc.light, dev)
+    geo = render.load_estimated_mesh(depth, use_mesh_normal=True).shading_normal()
+    gen = torch.Generator(device="cpu").manual_seed(6)
+    n_true = torch.nn.functional.normalize(geo + 0.2 * torch.randn(geo.shape, generator=gen).to(dev), dim=-1).contiguous()
+
+    def make_scene():
+        s = render.load_estimated_mesh(depth, use_mesh_normal=False)
+        s._set("emitter.data", light)
+        return s
+
+    with torch.no_grad():
+        gt = render.render_w_brdf(make_scene(), _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), n_true, spp)
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    start = torch.cat([init[0].reshape(-1, 3), init[1].reshape(-1, 1), init[2].reshape(-1, 1), geo.reshape(-1, 3)], dim=-1).contiguous()
+    fixed = {"albedo": init[0], "roughness": init[1], "metallic": init[2], "normal": geo}
+    torch.manual_seed(4)
+    net_a = posmlp.brdf_net("armn").to(dev)
+    net_a.lin4.weight.data.normal_(0, 0.02)                          # (the reference starts the output layer at zero: every hidden gradient would be zero)
+    net_b = copy.deepcopy(net_a)
+    runs = {}
+    for engine, net in ((True, net_a), (False, net_b)):
+        loop.PosMlpNormalPhase.ENGINE = engine
+        try:
+            ph = loop.PosMlpNormalPhase(make_scene(), gt, net, start, fixed, optimize_part=part, spp=spp, saver=loop.DeviceSaveBest())
+            assert (ph.engine is not None) == engine
+            first = []
+            if engine:
+                mses = [float(ph.step())]
+                first = [(gw[:, :wp_k].clone(), gb[:bp.numel()].clone()) for (gw, gb), (wp, bp), wp_k in
+                         zip(ph.engine.gviews, ph.engine.views, [getattr(net, f"lin{l}").linear.weight.shape[1] if l < 4 else net.lin4.weight.shape[1] for l in range(5)])]
+                first = [t for pair in first for t in pair]
+            else:
+                opt_step = ph.opt.step
+
+                def capture(*a, **kw):
+                    if not first:
+                        first.extend(p_.grad.detach().clone() for p_ in net.parameters())
+                    return opt_step(*a, **kw)
+
+                ph.opt.step = capture
+                mses = [float(ph.step())]
+            mses += [float(ph.step()) for _ in range(4)]
+        finally:
+            loop.PosMlpNormalPhase.ENGINE = True
+        runs[engine] = (mses, {k: v.detach().clone() for k, v in net.state_dict().items()}, float(ph.saver.best_loss),
+                        {k: v.clone() for k, v in ph.best_weights.items()}, first, {k: v.clone() for k, v in ph.saver.best.items()})
+    names = [n for n, _ in net_a.named_parameters()]
+    assert len(runs[True][4]) == len(runs[False][4]) == len(names)
+    errs = {name: ((ga - gb).norm().item() / (gb.norm().item() + 1e-30)) for ga, gb, name in zip(runs[True][4], runs[False][4], names)}
+    print("first-iteration gradients, engine against autograd, relative:", {k: f"{v:.1e}" for k, v in errs.items()})
+    for ga, gb, name in zip(runs[True][4], runs[False][4], names):        # f32-accurate products on both sides (two f16 pieces / three bf16 pieces)
+        assert ga.shape == gb.shape, name
+    # f32-accurate products on both sides; what separates them is the reference's own construction: a saturated output's straight-through value
+    # (clamp(u) + u) - u is 1 to ROUNDING, the outer clamp of :493-496 passes its gradient only if that rounding fell at or below 1, and two
+    # forwards that agree to 1e-7 disagree on a share of those entries (the autograd phase on the HIP layer kernels against the same phase on
+    # torch.mm differs by the same 3.7e-3 in the first layer, 5e-4 in the last: tools history in EXPERIMENTS.md)
+    assert max(errs.values()) <= 8e-3, errs
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert a == pytest.approx(b, rel=5e-4)
+    assert runs[True][2] == pytest.approx(runs[False][2], rel=5e-4)
+    for k, v in runs[True][1].items():                                    # (AdamW's first steps are lr * sign(g): entries whose gradient is rounding move either way)
+        diff = (v - runs[False][1][k]).abs()
+        assert diff.median().item() < 5e-6 and (diff > 1e-4).float().mean().item() < 0.15, (k, diff.max().item(), (diff > 1e-4).float().mean().item())
+    for k, v in runs[True][3].items():
+        diff = (v - runs[False][3][k]).abs()
+        assert diff.median().item() < 5e-6, k
+    for k in ("albedo", "roughness", "metallic", "normal"):
+        assert torch.allclose(runs[True][5][k], runs[False][5][k], atol=2e-3), k
+
+
 @pytest.mark.parametrize("model_name", ["none", "pos_mlp"])
 def test_use_mask_keeps_roughness_and_metallic_uniform_inside_the_mask(tmp_path, model_name):
     """--use_mask (inverse_img_w_mi.py:379-381,509-511,702-711): best_results/mask.png marks one material region."""
