@@ -443,8 +443,7 @@ class MlpEngine:
     The head (tanh, residual, clamps, `normalize`) and its backward are the caller's: a few element-wise passes over [M, 8].
 
     First layer on the thin-K f32 MFMA kernel (packed sines), 256-wide layers forward on two f16 pieces, backward products on two f16 pieces
-    under one exponent per 128-row tile, folds deferred to one launch (the kernels of `ArmMlpPhase`'s layer-by-layer path); the first layer's
-    weight gradient on the general f32 kernel."""
+    under one exponent per 128-row tile, folds deferred to one launch (the kernels of `ArmMlpPhase`'s layer-by-layer path)."""
 
     @staticmethod
     def why_not(net: torch.nn.Module, M: int, device) -> Optional[str]:
@@ -554,12 +553,14 @@ class MlpEngine:
             nj += 1
             n_prev = self.ns[l - 1]
             _, gb = self.gviews[l - 1]
+            if l == 1:      # into the first layer: its pre-activation gradient is not stored, the same launch forms its weight and bias gradient
+                o.mlp_first_layer_bwd_blk(g, self.tmax[l], self.wsplit_b[l], self.bufs[0], self.x0p, self.gviews[0][0], self.d0, n_prev, n_red, gb, defer=slot(nj))
+                nj += 2
+                break
             g_prev = self.gbufs[1] if g is self.gbufs[0] else self.gbufs[0]
             o.mlp_layer_bwd_input_blk(g, self.tmax[l], self.wsplit_b[l], self.bufs[l - 1], g_prev, n_prev, n_red, gb, self.tmax[l - 1], defer=slot(nj))
             nj += 1
             g, n_red = g_prev, n_prev
-        gw0, _ = self.gviews[0]
-        gw0[:, :self.d0].copy_(o.mlp_layer_bwd_weight(g, self.x0p, n_red, self.d0))      # the first layer's weight gradient (general f32 kernel)
         o.mlp_reduce_jobs(jobs, nj, self.flat)
 
     def adamw_step(self, stats: torch.Tensor) -> None:
