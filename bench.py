@@ -660,7 +660,10 @@ def main(argv=None):
             except Exception:
                 pmc = {}
         from materialist_amd.build import sources_digest
-        if pmc.get("csrc_sha16") != sources_digest():
+        if os.environ.get("MATPBR_LIB"):
+            # a measurement build beside the product library: the counter passes were not collected on it
+            pmc = {"stale": f"MATPBR_LIB={os.environ['MATPBR_LIB']}: the library that ran is not the one profiles/pmc_traffic.json was collected on"}
+        elif pmc.get("csrc_sha16") != sources_digest():
             # the counter passes were collected on other kernels than the ones this run executes: no traffic figure rather than a stale one
             pmc = {"stale": f"profiles/pmc_traffic.json was collected on csrc {pmc.get('csrc_sha16')}, this build is {sources_digest()}: "
                             "re-run tools/pmc_passes_r06.sh + tools/pmc_to_traffic.py --write"}
@@ -857,6 +860,7 @@ def main(argv=None):
             "metric": "opt_iterations_per_sec_512x512", "value": value, "unit": "it/s", "n_gpus": world,
             "device": (lambda pr: {"name": pr.name, "compute_units": pr.multi_processor_count, "memory_gb": round(pr.total_memory / 2 ** 30, 1),
                                    "gcn_arch": getattr(pr, "gcnArchName", None)})(torch.cuda.get_device_properties(dev)),
+            "library": os.environ.get("MATPBR_LIB") or "materialist_amd/libmatpbr.so", "csrc_sha16": __import__("materialist_amd.build", fromlist=["sources_digest"]).sources_digest(),
             "world_size": dist.get_world_size() if use_dist else 1, "collective_backend": dist.get_backend() if use_dist else None,
             "steps": args.steps, "warmup": args.warmup, "device_warmup": device_warmup, "cold_first_process_it_per_s": cold, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define MATPBR_VERSION 300 /* 0.3.0 */
+#define MATPBR_VERSION 310 /* round 6: the coordinate MLP's entry points moved to matpbr_mlp.h, five unused ones removed; lazy state 120 B/pixel, folded
+                              models 68 B/pixel in a new layout (opaque storage: size it with the *_bytes queries) */
 #define MATPBR_MAX_SPP 128
 #define MATPBR_NSH 25
 

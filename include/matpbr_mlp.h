@@ -152,7 +152,8 @@ int matpbr_mlp_split_weights_fmt(const float* w, int ldw, int N, int K, int flag
  *                                  matpbr_mlp_layer_bwd_input_blk (= matpbr_mlp_split_weights_fmt, the same bits), and `zero_words` 32-bit zeros
  *                                  at `zero` (the gradient tiles' maxima, which their producers fill by atomic max)
  *   matpbr_mlp_chain_fwd           x0 [M, ldx0 >= 16] (zero beyond d0) -> s_out[0..3] [M, ldo >= 256] (columns n[l].. of a 241-wide layer = x0,
- *                                  written here), th [M, 8], the maps (each nullable) as matpbr_mlp_arm_head_fwd.  M a multiple of 128 */
+ *                                  written here), th [M, 8], the maps (each nullable) as matpbr_mlp_arm_head_fwd.  M a multiple of 128; n_head = 5 (the 'arm'
+ *                                  head: anything else is MATPBR_ERR_INVALID_ARG) */
 size_t matpbr_mlp_chain_images_bytes(void);
 int matpbr_mlp_chain_prep(const float* const* w, const int* ldw, const int* n, const float* const* bias, int d0, void* images, void* const* bwd_images,
                           void* zero, long zero_words, void* stream);

@@ -382,7 +382,7 @@ int matpbr_mlp_chain_prep(const float* const* w, const int* ldw, const int* n, c
 
 int matpbr_mlp_chain_fwd(const float* x0, int ldx0, const void* images, float* const* s_out, int ldo, const int* n, const float* start, int lds, float* th,
                          float* map_a, float* map_r, float* map_m, int n_head, long M, void* stream) {
-  if (!x0 || !images || !s_out || !n || !start || !th || M <= 0 || n_head <= 0 || n_head > 8 || lds < n_head) return MATPBR_ERR_INVALID_ARG;
+  if (!x0 || !images || !s_out || !n || !start || !th || M <= 0 || n_head != 5 || lds < n_head) return MATPBR_ERR_INVALID_ARG;      // (the head epilogue is the five-output 'arm' head)
   if ((M % 128) || M > 0x7fffff00L || ldx0 < 16 || (ldx0 & 3) || ldo < 256 || (ldo & 3) || (reinterpret_cast<uintptr_t>(x0) & 15)) return MATPBR_ERR_UNSUPPORTED;
   ChainArgs p{};
   p.x0 = x0; p.ldx0 = ldx0; p.images = (const unsigned char*)images; p.ldo = ldo; p.M = (int)M; p.n_head = n_head;

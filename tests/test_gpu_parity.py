@@ -1240,6 +1240,10 @@ def test_armn_network_launch_by_launch_is_the_autograd_phase(part):
                 ph.opt.step = capture
                 mses = [float(ph.step())]
             mses += [float(ph.step()) for _ in range(4)]
+            if engine:      # Adam's bias corrections count the statistics row's iterations: the two counters move together
+                from materialist_amd import ops as _ops
+
+                assert float(ph.engine.hyper[1]) == 5.0 == float(ph.stats[0, _ops.STAT_ITERS])
         finally:
             loop.PosMlpNormalPhase.ENGINE = True
         runs[engine] = (mses, {k: v.detach().clone() for k, v in net.state_dict().items()}, float(ph.saver.best_loss),
@@ -2456,6 +2460,9 @@ def test_deferred_folds_of_the_backward_pass_are_the_same_bits():
                 ph.step()
             torch.cuda.synchronize()
             runs[defer] = (ph.gflat.clone(), ph.flat.clone(), ph.stats.clone())
+            from materialist_amd import ops as _ops
+
+            assert float(ph.hyper[1]) == 3.0 == float(ph.stats[0, _ops.STAT_ITERS])      # (the optimiser's step count IS the statistics row's)
         finally:
             ArmMlpPhase.DEFER_REDUCE = True
     assert float(runs[True][0].abs().max()) > 0.0
