@@ -36,7 +36,7 @@ LINE_LIMIT = 4096          # the driver parses the LAST stdout line; round 5's 2
 _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "world_size", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _CONFIG_KEYS = ("workload", "mode", "height", "width", "spp", "images_per_gpu", "light", "parallelism")
 _ROOF_KEYS = ("bound", "kernel", "workload", "achieved", "peak", "unit", "frac", "avg_launch_ms", "bytes_per_pixel", "traffic", "own_traffic_frac",
-              "grad_rel_l2", "grad_worst_pixel", "iteration_frac")
+              "grad_rel_l2", "grad_p999_pixel", "grad_worst_pixel", "iteration_frac")
 _CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 
 
@@ -691,6 +691,7 @@ def main(argv=None):
                                                       "whose sign(pred - gt) of the L1 term differs between two renders that agree to 1e-3 (converged pixels; grows as the part "
                                                       "converges).  The RENDER of the same kernel is within 1e-3 of exact sampling on every pixel (tests/test_gpu_lazy.py)"),
                 "grad_rel_l2": ge["derivatives_of_the_models"]["roughness"]["rel_l2"], "grad_worst_pixel": ge["derivatives_of_the_models"]["roughness"]["worst_pixel"],
+                "grad_p999_pixel": ge["derivatives_of_the_models"]["roughness"]["p999_pixel"],
                 "traffic": traffic, "traffic_source": pmc.get("source_r04") if traffic else pmc.get("stale"),
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "

@@ -102,9 +102,11 @@ __device__ __forceinline__ uint32_t pack_lohi_x2(float lo, float hi, float x2_0)
 enum { kFgG = 0, kFgH = 3, kFgPlanes = 6 };
 // The slopes eSD, eS1 of the detached derivatives come from a one-sided difference over kLzH; a sample that crosses the horizon inside that
 // stencil makes the difference a jump / h, not a slope.  Whatever they are, they may correct the derivative by at most half its size
-// at the far end of the pixel's interval (|e| <= 0.5 (|dSD| + |dS1|) / max(lo, hi)): the specification's LAZY_E_CAP.
-__device__ __forceinline__ float lazy_e_cap(float e, float dSD, float dS1, float lo, float hi) {
-    const float lim = 0.5f * (fabsf(dSD) + fabsf(dS1)) / fmaxf(fmaxf(lo, hi), 1e-4f);
+// at the far end of the pixel's interval (|e| <= 0.5 max_c (|dSD_c| + |dS1_c|) / max(lo, hi)): the specification's LAZY_E_CAP.  (Round 5 stated the
+// cap per channel: a channel whose dSD passes through zero -- a legitimate slope beside a small value -- lost it, 25 pixels of an image with
+// derivative errors of 1-3 %: tools/lazy_grad_diag.py with DIAG_DUMP.)
+__device__ __forceinline__ float lazy_e_cap(float e, float dmax, float lo, float hi) {      // dmax: the largest |dSD_c| + |dS1_c| of the pixel's channels
+    const float lim = 0.5f * dmax / fmaxf(fmaxf(lo, hi), 1e-4f);
     return fminf(fmaxf(e, -lim), lim);
 }
 // kFxJ carries (JA0_c, JY0_c) with JA0 = JX0 + m_ref JY0, m_ref = the pixel's metallic when its model was built, in eight bits (code / 255: the low
@@ -804,10 +806,11 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             rho = lazy_rho_next(rho, fabsf(dr), e, ej, tol_s, tol_s * (kLzTolJ / kLzTolS));
         }
         rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
+        const float dmax = fmaxf(fmaxf(fabsf(dSD[0]) + fabsf(dS1v[0]), fabsf(dSD[1]) + fabsf(dS1v[1])), fabsf(dSD[2]) + fabsf(dS1v[2]));
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float es = lazy_e_cap(eSD[c], dSD[c], dS1v[c], fminf(fv[18], rho), fminf(fv[19], rho));
-            eS1[c] = lazy_e_cap(eS1[c], dSD[c], dS1v[c], fminf(fv[18], rho), fminf(fv[19], rho));
+            const float es = lazy_e_cap(eSD[c], dmax, fminf(fv[18], rho), fminf(fv[19], rho));
+            eS1[c] = lazy_e_cap(eS1[c], dmax, fminf(fv[18], rho), fminf(fv[19], rho));
             eSD[c] = es;
         }
         *(uint32_t*)((char*)qs.plane[kLzRref] + o1) = as_u(rc_r);
@@ -1161,10 +1164,11 @@ __global__ __launch_bounds__(kBlock, 2) void lazy_refresh_kernel(const LazyRefre
                     rho = lazy_rho_next(rho, fabsf(dr), e, ej, tol_s, tol_s * (kLzTolJ / kLzTolS));
                 }
                 rho = fminf(fmaxf(rho, kLzRhoMin), kLzRhoMax);
+                const float dmax = fmaxf(fmaxf(fabsf(dSD[0]) + fabsf(dS1v[0]), fabsf(dSD[1]) + fabsf(dS1v[1])), fabsf(dSD[2]) + fabsf(dS1v[2]));
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float es = lazy_e_cap(eSD[c], dSD[c], dS1v[c], fminf(klo, rho), fminf(khi, rho));
-                    eS1[c] = lazy_e_cap(eS1[c], dSD[c], dS1v[c], fminf(klo, rho), fminf(khi, rho));
+                    const float es = lazy_e_cap(eSD[c], dmax, fminf(klo, rho), fminf(khi, rho));
+                    eS1[c] = lazy_e_cap(eS1[c], dmax, fminf(klo, rho), fminf(khi, rho));
                     eSD[c] = es;
                 }
                 uint32_t* S = q.state;

@@ -1033,8 +1033,10 @@ static void lazy_refresh_pixel(const real wo[3], const real n[3], const real a[3
     st[LZ_LO] = iv_round_down(st[LZ_LO]); st[LZ_HI] = iv_round_down(st[LZ_HI]);
     /* LAZY_E_CAP: a sample that crosses the horizon inside the stencil makes the one-sided difference of a detached derivative a jump / h, not
      * a slope; whatever eSD, eS1 are, they correct the derivative by at most half its size at the far end of the interval */
+    real dmax = R(0);      /* the pixel's largest |dSD_c| + |dS1_c| (round 6: per channel, a channel whose dSD passes through zero lost a legitimate slope) */
+    for (int c = 0; c < 3; ++c) dmax = rmax(dmax, fabs(st[LZ_DSD + c]) + fabs(st[LZ_DS1 + c]));
     for (int c = 0; c < 3; ++c) {
-        const real lim = R(0.5) * (fabs(st[LZ_DSD + c]) + fabs(st[LZ_DS1 + c])) / rmax(rmax(lo_cap, hi_cap), R(1e-4));
+        const real lim = R(0.5) * dmax / rmax(rmax(lo_cap, hi_cap), R(1e-4));
         st[LZ_ESD + c] = clampr(st[LZ_ESD + c], -lim, lim);
         st[LZ_ES1 + c] = clampr(st[LZ_ES1 + c], -lim, lim);
     }

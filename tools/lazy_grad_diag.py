@@ -58,6 +58,11 @@ for fold in ((True,) if os.environ.get('DIAG_FOLD_ONLY') else (True, False)):
             for i in idx.tolist():
                 print(f"   px {i}: eJ {float(eJ[i]):.2e} J exact {Je[:, i].tolist()} model {Jm[:, i].tolist()} e {float(e[i]):.2e} r {float(p_at[1].reshape(-1)[i]):.4f} dr {float(dr[i]):+.2e} lo {float(lo[i]):.2e} hi {float(hi[i]):.2e} rho {float(s[i,3]):.2e} "
                       f"frac {float(frac_int[i]):.2f} first/deriv {float(first[i]):.3f} g {float(g[i]):+.3e} gref {float(gr[i]):+.3e} gmean {float(gr.abs().mean()):.3e}")
+            if os.environ.get("DIAG_DUMP"):      # the worst pixels' inputs and model state, for a CPU session with the oracle
+                ii = idx.cpu().numpy()
+                np.savez(os.environ["DIAG_DUMP"], idx=ii, state=s[idx].cpu().numpy(), a=a_[idx].cpu().numpy(), r=rr[idx].cpu().numpy(), m=m_[idx].cpu().numpy(),
+                         n=ph.n.reshape(-1, 3)[idx].cpu().numpy(), light=ph.light.cpu().numpy(), J_exact=Je[:, idx].cpu().numpy(), J_model=Jm[:, idx].cpu().numpy(),
+                         dcache=dc[:, idx].cpu().numpy(), floor=0.5 * float(gt.mean()))
             # error against position in the interval and against the size of the first-order term
             for lo_f, hi_f in ((0, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.01)):
                 sel = (frac_int >= lo_f) & (frac_int < hi_f)
