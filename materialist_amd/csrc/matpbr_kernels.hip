@@ -1571,7 +1571,9 @@ size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
     if (H <= 0 || W <= 0 || batch <= 0) return 0;
     return ((size_t)batch * fwd_sums_cap(H, W) + (size_t)batch * step_part_stride(kRedBlocks) +
             2 * (size_t)batch * kStateStride /* the step kernel's alternating SaveBest / EarlyStopping state */ +
-            3 * (size_t)batch * grid_blocks(H, W) /* its per-workgroup regulariser sums */) * sizeof(float);
+            3 * (size_t)batch * grid_blocks(H, W) /* its per-workgroup regulariser sums */ +
+            18 * (size_t)batch * grid_blocks(H, W) /* round 6: the folded steps' per-block records of the next iteration's statistics, two sets */ + 2) * sizeof(float) +
+           (size_t)batch * 2 * kWalkShards * 6 * sizeof(long long) /* ... and the walked pixels' shares, fixed point, per parity and queue shard */;
 }
 
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* ph, int t, float lr, void* stream) {
@@ -1669,12 +1671,18 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     // [2][B][kStatsStride], at a fixed place (`part` moves with the number of forward sums, which differs between t = 1 and later steps)
     float* state2 = (float*)q.workspace + (size_t)q.batch * fwd_sums_cap(q.H, q.W) + (size_t)q.batch * step_part_stride(kRedBlocks);
     float* reg_sums = state2 + 2 * (size_t)q.batch * kStateStride;     // [B][grid_blocks][3]
+    float* block_rec = reg_sums + 3 * (size_t)q.batch * grid_blocks(q.H, q.W);      // [2][B][grid_blocks][9]: the folded steps' per-block records, by iteration parity
+    const size_t rec_set = 9 * (size_t)q.batch * grid_blocks(q.H, q.W);
+    long long* walk_acc = (long long*)(((uintptr_t)(block_rec + 2 * rec_set) + 7) & ~(uintptr_t)7);      // [B][2][kWalkShards][6]
+    // round 6: the folded steps form the statistics of iteration t + 1 where they form its render: from the second iteration on there is no statistics launch
+    const bool acc_mode = lazy_fused && fold != kFoldNone && t > 1;
     const bool rotate = lazy_fused && (q.flags & MATPBR_FLAG_ROTATE_BEST) != 0;
     const float* state_cur = state2 + (size_t)((t - 1) & 1) * q.batch * kStateStride;   // written by the step before (t = 1: from `stats`, below)
     if ((stages & MATPBR_STAGE_STATS) && lazy_fused) {
         // one launch: the partial rows; their fold and the SaveBest / EarlyStopping commit happen at the head of the step kernel
         if (t == 1) hipLaunchKernelGGL(step_state_init_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)q.stats, state2, q.batch);
-        if (t > 1)     // the step before left the regulariser sums of the parameters it wrote: this pass reads pred and the target only
+        if (acc_mode) {
+        } else if (t > 1)     // the step before left the regulariser sums of the parameters it wrote: this pass reads pred and the target only
             hipLaunchKernelGGL(loss_sums2_kernel<4>, dim3((unsigned)step_rows, (unsigned)q.batch), dim3(kBlock), 0, st, (const float*)q.pred, q.gt_srgb,
                                (const float*)q.stats, (const float*)q.pa, q.a0, (const float*)q.pr, q.r0, (const float*)q.pm, q.m0, part, n3, n1,
                                (const float*)fwd_sums, nfwd, q.part_mask, (const float*)reg_sums, (const float*)q.pred_next, rotate ? state_cur : nullptr,
@@ -1730,6 +1738,7 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         ls.es_patience = q.es_patience; ls.es_min_delta = q.es_min_delta;
         if (fold != kFoldNone) {
             for (int k = 0; k < kFxPlanes; ++k) ls.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
+            ls.rec_in = block_rec + (size_t)((t - 1) & 1) * rec_set; ls.rec_out = block_rec + (size_t)(t & 1) * rec_set; ls.walk_acc = fold == kFoldXY ? walk_acc : nullptr; ls.acc_mode = acc_mode ? 1 : 0;
             ls.walk_fix = (long long*)((char*)q.lazy_fold + lazy_fold_planes_bytes(n1, q.batch));
             ls.walk_cnt = (uint32_t*)(ls.walk_fix + (size_t)q.batch * lb.nblk);
             ls.walk_queue = ls.walk_cnt + (size_t)q.batch * 2 * kWalkShards;

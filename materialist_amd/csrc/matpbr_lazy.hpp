@@ -338,7 +338,27 @@ struct LazyStepArgs {
     uint32_t* walk_cnt;       // [B][2][kWalkShards]: entries of the walk queue's lists, per iteration parity
     uint32_t* walk_queue;     // [B][kWalkShards][walk_shard_cap(P)] pixel indices
     int walk_par;             // this iteration's parity
+    // round 6: the statistics of iteration t + 1 are formed where its render is formed (no statistics launch behind the step, none of its 24 B/pixel).
+    // With x0 = max(pred ratio_t, eps)^(1/2.2) (the exposure ratio of THIS iteration as the expansion point) and d0 = x0 - gt, every block leaves
+    //     S = sum pred,  A = sum d0^2,  Bq = sum d0 x0,  Cq = sum x0^2,  L = sum |d0|,  Mq = sum sign(d0) x0        (Bq, Cq, Mq: pixels above eps only)
+    // and the head of the next step, which knows ratio_{t+1} = sum gt / S, has with e = (ratio_{t+1} / ratio_t)^(1/2.2) - 1 (a few 1e-4)
+    //     sum (x - gt)^2 = A + 2 e Bq + e^2 Cq   exactly,     sum |x - gt| = L + e Mq   up to the pixels whose sign flips inside e (a relative 1e-7).
+    const float* rec_in;      // [B][nblk][9] per block: S, (A, Bq, Cq, L, Mq) of the streamed pixels, the three regulariser sums -- as the step BEFORE left them
+    float* rec_out;           // ... and where this step leaves its own (the other of two sets: a launch's heads read while its first workgroups finish)
+    long long* walk_acc;      // [B][2][kWalkShards][6] (S, A, Bq, Cq, L, Mq) of the walked pixels in fixed point (kWalkFix), per iteration parity and queue shard: integer atomics, order-free
+    int acc_mode;             // the head takes this iteration's statistics from block_sums / block_acc / walk_acc / reg_sums (t > 1) instead of fold_part's rows
 };
+// one channel of a freshly rendered pixel into the five sums above
+__device__ __forceinline__ void loss_acc(float pred, float gt, float ratio, float (&acc)[5]) {
+    const float x = pred * ratio;
+    const bool live = x > kLossEps;
+    const float x0 = pow_inv_gamma(fmaxf(x, kLossEps)), d0 = x0 - gt, xq = live ? x0 : 0.0f;
+    acc[0] = fmaf(d0, d0, acc[0]);
+    acc[1] = fmaf(d0, xq, acc[1]);
+    acc[2] = fmaf(xq, xq, acc[2]);
+    acc[3] += fabsf(d0);
+    acc[4] += d0 > 0.0f ? xq : (d0 < 0.0f ? -xq : 0.0f);
+}
 // LDS exchange between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be held back
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -656,7 +676,7 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_step_kernel(const LazyStepArgs
 template <bool FOLD, bool LEAN = false>
 __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, const StepPtrs& sp, const float* s_light, const float4* s_ring,
                                                     const float2* s_saz, const Geom& g, const RuleTable& tab, int b, int P, long BPl, int p,
-                                                    bool item_ok, int sub, float floor_, float tol_k, float tol_s, float& tot) {
+                                                    bool item_ok, int sub, float floor_, float tol_k, float tol_s, float& tot, float* rgb_out = nullptr) {
     const JacBwdArgs& q = qs.j;
     (void)q;
     const int half = sub >> 2, azi = sub & 3;
@@ -838,6 +858,7 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             }
             stf(sp.pred_next, o3 + 4 * c, rgb);
             tot += rgb;
+            if (FOLD && rgb_out != nullptr) rgb_out[c] = rgb;      // (the caller forms the pixel's share of the next iteration's statistics)
         }
         if (FOLD) {
             uint32_t xw[5];

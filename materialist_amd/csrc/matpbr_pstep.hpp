@@ -193,7 +193,7 @@ __device__ __forceinline__ float loss_go(float prc, float gt, float ratio, float
 
 // one pixel of a kFoldXY part; returns whether its new roughness has left its model's interval
 __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags f, float ratio,
-                                            float sr, bool improved, float& tot, float (&reg)[3]) {
+                                            float sr, bool improved, float& tot, float (&reg)[3], float (&acc)[5]) {
     const JacBwdArgs& q = qs.j;
     const unsigned o1 = i * 4u, o3 = i * 12u;
     if (qs.rotate) improved = false;      // no snapshot stores: the buffer just read IS the snapshot
@@ -255,6 +255,7 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
             xy_eval(X0[c], Y0[c], x.s[c], xy_x2(x.lohi, x.q, c), dr1, X, Y);
             rgb[c] = fmaf(m1, Y, X);
             tot += rgb[c];
+            loss_acc(rgb[c], gt[c], ratio, acc);               // its share of the next iteration's statistics
         }
         st3(sp.pred_next, o3, rgb[0], rgb[1], rgb[2]);
     }
@@ -262,7 +263,7 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
 }
 // one pixel of a kFoldGH part (never leaves its model: nothing of it depends on the roughness)
 __device__ __forceinline__ bool pstep_pixel(const PxGH& x, const LazyStepArgs& qs, const StepPtrs& sp, unsigned i, const PStepFlags, float ratio,
-                                            float sr, bool improved, float& tot, float (&reg)[3]) {
+                                            float sr, bool improved, float& tot, float (&reg)[3], float (&acc)[5]) {
     const JacBwdArgs& q = qs.j;
     const unsigned o3 = i * 12u;
     if (qs.rotate) improved = false;
@@ -282,6 +283,7 @@ __device__ __forceinline__ bool pstep_pixel(const PxGH& x, const LazyStepArgs& q
         reg[0] += fabsf(a1 - a0[c]);
         rgb[c] = fmaf(a1, x.G[c], x.H[c]);
         tot += rgb[c];
+        loss_acc(rgb[c], gt[c], ratio, acc);
     }
     if (q.d_a) st3(q.d_a, o3, gs[0], gs[1], gs[2]);
     if (improved && q.best_a) st3(q.best_a, o3, ac[0], ac[1], ac[2]);
@@ -310,6 +312,9 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     __shared__ float s_fold[4][6];
     __shared__ float s_bsum[kPstepMaxBlocks][4];
     __shared__ float s_breg[kPstepMaxBlocks][4][3];
+    __shared__ float s_bacc[kPstepMaxBlocks][4][5];
+    __shared__ float s_fold9[4][9];
+    __shared__ long long s_wk[6];
     __shared__ uint16_t s_wcnt[kPstepMaxBlocks][4];            // listed pixels per (block, wave)
     __shared__ uint16_t s_list[MODE == kFoldXY ? 4 : 1][MODE == kFoldXY ? kPstepListCap : 1];
     const JacBwdArgs& q = qs.j;
@@ -366,31 +371,74 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     {
         const float* rows = qs.fold_part + (long)b * step_part_stride(qs.fold_rows);
         float v[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = threadIdx.x; i < qs.fold_rows; i += kBlock) {
+        float w9[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (qs.acc_mode) {
+            // round 6: what the step before left per block for THIS iteration -- S, (A, Bq, Cq, L, Mq), the three regulariser sums -- in block order
+            // (thread i: blocks i, i + 256, ...; DPP tree; the four waves in order: the same bits in every workgroup, whatever the batch size)
+            for (int i = threadIdx.x; i < nblk_img; i += kBlock) {
+                const float* rec = qs.rec_in + ((long)b * nblk_img + i) * 9;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) v[k] += rows[(long)i * 5 + k];
-        }
+                for (int k = 0; k < 9; ++k) w9[k] += rec[k];
+            }
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const float w = wave_sum_to_lane63(v[k]);
-            if ((threadIdx.x & 63) == 63) s_fold[threadIdx.x >> 6][k] = w;
+            for (int k = 0; k < 9; ++k) {
+                const float w = wave_sum_to_lane63(w9[k]);
+                if ((threadIdx.x & 63) == 63) s_fold9[threadIdx.x >> 6][k] = w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < qs.fold_rows; i += kBlock) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) v[k] += rows[(long)i * 5 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float w = wave_sum_to_lane63(v[k]);
+                if ((threadIdx.x & 63) == 63) s_fold[threadIdx.x >> 6][k] = w;
+            }
         }
         float st[kStatsStride];
-        const float sp_total = rows[(long)qs.fold_rows * 5];
+        float sp_total = qs.acc_mode ? 0.0f : rows[(long)qs.fold_rows * 5];
         float bratio = -1.0f;
+        long long wk[6] = {0, 0, 0, 0, 0, 0};
+        if (qs.acc_mode && qs.walk_acc != nullptr && threadIdx.x >= 64 && threadIdx.x < 70) {
+            // the walked pixels' shares (the walk of the iteration before: the other parity), one thread per number over the shards: integer sums
+            const long long* wa = qs.walk_acc + ((long)b * 2 + (qs.walk_par ^ 1)) * kWalkShards * 6 + (threadIdx.x - 64);
+            long long t6 = 0;
+#pragma unroll 8
+            for (int sh = 0; sh < kWalkShards; ++sh) t6 += wa[sh * 6];
+            s_wk[threadIdx.x - 64] = t6;
+        }
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int i = 0; i < kStatsStride; ++i) st[i] = old[i];
             bratio = old[kStBestRatio];
         }
         __syncthreads();
+        if (threadIdx.x == 0 && qs.acc_mode && qs.walk_acc != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wk[k] = s_wk[k];
+        }
         if (threadIdx.x == 0) {
             float t[5];
+            if (qs.acc_mode) {
+                float u[9];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) t[k] = (s_fold[0][k] + s_fold[1][k]) + (s_fold[2][k] + s_fold[3][k]);
+                for (int k = 0; k < 9; ++k) u[k] = (s_fold9[0][k] + s_fold9[1][k]) + (s_fold9[2][k] + s_fold9[3][k]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) u[k] += (float)((double)wk[k] * (1.0 / kWalkFix));
+                sp_total = u[0];
+                const float ratio_new = st[kStGtSum] / sp_total, ratio_old = st[kStRatio];
+                const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(ratio_new / ratio_old) * (1.0f / 2.2f)) - 1.0f;
+                t[0] = fmaf(e, fmaf(e, u[3], 2.0f * u[2]), u[1]);      // sum (x - gt)^2 = A + 2 e Bq + e^2 Cq
+                t[1] = fmaf(e, u[5], u[4]);                            // sum |x - gt|   = L + e Mq
+                t[2] = u[6]; t[3] = u[7]; t[4] = u[8];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) t[k] = (s_fold[0][k] + s_fold[1][k]) + (s_fold[2][k] + s_fold[3][k]);
+                if (qs.reg_from_part) { t[2] = rows[(long)qs.fold_rows * 5 + 1]; t[3] = rows[(long)qs.fold_rows * 5 + 2]; t[4] = rows[(long)qs.fold_rows * 5 + 3]; }
+            }
             st[kStRatio] = st[kStGtSum] / sp_total;
             const float mse = t[0] * q.inv_n3, l1 = t[1] * q.inv_n3;
-            if (qs.reg_from_part) { t[2] = rows[(long)qs.fold_rows * 5 + 1]; t[3] = rows[(long)qs.fold_rows * 5 + 2]; t[4] = rows[(long)qs.fold_rows * 5 + 3]; }
             const float la = (q.part_mask & MATPBR_PART_A) ? t[2] * q.inv_n3 : 0.0f;
             const float lr = (q.part_mask & MATPBR_PART_R) ? t[3] * q.inv_n1 : 0.0f;
             const float lm = (q.part_mask & MATPBR_PART_M) ? t[4] * q.inv_n1 : 0.0f;
@@ -425,13 +473,13 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
     const unsigned long long below = (1ull << lane) - 1ull;
     int cntw = 0;                                              // entries of this wave's list (uniform)
     for (int t = 0; t < ntile; t += 2) {
-        float tot = 0.0f, reg[3] = {0.0f, 0.0f, 0.0f};
+        float tot = 0.0f, reg[3] = {0.0f, 0.0f, 0.0f}, acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         bool need0 = false, need1 = false;
         const int p0 = tile_px0(t) + (int)threadIdx.x, p1 = p0 + kTile;
-        if (p0 < P) need0 = pstep_pixel(A, qs, sp, (unsigned)(b * P + p0), f, ratio, sr, improved, tot, reg);
+        if (p0 < P) need0 = pstep_pixel(A, qs, sp, (unsigned)(b * P + p0), f, ratio, sr, improved, tot, reg, acc);
         if (t + 2 < ntile) pstep_load(A, qs, sp, (unsigned)(b * P + pix(t + 2)), f);
         __builtin_amdgcn_sched_barrier(0);
-        if (p1 < P) need1 = pstep_pixel(B, qs, sp, (unsigned)(b * P + p1), f, ratio, sr, improved, tot, reg);
+        if (p1 < P) need1 = pstep_pixel(B, qs, sp, (unsigned)(b * P + p1), f, ratio, sr, improved, tot, reg, acc);
         if (t + 3 < ntile) pstep_load(B, qs, sp, (unsigned)(b * P + pix(t + 3)), f);
         __builtin_amdgcn_sched_barrier(0);
         // the block's sums: DPP tree per wave here, the four waves in order at the end (fixed order)
@@ -442,6 +490,11 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         for (int k = 0; k < 3; ++k) {
             const float wr = wave_sum_to_lane63(reg[k]);
             if (lane == 63) s_breg[bl][wave][k] = wr;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float wa = wave_sum_to_lane63(acc[k]);
+            if (lane == 63) s_bacc[bl][wave][k] = wa;
         }
         if (MODE == kFoldXY) {                                 // listed pixels, in a fixed order: tile, then lane
             const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
@@ -459,6 +512,9 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         // the pixel alone, and the walk sums are order-free.
         if (blockIdx.x == 0 && threadIdx.x < kWalkShards)          // the next iteration's counters (their last reader has long finished)
             qs.walk_cnt[(b * 2 + (qs.walk_par ^ 1)) * kWalkShards + threadIdx.x] = 0u;
+        // ... and the sums THIS iteration's walk adds to (parity walk_par; the next step's heads read them): their last readers were the heads of the
+        // step before this one, and this launch's heads read the other parity
+        if (qs.walk_acc != nullptr && blockIdx.x == 0 && threadIdx.x < 6 * kWalkShards) qs.walk_acc[((long)b * 2 + qs.walk_par) * kWalkShards * 6 + threadIdx.x] = 0;
         if (cntw > 0) {                                            // (uniform per wave)
             const int shard = ((int)blockIdx.x * 4 + wave) % kWalkShards;
             uint32_t base = 0u;
@@ -498,6 +554,16 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
             qs.counts[(long)b * nblk_img + blockIdx.x + bl * gridDim.x] =
                 MODE == kFoldXY ? (uint32_t)(((int)s_wcnt[bl][0] + (int)s_wcnt[bl][1]) + ((int)s_wcnt[bl][2] + (int)s_wcnt[bl][3])) : 0u;
     }
+    // the block's record for the NEXT step's heads: S, (A, Bq, Cq, L, Mq), the three regulariser sums.  Two sets of records, by the parity of the
+    // iteration: this launch's heads read the other set -- a workgroup that starts late must not find what an early one has already finished
+    if (qs.rec_out && (int)threadIdx.x < 9 * nb) {
+        const int bl = threadIdx.x / 9, k = threadIdx.x - 9 * bl;
+        float v;
+        if (k == 0) v = (s_bsum[bl][0] + s_bsum[bl][1]) + (s_bsum[bl][2] + s_bsum[bl][3]);
+        else if (k < 6) v = (s_bacc[bl][0][k - 1] + s_bacc[bl][1][k - 1]) + (s_bacc[bl][2][k - 1] + s_bacc[bl][3][k - 1]);
+        else v = (s_breg[bl][0][k - 6] + s_breg[bl][1][k - 6]) + (s_breg[bl][2][k - 6] + s_breg[bl][3][k - 6]);
+        qs.rec_out[((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * 9 + k] = v;
+    }
     if (qs.reg_sums && (int)threadIdx.x < 3 * nb) {
         const int bl = threadIdx.x / 3, k = threadIdx.x - 3 * bl;
         qs.reg_sums[((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * 3 + k] = (s_breg[bl][0][k] + s_breg[bl][1][k]) + (s_breg[bl][2][k] + s_breg[bl][3][k]);
@@ -519,7 +585,7 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
 // dispatch alone is 20 us); waves packed four to a workgroup (a 240-register wave needs half a SIMD: a workgroup is placed only where all
 // four SIMDs have room, 40 us); chunks of eight filled per workgroup of the step kernel (mostly two or three pixels per chunk: twice the
 // waves, and at one image more chunks than waves); the walk inside the step kernel (128 registers: 25 k cycles per walk, 16 us of tail).
-__global__ __launch_bounds__(64) void lazy_pwalk_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
+__global__ __launch_bounds__(64, 2) void lazy_pwalk_kernel(const LazyStepArgs qs, const float* __restrict__ light, const Geom g, const RuleTable tab) {
     __shared__ float s_light[kNL + 1];
     __shared__ float4 s_ring[kMaxRings];
     __shared__ float2 s_saz[kMaxRings * kMaxAz];
@@ -564,10 +630,32 @@ __global__ __launch_bounds__(64) void lazy_pwalk_kernel(const LazyStepArgs qs, c
         const bool ok = 8 * k + (lane >> 3) < n;
         const int first = __shfl((int)pix, 0);                             // entry 8 k exists; (unconditionally: a shuffle inside the select below
         const int p = ok ? (int)pix : first;                               //  would read lane 0 while it is masked off)
-        float rs = 0.0f;
-        resample_walk_pixel<true>(qs, sp, s_light, s_ring, s_saz, g, tab, b, P, BPl, p, ok, sub, floor_, tol_k, tol_s, rs);
+        float rs = 0.0f, rgb3[3] = {0.0f, 0.0f, 0.0f}, a5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        resample_walk_pixel<true>(qs, sp, s_light, s_ring, s_saz, g, tab, b, P, BPl, p, ok, sub, floor_, tol_k, tol_s, rs, rgb3);
+        asm volatile("" ::: "memory");                          // (the target's three words are asked for HERE: hoisted above the walk they cost it its second wave per SIMD)
+        if (qs.walk_acc != nullptr && ok && sub == 0) {
+            const unsigned o3w = (unsigned)(b * P + p) * 12u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) loss_acc(rgb3[c], ldf(q.gt_srgb, o3w + 4 * c), ratio, a5);
+        }
         if (ok && sub == 0)
             atomicAdd((unsigned long long*)(qs.walk_fix + (long)b * nblk + p / kLazyBlockPixels), (unsigned long long)(long long)__double2ll_rn((double)rs * kWalkFix));
+        // the walked pixels' shares of the next iteration's statistics: each pixel's six numbers in fixed point, then INTEGER sums (a wave's eight
+        // pixels first, one atomic per number and wave, on the SHARD's six words: on six words per image 130 waves queued for 15 us): order-free, hence
+        // the same bits in every run and for every batch size
+        if (qs.walk_acc != nullptr) {
+            const bool mine = ok && sub == 0;
+            long long v6[6];
+            v6[0] = mine ? __double2ll_rn((double)rs * kWalkFix) : 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 5; ++k2) v6[1 + k2] = mine ? __double2ll_rn((double)a5[k2] * kWalkFix) : 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 6; ++k2) {
+#pragma unroll
+                for (int off = 8; off < 64; off <<= 1) v6[k2] += __shfl_xor(v6[k2], off);      // lanes 0, 8, ..., 56 hold the pixels
+                if (lane == 0) atomicAdd((unsigned long long*)(qs.walk_acc + (((long)b * 2 + qs.walk_par) * kWalkShards + shard) * 6 + k2), (unsigned long long)v6[k2]);
+            }
+        }
     }
 }
 
