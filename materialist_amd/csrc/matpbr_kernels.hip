@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kBlock) void phase_resolve_kernel(const ResolveArgs
             }
         }
     }
+    if (q.p0 == nullptr) return;      // a folded phase: no stored renders (fold_resolve_kernel forms what the caller reads)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float u = q.p0[o3 + c], v = q.p1[o3 + c];
@@ -1567,6 +1568,17 @@ int matpbr_brdf_normal_step(const MatpbrNormalStep* ns, int t, float lr, void* s
     return launch_status();
 }
 
+// the folded, persistent form of the step (matpbr_pstep.hpp) where the part has one: parts of r / m with the albedo folded into the models, part 'a'
+// with roughness and metallic folded in; a caller that wants a gradient the folded form does not have stays generic.  (Of a phase whose steps
+// render ahead: lazy_state, dcache and pred_next given.)
+static int phase_fold_mode(const MatpbrBrdfPhase& q) {
+    if (q.lazy_state == nullptr || q.dcache == nullptr || q.pred_next == nullptr || lazy_fwd_blocks((long)q.H * q.W) > kLazyMaxBlocks) return kFoldNone;
+    if (q.lazy_fold == nullptr || (q.flags & MATPBR_FLAG_GENERIC_STEP)) return kFoldNone;
+    if (!(q.part_mask & MATPBR_PART_A) && (q.part_mask & (MATPBR_PART_R | MATPBR_PART_M)) && q.d_a == nullptr) return kFoldXY;
+    if (q.part_mask == MATPBR_PART_A && q.d_r == nullptr && q.d_m == nullptr) return kFoldGH;
+    return kFoldNone;
+}
+
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch) {
     if (H <= 0 || W <= 0 || batch <= 0) return 0;
     return ((size_t)batch * fwd_sums_cap(H, W) + (size_t)batch * step_part_stride(kRedBlocks) +
@@ -1613,11 +1625,7 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
     const bool lazy_fused = lazy && q.pred_next != nullptr;   // backward of this iteration and forward of the next one in one launch
     // the folded, persistent form of that launch (matpbr_pstep.hpp) where the part has one: parts of r / m with the albedo folded into the
     // models, part 'a' with roughness and metallic folded in; a caller that wants a gradient the folded form does not have stays generic
-    int fold = kFoldNone;
-    if (lazy_fused && q.lazy_fold != nullptr && !(q.flags & MATPBR_FLAG_GENERIC_STEP)) {
-        if (!(q.part_mask & MATPBR_PART_A) && (q.part_mask & (MATPBR_PART_R | MATPBR_PART_M)) && q.d_a == nullptr) fold = kFoldXY;
-        else if (q.part_mask == MATPBR_PART_A && q.d_r == nullptr && q.d_m == nullptr) fold = kFoldGH;
-    }
+    const int fold = lazy_fused ? phase_fold_mode(q) : kFoldNone;
     // forward sums per image: t > 1 of the fused step: its workgroups' and the resampling launch's
     const bool resample = lazy_fused && fold == kFoldNone && ((q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr);   // otherwise no pixel ever leaves its model's interval (folded step: walked in-kernel)
     const int nres = grid_blocks(q.H, q.W) < kResampleWaves ? grid_blocks(q.H, q.W) : kResampleWaves;   // waves of the resampling launch per image
@@ -1738,7 +1746,7 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         ls.es_patience = q.es_patience; ls.es_min_delta = q.es_min_delta;
         if (fold != kFoldNone) {
             for (int k = 0; k < kFxPlanes; ++k) ls.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
-            ls.rec_in = block_rec + (size_t)((t - 1) & 1) * rec_set; ls.rec_out = block_rec + (size_t)(t & 1) * rec_set; ls.walk_acc = fold == kFoldXY ? walk_acc : nullptr; ls.acc_mode = acc_mode ? 1 : 0;
+            ls.rec_in = block_rec + (size_t)((t - 1) & 1) * rec_set; ls.rec_out = block_rec + (size_t)(t & 1) * rec_set; ls.walk_acc = fold == kFoldXY ? walk_acc : nullptr; ls.acc_mode = acc_mode ? 1 : 0; ls.no_pred = 1;
             ls.walk_fix = (long long*)((char*)q.lazy_fold + lazy_fold_planes_bytes(n1, q.batch));
             ls.walk_cnt = (uint32_t*)(ls.walk_fix + (size_t)q.batch * lb.nblk);
             ls.walk_queue = ls.walk_cnt + (size_t)q.batch * 2 * kWalkShards;
@@ -1778,23 +1786,54 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
 int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* ph, int t_done, void* stream) {
     if (!ph || t_done < 0) return MATPBR_ERR_INVALID_ARG;
     const MatpbrBrdfPhase& q = *ph;
-    if (!(q.flags & MATPBR_FLAG_ROTATE_BEST) || t_done == 0) return MATPBR_OK;       // nothing rotates
+    const bool rotate = (q.flags & MATPBR_FLAG_ROTATE_BEST) != 0;
+    const int fold = phase_fold_mode(q);
+    if ((!rotate && fold == kFoldNone) || t_done == 0) return MATPBR_OK;       // nothing rotates, every render is where the caller reads it
     if (!q.pa || !q.pr || !q.pm || !q.pred || !q.pred_next || !q.lazy_state || !q.workspace || q.batch <= 0 || q.H <= 0 || q.W <= 0) return MATPBR_ERR_INVALID_ARG;
     if (q.workspace_bytes < matpbr_brdf_phase_workspace_bytes(q.H, q.W, q.batch)) return MATPBR_ERR_WORKSPACE;
-    if (((q.part_mask & MATPBR_PART_A) && !q.best_a) || ((q.part_mask & MATPBR_PART_R) && !q.best_r) || ((q.part_mask & MATPBR_PART_M) && !q.best_m))
+    if (rotate && (((q.part_mask & MATPBR_PART_A) && !q.best_a) || ((q.part_mask & MATPBR_PART_R) && !q.best_r) || ((q.part_mask & MATPBR_PART_M) && !q.best_m)))
         return MATPBR_ERR_INVALID_ARG;
     const long n1 = (long)q.H * q.W;
     float* state2 = (float*)q.workspace + (size_t)q.batch * fwd_sums_cap(q.H, q.W) + (size_t)q.batch * step_part_stride(kRedBlocks);
-    ResolveArgs ra{};
-    ra.x0[0] = (q.part_mask & MATPBR_PART_A) ? q.pa : nullptr; ra.x1[0] = q.best_a;
-    ra.x0[1] = (q.part_mask & MATPBR_PART_R) ? q.pr : nullptr; ra.x1[1] = q.best_r;
-    ra.x0[2] = (q.part_mask & MATPBR_PART_M) ? q.pm : nullptr; ra.x1[2] = q.best_m;
-    ra.p0 = q.pred; ra.p1 = q.pred_next; ra.best_img = q.best_img;
-    ra.state = state2 + (size_t)(t_done & 1) * q.batch * kStateStride;
-    ra.n1 = n1;
+    const float* state = state2 + (size_t)(t_done & 1) * q.batch * kStateStride;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(phase_resolve_kernel, dim3((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch), dim3(kBlock), 0, st, ra);
-    hipLaunchKernelGGL(phase_resolve_done_kernel, dim3(1), dim3(kBlock), 0, st, state2, q.batch);
+    const dim3 pgrid((unsigned)((n1 + kBlock - 1) / kBlock), (unsigned)q.batch);
+    if (rotate) {
+        ResolveArgs ra{};
+        ra.x0[0] = (q.part_mask & MATPBR_PART_A) ? q.pa : nullptr; ra.x1[0] = q.best_a;
+        ra.x0[1] = (q.part_mask & MATPBR_PART_R) ? q.pr : nullptr; ra.x1[1] = q.best_r;
+        ra.x0[2] = (q.part_mask & MATPBR_PART_M) ? q.pm : nullptr; ra.x1[2] = q.best_m;
+        if (fold == kFoldNone) { ra.p0 = q.pred; ra.p1 = q.pred_next; ra.best_img = q.best_img; }     // (a folded phase has no stored renders to exchange)
+        ra.state = state;
+        ra.n1 = n1;
+        hipLaunchKernelGGL(phase_resolve_kernel, pgrid, dim3(kBlock), 0, st, ra);
+    }
+    if (fold != kFoldNone) {
+        // the render of the current parameters from the models; SaveBest's render from the models where they are exact in the best values, from
+        // the renderer where the roughness has moved (fold_resolve_kernel)
+        const bool slopes = (q.part_mask & MATPBR_PART_R) != 0 || q.d_r != nullptr;
+        const bool want_best = rotate && q.best_img != nullptr;
+        if (want_best && fold == kFoldXY && slopes) {
+            MatpbrCamera cam{q.fov_x_deg};
+            Geom g;
+            RuleTable tab;
+            if (!make_geom(q.H, q.W, &cam, g)) return MATPBR_ERR_INVALID_ARG;
+            if (!fill_rule_table(q.spp, tab)) return MATPBR_ERR_UNSUPPORTED;
+            if (!q.n || !q.light) return MATPBR_ERR_INVALID_ARG;
+            ShadeArgs sa{};
+            sa.a = q.pa; sa.r = (q.part_mask & MATPBR_PART_R) ? q.best_r : q.pr; sa.m = (q.part_mask & MATPBR_PART_M) ? q.best_m : q.pm;
+            sa.n = q.n; sa.dcache = q.dcache; sa.out = q.pred_next; sa.clamp = 1;
+            hipLaunchKernelGGL(shade_kernel<false>, dim3((unsigned)grid_blocks(q.H, q.W), (unsigned)q.batch), dim3(kBlock), 0, st, sa, q.light, g, tab);
+        }
+        FoldResolveArgs fa{};
+        fa.a = q.pa; fa.r = q.pr; fa.m = q.pm;
+        fa.best_a = want_best ? q.best_a : nullptr; fa.best_m = want_best && (q.part_mask & MATPBR_PART_M) ? q.best_m : nullptr;
+        for (int k = 0; k < kFxPlanes; ++k) fa.fplane[k] = (const uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
+        fa.out = q.pred; fa.best_lin = q.pred_next; fa.best_img = want_best ? q.best_img : nullptr; fa.state = state; fa.slopes = slopes ? 1 : 0;
+        if (fold == kFoldXY) hipLaunchKernelGGL(fold_resolve_kernel<kFoldXY>, pgrid, dim3(kBlock), 0, st, fa, (int)n1);
+        else hipLaunchKernelGGL(fold_resolve_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, fa, (int)n1);
+    }
+    if (rotate) hipLaunchKernelGGL(phase_resolve_done_kernel, dim3(1), dim3(kBlock), 0, st, state2, q.batch);
     return launch_status();
 }
 

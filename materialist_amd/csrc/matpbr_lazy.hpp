@@ -345,6 +345,7 @@ struct LazyStepArgs {
     //     sum (x - gt)^2 = A + 2 e Bq + e^2 Cq   exactly,     sum |x - gt| = L + e Mq   up to the pixels whose sign flips inside e (a relative 1e-7).
     const float* rec_in;      // [B][nblk][9] per block: S, (A, Bq, Cq, L, Mq) of the streamed pixels, the three regulariser sums -- as the step BEFORE left them
     float* rec_out;           // ... and where this step leaves its own (the other of two sets: a launch's heads read while its first workgroups finish)
+    int no_pred;              // round 6: the folded steps do not store the render they form (nothing of the loop reads it back: matpbr_brdf_phase_resolve evaluates the models for the caller)
     long long* walk_acc;      // [B][2][kWalkShards][6] (S, A, Bq, Cq, L, Mq) of the walked pixels in fixed point (kWalkFix), per iteration parity and queue shard: integer atomics, order-free
     int acc_mode;             // the head takes this iteration's statistics from block_sums / block_acc / walk_acc / reg_sums (t > 1) instead of fold_part's rows
 };
@@ -856,7 +857,7 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
                 *(uint32_t*)((char*)qs.fplane[kFxJ + c] + o1) = pack_h2(f.JX0, f.JY0);
                 rgb = fmaf(mv, f.Y0, f.X0);
             }
-            stf(sp.pred_next, o3 + 4 * c, rgb);
+            if (!(FOLD && qs.no_pred)) stf(sp.pred_next, o3 + 4 * c, rgb);
             tot += rgb;
             if (FOLD && rgb_out != nullptr) rgb_out[c] = rgb;      // (the caller forms the pixel's share of the next iteration's statistics)
         }

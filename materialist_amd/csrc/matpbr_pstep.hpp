@@ -257,7 +257,7 @@ __device__ __forceinline__ bool pstep_pixel(const PxXY& x, const LazyStepArgs& q
             tot += rgb[c];
             loss_acc(rgb[c], gt[c], ratio, acc);               // its share of the next iteration's statistics
         }
-        st3(sp.pred_next, o3, rgb[0], rgb[1], rgb[2]);
+        if (!qs.no_pred) st3(sp.pred_next, o3, rgb[0], rgb[1], rgb[2]);
     }
     return need;
 }
@@ -293,7 +293,7 @@ __device__ __forceinline__ bool pstep_pixel(const PxGH& x, const LazyStepArgs& q
         st3(q.av[0], o3, vi[0], vi[1], vi[2]);
         st3(sp.pa, o3, na[0], na[1], na[2]);
     }
-    st3(sp.pred_next, o3, rgb[0], rgb[1], rgb[2]);
+    if (!qs.no_pred) st3(sp.pred_next, o3, rgb[0], rgb[1], rgb[2]);
     return false;
 }
 
@@ -569,6 +569,79 @@ __global__ __launch_bounds__(kBlock, 4) void lazy_pstep_kernel(const LazyStepArg
         qs.reg_sums[((long)b * nblk_img + blockIdx.x + bl * gridDim.x) * 3 + k] = (s_breg[bl][0][k] + s_breg[bl][1][k]) + (s_breg[bl][2][k] + s_breg[bl][3][k]);
     }
     PS_NOTE(13, __builtin_amdgcn_s_memrealtime());
+}
+
+// =================================================================================================
+// matpbr_brdf_phase_resolve of a folded phase
+// =================================================================================================
+// The folded steps store no render (LazyStepArgs::no_pred): what the caller reads is formed here, when it asks.  `out`: the render of the CURRENT
+// parameters -- the step kernel's expression on the models' words, the bits the next step will judge.  best_img (MATPBR_FLAG_ROTATE_BEST, whose
+// steps store no snapshot either): max(render of SaveBest's maps x their exposure ratio, eps)^(1/2.2), the render being the model where it is
+// exact in the best values (kFoldGH: linear in the albedo; a part that leaves the roughness alone: linear in the metallic; a pixel without
+// geometry: a constant) and the renderer's own sum (shade_kernel, launched before this kernel into best_lin) where the roughness has moved --
+// the models have moved on since the best iteration, the maps have not.  One thread per pixel.
+struct FoldResolveArgs {
+    const float *a, *r, *m;            // the current parameters (raw)
+    const float *best_a, *best_m;      // SaveBest's maps (clamped); read only where named above
+    const uint32_t* fplane[kFxPlanes];
+    float* out;                        // [B,H,W,3]
+    const float* best_lin;             // [B,H,W,3] kFoldXY with slopes: the exact render of SaveBest's maps
+    float* best_img;                   // null: no best render asked for
+    const float* state;                // [B][kStateStride] of the last step
+    int slopes;
+};
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void fold_resolve_kernel(const FoldResolveArgs q, int P) {
+    const int b = blockIdx.y;
+    const int p = (int)blockIdx.x * kBlock + (int)threadIdx.x;
+    if (p >= P) return;
+    const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
+    const float bratio = q.best_img ? q.state[b * kStateStride + kStBestRatio] : -1.0f;
+    float rgb[3], best[3] = {0.0f, 0.0f, 0.0f};
+    if (MODE == kFoldXY) {
+        const float r = fminf(fmaxf(ldf(q.r, o1), 0.07f), 1.0f), m = fminf(fmaxf(ldf(q.m, o1), 0.0f), 1.0f);
+        uint32_t xy[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) xy[k] = ldu(q.fplane[kFxXY + k], o1);
+        float X0[3], Y0[3];
+        xy_unpack(xy, X0, Y0);
+        const uint32_t lohi_w = ldu(q.fplane[kFxLoHi], o1);
+        const bool constant = (lohi_w & 0xffffu) == 0xffffu;
+        float rref = 0.0f;
+        uint32_t lohi = 0u, qq = 0u, sw[3] = {0u, 0u, 0u};
+        if (q.slopes) {                                         // (as pstep_load_fixed)
+            rref = as_f(ldu(q.fplane[kFxRref], o1)); lohi = lohi_w; qq = ldu(q.fplane[kFxQ], o1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sw[c] = ldu(q.fplane[kFxS + c], o1);
+        }
+        const float dr = r - rref;
+        const float mb = bratio >= 0.0f && q.best_m ? fminf(fmaxf(ldf(q.best_m, o1), 0.0f), 1.0f) : m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float X, Y;
+            xy_eval(X0[c], Y0[c], sw[c], xy_x2(lohi, qq, c), dr, X, Y);
+            rgb[c] = fmaf(m, Y, X);
+            if (bratio >= 0.0f) best[c] = constant ? rgb[c] : (q.slopes ? ldf(q.best_lin, o3 + 4u * c) : fmaf(mb, Y, X));
+        }
+    } else {
+        const F3 av = ld3(q.a, o3);
+        const float a[3] = {fminf(fmaxf(av.x, 0.0f), 1.0f), fminf(fmaxf(av.y, 0.0f), 1.0f), fminf(fmaxf(av.z, 0.0f), 1.0f)};
+        float ab[3] = {a[0], a[1], a[2]};
+        if (bratio >= 0.0f && q.best_a) {
+            const F3 bv = ld3(q.best_a, o3);
+            ab[0] = fminf(fmaxf(bv.x, 0.0f), 1.0f); ab[1] = fminf(fmaxf(bv.y, 0.0f), 1.0f); ab[2] = fminf(fmaxf(bv.z, 0.0f), 1.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float G = as_f(ldu(q.fplane[kFgG + c], o1)), Hc = as_f(ldu(q.fplane[kFgH + c], o1));
+            rgb[c] = fmaf(a[c], G, Hc);
+            best[c] = fmaf(ab[c], G, Hc);
+        }
+    }
+    st3(q.out, o3, rgb[0], rgb[1], rgb[2]);
+    if (bratio >= 0.0f)
+        st3(q.best_img, o3, pow_inv_gamma(fmaxf(best[0] * bratio, kLossEps)), pow_inv_gamma(fmaxf(best[1] * bratio, kLossEps)),
+            pow_inv_gamma(fmaxf(best[2] * bratio, kLossEps)));
 }
 
 // =================================================================================================

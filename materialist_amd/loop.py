@@ -425,9 +425,9 @@ class FusedBrdfPhase:
     def _advance(self) -> None:
         ct = self._ct
         self.t += 1
-        if self.rotate:
-            self._dirty = True
-        elif self._pred_bufs is not None:
+        if self.rotate or self.fold:
+            self._dirty = True                    # (a folded phase stores no render: matpbr_brdf_phase_resolve forms it when somebody reads it)
+        if not self.rotate and self._pred_bufs is not None:
             # the buffer the step's last launch rendered the next iterate into becomes `pred` of the next step -- and `self.pred`, as in the
             # rotating form: the render of the current parameters
             self._pred_cur ^= 1

@@ -288,7 +288,14 @@ def test_savebest_without_copies_leaves_what_the_copying_step_leaves(part):
         for name in ("albedo", "roughness", "metallic"):
             assert torch.equal(rot.p[name], cpy.p[name]), (upto, name)
             assert torch.equal(rot.best[name], cpy.best[name]), (upto, name)
-        assert torch.equal(rot.best_img, cpy.best_img), upto
+        if part == "rm":
+            # a folded phase stores no renders: the rotating form's best image is formed when it is asked for, from the RENDERER on SaveBest's
+            # maps where the roughness has moved (matpbr_brdf_phase_resolve) -- the copying form keeps the model's render of the improving
+            # iteration, within the models' tolerance of it (1e-3 of max(|.|, mean) in linear radiance, 1 / 2.2 of that after the gamma)
+            err = (rot.best_img - cpy.best_img).abs() / torch.maximum(cpy.best_img, cpy.best_img.mean())
+            assert float(err.max()) <= 1e-3, (upto, float(err.max()))
+        else:
+            assert torch.equal(rot.best_img, cpy.best_img), upto
         assert torch.equal(rot.pred, cpy.pred), upto              # one meaning in both forms: the render of the current parameters
         assert torch.equal(rot.stats, cpy.stats), upto
         assert torch.equal(rot.history(), cpy.history()), upto
