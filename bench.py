@@ -675,7 +675,8 @@ def main(argv=None):
         roof = {"bound": "hbm", "kernel": "lazy_pstep_kernel (BRDF bwd of iteration t + Adam + fwd of t+1, one launch)",
                 "kernel_detail": "lazy_pstep_kernel<kFoldXY>: backward of iteration t (d loss/d pred, material gradients, regularisers, clamp gating, "
                                           "SaveBest by buffer rotation, Adam) + render of iteration t+1 from per-pixel local models in the roughness with the part's "
-                                          "constant albedo folded in (68 B/pixel of model); the pixels that left their model's interval are queued and re-sampled "
+                                          "constant albedo folded in (68 B/pixel of model); the loss statistics of iteration t+1 (SaveBest / EarlyStopping / "
+                                          "exposure ratio: no statistics launch, no stored render); the pixels that left their model's interval are queued and re-sampled "
                                           "(20 GGX samples) by the small launch behind it (resample_launch_ms)",
                 "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / (HBM_PEAK / 1e9), "avg_launch_ms": t_step,
                 "timing": "mean over iterations 301-500 of a phase of the kernel's own begin -> end, two HIP events handed to the launch on the launch "
@@ -695,8 +696,9 @@ def main(argv=None):
                 "traffic": traffic, "traffic_source": pmc.get("source_r04") if traffic else pmc.get("stale"),
                 "own_traffic_frac": (traffic / (t_step * 1e-3) / HBM_PEAK) if traffic else None,
                 "note": "algorithmic bytes = SURVEY 8d's 44 (forward) + 64 (backward, arm) B/pixel for the pair this launch performs; `traffic` = the bytes it "
-                        "really moves per launch (PMC; by construction 148 B/pixel in an 'rm' part: r, m read and written 16, the folded models 68, target 12, the "
-                        "next render 12, anchors 8, Adam moments 32), "
+                        "really moves per launch (PMC; by construction 136 B/pixel in an 'rm' part: r, m read and written 16, the folded models 68, target 12, "
+                        "anchors 8, Adam moments 32 -- the next render is no longer stored (round 6: its loss statistics are formed where it is formed, "
+                        "stats_launches_ms is 0 from the second iteration of a part on; matpbr_brdf_phase_resolve evaluates the models when the caller reads pred)), "
                         "own_traffic_frac = traffic / duration / peak: how close the launch is to the HBM limit on its OWN bytes"}
         ex = entry(px, tk["fwd_loop"], tk["bwd_loop"],
                    "round 2's pair (FusedBrdfPhase(lazy=False)): shade_kernel<jac> walks the 20 GGX samples of every pixel (cached diffuse lobe) + "
