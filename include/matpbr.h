@@ -63,7 +63,8 @@ enum { MATPBR_LIGHT_SH25 = 0, MATPBR_LIGHT_SH9 = 1, MATPBR_LIGHT_ENV_TEXELS = 2 
                                         iteration declares the buffers it has just read "best" and writes the new values into the others (any other
                                         iteration updates in place); nothing is copied in the loop (20 of 217 B/pixel of an improving 'rm' iteration,
                                         32 of 150 in an 'a' part).  The caller does NOT swap pred / pred_next between steps and must call
-                                        matpbr_brdf_phase_resolve before it reads pa / pr / pm / best_* / best_img / pred or starts the next part */
+                                        matpbr_brdf_phase_resolve before it reads pa / pr / pm / best_* / best_img / pred or starts the next part
+                                        (a folded part stores no render at all: every reader of `pred` calls resolve, with or without this flag) */
 #define MATPBR_FLAG_GENERIC_STEP 256u /* MatpbrBrdfPhase.flags: keep the pred_next step on the generic models even where the part has a folded form
                                         (`lazy_fold`): A/B measurements and tests of one form against the other */
 #define MATPBR_FLAG_JAC32 512u     /* matpbr_shade_fwd_lazy: `jac16` receives the NINE fp32 planes of matpbr_shade_fwd_ex's `jac` instead (matpbr_plane9_bytes()):
@@ -293,10 +294,16 @@ int matpbr_brdf_normal_step(const MatpbrNormalStep* step, int t, float lr, void*
 
 size_t matpbr_brdf_phase_workspace_bytes(int H, int W, int batch);
 int matpbr_brdf_phase_step(const MatpbrBrdfPhase* phase, int t, float lr, void* stream);
-/* MATPBR_FLAG_ROTATE_BEST: after the step with t = t_done, put everything where the copying form leaves it: current parameters in pa / pr / pm,
- * SaveBest's snapshots in best_a / best_r / best_m (maps of the part) and best_img (= the tone-mapped render of the best iteration of this
- * phase; untouched if none improved), the render of the CURRENT parameters (the next iteration's) in `pred`, the best iteration's in
- * `pred_next`.  The phase may go on afterwards (steps t_done + 1, ...).  Without the flag, or with t_done = 0: nothing to do. */
+/* After the step with t = t_done, put everything where the caller reads it.
+ * MATPBR_FLAG_ROTATE_BEST: current parameters in pa / pr / pm, SaveBest's snapshots in best_a / best_r / best_m (maps of the part) and best_img
+ * (= the tone-mapped render of the best iteration of this phase; untouched if none improved), the render of the CURRENT parameters (the next
+ * iteration's) in `pred`.
+ * A part with a folded form (`lazy_fold` given, no MATPBR_FLAG_GENERIC_STEP; with or without MATPBR_FLAG_ROTATE_BEST): its steps store NO render
+ * (round 6: they form the next iteration's loss statistics themselves) -- `pred` is written HERE, from the per-pixel models at the current
+ * parameters (the values the next step judges); under MATPBR_FLAG_ROTATE_BEST best_img is formed here too: from the models where they are exact in
+ * the best values, from the renderer on SaveBest's maps where the roughness has moved (within the models' 1e-3 of what the copying form stores in
+ * the improving iteration); `pred_next` is scratch.  The generic step leaves the best iteration's render in `pred_next` as before.
+ * The phase may go on afterwards (steps t_done + 1, ...).  With t_done = 0, or a generic copying phase: nothing to do. */
 int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* phase, int t_done, void* stream);
 /* The same iteration stage by stage (profiling, and callers that interleave their own work): matpbr_brdf_phase_step enqueues all of them. */
 #define MATPBR_STAGE_RENDER 1u   /* the render of the iteration (nothing to launch in the pred_next mode after t = 1) */
