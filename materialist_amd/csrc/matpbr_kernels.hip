@@ -1764,8 +1764,10 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             } else if (fold == kFoldXY) hipLaunchKernelGGL(lazy_pstep_kernel<kFoldXY>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
             else hipLaunchKernelGGL(lazy_pstep_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, ls, q.light, g, tab);
             if ((stages & MATPBR_STAGE_RESAMPLE) && pwalk) {     // one wave per chunk of eight listed pixels; 256 waves per image take a queue of any length
-                // waves per image: a multiple of the shards, 2048 in all at most (a long queue -- the first iterations of a part -- is walked in passes)
-                int walk_cap = 2048;
+                // waves per image: a multiple of the shards, 4096 in all at most (a long queue -- the first iterations of a part -- is walked in passes).
+                // (2048 through round 5: sixteen chunks per shard instead of eight at 8 x 512^2 -- in steady state ONE shard of 256 with more than 64
+                // entries sent one wave through a second pass, and the launch took 25-29 us instead of 20 in three iterations of four)
+                int walk_cap = 4096;
                 int nw = walk_cap / q.batch / kWalkShards * kWalkShards;
                 const int most = (int)((walk_shard_cap(n1) + 7) / 8) * kWalkShards;
                 nw = nw < kWalkShards ? kWalkShards : (nw > 1024 ? 1024 : nw);

@@ -664,8 +664,11 @@ __global__ __launch_bounds__(64, 2) void lazy_pwalk_kernel(const LazyStepArgs qs
     __shared__ float2 s_saz[kMaxRings * kMaxAz];
     const JacBwdArgs& q = qs.j;
     // workgroup -> (image, wave of the image), the image running fastest: the waves that have entries (the first ones of every image) are
-    // then the first the dispatcher starts (image by image, the last image's would wait for 1800 empty workgroups: 5 us)
-    const int B = qs.batch, b = (int)blockIdx.x % B, wv = (int)blockIdx.x / B, nwv = (int)gridDim.x / B;
+    // then the first the dispatcher starts (image by image, the last image's would wait for 1800 empty workgroups: 5 us).  The images rotate
+    // against the workgroup index from one group of B workgroups to the next: consecutive workgroups go to the XCDs in turn, and with
+    // b = blockIdx.x % 8 image b's walkers would all sit on XCD b (measured: 66 to 177 walkers per XCD at 8 x 512^2 for images that walk
+    // unequal numbers of pixels; rotated: 111 to 144)
+    const int B = qs.batch, wv = (int)blockIdx.x / B, b = ((int)blockIdx.x + wv) % B, nwv = (int)gridDim.x / B;
     const int P = g.H * g.W;
     const int nblk = lazy_fwd_blocks(P);
     const int lane = threadIdx.x;

@@ -545,6 +545,22 @@ class _BatchOfOne:
         return {k: v.unsqueeze(0) for k, v in self._ph.current_maps().items()}
 
 
+_GROUP_STREAMS: Dict[tuple, list] = {}
+
+
+def _group_streams(dev: torch.device, groups: int) -> list:
+    """The streams the groups of a PipelinedBrdfPhase step on: ONE set per device and group count for the whole process.  A set per phase
+    object (through round 5) meant new HIP streams for every part of every loop of a run, and HIP multiplexes a process's streams onto a
+    few hardware queues: once two groups' streams share a queue their launches are serialised again -- the overlap the groups exist for
+    is gone without a trace in the results (bench.py --mode fused --images-per-gpu 8, whose timed phase was the third one built in its
+    process: 70 k image-iterations/s against the 96-112 k of the same phase built first).  Phases that share the streams are ordered
+    against each other by them, which is what consecutive parts of a run want anyway."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(groups))
+    if key not in _GROUP_STREAMS:
+        _GROUP_STREAMS[key] = [torch.cuda.Stream(dev) for _ in range(groups)]
+    return _GROUP_STREAMS[key]
+
+
 class PipelinedBrdfPhase:
     """A batch of images as GROUPS of images, each a `FusedBrdfPhase` stepping on a stream of its own.  An image's iteration does not depend on the
     images beside it (a batch is its images alone, bit for bit: tests/test_gpu_lazy.py), so the groups are independent -- and the walk and
@@ -560,7 +576,7 @@ class PipelinedBrdfPhase:
         B, dev = gt_image.shape[0], gt_image.device
         per = B // groups
         self.B, self.groups = B, groups
-        self.streams = [torch.cuda.Stream(dev) for _ in range(groups)]
+        self.streams = _group_streams(dev, groups)
         self.phases = []
         here = torch.cuda.current_stream(dev)
         if make_phase is None:

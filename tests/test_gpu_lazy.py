@@ -658,4 +658,10 @@ def test_a_batch_cut_into_groups_on_streams_of_their_own_is_the_batch(part):
     a, b = one.poll(), two.poll()
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert two.t == one.t == 48 and two.lr_at(5) == one.lr_at(5)
+    # the groups' streams are the process's, not the phase's: a run builds a phase per part, and HIP has only a few hardware queues to spread a
+    # process's streams over (a second phase on streams of its own lost the overlap of its groups: bench.py --mode fused, 70 k instead of 110 k)
+    again = loop.PipelinedBrdfPhase(make_scene(), gt, *init, groups=2, **kw)
+    assert all(x is y for x, y in zip(again.streams, two.streams)) and len(again.streams) == 2
+    again.run(48)
+    assert torch.equal(again.stats, two.stats) and all(torch.equal(again.p[k], two.p[k]) for k in ("albedo", "roughness", "metallic"))
 
