@@ -32,8 +32,9 @@
 extern "C" {
 #endif
 
-#define MATPBR_VERSION 310 /* round 6: the coordinate MLP's entry points moved to matpbr_mlp.h, five unused ones removed; lazy state 120 B/pixel, folded
-                              models 68 B/pixel in a new layout (opaque storage: size it with the *_bytes queries) */
+#define MATPBR_VERSION 311 /* round 6: the coordinate MLP's entry points moved to matpbr_mlp.h, five unused ones removed; lazy state 120 B/pixel, folded
+                              models 68 B/pixel in a new layout (opaque storage: size it with the *_bytes queries); 311: a folded phase stores no
+                              render (`pred` is written by matpbr_brdf_phase_resolve) */
 #define MATPBR_MAX_SPP 128
 #define MATPBR_NSH 25
 

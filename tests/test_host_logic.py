@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.matpbr_version() == 310
+    assert lib.matpbr_version() == 311
     assert b"spp" in lib.matpbr_strerror(-2)
     assert lib.matpbr_shade_bwd_workspace_bytes(512, 512, 1, 25) == 512 * 75 * 4
     assert lib.matpbr_brdf_loss_workspace_bytes(2) > 0
