@@ -263,6 +263,52 @@ def test_lazy_render_stays_within_1e3_of_exact_sampling_on_every_pixel_of_every_
     assert nref[0] == 1.0 and nref[1:].mean() < 0.1
 
 
+@pytest.mark.parametrize("part", ["rm", "r", "m", "a"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_statistics_formed_inside_the_folded_step_are_the_statistics_launch(part, masked):
+    """Round 6: from its second iteration on a folded part has no statistics launch -- the step that forms the render of iteration t + 1 leaves, per
+    block, the sums from which the head of step t + 1 has the exposure ratio, the MSE (exactly: A + 2 e Bq + e^2 Cq around the ratio of iteration t)
+    and the L1 (up to pixels whose sign flips inside e); the walked pixels' shares arrive as integer atomics.  Against the generic step on the same
+    part, whose statistics launch reads the stored render: ratio, MSE, L1, the gradient scale and the regulariser terms of every iteration (an image
+    of a size that is no multiple of anything, with and without pixels without geometry).  The parameters of the two forms drift apart at the
+    models' storage precision (4e-5 after the first step, test_folded_persistent_step_is_the_generic_step): the statistics follow them, no more."""
+    from materialist_amd import loop, ops, render, synthetic
+
+    dev = _cuda()
+    H, W, spp = 96, 131, 64
+    sc = synthetic.make_scene(3, H, W)
+    mask = None
+    if masked:
+        mask = torch.zeros(H, W, dtype=torch.bool)
+        mask[:17] = True
+
+    def scene_():
+        s_ = render.load_estimated_mesh(_t(sc.depth, dev), use_mesh_normal=True, mesh_mask=mask)
+        s_._set("emitter.data", _t(sc.light, dev))
+        return s_
+
+    with torch.no_grad():
+        gt = render.render_w_brdf(scene_(), _t(sc.albedo, dev), _t(sc.roughness, dev), _t(sc.metallic, dev), None, spp)
+    init = [_t(x, dev) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
+    fo = loop.FusedBrdfPhase(scene_(), gt, *init, optimize_part=part, spp=spp, fold=True)
+    ge = loop.FusedBrdfPhase(scene_(), gt, *init, optimize_part=part, spp=spp, fold=False)
+    assert fo.fold and not ge.fold
+    worst = 0.0
+    for it in range(30):
+        fo.step()
+        ge.step()
+        a, b = fo.stats[0].double().cpu(), ge.stats[0].double().cpu()
+        for k in (ops.STAT_RATIO, ops.STAT_MSE, ops.STAT_L1, ops.STAT_SR, ops.STAT_LOSS):
+            worst = max(worst, abs(float(a[k] / b[k]) - 1.0))
+        for k in (ops.STAT_LA, ops.STAT_LR, ops.STAT_LM):
+            assert float(abs(a[k] - b[k])) <= 2e-6 * max(1.0, float(abs(b[k]))), (it, k, float(a[k]), float(b[k]))
+    from test_gpu_parity import _report
+
+    _report("in-step statistics vs statistics launch, 30 iterations: worst relative difference", worst, 3e-6)
+    assert worst <= 3e-6, worst
+    assert torch.equal(fo.history()[:30] > 0, ge.history()[:30] > 0)
+
+
 @pytest.mark.parametrize("part", ["rm", "a", "arm"])
 def test_savebest_without_copies_leaves_what_the_copying_step_leaves(part):
     """MATPBR_FLAG_ROTATE_BEST (the default of the lazy loop): parameters, SaveBest's maps and image, statistics and history against the
