@@ -90,7 +90,7 @@ def parse(argv=None):
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel; the reference renders with spp=64 (inverse_img_w_mi.py:625)")
     ap.add_argument("--images-per-gpu", type=int, default=1)
-    ap.add_argument("--mode", choices=["fused", "fused_one_phase", "torch", "pos_mlp"], default=None,
+    ap.add_argument("--mode", choices=["fused", "fused_one_phase", "fused_arm", "fused_a", "torch", "pos_mlp"], default=None,
                     help="default: pos_mlp (the reference's default mode: maps from the residual PosMLP) for one image per GPU, fused "
                          "(--model_name none, whole iteration in libmatpbr.so) for a batch; torch: the none-mode step composed from torch ops")
     ap.add_argument("--mlp-products", type=int, choices=[0, 6, 9], default=None,

@@ -257,12 +257,14 @@ typedef struct MatpbrBrdfPhase {
                                              slopes are that derivative -- i.e. the live reference's gradient convention (myutils/mi_plugin.py:227-230,
                                              1335-1341) instead of the stop-gradient default */
     void* lazy_fold;                      /* nullable, matpbr_lazy_fold_bytes(), pred_next mode only: room for the part's folded models.  With it a part
-                                             of r / m (d_a not requested) or part 'a' (d_r, d_m not requested) runs its iteration as TWO launches: the
-                                             statistics pass and one persistent streaming launch (at most 1024 workgroups, each streaming up to four
-                                             512-pixel blocks from two register sets and walking the samples of the pixels it listed at its end: no
-                                             MATPBR_STAGE_RESAMPLE launch); 144 ('rm') / 132 ('a') instead of 172 / 160 B/pixel.  The step with t == 1
-                                             derives the folded planes from the generic ones; the generic ones stay current (re-sampled pixels rewrite
-                                             both).  Other parts, and MATPBR_FLAG_GENERIC_STEP, run the generic step. */
+                                             of r / m (d_a not requested) or part 'a' (d_r, d_m not requested) runs its iteration as ONE persistent
+                                             streaming launch (at most 1024 workgroups, each streaming up to four 512-pixel blocks from two register
+                                             sets) that also forms the NEXT iteration's loss statistics (round 6: no statistics launch after t = 1)
+                                             and stores no render (`pred` is written by matpbr_brdf_phase_resolve; `pred_next` is scratch); in a part
+                                             that moves the roughness the listed pixels are re-sampled by the MATPBR_STAGE_RESAMPLE launch behind it.
+                                             136 ('rm') / 120 ('a') instead of 172 / 160 B/pixel.  The step with t == 1 derives the folded planes from
+                                             the generic ones; the generic ones stay current (re-sampled pixels rewrite both).  Other parts, and
+                                             MATPBR_FLAG_GENERIC_STEP, run the generic step. */
 } MatpbrBrdfPhase;
 /* A part of --opt_order that moves the normal map ('n', 'armn' under --model_name none with use_mesh_normal False; inverse_img_w_mi.py:356-432),
  * launch by launch without a framework in the iteration and with SaveBest / EarlyStopping on the device:

@@ -5,14 +5,17 @@
 // Adam moments: 172.6 B/pixel in an 'rm' part against the 108 B/pixel of the canonical forward + backward pair.  Two things are wrong with that:
 //   * bytes: a part moves SOME of the maps (--opt_order 'rm a', :343-357); what it leaves alone is a constant that folds into the model
 //     (kFoldXY: the albedo, 64 B/pixel of model and no albedo read; kFoldGH: roughness and metallic, 24 B/pixel of model and neither map read).
-//     'rm': r 4 + m 4 read, 8 written, model 68 (X0 / Y0 in 24 bits each, half-precision slopes of the detached derivatives: round 6), target 12, render 12, anchors 8, Adam moments 32 = 148 B/pixel (was 172);
-//     'a' : a 12 read, 12 written, model 24, target 12, render 12, anchors 12, Adam moments 48 = 132 B/pixel (was 160);
-//   * shape: 4096 workgroups of 512 pixels each fold the iteration's statistics before their first load, and the few pixels that leave their
-//     model's interval are a launch of their own (a 20 us latency chain at 8 x 512^2).  Here a workgroup takes up to four consecutive 512-pixel
-//     blocks (at most 1024 workgroups: all resident at four per CU), requests its first two tiles BEFORE it folds the statistics, streams tile
-//     after tile from two statically named register sets (the loads of the tile after next are in flight while a tile is computed), and walks
-//     the samples of the pixels it listed at its end, from LDS lists (eight lanes per pixel: resample_walk_pixel) -- no counts, no prefix over
-//     an image's lists, no second launch, and the render it leaves behind is complete.
+//     'rm': r 4 + m 4 read, 8 written, model 68 (X0 / Y0 in 24 bits each, half-precision slopes of the detached derivatives: round 6), target 12, anchors 8,
+//           Adam moments 32 = 136 B/pixel (was 172; 148 while the next render was stored);
+//     'a' : a 12 read, 12 written, model 24, target 12, anchors 12, Adam moments 48 = 120 B/pixel (was 160);
+//   * shape: 4096 workgroups of 512 pixels each fold the iteration's statistics before their first load.  Here a workgroup takes up to four
+//     512-pixel blocks (at most 1024 workgroups: all resident at four per CU), requests its first two tiles BEFORE it folds the statistics, and
+//     streams tile after tile from two statically named register sets (the loads of the tile after next are in flight while a tile is computed).
+//     The few pixels that leave their model's interval go to the image's walk queue (one atomic per wave with entries) and are re-sampled by
+//     lazy_pwalk_kernel, a launch of one wave per eight entries behind this one.
+//   * launches: the loss statistics of iteration t + 1 need nothing but the render of iteration t + 1, which is formed HERE: the kernel leaves per block
+//     the sums from which the next launch's heads have them (loss_acc, matpbr_lazy.hpp; two sets of records by iteration parity) -- no statistics
+//     launch after the first iteration of a part, and no stored render (matpbr_brdf_phase_resolve / fold_resolve_kernel form what the caller reads).
 // Thread t of a workgroup owns the pixels t and t + 256 of each of its blocks, as in lazy_step_kernel: per-block sums (render, regularisers)
 // are formed in the same order whatever the batch size and the number of blocks per workgroup (batch = stand-alone, bit for bit).
 // The arithmetic of a pixel is that of lazy_step_pixel with the folded expressions (matpbr_lazy.hpp, "folded models"); parts that move the
