@@ -1574,6 +1574,7 @@ int matpbr_brdf_normal_step(const MatpbrNormalStep* ns, int t, float lr, void* s
 static int phase_fold_mode(const MatpbrBrdfPhase& q) {
     if (q.lazy_state == nullptr || q.dcache == nullptr || q.pred_next == nullptr || lazy_fwd_blocks((long)q.H * q.W) > kLazyMaxBlocks) return kFoldNone;
     if (q.lazy_fold == nullptr || (q.flags & MATPBR_FLAG_GENERIC_STEP)) return kFoldNone;
+    if (lazy_fold_planes_bytes((long)q.H * q.W, q.batch) >= (1ull << 32)) return kFoldNone;      // (the lanes carry 32-bit byte offsets into the folded planes)
     if (!(q.part_mask & MATPBR_PART_A) && (q.part_mask & (MATPBR_PART_R | MATPBR_PART_M)) && q.d_a == nullptr) return kFoldXY;
     if (q.part_mask == MATPBR_PART_A && q.d_r == nullptr && q.d_m == nullptr) return kFoldGH;
     return kFoldNone;
@@ -1666,7 +1667,7 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
             fa.a = q.pa; fa.r = q.pr; fa.m = q.pm; fa.out = q.pred; fa.block_sums = fwd_sums; fa.stats = q.stats;
             fa.walk_cnt = (uint32_t*)((char*)q.lazy_fold + lazy_fold_planes_bytes(n1, q.batch) + (size_t)q.batch * lb.nblk * sizeof(long long));
             for (int k = 0; k < kLzPlanes; ++k) fa.plane[k] = lb.planes + (size_t)k * (size_t)q.batch * (size_t)n1;
-            for (int k = 0; k < kFxPlanes; ++k) fa.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
+            for (int k = 0; k < kFxPlanes; ++k) fa.fplane[k] = (uint32_t*)q.lazy_fold + fx_row_words(k);
             if (fold == kFoldXY) hipLaunchKernelGGL(lazy_fold_kernel<kFoldXY>, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, fa, (int)n1);
             else hipLaunchKernelGGL(lazy_fold_kernel<kFoldGH>, dim3((unsigned)lb.nblk, (unsigned)q.batch), dim3(kBlock), 0, st, fa, (int)n1);
         }
@@ -1745,7 +1746,7 @@ static int phase_stages_impl(const MatpbrBrdfPhase* ph, int t, float lr, uint32_
         ls.stats_out = q.stats; ls.history = q.history; ls.hist_len = q.hist_len; ls.batch = q.batch;
         ls.es_patience = q.es_patience; ls.es_min_delta = q.es_min_delta;
         if (fold != kFoldNone) {
-            for (int k = 0; k < kFxPlanes; ++k) ls.fplane[k] = (uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
+            for (int k = 0; k < kFxPlanes; ++k) ls.fplane[k] = (uint32_t*)q.lazy_fold + fx_row_words(k);
             ls.rec_in = block_rec + (size_t)((t - 1) & 1) * rec_set; ls.rec_out = block_rec + (size_t)(t & 1) * rec_set; ls.walk_acc = fold == kFoldXY ? walk_acc : nullptr; ls.acc_mode = acc_mode ? 1 : 0; ls.no_pred = 1;
             ls.walk_fix = (long long*)((char*)q.lazy_fold + lazy_fold_planes_bytes(n1, q.batch));
             ls.walk_cnt = (uint32_t*)(ls.walk_fix + (size_t)q.batch * lb.nblk);
@@ -1830,7 +1831,7 @@ int matpbr_brdf_phase_resolve(const MatpbrBrdfPhase* ph, int t_done, void* strea
         FoldResolveArgs fa{};
         fa.a = q.pa; fa.r = q.pr; fa.m = q.pm;
         fa.best_a = want_best ? q.best_a : nullptr; fa.best_m = want_best && (q.part_mask & MATPBR_PART_M) ? q.best_m : nullptr;
-        for (int k = 0; k < kFxPlanes; ++k) fa.fplane[k] = (const uint32_t*)q.lazy_fold + (size_t)k * (size_t)q.batch * (size_t)n1;
+        for (int k = 0; k < kFxPlanes; ++k) fa.fplane[k] = (const uint32_t*)q.lazy_fold + fx_row_words(k);
         fa.out = q.pred; fa.best_lin = q.pred_next; fa.best_img = want_best ? q.best_img : nullptr; fa.state = state; fa.slopes = slopes ? 1 : 0;
         if (fold == kFoldXY) hipLaunchKernelGGL(fold_resolve_kernel<kFoldXY>, pgrid, dim3(kBlock), 0, st, fa, (int)n1);
         else hipLaunchKernelGGL(fold_resolve_kernel<kFoldGH>, pgrid, dim3(kBlock), 0, st, fa, (int)n1);

@@ -139,7 +139,13 @@ __host__ __device__ inline int lazy_tiles(long P) { return (int)((P + kTile - 1)
 // pixels with ONE atomic on the counter of its shard, when it has streamed its last tile -- and clears the other parity's counters).
 constexpr double kWalkFix = 4294967296.0;
 constexpr int kWalkShards = 32;
-inline size_t lazy_fold_planes_bytes(long P, int batch) { return (size_t)kFxPlanes * (size_t)batch * (size_t)P * 4; }
+// The folded planes are stored TILE-major: the kFxPlanes words of 256 consecutive pixels (one tile of the persistent step) as kFxPlanes consecutive
+// 1-KB rows -- a tile's model is one contiguous 17-KB read instead of seventeen 1-KB reads 8 MB apart (plane-major, through the first half of round 6).
+// A plane's pointer is the address of its row in tile 0; fx_off(i) is the byte offset of pixel i (= b P + p) from there.
+constexpr unsigned kFxTileBytes = (unsigned)kFxPlanes * 1024u;
+inline size_t lazy_fold_planes_bytes(long P, int batch) { return (((size_t)batch * (size_t)P + 255) / 256) * (size_t)kFxTileBytes; }
+__device__ __forceinline__ unsigned fx_off(unsigned i) { return (i >> 8) * kFxTileBytes + ((i & 255u) << 2); }
+inline size_t fx_row_words(int k) { return (size_t)k * 256; }      // a plane's pointer: row k of tile 0 (in 32-bit words from the buffer's start)
 // entries of one shard: the pixels of every wave that may append to it (wave v of the 4 gridDim.x of an image: shard v % kWalkShards; a wave
 // owns 128 pixels of each of its workgroup's <= 4 blocks: <= 16 nblk + 576 pixels per shard whatever the launch geometry)
 __host__ __device__ inline long walk_shard_cap(long P) { return (P + 2 * kBlock - 1) / (2 * kBlock) * (2 * kBlock / kWalkShards) + 1024; }
@@ -681,7 +687,7 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
     const JacBwdArgs& q = qs.j;
     (void)q;
     const int half = sub >> 2, azi = sub & 3;
-    const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
+    const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u, of = fx_off(i);
     float rc[7];
 #pragma unroll
     for (int c = 0; c < 3; ++c) rc[1 + c] = fminf(fmaxf(ldf(sp.a, o3 + 4 * c), 0.0f), 1.0f);
@@ -853,8 +859,8 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
                 FoldXY f;
                 fold_xy(rc[1 + c], Pc[c], vSD[c], vS1[c], dP[c], A2[c], gSD[c], gS1[c], dSD[c], dS1v[c], eSD[c], eS1[c], mref_code(mv), f);
                 x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1; fx0[c] = f.X0; fy0[c] = f.Y0;
-                *(uint32_t*)((char*)qs.fplane[kFxS + c] + o1) = pack_h2(f.X1, f.Y1);
-                *(uint32_t*)((char*)qs.fplane[kFxJ + c] + o1) = pack_h2(f.JX0, f.JY0);
+                *(uint32_t*)((char*)qs.fplane[kFxS + c] + of) = pack_h2(f.X1, f.Y1);
+                *(uint32_t*)((char*)qs.fplane[kFxJ + c] + of) = pack_h2(f.JX0, f.JY0);
                 rgb = fmaf(mv, f.Y0, f.X0);
             }
             if (!(FOLD && qs.no_pred)) stf(sp.pred_next, o3 + 4 * c, rgb);
@@ -865,14 +871,14 @@ __device__ __forceinline__ void resample_walk_pixel(const LazyStepArgs& qs, cons
             uint32_t xw[5];
             xy_pack(fx0, fy0, mref_code(mv), xw);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) *(uint32_t*)((char*)qs.fplane[kFxXY + k] + o1) = xw[k];
-            *(uint32_t*)((char*)qs.fplane[kFxRref] + o1) = as_u(rc_r);
+            for (int k = 0; k < 5; ++k) *(uint32_t*)((char*)qs.fplane[kFxXY + k] + of) = xw[k];
+            *(uint32_t*)((char*)qs.fplane[kFxRref] + of) = as_u(rc_r);
             // the interval as the generic plane holds it (its half-precision words): both forms list a pixel in the same iteration, up to iv_pack's rounding
             const uint32_t lh = pack_h2(iv_round(fminf(fv[18], rho)), iv_round(fminf(fv[19], rho)));
-            *(uint32_t*)((char*)qs.fplane[kFxLoHi] + o1) = pack_lohi_x2(h2_lo(lh), h2_hi(lh), x2h[0]);
-            *(uint32_t*)((char*)qs.fplane[kFxQ] + o1) = pack_h2(x2h[1], x2h[2]);
+            *(uint32_t*)((char*)qs.fplane[kFxLoHi] + of) = pack_lohi_x2(h2_lo(lh), h2_hi(lh), x2h[0]);
+            *(uint32_t*)((char*)qs.fplane[kFxQ] + of) = pack_h2(x2h[1], x2h[2]);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) *(uint32_t*)((char*)qs.fplane[kFxE + c] + o1) = pack_h2(jx1[c], jy1[c]);
+            for (int c = 0; c < 3; ++c) *(uint32_t*)((char*)qs.fplane[kFxE + c] + of) = pack_h2(jx1[c], jy1[c]);
         }
     }
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
     for (int h = 0; h < 2; ++h) {
         const int p = blockIdx.x * kLazyBlockPixels + h * kBlock + (int)threadIdx.x;
         if (p >= P) continue;
-        const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
+        const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u, of = fx_off(i);
         const F3 av = ld3(q.a, o3);
         const float a[3] = {fminf(fmaxf(av.x, 0.0f), 1.0f), fminf(fmaxf(av.y, 0.0f), 1.0f), fminf(fmaxf(av.z, 0.0f), 1.0f)};
         const float r = fminf(fmaxf(ldf(q.r, o1), 0.07f), 1.0f), m = fminf(fmaxf(ldf(q.m, o1), 0.0f), 1.0f), omm = 1.0f - m;
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
                 fold_xy(a[c], Pv, SDv, S1v, h2_lo(pk), h2_hi(pk), h2_lo(sk), h2_hi(sk), h2_lo(dk), h2_hi(dk), h2_lo(ek), h2_hi(ek), mref_code(m), f);
                 const uint32_t s = pack_h2(f.X1, f.Y1);
                 x2h[c] = f.X2; jx1[c] = f.JX1; jy1[c] = f.JY1; fx0[c] = f.X0; fy0[c] = f.Y0;
-                stu(q.fplane[kFxS + c], o1, s);
-                stu(q.fplane[kFxJ + c], o1, pack_h2(f.JX0, f.JY0));
+                stu(q.fplane[kFxS + c], of, s);
+                stu(q.fplane[kFxJ + c], of, pack_h2(f.JX0, f.JY0));
                 float X, Y;
                 xy_eval(f.X0, f.Y0, s, (float)(_Float16)f.X2, dr, X, Y);      // the stored (half) words, as the step kernel reads them
                 rgb[c] = fmaf(m, Y, X);
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
                 const float Pc = fmaf(fmaf(h2_hi(pk), dr, h2_lo(pk)), dr, Pv);
                 const float SD = fmaf(h2_lo(sk), dr, SDv), S1 = fmaf(h2_hi(sk), dr, S1v);
                 const float G = fmaf(m, SD, omm * Pc), Hc = fmaf(omm * 0.04f, SD, S1);
-                stu(q.fplane[kFgG + c], o1, as_u(G));
-                stu(q.fplane[kFgH + c], o1, as_u(Hc));
+                stu(q.fplane[kFgG + c], of, as_u(G));
+                stu(q.fplane[kFgH + c], of, as_u(Hc));
                 rgb[c] = fmaf(a[c], G, Hc);
             }
             tot += rgb[c];
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(kBlock) void lazy_fold_kernel(const LazyFoldArgs q,
             uint32_t xw[5];
             xy_pack(fx0, fy0, mref_code(m), xw);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) stu(q.fplane[kFxXY + k], o1, xw[k]);
-            stu(q.fplane[kFxRref], o1, as_u(rref));
+            for (int k = 0; k < 5; ++k) stu(q.fplane[kFxXY + k], of, xw[k]);
+            stu(q.fplane[kFxRref], of, as_u(rref));
             const uint32_t lh = ldu(q.plane[kLzLoHi], o1);
-            stu(q.fplane[kFxLoHi], o1, pack_lohi_x2(h2_lo(lh), h2_hi(lh), x2h[0]));
-            stu(q.fplane[kFxQ], o1, pack_h2(x2h[1], x2h[2]));
+            stu(q.fplane[kFxLoHi], of, pack_lohi_x2(h2_lo(lh), h2_hi(lh), x2h[0]));
+            stu(q.fplane[kFxQ], of, pack_h2(x2h[1], x2h[2]));
 #pragma unroll
-            for (int c = 0; c < 3; ++c) stu(q.fplane[kFxE + c], o1, pack_h2(jx1[c], jy1[c]));
+            for (int c = 0; c < 3; ++c) stu(q.fplane[kFxE + c], of, pack_h2(jx1[c], jy1[c]));
         }
         st3(q.out, o3, rgb[0], rgb[1], rgb[2]);
     }
@@ -134,24 +134,24 @@ __device__ __forceinline__ void pstep_load_params(PxXY& x, const StepPtrs& sp, u
 }
 __device__ __forceinline__ void pstep_load_fixed(PxXY& x, const LazyStepArgs& qs, unsigned i, const PStepFlags f) {
     const JacBwdArgs& q = qs.j;
-    const unsigned o1 = i * 4u, o3 = i * 12u;
+    const unsigned o1 = i * 4u, o3 = i * 12u, of = fx_off(i);
     x.gt = ld3(q.gt_srgb, o3);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) x.xy[k] = ldu(qs.fplane[kFxXY + k], o1);
+    for (int k = 0; k < 5; ++k) x.xy[k] = ldu(qs.fplane[kFxXY + k], of);
     x.rref = 0.0f; x.lohi = 0u; x.q = 0u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) x.s[c] = x.j[c] = x.e[c] = 0u;
     if (f.slopes) {           // a part that leaves the roughness alone never moves away from r_ref (uniform branch)
-        x.rref = as_f(ldu(qs.fplane[kFxRref], o1)); x.lohi = ldu(qs.fplane[kFxLoHi], o1);
-        x.q = ldu(qs.fplane[kFxQ], o1);
+        x.rref = as_f(ldu(qs.fplane[kFxRref], of)); x.lohi = ldu(qs.fplane[kFxLoHi], of);
+        x.q = ldu(qs.fplane[kFxQ], of);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x.s[c] = ldu(qs.fplane[kFxS + c], o1);
+        for (int c = 0; c < 3; ++c) x.s[c] = ldu(qs.fplane[kFxS + c], of);
         if (f.att) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) x.j[c] = x.s[c];       // the models' own slopes are the derivative: no first-order correction on top (e = 0)
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { x.j[c] = ldu(qs.fplane[kFxJ + c], o1); x.e[c] = ldu(qs.fplane[kFxE + c], o1); }
+            for (int c = 0; c < 3; ++c) { x.j[c] = ldu(qs.fplane[kFxJ + c], of); x.e[c] = ldu(qs.fplane[kFxE + c], of); }
         }
     }
     x.r0 = x.m0 = x.mr = x.vr = x.mm = x.vm = 0.0f;
@@ -165,11 +165,11 @@ __device__ __forceinline__ void pstep_load(PxXY& x, const LazyStepArgs& qs, cons
 __device__ __forceinline__ void pstep_load_params(PxGH& x, const StepPtrs& sp, unsigned i) { x.a = ld3(sp.a, i * 12u); }
 __device__ __forceinline__ void pstep_load_fixed(PxGH& x, const LazyStepArgs& qs, unsigned i, const PStepFlags) {
     const JacBwdArgs& q = qs.j;
-    const unsigned o1 = i * 4u, o3 = i * 12u;
+    const unsigned o3 = i * 12u, of = fx_off(i);
     x.gt = ld3(q.gt_srgb, o3);
     x.a0 = ld3(q.a0, o3);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { x.G[c] = as_f(ldu(qs.fplane[kFgG + c], o1)); x.H[c] = as_f(ldu(qs.fplane[kFgH + c], o1)); }
+    for (int c = 0; c < 3; ++c) { x.G[c] = as_f(ldu(qs.fplane[kFgG + c], of)); x.H[c] = as_f(ldu(qs.fplane[kFgH + c], of)); }
     x.ma = F3{0.0f, 0.0f, 0.0f}; x.va = F3{0.0f, 0.0f, 0.0f};
     if (q.am[0]) { x.ma = ld3(q.am[0], o3); x.va = ld3(q.av[0], o3); }
 }
@@ -598,24 +598,24 @@ __global__ __launch_bounds__(kBlock) void fold_resolve_kernel(const FoldResolveA
     const int b = blockIdx.y;
     const int p = (int)blockIdx.x * kBlock + (int)threadIdx.x;
     if (p >= P) return;
-    const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u;
+    const unsigned i = (unsigned)(b * P + p), o1 = i * 4u, o3 = i * 12u, of = fx_off(i);
     const float bratio = q.best_img ? q.state[b * kStateStride + kStBestRatio] : -1.0f;
     float rgb[3], best[3] = {0.0f, 0.0f, 0.0f};
     if (MODE == kFoldXY) {
         const float r = fminf(fmaxf(ldf(q.r, o1), 0.07f), 1.0f), m = fminf(fmaxf(ldf(q.m, o1), 0.0f), 1.0f);
         uint32_t xy[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) xy[k] = ldu(q.fplane[kFxXY + k], o1);
+        for (int k = 0; k < 5; ++k) xy[k] = ldu(q.fplane[kFxXY + k], of);
         float X0[3], Y0[3];
         xy_unpack(xy, X0, Y0);
-        const uint32_t lohi_w = ldu(q.fplane[kFxLoHi], o1);
+        const uint32_t lohi_w = ldu(q.fplane[kFxLoHi], of);
         const bool constant = (lohi_w & 0xffffu) == 0xffffu;
         float rref = 0.0f;
         uint32_t lohi = 0u, qq = 0u, sw[3] = {0u, 0u, 0u};
         if (q.slopes) {                                         // (as pstep_load_fixed)
-            rref = as_f(ldu(q.fplane[kFxRref], o1)); lohi = lohi_w; qq = ldu(q.fplane[kFxQ], o1);
+            rref = as_f(ldu(q.fplane[kFxRref], of)); lohi = lohi_w; qq = ldu(q.fplane[kFxQ], of);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) sw[c] = ldu(q.fplane[kFxS + c], o1);
+            for (int c = 0; c < 3; ++c) sw[c] = ldu(q.fplane[kFxS + c], of);
         }
         const float dr = r - rref;
         const float mb = bratio >= 0.0f && q.best_m ? fminf(fmaxf(ldf(q.best_m, o1), 0.0f), 1.0f) : m;
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void fold_resolve_kernel(const FoldResolveA
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float G = as_f(ldu(q.fplane[kFgG + c], o1)), Hc = as_f(ldu(q.fplane[kFgH + c], o1));
+            const float G = as_f(ldu(q.fplane[kFgG + c], of)), Hc = as_f(ldu(q.fplane[kFgH + c], of));
             rgb[c] = fmaf(a[c], G, Hc);
             best[c] = fmaf(ab[c], G, Hc);
         }
