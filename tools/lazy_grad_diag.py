@@ -1,6 +1,7 @@
 """Where do the tail errors of the lazy step's d loss / d r come from?  Jacobian-only comparison (d loss / d pred formed on the lazy loop's own
 render on both sides, as tests/test_gpu_lazy.py) at a few iterations of an 'rm' part, folded against generic planes, with the worst pixels'
-model state printed (dr against the interval, the size of the first-order term, whether the e-cap bit).  usage: python tools/lazy_grad_diag.py"""
+model state printed (dr against the interval, the size of the first-order term, whether the e-cap bit).  usage: python tools/lazy_grad_diag.py [iterations...]
+env: DIAG_IMAGE (synthetic scene, default 0), DIAG_TOL (FusedBrdfPhase lazy_tol, default 1.0), DIAG_FOLD_ONLY (skip the generic step), DIAG_DUMP."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,7 +20,7 @@ with torch.no_grad():
 init = [t(x) for x in (sc.init_albedo, sc.init_roughness, sc.init_metallic)]
 checks = [int(x) for x in (sys.argv[1:] or [50, 200, 400, 800, 1200])]
 for fold in ((True,) if os.environ.get('DIAG_FOLD_ONLY') else (True, False)):
-    ph = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp, lazy=True, keep_grads=True, fold=fold)
+    ph = loop.FusedBrdfPhase(scene, gt, *init, optimize_part="rm", spp=spp, lazy=True, keep_grads=True, fold=fold, lazy_tol=float(os.environ.get("DIAG_TOL", "1.0")))
     exact, jac = torch.empty_like(gt), ops.plane9(gt)
     g_ref = {k: torch.empty_like(v) for k, v in ph.g.items()}
     for it in range(max(checks) + 1):
