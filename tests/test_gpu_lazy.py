@@ -343,6 +343,13 @@ def test_savebest_without_copies_leaves_what_the_copying_step_leaves(part):
         assert torch.equal(rot.pred, cpy.pred), upto              # one meaning in both forms: the render of the current parameters
         assert torch.equal(rot.stats, cpy.stats), upto
         assert torch.equal(rot.history(), cpy.history()), upto
+    if part == "rm":
+        # ... and IS the renderer's image of SaveBest's maps: best_img^2.2 / shade(best maps) is one number per image (the best iteration's exposure ratio)
+        lin = torch.empty_like(gt)
+        ops.shade_fwd(init[0].clamp(0, 1), rot.best["roughness"], rot.best["metallic"], rot.n, rot.light, spp, clamp_params=True, out=lin, dcache=rot.dcache)
+        q = (rot.best_img.double() ** 2.2) / lin.double().clamp_min(1e-12)
+        sel = lin > 1e-4
+        assert float(q[sel].std() / q[sel].mean()) <= 2e-6, float(q[sel].std() / q[sel].mean())
     # an image that cannot improve: the snapshots it came with survive the phase
     tiny = torch.tensor([0.0], device=dev)
     keep = loop.FusedBrdfPhase(scene, gt, *init, best_mse=tiny, optimize_part=part, spp=spp)
