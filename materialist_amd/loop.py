@@ -373,6 +373,8 @@ class FusedBrdfPhase:
             for buf in (self.ws, self.jac, self._pred, self._pred_bufs[1] if self.lazy else None):
                 if buf is not None:
                     buf.fill_(float(os.environ["MATPBR_POISON"]))
+            if self.lazy_fold is not None:
+                self.lazy_fold.fill_(255)          # (bytes: every word of the folded planes, the walk sums, counters and queue a NaN pattern / a huge count)
 
     def lr_at(self, t0: int) -> float:
         """Learning rate of the iteration with 0-based index t0: StepLR(100, 0.8) stepped only while lr > 1.5e-4 (:363-365,431-432)."""
