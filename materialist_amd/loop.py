@@ -378,17 +378,27 @@ class FusedBrdfPhase:
 
     def lr_at(self, t0: int) -> float:
         """Learning rate of the iteration with 0-based index t0: StepLR(100, 0.8) stepped only while lr > 1.5e-4 (:363-365,431-432)."""
+        w = t0 // 100                                            # (the same value for a hundred iterations: remembered, the loop below runs once per window)
+        cached = getattr(self, "_lr_window", (-1, 0.0))      # (other phase classes borrow this method)
+        if cached[0] == w:
+            return cached[1]
         lr, k = self.base_lr, 0
         while lr > 1.5e-4 and (k + 1) * 100 <= t0:
             lr *= 0.8
             k += 1
+        self._lr_window = (w, lr)
         return lr
 
     def step(self) -> None:
         ct = self._ct
-        with torch.cuda.device(self.gt.device), self.ops._timed("brdf_phase_step"):
-            code = self._lib.matpbr_brdf_phase_step(ct.byref(self._ph), self.t + 1, self.lr_at(self.t),
-                                                    ct.c_void_p(torch.cuda.current_stream(self.gt.device).cuda_stream))
+        dev = self.gt.device
+        if self.ops.KernelTimer.active is None and torch.cuda.current_device() == dev.index:
+            # the loop's own path: no context managers around the one call (a rank's iteration is enqueued by one Python thread: bench.py host_enqueue)
+            code = self._lib.matpbr_brdf_phase_step(ct.byref(self._ph), self.t + 1, self.lr_at(self.t), ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        else:
+            with torch.cuda.device(dev), self.ops._timed("brdf_phase_step"):
+                code = self._lib.matpbr_brdf_phase_step(ct.byref(self._ph), self.t + 1, self.lr_at(self.t),
+                                                        ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         self._libmod.check(code, "matpbr_brdf_phase_step")
         self._advance()
 
